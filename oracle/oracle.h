@@ -1,0 +1,132 @@
+/*
+ * oracle.h -- CPU restatement of sarlacc's alignment-and-consensus hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped
+ * product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library, and only as the checker / reported CPU baseline.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - the reference itself cannot be built in this image (it needs Rcpp, R,
+ *     Biostrings and SeqAn headers which are absent, and stand-in headers are
+ *     not allowed), so every function below is pinned against the literal
+ *     known answers in the reference's own testthat files and against
+ *     restatements of the R-side test oracles (tests/test_oracle_*.py);
+ *   - orc_msa_* has NO reference counterpart that can be pinned (the reference
+ *     delegates to SeqAn's T-Coffee and has no test of it): PARITY UNPINNED.
+ *
+ * String sets are passed as one concatenated byte buffer plus n+1 int64
+ * offsets.  All functions return 0 on success; on failure they return nonzero
+ * and orc_last_error() holds the message (same text as the reference throws).
+ */
+#ifndef SARLACC_ORACLE_H
+#define SARLACC_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* orc_last_error(void);
+
+/* ---- quality encoding (reference src/quality_encoding.cpp:5-47) ---- */
+/* names[i] is the single-character name of errors[i]. */
+int orc_check_encoding(const double* errors, const char* names, int n);
+
+/* ---- DP cost tables (reference src/reference_align.cpp:21-52) ---- */
+/* match/mismatch: [4][n] row-major. */
+int orc_cost_tables(const double* errors, int n, double* match, double* mismatch);
+
+/* ---- quality-weighted affine DP (reference src/reference_align.cpp:54-181) ---- */
+/* dirs: (L+1)*(R+1) int32, column-major [c*(L+1)+i]; may be NULL for score only. */
+int orc_align_one(const char* ref, int R, const char* seq, const char* qual, int L,
+                  const double* errors, const char* names, int nenc,
+                  double gapopen, double gapext, int local,
+                  double* score, int32_t* dirs);
+
+/* .Call adaptor_align (reference src/adaptor_align.cpp:11-77) */
+int orc_adaptor_align(const char* seq, const int64_t* seq_off,
+                      const char* qual, const int64_t* qual_off, int64_t n,
+                      const double* errors, const char* names, int nenc,
+                      double gapopen, double gapext,
+                      const char* adaptor, int adaptor_len,
+                      const int32_t* sec_starts, const int32_t* sec_ends, int nsec,
+                      double* scores, int32_t* starts, int32_t* ends,
+                      int32_t* sec_start_out, int32_t* sec_width_out);
+
+/* .Call adaptor_align_score_only (:79-110) and barcode_align (src/barcode_align.cpp:10-44) */
+int orc_align_scores(const char* seq, const int64_t* seq_off,
+                     const char* qual, const int64_t* qual_off, int64_t n,
+                     const double* errors, const char* names, int nenc,
+                     double gapopen, double gapext,
+                     const char* ref, int ref_len, int local, double* scores);
+
+/* .Call general_align (src/general_align.cpp:10-62).
+ * aln_ref/aln_query: caller-provided buffers, aln_off[n+1] receives offsets
+ * (strings are NOT NUL-terminated); pass aln_ref=NULL for edit_only. */
+int orc_general_align(const char* seq, const int64_t* seq_off,
+                      const char* qual, const int64_t* qual_off, int64_t n,
+                      const double* errors, const char* names, int nenc,
+                      double gapopen, double gapext,
+                      const char* ref, int ref_len,
+                      double* scores, int32_t* edits,
+                      char* aln_ref, char* aln_query, int64_t* aln_off, int64_t aln_cap);
+
+/* ---- masking (reference src/mask_bad_bases.cpp:10-52) ---- */
+int orc_mask_bad_bases(const char* seq, const int64_t* seq_off,
+                       const char* qual, const int64_t* qual_off, int64_t n,
+                       const double* errors, const char* names, int nenc,
+                       double threshold, char* out);
+
+/* ---- masked Levenshtein ---- */
+/* dense lower triangle, i-major (reference src/compute_lev_masked.cpp:13-64) */
+int orc_compute_lev_masked(const char* seq, const int64_t* off, int64_t n, double* out);
+/* trie neighbour search (reference src/sorted_trie.cpp; test hook :304-337).
+ * Output CSR: nbr_off[n+1], nbr[] (0-based), capacity nbr_cap; returns needed size in *nbr_need. */
+int orc_fast_levdist(const char* seq, const int64_t* off, int64_t n, int limit,
+                     int64_t* nbr_off, int32_t* nbr, int64_t nbr_cap, int64_t* nbr_need);
+
+/* ---- greedy clustering (reference src/cluster_umis.cpp:7-112) ---- */
+/* in: CSR links (0-based); out: CSR clusters (clu_off has at most n+1 entries). */
+int orc_cluster_umis(const int64_t* link_off, const int32_t* links, int64_t n,
+                     int64_t* nclusters, int64_t* clu_off, int32_t* clu);
+/* same result, O(E log) bucket implementation for large n (validated against the above) */
+int orc_cluster_umis_fast(const int64_t* link_off, const int32_t* links, int64_t n,
+                          int64_t* nclusters, int64_t* clu_off, int32_t* clu);
+
+/* ---- umi_group (reference src/umi_group.cpp:14-116) ---- */
+/* pregroups: CSR of 1-based read ids.  Output: flattened list of clusters of
+ * 1-based read ids (R side does unlist(out, recursive=FALSE), R/umiGroup.R:22),
+ * clu_off must hold total_reads+1 entries, clu total_reads entries. */
+int orc_umi_group(const char* umi1, const int64_t* off1,
+                  const char* umi2, const int64_t* off2, /* umi2 may be NULL */
+                  int64_t n, int thresh1, int thresh2,
+                  const int64_t* grp_off, const int32_t* grp, int64_t ngroups,
+                  int fast_cluster,
+                  int64_t* nclusters, int64_t* clu_off, int32_t* clu);
+
+/* ---- consensus (reference src/create_consensus.cpp) ---- */
+/* one alignment: rows concatenated; cons (cap >= width+1) NUL-terminated, lerr[width] */
+int orc_consensus_basic(const char* aln, const int64_t* off, int64_t nrows,
+                        double mincov, double pseudo,
+                        char* cons, double* lerr, int64_t* conlen);
+int orc_consensus_quality(const char* aln, const int64_t* off, int64_t nrows,
+                          const char* qual, const int64_t* qoff, int64_t nquals,
+                          double mincov,
+                          const double* errors, const char* names, int nenc,
+                          char* cons, double* lerr, int64_t* conlen);
+/* Phred+33 string from log-errors (reference src/create_consensus.cpp:18-32) */
+void orc_errors_to_string(const double* lerr, int64_t n, char* out);
+
+/* ---- MSA: own specification (DESIGN.md "MSA spec v1"), PARITY UNPINNED ---- */
+/* One group: reads (concatenated + offsets, nreads), integer scores.
+ * out: nreads rows of equal width *width, written row-major into out (cap bytes). */
+int orc_msa_group(const char* seq, const int64_t* off, int64_t nreads,
+                  int match, int mismatch, int gapopen, int gapext, int bandwidth,
+                  char* out, int64_t cap, int64_t* width);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
