@@ -1,0 +1,187 @@
+/*
+ * sarlacc_amd.h -- C ABI of the MI355X-native sarlacc hot path (libsarlacc_amd.so).
+ *
+ * Every entry point replaces one `.Call` routine of the reference
+ * (/root/reference/src/init.cpp:9-35, prototypes src/sarlacc.h:14-36); the
+ * citation next to each declaration names the routine it stands in for.  The
+ * reference's SEXP arguments become flat arrays:
+ *
+ *   XStringSet / character vector  ->  const char* chars (concatenated, no NULs)
+ *                                      + const int64_t* off (n+1 offsets)
+ *   named numeric `encoding`       ->  const double* enc_errors + const char* enc_names
+ *                                      (names[i] is the single-character name of errors[i])
+ *   list of integer vectors        ->  CSR: int64 off[n+1] + int32 values (1-based as in R)
+ *   numeric / integer scalars      ->  double / int
+ *
+ * Two levels are exported:
+ *   sarlacc_<name>(...)      host pointers in, host pointers out (what a cgo/.Call/ctypes
+ *                            shim binds; does the H2D/D2H copies itself);
+ *   sarlacc_dev_<name>(...)  device pointers in/out, asynchronous on a caller stream
+ *                            (inputs already resident in HBM; used by bench.py and by a
+ *                            pipeline that keeps reads on the GPU between stages).
+ *
+ * All functions return 0 on success.  On failure they return nonzero and
+ * sarlacc_last_error() returns the message; messages that the reference throws
+ * are reproduced verbatim (src/utils.cpp, src/reference_align.cpp, ...).
+ * There is NO CPU fallback: without a usable HIP device every compute entry
+ * point fails with an error.
+ */
+#ifndef SARLACC_AMD_H
+#define SARLACC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* library / device management (no reference counterpart)               */
+const char* sarlacc_last_error(void);
+int sarlacc_version(void);
+/* Number of visible HIP devices (0 when none / runtime unavailable). */
+int sarlacc_device_count(void);
+/* Select the device used by this thread's subsequent calls (default 0). */
+int sarlacc_set_device(int device);
+/* Release cached device workspaces. */
+void sarlacc_release_workspace(void);
+/* Duration in ms of the DP kernel launches recorded by the last
+ * sarlacc_dev_* align call (HIP events on the launch stream); <0 if none. */
+double sarlacc_last_kernel_ms(void);
+
+/* ------------------------------------------------------------------ */
+/* quality-weighted read-vs-reference DP                                 */
+
+/* replaces .Call adaptor_align  (src/adaptor_align.cpp:11-77)
+ * sec_starts 0-based, sec_ends 1-based (as passed by R/adaptorAlign.R:158).
+ * Outputs: scores[n], starts[n], ends[n] (1-based, 0/0 when empty),
+ *          sec_start_out / sec_width_out [nsec][n] row-major. */
+int sarlacc_adaptor_align(const char* seq, const int64_t* seq_off,
+                          const char* qual, const int64_t* qual_off, int64_t n,
+                          const double* enc_errors, const char* enc_names, int enc_n,
+                          double gapopen, double gapext,
+                          const char* adaptor, int adaptor_len,
+                          const int32_t* sec_starts, const int32_t* sec_ends, int nsec,
+                          double* scores, int32_t* starts, int32_t* ends,
+                          int32_t* sec_start_out, int32_t* sec_width_out);
+
+/* replaces .Call adaptor_align_score_only  (src/adaptor_align.cpp:79-110) */
+int sarlacc_adaptor_align_score_only(const char* seq, const int64_t* seq_off,
+                                     const char* qual, const int64_t* qual_off, int64_t n,
+                                     const double* enc_errors, const char* enc_names, int enc_n,
+                                     double gapopen, double gapext,
+                                     const char* adaptor, int adaptor_len, double* scores);
+
+/* replaces .Call barcode_align  (src/barcode_align.cpp:10-44), global mode */
+int sarlacc_barcode_align(const char* seq, const int64_t* seq_off,
+                          const char* qual, const int64_t* qual_off, int64_t n,
+                          const double* enc_errors, const char* enc_names, int enc_n,
+                          double gapopen, double gapext,
+                          const char* reference, int reference_len, double* scores);
+
+/* replaces .Call general_align  (src/general_align.cpp:10-62), global mode.
+ * aln_ref / aln_query receive the gapped strings back to back, aln_off[n+1] the
+ * offsets; pass edit_only != 0 (then aln_* may be NULL) for scores + edit distances.
+ * aln_cap is the capacity of each string buffer (sum(L)+n*R always suffices). */
+int sarlacc_general_align(const char* seq, const int64_t* seq_off,
+                          const char* qual, const int64_t* qual_off, int64_t n,
+                          const double* enc_errors, const char* enc_names, int enc_n,
+                          double gapopen, double gapext,
+                          const char* reference, int reference_len, int edit_only,
+                          double* scores, int32_t* edits,
+                          char* aln_ref, char* aln_query, int64_t* aln_off, int64_t aln_cap);
+
+/* replaces .Call mask_bad_bases  (src/mask_bad_bases.cpp:10-52); out has seq_off[n] bytes */
+int sarlacc_mask_bad_bases(const char* seq, const int64_t* seq_off,
+                           const char* qual, const int64_t* qual_off, int64_t n,
+                           const double* enc_errors, const char* enc_names, int enc_n,
+                           double threshold, char* out);
+
+/* Device-resident form of the three score/trace entry points above.
+ * d_seq/d_qual/d_off are device pointers (one shared offset array: lengths were
+ * validated when the batch was uploaded); stream is a hipStream_t (NULL = default).
+ *   mode: 0 = local (adaptor_align*), 1 = global (barcode_align/general_align)
+ *   d_starts/d_ends/d_sec_* may be NULL for score-only.
+ * max_len = longest read in the batch (host-known). */
+int sarlacc_dev_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off,
+                      int64_t n, int32_t max_len,
+                      const double* enc_errors, const char* enc_names, int enc_n,
+                      double gapopen, double gapext,
+                      const char* reference, int reference_len, int mode,
+                      const int32_t* sec_starts, const int32_t* sec_ends, int nsec,
+                      double* d_scores, int32_t* d_starts, int32_t* d_ends,
+                      int32_t* d_sec_start_out, int32_t* d_sec_width_out,
+                      void* stream);
+
+/* ------------------------------------------------------------------ */
+/* masked Levenshtein, neighbour search, clustering                      */
+
+/* replaces .Call compute_lev_masked  (src/compute_lev_masked.cpp:13-64);
+ * out has n(n-1)/2 doubles, i-major lower triangle (R 'dist' order). */
+int sarlacc_compute_lev_masked(const char* seq, const int64_t* off, int64_t n, double* out);
+
+/* replaces .Call fast_levdist_test  (src/sorted_trie.cpp:304-337).
+ * Neighbour lists (1-based) in the reference's trie order.  Two-call protocol:
+ * nbr==NULL returns the required size in *nbr_need and fills nbr_off. */
+int sarlacc_fast_levdist_test(const char* seq, const int64_t* off, int64_t n, int limit,
+                              int64_t* nbr_off, int32_t* nbr, int64_t nbr_cap, int64_t* nbr_need);
+
+/* replaces .Call cluster_umis_test  (src/cluster_umis_test.cpp:8-30).
+ * links: CSR of 1-based neighbour lists; clusters returned as CSR of 1-based ids
+ * (clu_off needs n+1 entries, clu n entries). */
+int sarlacc_cluster_umis_test(const int64_t* link_off, const int32_t* links, int64_t n,
+                              int64_t* nclusters, int64_t* clu_off, int32_t* clu);
+
+/* replaces .Call umi_group  (src/umi_group.cpp:14-116) followed by the
+ * unlist(out, recursive=FALSE) of R/umiGroup.R:22.
+ * umi2 may be NULL.  pregroups: CSR of 1-based read ids.  Output clusters as CSR
+ * of 1-based read ids (clu_off: total+1 entries, clu: total entries, where
+ * total = grp_off[ngroups]). */
+int sarlacc_umi_group(const char* umi1, const int64_t* off1,
+                      const char* umi2, const int64_t* off2, int64_t n,
+                      int thresh1, int thresh2,
+                      const int64_t* grp_off, const int32_t* grp, int64_t ngroups,
+                      int64_t* nclusters, int64_t* clu_off, int32_t* clu);
+
+/* ------------------------------------------------------------------ */
+/* per-group MSA and consensus                                           */
+
+/* replaces .Call quick_msa  (src/quick_msa.cpp:15-80); argument order as there
+ * (the R caller passes -gapOpening as gap_extension and -gapExtension as
+ * gap_opening, R/multiReadAlign.R:47).  Groups: CSR of 1-based read ids.
+ * Output: for group g, rows_g = size(g) strings of equal width width_out[g],
+ * written row-major at out + out_off[g]; out_off has ngroups+1 entries.
+ * Two-call protocol: out==NULL fills width_out/out_off only. */
+int sarlacc_quick_msa(const int64_t* grp_off, const int32_t* grp, int64_t ngroups,
+                      const char* seq, const int64_t* seq_off, int64_t nseq,
+                      double match, double mismatch, double gap_extension, double gap_opening,
+                      int bandwidth,
+                      int32_t* width_out, int64_t* out_off, char* out, int64_t out_cap);
+
+/* replaces .Call create_consensus_basic_loop  (src/create_consensus.cpp:150-170)
+ * and, with ngroups==1 and lerr!=NULL, create_consensus_basic (:137-148).
+ * Alignments: aln_off[nrows_total+1] string offsets, grp_rows[ngroups+1] row
+ * ranges per alignment.  cons/phred: concatenated outputs with cons_off[ngroups+1];
+ * capacity of each is the total alignment width.  lerr (optional) gets the
+ * natural-log error of every kept column, same offsets. */
+int sarlacc_create_consensus_basic_loop(const char* aln, const int64_t* aln_off,
+                                        const int64_t* grp_rows, int64_t ngroups,
+                                        double min_cov, double pseudo_count,
+                                        char* cons, char* phred, int64_t* cons_off, double* lerr);
+
+/* replaces .Call create_consensus_quality_loop  (src/create_consensus.cpp:287-308)
+ * and create_consensus_quality (:274-285).  qual strings are per alignment row,
+ * ungapped (consumed positionally, N included). */
+int sarlacc_create_consensus_quality_loop(const char* aln, const int64_t* aln_off,
+                                          const int64_t* grp_rows, int64_t ngroups,
+                                          const char* qual, const int64_t* qual_off,
+                                          const int64_t* qgrp_rows,
+                                          double min_cov,
+                                          const double* enc_errors, const char* enc_names, int enc_n,
+                                          char* cons, char* phred, int64_t* cons_off, double* lerr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

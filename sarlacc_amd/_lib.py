@@ -1,0 +1,53 @@
+"""Loader for libsarlacc_amd.so (HIP kernels + C ABI, include/sarlacc_amd.h).
+
+There is deliberately no fallback: if the shared library is missing or no HIP
+device is usable, every compute call raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsarlacc_amd.so")
+_lib = None
+
+
+class SarlaccError(RuntimeError):
+    """Error raised by the native library; the message is the reference's own
+    wherever the reference would have thrown (src/utils.cpp, src/reference_align.cpp ...)."""
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "sarlacc_amd: %s not found -- build it with `make -C sarlacc_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.sarlacc_last_error.restype = C.c_char_p
+        _lib.sarlacc_last_kernel_ms.restype = C.c_double
+    return _lib
+
+
+def check(rc):
+    if rc:
+        raise SarlaccError(lib().sarlacc_last_error().decode())
+
+
+def ptr(a):
+    """numpy array / None -> void*"""
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return int(lib().sarlacc_device_count())
+
+
+def set_device(device):
+    check(lib().sarlacc_set_device(int(device)))
+
+
+def last_kernel_ms():
+    return float(lib().sarlacc_last_kernel_ms())

@@ -1,0 +1,130 @@
+"""`.Call`-level interface: one function per native routine the reference registers
+(/root/reference/src/init.cpp:9-35), same names and argument order, operating on
+Python lists of strings / numpy arrays instead of SEXPs.  Each function is a thin
+ctypes shim over the C ABI in include/sarlacc_amd.h -- the exact counterpart of the
+R glue shown in INTEGRATION.md.  All arithmetic happens in the HIP library.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import SarlaccError, check, ptr
+from .encoding import as_encoding
+from .strset import StringSet, csr_from_lists, lists_from_csr
+
+
+def _scalar(x, what, kind):
+    """check_*_scalar of the reference (src/utils.cpp:5-32)."""
+    a = np.atleast_1d(np.asarray(x))
+    if a.size != 1:
+        raise SarlaccError("%s should be %s" % (what, kind))
+    return a[0]
+
+
+def _numeric(x, what):
+    return float(_scalar(x, what, "a numeric scalar"))
+
+
+def _integer(x, what):
+    return int(_scalar(x, what, "an integer scalar"))
+
+
+def _string(x, what):
+    if isinstance(x, (str, bytes)):
+        x = [x]
+    if len(x) != 1:
+        raise SarlaccError("%s should be a string" % what)
+    s = x[0]
+    return s.encode() if isinstance(s, str) else bytes(s)
+
+
+def _seq_qual(seq, qual):
+    s = StringSet.from_strings(seq)
+    q = StringSet.from_strings(qual)
+    if len(s) != len(q):
+        raise SarlaccError("sequence and quality vectors should have the same length")
+    return s, q
+
+
+# ---------------------------------------------------------------------------
+def adaptor_align(readseq, readqual, encoding, gapopen, gapext, adaptor, sec_starts, sec_ends):
+    """.Call adaptor_align (src/adaptor_align.cpp:11-77).
+    Returns [scores, starts, ends, [section starts...], [section widths...]]."""
+    ad = _string(adaptor, "adaptor sequence")
+    go = _numeric(gapopen, "gap opening penalty")
+    ge = _numeric(gapext, "gap extension penalty")
+    s, q = _seq_qual(readseq, readqual)
+    enc = as_encoding(encoding)
+    ss = np.ascontiguousarray(sec_starts, dtype=np.int32).reshape(-1)
+    se = np.ascontiguousarray(sec_ends, dtype=np.int32).reshape(-1)
+    if ss.size != se.size:
+        raise SarlaccError("section starts and ends should have the same length")
+    n, ns = len(s), ss.size
+    scores = np.zeros(n, np.float64)
+    starts = np.zeros(n, np.int32)
+    ends = np.zeros(n, np.int32)
+    so = np.zeros((max(ns, 1), max(n, 1)), np.int32)
+    sw = np.zeros((max(ns, 1), max(n, 1)), np.int32)
+    if ns == 0:
+        ss = np.zeros(1, np.int32)
+        se = np.zeros(1, np.int32)
+    check(_lib.lib().sarlacc_adaptor_align(
+        ptr(s.chars), ptr(s.off), ptr(q.chars), ptr(q.off), C.c_int64(n),
+        ptr(enc.errors), enc.names, len(enc), C.c_double(go), C.c_double(ge),
+        ad, len(ad), ptr(ss), ptr(se), ns,
+        ptr(scores), ptr(starts), ptr(ends), ptr(so), ptr(sw)))
+    sol = [so.reshape(-1)[k * n:(k + 1) * n].copy() for k in range(ns)]
+    swl = [sw.reshape(-1)[k * n:(k + 1) * n].copy() for k in range(ns)]
+    return [scores, starts, ends, sol, swl]
+
+
+def _scores_call(fn, seq, qual, encoding, gapopen, gapext, ref, what):
+    rf = _string(ref, what)
+    go = _numeric(gapopen, "gap opening penalty")
+    ge = _numeric(gapext, "gap extension penalty")
+    s, q = _seq_qual(seq, qual)
+    enc = as_encoding(encoding)
+    n = len(s)
+    scores = np.zeros(n, np.float64)
+    check(fn(ptr(s.chars), ptr(s.off), ptr(q.chars), ptr(q.off), C.c_int64(n),
+             ptr(enc.errors), enc.names, len(enc), C.c_double(go), C.c_double(ge),
+             rf, len(rf), ptr(scores)))
+    return scores
+
+
+def adaptor_align_score_only(readseq, readqual, encoding, gapopen, gapext, adaptor):
+    """.Call adaptor_align_score_only (src/adaptor_align.cpp:79-110)."""
+    return _scores_call(_lib.lib().sarlacc_adaptor_align_score_only, readseq, readqual, encoding,
+                        gapopen, gapext, adaptor, "adaptor sequence")
+
+
+def barcode_align(barcodeseq, barcodequal, encoding, gapopen, gapext, reference):
+    """.Call barcode_align (src/barcode_align.cpp:10-44)."""
+    return _scores_call(_lib.lib().sarlacc_barcode_align, barcodeseq, barcodequal, encoding,
+                        gapopen, gapext, reference, "barcode sequence")
+
+
+def general_align(inputseq, inputqual, encoding, gapopen, gapext, reference, edit_only):
+    """.Call general_align (src/general_align.cpp:10-62).
+    Returns [scores, edit distances, reference strings, query strings]."""
+    rf = _string(reference, "reference sequence")
+    go = _numeric(gapopen, "gap opening penalty")
+    ge = _numeric(gapext, "gap extension penalty")
+    s, q = _seq_qual(inputseq, inputqual)
+    only = bool(_scalar(edit_only, "edit-only specification", "a logical scalar"))
+    enc = as_encoding(encoding)
+    n = len(s)
+    scores = np.zeros(n, np.float64)
+    edits = np.zeros(n, np.int32)
+    cap = s.total + n * len(rf) + 1
+    ar = np.zeros(1 if only else cap, np.uint8)
+    aq = np.zeros(1 if only else cap, np.uint8)
+    ao = np.zeros(n + 1, np.int64)
+    check(_lib.lib().sarlacc_general_align(
+        ptr(s.chars), ptr(s.off), ptr(q.chars), ptr(q.off), C.c_int64(n),
+        ptr(enc.errors), enc.names, len(enc), C.c_double(go), C.c_double(ge),
+        rf, len(rf), int(only), ptr(scores), ptr(edits), ptr(ar), ptr(aq), ptr(ao), C.c_int64(cap)))
+    if only:
+        return [scores, edits, [], []]
+    return [scores, edits, StringSet(ar, ao).to_strings(), StringSet(aq, ao).to_strings()]

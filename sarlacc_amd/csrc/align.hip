@@ -1,0 +1,750 @@
+// align.hip -- quality-weighted read-vs-reference affine-gap DP on gfx950.
+//
+// Replaces the CPU loop of the reference's reference_align class
+// (/root/reference/src/reference_align.cpp:54-181 fill, :231-351 backtrack +
+// interval lookup, :353-389 strings) and its three .Call wrappers
+// (src/adaptor_align.cpp, src/barcode_align.cpp, src/general_align.cpp).
+//
+// Mapping (see DESIGN.md "DP kernel"):
+//   * one wavefront = up to NGMAX alignments side by side; inside one alignment a
+//     lane owns K consecutive reference (adaptor) columns, lanes are skewed by one
+//     read row (anti-diagonal wavefront);
+//   * per-column state (vertical jump score/point, previous score of the column)
+//     lives in VGPRs; per-row state (score of the column to the left, horizontal
+//     jump score/point, "left cell was a horizontal gap" flag) travels to the next
+//     lane with DPP wave_shr:1 moves -- no LDS on the recurrence path;
+//   * read bases + qualities are staged 64 rows at a time into an LDS ring, the
+//     5 x navail fp64 cost tables sit in LDS;
+//   * traceback directions (jump lengths, as the reference stores them) are
+//     streamed to a per-wave scratch tile in HBM in anti-diagonal order (one
+//     coalesced store per step) and walked by the group's leader lane afterwards.
+//
+// All arithmetic is fp64 add/sub/compare in the reference's order, compiled with
+// -ffp-contract=off, so scores are bit-identical to the CPU path.
+#include "common.hpp"
+
+#include "../../include/sarlacc_amd.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace sarlacc {
+
+constexpr int NGMAX = 4;   // alignments processed side by side in one wavefront
+constexpr int RING = 128;  // staged read positions per alignment (2 x 64)
+constexpr int MAX_REF = 1024;
+
+struct AlignArgs {
+    const uint8_t* seq;
+    const uint8_t* qual;
+    const int64_t* off;
+    long long n;
+    int R, W, ngroups, local;
+    int qoffset, navail;
+    double GO, GE;
+    const double* tables;     // [5][navail]: exact-match, exact-mismatch, 2-fold, 3-fold, N
+    const double* rowzero;    // [R+1] scores of DP row 0
+    const uint32_t* colinfo;  // [R+1] refcode | match-table << 8 | mismatch-table << 16
+    const uint8_t* refchars;  // [R]
+    double* scores;
+    int32_t* starts;
+    int32_t* ends;
+    const int32_t* sec_s;
+    const int32_t* sec_e;
+    int nsec;
+    int32_t* sec_so;
+    int32_t* sec_wo;
+    void* dirs;
+    unsigned long long dirs_per_wave;  // elements
+    int* badqual;                      // min index of a read holding a quality below the offset
+    uint8_t* aln_ref;                  // MODE 2: reversed gapped strings, stride L+R per read
+    uint8_t* aln_qry;
+    int32_t* aln_len;
+    int32_t* edits;
+};
+
+__device__ __forceinline__ int dpp_shr1(int v) {
+    // lane l receives lane l-1; lane 0 keeps its own value
+    return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ double dpp_shr1(double v) {
+    long long b = __double_as_longlong(v);
+    int lo = dpp_shr1(static_cast<int>(b));
+    int hi = dpp_shr1(static_cast<int>(b >> 32));
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
+template <typename DirT, int K>
+struct alignas(sizeof(DirT) * K <= 16 ? sizeof(DirT) * K : 16) DirPack {
+    DirT v[K];
+};
+
+// MODE 0: scores only.  MODE 1: scores + reference->read map (adaptor_align).
+// MODE 2: scores + gapped strings + edit distance (general_align).
+template <int K, typename DirT, int MODE>
+__global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* s_tab = reinterpret_cast<double*>(smem);
+    uint16_t* s_ring = reinterpret_cast<uint16_t*>(s_tab + 5 * A.navail);
+    int32_t* s_map = reinterpret_cast<int32_t*>(s_ring + NGMAX * RING);
+
+    const int lane = threadIdx.x;
+    const int W = A.W, R = A.R;
+    const int g = lane / W;
+    const int j = lane - g * W;
+    const bool lane_on = g < A.ngroups;
+    const bool leader = (j == 0);
+    const int c0 = j * K + 1;
+    const double NEG_INF = -__builtin_huge_val();
+    const double GO = A.GO, GE = A.GE;
+    const bool local = A.local != 0;
+
+    for (int x = lane; x < 5 * A.navail; x += 64) s_tab[x] = A.tables[x];
+
+    double vgo[K], vge[K], rz[K];
+    int refcode[K], tm[K], tmm[K];
+    bool colon[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int c = c0 + k;
+        colon[k] = lane_on && c <= R;
+        const int cc = c <= R ? c : R;
+        const uint32_t info = A.colinfo[cc];
+        refcode[k] = info & 0xff;
+        tm[k] = ((info >> 8) & 0xff) * A.navail;
+        tmm[k] = ((info >> 16) & 0xff) * A.navail;
+        const bool last = local && cc == R;
+        vgo[k] = last ? 0.0 : GO;
+        vge[k] = last ? 0.0 : GE;
+        rz[k] = A.rowzero[cc];
+    }
+    const double rz_left = A.rowzero[c0 - 1 <= R ? c0 - 1 : R];
+    const int jlast = (R - 1) / K, klast = (R - 1) % K;
+    DirT* const scr = static_cast<DirT*>(A.dirs) + static_cast<size_t>(blockIdx.x) * A.dirs_per_wave;
+    __syncthreads();
+
+    const long long nitems = (A.n + A.ngroups - 1) / A.ngroups;
+    for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const long long read = item * A.ngroups + g;
+        const bool valid = lane_on && read < A.n;
+        long long start = 0;
+        int L = 0;
+        if (valid) {
+            start = A.off[read];
+            L = static_cast<int>(A.off[read + 1] - start);
+        }
+        int Lmax = L;
+#pragma unroll
+        for (int m = 32; m; m >>= 1) Lmax = max(Lmax, __shfl_xor(Lmax, m));
+
+        long long gstart[NGMAX];
+        int glen[NGMAX];
+#pragma unroll
+        for (int gg = 0; gg < NGMAX; ++gg) {
+            const int src = gg < A.ngroups ? gg * W : 0;
+            gstart[gg] = __shfl(start, src);
+            const int len = __shfl(L, src);
+            glen[gg] = gg < A.ngroups ? len : 0;
+        }
+
+        // read staging: fetch 64 positions per alignment one refill ahead of use
+        auto fetch = [&](int gg, int r0) -> uint32_t {
+            const int r = r0 + lane;
+            uint32_t v = 0;
+            if (r < glen[gg]) v = A.qual[gstart[gg] + r] | (static_cast<uint32_t>(A.seq[gstart[gg] + r]) << 8);
+            return v;
+        };
+        auto stage = [&](int gg, int r0, uint32_t v) {
+            const int r = r0 + lane;
+            int qi = static_cast<int>(static_cast<signed char>(v & 0xff)) - A.qoffset;
+            if (r < glen[gg] && qi < 0) atomicMin(A.badqual, static_cast<int>(item * A.ngroups + gg));
+            qi = qi < 0 ? 0 : (qi >= A.navail ? A.navail - 1 : qi);
+            const uint32_t b = v >> 8;
+            const uint32_t code = b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u;
+            s_ring[gg * RING + (r & (RING - 1))] = static_cast<uint16_t>(qi | (code << 8));
+        };
+        uint32_t pf[NGMAX];
+#pragma unroll
+        for (int gg = 0; gg < NGMAX; ++gg) pf[gg] = fetch(gg, 0);
+
+        double S[K], UJ[K];
+        int UP[K];
+        bool vneg[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { S[k] = rz[k]; UJ[k] = NEG_INF; UP[k] = 0; vneg[k] = false; }
+        double s_in = 0.0, lj_in = NEG_INF, diag_prev = rz_left;
+        int lph_in = 0;  // left_jump_point * 2 + (left cell is a horizontal gap)
+
+        const int nsteps = Lmax + W;
+        for (int t = 0; t < nsteps; ++t) {
+            if ((t & 63) == 0) {
+#pragma unroll
+                for (int gg = 0; gg < NGMAX; ++gg) {
+                    stage(gg, t, pf[gg]);
+                    pf[gg] = fetch(gg, t + 64);
+                }
+            }
+            const int i = t - j;
+            if (leader) {  // column 0 of the DP (src/reference_align.cpp:63-78)
+                s_in = (local || i < 1) ? 0.0 : (-GO - GE * static_cast<double>(i - 1));
+                lj_in = NEG_INF;
+                lph_in = 0;
+            }
+            double out_s = s_in, out_lj = lj_in;
+            int out_lph = lph_in;
+            DirPack<DirT, K> dk;
+#pragma unroll
+            for (int k = 0; k < K; ++k) dk.v[k] = 0;
+
+            if (i == 0) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) { S[k] = rz[k]; UJ[k] = NEG_INF; UP[k] = 0; vneg[k] = false; }
+                diag_prev = rz_left;
+            } else if (valid && i >= 1 && i <= L) {
+                const uint32_t rd = s_ring[g * RING + ((i - 1) & (RING - 1))];
+                const int qi = rd & 0xff;
+                const int code = rd >> 8;
+                double diag = diag_prev;
+                diag_prev = s_in;
+                double left = s_in, lj = lj_in;
+                int lp = lph_in >> 1;
+                bool hp = lph_in & 1;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (colon[k]) {
+                        const int pos = c0 + k - 1;
+                        // horizontal candidate
+                        double H = left - (hp ? GE : GO);
+                        lj = lj - GE;
+                        int hstep = 1;
+                        if (lj > H) { hstep = 1 + pos - lp; H = lj; }
+                        else { lj = H; lp = pos; }
+                        // vertical candidate
+                        double V = S[k] - (vneg[k] ? vge[k] : vgo[k]);
+                        UJ[k] = UJ[k] - vge[k];
+                        int vstep = 1;
+                        if (UJ[k] > V) { vstep = 1 + i - UP[k]; V = UJ[k]; }
+                        else { UJ[k] = V; UP[k] = i; }
+                        // (mis)match candidate
+                        const double w = s_tab[(code == refcode[k] ? tm[k] : tmm[k]) + qi];
+                        const double M = diag + w;
+                        diag = S[k];
+                        int d;
+                        double best;
+                        if (M > H && M > V) { best = M; d = 0; }
+                        else if (H > V) { best = H; d = hstep; }
+                        else { best = V; d = -vstep; }
+                        S[k] = best;
+                        left = best;
+                        hp = d > 0;
+                        vneg[k] = d < 0;
+                        dk.v[k] = static_cast<DirT>(d);
+                    }
+                }
+                out_s = left;
+                out_lj = lj;
+                out_lph = lp * 2 + (hp ? 1 : 0);
+            }
+            if (MODE >= 1)
+                *reinterpret_cast<DirPack<DirT, K>*>(scr + (static_cast<size_t>(t) * 64 + lane) * K) = dk;
+
+            s_in = dpp_shr1(out_s);
+            lj_in = dpp_shr1(out_lj);
+            lph_in = dpp_shr1(out_lph);
+        }
+
+        if (valid && j == jlast) {
+            double sc = S[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) sc = (k == klast) ? S[k] : sc;
+            A.scores[read] = sc;
+        }
+
+        if (MODE >= 1) {
+            // make this wave's direction stores visible to its leader lanes
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (valid && leader) {
+                auto loadD = [&](int c, int row) -> int {
+                    if (row <= 0) return 1;  // D[c][0] = 1 (src/reference_align.cpp:118)
+                    const int jj = (c - 1) / K, kk = (c - 1) % K;
+                    const size_t tt = static_cast<size_t>(row + jj);
+                    int d = static_cast<int>(scr[(tt * 64 + (g * W + jj)) * K + kk]);
+                    // keep the walk inside the matrix whatever the scratch holds
+                    if (d < -row) d = -row;
+                    if (d > c) d = c;
+                    return d;
+                };
+                int row = L, c = R;
+                if (MODE == 1) {
+                    int32_t* map = s_map + g * (R + 1);
+                    while (c > 0) {
+                        int d = loadD(c, row);
+                        while (row > 0 && d < 0) { row += d; d = loadD(c, row); }
+                        if (d == 0) { map[c] = row * 2 + 1; --row; --c; }
+                        else { for (int x = 0; x < d; ++x) { map[c] = (row + 1) * 2; --c; } }
+                    }
+                    // (src/reference_align.cpp:307-351), size_t wrap kept via unsigned
+                    auto interval = [&](int a, int b, bool gaps, unsigned& s, unsigned& e) {
+                        if (!gaps) {
+                            s = map[a + 1] >> 1;
+                            e = (map[b] >> 1) + (map[b] & 1);
+                        } else {
+                            s = (a == 0) ? 1u : static_cast<unsigned>((map[a] >> 1) + (map[a] & 1));
+                            e = (b + 1 == R + 1) ? static_cast<unsigned>(L + 1) : static_cast<unsigned>(map[b + 1] >> 1);
+                        }
+                        s -= 1;
+                        e -= 1;
+                    };
+                    unsigned s, e;
+                    interval(0, R, false, s, e);
+                    const bool nonempty = s < e;
+                    A.starts[read] = nonempty ? static_cast<int32_t>(s + 1) : 0;
+                    A.ends[read] = nonempty ? static_cast<int32_t>(e) : 0;
+                    for (int x = 0; x < A.nsec; ++x) {
+                        interval(A.sec_s[x], A.sec_e[x], true, s, e);
+                        A.sec_so[static_cast<long long>(x) * A.n + read] = static_cast<int32_t>(s + 1);
+                        A.sec_wo[static_cast<long long>(x) * A.n + read] = static_cast<int32_t>(e - s);
+                    }
+                } else {
+                    // gapped strings, emitted from the end (src/reference_align.cpp:353-389)
+                    const long long base = start + read * static_cast<long long>(R);
+                    uint8_t* oref = A.aln_ref + base;
+                    uint8_t* oqry = A.aln_qry + base;
+                    const uint8_t* sq = A.seq + start;
+                    int m = 0, ed = 0;
+                    while (c > 0) {
+                        int d = loadD(c, row);
+                        while (row > 0 && d < 0) {
+                            for (int x = 0; x < -d; ++x) { oref[m] = '-'; oqry[m] = sq[row - 1]; ++m; ++ed; --row; }
+                            d = loadD(c, row);
+                        }
+                        if (d == 0) {
+                            const uint8_t rc = A.refchars[c - 1], qc = sq[row - 1];
+                            oref[m] = rc; oqry[m] = qc; ++m;
+                            ed += rc != qc;
+                            --row; --c;
+                        } else {
+                            for (int x = 0; x < d; ++x) { oref[m] = A.refchars[c - 1]; oqry[m] = '-'; ++m; ++ed; --c; }
+                        }
+                    }
+                    while (row > 0) { oref[m] = '-'; oqry[m] = sq[row - 1]; ++m; ++ed; --row; }
+                    A.aln_len[read] = m;
+                    A.edits[read] = ed;
+                }
+            }
+        }
+    }
+}
+
+// Empty reference: the DP has only column 0 (src/reference_align.cpp:63-78,:104).
+__global__ void k_align_emptyref(const int64_t* off, long long n, int local, double GO, double GE,
+                                 double* scores, int32_t* starts, int32_t* ends, int nsec,
+                                 int32_t* sec_so, int32_t* sec_wo, int32_t* aln_len, int32_t* edits,
+                                 const uint8_t* seq, uint8_t* aln_ref, uint8_t* aln_qry) {
+    const long long r = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    if (r >= n) return;
+    const int L = static_cast<int>(off[r + 1] - off[r]);
+    scores[r] = (local || L < 1) ? 0.0 : (-GO - GE * static_cast<double>(L - 1));
+    if (starts) { starts[r] = 0; ends[r] = 0; }
+    for (int x = 0; x < nsec; ++x) { sec_so[x * n + r] = 1; sec_wo[x * n + r] = 0; }
+    if (aln_len) {
+        // every read base sits opposite a gap; strings are stored reversed
+        for (int m = 0; m < L; ++m) { aln_ref[off[r] + m] = '-'; aln_qry[off[r] + m] = seq[off[r] + L - 1 - m]; }
+        aln_len[r] = L;
+        edits[r] = L;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+
+// Per-column lookup info: which fp64 table a column reads, decided by the
+// reference character alone (src/reference_align.cpp:184-212, SURVEY App.B Q2).
+static int column_info(char r, uint32_t* info) {
+    uint32_t code = 7, tmatch, tmis;
+    switch (r) {
+        case 'A': code = 0; tmatch = 0; tmis = 1; break;
+        case 'C': code = 1; tmatch = 0; tmis = 1; break;
+        case 'G': code = 2; tmatch = 0; tmis = 1; break;
+        case 'T': code = 3; tmatch = 0; tmis = 1; break;
+        case 'M': case 'R': case 'W': case 'S': case 'Y': case 'K': tmatch = tmis = 2; break;
+        case 'V': case 'H': case 'D': case 'B': tmatch = tmis = 3; break;
+        case 'N': tmatch = tmis = 4; break;
+        default: return 1;
+    }
+    *info = code | (tmatch << 8) | (tmis << 16);
+    return 0;
+}
+
+// (src/reference_align.cpp:21-52) -- built on the host with the host libm so the
+// device never evaluates a transcendental on the scoring path.
+static void build_tables(const double* errors, int n, std::vector<double>& tab) {
+    tab.assign(static_cast<size_t>(5) * n, 0.0);
+    const double four = 4.0, ratio = four / (four - 1.0);
+    auto odds = [&](double g, double e) { return std::log(g * (1 - e) * four + (1 - g) * e * ratio) / M_LN2; };
+    for (int q = 0; q < n; ++q) {
+        const double e = errors[q];
+        tab[0 * n + q] = odds(1.0 / 1.0, e);          // exact, match      (mode 1 match)
+        tab[1 * n + q] = odds(1 - 1.0 / 1.0, e);      // exact, mismatch   (mode 1 mismatch)
+        tab[2 * n + q] = odds(1 - 1.0 / 2.0, e);      // 2-fold            (mode 2 mismatch)
+        tab[3 * n + q] = odds(1.0 / 3.0, e);          // 3-fold            (mode 3 match)
+        tab[4 * n + q] = odds(1.0 / 4.0, e);          // N                 (mode 4 match)
+    }
+}
+
+struct Shape { int K, W, ngroups; };
+
+// Columns per lane / lanes per alignment / alignments per wave for a reference
+// of R columns: maximise busy lanes, prefer more columns per lane on ties (fewer
+// cross-lane moves per cell).
+static Shape pick_shape(int R) {
+    Shape best{1, 64, 1};
+    double best_u = -1;
+    for (int K : {1, 2, 4, 8, 16}) {
+        const int W = (R + K - 1) / K;
+        if (W > 64) continue;
+        const int ng = std::min(64 / W, NGMAX);
+        const double u = static_cast<double>(ng) * R / (64.0 * K);
+        if (u > best_u + 1e-9 || (u > best_u - 1e-9 && K > best.K && K <= 2)) { best_u = u; best = {K, W, ng}; }
+    }
+    return best;
+}
+
+template <int K, typename DirT>
+static int launch_mode(int mode, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
+    if (mode == 0) hipLaunchKernelGGL((k_align<K, DirT, 0>), dim3(grid), dim3(64), lds, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_align<K, DirT, 1>), dim3(grid), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL((k_align<K, DirT, 2>), dim3(grid), dim3(64), lds, s, a);
+    SL_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename DirT>
+static int launch_k(int K, int mode, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
+    switch (K) {
+        case 1: return launch_mode<1, DirT>(mode, a, grid, lds, s);
+        case 2: return launch_mode<2, DirT>(mode, a, grid, lds, s);
+        case 4: return launch_mode<4, DirT>(mode, a, grid, lds, s);
+        case 8: return launch_mode<8, DirT>(mode, a, grid, lds, s);
+        case 16: return launch_mode<16, DirT>(mode, a, grid, lds, s);
+    }
+    return fail("sarlacc_amd: unsupported columns-per-lane %d", K);
+}
+
+struct AlignOut {
+    double* d_scores = nullptr;
+    int32_t* d_starts = nullptr;
+    int32_t* d_ends = nullptr;
+    int32_t* d_sec_so = nullptr;
+    int32_t* d_sec_wo = nullptr;
+    // mode 2
+    uint8_t* d_aln_ref = nullptr;
+    uint8_t* d_aln_qry = nullptr;
+    int32_t* d_aln_len = nullptr;
+    int32_t* d_edits = nullptr;
+};
+
+// kernel_mode: 0 scores, 1 map, 2 strings.  Returns in *bad_qual_read the smallest
+// index of a read with a quality character below the encoding offset (or INT_MAX).
+static int run_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
+                     int32_t max_len, const double* enc_errors, const char* enc_names, int enc_n,
+                     double gapopen, double gapext, const char* ref, int R, bool local, int kernel_mode,
+                     const int32_t* sec_starts, const int32_t* sec_ends, int nsec, const AlignOut& out,
+                     hipStream_t stream, int* bad_qual_read) {
+    Context& c = ctx();
+    *bad_qual_read = std::numeric_limits<int>::max();
+    if (n <= 0) return 0;
+    if (R > MAX_REF) return fail("sarlacc_amd: reference longer than %d columns is not supported", MAX_REF);
+    if (n > std::numeric_limits<int>::max() - 8) return fail("sarlacc_amd: more than 2^31 reads in one call");
+    const double GO = gapopen + gapext, GE = gapext;  // (src/reference_align.cpp:8)
+
+    if (R == 0) {
+        const int bs = 256;
+        hipLaunchKernelGGL(k_align_emptyref, dim3(static_cast<unsigned>((n + bs - 1) / bs)), dim3(bs), 0, stream,
+                           d_off, static_cast<long long>(n), local ? 1 : 0, GO, GE, out.d_scores, out.d_starts,
+                           out.d_ends, nsec, out.d_sec_so, out.d_sec_wo, out.d_aln_len, out.d_edits, d_seq,
+                           out.d_aln_ref, out.d_aln_qry);
+        SL_HIP(hipGetLastError());
+        return 0;
+    }
+
+    // ---- small per-call tables ----
+    std::vector<double> tab;
+    build_tables(enc_errors, enc_n, tab);
+    std::vector<double> rowzero(R + 1);
+    rowzero[0] = 0.0;
+    for (int col = 1; col <= R; ++col) rowzero[col] = rowzero[col - 1] - (col == 1 ? GO : GE);  // (:115-118)
+    std::vector<uint32_t> colinfo(R + 1, 0);
+    for (int col = 1; col <= R; ++col)
+        if (column_info(ref[col - 1], &colinfo[col])) colinfo[col] = 7u | (4u << 8) | (4u << 16);  // caller reports the error
+
+    AlignArgs a{};
+    double* d_tab; double* d_rz; uint32_t* d_ci; uint8_t* d_ref; int32_t* d_ss = nullptr; int32_t* d_se = nullptr; int* d_bad;
+    SL_TRY(upload("align.tab", tab.data(), tab.size(), &d_tab, stream));
+    SL_TRY(upload("align.rz", rowzero.data(), rowzero.size(), &d_rz, stream));
+    SL_TRY(upload("align.ci", colinfo.data(), colinfo.size(), &d_ci, stream));
+    SL_TRY(upload("align.ref", reinterpret_cast<const uint8_t*>(ref), static_cast<size_t>(R), &d_ref, stream));
+    if (nsec) {
+        SL_TRY(upload("align.ss", sec_starts, static_cast<size_t>(nsec), &d_ss, stream));
+        SL_TRY(upload("align.se", sec_ends, static_cast<size_t>(nsec), &d_se, stream));
+    }
+    const int sentinel = std::numeric_limits<int>::max();
+    SL_TRY(upload("align.bad", &sentinel, 1, &d_bad, stream));
+
+    const Shape sh = pick_shape(R);
+    const bool wide = max_len > 32000;  // jump lengths no longer fit int16
+    const size_t dir_bytes = wide ? 4 : 2;
+    const long long nitems = (n + sh.ngroups - 1) / sh.ngroups;
+
+    // persistent grid: enough waves to fill the chip, bounded by the scratch budget
+    const size_t per_wave_elems = kernel_mode ? (static_cast<size_t>(max_len) + sh.W + 1) * 64 * sh.K : 0;
+    long long grid = std::min<long long>(nitems, static_cast<long long>(c.num_cu) * 12);
+    if (kernel_mode) {
+        const size_t budget = static_cast<size_t>(6) << 30;
+        const long long fit = std::max<long long>(1, static_cast<long long>(budget / std::max<size_t>(1, per_wave_elems * dir_bytes)));
+        grid = std::min(grid, fit);
+    }
+    void* d_dirs = nullptr;
+    if (kernel_mode) SL_TRY(c.buffer("align.dirs", static_cast<size_t>(grid) * per_wave_elems * dir_bytes, &d_dirs));
+
+    a.seq = d_seq; a.qual = d_qual; a.off = d_off; a.n = n;
+    a.R = R; a.W = sh.W; a.ngroups = sh.ngroups; a.local = local ? 1 : 0;
+    a.qoffset = static_cast<int>(enc_names[0]); a.navail = enc_n;
+    a.GO = GO; a.GE = GE;
+    a.tables = d_tab; a.rowzero = d_rz; a.colinfo = d_ci; a.refchars = d_ref;
+    a.scores = out.d_scores; a.starts = out.d_starts; a.ends = out.d_ends;
+    a.sec_s = d_ss; a.sec_e = d_se; a.nsec = nsec; a.sec_so = out.d_sec_so; a.sec_wo = out.d_sec_wo;
+    a.dirs = d_dirs; a.dirs_per_wave = per_wave_elems; a.badqual = d_bad;
+    a.aln_ref = out.d_aln_ref; a.aln_qry = out.d_aln_qry; a.aln_len = out.d_aln_len; a.edits = out.d_edits;
+
+    const size_t lds = sizeof(double) * 5 * enc_n + sizeof(uint16_t) * NGMAX * RING + sizeof(int32_t) * NGMAX * (R + 1) + 16;
+    SL_HIP(hipEventRecord(c.ev_start, stream));
+    if (wide) SL_TRY(launch_k<int32_t>(sh.K, kernel_mode, a, static_cast<int>(grid), lds, stream));
+    else SL_TRY(launch_k<int16_t>(sh.K, kernel_mode, a, static_cast<int>(grid), lds, stream));
+    SL_HIP(hipEventRecord(c.ev_stop, stream));
+    c.timed = true;
+
+    SL_HIP(hipMemcpyAsync(bad_qual_read, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+    SL_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+
+// Error that the reference would raise first while looping over the reads
+// (length mismatch is tested before each alignment, src/adaptor_align.cpp:51-53;
+// inside an alignment column 1 is evaluated first: its reference character, then
+// the qualities of every row, then the remaining reference characters).
+static int first_error(int64_t n, const int64_t* seq_off, const int64_t* qual_off, const char* ref, int R,
+                       int bad_qual_read) {
+    int64_t len_bad = -1;
+    if (qual_off)
+        for (int64_t i = 0; i < n; ++i)
+            if (seq_off[i + 1] - seq_off[i] != qual_off[i + 1] - qual_off[i]) { len_bad = i; break; }
+    int first_bad_col = -1;
+    uint32_t tmp;
+    for (int col = 0; col < R; ++col)
+        if (column_info(ref[col], &tmp)) { first_bad_col = col; break; }
+    int64_t first_nonempty = -1;
+    if (first_bad_col >= 0)
+        for (int64_t i = 0; i < n; ++i)
+            if (seq_off[i + 1] - seq_off[i] > 0) { first_nonempty = i; break; }
+
+    const int64_t INF = std::numeric_limits<int64_t>::max();
+    const int64_t e_len = len_bad >= 0 ? len_bad : INF;
+    const int64_t e_qual = (R > 0 && bad_qual_read != std::numeric_limits<int>::max()) ? bad_qual_read : INF;
+    const int64_t e_ref = first_nonempty >= 0 ? first_nonempty : INF;
+    const int64_t first = std::min(e_len, std::min(e_qual, e_ref));
+    if (first == INF) return 0;
+    if (first == e_len) return fail("sequence and quality strings should have the same length");
+    if (first == e_ref && first_bad_col == 0) return fail("unrecognized base in reference sequence");
+    if (first == e_qual) return fail("quality cannot be lower than smallest encoded value");
+    return fail("unrecognized base in reference sequence");
+}
+
+struct HostBatch {
+    uint8_t* d_seq = nullptr;
+    uint8_t* d_qual = nullptr;
+    int64_t* d_off = nullptr;
+    int32_t max_len = 0;
+    int64_t len_bad = -1;
+};
+
+// Uploads a batch given host string sets.  Reads whose quality string has a
+// different length make the whole call fail later (first_error), so qualities
+// are copied with the sequence offsets only when every length agrees.
+static int upload_batch(const char* seq, const int64_t* seq_off, const char* qual, const int64_t* qual_off,
+                        int64_t n, HostBatch* hb, hipStream_t s) {
+    int64_t mx = 0;
+    bool same = true;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t L = seq_off[i + 1] - seq_off[i];
+        mx = std::max(mx, L);
+        if (L != qual_off[i + 1] - qual_off[i]) { same = false; if (hb->len_bad < 0) hb->len_bad = i; }
+    }
+    if (mx > std::numeric_limits<int32_t>::max() / 2) return fail("sarlacc_amd: read longer than 2^30 bases");
+    hb->max_len = static_cast<int32_t>(mx);
+    if (!same) return 0;
+    const int64_t base = n ? seq_off[0] : 0;
+    const int64_t total = n ? seq_off[n] - base : 0;
+    std::vector<int64_t> rel(static_cast<size_t>(n) + 1);
+    for (int64_t i = 0; i <= n; ++i) rel[i] = (n ? seq_off[i] : 0) - base;
+    SL_TRY(upload("batch.seq", reinterpret_cast<const uint8_t*>(seq) + base, static_cast<size_t>(total), &hb->d_seq, s));
+    SL_TRY(upload("batch.qual", reinterpret_cast<const uint8_t*>(qual) + (n ? qual_off[0] : 0), static_cast<size_t>(total), &hb->d_qual, s));
+    SL_TRY(upload("batch.off", rel.data(), rel.size(), &hb->d_off, s));
+    return 0;
+}
+
+static int check_sections(const int32_t* ss, const int32_t* se, int nsec, int R) {
+    for (int x = 0; x < nsec; ++x)
+        if (ss[x] < 0 || ss[x] > R || se[x] < 0 || se[x] > R)
+            return fail("sarlacc_amd: section bounds outside the adaptor (the reference reads out of range here)");
+    return 0;
+}
+
+static int host_align(const char* seq, const int64_t* seq_off, const char* qual, const int64_t* qual_off, int64_t n,
+                      const double* enc_errors, const char* enc_names, int enc_n, double gapopen, double gapext,
+                      const char* ref, int R, bool local, int kernel_mode,
+                      const int32_t* sec_starts, const int32_t* sec_ends, int nsec,
+                      double* scores, int32_t* starts, int32_t* ends, int32_t* sec_so, int32_t* sec_wo,
+                      int32_t* edits, char* aln_ref, char* aln_qry, int64_t* aln_off, int64_t aln_cap) {
+    SL_TRY(check_encoding(enc_errors, enc_names, enc_n));
+    if (n < 0) return fail("sarlacc_amd: negative number of sequences");
+    if (kernel_mode == 1) SL_TRY(check_sections(sec_starts, sec_ends, nsec, R));
+    SL_TRY(ensure_device());
+    hipStream_t s = nullptr;
+    if (n == 0) { if (aln_off) aln_off[0] = 0; return 0; }
+
+    HostBatch hb;
+    SL_TRY(upload_batch(seq, seq_off, qual, qual_off, n, &hb, s));
+    if (hb.len_bad >= 0) {
+        // reads before the offending one could still raise an earlier error, but
+        // only a bad reference character is detectable without the qualities
+        return first_error(n, seq_off, qual_off, ref, R, std::numeric_limits<int>::max());
+    }
+    AlignOut out;
+    const size_t nn = static_cast<size_t>(n);
+    SL_TRY(scratch("out.scores", nn, &out.d_scores));
+    if (kernel_mode == 1) {
+        SL_TRY(scratch("out.starts", nn, &out.d_starts));
+        SL_TRY(scratch("out.ends", nn, &out.d_ends));
+        SL_TRY(scratch("out.sso", nn * std::max(nsec, 1), &out.d_sec_so));
+        SL_TRY(scratch("out.swo", nn * std::max(nsec, 1), &out.d_sec_wo));
+    }
+    const int64_t total = seq_off[n] - seq_off[0];
+    const size_t aln_bytes = static_cast<size_t>(total + n * R);
+    if (kernel_mode == 2) {
+        SL_TRY(scratch("out.aref", aln_bytes, &out.d_aln_ref));
+        SL_TRY(scratch("out.aqry", aln_bytes, &out.d_aln_qry));
+        SL_TRY(scratch("out.alen", nn, &out.d_aln_len));
+        SL_TRY(scratch("out.edits", nn, &out.d_edits));
+    }
+    int bad = 0;
+    SL_TRY(run_align(hb.d_seq, hb.d_qual, hb.d_off, n, hb.max_len, enc_errors, enc_names, enc_n, gapopen, gapext,
+                     ref, R, local, kernel_mode, sec_starts, sec_ends, nsec, out, s, &bad));
+    SL_TRY(first_error(n, seq_off, nullptr, ref, R, bad));
+
+    SL_HIP(hipMemcpy(scores, out.d_scores, nn * sizeof(double), hipMemcpyDeviceToHost));
+    if (kernel_mode == 1) {
+        SL_HIP(hipMemcpy(starts, out.d_starts, nn * sizeof(int32_t), hipMemcpyDeviceToHost));
+        SL_HIP(hipMemcpy(ends, out.d_ends, nn * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (nsec) {
+            SL_HIP(hipMemcpy(sec_so, out.d_sec_so, nn * nsec * sizeof(int32_t), hipMemcpyDeviceToHost));
+            SL_HIP(hipMemcpy(sec_wo, out.d_sec_wo, nn * nsec * sizeof(int32_t), hipMemcpyDeviceToHost));
+        }
+    }
+    if (kernel_mode == 2) {
+        SL_HIP(hipMemcpy(edits, out.d_edits, nn * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (aln_ref) {
+            std::vector<uint8_t> hr(aln_bytes), hq(aln_bytes);
+            std::vector<int32_t> hl(nn);
+            SL_HIP(hipMemcpy(hr.data(), out.d_aln_ref, aln_bytes, hipMemcpyDeviceToHost));
+            SL_HIP(hipMemcpy(hq.data(), out.d_aln_qry, aln_bytes, hipMemcpyDeviceToHost));
+            SL_HIP(hipMemcpy(hl.data(), out.d_aln_len, nn * sizeof(int32_t), hipMemcpyDeviceToHost));
+            int64_t used = 0;
+            aln_off[0] = 0;
+            for (int64_t i = 0; i < n; ++i) {
+                const int64_t base = (seq_off[i] - seq_off[0]) + i * static_cast<int64_t>(R);
+                const int32_t m = hl[i];
+                if (used + m > aln_cap) return fail("sarlacc_amd: alignment string buffer too small");
+                for (int32_t x = 0; x < m; ++x) {  // the device wrote them end-first
+                    aln_ref[used + x] = static_cast<char>(hr[base + m - 1 - x]);
+                    aln_qry[used + x] = static_cast<char>(hq[base + m - 1 - x]);
+                }
+                used += m;
+                aln_off[i + 1] = used;
+            }
+        }
+    }
+    return 0;
+}
+
+}  // namespace sarlacc
+
+using namespace sarlacc;
+
+extern "C" {
+
+int sarlacc_adaptor_align(const char* seq, const int64_t* seq_off, const char* qual, const int64_t* qual_off,
+                          int64_t n, const double* enc_errors, const char* enc_names, int enc_n, double gapopen,
+                          double gapext, const char* adaptor, int adaptor_len, const int32_t* sec_starts,
+                          const int32_t* sec_ends, int nsec, double* scores, int32_t* starts, int32_t* ends,
+                          int32_t* sec_start_out, int32_t* sec_width_out) {
+    return host_align(seq, seq_off, qual, qual_off, n, enc_errors, enc_names, enc_n, gapopen, gapext, adaptor,
+                      adaptor_len, true, 1, sec_starts, sec_ends, nsec, scores, starts, ends, sec_start_out,
+                      sec_width_out, nullptr, nullptr, nullptr, nullptr, 0);
+}
+
+int sarlacc_adaptor_align_score_only(const char* seq, const int64_t* seq_off, const char* qual,
+                                     const int64_t* qual_off, int64_t n, const double* enc_errors,
+                                     const char* enc_names, int enc_n, double gapopen, double gapext,
+                                     const char* adaptor, int adaptor_len, double* scores) {
+    return host_align(seq, seq_off, qual, qual_off, n, enc_errors, enc_names, enc_n, gapopen, gapext, adaptor,
+                      adaptor_len, true, 0, nullptr, nullptr, 0, scores, nullptr, nullptr, nullptr, nullptr, nullptr,
+                      nullptr, nullptr, nullptr, 0);
+}
+
+int sarlacc_barcode_align(const char* seq, const int64_t* seq_off, const char* qual, const int64_t* qual_off,
+                          int64_t n, const double* enc_errors, const char* enc_names, int enc_n, double gapopen,
+                          double gapext, const char* reference, int reference_len, double* scores) {
+    return host_align(seq, seq_off, qual, qual_off, n, enc_errors, enc_names, enc_n, gapopen, gapext, reference,
+                      reference_len, false, 0, nullptr, nullptr, 0, scores, nullptr, nullptr, nullptr, nullptr,
+                      nullptr, nullptr, nullptr, nullptr, 0);
+}
+
+int sarlacc_general_align(const char* seq, const int64_t* seq_off, const char* qual, const int64_t* qual_off,
+                          int64_t n, const double* enc_errors, const char* enc_names, int enc_n, double gapopen,
+                          double gapext, const char* reference, int reference_len, int edit_only, double* scores,
+                          int32_t* edits, char* aln_ref, char* aln_query, int64_t* aln_off, int64_t aln_cap) {
+    return host_align(seq, seq_off, qual, qual_off, n, enc_errors, enc_names, enc_n, gapopen, gapext, reference,
+                      reference_len, false, 2, nullptr, nullptr, 0, scores, nullptr, nullptr, nullptr, nullptr, edits,
+                      edit_only ? nullptr : aln_ref, edit_only ? nullptr : aln_query, aln_off, aln_cap);
+}
+
+int sarlacc_dev_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
+                      int32_t max_len, const double* enc_errors, const char* enc_names, int enc_n, double gapopen,
+                      double gapext, const char* reference, int reference_len, int mode, const int32_t* sec_starts,
+                      const int32_t* sec_ends, int nsec, double* d_scores, int32_t* d_starts, int32_t* d_ends,
+                      int32_t* d_sec_start_out, int32_t* d_sec_width_out, void* stream) {
+    SL_TRY(check_encoding(enc_errors, enc_names, enc_n));
+    SL_TRY(ensure_device());
+    const bool trace = d_starts != nullptr;
+    if (trace) SL_TRY(check_sections(sec_starts, sec_ends, nsec, reference_len));
+    AlignOut out;
+    out.d_scores = d_scores;
+    out.d_starts = d_starts;
+    out.d_ends = d_ends;
+    out.d_sec_so = d_sec_start_out;
+    out.d_sec_wo = d_sec_width_out;
+    int bad = 0;
+    SL_TRY(run_align(d_seq, d_qual, d_off, n, max_len, enc_errors, enc_names, enc_n, gapopen, gapext, reference,
+                     reference_len, mode == 0, trace ? 1 : 0, sec_starts, sec_ends, trace ? nsec : 0, out,
+                     static_cast<hipStream_t>(stream), &bad));
+    if (reference_len > 0 && bad != std::numeric_limits<int>::max())
+        return fail("quality cannot be lower than smallest encoded value");
+    uint32_t tmp;
+    for (int col = 0; col < reference_len; ++col)
+        if (column_info(reference[col], &tmp) && max_len > 0) return fail("unrecognized base in reference sequence");
+    return 0;
+}
+}

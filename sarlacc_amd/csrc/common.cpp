@@ -1,0 +1,119 @@
+// common.cpp -- error reporting, device context and workspace cache.
+#include "common.hpp"
+
+#include "../../include/sarlacc_amd.h"
+
+namespace sarlacc {
+
+std::string& last_error() {
+    static thread_local std::string msg;
+    return msg;
+}
+
+int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return 1;
+}
+
+Context& ctx() {
+    static thread_local Context c;
+    return c;
+}
+
+int ensure_device() {
+    Context& c = ctx();
+    if (c.ready) {
+        SL_HIP(hipSetDevice(c.device));
+        return 0;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail("sarlacc_amd: no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorName(e));
+    if (c.device >= count) return fail("sarlacc_amd: device %d out of range (%d visible)", c.device, count);
+    SL_HIP(hipSetDevice(c.device));
+    hipDeviceProp_t prop;
+    SL_HIP(hipGetDeviceProperties(&prop, c.device));
+    c.num_cu = prop.multiProcessorCount;
+    SL_HIP(hipEventCreate(&c.ev_start));
+    SL_HIP(hipEventCreate(&c.ev_stop));
+    c.ready = true;
+    return 0;
+}
+
+int Context::buffer(const char* name, size_t bytes, void** out) {
+    Workspace& w = ws[name];
+    if (w.cap < bytes) {
+        if (w.ptr) SL_HIP(hipFree(w.ptr));
+        w.ptr = nullptr;
+        w.cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&w.ptr, want);
+        if (e != hipSuccess) {
+            want = bytes;
+            e = hipMalloc(&w.ptr, want);
+        }
+        if (e != hipSuccess) return fail("sarlacc_amd: cannot allocate %zu bytes of device memory for '%s'", bytes, name);
+        w.cap = want;
+    }
+    *out = w.ptr;
+    return 0;
+}
+
+void Context::release() {
+    for (auto& kv : ws)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    ws.clear();
+}
+
+int check_encoding(const double* errors, const char* names, int n) {
+    if (n <= 0 || !errors || !names) return fail("encoding vector must be non-empty and named");
+    for (int i = 1; i < n; ++i) {
+        if (names[i] != static_cast<char>(names[i - 1] + 1))
+            return fail("names of encoding vector should increase consecutively");
+        if (errors[i] > errors[i - 1]) return fail("error probabilities should decrease");
+    }
+    return 0;
+}
+
+}  // namespace sarlacc
+
+extern "C" {
+
+const char* sarlacc_last_error(void) { return sarlacc::last_error().c_str(); }
+
+int sarlacc_version(void) { return 100; }
+
+int sarlacc_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+int sarlacc_set_device(int device) {
+    sarlacc::Context& c = sarlacc::ctx();
+    if (c.ready && c.device != device) {
+        c.release();
+        c.ready = false;
+    }
+    c.device = device;
+    return sarlacc::ensure_device();
+}
+
+void sarlacc_release_workspace(void) { sarlacc::ctx().release(); }
+
+double sarlacc_last_kernel_ms(void) {
+    sarlacc::Context& c = sarlacc::ctx();
+    if (!c.ready || !c.timed) return -1.0;
+    if (hipEventSynchronize(c.ev_stop) != hipSuccess) return -1.0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c.ev_start, c.ev_stop) != hipSuccess) return -1.0;
+    return ms;
+}
+}

@@ -1,0 +1,80 @@
+// common.hpp -- shared host-side plumbing of libsarlacc_amd.so: error reporting,
+// per-thread device context, cached device workspaces, upload helpers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace sarlacc {
+
+// ---- errors -------------------------------------------------------------
+std::string& last_error();
+int fail(const char* fmt, ...);
+
+#define SL_HIP(expr)                                                              \
+    do {                                                                          \
+        hipError_t e__ = (expr);                                                  \
+        if (e__ != hipSuccess)                                                    \
+            return ::sarlacc::fail("HIP error %s at %s:%d (%s)", hipGetErrorName(e__), \
+                                   __FILE__, __LINE__, #expr);                    \
+    } while (0)
+
+#define SL_TRY(expr)              \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__) return rc__;    \
+    } while (0)
+
+// ---- device context -------------------------------------------------------
+// One per host thread (a .Call runs on R's main thread; BiocParallel workers are
+// separate processes, /root/reference/R/adaptorAlign.R:126-134).
+struct Workspace {
+    void* ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct Context {
+    int device = 0;
+    bool ready = false;
+    int num_cu = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    std::map<std::string, Workspace> ws;
+
+    // Returns a cached device buffer of at least `bytes` (grown geometrically).
+    int buffer(const char* name, size_t bytes, void** out);
+    void release();
+};
+
+Context& ctx();
+// Makes sure a HIP device is usable; fails loudly otherwise (no CPU fallback).
+int ensure_device();
+
+template <typename T>
+int upload(const char* name, const T* host, size_t count, T** dev, hipStream_t s) {
+    void* p = nullptr;
+    SL_TRY(ctx().buffer(name, (count ? count : 1) * sizeof(T), &p));
+    if (count) SL_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));
+    *dev = static_cast<T*>(p);
+    return 0;
+}
+
+template <typename T>
+int scratch(const char* name, size_t count, T** dev) {
+    void* p = nullptr;
+    SL_TRY(ctx().buffer(name, (count ? count : 1) * sizeof(T), &p));
+    *dev = static_cast<T*>(p);
+    return 0;
+}
+
+// ---- quality encoding (reference src/quality_encoding.cpp:5-33) -------------
+int check_encoding(const double* errors, const char* names, int n);
+
+}  // namespace sarlacc

@@ -1,0 +1,87 @@
+"""Flat string-set representation used at the C-ABI boundary.
+
+The reference hands `.Call` routines Biostrings XStringSet objects or character
+vectors (/root/reference/src/DNA_input.cpp:82-88); across the C ABI these become
+one concatenated byte buffer plus n+1 int64 offsets.
+"""
+import numpy as np
+
+
+class StringSet:
+    """Concatenated bytes + offsets.  `chars` always holds at least one byte so
+    that its data pointer is valid for empty sets."""
+
+    __slots__ = ("chars", "off")
+
+    def __init__(self, chars, off):
+        self.chars = chars
+        self.off = off
+
+    @classmethod
+    def from_strings(cls, strings):
+        if isinstance(strings, StringSet):
+            return strings
+        bs = [s.encode() if isinstance(s, str) else bytes(s) for s in strings]
+        off = np.zeros(len(bs) + 1, dtype=np.int64)
+        if bs:
+            np.cumsum([len(b) for b in bs], out=off[1:])
+        joined = b"".join(bs)
+        chars = np.frombuffer(joined, dtype=np.uint8).copy() if joined else np.zeros(1, np.uint8)
+        return cls(chars, off)
+
+    @classmethod
+    def from_matrix(cls, mat):
+        """n x L uint8 matrix of equal-length strings."""
+        mat = np.ascontiguousarray(mat, dtype=np.uint8)
+        n, L = mat.shape
+        off = np.arange(n + 1, dtype=np.int64) * L
+        chars = mat.reshape(-1) if mat.size else np.zeros(1, np.uint8)
+        return cls(chars, off)
+
+    def __len__(self):
+        return len(self.off) - 1
+
+    @property
+    def total(self):
+        return int(self.off[-1])
+
+    def widths(self):
+        return np.diff(self.off)
+
+    def to_strings(self):
+        raw = self.chars.tobytes()
+        o = self.off
+        return [raw[o[i]:o[i + 1]].decode() for i in range(len(o) - 1)]
+
+    def __getitem__(self, i):
+        return self.chars[self.off[i]:self.off[i + 1]].tobytes().decode()
+
+    def subset(self, idx):
+        idx = np.asarray(idx, dtype=np.int64)
+        w = self.off[idx + 1] - self.off[idx]
+        off = np.zeros(len(idx) + 1, dtype=np.int64)
+        np.cumsum(w, out=off[1:])
+        total = int(off[-1])
+        chars = np.zeros(max(total, 1), np.uint8)
+        if total:
+            # gather positions: for each output byte, its source index
+            src = np.repeat(self.off[idx] - off[:-1], w) + np.arange(total, dtype=np.int64)
+            chars[:total] = self.chars[src]
+        return StringSet(chars, off)
+
+
+def csr_from_lists(lists):
+    """list of integer sequences -> (int64 offsets, int32 values)"""
+    off = np.zeros(len(lists) + 1, dtype=np.int64)
+    if len(lists):
+        np.cumsum([len(x) for x in lists], out=off[1:])
+    if off[-1]:
+        vals = np.concatenate([np.asarray(x, dtype=np.int32).reshape(-1) for x in lists])
+    else:
+        vals = np.zeros(1, np.int32)
+    return off, np.ascontiguousarray(vals, dtype=np.int32)
+
+
+def lists_from_csr(off, vals, n=None):
+    n = len(off) - 1 if n is None else n
+    return [vals[off[i]:off[i + 1]].copy() for i in range(n)]

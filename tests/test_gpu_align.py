@@ -1,0 +1,216 @@
+"""GPU parity: HIP quality-weighted DP vs the CPU oracle, through the C ABI.
+
+Mirrors /root/reference/tests/testthat/test-adaptor-align.R and
+test-general-align.R: same literal reads/adaptors, same edge cases (empty adaptor,
+empty read, affine-gap traps, section extraction), plus randomized differential
+batches.  Scores must be bit-identical (fp64, same operation order); positions,
+sections, edit distances and alignment strings identical.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ADAPTOR = "AAAAGGGGCCCCTTTT"
+READS = ["AAAAGGGGCCCCTTTT", "acgtacgtacgtAAAAGGGGCCCCTTTT", "AAAAGGGGCCCCTTTTacgtacgtacgt",
+         "GGGGCCCCTTTT", "AAAAGGGGCCCC", "acgtacgtacgtAAAAGGGGCCCCTTTTacgtacgtacgt",
+         "acgtacgtacgtAAAAGGGGCCCC", "GGGGCCCCTTTTacgtacgtacgt", "GGGGCCCC",
+         "AAAAGGGGacgtCCCCTTTT", "AAAAGGCCTTTT"]  # test-adaptor-align.R:5-19 (DNAStringSet upper-cases)
+READS = [r.upper() for r in READS]
+IUPAC = "ACGTMRWSYKVHDBN"
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+def rand_quals(reads, seed, lo=33, hi=126):
+    rng = np.random.default_rng(seed)
+    return [rng.integers(lo, hi + 1, len(r)).astype(np.uint8).tobytes().decode() for r in reads]
+
+
+def compare_adaptor(oracle, oenc, enc, reads, quals, adaptor, go, ge, ss=(), se=()):
+    from sarlacc_amd import calls
+    ref = oracle.adaptor_align(reads, quals, oenc, go, ge, adaptor, ss, se)
+    out = calls.adaptor_align(reads, quals, enc, go, ge, adaptor, ss, se)
+    assert np.array_equal(bits(ref[0]), bits(out[0])), "scores differ"
+    assert np.array_equal(ref[1], out[1]), "starts differ"
+    assert np.array_equal(ref[2], out[2]), "ends differ"
+    assert len(ref[3]) == len(out[3])
+    for a, b in zip(ref[3], out[3]):
+        assert np.array_equal(a, b), "section starts differ"
+    for a, b in zip(ref[4], out[4]):
+        assert np.array_equal(a, b), "section widths differ"
+    so = calls.adaptor_align_score_only(reads, quals, enc, go, ge, adaptor)
+    assert np.array_equal(bits(ref[0]), bits(so))
+    return out
+
+
+def test_wave_shift_selftest(enc):
+    # known answer from the reference's own test (test-adaptor-align.R:53-56):
+    # empty read vs 16-mer, go=5, ge=1 -> -(16+5)
+    from sarlacc_amd import calls
+    out = calls.adaptor_align(["", ""], ["", ""], enc, 5, 1, ADAPTOR, [], [])
+    assert out[0].tolist() == [-21.0, -21.0]
+    assert out[1].tolist() == [0, 0] and out[2].tolist() == [0, 0]
+
+
+def test_reference_literals(oracle, oenc, enc):
+    quals = rand_quals(READS, 141000)
+    out = compare_adaptor(oracle, oenc, enc, READS, quals, ADAPTOR, 5, 1)
+    assert len(out[0]) == len(READS)
+    # clean copies of the adaptor must be found where they were planted
+    q20 = [chr(53) * len(r) for r in READS]
+    out = compare_adaptor(oracle, oenc, enc, READS, q20, ADAPTOR, 5, 1, [4], [8])
+    assert out[1][0] == 1 and out[2][0] == 16
+    assert out[1][1] == 13 and out[2][1] == 28
+    assert abs(out[0][1] - 31.768006884878162) < 1e-12  # SURVEY section 8c recorded reference output
+    assert out[3][0][1] == 17 and out[4][0][1] == 4
+
+
+def test_empty_adaptor_and_reads(oracle, oenc, enc):
+    quals = rand_quals(READS, 7)
+    out = compare_adaptor(oracle, oenc, enc, READS, quals, "", 5, 1)
+    assert not out[0].any() and not out[1].any() and not out[2].any()
+    compare_adaptor(oracle, oenc, enc, ["", "ACGT", ""], ["", "IIII", ""], ADAPTOR, 5, 1, [0, 3], [16, 9])
+    from sarlacc_amd import calls
+    out = calls.adaptor_align([], [], enc, 5, 1, ADAPTOR, [], [])
+    assert len(out[0]) == 0
+
+
+def test_affine_gap_traps(oracle, oenc, enc):
+    # test-adaptor-align.R:59-85
+    compare_adaptor(oracle, oenc, enc, ["AAAAAAAAA"], ["+" * 9], "AAACCCAAATTTAAA", 5, 1)
+    compare_adaptor(oracle, oenc, enc, ["AAACCCAAA"], ["+" * 9], "AAAAAA", 5, 1)
+
+
+def test_section_extraction(oracle, oenc, enc):
+    # every internal (start,end) pair, like combn(nchar(adaptor)-1, 2) in the reference test
+    R = len(ADAPTOR)
+    ss, se = [], []
+    for a in range(1, R):
+        for b in range(a + 1, R):
+            ss.append(a)
+            se.append(b)
+    quals = rand_quals(READS, 3)
+    compare_adaptor(oracle, oenc, enc, READS, quals, ADAPTOR, 5, 1, ss, se)
+    out = compare_adaptor(oracle, oenc, enc, READS, quals, ADAPTOR, 5, 1, [0], [R])
+    assert out[3][0].tolist() == [1] * len(READS)
+    assert out[4][0].tolist() == [len(r) for r in READS]
+
+
+@pytest.mark.parametrize("R", [1, 2, 3, 7, 15, 16, 17, 22, 30, 31, 32, 33, 50, 64, 65, 70, 100, 128, 129, 200, 300, 600])
+def test_random_differential(oracle, oenc, enc, R):
+    rng = np.random.default_rng(1000 + R)
+    from sarlacc_amd.mock import random_reads
+    adaptor = "".join(rng.choice(list(IUPAC if R % 2 else "ACGT"), R))
+    nreads = 37 if R < 100 else 9
+    reads, quals = random_reads(nreads, 0, 150 if R < 100 else 80, seed=R)
+    # plant noisy copies so that real alignments exist
+    core = "".join(c if c in "ACGT" else "A" for c in adaptor)
+    reads[1] = reads[1][:20] + core + reads[1][20:]
+    quals[1] = rand_quals([reads[1]], R)[0]
+    go, ge = ((5, 1), (2.5, 0.75), (1, 1), (20, 1))[R % 4]
+    nsec = min(R, 3)
+    ss = sorted(rng.integers(0, R, nsec).tolist())
+    se = [int(rng.integers(s, R) + 1) for s in ss]
+    compare_adaptor(oracle, oenc, enc, reads, quals, adaptor, go, ge, ss, se)
+
+
+def test_c2_shape_sample(oracle, oenc, enc):
+    # BASELINE config 2 shape on a sample the oracle finishes in seconds:
+    # 2 kb mock reads vs a 30-bp adaptor (9 fixed + 12 N + 9 fixed), go=5, ge=1
+    from sarlacc_amd.mock import mock_reads
+    a1 = "ACGATCAGC" + "N" * 12 + "GTCAGTCAG"
+    a2 = "CACACTGAGCAGCGACTAGACA"
+    sim = mock_reads(a1, a2, nmolecules=12, nreads=10, seqlen=2000 - 52, seed=1000)
+    reads, quals = sim["reads"].to_strings(), sim["quals"].to_strings()
+    out = compare_adaptor(oracle, oenc, enc, reads, quals, a1, 5, 1, [9], [21])
+    fwd = ~sim["flipped"]
+    assert (out[0][fwd] > 15).mean() > 0.9  # the planted adaptor is found on forward reads
+    assert (out[1][fwd] <= 3).mean() > 0.8
+
+
+def test_ragged_and_long(oracle, oenc, enc):
+    from sarlacc_amd.mock import random_reads
+    reads, quals = random_reads(23, 0, 3000, seed=5)
+    reads[3] = ""
+    quals[3] = ""
+    compare_adaptor(oracle, oenc, enc, reads, quals, "ACGTNNNNACGTRYACGT", 5, 1, [4], [8])
+
+
+def test_int32_directions_for_very_long_reads(oracle, oenc, enc):
+    from sarlacc_amd.mock import random_reads
+    reads, quals = random_reads(3, 33000, 34000, seed=9)
+    compare_adaptor(oracle, oenc, enc, reads, quals, "ACGTACGTAC", 5, 1, [2], [5])
+
+
+def test_quality_extremes(oracle, oenc, enc):
+    # '!' (error prob 1: match score -inf) and '~'
+    reads = ["ACGTACGTACGT", "ACGTACGTACGT", "ACGTACGTACGT"]
+    quals = ["!" * 12, "~" * 12, "!~" * 6]
+    compare_adaptor(oracle, oenc, enc, reads, quals, "ACGTACGT", 5, 1, [2], [4])
+
+
+def test_barcode_align_global(oracle, oenc, enc):
+    from sarlacc_amd import calls
+    from sarlacc_amd.mock import random_reads
+    for R, seed in ((12, 1), (8, 2), (40, 3), (0, 4)):
+        rng = np.random.default_rng(seed)
+        ref = "".join(rng.choice(list("ACGT"), R))
+        reads, quals = random_reads(50, 0, 30, seed=seed)
+        a = oracle.barcode_align(reads, quals, oenc, 5, 1, ref)
+        b = calls.barcode_align(reads, quals, enc, 5, 1, ref)
+        assert np.array_equal(bits(a), bits(b))
+
+
+def test_general_align(oracle, oenc, enc):
+    from sarlacc_amd import calls
+    from sarlacc_amd.mock import random_reads
+    rng = np.random.default_rng(32000)
+    for trial, go in enumerate((5, 20, 1)):
+        ref = "".join(rng.choice(list("ACGT"), 50))
+        reads, quals = random_reads(40, 20, 80, seed=32000 + trial, qual_lo=43, qual_hi=83)
+        reads.append("")
+        quals.append("")
+        a = oracle.general_align(reads, quals, oenc, go, 1, ref)
+        b = calls.general_align(reads, quals, enc, go, 1, ref, False)
+        assert np.array_equal(bits(a[0]), bits(b[0]))
+        assert np.array_equal(a[1], b[1])
+        assert a[2] == b[2] and a[3] == b[3]
+        for r, q, read in zip(b[2], b[3], reads):
+            assert len(r) == len(q)
+            assert r.replace("-", "") == ref and q.replace("-", "") == read
+        c = calls.general_align(reads, quals, enc, go, 1, ref, True)
+        assert np.array_equal(a[1], c[1]) and c[2] == [] and c[3] == []
+    # batch == one at a time (test-general-align.R:81-93)
+    one = [calls.general_align([r], [q], enc, 5, 1, ref, False) for r, q in zip(reads[:5], quals[:5])]
+    many = calls.general_align(reads[:5], quals[:5], enc, 5, 1, ref, False)
+    assert [o[2][0] for o in one] == many[2]
+    # empty reference
+    a = oracle.general_align(reads[:4], quals[:4], oenc, 5, 1, "")
+    b = calls.general_align(reads[:4], quals[:4], enc, 5, 1, "", False)
+    assert np.array_equal(bits(a[0]), bits(b[0])) and a[2] == b[2] and a[3] == b[3] and np.array_equal(a[1], b[1])
+
+
+def test_error_behaviour(oracle, oenc, enc):
+    from sarlacc_amd import SarlaccError, calls
+    with pytest.raises(SarlaccError, match="same length"):
+        calls.adaptor_align(["ACGT"], ["III"], enc, 5, 1, ADAPTOR, [], [])
+    with pytest.raises(SarlaccError, match="same length"):
+        calls.adaptor_align(["ACGT"], ["IIII", "I"], enc, 5, 1, ADAPTOR, [], [])
+    with pytest.raises(SarlaccError, match="unrecognized base in reference sequence"):
+        calls.adaptor_align(["ACGT"], ["IIII"], enc, 5, 1, "ACXT", [], [])
+    # no cell is evaluated for an empty read, so a bad adaptor character is not noticed
+    out = calls.adaptor_align([""], [""], enc, 5, 1, "ACXT", [], [])
+    assert out[0][0] == oracle.adaptor_align([""], [""], oenc, 5, 1, "ACXT")[0][0]
+    with pytest.raises(SarlaccError, match="quality cannot be lower than smallest encoded value"):
+        calls.adaptor_align(["ACGT"], ["II I"], enc, 5, 1, ADAPTOR, [], [])
+    with pytest.raises(SarlaccError, match="gap opening penalty should be a numeric scalar"):
+        calls.adaptor_align(["ACGT"], ["IIII"], enc, [5, 6], 1, ADAPTOR, [], [])
+    with pytest.raises(SarlaccError, match="section starts and ends should have the same length"):
+        calls.adaptor_align(["ACGT"], ["IIII"], enc, 5, 1, ADAPTOR, [1, 2], [3])
+    import sarlacc_amd
+    bad = sarlacc_amd.Encoding([0.1, 0.2], b"!\"")
+    with pytest.raises(SarlaccError, match="error probabilities should decrease"):
+        calls.adaptor_align(["ACGT"], ["!!!!"], bad, 5, 1, ADAPTOR, [], [])
