@@ -128,3 +128,71 @@ def general_align(inputseq, inputqual, encoding, gapopen, gapext, reference, edi
     if only:
         return [scores, edits, [], []]
     return [scores, edits, StringSet(ar, ao).to_strings(), StringSet(aq, ao).to_strings()]
+
+
+# ---------------------------------------------------------------------------
+def _aln_list(alignments):
+    """list of alignments (each a list of equal-width strings) -> flat rows + row ranges"""
+    rows = []
+    grp = np.zeros(len(alignments) + 1, dtype=np.int64)
+    for k, a in enumerate(alignments):
+        a = a.to_strings() if isinstance(a, StringSet) else list(a)
+        rows.extend(a)
+        grp[k + 1] = grp[k] + len(a)
+    return StringSet.from_strings(rows), grp
+
+
+def _consensus(alignments, min_cov, pseudo, qualities, encoding, want_lerr):
+    s, grp = _aln_list(alignments)
+    ng = len(alignments)
+    cap = max(s.total, 1)
+    cons = np.zeros(cap, np.uint8)
+    phred = np.zeros(cap, np.uint8)
+    coff = np.zeros(ng + 1, np.int64)
+    lerr = np.zeros(cap, np.float64) if want_lerr else None
+    if qualities is None:
+        check(_lib.lib().sarlacc_create_consensus_basic_loop(
+            ptr(s.chars), ptr(s.off), ptr(grp), C.c_int64(ng), C.c_double(min_cov), C.c_double(pseudo),
+            ptr(cons), ptr(phred), ptr(coff), ptr(lerr)))
+    else:
+        q, qgrp = _aln_list(qualities)
+        enc = as_encoding(encoding)
+        check(_lib.lib().sarlacc_create_consensus_quality_loop(
+            ptr(s.chars), ptr(s.off), ptr(grp), C.c_int64(ng), ptr(q.chars), ptr(q.off), ptr(qgrp),
+            C.c_double(min_cov), ptr(enc.errors), enc.names, len(enc),
+            ptr(cons), ptr(phred), ptr(coff), ptr(lerr)))
+    cs = StringSet(cons, coff).to_strings()
+    ps = StringSet(phred, coff).to_strings()
+    return cs, ps, (lerr, coff)
+
+
+def create_consensus_basic(alignments, min_cov, pseudo_count):
+    """.Call create_consensus_basic (src/create_consensus.cpp:137-148): [consensus, log errors]."""
+    mc = _numeric(min_cov, "minimum coverage")
+    pc = _numeric(pseudo_count, "pseudo count")
+    cs, _, (lerr, coff) = _consensus([alignments], mc, pc, None, None, True)
+    return [cs[0], lerr[:coff[1]].copy()]
+
+
+def create_consensus_basic_loop(alignments, min_cov, pseudo_count):
+    """.Call create_consensus_basic_loop (src/create_consensus.cpp:150-170): [consensus strings, Phred strings]."""
+    mc = _numeric(min_cov, "minimum coverage")
+    pc = _numeric(pseudo_count, "pseudo count")
+    cs, ps, _ = _consensus(alignments, mc, pc, None, None, False)
+    return [cs, ps]
+
+
+def create_consensus_quality(alignments, min_cov, qualities, encoding):
+    """.Call create_consensus_quality (src/create_consensus.cpp:274-285)."""
+    mc = _numeric(min_cov, "minimum coverage")
+    cs, _, (lerr, coff) = _consensus([alignments], mc, 0.0, [qualities], encoding, True)
+    return [cs[0], lerr[:coff[1]].copy()]
+
+
+def create_consensus_quality_loop(alignments, min_cov, qualities, encoding):
+    """.Call create_consensus_quality_loop (src/create_consensus.cpp:287-308)."""
+    mc = _numeric(min_cov, "minimum coverage")
+    if len(qualities) != len(alignments):
+        raise SarlaccError("sarlacc_amd: alignments and qualities lists differ in length")
+    cs, ps, _ = _consensus(alignments, mc, 0.0, qualities, encoding, False)
+    return [cs, ps]

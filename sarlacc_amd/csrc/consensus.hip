@@ -1,0 +1,406 @@
+// consensus.hip -- per-column consensus vote over per-group alignments on gfx950.
+//
+// Replaces internal_create_consensus_basic / _quality and their _loop wrappers
+// (/root/reference/src/create_consensus.cpp:61-135, :178-272, :150-170, :287-308)
+// and errorsToString (:18-32).
+//
+// Mapping: one wavefront per alignment (group); lanes own 64 consecutive columns,
+// rows are streamed in the reference's row order so every per-column fp64 sum adds
+// the same terms in the same order (bit-identical sums => identical base calls).
+// The position of a base inside its ungapped quality string is a running prefix
+// count of non-gap characters: per 64-column chunk it is ballot + popcount, the
+// per-row carry sits in LDS.  Kept columns are compacted with the same trick.
+// log1p(-e) / log(e/3) come from host-built tables (host libm); the device only
+// evaluates transcendentals for the per-column error (log1p / exp), and columns
+// whose Phred value falls within 1e-9 of a rounding boundary are re-evaluated on
+// the host with the host libm so the emitted Phred characters never depend on
+// device-vs-host libm differences.
+//
+// This is the one streaming, HBM-bound stage of the path: 2 B in per alignment
+// cell (gapped base + quality), 2 B out per kept column.
+#include "common.hpp"
+
+#include "../../include/sarlacc_amd.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace sarlacc {
+
+struct ConsArgs {
+    const uint8_t* aln;
+    const int64_t* aln_off;    // per row
+    const int64_t* grp_rows;   // [ngroups+1]
+    long long ngroups;
+    const uint8_t* qual;       // quality mode only
+    const int64_t* qual_off;   // per row (same row numbering as aln)
+    const double* right;       // [navail] log1p(-e)
+    const double* wrong;       // [navail] log(e/3)
+    int qoffset, navail, max_rows;
+    double mincov, pseudo, ln10;
+    const int64_t* out_off;    // [ngroups] start of the group's output (= offset of its first row)
+    uint8_t* cons;
+    uint8_t* phred;
+    double* lerr;              // optional
+    int32_t* cons_len;         // [ngroups]
+    int8_t* row_status;        // quality: 0 ok, 1 bad quality char, 2 shorter, 3 longer
+    unsigned long long* first_bad_char;  // basic: min byte index of an unknown character
+    // near-boundary columns to be resolved on the host
+    int* fix_count;
+    int fix_cap;
+    long long* fix_pos;        // output byte index
+    double* fix_val;           // 4 per entry: sorted scores (quality) or {max,total,0,0} (basic)
+};
+
+__device__ __forceinline__ double dev_log1pexp(double x) {
+    // R nmath log1pexp: x <= 18 -> log1p(exp x); 18 < x <= 33.3 -> x + exp(-x); else x
+    if (x <= 18.) return log1p(exp(x));
+    if (x > 33.3) return x;
+    return x + exp(-x);
+}
+
+template <bool QUALITY>
+__global__ void __launch_bounds__(64) k_consensus(const ConsArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* s_right = reinterpret_cast<double*>(smem);
+    double* s_wrong = s_right + (QUALITY ? A.navail : 0);
+    int* s_pos = reinterpret_cast<int*>(s_wrong + (QUALITY ? A.navail : 0));
+    int* s_bad = s_pos + A.max_rows;
+
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (QUALITY)
+        for (int x = lane; x < A.navail; x += 64) { s_right[x] = A.right[x]; s_wrong[x] = A.wrong[x]; }
+    __syncthreads();
+
+    for (long long g = blockIdx.x; g < A.ngroups; g += gridDim.x) {
+        const long long row0 = A.grp_rows[g];
+        const int nrows = static_cast<int>(A.grp_rows[g + 1] - row0);
+        if (nrows == 0) {
+            if (lane == 0) A.cons_len[g] = 0;
+            continue;
+        }
+        const long long W = A.aln_off[row0 + 1] - A.aln_off[row0];
+        const double thresh = static_cast<double>(nrows) * A.mincov;
+        const long long obase = A.out_off[g];
+        for (int r = lane; r < nrows; r += 64) { s_pos[r] = 0; s_bad[r] = 0; }
+        int outpos = 0;
+
+        for (long long c0 = 0; c0 < W; c0 += 64) {
+            const long long col = c0 + lane;
+            const bool active = col < W;
+            double sA = 0, sC = 0, sG = 0, sT = 0;
+            int inc = 0;
+            for (int r = 0; r < nrows; ++r) {
+                const long long roff = A.aln_off[row0 + r];
+                const uint8_t ch = active ? A.aln[roff + col] : static_cast<uint8_t>('-');
+                const bool nongap = ch != '-';
+                const unsigned long long mask = __ballot(nongap);
+                int p = 0;
+                if (QUALITY) {
+                    p = s_pos[r] + __popcll(mask & lt);
+                    if (lane == 0) s_pos[r] += __popcll(mask);
+                }
+                if (nongap) {
+                    ++inc;
+                    if (QUALITY) {
+                        const long long qo = A.qual_off[row0 + r];
+                        const int qlen = static_cast<int>(A.qual_off[row0 + r + 1] - qo);
+                        if (ch != 'N' && p < qlen) {
+                            int qi = static_cast<int>(static_cast<signed char>(A.qual[qo + p])) - A.qoffset;
+                            if (qi < 0) { s_bad[r] = 1; qi = 0; }
+                            if (qi >= A.navail) qi = A.navail - 1;
+                            const double right = s_right[qi], wrong = s_wrong[qi];
+                            sA += (ch == 'A') ? right : wrong;
+                            sC += (ch == 'C') ? right : wrong;
+                            sG += (ch == 'G') ? right : wrong;
+                            sT += (ch == 'T') ? right : wrong;
+                        }
+                    } else if (ch != 'N') {
+                        if (ch == 'A') sA += 1;
+                        else if (ch == 'C') sC += 1;
+                        else if (ch == 'G') sG += 1;
+                        else if (ch == 'T') sT += 1;
+                        else atomicMin(A.first_bad_char, static_cast<unsigned long long>(roff + col));
+                    }
+                }
+            }
+            const bool keep = active && !(inc < thresh);
+            // first maximum in A,C,G,T order (std::max_element)
+            int best = 0;
+            double bv = sA;
+            if (sC > bv) { bv = sC; best = 1; }
+            if (sG > bv) { bv = sG; best = 2; }
+            if (sT > bv) { bv = sT; best = 3; }
+            double le;
+            double f0, f1, f2 = 0, f3 = 0;
+            if (QUALITY) {
+                // ascending sort of the four log-probabilities, then running log-sum-exp
+                double a = sA, b = sC, c = sG, d = sT, t;
+                if (a > b) { t = a; a = b; b = t; }
+                if (c > d) { t = c; c = d; d = t; }
+                if (a > c) { t = a; a = c; c = t; }
+                if (b > d) { t = b; b = d; d = t; }
+                if (b > c) { t = b; b = c; c = t; }
+                double denom = a;
+                denom += dev_log1pexp(b - denom);
+                denom += dev_log1pexp(c - denom);
+                const double err3 = denom;
+                denom += dev_log1pexp(d - denom);
+                le = err3 - denom;
+                f0 = a; f1 = b; f2 = c; f3 = d;
+            } else {
+                int total = 0;
+                total = static_cast<int>(total + sA);
+                total = static_cast<int>(total + sC);
+                total = static_cast<int>(total + sG);
+                total = static_cast<int>(total + sT);
+                const double p = (bv + A.pseudo / 4) / (static_cast<double>(total) + A.pseudo);
+                le = log1p(-p);
+                f0 = bv; f1 = static_cast<double>(total);
+            }
+            const double x = -10 * le / A.ln10;
+            double qv = round(x);
+            if (qv > 93.0) qv = 93.0;
+            const double frac = x - floor(x);
+            const bool near = keep && x < 93.4 && fabs(frac - 0.5) < 1e-9;
+
+            const unsigned long long kmask = __ballot(keep);
+            const int o = outpos + __popcll(kmask & lt);
+            if (keep) {
+                A.cons[obase + o] = "ACGT"[best];
+                A.phred[obase + o] = static_cast<uint8_t>(static_cast<int>(qv) + 33);
+                if (A.lerr) A.lerr[obase + o] = le;
+                if (near) {
+                    const int slot = atomicAdd(A.fix_count, 1);
+                    if (slot < A.fix_cap) {
+                        A.fix_pos[slot] = obase + o;
+                        A.fix_val[4 * slot + 0] = f0; A.fix_val[4 * slot + 1] = f1;
+                        A.fix_val[4 * slot + 2] = f2; A.fix_val[4 * slot + 3] = f3;
+                    }
+                }
+            }
+            outpos += __popcll(kmask);
+        }
+        if (lane == 0) A.cons_len[g] = outpos;
+        if (QUALITY) {
+            for (int r = lane; r < nrows; r += 64) {
+                const int qlen = static_cast<int>(A.qual_off[row0 + r + 1] - A.qual_off[row0 + r]);
+                const int used = s_pos[r];
+                A.row_status[row0 + r] = s_bad[r] ? 1 : (used == qlen ? 0 : (used > qlen ? 2 : 3));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+static double host_log1pexp(double x) {
+    if (x <= 18.) return std::log1p(std::exp(x));
+    if (x > 33.3) return x;
+    return x + std::exp(-x);
+}
+
+static char phred_char(double le) {
+    const double q = std::min(std::round(-10 * le / std::log(10)), 93.0);
+    return static_cast<char>(static_cast<int>(q) + 33);
+}
+
+static int run_consensus(bool quality, const char* aln, const int64_t* aln_off, const int64_t* grp_rows,
+                         int64_t ngroups, const char* qual, const int64_t* qual_off, const int64_t* qgrp_rows,
+                         double min_cov, double pseudo, const double* enc_errors, const char* enc_names, int enc_n,
+                         char* cons, char* phred, int64_t* cons_off, double* lerr) {
+    if (ngroups < 0) return fail("sarlacc_amd: negative number of alignments");
+    if (quality) SL_TRY(check_encoding(enc_errors, enc_names, enc_n));
+    cons_off[0] = 0;
+    if (ngroups == 0) return 0;
+    const int64_t nrows_total = grp_rows[ngroups];
+
+    // host-side structural checks, in the reference's order (group by group):
+    // equal row widths (src/DNA_input.cpp:90-104), then matching entry counts (:186-190)
+    int64_t struct_err_group = -1;
+    int struct_err_kind = 0;
+    int max_rows = 1;
+    for (int64_t g = 0; g < ngroups && struct_err_group < 0; ++g) {
+        const int64_t r0 = grp_rows[g], r1 = grp_rows[g + 1];
+        max_rows = static_cast<int>(std::max<int64_t>(max_rows, r1 - r0));
+        for (int64_t r = r0 + 1; r < r1; ++r)
+            if (aln_off[r + 1] - aln_off[r] != aln_off[r0 + 1] - aln_off[r0]) { struct_err_group = g; struct_err_kind = 1; break; }
+        if (struct_err_group < 0 && quality && (qgrp_rows[g + 1] - qgrp_rows[g]) != (r1 - r0)) {
+            struct_err_group = g;
+            struct_err_kind = 2;
+        }
+    }
+    // Only groups before the first structural error are evaluated on the device.
+    const int64_t ng_eval = struct_err_group >= 0 ? struct_err_group : ngroups;
+    const int64_t rows_eval = grp_rows[ng_eval];
+    if (quality)
+        for (int64_t g = 0; g < ng_eval; ++g)
+            if (qgrp_rows[g] != grp_rows[g]) return fail("sarlacc_amd: alignment and quality row numbering differ");
+
+    SL_TRY(ensure_device());
+    hipStream_t s = nullptr;
+    Context& c = ctx();
+    const int64_t total = aln_off[nrows_total] - aln_off[0];
+    const int64_t base = aln_off[0];
+
+    std::vector<int64_t> rel(static_cast<size_t>(nrows_total) + 1), out_off(static_cast<size_t>(std::max<int64_t>(ngroups, 1)));
+    for (int64_t r = 0; r <= nrows_total; ++r) rel[r] = aln_off[r] - base;
+    for (int64_t g = 0; g < ngroups; ++g) out_off[g] = rel[grp_rows[g]];
+
+    ConsArgs a{};
+    uint8_t* d_aln; int64_t* d_aoff; int64_t* d_grows; int64_t* d_ooff;
+    SL_TRY(upload("cons.aln", reinterpret_cast<const uint8_t*>(aln) + base, static_cast<size_t>(total), &d_aln, s));
+    SL_TRY(upload("cons.aoff", rel.data(), rel.size(), &d_aoff, s));
+    SL_TRY(upload("cons.grows", grp_rows, static_cast<size_t>(ngroups) + 1, &d_grows, s));
+    SL_TRY(upload("cons.ooff", out_off.data(), out_off.size(), &d_ooff, s));
+    a.aln = d_aln; a.aln_off = d_aoff; a.grp_rows = d_grows; a.ngroups = ng_eval; a.out_off = d_ooff;
+
+    std::vector<double> right, wrong;
+    if (quality) {
+        const int64_t qrows = qgrp_rows[ng_eval];
+        const int64_t qbase = qual_off[0];
+        const int64_t qtotal = qual_off[qrows] - qbase;
+        std::vector<int64_t> qrel(static_cast<size_t>(qrows) + 1);
+        for (int64_t r = 0; r <= qrows; ++r) qrel[r] = qual_off[r] - qbase;
+        uint8_t* d_q; int64_t* d_qoff; double* d_r; double* d_w;
+        SL_TRY(upload("cons.qual", reinterpret_cast<const uint8_t*>(qual) + qbase, static_cast<size_t>(qtotal), &d_q, s));
+        SL_TRY(upload("cons.qoff", qrel.data(), qrel.size(), &d_qoff, s));
+        right.resize(enc_n);
+        wrong.resize(enc_n);
+        for (int k = 0; k < enc_n; ++k) {  // (src/create_consensus.cpp:14,:218-226)
+            double e = enc_errors[k];
+            if (e > 0.99999999) e = 0.99999999;
+            else if (e < 0.00000001) e = 0.00000001;
+            right[k] = std::log1p(-e);
+            wrong[k] = std::log(e / 3);
+        }
+        SL_TRY(upload("cons.right", right.data(), right.size(), &d_r, s));
+        SL_TRY(upload("cons.wrong", wrong.data(), wrong.size(), &d_w, s));
+        a.qual = d_q; a.qual_off = d_qoff; a.right = d_r; a.wrong = d_w;
+        a.qoffset = static_cast<int>(enc_names[0]); a.navail = enc_n;
+    }
+    a.mincov = min_cov; a.pseudo = pseudo; a.ln10 = std::log(10); a.max_rows = max_rows;
+
+    uint8_t* d_cons; uint8_t* d_phred; double* d_lerr = nullptr; int32_t* d_len; int8_t* d_status;
+    unsigned long long* d_badchar; int* d_fixn; long long* d_fixpos; double* d_fixval;
+    const int fix_cap = 4096;
+    SL_TRY(scratch("cons.out", static_cast<size_t>(total), &d_cons));
+    SL_TRY(scratch("cons.phred", static_cast<size_t>(total), &d_phred));
+    if (lerr) SL_TRY(scratch("cons.lerr", static_cast<size_t>(total), &d_lerr));
+    SL_TRY(scratch("cons.len", static_cast<size_t>(ngroups), &d_len));
+    SL_TRY(scratch("cons.status", static_cast<size_t>(std::max<int64_t>(rows_eval, 1)), &d_status));
+    SL_TRY(scratch("cons.badchar", 1, &d_badchar));
+    SL_TRY(scratch("cons.fixn", 1, &d_fixn));
+    SL_TRY(scratch("cons.fixpos", fix_cap, &d_fixpos));
+    SL_TRY(scratch("cons.fixval", 4 * fix_cap, &d_fixval));
+    SL_HIP(hipMemsetAsync(d_status, 0, static_cast<size_t>(std::max<int64_t>(rows_eval, 1)), s));
+    SL_HIP(hipMemsetAsync(d_badchar, 0xff, sizeof(unsigned long long), s));
+    SL_HIP(hipMemsetAsync(d_fixn, 0, sizeof(int), s));
+    a.cons = d_cons; a.phred = d_phred; a.lerr = d_lerr; a.cons_len = d_len; a.row_status = d_status;
+    a.first_bad_char = d_badchar; a.fix_count = d_fixn; a.fix_cap = fix_cap; a.fix_pos = d_fixpos; a.fix_val = d_fixval;
+
+    if (ng_eval > 0) {
+        const size_t lds = (quality ? 2 * sizeof(double) * enc_n : 0) + 2 * sizeof(int) * static_cast<size_t>(max_rows) + 16;
+        if (lds > 160 * 1024) return fail("sarlacc_amd: alignment with %d rows does not fit the consensus kernel", max_rows);
+        const int grid = static_cast<int>(std::min<int64_t>(ng_eval, static_cast<int64_t>(c.num_cu) * 32));
+        SL_HIP(hipEventRecord(c.ev_start, s));
+        if (quality) hipLaunchKernelGGL(k_consensus<true>, dim3(grid), dim3(64), lds, s, a);
+        else hipLaunchKernelGGL(k_consensus<false>, dim3(grid), dim3(64), lds, s, a);
+        SL_HIP(hipGetLastError());
+        SL_HIP(hipEventRecord(c.ev_stop, s));
+        c.timed = true;
+    }
+
+    // ---- results and error resolution ----
+    std::vector<int32_t> len(static_cast<size_t>(ngroups), 0);
+    std::vector<int8_t> status(static_cast<size_t>(std::max<int64_t>(rows_eval, 1)), 0);
+    unsigned long long badchar = ~0ull;
+    int fixn = 0;
+    if (ng_eval > 0) {
+        SL_HIP(hipMemcpy(len.data(), d_len, sizeof(int32_t) * static_cast<size_t>(ng_eval), hipMemcpyDeviceToHost));
+        SL_HIP(hipMemcpy(status.data(), d_status, static_cast<size_t>(std::max<int64_t>(rows_eval, 1)), hipMemcpyDeviceToHost));
+        SL_HIP(hipMemcpy(&badchar, d_badchar, sizeof badchar, hipMemcpyDeviceToHost));
+        SL_HIP(hipMemcpy(&fixn, d_fixn, sizeof fixn, hipMemcpyDeviceToHost));
+    }
+    // earliest error in the reference's processing order
+    if (!quality && badchar != ~0ull) {
+        char msg[96];
+        snprintf(msg, sizeof msg, "unknown character '%c' in alignment string", aln[base + static_cast<int64_t>(badchar)]);
+        return fail("%s", msg);
+    }
+    if (quality)
+        for (int64_t r = 0; r < rows_eval; ++r) {
+            if (status[r] == 1) return fail("quality cannot be lower than smallest encoded value");
+            if (status[r] == 2) return fail("quality vector is shorter than the alignment sequence");
+            if (status[r] == 3) return fail("quality vector is longer than the alignment sequence");
+        }
+    if (struct_err_kind == 1) return fail("alignment strings should have the same length");
+    if (struct_err_kind == 2) return fail("alignments and qualities have different numbers of entries");
+    if (fixn > fix_cap) return fail("sarlacc_amd: too many Phred values on a rounding boundary (%d)", fixn);
+
+    std::vector<uint8_t> hc(static_cast<size_t>(total)), hp(static_cast<size_t>(total));
+    std::vector<double> hl;
+    if (total) {
+        SL_HIP(hipMemcpy(hc.data(), d_cons, static_cast<size_t>(total), hipMemcpyDeviceToHost));
+        SL_HIP(hipMemcpy(hp.data(), d_phred, static_cast<size_t>(total), hipMemcpyDeviceToHost));
+        if (lerr) {
+            hl.resize(static_cast<size_t>(total));
+            SL_HIP(hipMemcpy(hl.data(), d_lerr, sizeof(double) * static_cast<size_t>(total), hipMemcpyDeviceToHost));
+        }
+    }
+    if (fixn > 0) {  // exact host-libm re-evaluation of boundary columns
+        std::vector<long long> fp(static_cast<size_t>(fixn));
+        std::vector<double> fv(static_cast<size_t>(fixn) * 4);
+        SL_HIP(hipMemcpy(fp.data(), d_fixpos, sizeof(long long) * fp.size(), hipMemcpyDeviceToHost));
+        SL_HIP(hipMemcpy(fv.data(), d_fixval, sizeof(double) * fv.size(), hipMemcpyDeviceToHost));
+        for (int k = 0; k < fixn; ++k) {
+            double le;
+            if (quality) {
+                double denom = fv[4 * k];
+                denom += host_log1pexp(fv[4 * k + 1] - denom);
+                denom += host_log1pexp(fv[4 * k + 2] - denom);
+                const double err3 = denom;
+                denom += host_log1pexp(fv[4 * k + 3] - denom);
+                le = err3 - denom;
+            } else {
+                le = std::log1p(-((fv[4 * k] + pseudo / 4) / (fv[4 * k + 1] + pseudo)));
+            }
+            hp[static_cast<size_t>(fp[k])] = static_cast<uint8_t>(phred_char(le));
+            if (lerr) hl[static_cast<size_t>(fp[k])] = le;
+        }
+    }
+    int64_t used = 0;
+    for (int64_t g = 0; g < ngroups; ++g) {
+        const int64_t ob = out_off[g];
+        std::memcpy(cons + used, hc.data() + ob, static_cast<size_t>(len[g]));
+        std::memcpy(phred + used, hp.data() + ob, static_cast<size_t>(len[g]));
+        if (lerr) std::memcpy(lerr + used, hl.data() + ob, sizeof(double) * static_cast<size_t>(len[g]));
+        used += len[g];
+        cons_off[g + 1] = used;
+    }
+    return 0;
+}
+
+}  // namespace sarlacc
+
+using namespace sarlacc;
+
+extern "C" {
+
+int sarlacc_create_consensus_basic_loop(const char* aln, const int64_t* aln_off, const int64_t* grp_rows,
+                                        int64_t ngroups, double min_cov, double pseudo_count, char* cons,
+                                        char* phred, int64_t* cons_off, double* lerr) {
+    return run_consensus(false, aln, aln_off, grp_rows, ngroups, nullptr, nullptr, nullptr, min_cov, pseudo_count,
+                         nullptr, nullptr, 0, cons, phred, cons_off, lerr);
+}
+
+int sarlacc_create_consensus_quality_loop(const char* aln, const int64_t* aln_off, const int64_t* grp_rows,
+                                          int64_t ngroups, const char* qual, const int64_t* qual_off,
+                                          const int64_t* qgrp_rows, double min_cov, const double* enc_errors,
+                                          const char* enc_names, int enc_n, char* cons, char* phred,
+                                          int64_t* cons_off, double* lerr) {
+    return run_consensus(true, aln, aln_off, grp_rows, ngroups, qual, qual_off, qgrp_rows, min_cov, 0.0, enc_errors,
+                         enc_names, enc_n, cons, phred, cons_off, lerr);
+}
+}
