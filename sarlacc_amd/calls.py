@@ -196,3 +196,81 @@ def create_consensus_quality_loop(alignments, min_cov, qualities, encoding):
         raise SarlaccError("sarlacc_amd: alignments and qualities lists differ in length")
     cs, ps, _ = _consensus(alignments, mc, 0.0, qualities, encoding, False)
     return [cs, ps]
+
+
+# ---------------------------------------------------------------------------
+def mask_bad_bases(sequences, qualities, encoding, threshold):
+    """.Call mask_bad_bases (src/mask_bad_bases.cpp:10-52): base -> 'N' where error > threshold."""
+    s, q = _seq_qual(sequences, qualities)
+    enc = as_encoding(encoding)
+    thr = _numeric(threshold, "quality threshold")
+    out = np.zeros(max(s.total, 1), np.uint8)
+    check(_lib.lib().sarlacc_mask_bad_bases(
+        ptr(s.chars), ptr(s.off), ptr(q.chars), ptr(q.off), C.c_int64(len(s)),
+        ptr(enc.errors), enc.names, len(enc), C.c_double(thr), ptr(out)))
+    return StringSet(out, s.off.copy()).to_strings()
+
+
+def compute_lev_masked(sequences):
+    """.Call compute_lev_masked (src/compute_lev_masked.cpp:13-64): lower triangle, R 'dist' order."""
+    s = StringSet.from_strings(sequences)
+    n = len(s)
+    out = np.zeros(max(n * (n - 1) // 2, 1), np.float64)
+    check(_lib.lib().sarlacc_compute_lev_masked(ptr(s.chars), ptr(s.off), C.c_int64(n), ptr(out)))
+    return out[: n * (n - 1) // 2]
+
+
+def fast_levdist_test(sequences, limit, sorted=True):
+    """.Call fast_levdist_test (src/sorted_trie.cpp:304-337): per sequence the 1-based
+    indices of everything within `limit`, in the reference's trie order.  `sorted` only
+    changes the processing order inside the reference and never its output."""
+    s = StringSet.from_strings(sequences)
+    lim = _integer(limit, "limit")
+    _scalar(sorted, "sort specification", "a logical scalar")
+    n = len(s)
+    off = np.zeros(n + 1, np.int64)
+    need = C.c_int64(0)
+    cap = max(32 * n, 1024)
+    while True:
+        nbr = np.zeros(cap, np.int32)
+        check(_lib.lib().sarlacc_fast_levdist_test(ptr(s.chars), ptr(s.off), C.c_int64(n), lim,
+                                                   ptr(off), ptr(nbr), C.c_int64(cap), C.byref(need)))
+        if need.value <= cap:
+            break
+        cap = need.value
+    return lists_from_csr(off, nbr)
+
+
+def cluster_umis_test(links):
+    """.Call cluster_umis_test (src/cluster_umis_test.cpp:8-30): list of 1-based link vectors
+    -> list of 1-based clusters in the reference's output order."""
+    off, vals = csr_from_lists(links)
+    n = len(links)
+    ncl = C.c_int64(0)
+    co = np.zeros(n + 2, np.int64)
+    cl = np.zeros(max(n, 1), np.int32)
+    check(_lib.lib().sarlacc_cluster_umis_test(ptr(off), ptr(vals), C.c_int64(n), C.byref(ncl), ptr(co), ptr(cl)))
+    return lists_from_csr(co, cl, ncl.value)
+
+
+def umi_group(umi1, thresh1, umi2, thresh2, pregroup):
+    """.Call umi_group (src/umi_group.cpp:14-116) + the unlist(recursive=FALSE) of
+    R/umiGroup.R:22: flattened list of clusters of 1-based read ids."""
+    s1 = StringSet.from_strings(umi1)
+    t1 = _integer(thresh1, "threshold 1")
+    s2 = None
+    if umi2 is not None:
+        s2 = StringSet.from_strings(umi2)
+        if len(s2) != len(s1):
+            raise SarlaccError("'umi1' and 'umi2' should have the same length")
+    t2 = _integer(thresh2, "threshold 2")
+    goff, gvals = csr_from_lists(pregroup)
+    total = int(goff[-1])
+    ncl = C.c_int64(0)
+    co = np.zeros(total + 2, np.int64)
+    cl = np.zeros(max(total, 1), np.int32)
+    check(_lib.lib().sarlacc_umi_group(
+        ptr(s1.chars), ptr(s1.off), ptr(s2.chars) if s2 is not None else None,
+        ptr(s2.off) if s2 is not None else None, C.c_int64(len(s1)), t1, t2,
+        ptr(goff), ptr(gvals), C.c_int64(len(pregroup)), C.byref(ncl), ptr(co), ptr(cl)))
+    return lists_from_csr(co, cl, ncl.value)

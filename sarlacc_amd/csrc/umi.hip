@@ -1,0 +1,901 @@
+// umi.hip -- masked-Levenshtein neighbour search and greedy UMI clustering on gfx950.
+//
+// Replaces, for the umiGroup stage of the reference:
+//   sorted_trie            /root/reference/src/sorted_trie.cpp:107-278 (thresholded search)
+//   compute_lev_masked     src/compute_lev_masked.cpp:13-64            (dense distances)
+//   cluster_umis           src/cluster_umis.cpp:7-112                  (greedy clustering)
+//   umi_group              src/umi_group.cpp:14-116                    (per pre-group driver)
+//
+// Design (DESIGN.md "UMI stage"):
+//   * The trie returns exactly { j : d2(i,j) <= 2*limit } listed in the order
+//     A<C<G<T<N, shorter prefix first, ties by input index (SURVEY App.B Q11).  We
+//     get the same lists from an all-pairs tile kernel over the UMIs sorted in that
+//     order: 2-bit packed bases + N bit-mask per UMI, one thread per (row, tile),
+//     columns broadcast from LDS, a composition / length lower bound rejecting most
+//     pairs, then an exact banded DP in registers (band = limit, costs x2 as in
+//     src/sorted_trie.cpp:13-21).  Only the upper triangle is evaluated; directed
+//     adjacency is a radix sort of (row << 32 | column-rank) keys.
+//   * The greedy clustering is sequential by definition; it is evaluated exactly,
+//     in parallel rounds: a node whose (remaining, index) key is the maximum within
+//     two hops cannot be affected by any earlier pick, so all such nodes are picked
+//     in the same round.  The pick sequence of the reference is recovered by sorting
+//     the picks by their key (descending), solos first (SURVEY section 0, App.B Q12).
+#include <cstdlib>
+#include <cstring>
+
+#include "common.hpp"
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/sarlacc_amd.h"
+
+#include <algorithm>
+#include <limits>
+#include <string>
+
+namespace sarlacc {
+
+constexpr int UMI_MAXLEN = 32;
+constexpr int TILE = 256;
+constexpr int INF_D = 1 << 20;
+
+// ---------------------------------------------------------------------------
+// encoding
+
+struct UmiArrays {
+    unsigned long long* code;   // 2 bits per base (N stored as 0)
+    uint32_t* nmask;            // bit i set: base i is N
+    uint32_t* comp;             // counts of A,C,G,T, one byte each
+    uint32_t* meta;             // len | nN << 8
+};
+
+// members: optional 1-based ids selecting the strings of one pre-group.
+__global__ void k_umi_encode(const uint8_t* chars, const int64_t* off, const int32_t* members, int n,
+                             UmiArrays U, unsigned long long* key_hi, unsigned long long* key_lo, int* idx,
+                             int* bad /* [0]: min local index with unsupported char, [1]: min index too long */) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const long long id = members ? static_cast<long long>(members[s]) - 1 : s;
+    const long long o = off[id];
+    const int len = static_cast<int>(off[id + 1] - o);
+    idx[s] = s;
+    if (len > UMI_MAXLEN) {
+        atomicMin(&bad[1], s);
+        U.code[s] = 0; U.nmask[s] = 0; U.comp[s] = 0; U.meta[s] = 0; key_hi[s] = 0; key_lo[s] = 0;
+        return;
+    }
+    unsigned long long code = 0, khi = 0, klo = 0;
+    uint32_t nmask = 0, comp = 0;
+    for (int i = 0; i < len; ++i) {
+        const uint8_t c = chars[o + i];
+        unsigned v;  // trie child order A,C,G,T,N (src/sorted_trie.cpp:10)
+        switch (c) {
+            case 'A': v = 0; break;
+            case 'C': v = 1; break;
+            case 'G': v = 2; break;
+            case 'T': v = 3; break;
+            case 'N': v = 4; break;
+            default: v = 4; atomicMin(&bad[0], s); break;
+        }
+        if (v == 4) nmask |= 1u << i;
+        else { code |= static_cast<unsigned long long>(v) << (2 * i); comp += 1u << (8 * v); }
+        const unsigned long long k = v + 1;  // 0 = past the end, so prefixes sort first
+        if (i < 21) khi |= k << (3 * (20 - i));
+        else klo |= k << (3 * (20 - (i - 21)));
+    }
+    U.code[s] = code; U.nmask[s] = nmask; U.comp[s] = comp;
+    U.meta[s] = static_cast<uint32_t>(len) | (static_cast<uint32_t>(__popc(nmask)) << 8);
+    key_hi[s] = khi; key_lo[s] = klo;
+}
+
+__global__ void k_gather_u64(const unsigned long long* src, const int* perm, unsigned long long* dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+
+__global__ void k_gather_umi(UmiArrays src, const int* perm, UmiArrays dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = perm[i];
+    dst.code[i] = src.code[p]; dst.nmask[i] = src.nmask[p]; dst.comp[i] = src.comp[p]; dst.meta[i] = src.meta[p];
+}
+
+// ---------------------------------------------------------------------------
+// distance
+
+// Doubled masked Levenshtein distance restricted to the band |i-j| <= K; returns
+// INF_D as soon as every cell of a row exceeds lim2 (src/sorted_trie.cpp:13-21 costs).
+template <int K>
+__device__ __forceinline__ int banded_lev2(unsigned long long ca, uint32_t na, int la,
+                                           unsigned long long cb, uint32_t nb, int lb, int lim2) {
+    constexpr int BW = 2 * K + 1;
+    int v[BW];
+#pragma unroll
+    for (int d = 0; d < BW; ++d) {
+        const int i = d - K;
+        v[d] = (i >= 0 && i <= la) ? 2 * i : INF_D;
+    }
+    for (int j = 1; j <= lb; ++j) {
+        const unsigned cbj = static_cast<unsigned>(cb >> (2 * (j - 1))) & 3u;
+        const unsigned nbj = (nb >> (j - 1)) & 1u;
+        int rowmin = INF_D, left = INF_D;
+#pragma unroll
+        for (int d = 0; d < BW; ++d) {
+            const int i = j + d - K;
+            int best = INF_D;
+            if (i >= 0 && i <= la) {
+                if (i == 0) {
+                    best = 2 * j;
+                } else {
+                    const unsigned nai = (na >> (i - 1)) & 1u;
+                    const unsigned cai = static_cast<unsigned>(ca >> (2 * (i - 1))) & 3u;
+                    const int sub = (nai | nbj) ? 1 : (cai == cbj ? 0 : 2);
+                    best = v[d] + sub;
+                    if (d + 1 < BW) best = min(best, v[d + 1] + 2);
+                    best = min(best, left + 2);
+                }
+            }
+            v[d] = best;
+            left = best;
+            rowmin = min(rowmin, best);
+        }
+        if (rowmin > lim2) return INF_D;
+    }
+    const int dd = la - lb + K;
+    int res = INF_D;
+#pragma unroll
+    for (int d = 0; d < BW; ++d) res = (d == dd) ? v[d] : res;
+    return res;
+}
+
+struct PairArgs {
+    UmiArrays U;                    // in trie (rank) order
+    int n;
+    int lim2;
+    unsigned long long* edges;      // (rank_i << 32 | rank_j), rank_i < rank_j
+    unsigned long long* count;
+    unsigned long long cap;
+};
+
+template <int K>
+__global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bj < bi) return;
+    __shared__ unsigned long long s_code[TILE];
+    __shared__ uint32_t s_nmask[TILE], s_comp[TILE], s_meta[TILE];
+    const int t = threadIdx.x;
+    const int jcol = bj * TILE + t;
+    if (jcol < A.n) {
+        s_code[t] = A.U.code[jcol]; s_nmask[t] = A.U.nmask[jcol]; s_comp[t] = A.U.comp[jcol]; s_meta[t] = A.U.meta[jcol];
+    } else {
+        s_code[t] = 0; s_nmask[t] = 0; s_comp[t] = 0; s_meta[t] = 0xffffu;  // len 255: never matches
+    }
+    __syncthreads();
+    const int i = bi * TILE + t;
+    if (i >= A.n) return;
+    const unsigned long long ca = A.U.code[i];
+    const uint32_t na = A.U.nmask[i], compa = A.U.comp[i], ma = A.U.meta[i];
+    const int la = ma & 0xff, nNa = (ma >> 8) & 0xff;
+    const int jn = min(TILE, A.n - bj * TILE);
+    const int j0 = (bi == bj) ? t + 1 : 0;
+    for (int jj = j0; jj < jn; ++jj) {
+        const uint32_t mb = s_meta[jj];
+        const int lb = mb & 0xff, nNb = (mb >> 8) & 0xff;
+        const int dl = la > lb ? la - lb : lb - la;
+        if (2 * dl > A.lim2) continue;
+        // composition lower bound: every edit costs >= 1 and moves the 5-letter
+        // composition by <= 2 (<= its cost when no N is involved)
+        const int l1 = static_cast<int>(__builtin_amdgcn_sad_u8(compa, s_comp[jj], 0u)) + (nNa > nNb ? nNa - nNb : nNb - nNa);
+        const uint32_t nb = s_nmask[jj];
+        if (l1 > (((na | nb) != 0u) ? 2 * A.lim2 : A.lim2)) continue;
+        const int d = banded_lev2<K>(ca, na, la, s_code[jj], nb, lb, A.lim2);
+        if (d <= A.lim2) {
+            const unsigned long long slot = atomicAdd(A.count, 1ull);
+            if (slot < A.cap)
+                A.edges[slot] = (static_cast<unsigned long long>(i) << 32) | static_cast<unsigned>(bj * TILE + jj);
+        }
+    }
+}
+
+// Dense distances for compute_lev_masked: out in R 'dist' order (i-major lower triangle),
+// value = d2 / 2 (multiples of 0.5 are exact in fp64).
+__global__ void k_lev_dense(UmiArrays U, int n, double* out) {
+    const long long p = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    const long long npairs = static_cast<long long>(n) * (n - 1) / 2;
+    if (p >= npairs) return;
+    // invert p -> (i, j), i < j, i-major
+    long long i = static_cast<long long>((2.0 * n - 1 - sqrt((2.0 * n - 1) * (2.0 * n - 1) - 8.0 * p)) / 2);
+    auto start = [&](long long r) { return r * (2LL * n - r - 1) / 2; };
+    while (i > 0 && start(i) > p) --i;
+    while (start(i + 1) <= p) ++i;
+    const long long j = i + 1 + (p - start(i));
+    const uint32_t ma = U.meta[i], mb = U.meta[j];
+    const int d = banded_lev2<UMI_MAXLEN>(U.code[i], U.nmask[i], ma & 0xff, U.code[j], U.nmask[j], mb & 0xff, 4 * UMI_MAXLEN);
+    out[p] = static_cast<double>(d) / 2.0;
+}
+
+// ---------------------------------------------------------------------------
+// adjacency
+
+// undirected rank pairs -> directed keys (orig_row << 32 | column rank), plus self links
+__global__ void k_expand_edges(const unsigned long long* edges, unsigned long long m, const int* perm,
+                               unsigned long long* keys) {
+    const unsigned long long e = blockIdx.x * static_cast<unsigned long long>(blockDim.x) + threadIdx.x;
+    if (e >= m) return;
+    const unsigned ri = static_cast<unsigned>(edges[e] >> 32), rj = static_cast<unsigned>(edges[e]);
+    keys[2 * e] = (static_cast<unsigned long long>(perm[ri]) << 32) | rj;
+    keys[2 * e + 1] = (static_cast<unsigned long long>(perm[rj]) << 32) | ri;
+}
+
+__global__ void k_self_flags(UmiArrays U, int n, int lim2, int* flag) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) flag[r] = (static_cast<int>((U.meta[r] >> 8) & 0xff) <= lim2) ? 1 : 0;  // d2(x,x) = #N (App.B Q10)
+}
+
+__global__ void k_self_keys(const int* flag, const long long* pos, const int* perm, int n, unsigned long long* keys) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && flag[r]) keys[pos[r]] = (static_cast<unsigned long long>(perm[r]) << 32) | static_cast<unsigned>(r);
+}
+
+// sorted keys (row << 32 | x) -> row offsets
+__global__ void k_row_offsets(const unsigned long long* keys, long long nk, int n, long long* off) {
+    const long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    if (i > nk) return;
+    const long long prev = (i == 0) ? -1 : static_cast<long long>(keys[i - 1] >> 32);
+    const long long cur = (i == nk) ? n : static_cast<long long>(keys[i] >> 32);
+    for (long long r = prev + 1; r <= cur; ++r) off[r] = i;
+}
+
+__global__ void k_cols_from_keys(const unsigned long long* keys, long long nk, const int* perm, int* nbr) {
+    const long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    if (i < nk) nbr[i] = perm[static_cast<unsigned>(keys[i])];
+}
+
+// (row << 32 | rank) -> (row << 32 | orig col)
+__global__ void k_keys_to_orig(const unsigned long long* keys, long long nk, const int* perm, unsigned long long* out) {
+    const long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    if (i < nk) out[i] = (keys[i] & 0xffffffff00000000ull) | static_cast<unsigned>(perm[static_cast<unsigned>(keys[i])]);
+}
+
+// keep[i] = 1 if (row, perm2[rank]) of keys2[i] is present in the sorted set s1
+__global__ void k_intersect_flags(const unsigned long long* keys2, long long nk2, const int* perm2,
+                                  const unsigned long long* s1, long long n1, int* keep) {
+    const long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    if (i >= nk2) return;
+    const unsigned long long want = (keys2[i] & 0xffffffff00000000ull) | static_cast<unsigned>(perm2[static_cast<unsigned>(keys2[i])]);
+    long long lo = 0, hi = n1;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (s1[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    keep[i] = (lo < n1 && s1[lo] == want) ? 1 : 0;
+}
+
+__global__ void k_compact_keys(const unsigned long long* keys, const int* keep, const long long* pos, long long nk,
+                               unsigned long long* out) {
+    const long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    if (i < nk && keep[i]) out[pos[i]] = keys[i];
+}
+
+// ---------------------------------------------------------------------------
+// greedy clustering in exact parallel rounds
+
+struct ClusterState {
+    const long long* off;
+    const int* nbr;
+    int n;
+    int* remaining;
+    int* state;                 // 0 live, 1 solo, 2 clustered
+    int* mark;                  // round in which the node was clustered
+    unsigned long long* key;
+    unsigned long long* m1;
+    int* seed;                  // 1 if picked as a seed (any round)
+    unsigned long long* pickkey;
+    int* memb;                  // members of the cluster seeded at v, stored at off[v]..
+    int* csize;
+    int* err;                   // [0] min index with empty list, [1] min index bad solo, [2] missing self / asymmetric
+    int* live;                  // count of live pool nodes this round
+};
+
+__global__ void k_cl_init(ClusterState S, int check_sym) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= S.n) return;
+    const long long a = S.off[v], b = S.off[v + 1];
+    const int deg = static_cast<int>(b - a);
+    S.remaining[v] = deg;
+    S.seed[v] = 0; S.csize[v] = 0; S.mark[v] = -1; S.pickkey[v] = 0;
+    int st = 0;
+    if (deg == 0) { atomicMin(&S.err[0], v); st = 1; }
+    else if (deg == 1) {
+        if (S.nbr[a] != v) atomicMin(&S.err[1], v);
+        st = 1;
+    } else if (check_sym) {
+        bool self = false;
+        for (long long p = a; p < b; ++p) {
+            const int w = S.nbr[p];
+            if (w == v) self = true;
+            else {  // symmetric?
+                bool back = false;
+                for (long long q = S.off[w]; q < S.off[w + 1] && !back; ++q) back = S.nbr[q] == v;
+                if (!back) atomicMin(&S.err[2], v);
+            }
+        }
+        if (!self) atomicMin(&S.err[2], v);
+    }
+    S.state[v] = st;
+}
+
+__global__ void k_cl_keys(ClusterState S) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= S.n) return;
+    unsigned long long k = 0;
+    if (S.state[v] == 0 && S.remaining[v] > 0) {
+        k = (static_cast<unsigned long long>(S.remaining[v]) << 32) | static_cast<unsigned>(v);
+        atomicAdd(S.live, 1);
+    }
+    S.key[v] = k;
+}
+
+__global__ void k_cl_m1(ClusterState S) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= S.n) return;
+    unsigned long long m = 0;
+    if (S.state[v] == 0)
+        for (long long p = S.off[v]; p < S.off[v + 1]; ++p) m = max(m, S.key[S.nbr[p]]);
+    S.m1[v] = m;
+}
+
+// A live node is picked when its key is the maximum over everything within two hops
+// through live nodes: no earlier pick of the sequential greedy can touch it.
+__global__ void k_cl_pick(ClusterState S, int round) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= S.n) return;
+    const unsigned long long k = S.key[v];
+    if (k == 0) return;
+    unsigned long long m2 = k;
+    for (long long p = S.off[v]; p < S.off[v + 1]; ++p) {
+        const int w = S.nbr[p];
+        if (S.state[w] == 0) m2 = max(m2, S.m1[w]);
+    }
+    if (m2 != k) return;
+    // cluster = still-unused neighbours in list order (src/cluster_umis.cpp:78-91)
+    int c = 0;
+    const long long a = S.off[v];
+    for (long long p = a; p < S.off[v + 1]; ++p) {
+        const int w = S.nbr[p];
+        if (S.state[w] == 0) { S.memb[a + c] = w; ++c; S.mark[w] = round; }
+    }
+    S.csize[v] = c;
+    S.seed[v] = 1;
+    S.pickkey[v] = k;
+}
+
+// state flips happen in a separate pass so that k_cl_pick sees a consistent snapshot
+__global__ void k_cl_commit(ClusterState S, int round) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= S.n) return;
+    if (S.mark[v] == round) { S.state[v] = 2; S.remaining[v] = 0; }
+}
+
+__global__ void k_cl_decrement(ClusterState S, int round) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= S.n || S.mark[v] != round) return;
+    for (long long p = S.off[v]; p < S.off[v + 1]; ++p) {
+        const int x = S.nbr[p];
+        if (S.state[x] == 0) atomicSub(&S.remaining[x], 1);
+    }
+}
+
+// output assembly
+__global__ void k_cl_flags(ClusterState S, int* is_solo, int* is_seed) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= S.n) return;
+    is_solo[v] = (S.state[v] == 1) ? 1 : 0;
+    is_seed[v] = S.seed[v];
+}
+
+__global__ void k_cl_list_solos(const int* is_solo, const long long* pos, int n, int* order) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n && is_solo[v]) order[pos[v]] = v;
+}
+
+__global__ void k_cl_list_seeds(const int* is_seed, const long long* pos, const unsigned long long* pickkey, int n,
+                                unsigned long long* sortkey, int* val) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n && is_seed[v]) { sortkey[pos[v]] = ~pickkey[v]; val[pos[v]] = v; }  // ascending ~key = descending key
+}
+
+__global__ void k_cl_sizes(ClusterState S, const int* order, long long nsolo, long long nclu, int* sizes) {
+    const long long c = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    if (c < nclu) sizes[c] = (c < nsolo) ? 1 : S.csize[order[c]];
+}
+
+__global__ void k_cl_write(ClusterState S, const int* order, long long nsolo, long long nclu, const long long* coff,
+                           const int32_t* members /* optional 1-based ids */, int32_t* out) {
+    const long long c = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    if (c >= nclu) return;
+    const int v = order[c];
+    const long long o = coff[c];
+    if (c < nsolo) { out[o] = members ? members[v] : v + 1; return; }
+    const long long a = S.off[v];
+    for (int k = 0; k < S.csize[v]; ++k) {
+        const int w = S.memb[a + k];
+        out[o + k] = members ? members[w] : w + 1;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host orchestration
+
+static inline unsigned nblk(long long n, int bs) { return static_cast<unsigned>((n + bs - 1) / bs); }
+
+static int sort_keys_u64(const char* tag, unsigned long long* in, unsigned long long* out, size_t n, int bits, hipStream_t s) {
+    size_t tmp = 0;
+    SL_HIP(rocprim::radix_sort_keys(nullptr, tmp, in, out, n, 0, bits, s));
+    void* d_tmp;
+    SL_TRY(ctx().buffer((std::string(tag) + ".sorttmp").c_str(), tmp ? tmp : 16, &d_tmp));
+    SL_HIP(rocprim::radix_sort_keys(d_tmp, tmp, in, out, n, 0, bits, s));
+    return 0;
+}
+
+static int sort_pairs_u64_i32(const char* tag, unsigned long long* kin, unsigned long long* kout, int* vin, int* vout,
+                              size_t n, int bits, hipStream_t s) {
+    size_t tmp = 0;
+    SL_HIP(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0, bits, s));
+    void* d_tmp;
+    SL_TRY(ctx().buffer((std::string(tag) + ".sorttmp").c_str(), tmp ? tmp : 16, &d_tmp));
+    SL_HIP(rocprim::radix_sort_pairs(d_tmp, tmp, kin, kout, vin, vout, n, 0, bits, s));
+    return 0;
+}
+
+static int exclusive_scan_i32(const char* tag, const int* in, long long* out, size_t n, hipStream_t s) {
+    size_t tmp = 0;
+    SL_HIP(rocprim::exclusive_scan(nullptr, tmp, in, out, 0ll, n, rocprim::plus<long long>(), s));
+    void* d_tmp;
+    SL_TRY(ctx().buffer((std::string(tag) + ".scantmp").c_str(), tmp ? tmp : 16, &d_tmp));
+    SL_HIP(rocprim::exclusive_scan(d_tmp, tmp, in, out, 0ll, n, rocprim::plus<long long>(), s));
+    return 0;
+}
+
+static int ceil_log2(unsigned long long x) {
+    int b = 1;
+    while (b < 64 && (1ull << b) < x) ++b;
+    return b;
+}
+
+static int alloc_umi(const std::string& p, size_t n, UmiArrays* U) {
+    SL_TRY(scratch((p + ".code").c_str(), n, &U->code));
+    SL_TRY(scratch((p + ".nmask").c_str(), n, &U->nmask));
+    SL_TRY(scratch((p + ".comp").c_str(), n, &U->comp));
+    SL_TRY(scratch((p + ".meta").c_str(), n, &U->meta));
+    return 0;
+}
+
+struct SortedUmis {
+    UmiArrays U;   // in trie (rank) order
+    int* perm;     // rank -> local index
+    int n;
+};
+
+// Encode one set of UMIs (optionally the members of a pre-group) and order it like the trie.
+static int encode_and_rank(const std::string& p, const uint8_t* d_chars, const int64_t* d_off, const int32_t* d_members,
+                           int n, SortedUmis* out, hipStream_t s) {
+    UmiArrays raw;
+    SL_TRY(alloc_umi(p + ".raw", n, &raw));
+    SL_TRY(alloc_umi(p + ".srt", n, &out->U));
+    unsigned long long *khi, *klo, *k2;
+    int *idx, *idx2, *bad;
+    SL_TRY(scratch((p + ".khi").c_str(), n, &khi));
+    SL_TRY(scratch((p + ".klo").c_str(), n, &klo));
+    SL_TRY(scratch((p + ".k2").c_str(), n, &k2));
+    SL_TRY(scratch((p + ".idx").c_str(), n, &idx));
+    SL_TRY(scratch((p + ".idx2").c_str(), n, &idx2));
+    SL_TRY(scratch((p + ".bad").c_str(), 2, &bad));
+    const int init[2] = {std::numeric_limits<int>::max(), std::numeric_limits<int>::max()};
+    SL_HIP(hipMemcpyAsync(bad, init, sizeof init, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_umi_encode, dim3(nblk(n, 256)), dim3(256), 0, s, d_chars, d_off, d_members, n, raw, khi, klo, idx, bad);
+    SL_HIP(hipGetLastError());
+    int hbad[2];
+    SL_HIP(hipMemcpyAsync(hbad, bad, sizeof hbad, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    if (hbad[1] != init[1]) return fail("sarlacc_amd: UMI longer than %d bases is not supported", UMI_MAXLEN);
+    if (hbad[0] != init[0])
+        return fail("sarlacc_amd: UMI contains a character outside ACGTN (the reference silently drops such strings)");
+    // least-significant key first; both sorts are stable, ties keep the input order
+    SL_TRY(sort_pairs_u64_i32(p.c_str(), klo, k2, idx, idx2, n, 64, s));
+    hipLaunchKernelGGL(k_gather_u64, dim3(nblk(n, 256)), dim3(256), 0, s, khi, idx2, klo, n);
+    SL_TRY(sort_pairs_u64_i32(p.c_str(), klo, k2, idx2, idx, n, 64, s));
+    hipLaunchKernelGGL(k_gather_umi, dim3(nblk(n, 256)), dim3(256), 0, s, raw, idx, out->U, n);
+    SL_HIP(hipGetLastError());
+    out->perm = idx;
+    out->n = n;
+    return 0;
+}
+
+template <int K>
+static void launch_pairs(const PairArgs& a, hipStream_t s) {
+    const unsigned nt = nblk(a.n, TILE);
+    hipLaunchKernelGGL(k_umi_pairs<K>, dim3(nt, nt), dim3(TILE), 0, s, a);
+}
+
+struct DirectedKeys {
+    unsigned long long* keys;  // sorted (orig_row << 32 | column rank)
+    long long nk;
+};
+
+// All neighbour pairs within `limit`, as sorted directed keys (self links included).
+static int neighbour_keys(const std::string& p, const SortedUmis& S, int limit, DirectedKeys* out, hipStream_t s) {
+    Context& c = ctx();
+    const int n = S.n;
+    if (limit < 0) limit = -1;  // nothing can match a negative limit
+    const int lim2 = 2 * limit;
+    unsigned long long* d_count;
+    SL_TRY(scratch((p + ".ecount").c_str(), 1, &d_count));
+    unsigned long long cap = std::max<unsigned long long>(1u << 20, 32ull * n);
+    unsigned long long m = 0;
+    unsigned long long* d_edges = nullptr;
+    if (n > static_cast<long long>(65535) * TILE) return fail("sarlacc_amd: more than %d UMIs in one pre-group", 65535 * TILE);
+    for (int attempt = 0; attempt < 2 && limit >= 0; ++attempt) {
+        void* pe;
+        SL_TRY(c.buffer((p + ".edges").c_str(), cap * sizeof(unsigned long long), &pe));
+        d_edges = static_cast<unsigned long long*>(pe);
+        SL_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
+        PairArgs a{S.U, n, lim2, d_edges, d_count, cap};
+        SL_HIP(hipEventRecord(c.ev_start, s));
+        const int K = std::min(limit, UMI_MAXLEN);
+        if (K <= 0) launch_pairs<0>(a, s);
+        else if (K == 1) launch_pairs<1>(a, s);
+        else if (K == 2) launch_pairs<2>(a, s);
+        else if (K == 3) launch_pairs<3>(a, s);
+        else if (K == 4) launch_pairs<4>(a, s);
+        else if (K == 5) launch_pairs<5>(a, s);
+        else if (K <= 8) launch_pairs<8>(a, s);
+        else if (K <= 16) launch_pairs<16>(a, s);
+        else launch_pairs<UMI_MAXLEN>(a, s);
+        SL_HIP(hipGetLastError());
+        SL_HIP(hipEventRecord(c.ev_stop, s));
+        c.timed = true;
+        SL_HIP(hipMemcpyAsync(&m, d_count, sizeof m, hipMemcpyDeviceToHost, s));
+        SL_HIP(hipStreamSynchronize(s));
+        if (m <= cap) break;
+        cap = m;  // the kernel kept counting: second attempt has the exact size
+    }
+    // self links
+    int* d_flag; long long* d_pos;
+    SL_TRY(scratch((p + ".sflag").c_str(), static_cast<size_t>(n) + 1, &d_flag));
+    SL_TRY(scratch((p + ".spos").c_str(), static_cast<size_t>(n) + 1, &d_pos));
+    hipLaunchKernelGGL(k_self_flags, dim3(nblk(n, 256)), dim3(256), 0, s, S.U, n, lim2, d_flag);
+    SL_HIP(hipMemsetAsync(d_flag + n, 0, sizeof(int), s));
+    SL_TRY(exclusive_scan_i32(p.c_str(), d_flag, d_pos, static_cast<size_t>(n) + 1, s));
+    long long nself = 0;
+    SL_HIP(hipMemcpyAsync(&nself, d_pos + n, sizeof nself, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    const long long nk = 2 * static_cast<long long>(m) + nself;
+    unsigned long long *d_k0, *d_k1;
+    SL_TRY(scratch((p + ".k0").c_str(), static_cast<size_t>(nk), &d_k0));
+    SL_TRY(scratch((p + ".k1").c_str(), static_cast<size_t>(nk), &d_k1));
+    if (m) hipLaunchKernelGGL(k_expand_edges, dim3(nblk(static_cast<long long>(m), 256)), dim3(256), 0, s, d_edges, m, S.perm, d_k0 + nself);
+    hipLaunchKernelGGL(k_self_keys, dim3(nblk(n, 256)), dim3(256), 0, s, d_flag, d_pos, S.perm, n, d_k0);
+    SL_HIP(hipGetLastError());
+    if (nk) SL_TRY(sort_keys_u64(p.c_str(), d_k0, d_k1, static_cast<size_t>(nk), 32 + ceil_log2(static_cast<unsigned long long>(n) + 1), s));
+    out->keys = d_k1;
+    out->nk = nk;
+    return 0;
+}
+
+struct DevAdj {
+    long long* off;  // [n+1]
+    int* nbr;        // local 0-based ids, trie order
+    long long nnz;
+};
+
+static int adjacency_from_keys(const std::string& p, const unsigned long long* keys, long long nk, const int* perm, int n,
+                               DevAdj* adj, hipStream_t s) {
+    SL_TRY(scratch((p + ".off").c_str(), static_cast<size_t>(n) + 1, &adj->off));
+    SL_TRY(scratch((p + ".nbr").c_str(), static_cast<size_t>(nk), &adj->nbr));
+    hipLaunchKernelGGL(k_row_offsets, dim3(nblk(nk + 1, 256)), dim3(256), 0, s, keys, nk, n, adj->off);
+    if (nk) hipLaunchKernelGGL(k_cols_from_keys, dim3(nblk(nk, 256)), dim3(256), 0, s, keys, nk, perm, adj->nbr);
+    SL_HIP(hipGetLastError());
+    adj->nnz = nk;
+    return 0;
+}
+
+// Neighbour lists for one group: UMI1 only, or UMI1 n UMI2 listed in UMI2's order
+// (src/umi_group.cpp:59-103).
+static int group_adjacency(const uint8_t* d_c1, const int64_t* d_o1, const uint8_t* d_c2, const int64_t* d_o2,
+                           const int32_t* d_members, int n, int limit1, int limit2, DevAdj* adj, hipStream_t s) {
+    SortedUmis S1;
+    DirectedKeys K1;
+    SL_TRY(encode_and_rank("u1", d_c1, d_o1, d_members, n, &S1, s));
+    SL_TRY(neighbour_keys("u1", S1, limit1, &K1, s));
+    if (!d_c2) return adjacency_from_keys("adj", K1.keys, K1.nk, S1.perm, n, adj, s);
+
+    // membership set of UMI1 links keyed by original column id
+    unsigned long long *d_s1a, *d_s1;
+    SL_TRY(scratch("u1.set0", static_cast<size_t>(K1.nk), &d_s1a));
+    SL_TRY(scratch("u1.set1", static_cast<size_t>(K1.nk), &d_s1));
+    if (K1.nk) {
+        hipLaunchKernelGGL(k_keys_to_orig, dim3(nblk(K1.nk, 256)), dim3(256), 0, s, K1.keys, K1.nk, S1.perm, d_s1a);
+        SL_TRY(sort_keys_u64("u1", d_s1a, d_s1, static_cast<size_t>(K1.nk), 64, s));
+    }
+    SortedUmis S2;
+    DirectedKeys K2;
+    SL_TRY(encode_and_rank("u2", d_c2, d_o2, d_members, n, &S2, s));
+    SL_TRY(neighbour_keys("u2", S2, limit2, &K2, s));
+    int* d_keep; long long* d_pos;
+    SL_TRY(scratch("u2.keep", static_cast<size_t>(K2.nk) + 1, &d_keep));
+    SL_TRY(scratch("u2.kpos", static_cast<size_t>(K2.nk) + 1, &d_pos));
+    if (K2.nk) hipLaunchKernelGGL(k_intersect_flags, dim3(nblk(K2.nk, 256)), dim3(256), 0, s, K2.keys, K2.nk, S2.perm, d_s1, K1.nk, d_keep);
+    SL_HIP(hipMemsetAsync(d_keep + K2.nk, 0, sizeof(int), s));
+    SL_TRY(exclusive_scan_i32("u2", d_keep, d_pos, static_cast<size_t>(K2.nk) + 1, s));
+    long long nkeep = 0;
+    SL_HIP(hipMemcpyAsync(&nkeep, d_pos + K2.nk, sizeof nkeep, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    unsigned long long* d_kk;
+    SL_TRY(scratch("u2.kept", static_cast<size_t>(nkeep), &d_kk));
+    if (K2.nk) hipLaunchKernelGGL(k_compact_keys, dim3(nblk(K2.nk, 256)), dim3(256), 0, s, K2.keys, d_keep, d_pos, K2.nk, d_kk);
+    SL_HIP(hipGetLastError());
+    return adjacency_from_keys("adj", d_kk, nkeep, S2.perm, n, adj, s);
+}
+
+struct ClusterResult {
+    long long nclu = 0;
+    long long* d_coff = nullptr;  // [nclu+1]
+    int32_t* d_out = nullptr;     // member ids (1-based; mapped through members when given)
+    long long total = 0;
+};
+
+// Greedy clustering of a device CSR graph.  `require_symmetric` is the documented
+// precondition of this implementation (the reference's results on asymmetric input
+// are an accident of its update order; umi_group always produces symmetric lists).
+static int cluster_dev(const DevAdj& adj, int n, const int32_t* d_members, bool check_sym, ClusterResult* res, hipStream_t s) {
+    ClusterState S{};
+    S.off = adj.off; S.nbr = adj.nbr; S.n = n;
+    const size_t nn = static_cast<size_t>(n) + 1;
+    SL_TRY(scratch("cl.remaining", nn, &S.remaining));
+    SL_TRY(scratch("cl.state", nn, &S.state));
+    SL_TRY(scratch("cl.mark", nn, &S.mark));
+    SL_TRY(scratch("cl.key", nn, &S.key));
+    SL_TRY(scratch("cl.m1", nn, &S.m1));
+    SL_TRY(scratch("cl.seed", nn, &S.seed));
+    SL_TRY(scratch("cl.pickkey", nn, &S.pickkey));
+    SL_TRY(scratch("cl.memb", static_cast<size_t>(adj.nnz) + 1, &S.memb));
+    SL_TRY(scratch("cl.csize", nn, &S.csize));
+    SL_TRY(scratch("cl.err", 3, &S.err));
+    SL_TRY(scratch("cl.live", 1, &S.live));
+    const int big = std::numeric_limits<int>::max();
+    const int init[3] = {big, big, big};
+    SL_HIP(hipMemcpyAsync(S.err, init, sizeof init, hipMemcpyHostToDevice, s));
+    const dim3 g(nblk(n, 256)), b(256);
+    hipLaunchKernelGGL(k_cl_init, g, b, 0, s, S, check_sym ? 1 : 0);
+    int herr[3];
+    SL_HIP(hipMemcpyAsync(herr, S.err, sizeof herr, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    // first error in index order, as the reference's loop would meet it (src/cluster_umis.cpp:21-40)
+    if (herr[0] != big || herr[1] != big) {
+        if (herr[0] < herr[1]) return fail("zero length read group");
+        return fail("single-read groups should contain only the read itself");
+    }
+    if (herr[2] != big)
+        return fail("sarlacc_amd: neighbour lists must be symmetric and contain the read itself (list %d is not)", herr[2] + 1);
+
+    for (int round = 0;; ++round) {
+        SL_HIP(hipMemsetAsync(S.live, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_cl_keys, g, b, 0, s, S);
+        int live = 0;
+        SL_HIP(hipMemcpyAsync(&live, S.live, sizeof live, hipMemcpyDeviceToHost, s));
+        SL_HIP(hipStreamSynchronize(s));
+        if (live == 0) break;
+        hipLaunchKernelGGL(k_cl_m1, g, b, 0, s, S);
+        hipLaunchKernelGGL(k_cl_pick, g, b, 0, s, S, round);
+        hipLaunchKernelGGL(k_cl_commit, g, b, 0, s, S, round);
+        hipLaunchKernelGGL(k_cl_decrement, g, b, 0, s, S, round);
+        SL_HIP(hipGetLastError());
+        if (round > 4 * n + 16) return fail("sarlacc_amd: clustering did not converge");
+    }
+
+    // ---- output order: solos by index, then picks by key descending ----
+    int *d_issolo, *d_isseed, *d_order, *d_val, *d_val2, *d_sizes;
+    long long *d_spos, *d_kpos;
+    unsigned long long *d_sk, *d_sk2;
+    SL_TRY(scratch("cl.issolo", nn, &d_issolo));
+    SL_TRY(scratch("cl.isseed", nn, &d_isseed));
+    SL_TRY(scratch("cl.spos", nn, &d_spos));
+    SL_TRY(scratch("cl.kpos", nn, &d_kpos));
+    SL_TRY(scratch("cl.order", nn, &d_order));
+    SL_TRY(scratch("cl.val", nn, &d_val));
+    SL_TRY(scratch("cl.val2", nn, &d_val2));
+    SL_TRY(scratch("cl.sk", nn, &d_sk));
+    SL_TRY(scratch("cl.sk2", nn, &d_sk2));
+    SL_TRY(scratch("cl.sizes", nn, &d_sizes));
+    hipLaunchKernelGGL(k_cl_flags, g, b, 0, s, S, d_issolo, d_isseed);
+    SL_HIP(hipMemsetAsync(d_issolo + n, 0, sizeof(int), s));
+    SL_HIP(hipMemsetAsync(d_isseed + n, 0, sizeof(int), s));
+    SL_TRY(exclusive_scan_i32("cl", d_issolo, d_spos, nn, s));
+    SL_TRY(exclusive_scan_i32("cl", d_isseed, d_kpos, nn, s));
+    long long nsolo = 0, nseed = 0;
+    SL_HIP(hipMemcpyAsync(&nsolo, d_spos + n, sizeof nsolo, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipMemcpyAsync(&nseed, d_kpos + n, sizeof nseed, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    const long long nclu = nsolo + nseed;
+    hipLaunchKernelGGL(k_cl_list_solos, g, b, 0, s, d_issolo, d_spos, n, d_order);
+    if (nseed) {
+        hipLaunchKernelGGL(k_cl_list_seeds, g, b, 0, s, d_isseed, d_kpos, S.pickkey, n, d_sk, d_val);
+        SL_TRY(sort_pairs_u64_i32("cl", d_sk, d_sk2, d_val, d_val2, static_cast<size_t>(nseed), 64, s));
+        SL_HIP(hipMemcpyAsync(d_order + nsolo, d_val2, sizeof(int) * static_cast<size_t>(nseed), hipMemcpyDeviceToDevice, s));
+    }
+    long long* d_coff;
+    int32_t* d_out;
+    SL_TRY(scratch("cl.coff", static_cast<size_t>(nclu) + 2, &d_coff));
+    SL_TRY(scratch("cl.out", nn, &d_out));
+    if (nclu) {
+        hipLaunchKernelGGL(k_cl_sizes, dim3(nblk(nclu, 256)), b, 0, s, S, d_order, nsolo, nclu, d_sizes);
+        SL_HIP(hipMemsetAsync(d_sizes + nclu, 0, sizeof(int), s));
+        SL_TRY(exclusive_scan_i32("cl", d_sizes, d_coff, static_cast<size_t>(nclu) + 1, s));
+        hipLaunchKernelGGL(k_cl_write, dim3(nblk(nclu, 256)), b, 0, s, S, d_order, nsolo, nclu, d_coff, d_members, d_out);
+        SL_HIP(hipGetLastError());
+        SL_HIP(hipMemcpyAsync(&res->total, d_coff + nclu, sizeof(long long), hipMemcpyDeviceToHost, s));
+        SL_HIP(hipStreamSynchronize(s));
+    } else {
+        const long long zero = 0;
+        SL_HIP(hipMemcpyAsync(d_coff, &zero, sizeof zero, hipMemcpyHostToDevice, s));
+        res->total = 0;
+    }
+    res->nclu = nclu;
+    res->d_coff = d_coff;
+    res->d_out = d_out;
+    return 0;
+}
+
+static int upload_strings(const char* tag, const char* chars, const int64_t* off, int64_t n, uint8_t** d_chars,
+                          int64_t** d_off, hipStream_t s) {
+    const int64_t base = n ? off[0] : 0;
+    const int64_t total = n ? off[n] - base : 0;
+    std::vector<int64_t> rel(static_cast<size_t>(n) + 1);
+    for (int64_t i = 0; i <= n; ++i) rel[i] = (n ? off[i] : 0) - base;
+    SL_TRY(upload((std::string(tag) + ".chars").c_str(), reinterpret_cast<const uint8_t*>(chars) + base, static_cast<size_t>(total), d_chars, s));
+    SL_TRY(upload((std::string(tag) + ".off").c_str(), rel.data(), rel.size(), d_off, s));
+    return 0;
+}
+
+}  // namespace sarlacc
+
+using namespace sarlacc;
+
+extern "C" {
+
+int sarlacc_compute_lev_masked(const char* seq, const int64_t* off, int64_t n, double* out) {
+    if (n < 0) return fail("sarlacc_amd: negative number of sequences");
+    if (n < 2) return 0;
+    if (n > 60000) return fail("sarlacc_amd: compute_lev_masked is dense (n^2/2 doubles); n = %lld is too large", static_cast<long long>(n));
+    SL_TRY(ensure_device());
+    hipStream_t s = nullptr;
+    uint8_t* d_c; int64_t* d_o;
+    SL_TRY(upload_strings("lev", seq, off, n, &d_c, &d_o, s));
+    // no ordering needed: encode in input order
+    UmiArrays U;
+    SL_TRY(alloc_umi("lev.raw", n, &U));
+    unsigned long long *khi, *klo; int *idx, *bad;
+    SL_TRY(scratch("lev.khi", n, &khi));
+    SL_TRY(scratch("lev.klo", n, &klo));
+    SL_TRY(scratch("lev.idx", n, &idx));
+    SL_TRY(scratch("lev.bad", 2, &bad));
+    const int init[2] = {std::numeric_limits<int>::max(), std::numeric_limits<int>::max()};
+    SL_HIP(hipMemcpyAsync(bad, init, sizeof init, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_umi_encode, dim3(nblk(n, 256)), dim3(256), 0, s, d_c, d_o, static_cast<const int32_t*>(nullptr), static_cast<int>(n), U, khi, klo, idx, bad);
+    int hbad[2];
+    SL_HIP(hipMemcpyAsync(hbad, bad, sizeof hbad, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    if (hbad[1] != init[1]) return fail("sarlacc_amd: sequence longer than %d bases is not supported", UMI_MAXLEN);
+    // characters outside ACGTN behave as ordinary distinct letters in the reference
+    // (src/compute_lev_masked.cpp:51); only ACGTN is supported here
+    if (hbad[0] != init[0]) return fail("sarlacc_amd: sequence contains a character outside ACGTN");
+    const long long npairs = n * (n - 1) / 2;
+    double* d_out;
+    SL_TRY(scratch("lev.out", static_cast<size_t>(npairs), &d_out));
+    hipLaunchKernelGGL(k_lev_dense, dim3(nblk(npairs, 128)), dim3(128), 0, s, U, static_cast<int>(n), d_out);
+    SL_HIP(hipGetLastError());
+    SL_HIP(hipMemcpy(out, d_out, sizeof(double) * static_cast<size_t>(npairs), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sarlacc_fast_levdist_test(const char* seq, const int64_t* off, int64_t n, int limit, int64_t* nbr_off,
+                              int32_t* nbr, int64_t nbr_cap, int64_t* nbr_need) {
+    if (n < 0) return fail("sarlacc_amd: negative number of sequences");
+    *nbr_need = 0;
+    nbr_off[0] = 0;
+    if (n == 0) return 0;
+    SL_TRY(ensure_device());
+    hipStream_t s = nullptr;
+    uint8_t* d_c; int64_t* d_o;
+    SL_TRY(upload_strings("lv", seq, off, n, &d_c, &d_o, s));
+    DevAdj adj;
+    SL_TRY(group_adjacency(d_c, d_o, nullptr, nullptr, nullptr, static_cast<int>(n), limit, limit, &adj, s));
+    std::vector<long long> hoff(static_cast<size_t>(n) + 1);
+    SL_HIP(hipMemcpy(hoff.data(), adj.off, sizeof(long long) * hoff.size(), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i <= n; ++i) nbr_off[i] = hoff[i];
+    *nbr_need = adj.nnz;
+    if (!nbr || nbr_cap < adj.nnz) return 0;  // sizing call
+    std::vector<int> h(static_cast<size_t>(adj.nnz));
+    if (adj.nnz) SL_HIP(hipMemcpy(h.data(), adj.nbr, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
+    for (long long i = 0; i < adj.nnz; ++i) nbr[i] = h[i] + 1;
+    return 0;
+}
+
+int sarlacc_cluster_umis_test(const int64_t* link_off, const int32_t* links, int64_t n, int64_t* nclusters,
+                              int64_t* clu_off, int32_t* clu) {
+    if (n < 0) return fail("sarlacc_amd: negative number of lists");
+    *nclusters = 0;
+    clu_off[0] = 0;
+    if (n == 0) return 0;
+    SL_TRY(ensure_device());
+    hipStream_t s = nullptr;
+    const int64_t nnz = link_off[n] - link_off[0];
+    std::vector<long long> hoff(static_cast<size_t>(n) + 1);
+    std::vector<int> hn(static_cast<size_t>(nnz) + 1);
+    for (int64_t i = 0; i <= n; ++i) hoff[i] = link_off[i] - link_off[0];
+    for (int64_t i = 0; i < nnz; ++i) {
+        const int32_t v = links[link_off[0] + i];
+        if (v < 1 || v > n) return fail("sarlacc_amd: link %d outside 1..%lld", v, static_cast<long long>(n));
+        hn[i] = v - 1;
+    }
+    DevAdj adj;
+    SL_TRY(upload("adj.off", hoff.data(), hoff.size(), &adj.off, s));
+    SL_TRY(upload("adj.nbr", hn.data(), hn.size(), &adj.nbr, s));
+    adj.nnz = nnz;
+    ClusterResult res;
+    SL_TRY(cluster_dev(adj, static_cast<int>(n), nullptr, true, &res, s));
+    std::vector<long long> co(static_cast<size_t>(res.nclu) + 1);
+    SL_HIP(hipMemcpy(co.data(), res.d_coff, sizeof(long long) * co.size(), hipMemcpyDeviceToHost));
+    if (res.total) SL_HIP(hipMemcpy(clu, res.d_out, sizeof(int32_t) * static_cast<size_t>(res.total), hipMemcpyDeviceToHost));
+    for (long long c = 0; c <= res.nclu; ++c) clu_off[c] = co[c];
+    *nclusters = res.nclu;
+    return 0;
+}
+
+int sarlacc_umi_group(const char* umi1, const int64_t* off1, const char* umi2, const int64_t* off2, int64_t n,
+                      int thresh1, int thresh2, const int64_t* grp_off, const int32_t* grp, int64_t ngroups,
+                      int64_t* nclusters, int64_t* clu_off, int32_t* clu) {
+    if (n < 0 || ngroups < 0) return fail("sarlacc_amd: negative sizes");
+    *nclusters = 0;
+    clu_off[0] = 0;
+    if (ngroups == 0) return 0;
+    const int64_t total = grp_off[ngroups] - grp_off[0];
+    for (int64_t i = 0; i < total; ++i) {
+        const int32_t v = grp[grp_off[0] + i];
+        if (v < 1 || v > n) return fail("sarlacc_amd: pre-group index %d outside 1..%lld", v, static_cast<long long>(n));
+    }
+    SL_TRY(ensure_device());
+    hipStream_t s = nullptr;
+    uint8_t *d_c1, *d_c2 = nullptr;
+    int64_t *d_o1, *d_o2 = nullptr;
+    SL_TRY(upload_strings("g1", umi1, off1, n, &d_c1, &d_o1, s));
+    if (umi2) SL_TRY(upload_strings("g2", umi2, off2, n, &d_c2, &d_o2, s));
+    int32_t* d_grp;
+    SL_TRY(upload("g.members", grp + grp_off[0], static_cast<size_t>(total), &d_grp, s));
+
+    int64_t nc = 0;
+    for (int64_t g = 0; g < ngroups; ++g) {
+        const int64_t a = grp_off[g] - grp_off[0], N = grp_off[g + 1] - grp_off[g];
+        if (N == 1) {  // passthrough (src/umi_group.cpp:39-42)
+            clu[clu_off[nc]] = grp[grp_off[g]];
+            clu_off[nc + 1] = clu_off[nc] + 1;
+            ++nc;
+            continue;
+        }
+        if (N == 0) continue;
+        DevAdj adj;
+        SL_TRY(group_adjacency(d_c1, d_o1, d_c2, d_o2, d_grp + a, static_cast<int>(N), thresh1, thresh2, &adj, s));
+        ClusterResult res;
+        SL_TRY(cluster_dev(adj, static_cast<int>(N), d_grp + a, false, &res, s));
+        std::vector<long long> co(static_cast<size_t>(res.nclu) + 1);
+        SL_HIP(hipMemcpy(co.data(), res.d_coff, sizeof(long long) * co.size(), hipMemcpyDeviceToHost));
+        const int64_t base = clu_off[nc];
+        if (res.total) SL_HIP(hipMemcpy(clu + base, res.d_out, sizeof(int32_t) * static_cast<size_t>(res.total), hipMemcpyDeviceToHost));
+        for (long long c = 0; c < res.nclu; ++c) clu_off[nc + c + 1] = base + co[c + 1];
+        nc += res.nclu;
+    }
+    *nclusters = nc;
+    return 0;
+}
+}

@@ -1,0 +1,196 @@
+"""GPU parity: masked Levenshtein, neighbour search, greedy clustering and umi_group
+against the CPU oracle, through the C ABI.  Everything here is integer work and
+must be identical, including the order of neighbours inside each list and the
+order of clusters / members in the output.
+
+Mirrors /root/reference/tests/testthat/test-levenshtein.R and test-umicluster.R
+(random sequences incl. empty strings and duplicates, limits 1/2/5, masked cases,
+random symmetric graphs at several densities, one and two UMIs, pre-groups, solos)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def seqsim(rng, n, lo, hi, alphabet="ACGT"):
+    return ["".join(rng.choice(list(alphabet), int(rng.integers(lo, hi + 1)))) for _ in range(n)]
+
+
+def umisim(rng, n, length, rate=0.1, alphabet="ACGT"):
+    ref = rng.choice(list("ACGT"), length)
+    out = []
+    for _ in range(n):
+        t = ref.copy()
+        ch = rng.random(length) < rate
+        t[ch] = rng.choice(list(alphabet), int(ch.sum()))
+        out.append("".join(t))
+    return out
+
+
+def same_lists(a, b):
+    assert len(a) == len(b), (len(a), len(b))
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert list(x) == list(y), (k, list(x), list(y))
+
+
+@pytest.mark.parametrize("lo,hi", [(1, 20), (5, 10), (0, 5), (28, 32)])
+def test_lev_masked_dense(oracle, lo, hi):
+    from sarlacc_amd import calls
+    rng = np.random.default_rng(1000 + lo)
+    seqs = seqsim(rng, 70, lo, hi, "ACGTN" if lo == 5 else "ACGT")
+    assert calls.compute_lev_masked(seqs).tolist() == oracle.compute_lev_masked(seqs).tolist()
+    ref = "ACAGCTAGC"
+    for i in range(len(ref)):
+        masked = ref[:i] + "N" + ref[i + 1:]
+        assert calls.compute_lev_masked([ref, masked]).tolist() == [0.5]
+        assert calls.compute_lev_masked([ref, ref]).tolist() == [0.0]
+        assert calls.compute_lev_masked([masked, masked]).tolist() == [0.5]
+    assert calls.compute_lev_masked(["ACGT"]).size == 0 and calls.compute_lev_masked([]).size == 0
+
+
+@pytest.mark.parametrize("lo,hi,dup,alphabet", [(1, 20, False, "ACGT"), (5, 10, False, "ACGT"), (5, 10, True, "ACGT"),
+                                               (0, 5, False, "ACGT"), (4, 9, False, "ACGTN"), (22, 32, False, "ACGT")])
+def test_fast_levdist(oracle, lo, hi, dup, alphabet):
+    from sarlacc_amd import calls
+    rng = np.random.default_rng(lo * 100 + hi + dup)
+    seqs = seqsim(rng, 50 if dup else 100, lo, hi, alphabet)
+    if dup:
+        seqs = [seqs[i] for i in rng.integers(0, 50, 100)]
+    for limit in (0, 1, 2, 3, 5, 9):
+        same_lists(calls.fast_levdist_test(seqs, limit, True), oracle.fast_levdist_test(seqs, limit))
+    same_lists(calls.fast_levdist_test(seqs, 2, False), oracle.fast_levdist_test(seqs, 2))
+
+
+def test_fast_levdist_masked_known_answers():
+    from sarlacc_amd import calls
+    ref = "ACAGCTAGC"
+    for i in range(len(ref)):
+        masked = ref[:i] + "N" + ref[i + 1:]
+        out = calls.fast_levdist_test([ref, masked], 1)
+        assert sorted(out[0].tolist()) == [1, 2] and sorted(out[1].tolist()) == [1, 2]
+        out = calls.fast_levdist_test([ref, masked], 0)
+        assert out[0].tolist() == [1] and out[1].tolist() == []
+    assert calls.fast_levdist_test([], 1) == []
+
+
+def test_fast_levdist_more_than_one_tile(oracle):
+    from sarlacc_amd import calls
+    rng = np.random.default_rng(8)
+    seqs = []
+    for _ in range(90):
+        seqs += umisim(rng, 10, 12, rate=0.06)
+    perm = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in perm]
+    for limit in (1, 2):
+        same_lists(calls.fast_levdist_test(seqs, limit), oracle.fast_levdist_test(seqs, limit))
+
+
+def mockup(rng, n, density):
+    a = rng.random((n, n)) < density
+    a = np.triu(a, 1)
+    a = a | a.T | np.eye(n, dtype=bool)
+    return [(np.flatnonzero(a[:, j]) + 1).tolist() for j in range(n)]
+
+
+@pytest.mark.parametrize("n,density", [(20, 0.05), (20, 0.1), (20, 0.2), (50, 0.2), (50, 0.4), (50, 0.1), (50, 0.0),
+                                       (400, 0.01), (1000, 0.003)])
+def test_cluster_umis(oracle, n, density):
+    from sarlacc_amd import calls
+    rng = np.random.default_rng(int(n * 1000 + density * 1000))
+    for _ in range(3):
+        links = mockup(rng, n, density)
+        # neighbour order inside a list matters: shuffle it
+        links = [list(rng.permutation(l)) for l in links]
+        same_lists(calls.cluster_umis_test(links), oracle.cluster_umis_test(links))
+
+
+def test_cluster_errors():
+    from sarlacc_amd import SarlaccError, calls
+    with pytest.raises(SarlaccError, match="zero length read group"):
+        calls.cluster_umis_test([[1], []])
+    with pytest.raises(SarlaccError, match="single-read groups should contain only the read itself"):
+        calls.cluster_umis_test([[2], [1, 2]])
+    assert calls.cluster_umis_test([]) == []
+
+
+def test_umi_group(oracle):
+    from sarlacc_amd import calls
+    rng = np.random.default_rng(77)
+    seqs1, seqs2, pre = [], [], []
+    for x in range(10):
+        N = int(rng.integers(10, 21))
+        seqs1 += umisim(rng, N, 10)
+        seqs2 += umisim(rng, N, 5)
+        pre += [x] * N
+    o = rng.permutation(len(pre))
+    seqs1 = [seqs1[i] for i in o]
+    seqs2 = [seqs2[i] for i in o]
+    pre = np.array(pre)[o]
+    everything = [list(range(1, len(seqs1) + 1))]
+    by_group = [(np.flatnonzero(pre == g) + 1).tolist() for g in range(10)]
+    for groups in (everything, by_group):
+        for t in (0, 1, 3):
+            same_lists(calls.umi_group(seqs1, t, None, t, groups), oracle.umi_group(seqs1, t, None, t, groups))
+        for t1, t2 in ((1, 1), (3, 1), (2, 0)):
+            same_lists(calls.umi_group(seqs1, t1, seqs2, t2, groups), oracle.umi_group(seqs1, t1, seqs2, t2, groups))
+    out = calls.umi_group(seqs1[:10], 1, None, 1, [[i] for i in range(1, 11)])
+    assert [c.tolist() for c in out] == [[i] for i in range(1, 11)]
+    # Rd examples (man/umiGroup.Rd:49-65), outputs recorded from the reference in SURVEY section 8c
+    u1 = ["AACCGGTT", "AACGGTT", "ACCCGGTT", "AACCGGTTT"]
+    u2 = ["AACCGGTT", "CACCGGTT", "AACCCGGTA", "AACGGGTT"]
+    g = [[1, 2, 3, 4]]
+    assert [c.tolist() for c in calls.umi_group(u1, 3, None, 3, g)] == [[1, 4, 2, 3]]
+    assert [c.tolist() for c in calls.umi_group(u1, 0, None, 0, g)] == [[1], [2], [3], [4]]
+    assert [c.tolist() for c in calls.umi_group(u1, 3, u2, 3, g)] == [[3, 1, 4, 2]]
+
+
+def test_umi_group_masked_and_errors(oracle):
+    from sarlacc_amd import SarlaccError, calls
+    rng = np.random.default_rng(5)
+    seqs = []
+    for _ in range(12):
+        seqs += umisim(rng, 8, 12, rate=0.08, alphabet="ACGTN")
+    g = [list(range(1, len(seqs) + 1))]
+    for t in (1, 2, 3):
+        try:
+            want = oracle.umi_group(seqs, t, None, t, g)
+        except oracle.OracleError as e:
+            with pytest.raises(SarlaccError, match=str(e)):
+                calls.umi_group(seqs, t, None, t, g)
+            continue
+        same_lists(calls.umi_group(seqs, t, None, t, g), want)
+    # a UMI with more Ns than 2*limit is not its own neighbour (App.B Q10)
+    with pytest.raises(SarlaccError, match="zero length read group"):
+        calls.umi_group(["ACNNNGT", "ACGTTGT"], 1, None, 1, [[1, 2]])
+    with pytest.raises(SarlaccError, match="should have the same length"):
+        calls.umi_group(["ACGT", "ACGA"], 1, ["ACGT"], 1, [[1, 2]])
+
+
+def test_c3_shape_sample(oracle):
+    # BASELINE config 3 shape on a sample the oracle finishes in seconds: 12-bp UMIs,
+    # 10 reads per molecule with the mockReads error process, one pre-group
+    from sarlacc_amd import calls
+    from sarlacc_amd.mock import NUC, mutate
+    rng = np.random.default_rng(1000)
+    umis = []
+    for _ in range(400):
+        truth = NUC[rng.integers(0, 4, 12)]
+        umis += [mutate(truth, rng).tobytes().decode() for _ in range(10)]
+    g = [list(range(1, len(umis) + 1))]
+    for t in (1, 2):
+        got = calls.umi_group(umis, t, None, t, g)
+        same_lists(got, oracle.umi_group(umis, t, None, t, g, fast=True))
+        assert sorted(x for c in got for x in c.tolist()) == g[0]
+
+
+def test_mask_bad_bases(oracle, oenc, enc):
+    from sarlacc_amd import SarlaccError, calls
+    from sarlacc_amd.mock import random_reads
+    seqs, quals = random_reads(60, 0, 60, seed=3)
+    for thr in (0.001, 0.01, 0.05, 0.1, 0.5):
+        assert calls.mask_bad_bases(seqs, quals, enc, thr) == oracle.mask_bad_bases(seqs, quals, oenc, thr)
+    assert calls.mask_bad_bases([], [], enc, 0.1) == []
+    with pytest.raises(SarlaccError, match="same length"):
+        calls.mask_bad_bases(["ACGT"], ["III"], enc, 0.1)
+    with pytest.raises(SarlaccError, match="quality cannot be lower"):
+        calls.mask_bad_bases(["ACGT"], ["II I"], enc, 0.1)
