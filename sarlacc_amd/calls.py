@@ -274,3 +274,40 @@ def umi_group(umi1, thresh1, umi2, thresh2, pregroup):
         ptr(s2.off) if s2 is not None else None, C.c_int64(len(s1)), t1, t2,
         ptr(goff), ptr(gvals), C.c_int64(len(pregroup)), C.byref(ncl), ptr(co), ptr(cl)))
     return lists_from_csr(co, cl, ncl.value)
+
+
+def quick_msa(groupings, sequences, match, mismatch, gapExtension, gapOpening, bandwidth):
+    """.Call quick_msa (src/quick_msa.cpp:15-80), same argument order (the R caller passes
+    -gapOpening as gapExtension and -gapExtension as gapOpening, R/multiReadAlign.R:47).
+    Returns one list of equal-width gapped strings per group."""
+    s = StringSet.from_strings(sequences)
+    ma = _numeric(match, "match score")
+    mm = _numeric(mismatch, "mismatch score")
+    gx = _numeric(gapExtension, "gap extension score")
+    go = _numeric(gapOpening, "gap opening score")
+    bw = _integer(bandwidth, "bandwidth")
+    goff, gvals = csr_from_lists(groupings)
+    ng = len(groupings)
+    width = np.zeros(max(ng, 1), np.int32)
+    ooff = np.zeros(ng + 1, np.int64)
+    args = (ptr(goff), ptr(gvals), C.c_int64(ng), ptr(s.chars), ptr(s.off), C.c_int64(len(s)),
+            C.c_double(ma), C.c_double(mm), C.c_double(gx), C.c_double(go), bw, ptr(width), ptr(ooff))
+    # generous first guess: every read padded to twice the longest member
+    sizes = np.diff(goff)
+    cap = int(s.total * 2 + 64) if ng else 1
+    for attempt in range(2):
+        out = np.zeros(max(cap, 1), np.uint8)
+        try:
+            check(_lib.lib().sarlacc_quick_msa(*args, ptr(out), C.c_int64(cap)))
+            break
+        except SarlaccError as e:
+            if attempt == 0 and "buffer too small" in str(e):
+                cap = int(ooff[ng])
+                continue
+            raise
+    res = []
+    for g in range(ng):
+        w, m = int(width[g]), int(sizes[g])
+        blk = out[ooff[g]:ooff[g + 1]].tobytes()
+        res.append([blk[r * w:(r + 1) * w].decode() for r in range(m)])
+    return res

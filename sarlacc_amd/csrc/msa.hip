@@ -1,0 +1,493 @@
+// msa.hip -- per-group multiple sequence alignment ("MSA spec v1") on gfx950.
+//
+// Stands in for the reference's quick_msa (/root/reference/src/quick_msa.cpp:15-80),
+// which hands each group to SeqAn's T-Coffee.  SeqAn is a third-party dependency
+// that is neither in the reference tree nor pinned by any reference test, so the
+// arithmetic here follows our own written specification (DESIGN.md "MSA spec v1",
+// checker: oracle/msa.c) and keeps only the documented contract of quick_msa:
+// integer simple scores, banded global pairwise alignment, one gapped row per read in
+// group order, equal widths, '-' for gaps, non-ACGT shown as N, singletons verbatim.
+//
+// Kernels:
+//   k_msa_pairwise  one wavefront per (read, centre) pair: banded Gotoh filled row by
+//                   row, lanes own C consecutive band cells; vertical/diagonal inputs
+//                   are in-lane or one DPP shift away, the horizontal gap chain is a
+//                   max-plus prefix scan across the wave (DPP row_shr / row_bcast);
+//                   4 traceback bits per cell stream to a per-wave HBM tile (one
+//                   coalesced dword per lane per row) and are walked back through an
+//                   LDS window of 32 rows.
+//   k_msa_width     per group: column budget (max insertions before each centre base).
+//   k_msa_write     per group: emits the gapped rows.
+#include <cstdlib>
+#include <cstring>
+
+#include "common.hpp"
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/sarlacc_amd.h"
+
+#include <algorithm>
+#include <limits>
+#include <vector>
+
+namespace sarlacc {
+
+constexpr int MSA_NEG = -(1 << 28);
+constexpr int TB_ROWS = 32;
+
+struct MsaJob {
+    long long read_off;   // into seq
+    long long ctr_off;
+    long long out_off;    // into ins[] (lc+1 entries) and aln[] (lc entries, same base)
+    int lr, lc;
+};
+
+struct MsaArgs {
+    const uint8_t* seq;
+    const MsaJob* jobs;
+    int njobs;
+    int ma, mm, go, ge, bw;
+    uint16_t* ins;          // per pair: insertions before each centre position
+    uint8_t* aln;           // per pair: 1 if the centre base is matched to a read base
+    void* tb;               // per-wave traceback tile
+    unsigned long long tb_per_wave;  // in tile words
+    int ctr_cap;            // bytes reserved for the staged centre
+};
+
+__device__ __forceinline__ uint8_t dna5_code(uint8_t c) {
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+    }
+    return 4;
+}
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_int(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false);
+}
+constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;
+
+// inclusive max-scan over the 64 lanes
+__device__ __forceinline__ int wave_scan_max(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(MSA_NEG, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(MSA_NEG, v, 0x112 /* row_shr:2 */, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(MSA_NEG, v, 0x114 /* row_shr:4 */, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(MSA_NEG, v, 0x118 /* row_shr:8 */, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(MSA_NEG, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(MSA_NEG, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
+    return v;
+}
+
+template <int C>
+struct TbWord { using type = uint32_t; };
+template <>
+struct TbWord<16> { using type = unsigned long long; };
+
+template <int C>
+__global__ void __launch_bounds__(64) k_msa_pairwise(const MsaArgs A) {
+    using Word = typename TbWord<C>::type;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Word* s_tb = reinterpret_cast<Word*>(smem);
+    uint8_t* s_ctr = reinterpret_cast<uint8_t*>(s_tb + TB_ROWS * 64);
+
+    const int lane = threadIdx.x;
+    const int ma = A.ma, mm = A.mm, go = A.go, ge = A.ge;
+    const int step = (go <= ge) ? ge : go;      // slope of the horizontal gap chain
+    const int fadd = go - step;
+    Word* const tile = static_cast<Word*>(A.tb) + static_cast<size_t>(blockIdx.x) * A.tb_per_wave;
+
+    for (int job = blockIdx.x; job < A.njobs; job += gridDim.x) {
+        const MsaJob J = A.jobs[job];
+        const int lr = J.lr, lc = J.lc;
+        const int dlo = min(0, lc - lr) - A.bw;
+        const int dhi = max(0, lc - lr) + A.bw;
+        const int B = dhi - dlo + 1;
+        const uint8_t* rd = A.seq + J.read_off;
+        const uint8_t* ct = A.seq + J.ctr_off;
+        for (int p = lane; p < lc; p += 64) s_ctr[p] = dna5_code(ct[p]);
+        __syncthreads();
+        auto ctr_at = [&](int idx) -> int { return (idx >= 0 && idx < lc) ? s_ctr[idx] : 0xff; };
+
+        int Hp[C], Ep[C], cw[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            Hp[k] = MSA_NEG;
+            Ep[k] = MSA_NEG;
+            cw[k] = ctr_at(dlo + lane * C + k - 1);  // centre base of column j = dlo + x at row 0
+        }
+
+        for (int i = 0; i <= lr; ++i) {
+            const int rc = (i > 0) ? dna5_code(rd[i - 1]) : 0xfe;
+            const int upH_r = dpp_int<DPP_WAVE_SHL1>(MSA_NEG, Hp[0]);
+            const int upE_r = dpp_int<DPP_WAVE_SHL1>(MSA_NEG, Ep[0]);
+            int hq[C], ev[C], dv[C], lp[C];
+            unsigned eo = 0;
+            int run = MSA_NEG;
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const int x = lane * C + k;
+                const int j = i + dlo + x;
+                const bool valid = x < B && j >= 0 && j <= lc;
+                const int uH = (k + 1 < C) ? Hp[k + 1] : (lane < 63 ? upH_r : MSA_NEG);
+                const int uE = (k + 1 < C) ? Ep[k + 1] : (lane < 63 ? upE_r : MSA_NEG);
+                const int eop = uH + go, eex = uE + ge;
+                int e = max(eop, eex);
+                if (eop >= eex) eo |= 1u << k;
+                int d = Hp[k] + (rc == cw[k] ? ma : mm);
+                if (i == 0) { e = MSA_NEG; d = (j == 0) ? 0 : MSA_NEG; }
+                if (!valid) { e = MSA_NEG; d = MSA_NEG; }
+                e = max(e, MSA_NEG);
+                d = max(d, MSA_NEG);
+                ev[k] = e;
+                dv[k] = d;
+                hq[k] = max(d, e);
+                run = max(run, hq[k] - step * x);
+                lp[k] = run;
+            }
+            const int incl = wave_scan_max(run);
+            const int excl = dpp_int<DPP_WAVE_SHR1>(MSA_NEG, incl);
+            int Hn[C], Fn[C];
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const int x = lane * C + k;
+                const int j = i + dlo + x;
+                const bool valid = x < B && j >= 0 && j <= lc;
+                const int pprev = (k > 0) ? max(excl, lp[k - 1]) : excl;
+                int f = step * x + pprev + fadd;
+                if (!valid || j < 1 || x < 1) f = MSA_NEG;
+                f = max(f, MSA_NEG);
+                Fn[k] = f;
+                Hn[k] = valid ? max(hq[k], f) : MSA_NEG;
+            }
+            const int lH = dpp_int<DPP_WAVE_SHR1>(MSA_NEG, Hn[C - 1]);
+            const int lF = dpp_int<DPP_WAVE_SHR1>(MSA_NEG, Fn[C - 1]);
+            Word bits = 0;
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const int pH = (k > 0) ? Hn[k - 1] : lH;
+                const int pF = (k > 0) ? Fn[k - 1] : lF;
+                const unsigned fo = (pH + go >= pF + ge) ? 1u : 0u;
+                const int d = dv[k], e = ev[k], f = Fn[k];
+                unsigned hd;
+                if (d >= e && d >= f) hd = 0;
+                else if (e >= f) hd = 1;
+                else hd = 2;
+                const unsigned t = hd | (((eo >> k) & 1u) << 2) | (fo << 3);
+                bits |= static_cast<Word>(t) << (4 * k);
+            }
+            tile[static_cast<size_t>(i) * 64 + lane] = bits;
+#pragma unroll
+            for (int k = 0; k < C; ++k) { Hp[k] = Hn[k]; Ep[k] = ev[k]; }
+            // slide the centre window by one column
+            const int nxt = dpp_int<DPP_WAVE_SHL1>(0xff, cw[0]);
+#pragma unroll
+            for (int k = 0; k + 1 < C; ++k) cw[k] = cw[k + 1];
+            cw[C - 1] = (lane < 63) ? nxt : ctr_at(i + 1 + dlo + 64 * C - 2);
+        }
+
+        // ---- traceback through an LDS window (wave-uniform walk) ----
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        uint16_t* ins = A.ins + J.out_off;
+        uint8_t* aln = A.aln + J.out_off;
+        int i = lr, j = lc, state = 0, cnt = 0;
+        int cb = lr + 1;  // first row held in the window (none yet)
+        while (i > 0 || j > 0) {
+            if (i < cb) {
+                cb = max(0, i - (TB_ROWS - 1));
+                __syncthreads();
+                for (int r = 0; r < TB_ROWS; ++r)
+                    if (cb + r <= lr) s_tb[r * 64 + lane] = tile[static_cast<size_t>(cb + r) * 64 + lane];
+                __syncthreads();
+            }
+            const int x = j - i - dlo;
+            const unsigned t = static_cast<unsigned>(s_tb[(i - cb) * 64 + x / C] >> (4 * (x % C))) & 15u;
+            if (state == 0) {
+                state = t & 3;
+                if (state == 0) {           // diagonal: centre base j-1 matched
+                    if (lane == 0) { ins[j] = static_cast<uint16_t>(cnt); aln[j - 1] = 1; }
+                    cnt = 0; --i; --j;
+                }
+                continue;
+            }
+            if (state == 1) {               // read base inserted before centre position j
+                ++cnt;
+                state = (t & 4) ? 0 : 1;
+                --i;
+            } else {                        // centre base j-1 opposite a gap
+                if (lane == 0) { ins[j] = static_cast<uint16_t>(cnt); aln[j - 1] = 0; }
+                cnt = 0;
+                state = (t & 8) ? 0 : 2;
+                --j;
+            }
+        }
+        if (lane == 0) ins[0] = static_cast<uint16_t>(cnt);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+struct MsaGroup {
+    long long first_job;   // jobs of this group are first_job .. first_job + nreads - 2 (centre has none)
+    long long read0;       // index of the group's first entry in the flattened member list
+    int nreads;
+    int centre;            // position of the centre inside the group
+    int lc;
+};
+
+struct MergeArgs {
+    const uint8_t* seq;
+    const int64_t* seq_off;
+    const int32_t* members;   // flattened 1-based read ids
+    const MsaGroup* groups;
+    const MsaJob* jobs;
+    long long ngroups;
+    const uint16_t* ins;
+    const uint8_t* aln;
+    uint16_t* maxins;          // per group: lc+1 entries at mi_off[g]
+    const long long* mi_off;
+    int32_t* width;            // per group
+    const long long* out_off;  // per group start in out
+    uint8_t* out;
+};
+
+// job index of read position r (inside its group), -1 for the centre
+__device__ __forceinline__ long long job_of(const MsaGroup& G, int r) {
+    if (r == G.centre) return -1;
+    return G.first_job + (r < G.centre ? r : r - 1);
+}
+
+__global__ void k_msa_width(MergeArgs A) {
+    const long long g = blockIdx.x;
+    const MsaGroup G = A.groups[g];
+    __shared__ long long s_sum;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    if (G.nreads < 2) {
+        if (threadIdx.x == 0) {
+            int w = 0;
+            if (G.nreads == 1) { const long long id = A.members[G.read0] - 1; w = static_cast<int>(A.seq_off[id + 1] - A.seq_off[id]); }
+            A.width[g] = w;
+        }
+        return;
+    }
+    long long local = 0;
+    for (int p = threadIdx.x; p <= G.lc; p += blockDim.x) {
+        int m = 0;
+        for (int r = 0; r < G.nreads; ++r) {
+            const long long jb = job_of(G, r);
+            if (jb >= 0) m = max(m, static_cast<int>(A.ins[A.jobs[jb].out_off + p]));
+        }
+        A.maxins[A.mi_off[g] + p] = static_cast<uint16_t>(m);
+        local += m;
+    }
+    atomicAdd(reinterpret_cast<unsigned long long*>(&s_sum), static_cast<unsigned long long>(local));
+    __syncthreads();
+    if (threadIdx.x == 0) A.width[g] = static_cast<int32_t>(G.lc + s_sum);
+}
+
+// One block per (group, read): columns come from prefix sums over the centre positions.
+__global__ void k_msa_write(MergeArgs A, const long long* row_group, const int* row_pos, long long nrows) {
+    const long long row = blockIdx.x;
+    if (row >= nrows) return;
+    const long long g = row_group[row];
+    const int r = row_pos[row];
+    const MsaGroup G = A.groups[g];
+    const long long id = A.members[G.read0 + r] - 1;
+    const uint8_t* src = A.seq + A.seq_off[id];
+    const int W = A.width[g];
+    uint8_t* dst = A.out + A.out_off[g] + static_cast<long long>(r) * W;
+    if (G.nreads == 1) {  // verbatim (src/quick_msa.cpp:46-50)
+        for (int p = threadIdx.x; p < W; p += blockDim.x) dst[p] = src[p];
+        return;
+    }
+    const long long jb = job_of(G, r);
+    const uint16_t* ins = jb >= 0 ? A.ins + A.jobs[jb].out_off : nullptr;
+    const uint8_t* aln = jb >= 0 ? A.aln + A.jobs[jb].out_off : nullptr;
+    const uint16_t* mi = A.maxins + A.mi_off[g];
+    // serial chunked prefix: each thread owns a contiguous slice of centre positions
+    const int lc = G.lc;
+    const int per = (lc + 1 + blockDim.x - 1) / blockDim.x;
+    const int p0 = min(static_cast<int>(threadIdx.x) * per, lc + 1), p1 = min(p0 + per, lc + 1);
+    __shared__ long long s_col[1024], s_rp[1024];
+    long long ccol = 0, crp = 0;
+    for (int p = p0; p < p1; ++p) {
+        ccol += mi[p] + (p < lc ? 1 : 0);
+        crp += (ins ? ins[p] : 0) + ((p < lc) ? (aln ? aln[p] : 1) : 0);
+    }
+    s_col[threadIdx.x] = ccol;
+    s_rp[threadIdx.x] = crp;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long a = 0, b = 0;
+        for (unsigned t = 0; t < blockDim.x; ++t) {
+            const long long x = s_col[t], y = s_rp[t];
+            s_col[t] = a; s_rp[t] = b;
+            a += x; b += y;
+        }
+    }
+    __syncthreads();
+    long long col = s_col[threadIdx.x], rp = s_rp[threadIdx.x];
+    for (int p = p0; p < p1; ++p) {
+        const int k = ins ? ins[p] : 0;
+        const int m = mi[p];
+        for (int x = 0; x < k; ++x) dst[col++] = "ACGTN"[dna5_code(src[rp++])];
+        for (int x = k; x < m; ++x) dst[col++] = '-';
+        if (p < lc) {
+            const bool matched = aln ? aln[p] != 0 : true;
+            dst[col++] = matched ? "ACGTN"[dna5_code(src[rp++])] : '-';
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+template <int C>
+static int launch_pairwise(const MsaArgs& a, int grid, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL(k_msa_pairwise<C>, dim3(grid), dim3(64), lds, s, a);
+    SL_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace sarlacc
+
+using namespace sarlacc;
+
+extern "C" int sarlacc_quick_msa(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq,
+                                 const int64_t* seq_off, int64_t nseq, double match, double mismatch,
+                                 double gap_extension, double gap_opening, int bandwidth, int32_t* width_out,
+                                 int64_t* out_off, char* out, int64_t out_cap) {
+    if (ngroups < 0 || nseq < 0) return fail("sarlacc_amd: negative sizes");
+    out_off[0] = 0;
+    if (ngroups == 0) return 0;
+    if (bandwidth < 0) return fail("sarlacc_amd: negative bandwidth");
+    const int64_t nmemb = grp_off[ngroups] - grp_off[0];
+    for (int64_t i = 0; i < nmemb; ++i) {
+        const int32_t v = grp[grp_off[0] + i];
+        if (v < 1 || v > nseq) return fail("sarlacc_amd: group index %d outside 1..%lld", v, static_cast<long long>(nseq));
+    }
+    // ---- host-side job list: centre = lower median by (length, position) ----
+    std::vector<MsaGroup> groups(static_cast<size_t>(ngroups));
+    std::vector<MsaJob> jobs;
+    std::vector<long long> mi_off(static_cast<size_t>(ngroups) + 1, 0), row_group;
+    std::vector<int> row_pos;
+    long long pair_out = 0;
+    int max_lr = 0, max_lc = 0, max_band = 1;
+    std::vector<std::pair<int64_t, int>> order;
+    for (int64_t g = 0; g < ngroups; ++g) {
+        const int32_t* mem = grp + grp_off[g];
+        const int m = static_cast<int>(grp_off[g + 1] - grp_off[g]);
+        MsaGroup G{};
+        G.first_job = static_cast<long long>(jobs.size());
+        G.read0 = grp_off[g] - grp_off[0];
+        G.nreads = m;
+        G.centre = 0;
+        G.lc = 0;
+        auto len_of = [&](int r) { return seq_off[mem[r]] - seq_off[mem[r] - 1]; };
+        if (m >= 2) {
+            order.clear();
+            for (int r = 0; r < m; ++r) order.emplace_back(len_of(r), r);
+            std::sort(order.begin(), order.end());
+            G.centre = order[(m - 1) / 2].second;
+            const int64_t lc = len_of(G.centre);
+            if (lc > 60000) return fail("sarlacc_amd: reads longer than 60000 bases are not supported by the MSA stage");
+            G.lc = static_cast<int>(lc);
+            for (int r = 0; r < m; ++r) {
+                if (r == G.centre) continue;
+                const int64_t lr = len_of(r);
+                if (lr > 60000) return fail("sarlacc_amd: reads longer than 60000 bases are not supported by the MSA stage");
+                MsaJob J{};
+                J.read_off = seq_off[mem[r] - 1] - seq_off[0];
+                J.ctr_off = seq_off[mem[G.centre] - 1] - seq_off[0];
+                J.out_off = pair_out;
+                J.lr = static_cast<int>(lr);
+                J.lc = G.lc;
+                pair_out += G.lc + 1;
+                jobs.push_back(J);
+                max_lr = std::max(max_lr, J.lr);
+                const long long band = std::llabs(static_cast<long long>(G.lc) - J.lr) + 2LL * bandwidth + 1;
+                if (band > 1024) return fail("sarlacc_amd: alignment band of %lld diagonals exceeds 1024 (length difference + 2*bandwidth + 1)", band);
+                max_band = std::max(max_band, static_cast<int>(band));
+            }
+            max_lc = std::max(max_lc, G.lc);
+        }
+        mi_off[g + 1] = mi_off[g] + (m >= 2 ? G.lc + 1 : 0);
+        for (int r = 0; r < m; ++r) { row_group.push_back(g); row_pos.push_back(r); }
+        groups[g] = G;
+    }
+    SL_TRY(ensure_device());
+    hipStream_t s = nullptr;
+    Context& c = ctx();
+    const int64_t total = nseq ? seq_off[nseq] - seq_off[0] : 0;
+    std::vector<int64_t> rel(static_cast<size_t>(nseq) + 1);
+    for (int64_t i = 0; i <= nseq; ++i) rel[i] = (nseq ? seq_off[i] : 0) - (nseq ? seq_off[0] : 0);
+
+    uint8_t* d_seq; int64_t* d_soff; int32_t* d_mem; MsaGroup* d_groups; MsaJob* d_jobs; long long* d_mioff;
+    SL_TRY(upload("msa.seq", reinterpret_cast<const uint8_t*>(seq) + (nseq ? seq_off[0] : 0), static_cast<size_t>(total), &d_seq, s));
+    SL_TRY(upload("msa.soff", rel.data(), rel.size(), &d_soff, s));
+    SL_TRY(upload("msa.mem", grp + grp_off[0], static_cast<size_t>(nmemb), &d_mem, s));
+    SL_TRY(upload("msa.groups", groups.data(), groups.size(), &d_groups, s));
+    SL_TRY(upload("msa.jobs", jobs.data(), jobs.size(), &d_jobs, s));
+    SL_TRY(upload("msa.mioff", mi_off.data(), mi_off.size(), &d_mioff, s));
+
+    uint16_t* d_ins; uint8_t* d_aln; uint16_t* d_maxins; int32_t* d_width;
+    SL_TRY(scratch("msa.ins", static_cast<size_t>(pair_out) + 1, &d_ins));
+    SL_TRY(scratch("msa.aln", static_cast<size_t>(pair_out) + 1, &d_aln));
+    SL_TRY(scratch("msa.maxins", static_cast<size_t>(mi_off[ngroups]) + 1, &d_maxins));
+    SL_TRY(scratch("msa.width", static_cast<size_t>(ngroups), &d_width));
+
+    if (!jobs.empty()) {
+        const int C = max_band <= 256 ? 4 : (max_band <= 512 ? 8 : 16);
+        const size_t word = C == 16 ? 8 : 4;
+        const size_t per_wave = (static_cast<size_t>(max_lr) + 2) * 64;
+        long long grid = std::min<long long>(static_cast<long long>(jobs.size()), static_cast<long long>(c.num_cu) * 8);
+        const size_t budget = static_cast<size_t>(8) << 30;
+        grid = std::min<long long>(grid, std::max<long long>(1, static_cast<long long>(budget / (per_wave * word))));
+        void* d_tb;
+        SL_TRY(c.buffer("msa.tb", static_cast<size_t>(grid) * per_wave * word, &d_tb));
+        MsaArgs a{};
+        a.seq = d_seq; a.jobs = d_jobs; a.njobs = static_cast<int>(jobs.size());
+        a.ma = static_cast<int>(match); a.mm = static_cast<int>(mismatch);
+        // SeqAn's Score(match, mismatch, gap_extend, gap_open): gap of length k = open + (k-1)*extend
+        a.go = static_cast<int>(gap_opening); a.ge = static_cast<int>(gap_extension);
+        a.bw = bandwidth; a.ins = d_ins; a.aln = d_aln; a.tb = d_tb; a.tb_per_wave = per_wave;
+        a.ctr_cap = max_lc + 16;
+        const size_t lds = TB_ROWS * 64 * word + static_cast<size_t>(max_lc) + 64;
+        SL_HIP(hipEventRecord(c.ev_start, s));
+        if (C == 4) SL_TRY(launch_pairwise<4>(a, static_cast<int>(grid), lds, s));
+        else if (C == 8) SL_TRY(launch_pairwise<8>(a, static_cast<int>(grid), lds, s));
+        else SL_TRY(launch_pairwise<16>(a, static_cast<int>(grid), lds, s));
+        SL_HIP(hipEventRecord(c.ev_stop, s));
+        c.timed = true;
+    }
+    MergeArgs m{};
+    m.seq = d_seq; m.seq_off = d_soff; m.members = d_mem; m.groups = d_groups; m.jobs = d_jobs; m.ngroups = ngroups;
+    m.ins = d_ins; m.aln = d_aln; m.maxins = d_maxins; m.mi_off = d_mioff; m.width = d_width;
+    hipLaunchKernelGGL(k_msa_width, dim3(static_cast<unsigned>(ngroups)), dim3(256), 0, s, m);
+    SL_HIP(hipGetLastError());
+    std::vector<int32_t> width(static_cast<size_t>(ngroups));
+    SL_HIP(hipMemcpy(width.data(), d_width, sizeof(int32_t) * width.size(), hipMemcpyDeviceToHost));
+    std::vector<long long> ooff(static_cast<size_t>(ngroups) + 1, 0);
+    for (int64_t g = 0; g < ngroups; ++g) {
+        width_out[g] = width[g];
+        ooff[g + 1] = ooff[g] + static_cast<long long>(width[g]) * groups[g].nreads;
+        out_off[g + 1] = ooff[g + 1];
+    }
+    if (!out) return 0;  // sizing call
+    if (out_cap < ooff[ngroups]) return fail("sarlacc_amd: MSA output buffer too small (%lld needed)", ooff[ngroups]);
+    if (ooff[ngroups] == 0) return 0;
+    long long* d_ooff; long long* d_rg; int* d_rp; uint8_t* d_out;
+    SL_TRY(upload("msa.ooff", ooff.data(), ooff.size(), &d_ooff, s));
+    SL_TRY(upload("msa.rg", row_group.data(), row_group.size(), &d_rg, s));
+    SL_TRY(upload("msa.rp", row_pos.data(), row_pos.size(), &d_rp, s));
+    SL_TRY(scratch("msa.out", static_cast<size_t>(ooff[ngroups]), &d_out));
+    m.out_off = d_ooff; m.out = d_out;
+    const long long nrows = static_cast<long long>(row_group.size());
+    hipLaunchKernelGGL(k_msa_write, dim3(static_cast<unsigned>(nrows)), dim3(256), 0, s, m, d_rg, d_rp, nrows);
+    SL_HIP(hipGetLastError());
+    SL_HIP(hipMemcpy(out, d_out, static_cast<size_t>(ooff[ngroups]), hipMemcpyDeviceToHost));
+    return 0;
+}
