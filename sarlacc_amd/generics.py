@@ -1,0 +1,270 @@
+"""Counterparts of the reference's exported R generics on the hot path
+(/root/reference/R/*.R), written against sarlacc_amd.calls the same way the R
+functions are written against `.Call(cxx_*)`.  The reference's toolchain (R,
+Biostrings, S4Vectors) is absent from the build image, so this host layer is Python;
+names, argument meaning, defaults, return structure and error behaviour follow the R
+code, with plain containers standing in for the Bioconductor classes:
+
+    QualityScaledDNAStringSet  ->  Reads(seq, qual, names)
+    DataFrame                  ->  dict of numpy arrays / lists (+ "metadata" dict)
+
+Only orchestration lives here -- every arithmetic step is a call into the HIP library.
+"""
+import re
+
+import numpy as np
+
+from . import calls
+from .encoding import Encoding, phred_encoding
+from .mock import _COMP
+from .strset import StringSet
+
+
+class Reads:
+    """Minimal stand-in for QualityScaledDNAStringSet: sequences + (optional) Phred+33 qualities."""
+
+    def __init__(self, seq, qual=None, names=None, encoding=None):
+        self.seq = StringSet.from_strings(seq)
+        self.qual = None if qual is None else StringSet.from_strings(qual)
+        if self.qual is not None and len(self.qual) != len(self.seq):
+            raise ValueError("sequence and quality vectors should have the same length")
+        self.names = list(names) if names is not None else None
+        self.encoding = encoding if encoding is not None else phred_encoding()
+
+    def __len__(self):
+        return len(self.seq)
+
+    def width(self):
+        return self.seq.widths()
+
+    def subset(self, idx):
+        idx = np.asarray(idx, dtype=np.int64)
+        return Reads(self.seq.subset(idx), None if self.qual is None else self.qual.subset(idx),
+                     None if self.names is None else [self.names[i] for i in idx], self.encoding)
+
+
+def read_fastq(path):
+    """4-line FASTQ -> Reads (the reference streams with ShortRead::FastqStreamer,
+    R/adaptorAlign.R:26-37; ingest is host IO and stays on the host)."""
+    names, seqs, quals = [], [], []
+    with open(path, "rb") as fh:
+        while True:
+            h = fh.readline()
+            if not h:
+                break
+            s = fh.readline().rstrip(b"\r\n")
+            fh.readline()
+            q = fh.readline().rstrip(b"\r\n")
+            names.append(h[1:].rstrip(b"\r\n").decode())
+            seqs.append(s.upper())
+            quals.append(q)
+    return Reads(seqs, quals, names)
+
+
+def write_fastq(path, reads, append=False):
+    with open(path, "ab" if append else "wb") as fh:
+        for i, (s, q) in enumerate(zip(reads.seq.to_strings(), reads.qual.to_strings())):
+            name = reads.names[i] if reads.names else "READ_%d" % (i + 1)
+            fh.write(b"@" + name.encode() + b"\n" + s.encode() + b"\n+\n" + q.encode() + b"\n")
+
+
+# ---------------------------------------------------------------------------
+# adaptorAlign (R/adaptorAlign.R)
+
+def _setup_subseqs(adaptor):
+    """.setup_subseqs (R/adaptorAlign.R:136-143): maximal runs of non-ACTG, 1-based inclusive."""
+    starts, ends = [], []
+    for m in re.finditer(r"[^ACTG]+", adaptor):
+        starts.append(m.start() + 1)
+        ends.append(m.end())
+    return {"starts": np.array(starts, dtype=np.int32), "ends": np.array(ends, dtype=np.int32)}
+
+
+def _subseq(ss, start, width):
+    """XVector::subseq on a StringSet with per-element 1-based start and width."""
+    start = np.asarray(start, dtype=np.int64)
+    width = np.asarray(width, dtype=np.int64)
+    off = np.zeros(len(ss) + 1, dtype=np.int64)
+    np.cumsum(width, out=off[1:])
+    total = int(off[-1])
+    chars = np.zeros(max(total, 1), np.uint8)
+    if total:
+        src = np.repeat(ss.off[:-1] + start - 1 - off[:-1], width) + np.arange(total, dtype=np.int64)
+        chars[:total] = ss.chars[src]
+    return StringSet(chars, off)
+
+
+def _reverse_each(ss, complement):
+    """Per-string reversal (optionally complemented) of a StringSet."""
+    total = ss.total
+    chars = np.zeros(max(total, 1), np.uint8)
+    if total:
+        w = ss.widths()
+        pos = np.arange(total, dtype=np.int64) - np.repeat(ss.off[:-1], w)
+        src = np.repeat(ss.off[:-1] + w - 1, w) - pos
+        vals = ss.chars[src]
+        chars[:total] = _COMP[vals] if complement else vals
+    return StringSet(chars, ss.off.copy())
+
+
+def _get_front_and_back(reads, tolerance):
+    """.get_front_and_back (R/adaptorAlign.R:86-95): first min(tol,width) bases, and the
+    reverse complement of the last min(tol,width) bases (qualities reversed)."""
+    w = reads.width()
+    tol = np.minimum(int(tolerance), w)
+    front = Reads(_subseq(reads.seq, np.ones(len(w), np.int64), tol), _subseq(reads.qual, np.ones(len(w), np.int64), tol),
+                  encoding=reads.encoding)
+    bstart = w - tol + 1
+    back = Reads(_reverse_each(_subseq(reads.seq, bstart, tol), True), _reverse_each(_subseq(reads.qual, bstart, tol), False),
+                 encoding=reads.encoding)
+    return front, back
+
+
+def _align_and_extract(adaptor, reads, gap_opening, gap_extension, subseq_starts, subseq_ends):
+    """.align_and_extract (R/adaptorAlign.R:145-178)."""
+    out = calls.adaptor_align(reads.seq, reads.qual, reads.encoding, gap_opening, gap_extension, adaptor,
+                              np.asarray(subseq_starts, dtype=np.int32) - 1, subseq_ends)
+    res = {"score": out[0], "start": out[1], "end": out[2], "subseq": {}}
+    for i, (st, wd) in enumerate(zip(out[3], out[4])):
+        res["subseq"]["Sub%d" % (i + 1)] = _subseq(reads.seq, st, wd).to_strings()
+    return res
+
+
+def _resolve_strand(start_score, end_score, rc_start_score, rc_end_score):
+    """.resolve_strand (R/adaptorAlign.R:112-122): reverse iff fscore < rscore (strict)."""
+    fscore = np.maximum(start_score, 0) + np.maximum(end_score, 0)
+    rscore = np.maximum(rc_start_score, 0) + np.maximum(rc_end_score, 0)
+    rev = fscore < rscore
+    return rev, np.where(rev, rscore, fscore)
+
+
+def _swap_rows(a, b, mask):
+    for key in ("score", "start", "end"):
+        a[key] = np.where(mask, b[key], a[key])
+    for k in a["subseq"]:
+        a["subseq"][k] = [y if m else x for x, y, m in zip(a["subseq"][k], b["subseq"][k], mask)]
+
+
+def adaptorAlign(adaptor1, adaptor2, reads, tolerance=250, gapOpening=5, gapExtension=1):
+    """adaptorAlign (R/adaptorAlign.R:7-78).  `reads` is a Reads object or a FASTQ path."""
+    adaptor1, adaptor2 = str(adaptor1).upper(), str(adaptor2).upper()
+    filepath = None
+    if isinstance(reads, str):
+        filepath = reads
+        reads = read_fastq(reads)
+    sub1, sub2 = _setup_subseqs(adaptor1), _setup_subseqs(adaptor2)
+    front, back = _get_front_and_back(reads, tolerance)
+    args = (gapOpening, gapExtension)
+    cur_starts = _align_and_extract(adaptor1, front, *args, sub1["starts"], sub1["ends"])
+    cur_ends = _align_and_extract(adaptor2, back, *args, sub2["starts"], sub2["ends"])
+    rc_starts = _align_and_extract(adaptor1, back, *args, sub1["starts"], sub1["ends"])
+    rc_ends = _align_and_extract(adaptor2, front, *args, sub2["starts"], sub2["ends"])
+    rev, _ = _resolve_strand(cur_starts["score"], cur_ends["score"], rc_starts["score"], rc_ends["score"])
+    _swap_rows(cur_starts, rc_starts, rev)
+    _swap_rows(cur_ends, rc_ends, rev)
+    width = reads.width().astype(np.int32)
+    # adaptor 2 was aligned on the reverse strand: report in read coordinates (:67-71)
+    cur_ends["start"], cur_ends["end"] = (width - cur_ends["start"] + 1).astype(np.int32), (width - cur_ends["end"] + 1).astype(np.int32)
+    details = {"gapOpening": gapOpening, "gapExtension": gapExtension}
+    cur_starts["metadata"] = dict(sequence=adaptor1, **details)
+    cur_ends["metadata"] = dict(sequence=adaptor2, **details)
+    return {"read.width": width, "adaptor1": cur_starts, "adaptor2": cur_ends, "reversed": rev,
+            "names": reads.names, "metadata": {"filepath": filepath, "qual.type": "phred", "tolerance": tolerance}}
+
+
+# ---------------------------------------------------------------------------
+def barcodeAlign(sequences, barcodes, gapOpening=5, gapExtension=1):
+    """barcodeAlign (R/barcodeAlign.R:4-40): best barcode, its score, and the gap to the next best."""
+    n = len(sequences)
+    current = np.full(n, -np.inf)
+    nextbest = np.full(n, -np.inf)
+    ident = np.full(n, -1, dtype=np.int64)  # NA_integer_
+    for b, bc in enumerate(barcodes):
+        scores = calls.barcode_align(sequences.seq, sequences.qual, sequences.encoding, gapOpening, gapExtension, str(bc))
+        keep = scores > current
+        second = ~keep & (scores > nextbest)
+        ident[keep] = b + 1
+        nextbest[keep] = current[keep]
+        current[keep] = scores[keep]
+        nextbest[second] = scores[second]
+    return {"barcode": ident, "score": current, "gap": current - nextbest,
+            "metadata": {"gapOpening": gapOpening, "gapExtension": gapExtension, "barcodes": list(barcodes)}}
+
+
+def qualityAlign(sequences, reference, gapOpening=5, gapExtension=1, edit_only=False):
+    """qualityAlign (R/qualityAlign.R:4-27)."""
+    ref = str(reference).upper()
+    out = calls.general_align(sequences.seq, sequences.qual, sequences.encoding, gapOpening, gapExtension, ref, edit_only)
+    res = {"score": out[0], "edit": out[1]}
+    if not edit_only:
+        res["reference"], res["query"] = out[2], out[3]
+    res["metadata"] = {"gapOpening": gapOpening, "gapExtension": gapExtension, "reference": reference}
+    return res
+
+
+# ---------------------------------------------------------------------------
+def qualityMask(seq, max_err):
+    """qualityMask (R/qualityMask.R:5-16): mask when max_err is given and qualities exist."""
+    has_quals = isinstance(seq, Reads) and seq.qual is not None
+    if max_err is not None and not (isinstance(max_err, float) and np.isnan(max_err)) and has_quals:
+        return StringSet.from_strings(calls.mask_bad_bases(seq.seq, seq.qual, seq.encoding, max_err))
+    return seq.seq if isinstance(seq, Reads) else StringSet.from_strings(seq)
+
+
+def umiGroup(UMI1, threshold1=3, UMI2=None, threshold2=None, max_err=None, groups=None):
+    """umiGroup (R/umiGroup.R:2-23): list of clusters of 1-based read indices."""
+    if threshold2 is None:
+        threshold2 = threshold1
+    u1 = qualityMask(UMI1, max_err)
+    u2 = qualityMask(UMI2, max_err) if UMI2 is not None else None
+    n = len(u1)
+    if groups is None:
+        by_group = [np.arange(1, n + 1, dtype=np.int32)]
+    elif len(groups) and np.ndim(groups[0]) == 0:
+        g = np.asarray(groups)
+        by_group = [np.flatnonzero(g == lev).astype(np.int32) + 1 for lev in np.unique(g)]  # split(seq_along, groups)
+    else:
+        by_group = [np.asarray(x, dtype=np.int32) for x in groups]
+    return calls.umi_group(u1, threshold1, u2, threshold2, by_group)
+
+
+def expectedDist(sequences, max_err=None):
+    """expectedDist (R/expectedDist.R:2-11)."""
+    return calls.compute_lev_masked(qualityMask(sequences, max_err))
+
+
+# ---------------------------------------------------------------------------
+def multiReadAlign(reads, groups, max_error=None, match=0, mismatch=-1, gapOpening=5, gapExtension=1, bandwidth=100):
+    """multiReadAlign (R/multiReadAlign.R:7-44).  `groups`: list of 1-based index vectors, or a
+    per-read grouping vector.  `max_error` is accepted and ignored like in the reference (App.B Q16)."""
+    rd = reads if isinstance(reads, Reads) else Reads(reads)
+    n = len(rd)
+    names = None
+    if len(groups) and np.ndim(groups[0]) == 0:
+        g = np.asarray(groups)
+        if g.size != n:
+            raise ValueError("length of 'reads' and 'groups' should be the same")
+        levels = np.unique(g)
+        by_group = [np.flatnonzero(g == lev).astype(np.int32) + 1 for lev in levels]
+        names = [str(x) for x in levels]
+    else:
+        by_group = [np.asarray(x, dtype=np.int32) for x in groups]
+    aln = calls.quick_msa(by_group, rd.seq, match, mismatch, -gapOpening, -gapExtension, bandwidth)
+    out = {"alignments": aln, "names": names}
+    if rd.qual is not None:
+        q = rd.qual.to_strings()
+        out["qualities"] = [[q[i - 1] for i in idx] for idx in by_group]
+        out["encoding"] = rd.encoding
+    return out
+
+
+def consensusReadSeq(alignments, pseudo_count=1, min_coverage=0.6):
+    """consensusReadSeq (R/consensusReadSeq.R:5-26): quality-weighted vote when qualities are
+    present, count-based otherwise.  Returns Reads(consensus, Phred+33 qualities)."""
+    aln = alignments["alignments"]
+    qual = alignments.get("qualities")
+    if qual is not None:
+        out = calls.create_consensus_quality_loop(aln, min_coverage, qual, alignments.get("encoding", phred_encoding()))
+    else:
+        out = calls.create_consensus_basic_loop(aln, min_coverage, pseudo_count)
+    return Reads(out[0], out[1], alignments.get("names"))

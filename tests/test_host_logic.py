@@ -1,0 +1,154 @@
+"""CPU tests of the host-side logic (no GPU): string-set plumbing, the R-generic
+counterparts' pure logic, the mock generator, the C-ABI surface, and the
+fail-loudly-without-a-GPU contract."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "sarlacc_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(sarlacc_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 19
+    so = os.path.join(ROOT, "sarlacc_amd", "libsarlacc_amd.so")
+    if not os.path.exists(so):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(so)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_product_fails_loudly_without_gpu():
+    import sarlacc_amd
+    from sarlacc_amd import calls
+    if sarlacc_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(sarlacc_amd.SarlaccError, match="no HIP device"):
+        calls.adaptor_align(["ACGT"], ["IIII"], sarlacc_amd.phred_encoding(), 5, 1, "ACG", [], [])
+    with pytest.raises(sarlacc_amd.SarlaccError, match="no HIP device"):
+        calls.umi_group(["ACGT", "ACGA"], 1, None, 1, [[1, 2]])
+    with pytest.raises(sarlacc_amd.SarlaccError, match="no HIP device"):
+        calls.create_consensus_basic(["ACGT"], 0.6, 1)
+    with pytest.raises(sarlacc_amd.SarlaccError, match="no HIP device"):
+        calls.quick_msa([[1, 2]], ["ACGT", "ACGA"], 0, -1, -5, -1, 100)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sarlacc_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                txt = open(os.path.join(base, f)).read()
+                assert "oracle" not in txt.replace("oracle/msa.c", "").replace("checker: oracle", "") or f in (), (f,)
+
+
+def test_stringset_roundtrip_and_subset():
+    from sarlacc_amd.strset import StringSet, csr_from_lists, lists_from_csr
+    strs = ["ACGT", "", "A", "GGGTTT"]
+    ss = StringSet.from_strings(strs)
+    assert ss.to_strings() == strs and len(ss) == 4 and ss.total == 11
+    assert ss.subset([3, 0, 1]).to_strings() == ["GGGTTT", "ACGT", ""]
+    assert StringSet.from_strings([]).to_strings() == []
+    off, vals = csr_from_lists([[1, 2], [], [3]])
+    assert [x.tolist() for x in lists_from_csr(off, vals)] == [[1, 2], [], [3]]
+
+
+def test_setup_subseqs_known_values():
+    # tests/testthat/test-adaptor-align.R:124-128
+    from sarlacc_amd.generics import _setup_subseqs
+    for ad, (s, e) in {"AAAAGGNNNNCCTTTT": (7, 10), "AAAAGGYYYYCCTTTT": (7, 10), "AAAAGGCCTTTTRRRR": (13, 16)}.items():
+        out = _setup_subseqs(ad)
+        assert out["starts"].tolist() == [s] and out["ends"].tolist() == [e]
+    out = _setup_subseqs("ACGT")
+    assert out["starts"].size == 0 and out["ends"].size == 0
+    out = _setup_subseqs("NNACGNNNT")
+    assert out["starts"].tolist() == [1, 6] and out["ends"].tolist() == [2, 8]
+
+
+def test_front_and_back():
+    # tests/testthat/test-adaptor-align.R:130-139
+    from sarlacc_amd.generics import Reads, _get_front_and_back
+    from sarlacc_amd.mock import revcomp
+    seqs = ["AAAAGGGGCCCCTTTT", "ACGTACGTACGTAAAAGGGGCCCCTTTT", "GGGGCCCC", ""]
+    quals = ["".join(chr(40 + (i % 50)) for i in range(len(s))) for s in seqs]
+    rd = Reads(seqs, quals)
+    front, back = _get_front_and_back(rd, 10)
+    assert front.seq.to_strings() == [s[:10] for s in seqs]
+    assert [revcomp(b) for b in back.seq.to_strings()] == [s[max(0, len(s) - 10):] for s in seqs]
+    assert back.qual.to_strings() == [q[max(0, len(q) - 10):][::-1] for q in quals]
+    front, back = _get_front_and_back(rd, 10000)
+    assert front.seq.to_strings() == seqs and [revcomp(b) for b in back.seq.to_strings()] == seqs
+
+
+def test_resolve_strand():
+    from sarlacc_amd.generics import _resolve_strand
+    rev, sc = _resolve_strand(np.array([5.0, -3.0, 2.0]), np.array([1.0, -1.0, 2.0]),
+                              np.array([2.0, 4.0, 2.0]), np.array([3.0, -9.0, 2.0]))
+    assert rev.tolist() == [False, True, False] and sc.tolist() == [6.0, 4.0, 4.0]
+
+
+def test_mock_reads_shape():
+    from sarlacc_amd.mock import mock_reads, revcomp
+    a1 = "ACGATCAGC" + "N" * 12 + "GTCAGTCAG"
+    sim = mock_reads(a1, "CACACTGAGCAGCGACTAGACA", nmolecules=5, nreads=4, seqlen=300, seed=1)
+    assert len(sim["reads"]) == 20 and len(sim["quals"]) == 20
+    assert (sim["reads"].widths() == sim["quals"].widths()).all()
+    assert all(len(u) == 12 for u in sim["umi"])
+    assert abs(np.mean(sim["reads"].widths()) - 352) < 15
+    assert revcomp("ACGTN") == "NACGT"
+
+
+def test_encoding_vector():
+    import sarlacc_amd
+    enc = sarlacc_amd.phred_encoding()
+    assert len(enc) == 94 and enc.names[:2] == b"!\"" and enc.errors[0] == 1.0 and abs(enc.errors[20] - 0.01) < 1e-15
+    assert enc.to_error(b"!5~").tolist() == [1.0, 10 ** -2.0, 10 ** -9.3]
+
+
+def test_generic_pipeline_runs_on_the_oracle(monkeypatch):
+    """BASELINE config 1 (plumbing, no GPU): mockReads 1k x 1kb-shaped data through
+    adaptorAlign -> umiGroup -> multiReadAlign -> consensusReadSeq with the oracle standing
+    in for the HIP library.  Checks the host logic and the biology end to end."""
+    from sarlacc_amd import generics
+    from sarlacc_amd.mock import mock_reads
+    from tests import oracle_calls
+    from tests.test_oracle_umi import lev2
+    monkeypatch.setattr(generics, "calls", oracle_calls)
+    a1 = "ACGATCAGC" + "N" * 12 + "GTCAGTCAG"
+    a2 = "CACACTGAGCAGCGACTAGACA"
+    sim = mock_reads(a1, a2, nmolecules=12, nreads=8, seqlen=400, seed=1000)
+    rd = generics.Reads(sim["reads"], sim["quals"], ["R%d" % i for i in range(len(sim["reads"]))])
+    aln = generics.adaptorAlign(a1, a2, rd)
+    assert (aln["reversed"] == sim["flipped"]).mean() > 0.95
+    good = (aln["adaptor1"]["score"] > 10) & (aln["adaptor2"]["score"] > 5)
+    assert good.mean() > 0.8
+    # orient reads, take UMIs from the adaptor-1 section
+    umis = aln["adaptor1"]["subseq"]["Sub1"]
+    keep = np.flatnonzero(good)
+    groups = generics.umiGroup([umis[i] for i in keep], threshold1=2)
+    assert sorted(x for g in groups for x in g.tolist()) == list(range(1, len(keep) + 1))
+    # clusters are (almost) pure with respect to the molecule of origin
+    mol = sim["molecule"][keep]
+    big = [g for g in groups if len(g) >= 4]
+    assert len(big) >= 8
+    assert np.mean([len(set(mol[g - 1])) == 1 for g in big]) > 0.9
+    # orient and trim, then MSA + consensus per cluster
+    from sarlacc_amd.mock import revcomp
+    seqs, quals = sim["reads"].to_strings(), sim["quals"].to_strings()
+    orient_s = [revcomp(seqs[i]) if aln["reversed"][i] else seqs[i] for i in keep]
+    orient_q = [quals[i][::-1] if aln["reversed"][i] else quals[i] for i in keep]
+    msa = generics.multiReadAlign(generics.Reads(orient_s, orient_q), big)
+    cons = generics.consensusReadSeq(msa)
+    assert len(cons) == len(big)
+    for c, g in zip(cons.seq.to_strings(), big):
+        truth = sim["reference"][mol[g[0] - 1]]
+        assert lev2(c, truth) / 2 <= 0.05 * len(truth)
+    basic = generics.consensusReadSeq({"alignments": msa["alignments"]})
+    assert len(basic) == len(big)
