@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 namespace sarlacc {
@@ -493,14 +494,21 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t*
     const int sentinel = std::numeric_limits<int>::max();
     SL_TRY(upload("align.bad", &sentinel, 1, &d_bad, stream));
 
-    const Shape sh = pick_shape(R);
+    Shape sh = pick_shape(R);
+    if (const char* ek = std::getenv("SARLACC_ALIGN_K")) {  // tuning override
+        const int K = std::atoi(ek);
+        const int W = (R + K - 1) / K;
+        if ((K == 1 || K == 2 || K == 4 || K == 8 || K == 16) && W <= 64) sh = {K, W, std::min(64 / W, NGMAX)};
+    }
     const bool wide = max_len > 32000;  // jump lengths no longer fit int16
     const size_t dir_bytes = wide ? 4 : 2;
     const long long nitems = (n + sh.ngroups - 1) / sh.ngroups;
 
     // persistent grid: enough waves to fill the chip, bounded by the scratch budget
     const size_t per_wave_elems = kernel_mode ? (static_cast<size_t>(max_len) + sh.W + 1) * 64 * sh.K : 0;
-    long long grid = std::min<long long>(nitems, static_cast<long long>(c.num_cu) * 12);
+    int waves_per_cu = 12;
+    if (const char* ew = std::getenv("SARLACC_ALIGN_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(ew));
+    long long grid = std::min<long long>(nitems, static_cast<long long>(c.num_cu) * waves_per_cu);
     if (kernel_mode) {
         const size_t budget = static_cast<size_t>(6) << 30;
         const long long fit = std::max<long long>(1, static_cast<long long>(budget / std::max<size_t>(1, per_wave_elems * dir_bytes)));
