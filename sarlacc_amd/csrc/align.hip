@@ -506,7 +506,7 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t*
 
     // persistent grid: enough waves to fill the chip, bounded by the scratch budget
     const size_t per_wave_elems = kernel_mode ? (static_cast<size_t>(max_len) + sh.W + 1) * 64 * sh.K : 0;
-    int waves_per_cu = 12;
+    int waves_per_cu = 16;
     if (const char* ew = std::getenv("SARLACC_ALIGN_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(ew));
     long long grid = std::min<long long>(nitems, static_cast<long long>(c.num_cu) * waves_per_cu);
     if (kernel_mode) {
