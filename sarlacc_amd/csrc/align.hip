@@ -76,15 +76,24 @@ __device__ __forceinline__ double dpp_shr1(double v) {
     return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
 }
 
-template <typename DirT, int K>
-struct alignas(sizeof(DirT) * K <= 16 ? sizeof(DirT) * K : 16) DirPack {
-    DirT v[K];
+// Directions of UNR consecutive steps x K columns of one lane, stored with one instruction.
+template <typename DirT, int N>
+struct alignas(sizeof(DirT) * N <= 16 ? sizeof(DirT) * N : 16) DirPack {
+    DirT v[N];
+};
+
+template <int K, typename DirT>
+struct Unroll {
+    static constexpr int raw = 16 / (K * static_cast<int>(sizeof(DirT)));
+    static constexpr int value = raw > 0 ? raw : 1;  // steps whose directions fill one 16-byte store
 };
 
 // MODE 0: scores only.  MODE 1: scores + reference->read map (adaptor_align).
 // MODE 2: scores + gapped strings + edit distance (general_align).
-template <int K, typename DirT, int MODE>
+// LOCAL: free leading read bases + free vertical gaps in the last column (adaptor mode).
+template <int K, typename DirT, int MODE, bool LOCAL>
 __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
+    constexpr int UNR = Unroll<K, DirT>::value;
     extern __shared__ __align__(16) unsigned char smem[];
     double* s_tab = reinterpret_cast<double*>(smem);
     uint16_t* s_ring = reinterpret_cast<uint16_t*>(s_tab + 5 * A.navail);
@@ -99,22 +108,22 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
     const int c0 = j * K + 1;
     const double NEG_INF = -__builtin_huge_val();
     const double GO = A.GO, GE = A.GE;
-    const bool local = A.local != 0;
+    constexpr bool local = LOCAL;
 
     for (int x = lane; x < 5 * A.navail; x += 64) s_tab[x] = A.tables[x];
 
     double vgo[K], vge[K], rz[K];
     int refcode[K], tm[K], tmm[K];
-    bool colon[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int c = c0 + k;
-        colon[k] = lane_on && c <= R;
+        // columns past R (last lane when K does not divide R) reuse column R's tables: they
+        // compute garbage that nothing reads (their outputs only feed a leader or an idle lane)
         const int cc = c <= R ? c : R;
         const uint32_t info = A.colinfo[cc];
         refcode[k] = info & 0xff;
-        tm[k] = ((info >> 8) & 0xff) * A.navail;
-        tmm[k] = ((info >> 16) & 0xff) * A.navail;
+        tm[k] = static_cast<int>(((info >> 8) & 0xff) * A.navail * sizeof(double));    // byte offsets into s_tab
+        tmm[k] = static_cast<int>(((info >> 16) & 0xff) * A.navail * sizeof(double));
         const bool last = local && cc == R;
         vgo[k] = last ? 0.0 : GO;
         vge[k] = last ? 0.0 : GE;
@@ -123,6 +132,7 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
     const double rz_left = A.rowzero[c0 - 1 <= R ? c0 - 1 : R];
     const int jlast = (R - 1) / K, klast = (R - 1) % K;
     DirT* const scr = static_cast<DirT*>(A.dirs) + static_cast<size_t>(blockIdx.x) * A.dirs_per_wave;
+    const unsigned char* const tab_bytes = reinterpret_cast<const unsigned char*>(s_tab);
     __syncthreads();
 
     const long long nitems = (A.n + A.ngroups - 1) / A.ngroups;
@@ -135,18 +145,19 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
             start = A.off[read];
             L = static_cast<int>(A.off[read + 1] - start);
         }
-        int Lmax = L;
-#pragma unroll
-        for (int m = 32; m; m >>= 1) Lmax = max(Lmax, __shfl_xor(Lmax, m));
-
+        // wave-uniform description of the (up to NGMAX) reads of this work item, kept in SGPRs
         long long gstart[NGMAX];
         int glen[NGMAX];
+        int Lmax = 0;
 #pragma unroll
         for (int gg = 0; gg < NGMAX; ++gg) {
             const int src = gg < A.ngroups ? gg * W : 0;
-            gstart[gg] = __shfl(start, src);
-            const int len = __shfl(L, src);
+            const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(start), src));
+            const int hi = __builtin_amdgcn_readlane(static_cast<int>(start >> 32), src);
+            const int len = __builtin_amdgcn_readlane(L, src);
+            gstart[gg] = (static_cast<long long>(hi) << 32) | lo;
             glen[gg] = gg < A.ngroups ? len : 0;
+            Lmax = max(Lmax, glen[gg]);
         }
 
         // read staging: fetch 64 positions per alignment one refill ahead of use
@@ -163,7 +174,8 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
             qi = qi < 0 ? 0 : (qi >= A.navail ? A.navail - 1 : qi);
             const uint32_t b = v >> 8;
             const uint32_t code = b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u;
-            s_ring[gg * RING + (r & (RING - 1))] = static_cast<uint16_t>(qi | (code << 8));
+            // quality index pre-scaled to a byte offset into an fp64 table
+            s_ring[gg * RING + (r & (RING - 1))] = static_cast<uint16_t>((qi << 3) | (code << 12));
         };
         uint32_t pf[NGMAX];
 #pragma unroll
@@ -177,82 +189,85 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
         double s_in = 0.0, lj_in = NEG_INF, diag_prev = rz_left;
         int lph_in = 0;  // left_jump_point * 2 + (left cell is a horizontal gap)
 
-        const int nsteps = Lmax + W;
-        for (int t = 0; t < nsteps; ++t) {
-            if ((t & 63) == 0) {
+        const int nsteps = ((Lmax + W + UNR - 1) / UNR) * UNR;
+        for (int t0 = 0; t0 < nsteps; t0 += UNR) {
+            if ((t0 & 63) == 0) {
 #pragma unroll
                 for (int gg = 0; gg < NGMAX; ++gg) {
-                    stage(gg, t, pf[gg]);
-                    pf[gg] = fetch(gg, t + 64);
+                    stage(gg, t0, pf[gg]);
+                    pf[gg] = fetch(gg, t0 + 64);
                 }
             }
-            const int i = t - j;
-            if (leader) {  // column 0 of the DP (src/reference_align.cpp:63-78)
-                s_in = (local || i < 1) ? 0.0 : (-GO - GE * static_cast<double>(i - 1));
-                lj_in = NEG_INF;
-                lph_in = 0;
-            }
-            double out_s = s_in, out_lj = lj_in;
-            int out_lph = lph_in;
-            DirPack<DirT, K> dk;
+            DirPack<DirT, UNR * K> pk;
 #pragma unroll
-            for (int k = 0; k < K; ++k) dk.v[k] = 0;
-
-            if (i == 0) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) { S[k] = rz[k]; UJ[k] = NEG_INF; UP[k] = 0; vneg[k] = false; }
-                diag_prev = rz_left;
-            } else if (valid && i >= 1 && i <= L) {
-                const uint32_t rd = s_ring[g * RING + ((i - 1) & (RING - 1))];
-                const int qi = rd & 0xff;
-                const int code = rd >> 8;
-                double diag = diag_prev;
-                diag_prev = s_in;
+            for (int u = 0; u < UNR; ++u) {
+                const int t = t0 + u;
+                const int i = t - j;
+                if (leader) {  // column 0 of the DP (src/reference_align.cpp:63-78)
+                    if (LOCAL) s_in = 0.0;
+                    else s_in = (i < 1) ? 0.0 : (-GO - GE * static_cast<double>(i - 1));
+                    lj_in = NEG_INF;
+                    lph_in = 0;
+                }
                 double left = s_in, lj = lj_in;
                 int lp = lph_in >> 1;
                 bool hp = lph_in & 1;
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    if (colon[k]) {
-                        const int pos = c0 + k - 1;
-                        // horizontal candidate
-                        double H = left - (hp ? GE : GO);
-                        lj = lj - GE;
-                        int hstep = 1;
-                        if (lj > H) { hstep = 1 + pos - lp; H = lj; }
-                        else { lj = H; lp = pos; }
-                        // vertical candidate
-                        double V = S[k] - (vneg[k] ? vge[k] : vgo[k]);
-                        UJ[k] = UJ[k] - vge[k];
-                        int vstep = 1;
-                        if (UJ[k] > V) { vstep = 1 + i - UP[k]; V = UJ[k]; }
-                        else { UJ[k] = V; UP[k] = i; }
-                        // (mis)match candidate
-                        const double w = s_tab[(code == refcode[k] ? tm[k] : tmm[k]) + qi];
-                        const double M = diag + w;
-                        diag = S[k];
-                        int d;
-                        double best;
-                        if (M > H && M > V) { best = M; d = 0; }
-                        else if (H > V) { best = H; d = hstep; }
-                        else { best = V; d = -vstep; }
-                        S[k] = best;
-                        left = best;
-                        hp = d > 0;
-                        vneg[k] = d < 0;
-                        dk.v[k] = static_cast<DirT>(d);
+                for (int k = 0; k < K; ++k) pk.v[u * K + k] = 0;
+
+                if (valid && i >= 1 && i <= L) {
+                    const uint32_t rd = s_ring[g * RING + ((i - 1) & (RING - 1))];
+                    const int qoff = rd & 0xfff;   // byte offset of the quality inside a table
+                    const int code = rd >> 12;
+                    double diag = diag_prev;
+                    diag_prev = s_in;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        {
+                            const int pos = c0 + k - 1;
+                            // Every "if (a > b) {x = a} else {a = b}" pair of the reference leaves
+                            // max(a, b) in both; no NaN or -0 can occur on this path, so fmax is the
+                            // same value bit for bit (src/reference_align.cpp:125-158).
+                            const double hcand = left - (hp ? GE : GO);
+                            const double ljm = lj - GE;
+                            const bool hj = ljm > hcand;
+                            const int hstep = hj ? (1 + pos - lp) : 1;
+                            lp = hj ? lp : pos;
+                            const double H = fmax(ljm, hcand);
+                            lj = H;
+                            const double vcand = S[k] - (vneg[k] ? vge[k] : vgo[k]);
+                            const double ujm = UJ[k] - vge[k];
+                            const bool vj = ujm > vcand;
+                            const int vstep = vj ? (1 + i - UP[k]) : 1;
+                            UP[k] = vj ? UP[k] : i;
+                            const double V = fmax(ujm, vcand);
+                            UJ[k] = V;
+                            const double w = *reinterpret_cast<const double*>(
+                                tab_bytes + (code == refcode[k] ? tm[k] : tmm[k]) + qoff);
+                            const double M = diag + w;
+                            diag = S[k];
+                            // (:164-174): M only if greater than both, else H only if greater than V
+                            const bool hv = H > V;
+                            const double G = fmax(H, V);
+                            const int dg = hv ? hstep : -vstep;
+                            const bool takem = M > G;
+                            const double best = fmax(M, G);
+                            const int d = takem ? 0 : dg;
+                            S[k] = best;
+                            left = best;
+                            hp = d > 0;
+                            vneg[k] = d < 0;
+                            pk.v[u * K + k] = static_cast<DirT>(d);
+                        }
                     }
                 }
-                out_s = left;
-                out_lj = lj;
-                out_lph = lp * 2 + (hp ? 1 : 0);
+                s_in = dpp_shr1(left);
+                lj_in = dpp_shr1(lj);
+                lph_in = dpp_shr1(lp * 2 + (hp ? 1 : 0));
             }
             if (MODE >= 1)
-                *reinterpret_cast<DirPack<DirT, K>*>(scr + (static_cast<size_t>(t) * 64 + lane) * K) = dk;
-
-            s_in = dpp_shr1(out_s);
-            lj_in = dpp_shr1(out_lj);
-            lph_in = dpp_shr1(out_lph);
+                *reinterpret_cast<DirPack<DirT, UNR * K>*>(
+                    scr + (static_cast<size_t>(t0 / UNR) * 64 + lane) * (UNR * K)) = pk;
         }
 
         if (valid && j == jlast) {
@@ -270,8 +285,8 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
                 auto loadD = [&](int c, int row) -> int {
                     if (row <= 0) return 1;  // D[c][0] = 1 (src/reference_align.cpp:118)
                     const int jj = (c - 1) / K, kk = (c - 1) % K;
-                    const size_t tt = static_cast<size_t>(row + jj);
-                    int d = static_cast<int>(scr[(tt * 64 + (g * W + jj)) * K + kk]);
+                    const int tt = row + jj;
+                    int d = static_cast<int>(scr[(static_cast<size_t>(tt / UNR) * 64 + (g * W + jj)) * (UNR * K) + (tt % UNR) * K + kk]);
                     // keep the walk inside the matrix whatever the scratch holds
                     if (d < -row) d = -row;
                     if (d > c) d = c;
@@ -414,22 +429,25 @@ static Shape pick_shape(int R) {
 }
 
 template <int K, typename DirT>
-static int launch_mode(int mode, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
-    if (mode == 0) hipLaunchKernelGGL((k_align<K, DirT, 0>), dim3(grid), dim3(64), lds, s, a);
-    else if (mode == 1) hipLaunchKernelGGL((k_align<K, DirT, 1>), dim3(grid), dim3(64), lds, s, a);
-    else hipLaunchKernelGGL((k_align<K, DirT, 2>), dim3(grid), dim3(64), lds, s, a);
+static int launch_mode(int mode, bool local, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
+    // adaptor_align is always local, general_align always global; score-only comes in both
+    if (mode == 0 && local) hipLaunchKernelGGL((k_align<K, DirT, 0, true>), dim3(grid), dim3(64), lds, s, a);
+    else if (mode == 0) hipLaunchKernelGGL((k_align<K, DirT, 0, false>), dim3(grid), dim3(64), lds, s, a);
+    else if (mode == 1 && local) hipLaunchKernelGGL((k_align<K, DirT, 1, true>), dim3(grid), dim3(64), lds, s, a);
+    else if (mode == 2 && !local) hipLaunchKernelGGL((k_align<K, DirT, 2, false>), dim3(grid), dim3(64), lds, s, a);
+    else return fail("sarlacc_amd: unsupported alignment mode");
     SL_HIP(hipGetLastError());
     return 0;
 }
 
 template <typename DirT>
-static int launch_k(int K, int mode, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
+static int launch_k(int K, int mode, bool local, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
     switch (K) {
-        case 1: return launch_mode<1, DirT>(mode, a, grid, lds, s);
-        case 2: return launch_mode<2, DirT>(mode, a, grid, lds, s);
-        case 4: return launch_mode<4, DirT>(mode, a, grid, lds, s);
-        case 8: return launch_mode<8, DirT>(mode, a, grid, lds, s);
-        case 16: return launch_mode<16, DirT>(mode, a, grid, lds, s);
+        case 1: return launch_mode<1, DirT>(mode, local, a, grid, lds, s);
+        case 2: return launch_mode<2, DirT>(mode, local, a, grid, lds, s);
+        case 4: return launch_mode<4, DirT>(mode, local, a, grid, lds, s);
+        case 8: return launch_mode<8, DirT>(mode, local, a, grid, lds, s);
+        case 16: return launch_mode<16, DirT>(mode, local, a, grid, lds, s);
     }
     return fail("sarlacc_amd: unsupported columns-per-lane %d", K);
 }
@@ -458,6 +476,7 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t*
     *bad_qual_read = std::numeric_limits<int>::max();
     if (n <= 0) return 0;
     if (R > MAX_REF) return fail("sarlacc_amd: reference longer than %d columns is not supported", MAX_REF);
+    if (enc_n > 256) return fail("sarlacc_amd: encoding vector longer than 256 entries");
     if (n > std::numeric_limits<int>::max() - 8) return fail("sarlacc_amd: more than 2^31 reads in one call");
     const double GO = gapopen + gapext, GE = gapext;  // (src/reference_align.cpp:8)
 
@@ -505,7 +524,8 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t*
     const long long nitems = (n + sh.ngroups - 1) / sh.ngroups;
 
     // persistent grid: enough waves to fill the chip, bounded by the scratch budget
-    const size_t per_wave_elems = kernel_mode ? (static_cast<size_t>(max_len) + sh.W + 1) * 64 * sh.K : 0;
+    // steps are rounded up to the store granule (<= 8 steps)
+    const size_t per_wave_elems = kernel_mode ? (static_cast<size_t>(max_len) + sh.W + 16) * 64 * sh.K : 0;
     int waves_per_cu = 16;
     if (const char* ew = std::getenv("SARLACC_ALIGN_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(ew));
     long long grid = std::min<long long>(nitems, static_cast<long long>(c.num_cu) * waves_per_cu);
@@ -529,8 +549,8 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t*
 
     const size_t lds = sizeof(double) * 5 * enc_n + sizeof(uint16_t) * NGMAX * RING + sizeof(int32_t) * NGMAX * (R + 1) + 16;
     SL_HIP(hipEventRecord(c.ev_start, stream));
-    if (wide) SL_TRY(launch_k<int32_t>(sh.K, kernel_mode, a, static_cast<int>(grid), lds, stream));
-    else SL_TRY(launch_k<int16_t>(sh.K, kernel_mode, a, static_cast<int>(grid), lds, stream));
+    if (wide) SL_TRY(launch_k<int32_t>(sh.K, kernel_mode, local, a, static_cast<int>(grid), lds, stream));
+    else SL_TRY(launch_k<int16_t>(sh.K, kernel_mode, local, a, static_cast<int>(grid), lds, stream));
     SL_HIP(hipEventRecord(c.ev_stop, stream));
     c.timed = true;
 
