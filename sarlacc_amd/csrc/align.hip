@@ -188,6 +188,11 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
         for (int k = 0; k < K; ++k) { S[k] = rz[k]; UJ[k] = NEG_INF; UP[k] = 0; vneg[k] = false; }
         double s_in = 0.0, lj_in = NEG_INF, diag_prev = rz_left;
         int lph_in = 0;  // left_jump_point * 2 + (left cell is a horizontal gap)
+        // Landing row of the upward walk the traceback performs in column R (tracked by the lane
+        // owning that column): land[i] = i if D[R][i] >= 0, else land[i - |D[R][i]|].  Without it
+        // the walk up the last column (free vertical gaps => ~L single steps in local mode) costs
+        // ~L dependent loads per read.
+        int land_prev = 0, land_up = 0;
 
         const int nsteps = ((Lmax + W + UNR - 1) / UNR) * UNR;
         for (int t0 = 0; t0 < nsteps; t0 += UNR) {
@@ -221,6 +226,8 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
                     const int code = rd >> 12;
                     double diag = diag_prev;
                     diag_prev = s_in;
+                    int d_last = 0;
+                    bool vj_last = false;
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         {
@@ -258,7 +265,16 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
                             hp = d > 0;
                             vneg[k] = d < 0;
                             pk.v[u * K + k] = static_cast<DirT>(d);
+                            if (MODE >= 1) {
+                                d_last = (k == klast) ? d : d_last;
+                                vj_last = (k == klast) ? vj : vj_last;
+                            }
                         }
+                    }
+                    if (MODE >= 1) {
+                        const int land_i = (d_last >= 0) ? i : (vj_last ? land_up : land_prev);
+                        land_up = vj_last ? land_up : land_prev;
+                        land_prev = land_i;
                     }
                 }
                 s_in = dpp_shr1(left);
@@ -281,6 +297,7 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
             // make this wave's direction stores visible to its leader lanes
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int land = __shfl(land_prev, g * W + jlast);  // where the walk up column R ends
             if (valid && leader) {
                 auto loadD = [&](int c, int row) -> int {
                     if (row <= 0) return 1;  // D[c][0] = 1 (src/reference_align.cpp:118)
@@ -295,6 +312,7 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
                 int row = L, c = R;
                 if (MODE == 1) {
                     int32_t* map = s_map + g * (R + 1);
+                    row = land;  // up moves leave the map untouched (src/reference_align.cpp:286)
                     while (c > 0) {
                         int d = loadD(c, row);
                         while (row > 0 && d < 0) { row += d; d = loadD(c, row); }
@@ -330,6 +348,7 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
                     uint8_t* oqry = A.aln_qry + base;
                     const uint8_t* sq = A.seq + start;
                     int m = 0, ed = 0;
+                    for (; row > land; --row) { oref[m] = '-'; oqry[m] = sq[row - 1]; ++m; ++ed; }
                     while (c > 0) {
                         int d = loadD(c, row);
                         while (row > 0 && d < 0) {
