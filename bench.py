@@ -42,6 +42,57 @@ def cpu_baseline(sample_seq, sample_qual):
             "sample": "%d reads of the same batch (%.1f s of oracle adaptor_align, 1 thread)" % (len(sample_seq), dt)}
 
 
+def pmc_traffic(n_reads):
+    """HBM bytes per launch of the DP kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_1M_*.json; FETCH_SIZE and WRITE_SIZE are collected in separate passes and
+    cannot be collected from inside this process).  Returned only for the configuration the
+    passes were run on; FETCH_SIZE is taken at face value (the guide's possible 2x under-count
+    for wide reads is noted in the file)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_pmc_1M_*.json")))
+    if not files or n_reads != 1_000_000:
+        return None
+    with open(files[-1]) as fh:
+        d = json.load(fh)
+    kb = sum(d["FETCH_SIZE_KB_per_launch"]) / len(d["FETCH_SIZE_KB_per_launch"]) + \
+        sum(d["WRITE_SIZE_KB_per_launch"]) / len(d["WRITE_SIZE_KB_per_launch"])
+    return kb * 1024.0
+
+
+def pipeline_sample(groups=4000, read_len=2000, copies=10):
+    """Second half of the headline metric on a bounded sample: reads/min through
+    umi_group -> quick_msa -> create_consensus_quality_loop (host-pointer C ABI, PCIe included)."""
+    import numpy as np
+    import sarlacc_amd
+    from sarlacc_amd import calls
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from perf_pipeline import NUC, noisy_copies
+    rng = np.random.default_rng(1000)
+    umis, _ = noisy_copies(NUC[rng.integers(0, 4, (groups, 12))], copies, rng)
+    reads, quals = noisy_copies(NUC[rng.integers(0, 4, (groups, read_len))], copies, rng)
+    n = len(reads)
+    enc = sarlacc_amd.phred_encoding()
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        clusters = calls.umi_group(umis, 1, None, 1, [np.arange(1, n + 1, dtype=np.int32)])
+        t1 = time.perf_counter()
+        big = [g for g in clusters if len(g) >= 2]
+        goff = np.zeros(len(big) + 1, np.int64)
+        goff[1:] = np.cumsum([len(g) for g in big])
+        gflat = np.concatenate(big).astype(np.int32)
+        qsub = quals.subset(gflat.astype(np.int64) - 1)
+        t2 = time.perf_counter()
+        rows, grp_rows, _ = calls.quick_msa_flat(goff, gflat, reads, 0, -1, -5, -1, 100)
+        cons, _ = calls.create_consensus_flat(rows, grp_rows, 0.6, quals=qsub, encoding=enc)
+        t3 = time.perf_counter()
+        dt = (t1 - t0) + (t3 - t2)
+        best = dt if best is None else min(best, dt)
+    return {"reads_per_min": n / best * 60.0, "reads": n, "consensus_reads": len(cons),
+            "workload": "%d molecules x %d reads x %d bp, 12-bp UMIs: umi_group(threshold 1) -> quick_msa(bandwidth 100) "
+                        "-> create_consensus_quality_loop, host-pointer C ABI incl. PCIe" % (groups, copies, read_len)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,6 +102,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=2000)
     ap.add_argument("--cpu-sample", type=int, default=6000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -135,9 +187,12 @@ def main():
             "kernel_ms": k_ms,
             "kernel_gcups": cells / (k_ms * 1e-3) / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n),
+                         "algorithmic_bytes": alg_bytes,
                          "note": "DP is VALU/latency bound; compulsory traffic is 0.042 B/cell"},
         }
+        if not args.no_pipeline:
+            out["pipeline"] = pipeline_sample()
         if not args.no_cpu:
             m = min(args.cpu_sample, n)
             s_s, s_q = devsynth.to_host_strings(seq, qual, off, m)

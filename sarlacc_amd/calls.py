@@ -311,3 +311,57 @@ def quick_msa(groupings, sequences, match, mismatch, gapExtension, gapOpening, b
         blk = out[ooff[g]:ooff[g + 1]].tobytes()
         res.append([blk[r * w:(r + 1) * w].decode() for r in range(m)])
     return res
+
+
+# ---------------------------------------------------------------------------
+# Flat variants (numpy in, numpy out) for large batches: same C ABI calls without
+# materialising Python string lists.
+
+def quick_msa_flat(grp_off, grp, seqs, match, mismatch, gapExtension, gapOpening, bandwidth):
+    """quick_msa on CSR groups.  Returns (rows StringSet, grp_rows int64[ngroups+1], width int32[ngroups]):
+    rows are the gapped strings of all groups in order, grp_rows the row range of each group."""
+    s = StringSet.from_strings(seqs)
+    goff = np.ascontiguousarray(grp_off, dtype=np.int64)
+    gvals = np.ascontiguousarray(grp, dtype=np.int32)
+    if gvals.size == 0:
+        gvals = np.zeros(1, np.int32)
+    ng = goff.size - 1
+    width = np.zeros(max(ng, 1), np.int32)
+    ooff = np.zeros(ng + 1, np.int64)
+    args = (ptr(goff), ptr(gvals), C.c_int64(ng), ptr(s.chars), ptr(s.off), C.c_int64(len(s)),
+            C.c_double(match), C.c_double(mismatch), C.c_double(gapExtension), C.c_double(gapOpening), int(bandwidth),
+            ptr(width), ptr(ooff))
+    check(_lib.lib().sarlacc_quick_msa(*args, None, C.c_int64(0)))      # sizing call
+    cap = int(ooff[ng])
+    out = np.zeros(max(cap, 1), np.uint8)
+    check(_lib.lib().sarlacc_quick_msa(*args, ptr(out), C.c_int64(cap)))
+    sizes = np.diff(goff)
+    grp_rows = np.zeros(ng + 1, np.int64)
+    np.cumsum(sizes, out=grp_rows[1:])
+    row_w = np.repeat(width[:ng].astype(np.int64), sizes)
+    row_off = np.zeros(row_w.size + 1, np.int64)
+    np.cumsum(row_w, out=row_off[1:])
+    return StringSet(out, row_off), grp_rows, width[:ng]
+
+
+def create_consensus_flat(rows, grp_rows, min_cov, pseudo_count=1.0, quals=None, qgrp_rows=None, encoding=None):
+    """Consensus over alignments given as (rows StringSet, grp_rows).  Returns (consensus StringSet,
+    phred StringSet).  With `quals` (ungapped quality strings per row) the quality-weighted vote runs."""
+    ng = len(grp_rows) - 1
+    grp_rows = np.ascontiguousarray(grp_rows, dtype=np.int64)
+    cap = max(rows.total, 1)
+    cons = np.zeros(cap, np.uint8)
+    phred = np.zeros(cap, np.uint8)
+    coff = np.zeros(ng + 1, np.int64)
+    if quals is None:
+        check(_lib.lib().sarlacc_create_consensus_basic_loop(
+            ptr(rows.chars), ptr(rows.off), ptr(grp_rows), C.c_int64(ng), C.c_double(min_cov), C.c_double(pseudo_count),
+            ptr(cons), ptr(phred), ptr(coff), None))
+    else:
+        enc = as_encoding(encoding)
+        q = StringSet.from_strings(quals)
+        qg = grp_rows if qgrp_rows is None else np.ascontiguousarray(qgrp_rows, dtype=np.int64)
+        check(_lib.lib().sarlacc_create_consensus_quality_loop(
+            ptr(rows.chars), ptr(rows.off), ptr(grp_rows), C.c_int64(ng), ptr(q.chars), ptr(q.off), ptr(qg),
+            C.c_double(min_cov), ptr(enc.errors), enc.names, len(enc), ptr(cons), ptr(phred), ptr(coff), None))
+    return StringSet(cons, coff.copy()), StringSet(phred, coff.copy())
