@@ -77,23 +77,30 @@ __device__ __forceinline__ double dpp_shr1(double v) {
 }
 
 // Directions of UNR consecutive steps x K columns of one lane, stored with one instruction.
-template <typename DirT, int N>
-struct alignas(sizeof(DirT) * N <= 16 ? sizeof(DirT) * N : 16) DirPack {
-    DirT v[N];
-};
-
-template <int K, typename DirT>
-struct Unroll {
-    static constexpr int raw = 16 / (K * static_cast<int>(sizeof(DirT)));
-    static constexpr int value = raw > 0 ? raw : 1;  // steps whose directions fill one 16-byte store
-};
+// Traceback code of one cell, 4 bits:
+//   bits 0-1  move taken: 0 diagonal, 1 horizontal gap, 2 vertical gap
+//   bit  2    the horizontal jump was continued here (left_jump_point kept)
+//   bit  3    the vertical jump was continued here (up_jump_point kept)
+// The reference stores jump LENGTHS (src/reference_align.cpp:139,154,170-177); they are
+// recovered during the walk: a horizontal step at column c is 1 + (number of consecutive
+// columns c, c-1, ... whose bit 2 is set), a vertical step at row i is 1 + (number of
+// consecutive rows i, i-1, ... whose bit 3 is set) -- exactly 1 + pos - left_jump_point and
+// 1 + i - up_jump_point.  A lane packs the codes of STEPS consecutive steps x K columns
+// into one word: 0.5 B per cell instead of the 2-4 B of a stored length.
+template <int K>
+struct TbSteps { static constexpr int value = (8 / K) > 0 ? 8 / K : 1; };
+template <int K>
+struct TbStore { using type = uint32_t; };
+template <>
+struct TbStore<16> { using type = unsigned long long; };
 
 // MODE 0: scores only.  MODE 1: scores + reference->read map (adaptor_align).
 // MODE 2: scores + gapped strings + edit distance (general_align).
 // LOCAL: free leading read bases + free vertical gaps in the last column (adaptor mode).
-template <int K, typename DirT, int MODE, bool LOCAL>
-__global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
-    constexpr int UNR = Unroll<K, DirT>::value;
+template <int K, int MODE, bool LOCAL>
+__global__ void __launch_bounds__(64, 5) k_align(const AlignArgs A) {
+    constexpr int UNR = TbSteps<K>::value;
+    using Word = typename TbStore<K>::type;
     extern __shared__ __align__(16) unsigned char smem[];
     double* s_tab = reinterpret_cast<double*>(smem);
     uint16_t* s_ring = reinterpret_cast<uint16_t*>(s_tab + 5 * A.navail);
@@ -131,7 +138,7 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
     }
     const double rz_left = A.rowzero[c0 - 1 <= R ? c0 - 1 : R];
     const int jlast = (R - 1) / K, klast = (R - 1) % K;
-    DirT* const scr = static_cast<DirT*>(A.dirs) + static_cast<size_t>(blockIdx.x) * A.dirs_per_wave;
+    Word* const scr = static_cast<Word*>(A.dirs) + static_cast<size_t>(blockIdx.x) * A.dirs_per_wave;
     const unsigned char* const tab_bytes = reinterpret_cast<const unsigned char*>(s_tab);
     __syncthreads();
 
@@ -182,16 +189,15 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
         for (int gg = 0; gg < NGMAX; ++gg) pf[gg] = fetch(gg, 0);
 
         double S[K], UJ[K];
-        int UP[K];
         bool vneg[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) { S[k] = rz[k]; UJ[k] = NEG_INF; UP[k] = 0; vneg[k] = false; }
+        for (int k = 0; k < K; ++k) { S[k] = rz[k]; UJ[k] = NEG_INF; vneg[k] = false; }
         double s_in = 0.0, lj_in = NEG_INF, diag_prev = rz_left;
-        int lph_in = 0;  // left_jump_point * 2 + (left cell is a horizontal gap)
+        int hp_in = 0;  // the cell to the left is a horizontal gap
         // Landing row of the upward walk the traceback performs in column R (tracked by the lane
-        // owning that column): land[i] = i if D[R][i] >= 0, else land[i - |D[R][i]|].  Without it
-        // the walk up the last column (free vertical gaps => ~L single steps in local mode) costs
-        // ~L dependent loads per read.
+        // owning that column): land[i] = i if the move at (i,R) is not vertical, else the landing
+        // row of the cell the vertical jump leads to.  Without it the walk up the last column
+        // (free vertical gaps => ~L single steps in local mode) costs ~L dependent loads per read.
         int land_prev = 0, land_up = 0;
 
         const int nsteps = ((Lmax + W + UNR - 1) / UNR) * UNR;
@@ -203,7 +209,7 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
                     pf[gg] = fetch(gg, t0 + 64);
                 }
             }
-            DirPack<DirT, UNR * K> pk;
+            Word pk = 0;
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int t = t0 + u;
@@ -212,13 +218,10 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
                     if (LOCAL) s_in = 0.0;
                     else s_in = (i < 1) ? 0.0 : (-GO - GE * static_cast<double>(i - 1));
                     lj_in = NEG_INF;
-                    lph_in = 0;
+                    hp_in = 0;
                 }
                 double left = s_in, lj = lj_in;
-                int lp = lph_in >> 1;
-                bool hp = lph_in & 1;
-#pragma unroll
-                for (int k = 0; k < K; ++k) pk.v[u * K + k] = 0;
+                bool hp = hp_in != 0;
 
                 if (valid && i >= 1 && i <= L) {
                     const uint32_t rd = s_ring[g * RING + ((i - 1) & (RING - 1))];
@@ -226,64 +229,53 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
                     const int code = rd >> 12;
                     double diag = diag_prev;
                     diag_prev = s_in;
-                    int d_last = 0;
-                    bool vj_last = false;
+                    bool nonvert_last = true, vj_last = false;
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        {
-                            const int pos = c0 + k - 1;
-                            // Every "if (a > b) {x = a} else {a = b}" pair of the reference leaves
-                            // max(a, b) in both; no NaN or -0 can occur on this path, so fmax is the
-                            // same value bit for bit (src/reference_align.cpp:125-158).
-                            const double hcand = left - (hp ? GE : GO);
-                            const double ljm = lj - GE;
-                            const bool hj = ljm > hcand;
-                            const int hstep = hj ? (1 + pos - lp) : 1;
-                            lp = hj ? lp : pos;
-                            const double H = fmax(ljm, hcand);
-                            lj = H;
-                            const double vcand = S[k] - (vneg[k] ? vge[k] : vgo[k]);
-                            const double ujm = UJ[k] - vge[k];
-                            const bool vj = ujm > vcand;
-                            const int vstep = vj ? (1 + i - UP[k]) : 1;
-                            UP[k] = vj ? UP[k] : i;
-                            const double V = fmax(ujm, vcand);
-                            UJ[k] = V;
-                            const double w = *reinterpret_cast<const double*>(
-                                tab_bytes + (code == refcode[k] ? tm[k] : tmm[k]) + qoff);
-                            const double M = diag + w;
-                            diag = S[k];
-                            // (:164-174): M only if greater than both, else H only if greater than V
-                            const bool hv = H > V;
-                            const double G = fmax(H, V);
-                            const int dg = hv ? hstep : -vstep;
-                            const bool takem = M > G;
-                            const double best = fmax(M, G);
-                            const int d = takem ? 0 : dg;
-                            S[k] = best;
-                            left = best;
-                            hp = d > 0;
-                            vneg[k] = d < 0;
-                            pk.v[u * K + k] = static_cast<DirT>(d);
-                            if (MODE >= 1) {
-                                d_last = (k == klast) ? d : d_last;
-                                vj_last = (k == klast) ? vj : vj_last;
-                            }
+                        // Every "if (a > b) {x = a} else {a = b}" pair of the reference leaves
+                        // max(a, b) in both; no NaN or -0 can occur on this path, so fmax is the
+                        // same value bit for bit (src/reference_align.cpp:125-158).
+                        const double hcand = left - (hp ? GE : GO);
+                        const double ljm = lj - GE;
+                        const bool hj = ljm > hcand;
+                        const double H = fmax(ljm, hcand);
+                        lj = H;
+                        const double vcand = S[k] - (vneg[k] ? vge[k] : vgo[k]);
+                        const double ujm = UJ[k] - vge[k];
+                        const bool vj = ujm > vcand;
+                        const double V = fmax(ujm, vcand);
+                        UJ[k] = V;
+                        const double w = *reinterpret_cast<const double*>(
+                            tab_bytes + (code == refcode[k] ? tm[k] : tmm[k]) + qoff);
+                        const double M = diag + w;
+                        diag = S[k];
+                        // (:164-174): M only if greater than both, else H only if greater than V
+                        const bool hv = H > V;
+                        const double G = fmax(H, V);
+                        const bool takem = M > G;
+                        const double best = fmax(M, G);
+                        S[k] = best;
+                        left = best;
+                        hp = !takem && hv;
+                        vneg[k] = !takem && !hv;
+                        if (MODE >= 1) {
+                            const unsigned nib = (takem ? 0u : (hv ? 1u : 2u)) | (hj ? 4u : 0u) | (vj ? 8u : 0u);
+                            pk |= static_cast<Word>(nib) << (4 * (u * K + k));
+                            nonvert_last = (k == klast) ? (takem || hv) : nonvert_last;
+                            vj_last = (k == klast) ? vj : vj_last;
                         }
                     }
                     if (MODE >= 1) {
-                        const int land_i = (d_last >= 0) ? i : (vj_last ? land_up : land_prev);
+                        const int land_i = nonvert_last ? i : (vj_last ? land_up : land_prev);
                         land_up = vj_last ? land_up : land_prev;
                         land_prev = land_i;
                     }
                 }
                 s_in = dpp_shr1(left);
                 lj_in = dpp_shr1(lj);
-                lph_in = dpp_shr1(lp * 2 + (hp ? 1 : 0));
+                hp_in = dpp_shr1(hp ? 1 : 0);
             }
-            if (MODE >= 1)
-                *reinterpret_cast<DirPack<DirT, UNR * K>*>(
-                    scr + (static_cast<size_t>(t0 / UNR) * 64 + lane) * (UNR * K)) = pk;
+            if (MODE >= 1) __builtin_nontemporal_store(pk, scr + static_cast<size_t>(t0 / UNR) * 64 + lane);
         }
 
         if (valid && j == jlast) {
@@ -294,20 +286,32 @@ __global__ void __launch_bounds__(64) k_align(const AlignArgs A) {
         }
 
         if (MODE >= 1) {
-            // make this wave's direction stores visible to its leader lanes
+            // make this wave's traceback stores visible to its leader lanes
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const int land = __shfl(land_prev, g * W + jlast);  // where the walk up column R ends
             if (valid && leader) {
-                auto loadD = [&](int c, int row) -> int {
-                    if (row <= 0) return 1;  // D[c][0] = 1 (src/reference_align.cpp:118)
+                auto nibble = [&](int c, int row) -> unsigned {  // 1 <= c <= R, 1 <= row <= L
                     const int jj = (c - 1) / K, kk = (c - 1) % K;
                     const int tt = row + jj;
-                    int d = static_cast<int>(scr[(static_cast<size_t>(tt / UNR) * 64 + (g * W + jj)) * (UNR * K) + (tt % UNR) * K + kk]);
-                    // keep the walk inside the matrix whatever the scratch holds
-                    if (d < -row) d = -row;
-                    if (d > c) d = c;
-                    return d;
+                    const Word w = scr[static_cast<size_t>(tt / UNR) * 64 + (g * W + jj)];
+                    return static_cast<unsigned>(w >> (4 * ((tt % UNR) * K + kk))) & 15u;
+                };
+                // direction value the reference would have stored at (row, c)
+                auto loadD = [&](int c, int row) -> int {
+                    if (row <= 0) return 1;  // D[c][0] = 1 (src/reference_align.cpp:118)
+                    unsigned nb = nibble(c, row);
+                    const unsigned move = nb & 3u;
+                    if (move == 0) return 0;
+                    int n = 0;
+                    if (move == 1) {
+                        int x = c;
+                        while ((nb & 4u) && x > 1) { ++n; --x; nb = nibble(x, row); }
+                        return 1 + n;
+                    }
+                    int y = row;
+                    while ((nb & 8u) && y > 1) { ++n; --y; nb = nibble(c, y); }
+                    return -(1 + n);
                 };
                 int row = L, c = R;
                 if (MODE == 1) {
@@ -447,26 +451,25 @@ static Shape pick_shape(int R) {
     return best;
 }
 
-template <int K, typename DirT>
+template <int K>
 static int launch_mode(int mode, bool local, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
     // adaptor_align is always local, general_align always global; score-only comes in both
-    if (mode == 0 && local) hipLaunchKernelGGL((k_align<K, DirT, 0, true>), dim3(grid), dim3(64), lds, s, a);
-    else if (mode == 0) hipLaunchKernelGGL((k_align<K, DirT, 0, false>), dim3(grid), dim3(64), lds, s, a);
-    else if (mode == 1 && local) hipLaunchKernelGGL((k_align<K, DirT, 1, true>), dim3(grid), dim3(64), lds, s, a);
-    else if (mode == 2 && !local) hipLaunchKernelGGL((k_align<K, DirT, 2, false>), dim3(grid), dim3(64), lds, s, a);
+    if (mode == 0 && local) hipLaunchKernelGGL((k_align<K, 0, true>), dim3(grid), dim3(64), lds, s, a);
+    else if (mode == 0) hipLaunchKernelGGL((k_align<K, 0, false>), dim3(grid), dim3(64), lds, s, a);
+    else if (mode == 1 && local) hipLaunchKernelGGL((k_align<K, 1, true>), dim3(grid), dim3(64), lds, s, a);
+    else if (mode == 2 && !local) hipLaunchKernelGGL((k_align<K, 2, false>), dim3(grid), dim3(64), lds, s, a);
     else return fail("sarlacc_amd: unsupported alignment mode");
     SL_HIP(hipGetLastError());
     return 0;
 }
 
-template <typename DirT>
 static int launch_k(int K, int mode, bool local, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
     switch (K) {
-        case 1: return launch_mode<1, DirT>(mode, local, a, grid, lds, s);
-        case 2: return launch_mode<2, DirT>(mode, local, a, grid, lds, s);
-        case 4: return launch_mode<4, DirT>(mode, local, a, grid, lds, s);
-        case 8: return launch_mode<8, DirT>(mode, local, a, grid, lds, s);
-        case 16: return launch_mode<16, DirT>(mode, local, a, grid, lds, s);
+        case 1: return launch_mode<1>(mode, local, a, grid, lds, s);
+        case 2: return launch_mode<2>(mode, local, a, grid, lds, s);
+        case 4: return launch_mode<4>(mode, local, a, grid, lds, s);
+        case 8: return launch_mode<8>(mode, local, a, grid, lds, s);
+        case 16: return launch_mode<16>(mode, local, a, grid, lds, s);
     }
     return fail("sarlacc_amd: unsupported columns-per-lane %d", K);
 }
@@ -538,23 +541,21 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t*
         const int W = (R + K - 1) / K;
         if ((K == 1 || K == 2 || K == 4 || K == 8 || K == 16) && W <= 64) sh = {K, W, std::min(64 / W, NGMAX)};
     }
-    const bool wide = max_len > 32000;  // jump lengths no longer fit int16
-    const size_t dir_bytes = wide ? 4 : 2;
     const long long nitems = (n + sh.ngroups - 1) / sh.ngroups;
-
-    // persistent grid: enough waves to fill the chip, bounded by the scratch budget
-    // steps are rounded up to the store granule (<= 8 steps)
-    const size_t per_wave_elems = kernel_mode ? (static_cast<size_t>(max_len) + sh.W + 16) * 64 * sh.K : 0;
-    int waves_per_cu = 16;
+    // traceback tile of one resident wave: one word per lane per TbSteps<K> steps (4 bits per cell)
+    const int tb_steps = std::max(1, 8 / sh.K);
+    const size_t word_bytes = sh.K == 16 ? 8 : 4;
+    const size_t per_wave_elems = kernel_mode ? ((static_cast<size_t>(max_len) + sh.W + 16) / tb_steps + 2) * 64 : 0;
+    int waves_per_cu = 20;
     if (const char* ew = std::getenv("SARLACC_ALIGN_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(ew));
     long long grid = std::min<long long>(nitems, static_cast<long long>(c.num_cu) * waves_per_cu);
     if (kernel_mode) {
         const size_t budget = static_cast<size_t>(6) << 30;
-        const long long fit = std::max<long long>(1, static_cast<long long>(budget / std::max<size_t>(1, per_wave_elems * dir_bytes)));
+        const long long fit = std::max<long long>(1, static_cast<long long>(budget / std::max<size_t>(1, per_wave_elems * word_bytes)));
         grid = std::min(grid, fit);
     }
     void* d_dirs = nullptr;
-    if (kernel_mode) SL_TRY(c.buffer("align.dirs", static_cast<size_t>(grid) * per_wave_elems * dir_bytes, &d_dirs));
+    if (kernel_mode) SL_TRY(c.buffer("align.dirs", static_cast<size_t>(grid) * per_wave_elems * word_bytes, &d_dirs));
 
     a.seq = d_seq; a.qual = d_qual; a.off = d_off; a.n = n;
     a.R = R; a.W = sh.W; a.ngroups = sh.ngroups; a.local = local ? 1 : 0;
@@ -568,8 +569,7 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t*
 
     const size_t lds = sizeof(double) * 5 * enc_n + sizeof(uint16_t) * NGMAX * RING + sizeof(int32_t) * NGMAX * (R + 1) + 16;
     SL_HIP(hipEventRecord(c.ev_start, stream));
-    if (wide) SL_TRY(launch_k<int32_t>(sh.K, kernel_mode, local, a, static_cast<int>(grid), lds, stream));
-    else SL_TRY(launch_k<int16_t>(sh.K, kernel_mode, local, a, static_cast<int>(grid), lds, stream));
+    SL_TRY(launch_k(sh.K, kernel_mode, local, a, static_cast<int>(grid), lds, stream));
     SL_HIP(hipEventRecord(c.ev_stop, stream));
     c.timed = true;
 
