@@ -137,10 +137,15 @@ def main():
     sso = torch.empty(n, dtype=torch.int32, device=device)
     swo = torch.empty(n, dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream().cuda_stream
+    # resident format: 2-bit packed bases + exception bit-mask + 1 B quality per base
+    packed = torch.empty(total_bases // 4 + 2, dtype=torch.uint8, device=device)
+    nmask = torch.empty(total_bases // 8 + 1, dtype=torch.uint8, device=device)
+    sdev.dev_pack_reads(seq, total_bases, packed, nmask, stream)
+    torch.cuda.synchronize()
 
     def step():
-        sdev.dev_align(seq, qual, off, n, max_len, enc, GAP_OPEN, GAP_EXT, ADAPTOR1, True,
-                       UMI_SECTION[0], UMI_SECTION[1], scores, starts, ends, sso, swo, stream)
+        sdev.dev_align(packed, qual, off, n, max_len, enc, GAP_OPEN, GAP_EXT, ADAPTOR1, True,
+                       UMI_SECTION[0], UMI_SECTION[1], scores, starts, ends, sso, swo, stream, d_nmask=nmask)
         return sarlacc_amd.last_kernel_ms()
 
     def fence():
@@ -182,6 +187,7 @@ def main():
             "config": {"workload": "adaptorAlign: %d x %d bp mockReads-like reads per GPU vs 30 bp adaptor, "
                                    "local quality DP + traceback + 1 section, go=5 ge=1" % (n, args.read_len),
                        "reads_per_gpu": n, "read_len": args.read_len, "adaptor_len": R,
+                       "resident_format": "2-bit packed bases + 1-bit non-ACGT mask + 1 B quality per base",
                        "sharding": "reads split across ranks, no collective"},
             "reads_per_s": n * world * args.steps / elapsed,
             "kernel_ms": k_ms,

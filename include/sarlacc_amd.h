@@ -114,6 +114,25 @@ int sarlacc_dev_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t
                       int32_t* d_sec_start_out, int32_t* d_sec_width_out,
                       void* stream);
 
+/* Resident read format of the DP kernel: 2-bit packed bases (4 per byte, base i of the
+ * concatenated batch in bits 2*(i%4) of byte i/4: A=0 C=1 G=2 T=3) plus one exception bit per
+ * base (8 per byte) set where the character is not A/C/G/T (such bases mismatch every A/C/G/T
+ * reference column, exactly like the reference's `ref==obs` test, src/reference_align.cpp:188).
+ * d_packed needs ceil(total/4)+1 bytes, d_nmask ceil(total/8) bytes. */
+int sarlacc_dev_pack_reads(const uint8_t* d_seq, int64_t total, uint8_t* d_packed, uint8_t* d_nmask,
+                           void* stream);
+
+/* sarlacc_dev_align on the packed format (offsets still count bases). */
+int sarlacc_dev_align_packed(const uint8_t* d_packed, const uint8_t* d_nmask, const uint8_t* d_qual,
+                             const int64_t* d_off, int64_t n, int32_t max_len,
+                             const double* enc_errors, const char* enc_names, int enc_n,
+                             double gapopen, double gapext,
+                             const char* reference, int reference_len, int mode,
+                             const int32_t* sec_starts, const int32_t* sec_ends, int nsec,
+                             double* d_scores, int32_t* d_starts, int32_t* d_ends,
+                             int32_t* d_sec_start_out, int32_t* d_sec_width_out,
+                             void* stream);
+
 /* ------------------------------------------------------------------ */
 /* masked Levenshtein, neighbour search, clustering                      */
 

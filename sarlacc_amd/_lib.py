@@ -16,6 +16,26 @@ class SarlaccError(RuntimeError):
     wherever the reference would have thrown (src/utils.cpp, src/reference_align.cpp ...)."""
 
 
+def _preload_shared_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two
+    copies of the HIP runtime in one process cannot both own the GPU ("No HIP GPUs are
+    available" in whichever initialises second), so when torch is installed its copy is loaded
+    first and libsarlacc_amd.so binds to it by SONAME -- whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -23,6 +43,7 @@ def lib():
             raise ImportError(
                 "sarlacc_amd: %s not found -- build it with `make -C sarlacc_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        _preload_shared_hip_runtime()
         _lib = C.CDLL(LIB_PATH)
         _lib.sarlacc_last_error.restype = C.c_char_p
         _lib.sarlacc_last_kernel_ms.restype = C.c_double

@@ -37,7 +37,8 @@ constexpr int RING = 128;  // staged read positions per alignment (2 x 64)
 constexpr int MAX_REF = 1024;
 
 struct AlignArgs {
-    const uint8_t* seq;
+    const uint8_t* seq;       // ASCII bases, or 2-bit packed bases when nmask != nullptr
+    const uint8_t* nmask;     // packed input only: 1 bit per base, set where the base is not A/C/G/T
     const uint8_t* qual;
     const int64_t* off;
     long long n;
@@ -171,7 +172,18 @@ __global__ void __launch_bounds__(64, 5) k_align(const AlignArgs A) {
         auto fetch = [&](int gg, int r0) -> uint32_t {
             const int r = r0 + lane;
             uint32_t v = 0;
-            if (r < glen[gg]) v = A.qual[gstart[gg] + r] | (static_cast<uint32_t>(A.seq[gstart[gg] + r]) << 8);
+            if (r < glen[gg]) {
+                const long long idx = gstart[gg] + r;
+                uint32_t b;
+                if (A.nmask) {  // 2-bit packed bases + exception mask (sarlacc_dev_pack_reads)
+                    const uint32_t two = (A.seq[idx >> 2] >> ((idx & 3) * 2)) & 3u;
+                    const uint32_t exc = (A.nmask[idx >> 3] >> (idx & 7)) & 1u;
+                    b = exc ? 'N' : static_cast<uint32_t>("ACGT"[two]);
+                } else {
+                    b = A.seq[idx];
+                }
+                v = A.qual[idx] | (b << 8);
+            }
             return v;
         };
         auto stage = [&](int gg, int r0, uint32_t v) {
@@ -489,7 +501,7 @@ struct AlignOut {
 
 // kernel_mode: 0 scores, 1 map, 2 strings.  Returns in *bad_qual_read the smallest
 // index of a read with a quality character below the encoding offset (or INT_MAX).
-static int run_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
+static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
                      int32_t max_len, const double* enc_errors, const char* enc_names, int enc_n,
                      double gapopen, double gapext, const char* ref, int R, bool local, int kernel_mode,
                      const int32_t* sec_starts, const int32_t* sec_ends, int nsec, const AlignOut& out,
@@ -557,7 +569,7 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t*
     void* d_dirs = nullptr;
     if (kernel_mode) SL_TRY(c.buffer("align.dirs", static_cast<size_t>(grid) * per_wave_elems * word_bytes, &d_dirs));
 
-    a.seq = d_seq; a.qual = d_qual; a.off = d_off; a.n = n;
+    a.seq = d_seq; a.nmask = d_nmask; a.qual = d_qual; a.off = d_off; a.n = n;
     a.R = R; a.W = sh.W; a.ngroups = sh.ngroups; a.local = local ? 1 : 0;
     a.qoffset = static_cast<int>(enc_names[0]); a.navail = enc_n;
     a.GO = GO; a.GE = GE;
@@ -687,7 +699,7 @@ static int host_align(const char* seq, const int64_t* seq_off, const char* qual,
         SL_TRY(scratch("out.edits", nn, &out.d_edits));
     }
     int bad = 0;
-    SL_TRY(run_align(hb.d_seq, hb.d_qual, hb.d_off, n, hb.max_len, enc_errors, enc_names, enc_n, gapopen, gapext,
+    SL_TRY(run_align(hb.d_seq, nullptr, hb.d_qual, hb.d_off, n, hb.max_len, enc_errors, enc_names, enc_n, gapopen, gapext,
                      ref, R, local, kernel_mode, sec_starts, sec_ends, nsec, out, s, &bad));
     SL_TRY(first_error(n, seq_off, nullptr, ref, R, bad));
 
@@ -768,14 +780,16 @@ int sarlacc_general_align(const char* seq, const int64_t* seq_off, const char* q
                       edit_only ? nullptr : aln_ref, edit_only ? nullptr : aln_query, aln_off, aln_cap);
 }
 
-int sarlacc_dev_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
-                      int32_t max_len, const double* enc_errors, const char* enc_names, int enc_n, double gapopen,
-                      double gapext, const char* reference, int reference_len, int mode, const int32_t* sec_starts,
-                      const int32_t* sec_ends, int nsec, double* d_scores, int32_t* d_starts, int32_t* d_ends,
-                      int32_t* d_sec_start_out, int32_t* d_sec_width_out, void* stream) {
+static int dev_align_impl(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t* d_qual, const int64_t* d_off,
+                          int64_t n, int32_t max_len, const double* enc_errors, const char* enc_names, int enc_n,
+                          double gapopen, double gapext, const char* reference, int reference_len, int mode,
+                          const int32_t* sec_starts, const int32_t* sec_ends, int nsec, double* d_scores,
+                          int32_t* d_starts, int32_t* d_ends, int32_t* d_sec_start_out, int32_t* d_sec_width_out,
+                          void* stream) {
     SL_TRY(check_encoding(enc_errors, enc_names, enc_n));
     SL_TRY(ensure_device());
     const bool trace = d_starts != nullptr;
+    if (trace && mode != 0) return fail("sarlacc_amd: positions are only defined for the local (adaptor) mode");
     if (trace) SL_TRY(check_sections(sec_starts, sec_ends, nsec, reference_len));
     AlignOut out;
     out.d_scores = d_scores;
@@ -784,7 +798,7 @@ int sarlacc_dev_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t
     out.d_sec_so = d_sec_start_out;
     out.d_sec_wo = d_sec_width_out;
     int bad = 0;
-    SL_TRY(run_align(d_seq, d_qual, d_off, n, max_len, enc_errors, enc_names, enc_n, gapopen, gapext, reference,
+    SL_TRY(run_align(d_seq, d_nmask, d_qual, d_off, n, max_len, enc_errors, enc_names, enc_n, gapopen, gapext, reference,
                      reference_len, mode == 0, trace ? 1 : 0, sec_starts, sec_ends, trace ? nsec : 0, out,
                      static_cast<hipStream_t>(stream), &bad));
     if (reference_len > 0 && bad != std::numeric_limits<int>::max())
@@ -793,5 +807,60 @@ int sarlacc_dev_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t
     for (int col = 0; col < reference_len; ++col)
         if (column_info(reference[col], &tmp) && max_len > 0) return fail("unrecognized base in reference sequence");
     return 0;
+}
+
+// 8 bases per thread: 2 bytes of 2-bit codes + 1 byte of exception bits
+__global__ void k_pack_reads(const uint8_t* seq, long long total, uint8_t* packed, uint8_t* nmask) {
+    const long long o = (blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x) * 8;
+    if (o >= total) return;
+    uint32_t bits = 0, exc = 0;
+    for (int k = 0; k < 8; ++k) {
+        const uint8_t c = (o + k < total) ? seq[o + k] : static_cast<uint8_t>('A');
+        uint32_t v;
+        switch (c) {
+            case 'A': v = 0; break;
+            case 'C': v = 1; break;
+            case 'G': v = 2; break;
+            case 'T': v = 3; break;
+            default: v = 0; exc |= 1u << k; break;
+        }
+        bits |= v << (2 * k);
+    }
+    packed[o / 4] = static_cast<uint8_t>(bits);
+    packed[o / 4 + 1] = static_cast<uint8_t>(bits >> 8);  // the buffer has one spare byte
+    nmask[o / 8] = static_cast<uint8_t>(exc);
+}
+
+int sarlacc_dev_pack_reads(const uint8_t* d_seq, int64_t total, uint8_t* d_packed, uint8_t* d_nmask, void* stream) {
+    if (total < 0) return fail("sarlacc_amd: negative size");
+    if (total == 0) return 0;
+    SL_TRY(ensure_device());
+    const long long threads = (total + 7) / 8;
+    hipLaunchKernelGGL(k_pack_reads, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), d_seq, static_cast<long long>(total), d_packed, d_nmask);
+    SL_HIP(hipGetLastError());
+    return 0;
+}
+
+int sarlacc_dev_align(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
+                      int32_t max_len, const double* enc_errors, const char* enc_names, int enc_n, double gapopen,
+                      double gapext, const char* reference, int reference_len, int mode, const int32_t* sec_starts,
+                      const int32_t* sec_ends, int nsec, double* d_scores, int32_t* d_starts, int32_t* d_ends,
+                      int32_t* d_sec_start_out, int32_t* d_sec_width_out, void* stream) {
+    return dev_align_impl(d_seq, nullptr, d_qual, d_off, n, max_len, enc_errors, enc_names, enc_n, gapopen, gapext,
+                          reference, reference_len, mode, sec_starts, sec_ends, nsec, d_scores, d_starts, d_ends,
+                          d_sec_start_out, d_sec_width_out, stream);
+}
+
+int sarlacc_dev_align_packed(const uint8_t* d_packed, const uint8_t* d_nmask, const uint8_t* d_qual,
+                             const int64_t* d_off, int64_t n, int32_t max_len, const double* enc_errors,
+                             const char* enc_names, int enc_n, double gapopen, double gapext, const char* reference,
+                             int reference_len, int mode, const int32_t* sec_starts, const int32_t* sec_ends, int nsec,
+                             double* d_scores, int32_t* d_starts, int32_t* d_ends, int32_t* d_sec_start_out,
+                             int32_t* d_sec_width_out, void* stream) {
+    if (!d_nmask) return fail("sarlacc_amd: packed alignment needs the exception mask of sarlacc_dev_pack_reads");
+    return dev_align_impl(d_packed, d_nmask, d_qual, d_off, n, max_len, enc_errors, enc_names, enc_n, gapopen, gapext,
+                          reference, reference_len, mode, sec_starts, sec_ends, nsec, d_scores, d_starts, d_ends,
+                          d_sec_start_out, d_sec_width_out, stream);
 }
 }

@@ -214,3 +214,43 @@ def test_error_behaviour(oracle, oenc, enc):
     bad = sarlacc_amd.Encoding([0.1, 0.2], b"!\"")
     with pytest.raises(SarlaccError, match="error probabilities should decrease"):
         calls.adaptor_align(["ACGT"], ["!!!!"], bad, 5, 1, ADAPTOR, [], [])
+
+
+def test_device_resident_and_packed_paths(oracle, oenc, enc):
+    """sarlacc_dev_align on resident ASCII reads and on the 2-bit packed format
+    (sarlacc_dev_pack_reads) must both equal the oracle, including reads with non-ACGT bases."""
+    torch = pytest.importorskip("torch")
+    from sarlacc_amd import device as sdev
+    from sarlacc_amd.mock import random_reads
+    from sarlacc_amd.strset import StringSet
+    reads, quals = random_reads(301, 0, 400, seed=77, alphabet=b"ACGTACGTACGTNR")
+    adaptor = "ACGTNNNNACGTRYACGT"
+    want = oracle.adaptor_align(reads, quals, oenc, 5, 1, adaptor, [4], [8])
+    s, q = StringSet.from_strings(reads), StringSet.from_strings(quals)
+    dev = torch.device("cuda", 0)
+    n, total = len(s), s.total
+    d_seq = torch.from_numpy(s.chars).to(dev)
+    d_qual = torch.from_numpy(q.chars).to(dev)
+    d_off = torch.from_numpy(s.off).to(dev)
+    max_len = int(s.widths().max())
+    stream = torch.cuda.current_stream().cuda_stream
+    packed = torch.zeros(total // 4 + 2, dtype=torch.uint8, device=dev)
+    nmask = torch.zeros(total // 8 + 1, dtype=torch.uint8, device=dev)
+    sdev.dev_pack_reads(d_seq, total, packed, nmask, stream)
+    for seq_buf, mask in ((d_seq, None), (packed, nmask)):
+        sc = torch.zeros(n, dtype=torch.float64, device=dev)
+        st = torch.zeros(n, dtype=torch.int32, device=dev)
+        en = torch.zeros_like(st)
+        so = torch.zeros_like(st)
+        sw = torch.zeros_like(st)
+        sdev.dev_align(seq_buf, d_qual, d_off, n, max_len, enc, 5, 1, adaptor, True, [4], [8], sc, st, en, so, sw,
+                       stream, d_nmask=mask)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(sc.cpu().numpy()), bits(want[0]))
+        assert np.array_equal(st.cpu().numpy(), want[1]) and np.array_equal(en.cpu().numpy(), want[2])
+        assert np.array_equal(so.cpu().numpy(), want[3][0]) and np.array_equal(sw.cpu().numpy(), want[4][0])
+        sc2 = torch.zeros(n, dtype=torch.float64, device=dev)
+        sdev.dev_align(seq_buf, d_qual, d_off, n, max_len, enc, 5, 1, adaptor, False, (), (), sc2, None, None, None, None,
+                       stream, d_nmask=mask)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(sc2.cpu().numpy()), bits(oracle.barcode_align(reads, quals, oenc, 5, 1, adaptor)))
