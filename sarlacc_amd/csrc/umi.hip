@@ -93,6 +93,14 @@ __global__ void k_gather_u64(const unsigned long long* src, const int* perm, uns
     if (i < n) dst[i] = src[perm[i]];
 }
 
+__global__ void k_gather_gid(const int* gid, const int* perm, unsigned long long* key, int* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int g = gid[perm[i]];
+    if (key) key[i] = static_cast<unsigned long long>(g);
+    if (out) out[i] = g;
+}
+
 __global__ void k_gather_umi(UmiArrays src, const int* perm, UmiArrays dst, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -149,7 +157,8 @@ __device__ __forceinline__ int banded_lev2(unsigned long long ca, uint32_t na, i
 }
 
 struct PairArgs {
-    UmiArrays U;                    // in trie (rank) order
+    UmiArrays U;                    // in (pre-group, trie) order
+    const int* gid;                 // pre-group of every element in that order (nullptr: one group)
     int n;
     int lim2;
     unsigned long long* edges;      // (rank_i << 32 | rank_j), rank_i < rank_j
@@ -163,22 +172,33 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
     if (bj < bi) return;
     __shared__ unsigned long long s_code[TILE];
     __shared__ uint32_t s_nmask[TILE], s_comp[TILE], s_meta[TILE];
+    __shared__ int s_gid[TILE];
     const int t = threadIdx.x;
+    if (A.gid && bj > bi) {
+        // elements are sorted by pre-group: the tiles share no group unless the first group of
+        // the column tile is still open at the end of the row tile
+        const int row_last = min(bi * TILE + TILE, A.n) - 1;
+        if (A.gid[bj * TILE] > A.gid[row_last]) return;
+    }
     const int jcol = bj * TILE + t;
     if (jcol < A.n) {
         s_code[t] = A.U.code[jcol]; s_nmask[t] = A.U.nmask[jcol]; s_comp[t] = A.U.comp[jcol]; s_meta[t] = A.U.meta[jcol];
+        s_gid[t] = A.gid ? A.gid[jcol] : 0;
     } else {
         s_code[t] = 0; s_nmask[t] = 0; s_comp[t] = 0; s_meta[t] = 0xffffu;  // len 255: never matches
+        s_gid[t] = -1;
     }
     __syncthreads();
     const int i = bi * TILE + t;
     if (i >= A.n) return;
+    const int gi = A.gid ? A.gid[i] : 0;
     const unsigned long long ca = A.U.code[i];
     const uint32_t na = A.U.nmask[i], compa = A.U.comp[i], ma = A.U.meta[i];
     const int la = ma & 0xff, nNa = (ma >> 8) & 0xff;
     const int jn = min(TILE, A.n - bj * TILE);
     const int j0 = (bi == bj) ? t + 1 : 0;
     for (int jj = j0; jj < jn; ++jj) {
+        if (s_gid[jj] != gi) continue;
         const uint32_t mb = s_meta[jj];
         const int lb = mb & 0xff, nNb = (mb >> 8) & 0xff;
         const int dl = la > lb ? la - lb : lb - la;
@@ -227,9 +247,13 @@ __global__ void k_expand_edges(const unsigned long long* edges, unsigned long lo
     keys[2 * e + 1] = (static_cast<unsigned long long>(perm[rj]) << 32) | ri;
 }
 
-__global__ void k_self_flags(UmiArrays U, int n, int lim2, int* flag) {
+// single: pre-groups of one read pass through untouched (src/umi_group.cpp:39-42): they always
+// get their self link so that the clustering emits them as solos without any check
+__global__ void k_self_flags(UmiArrays U, int n, int lim2, const uint8_t* single, const int* perm, int* flag) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) flag[r] = (static_cast<int>((U.meta[r] >> 8) & 0xff) <= lim2) ? 1 : 0;  // d2(x,x) = #N (App.B Q10)
+    if (r >= n) return;
+    const bool self = static_cast<int>((U.meta[r] >> 8) & 0xff) <= lim2;  // d2(x,x) = #N (App.B Q10)
+    flag[r] = (self || (single && single[perm[r]])) ? 1 : 0;
 }
 
 __global__ void k_self_keys(const int* flag, const long long* pos, const int* perm, int n, unsigned long long* keys) {
@@ -394,29 +418,33 @@ __global__ void k_cl_flags(ClusterState S, int* is_solo, int* is_seed) {
     is_seed[v] = S.seed[v];
 }
 
-__global__ void k_cl_list_solos(const int* is_solo, const long long* pos, int n, int* order) {
+// Clusters in one list: solos get key = index (top bit clear), picks key = ~pickkey (top bit
+// set): an ascending sort lists solos by index, then picks by (remaining, index) descending.
+__global__ void k_cl_list(const int* is_solo, const long long* spos, const int* is_seed, const long long* kpos,
+                          long long nsolo, const unsigned long long* pickkey, int n, unsigned long long* sortkey, int* val) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < n && is_solo[v]) order[pos[v]] = v;
+    if (v >= n) return;
+    if (is_solo[v]) { sortkey[spos[v]] = static_cast<unsigned long long>(v); val[spos[v]] = v; }
+    if (is_seed[v]) { sortkey[nsolo + kpos[v]] = ~pickkey[v]; val[nsolo + kpos[v]] = v; }
 }
 
-__global__ void k_cl_list_seeds(const int* is_seed, const long long* pos, const unsigned long long* pickkey, int n,
-                                unsigned long long* sortkey, int* val) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < n && is_seed[v]) { sortkey[pos[v]] = ~pickkey[v]; val[pos[v]] = v; }  // ascending ~key = descending key
-}
-
-__global__ void k_cl_sizes(ClusterState S, const int* order, long long nsolo, long long nclu, int* sizes) {
+__global__ void k_cl_gidkey(const int* gid, const int* val, long long n, unsigned long long* key) {
     const long long c = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
-    if (c < nclu) sizes[c] = (c < nsolo) ? 1 : S.csize[order[c]];
+    if (c < n) key[c] = static_cast<unsigned long long>(gid[val[c]]);
 }
 
-__global__ void k_cl_write(ClusterState S, const int* order, long long nsolo, long long nclu, const long long* coff,
+__global__ void k_cl_sizes(ClusterState S, const int* order, long long nclu, int* sizes) {
+    const long long c = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    if (c < nclu) sizes[c] = S.seed[order[c]] ? S.csize[order[c]] : 1;
+}
+
+__global__ void k_cl_write(ClusterState S, const int* order, long long nclu, const long long* coff,
                            const int32_t* members /* optional 1-based ids */, int32_t* out) {
     const long long c = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
     if (c >= nclu) return;
     const int v = order[c];
     const long long o = coff[c];
-    if (c < nsolo) { out[o] = members ? members[v] : v + 1; return; }
+    if (!S.seed[v]) { out[o] = members ? members[v] : v + 1; return; }
     const long long a = S.off[v];
     for (int k = 0; k < S.csize[v]; ++k) {
         const int w = S.memb[a + k];
@@ -472,14 +500,15 @@ static int alloc_umi(const std::string& p, size_t n, UmiArrays* U) {
 }
 
 struct SortedUmis {
-    UmiArrays U;   // in trie (rank) order
+    UmiArrays U;   // in (pre-group, trie) order
     int* perm;     // rank -> local index
+    int* gid;      // pre-group per rank (nullptr: a single group)
     int n;
 };
 
 // Encode one set of UMIs (optionally the members of a pre-group) and order it like the trie.
 static int encode_and_rank(const std::string& p, const uint8_t* d_chars, const int64_t* d_off, const int32_t* d_members,
-                           int n, SortedUmis* out, hipStream_t s) {
+                           const int* d_gid, int ngroups, int n, SortedUmis* out, hipStream_t s) {
     UmiArrays raw;
     SL_TRY(alloc_umi(p + ".raw", n, &raw));
     SL_TRY(alloc_umi(p + ".srt", n, &out->U));
@@ -505,6 +534,16 @@ static int encode_and_rank(const std::string& p, const uint8_t* d_chars, const i
     SL_TRY(sort_pairs_u64_i32(p.c_str(), klo, k2, idx, idx2, n, 64, s));
     hipLaunchKernelGGL(k_gather_u64, dim3(nblk(n, 256)), dim3(256), 0, s, khi, idx2, klo, n);
     SL_TRY(sort_pairs_u64_i32(p.c_str(), klo, k2, idx2, idx, n, 64, s));
+    out->gid = nullptr;
+    if (d_gid && ngroups > 1) {  // most significant key: the pre-group
+        int* gsorted;
+        SL_TRY(scratch((p + ".gid").c_str(), n, &gsorted));
+        hipLaunchKernelGGL(k_gather_gid, dim3(nblk(n, 256)), dim3(256), 0, s, d_gid, idx, klo, static_cast<int*>(nullptr), n);
+        SL_TRY(sort_pairs_u64_i32(p.c_str(), klo, k2, idx, idx2, n, ceil_log2(static_cast<unsigned long long>(ngroups) + 1), s));
+        SL_HIP(hipMemcpyAsync(idx, idx2, sizeof(int) * static_cast<size_t>(n), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_gather_gid, dim3(nblk(n, 256)), dim3(256), 0, s, d_gid, idx, static_cast<unsigned long long*>(nullptr), gsorted, n);
+        out->gid = gsorted;
+    }
     hipLaunchKernelGGL(k_gather_umi, dim3(nblk(n, 256)), dim3(256), 0, s, raw, idx, out->U, n);
     SL_HIP(hipGetLastError());
     out->perm = idx;
@@ -524,7 +563,7 @@ struct DirectedKeys {
 };
 
 // All neighbour pairs within `limit`, as sorted directed keys (self links included).
-static int neighbour_keys(const std::string& p, const SortedUmis& S, int limit, DirectedKeys* out, hipStream_t s) {
+static int neighbour_keys(const std::string& p, const SortedUmis& S, int limit, const uint8_t* d_single, DirectedKeys* out, hipStream_t s) {
     Context& c = ctx();
     const int n = S.n;
     if (limit < 0) limit = -1;  // nothing can match a negative limit
@@ -540,7 +579,7 @@ static int neighbour_keys(const std::string& p, const SortedUmis& S, int limit, 
         SL_TRY(c.buffer((p + ".edges").c_str(), cap * sizeof(unsigned long long), &pe));
         d_edges = static_cast<unsigned long long*>(pe);
         SL_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
-        PairArgs a{S.U, n, lim2, d_edges, d_count, cap};
+        PairArgs a{S.U, S.gid, n, lim2, d_edges, d_count, cap};
         SL_HIP(hipEventRecord(c.ev_start, s));
         const int K = std::min(limit, UMI_MAXLEN);
         if (K <= 0) launch_pairs<0>(a, s);
@@ -564,7 +603,7 @@ static int neighbour_keys(const std::string& p, const SortedUmis& S, int limit, 
     int* d_flag; long long* d_pos;
     SL_TRY(scratch((p + ".sflag").c_str(), static_cast<size_t>(n) + 1, &d_flag));
     SL_TRY(scratch((p + ".spos").c_str(), static_cast<size_t>(n) + 1, &d_pos));
-    hipLaunchKernelGGL(k_self_flags, dim3(nblk(n, 256)), dim3(256), 0, s, S.U, n, lim2, d_flag);
+    hipLaunchKernelGGL(k_self_flags, dim3(nblk(n, 256)), dim3(256), 0, s, S.U, n, lim2, d_single, S.perm, d_flag);
     SL_HIP(hipMemsetAsync(d_flag + n, 0, sizeof(int), s));
     SL_TRY(exclusive_scan_i32(p.c_str(), d_flag, d_pos, static_cast<size_t>(n) + 1, s));
     long long nself = 0;
@@ -603,11 +642,12 @@ static int adjacency_from_keys(const std::string& p, const unsigned long long* k
 // Neighbour lists for one group: UMI1 only, or UMI1 n UMI2 listed in UMI2's order
 // (src/umi_group.cpp:59-103).
 static int group_adjacency(const uint8_t* d_c1, const int64_t* d_o1, const uint8_t* d_c2, const int64_t* d_o2,
-                           const int32_t* d_members, int n, int limit1, int limit2, DevAdj* adj, hipStream_t s) {
+                           const int32_t* d_members, const int* d_gid, const uint8_t* d_single, int ngroups, int n,
+                           int limit1, int limit2, DevAdj* adj, hipStream_t s) {
     SortedUmis S1;
     DirectedKeys K1;
-    SL_TRY(encode_and_rank("u1", d_c1, d_o1, d_members, n, &S1, s));
-    SL_TRY(neighbour_keys("u1", S1, limit1, &K1, s));
+    SL_TRY(encode_and_rank("u1", d_c1, d_o1, d_members, d_gid, ngroups, n, &S1, s));
+    SL_TRY(neighbour_keys("u1", S1, limit1, d_single, &K1, s));
     if (!d_c2) return adjacency_from_keys("adj", K1.keys, K1.nk, S1.perm, n, adj, s);
 
     // membership set of UMI1 links keyed by original column id
@@ -620,8 +660,8 @@ static int group_adjacency(const uint8_t* d_c1, const int64_t* d_o1, const uint8
     }
     SortedUmis S2;
     DirectedKeys K2;
-    SL_TRY(encode_and_rank("u2", d_c2, d_o2, d_members, n, &S2, s));
-    SL_TRY(neighbour_keys("u2", S2, limit2, &K2, s));
+    SL_TRY(encode_and_rank("u2", d_c2, d_o2, d_members, d_gid, ngroups, n, &S2, s));
+    SL_TRY(neighbour_keys("u2", S2, limit2, d_single, &K2, s));
     int* d_keep; long long* d_pos;
     SL_TRY(scratch("u2.keep", static_cast<size_t>(K2.nk) + 1, &d_keep));
     SL_TRY(scratch("u2.kpos", static_cast<size_t>(K2.nk) + 1, &d_pos));
@@ -648,7 +688,8 @@ struct ClusterResult {
 // Greedy clustering of a device CSR graph.  `require_symmetric` is the documented
 // precondition of this implementation (the reference's results on asymmetric input
 // are an accident of its update order; umi_group always produces symmetric lists).
-static int cluster_dev(const DevAdj& adj, int n, const int32_t* d_members, bool check_sym, ClusterResult* res, hipStream_t s) {
+static int cluster_dev(const DevAdj& adj, int n, const int32_t* d_members, const int* d_gid, int ngroups, bool check_sym,
+                       ClusterResult* res, hipStream_t s) {
     ClusterState S{};
     S.off = adj.off; S.nbr = adj.nbr; S.n = n;
     const size_t nn = static_cast<size_t>(n) + 1;
@@ -718,21 +759,27 @@ static int cluster_dev(const DevAdj& adj, int n, const int32_t* d_members, bool 
     SL_HIP(hipMemcpyAsync(&nseed, d_kpos + n, sizeof nseed, hipMemcpyDeviceToHost, s));
     SL_HIP(hipStreamSynchronize(s));
     const long long nclu = nsolo + nseed;
-    hipLaunchKernelGGL(k_cl_list_solos, g, b, 0, s, d_issolo, d_spos, n, d_order);
-    if (nseed) {
-        hipLaunchKernelGGL(k_cl_list_seeds, g, b, 0, s, d_isseed, d_kpos, S.pickkey, n, d_sk, d_val);
-        SL_TRY(sort_pairs_u64_i32("cl", d_sk, d_sk2, d_val, d_val2, static_cast<size_t>(nseed), 64, s));
-        SL_HIP(hipMemcpyAsync(d_order + nsolo, d_val2, sizeof(int) * static_cast<size_t>(nseed), hipMemcpyDeviceToDevice, s));
+    if (nclu) {
+        hipLaunchKernelGGL(k_cl_list, g, b, 0, s, d_issolo, d_spos, d_isseed, d_kpos, nsolo, S.pickkey, n, d_sk, d_val);
+        SL_TRY(sort_pairs_u64_i32("cl", d_sk, d_sk2, d_val, d_val2, static_cast<size_t>(nclu), 64, s));
+        if (d_gid && ngroups > 1) {  // stable: keeps the in-group order, groups in input order
+            hipLaunchKernelGGL(k_cl_gidkey, dim3(nblk(nclu, 256)), b, 0, s, d_gid, d_val2, nclu, d_sk);
+            SL_TRY(sort_pairs_u64_i32("cl", d_sk, d_sk2, d_val2, d_val, static_cast<size_t>(nclu),
+                                      ceil_log2(static_cast<unsigned long long>(ngroups) + 1), s));
+            SL_HIP(hipMemcpyAsync(d_order, d_val, sizeof(int) * static_cast<size_t>(nclu), hipMemcpyDeviceToDevice, s));
+        } else {
+            SL_HIP(hipMemcpyAsync(d_order, d_val2, sizeof(int) * static_cast<size_t>(nclu), hipMemcpyDeviceToDevice, s));
+        }
     }
     long long* d_coff;
     int32_t* d_out;
     SL_TRY(scratch("cl.coff", static_cast<size_t>(nclu) + 2, &d_coff));
     SL_TRY(scratch("cl.out", nn, &d_out));
     if (nclu) {
-        hipLaunchKernelGGL(k_cl_sizes, dim3(nblk(nclu, 256)), b, 0, s, S, d_order, nsolo, nclu, d_sizes);
+        hipLaunchKernelGGL(k_cl_sizes, dim3(nblk(nclu, 256)), b, 0, s, S, d_order, nclu, d_sizes);
         SL_HIP(hipMemsetAsync(d_sizes + nclu, 0, sizeof(int), s));
         SL_TRY(exclusive_scan_i32("cl", d_sizes, d_coff, static_cast<size_t>(nclu) + 1, s));
-        hipLaunchKernelGGL(k_cl_write, dim3(nblk(nclu, 256)), b, 0, s, S, d_order, nsolo, nclu, d_coff, d_members, d_out);
+        hipLaunchKernelGGL(k_cl_write, dim3(nblk(nclu, 256)), b, 0, s, S, d_order, nclu, d_coff, d_members, d_out);
         SL_HIP(hipGetLastError());
         SL_HIP(hipMemcpyAsync(&res->total, d_coff + nclu, sizeof(long long), hipMemcpyDeviceToHost, s));
         SL_HIP(hipStreamSynchronize(s));
@@ -810,7 +857,7 @@ int sarlacc_fast_levdist_test(const char* seq, const int64_t* off, int64_t n, in
     uint8_t* d_c; int64_t* d_o;
     SL_TRY(upload_strings("lv", seq, off, n, &d_c, &d_o, s));
     DevAdj adj;
-    SL_TRY(group_adjacency(d_c, d_o, nullptr, nullptr, nullptr, static_cast<int>(n), limit, limit, &adj, s));
+    SL_TRY(group_adjacency(d_c, d_o, nullptr, nullptr, nullptr, nullptr, nullptr, 1, static_cast<int>(n), limit, limit, &adj, s));
     std::vector<long long> hoff(static_cast<size_t>(n) + 1);
     SL_HIP(hipMemcpy(hoff.data(), adj.off, sizeof(long long) * hoff.size(), hipMemcpyDeviceToHost));
     for (int64_t i = 0; i <= n; ++i) nbr_off[i] = hoff[i];
@@ -844,7 +891,7 @@ int sarlacc_cluster_umis_test(const int64_t* link_off, const int32_t* links, int
     SL_TRY(upload("adj.nbr", hn.data(), hn.size(), &adj.nbr, s));
     adj.nnz = nnz;
     ClusterResult res;
-    SL_TRY(cluster_dev(adj, static_cast<int>(n), nullptr, true, &res, s));
+    SL_TRY(cluster_dev(adj, static_cast<int>(n), nullptr, nullptr, 1, true, &res, s));
     std::vector<long long> co(static_cast<size_t>(res.nclu) + 1);
     SL_HIP(hipMemcpy(co.data(), res.d_coff, sizeof(long long) * co.size(), hipMemcpyDeviceToHost));
     if (res.total) SL_HIP(hipMemcpy(clu, res.d_out, sizeof(int32_t) * static_cast<size_t>(res.total), hipMemcpyDeviceToHost));
@@ -871,29 +918,31 @@ int sarlacc_umi_group(const char* umi1, const int64_t* off1, const char* umi2, c
     int64_t *d_o1, *d_o2 = nullptr;
     SL_TRY(upload_strings("g1", umi1, off1, n, &d_c1, &d_o1, s));
     if (umi2) SL_TRY(upload_strings("g2", umi2, off2, n, &d_c2, &d_o2, s));
-    int32_t* d_grp;
-    SL_TRY(upload("g.members", grp + grp_off[0], static_cast<size_t>(total), &d_grp, s));
-
-    int64_t nc = 0;
+    // all pre-groups go through the kernels together: elements = flattened member list,
+    // pairs are only formed inside a pre-group, clusters come back group by group
+    if (total > std::numeric_limits<int>::max() - 1024) return fail("sarlacc_amd: more than 2^31 pre-group members");
+    const int N = static_cast<int>(total);
+    std::vector<int> gid(static_cast<size_t>(N) + 1);
+    std::vector<uint8_t> single(static_cast<size_t>(N) + 1, 0);
     for (int64_t g = 0; g < ngroups; ++g) {
-        const int64_t a = grp_off[g] - grp_off[0], N = grp_off[g + 1] - grp_off[g];
-        if (N == 1) {  // passthrough (src/umi_group.cpp:39-42)
-            clu[clu_off[nc]] = grp[grp_off[g]];
-            clu_off[nc + 1] = clu_off[nc] + 1;
-            ++nc;
-            continue;
-        }
-        if (N == 0) continue;
+        const int64_t a = grp_off[g] - grp_off[0], b = grp_off[g + 1] - grp_off[0];
+        for (int64_t i = a; i < b; ++i) { gid[i] = static_cast<int>(g); single[i] = (b - a == 1); }
+    }
+    int64_t nc = 0;
+    if (N > 0) {
+        int32_t* d_grp; int* d_gid; uint8_t* d_single;
+        SL_TRY(upload("g.members", grp + grp_off[0], static_cast<size_t>(N), &d_grp, s));
+        SL_TRY(upload("g.gid", gid.data(), static_cast<size_t>(N), &d_gid, s));
+        SL_TRY(upload("g.single", single.data(), static_cast<size_t>(N), &d_single, s));
         DevAdj adj;
-        SL_TRY(group_adjacency(d_c1, d_o1, d_c2, d_o2, d_grp + a, static_cast<int>(N), thresh1, thresh2, &adj, s));
+        SL_TRY(group_adjacency(d_c1, d_o1, d_c2, d_o2, d_grp, d_gid, d_single, static_cast<int>(ngroups), N, thresh1, thresh2, &adj, s));
         ClusterResult res;
-        SL_TRY(cluster_dev(adj, static_cast<int>(N), d_grp + a, false, &res, s));
+        SL_TRY(cluster_dev(adj, N, d_grp, d_gid, static_cast<int>(ngroups), false, &res, s));
         std::vector<long long> co(static_cast<size_t>(res.nclu) + 1);
         SL_HIP(hipMemcpy(co.data(), res.d_coff, sizeof(long long) * co.size(), hipMemcpyDeviceToHost));
-        const int64_t base = clu_off[nc];
-        if (res.total) SL_HIP(hipMemcpy(clu + base, res.d_out, sizeof(int32_t) * static_cast<size_t>(res.total), hipMemcpyDeviceToHost));
-        for (long long c = 0; c < res.nclu; ++c) clu_off[nc + c + 1] = base + co[c + 1];
-        nc += res.nclu;
+        if (res.total) SL_HIP(hipMemcpy(clu, res.d_out, sizeof(int32_t) * static_cast<size_t>(res.total), hipMemcpyDeviceToHost));
+        for (long long c = 0; c <= res.nclu; ++c) clu_off[c] = co[c];
+        nc = res.nclu;
     }
     *nclusters = nc;
     return 0;
