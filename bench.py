@@ -113,16 +113,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    backend = os.environ.get("SARLACC_DIST_BACKEND", "nccl")  # gloo only to exercise this path on one GPU
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a HIP device")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    red_device = device if backend == "nccl" else torch.device("cpu")
 
     import sarlacc_amd
     from sarlacc_amd import device as sdev
     from sarlacc_amd import devsynth
-    sarlacc_amd.set_device(local_rank)
+    sarlacc_amd.set_device(dev_index)
     enc = sarlacc_amd.phred_encoding()
 
     n = args.reads
@@ -164,8 +170,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    tot_cells = torch.tensor([float(cells)], dtype=torch.float64, device=device)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
+    tot_cells = torch.tensor([float(cells)], dtype=torch.float64, device=red_device)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot_cells, op=dist.ReduceOp.SUM)
