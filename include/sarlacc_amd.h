@@ -133,6 +133,23 @@ int sarlacc_dev_align_packed(const uint8_t* d_packed, const uint8_t* d_nmask, co
                              int32_t* d_sec_start_out, int32_t* d_sec_width_out,
                              void* stream);
 
+/* ---- resident batches for the scrambled-control callers ----
+ * tuneAlignment (R/tuneAlignment.R:30-72) and getAdaptorThresholds
+ * (R/getAdaptorThresholds.R:35-48,105-128) align the same read windows many times; these
+ * helpers keep them in HBM: plain device allocation / copies, .get_front_and_back
+ * (R/adaptorAlign.R:86-95) and .scramble_input (R/getAdaptorThresholds.R:68-92) on the device. */
+int sarlacc_dev_malloc(void** p, int64_t bytes);
+int sarlacc_dev_free(void* p);
+int sarlacc_dev_upload(void* d, const void* h, int64_t bytes);
+int sarlacc_dev_download(void* h, const void* d, int64_t bytes);
+/* which = 0: first min(tol,width) bases; which = 1: reverse complement of the last
+ * min(tol,width) bases with reversed qualities.  d_woff: offsets of the windows (n+1). */
+int sarlacc_dev_windows(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
+                        const int64_t* d_woff, int which, uint8_t* d_oseq, uint8_t* d_oqual, void* stream);
+/* Per-read Fisher-Yates shuffle (bases and qualities together), splitmix64 stream per read. */
+int sarlacc_dev_scramble(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
+                         uint64_t seed, uint8_t* d_oseq, uint8_t* d_oqual, void* stream);
+
 /* ------------------------------------------------------------------ */
 /* masked Levenshtein, neighbour search, clustering                      */
 

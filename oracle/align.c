@@ -413,3 +413,36 @@ int orc_mask_bad_bases(const char* seq, const int64_t* seq_off,
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------ */
+/* Per-read shuffle used by the scrambled-control callers.  The reference shuffles with R's
+ * sample() (R/getAdaptorThresholds.R:68-92), which cannot be reproduced without R; this
+ * restates OUR generator (sarlacc_amd/csrc/resident.hip:k_scramble) so the device shuffle can
+ * be checked byte for byte: splitmix64 stream per read seeded with
+ * seed ^ (read+1)*0xD1342543DE82EF95, Fisher-Yates from the end, partner of k =
+ * ((next>>32)*(k+1))>>32. */
+static uint64_t splitmix64(uint64_t* x) {
+    *x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = *x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int orc_scramble(const char* seq, const char* qual, const int64_t* off, int64_t n, uint64_t seed,
+                 char* oseq, char* oqual) {
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t s = off[r], L = off[r + 1] - s;
+        memcpy(oseq + s, seq + s, (size_t)L);
+        memcpy(oqual + s, qual + s, (size_t)L);
+        uint64_t st = seed ^ ((uint64_t)(r + 1) * 0xD1342543DE82EF95ull);
+        for (int64_t k = L - 1; k > 0; --k) {
+            const uint64_t rnd = splitmix64(&st) >> 32;
+            const int64_t j = (int64_t)((rnd * (uint64_t)(k + 1)) >> 32);
+            char a = oseq[s + k], b = oqual[s + k];
+            oseq[s + k] = oseq[s + j]; oqual[s + k] = oqual[s + j];
+            oseq[s + j] = a; oqual[s + j] = b;
+        }
+    }
+    return 0;
+}

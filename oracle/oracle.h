@@ -79,6 +79,10 @@ int orc_mask_bad_bases(const char* seq, const int64_t* seq_off,
                        const double* errors, const char* names, int nenc,
                        double threshold, char* out);
 
+/* per-read shuffle of the scrambled-control callers (our generator, see align.c) */
+int orc_scramble(const char* seq, const char* qual, const int64_t* off, int64_t n, uint64_t seed,
+                 char* oseq, char* oqual);
+
 /* ---- masked Levenshtein ---- */
 /* dense lower triangle, i-major (reference src/compute_lev_masked.cpp:13-64) */
 int orc_compute_lev_masked(const char* seq, const int64_t* off, int64_t n, double* out);

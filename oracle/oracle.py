@@ -180,6 +180,14 @@ def mask_bad_bases(seq, qual, encoding, threshold):
     return unpack(out, so)
 
 
+def scramble(seq, qual, seed):
+    sb, so = pack(seq)
+    qb, _ = pack(qual)
+    os_, oq = np.zeros_like(sb), np.zeros_like(qb)
+    _check(lib().orc_scramble(_p(sb), _p(qb), _p(so), C.c_int64(len(so) - 1), C.c_uint64(seed), _p(os_), _p(oq)))
+    return unpack(os_, so), unpack(oq, so)
+
+
 def compute_lev_masked(seqs):
     sb, so = pack(seqs)
     n = len(so) - 1

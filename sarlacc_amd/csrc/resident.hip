@@ -1,0 +1,123 @@
+// resident.hip -- device-resident read batches for callers that reuse the same reads many
+// times: the scrambled-control grid search of tuneAlignment (/root/reference/R/tuneAlignment.R:30-72,
+// up to 7 x 5 parameter pairs x 4 orientations x {real, scrambled}) and getAdaptorThresholds
+// (R/getAdaptorThresholds.R:35-48,105-128).  Reads are uploaded once; the front/back windows
+// (.get_front_and_back, R/adaptorAlign.R:86-95) and the per-read shuffles (.scramble_input,
+// R/getAdaptorThresholds.R:68-92) are built on the device, and every grid point is one
+// score-only launch of the DP kernel on resident data.
+#include "common.hpp"
+
+#include "../../include/sarlacc_amd.h"
+
+namespace sarlacc {
+
+__device__ __forceinline__ uint8_t complement_base(uint8_t c) {
+    switch (c) {  // Biostrings reverseComplement on DNA incl. IUPAC codes
+        case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+        case 'M': return 'K'; case 'K': return 'M'; case 'R': return 'Y'; case 'Y': return 'R';
+        case 'V': return 'B'; case 'B': return 'V'; case 'H': return 'D'; case 'D': return 'H';
+    }
+    return c;  // W, S, N, '-' map to themselves
+}
+
+// which = 0: first min(tol, L) bases.  which = 1: reverse complement of the last min(tol, L)
+// bases, qualities reversed.  woff are the offsets of the output windows.
+__global__ void k_windows(const uint8_t* seq, const uint8_t* qual, const int64_t* off, long long n,
+                          const int64_t* woff, int which, uint8_t* oseq, uint8_t* oqual) {
+    const long long r = blockIdx.x;
+    if (r >= n) return;
+    const long long s = off[r], L = off[r + 1] - s;
+    const long long w0 = woff[r], w = woff[r + 1] - w0;
+    for (long long p = threadIdx.x; p < w; p += blockDim.x) {
+        if (which == 0) {
+            oseq[w0 + p] = seq[s + p];
+            oqual[w0 + p] = qual[s + p];
+        } else {
+            const long long src = s + L - 1 - p;
+            oseq[w0 + p] = complement_base(seq[src]);
+            oqual[w0 + p] = qual[src];
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long& x) {
+    x += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Fisher-Yates shuffle of every read (bases and qualities with the same permutation).
+// Stream per read: splitmix64 seeded with seed ^ (read + 1) * 0xD1342543DE82EF95; the swap
+// partner of position k is ((next >> 32) * (k + 1)) >> 32.  oracle/align.c:orc_scramble
+// restates it for parity tests.
+__global__ void k_scramble(const uint8_t* seq, const uint8_t* qual, const int64_t* off, long long n,
+                           unsigned long long seed, uint8_t* oseq, uint8_t* oqual) {
+    const long long r = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    if (r >= n) return;
+    const long long s = off[r], L = off[r + 1] - s;
+    for (long long p = 0; p < L; ++p) { oseq[s + p] = seq[s + p]; oqual[s + p] = qual[s + p]; }
+    unsigned long long st = seed ^ (static_cast<unsigned long long>(r + 1) * 0xD1342543DE82EF95ull);
+    for (long long k = L - 1; k > 0; --k) {
+        const unsigned long long rnd = splitmix64(st) >> 32;
+        const long long jx = static_cast<long long>((rnd * static_cast<unsigned long long>(k + 1)) >> 32);
+        const uint8_t a = oseq[s + k], b = oqual[s + k];
+        oseq[s + k] = oseq[s + jx]; oqual[s + k] = oqual[s + jx];
+        oseq[s + jx] = a; oqual[s + jx] = b;
+    }
+}
+
+}  // namespace sarlacc
+
+using namespace sarlacc;
+
+extern "C" {
+
+int sarlacc_dev_malloc(void** p, int64_t bytes) {
+    if (!p || bytes < 0) return fail("sarlacc_amd: bad allocation request");
+    SL_TRY(ensure_device());
+    SL_HIP(hipMalloc(p, static_cast<size_t>(bytes > 0 ? bytes : 1)));
+    return 0;
+}
+
+int sarlacc_dev_free(void* p) {
+    if (p) SL_HIP(hipFree(p));
+    return 0;
+}
+
+int sarlacc_dev_upload(void* d, const void* h, int64_t bytes) {
+    SL_TRY(ensure_device());
+    if (bytes > 0) SL_HIP(hipMemcpy(d, h, static_cast<size_t>(bytes), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int sarlacc_dev_download(void* h, const void* d, int64_t bytes) {
+    SL_TRY(ensure_device());
+    if (bytes > 0) SL_HIP(hipMemcpy(h, d, static_cast<size_t>(bytes), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sarlacc_dev_windows(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
+                        const int64_t* d_woff, int which, uint8_t* d_oseq, uint8_t* d_oqual, void* stream) {
+    if (n < 0 || (which != 0 && which != 1)) return fail("sarlacc_amd: bad window request");
+    if (n == 0) return 0;
+    SL_TRY(ensure_device());
+    hipLaunchKernelGGL(k_windows, dim3(static_cast<unsigned>(n)), dim3(64), 0, static_cast<hipStream_t>(stream), d_seq,
+                       d_qual, d_off, static_cast<long long>(n), d_woff, which, d_oseq, d_oqual);
+    SL_HIP(hipGetLastError());
+    return 0;
+}
+
+int sarlacc_dev_scramble(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
+                         uint64_t seed, uint8_t* d_oseq, uint8_t* d_oqual, void* stream) {
+    if (n < 0) return fail("sarlacc_amd: negative number of reads");
+    if (n == 0) return 0;
+    SL_TRY(ensure_device());
+    hipLaunchKernelGGL(k_scramble, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(64), 0,
+                       static_cast<hipStream_t>(stream), d_seq, d_qual, d_off, static_cast<long long>(n),
+                       static_cast<unsigned long long>(seed), d_oseq, d_oqual);
+    SL_HIP(hipGetLastError());
+    return 0;
+}
+}

@@ -268,3 +268,85 @@ def consensusReadSeq(alignments, pseudo_count=1, min_coverage=0.6):
     else:
         out = calls.create_consensus_basic_loop(aln, min_coverage, pseudo_count)
     return Reads(out[0], out[1], alignments.get("names"))
+
+
+# ---------------------------------------------------------------------------
+# scrambled-control callers (SURVEY section 8 f1): same DP kernel, reads kept resident
+
+def _tied_overlap(real, fake):
+    """.tied_overlap (R/tuneAlignment.R:80-87): mean of findInterval with closed/open left ends."""
+    fake = np.sort(np.asarray(fake, dtype=np.float64))
+    real = np.asarray(real, dtype=np.float64)
+    upper = np.searchsorted(fake, real, side="right")
+    lower = np.searchsorted(fake, real, side="left")
+    return float(((upper + lower) / 2).sum() / (real.size * fake.size))
+
+
+def _alignment_scores(dev_start, dev_end, adaptor1, adaptor2, go, ge):
+    """.get_alignment_scores (R/tuneAlignment.R:103-116) on resident windows."""
+    return {"START": dev_start.align_scores(adaptor1, go, ge), "END": dev_end.align_scores(adaptor2, go, ge),
+            "RSTART": dev_end.align_scores(adaptor1, go, ge), "REND": dev_start.align_scores(adaptor2, go, ge)}
+
+
+def tuneAlignment(adaptor1, adaptor2, reads, tolerance=200, number=10000, gapOp_range=(4, 10), gapExt_range=(1, 5), seed=0):
+    """tuneAlignment (R/tuneAlignment.R:6-77): grid search of the gap penalties that best separate
+    real from scrambled alignment scores.  Reads are sampled, uploaded once and stay in HBM for the
+    whole grid (windows and shuffles are built on the device).  `seed` drives the read sample and
+    the shuffles (the reference uses R's global RNG)."""
+    from .resident import DeviceReads
+    adaptor1, adaptor2 = str(adaptor1).upper(), str(adaptor2).upper()
+    if isinstance(reads, str):
+        reads = read_fastq(reads)
+    if len(reads) == 0:
+        return {"parameters": {"gapOpening": None, "gapExtension": None}, "scores": {"reads": np.zeros(0), "scrambled": np.zeros(0)}}
+    if len(reads) > number:  # FastqSampler(filepath, number)
+        keep = np.sort(np.random.default_rng(seed).choice(len(reads), int(number), replace=False))
+        reads = reads.subset(keep)
+    dev = DeviceReads.upload(reads)
+    start, end = dev.front_and_back(tolerance)
+    sstart, send = start.scramble(2 * seed + 1), end.scramble(2 * seed + 2)
+    go_lo, go_hi = (int(x) for x in np.maximum.accumulate(gapOp_range))
+    ge_lo, ge_hi = (int(x) for x in np.maximum.accumulate(gapExt_range))
+    best = {"score": 0.0, "go": None, "ge": None, "reads": None, "scrambled": None}
+    for go in range(go_lo, go_hi + 1):
+        for ge in range(ge_lo, ge_hi + 1):
+            r = _alignment_scores(start, end, adaptor1, adaptor2, go, ge)
+            x = _alignment_scores(sstart, send, adaptor1, adaptor2, go, ge)
+            rs = _resolve_strand(r["START"], r["END"], r["RSTART"], r["REND"])[1]
+            xs = _resolve_strand(x["START"], x["END"], x["RSTART"], x["REND"])[1]
+            cur = _tied_overlap(rs, xs)
+            if best["score"] < cur:
+                best = {"score": cur, "go": go, "ge": ge, "reads": rs, "scrambled": xs}
+    return {"parameters": {"gapOpening": best["go"], "gapExtension": best["ge"]},
+            "scores": {"reads": best["reads"], "scrambled": best["scrambled"]}}
+
+
+def _compute_threshold(real, scrambled, error):
+    """.compute_threshold (R/getAdaptorThresholds.R:94-103)."""
+    real = np.sort(np.asarray(real, dtype=np.float64))
+    scrambled = np.sort(np.asarray(scrambled, dtype=np.float64))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        fdr = (scrambled.size - np.searchsorted(scrambled, real, side="right")) / (real.size - np.arange(1, real.size + 1))
+    ok = np.flatnonzero(fdr <= error)
+    return float(real[ok.min()]) if ok.size else float("nan")
+
+
+def getAdaptorThresholds(aligned, reads, error=0.01, seed=0):
+    """getAdaptorThresholds (R/getAdaptorThresholds.R:6-66): score thresholds achieving the given
+    error rate against scrambled reads.  `aligned` is adaptorAlign's result for `reads`
+    (the reference re-streams the FASTQ file named in the metadata; pass the same reads here)."""
+    from .resident import DeviceReads
+    if isinstance(reads, str):
+        reads = read_fastq(reads)
+    md1 = aligned["adaptor1"]["metadata"]
+    go, ge = md1["gapOpening"], md1["gapExtension"]
+    adaptor1, adaptor2 = md1["sequence"], aligned["adaptor2"]["metadata"]["sequence"]
+    dev = DeviceReads.upload(reads)
+    start, end = dev.front_and_back(aligned["metadata"]["tolerance"])
+    x = _alignment_scores(start.scramble(2 * seed + 1), end.scramble(2 * seed + 2), adaptor1, adaptor2, go, ge)
+    rev = _resolve_strand(x["START"], x["END"], x["RSTART"], x["REND"])[0]
+    scram1 = np.where(rev, x["RSTART"], x["START"])
+    scram2 = np.where(rev, x["REND"], x["END"])
+    real1, real2 = aligned["adaptor1"]["score"], aligned["adaptor2"]["score"]
+    return {"threshold1": _compute_threshold(real1, scram1, error), "threshold2": _compute_threshold(real2, scram2, error),
+            "scores1": {"reads": real1, "scrambled": scram1}, "scores2": {"reads": real2, "scrambled": scram2}}
