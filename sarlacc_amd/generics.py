@@ -174,13 +174,23 @@ def adaptorAlign(adaptor1, adaptor2, reads, tolerance=250, gapOpening=5, gapExte
 
 # ---------------------------------------------------------------------------
 def barcodeAlign(sequences, barcodes, gapOpening=5, gapExtension=1):
-    """barcodeAlign (R/barcodeAlign.R:4-40): best barcode, its score, and the gap to the next best."""
+    """barcodeAlign (R/barcodeAlign.R:4-40): best barcode, its score, and the gap to the next best.
+    The barcode reads are uploaded once and stay resident while every candidate is aligned
+    (the reference re-marshals them for each barcode, R/barcodeAlign.R:20-24)."""
     n = len(sequences)
     current = np.full(n, -np.inf)
     nextbest = np.full(n, -np.inf)
     ident = np.full(n, -1, dtype=np.int64)  # NA_integer_
+    dev = None
+    if calls.__name__.endswith("sarlacc_amd.calls") and n:
+        from .resident import DeviceReads
+        dev = DeviceReads.upload(sequences)
     for b, bc in enumerate(barcodes):
-        scores = calls.barcode_align(sequences.seq, sequences.qual, sequences.encoding, gapOpening, gapExtension, str(bc))
+        if dev is not None:
+            calls._string(str(bc), "barcode sequence")
+            scores = dev.align_scores(str(bc), gapOpening, gapExtension, local=False)
+        else:
+            scores = calls.barcode_align(sequences.seq, sequences.qual, sequences.encoding, gapOpening, gapExtension, str(bc))
         keep = scores > current
         second = ~keep & (scores > nextbest)
         ident[keep] = b + 1
@@ -350,3 +360,35 @@ def getAdaptorThresholds(aligned, reads, error=0.01, seed=0):
     real1, real2 = aligned["adaptor1"]["score"], aligned["adaptor2"]["score"]
     return {"threshold1": _compute_threshold(real1, scram1, error), "threshold2": _compute_threshold(real2, scram2, error),
             "scores1": {"reads": real1, "scrambled": scram1}, "scores2": {"reads": real2, "scrambled": scram2}}
+
+
+# ---------------------------------------------------------------------------
+def extractSubseq(aligned, reads, subseq1=None, subseq2=None):
+    """extractSubseq (R/extractSubseq.R:5-117): re-align with the orientation already known and
+    pull out the read subsequences opposite the given adaptor positions (1-based inclusive
+    `starts` / `ends`).  Like the reference it insists that the re-computed scores equal the
+    stored ones -- scores are bit-reproducible here, so equality is exact."""
+    if subseq1 is None and subseq2 is None:
+        raise ValueError("at least one of 'subseq1' or 'subseq2' must be specified")
+    if isinstance(reads, str):
+        reads = read_fastq(reads)
+    md1, md2 = aligned["adaptor1"]["metadata"], aligned["adaptor2"]["metadata"]
+    go, ge = md1["gapOpening"], md1["gapExtension"]
+    front, back = _get_front_and_back(reads, aligned["metadata"]["tolerance"])
+    flipped = np.asarray(aligned["reversed"], dtype=bool)
+
+    def pick(a, b):  # a[flipped] <- b[flipped]
+        fs, bs = a.seq.to_strings(), b.seq.to_strings()
+        fq, bq = a.qual.to_strings(), b.qual.to_strings()
+        return Reads([y if f else x for x, y, f in zip(fs, bs, flipped)], [y if f else x for x, y, f in zip(fq, bq, flipped)],
+                     encoding=reads.encoding)
+
+    out = {}
+    for key, sub, rd, md in (("adaptor1", subseq1, pick(front, back), md1), ("adaptor2", subseq2, pick(back, front), md2)):
+        if sub is None or (len(sub["starts"]) == 0 and len(sub["ends"]) == 0):
+            continue
+        res = _align_and_extract(md["sequence"], rd, go, ge, np.asarray(sub["starts"]), np.asarray(sub["ends"]))
+        if not np.allclose(res["score"], aligned[key]["score"], rtol=1.5e-8, atol=0):
+            raise RuntimeError("score mismatch from 'aligned' for adaptor %s" % key[-1])
+        out[key] = res["subseq"]
+    return out

@@ -104,3 +104,27 @@ def test_barcode_quality_expected(monkeypatch):
     assert g3.tolist() == w3.tolist()
     assert g4 == w4
     assert isinstance(g4[2], list)
+
+
+def test_extract_subseq_and_resident_barcodes(monkeypatch):
+    """extractSubseq (R/extractSubseq.R) re-aligns with known orientation and must agree with the
+    stored scores; constant adaptor regions come back (nearly) as written."""
+    from sarlacc_amd import generics
+    from sarlacc_amd.mock import mock_reads
+    from tests import oracle_calls
+    sim = mock_reads(A1, A2, nmolecules=10, nreads=6, seqlen=300, seed=21)
+    rd = generics.Reads(sim["reads"], sim["quals"])
+    aligned = generics.adaptorAlign(A1, A2, rd)
+    sub = generics.extractSubseq(aligned, rd, subseq1={"starts": [1, 22], "ends": [9, 30]}, subseq2={"starts": [5], "ends": [11]})
+    assert set(sub) == {"adaptor1", "adaptor2"} and set(sub["adaptor1"]) == {"Sub1", "Sub2"}
+    good = aligned["adaptor1"]["score"] > 15
+    exact = np.mean([s == A1[:9] for s, g in zip(sub["adaptor1"]["Sub1"], good) if g])
+    assert exact > 0.4
+    only1 = generics.extractSubseq(aligned, rd, subseq1={"starts": [1], "ends": [9]})
+    assert set(only1) == {"adaptor1"} and only1["adaptor1"]["Sub1"] == sub["adaptor1"]["Sub1"]
+    with pytest.raises(ValueError):
+        generics.extractSubseq(aligned, rd)
+    # same through the oracle
+    monkeypatch.setattr(generics, "calls", oracle_calls)
+    want = generics.extractSubseq(aligned, rd, subseq1={"starts": [1, 22], "ends": [9, 30]}, subseq2={"starts": [5], "ends": [11]})
+    assert want == sub
