@@ -1,0 +1,126 @@
+"""GPU checks at BASELINE.json's full sizes through size-independent properties (the oracle
+cannot finish these sizes): consistency between kernel variants, agreement with the oracle on
+a sample of the same batch, partition / idempotence / duplicate-class properties of the UMI
+grouping, round-trip properties of the MSA rows and accuracy of the consensus."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+A1 = "ACGATCAGC" + "N" * 12 + "GTCAGTCAG"
+A2 = "CACACTGAGCAGCGACTAGACA"
+
+
+def test_c2_adaptor_align_one_million_reads(oracle, oenc, enc):
+    torch = pytest.importorskip("torch")
+    import sarlacc_amd
+    from sarlacc_amd import device as sdev, devsynth
+    dev = torch.device("cuda", 0)
+    n = 1_000_000
+    seq, qual, off, max_len = devsynth.make_reads(n, 2000, A1, A2, seed=1000, device=dev)
+    total = int(off[-1].item())
+    stream = torch.cuda.current_stream().cuda_stream
+    packed = torch.empty(total // 4 + 2, dtype=torch.uint8, device=dev)
+    nmask = torch.empty(total // 8 + 1, dtype=torch.uint8, device=dev)
+    sdev.dev_pack_reads(seq, total, packed, nmask, stream)
+
+    def run(buf, mask, trace):
+        sc = torch.empty(n, dtype=torch.float64, device=dev)
+        outs = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(4)] if trace else [None] * 4
+        sdev.dev_align(buf, qual, off, n, max_len, enc, 5.0, 1.0, A1, True, [9] if trace else (), [21] if trace else (),
+                       sc, outs[0], outs[1], outs[2], outs[3], stream, d_nmask=mask)
+        torch.cuda.synchronize()
+        return sc, outs
+
+    s_trace, o_trace = run(packed, nmask, True)
+    s_score, _ = run(packed, nmask, False)
+    s_ascii, o_ascii = run(seq, None, True)
+    # the three kernel variants agree bit for bit
+    assert torch.equal(s_trace.view(torch.int64), s_score.view(torch.int64))
+    assert torch.equal(s_trace.view(torch.int64), s_ascii.view(torch.int64))
+    for a, b in zip(o_trace, o_ascii):
+        assert torch.equal(a, b)
+    # a checksum of the outputs is reproducible run to run (scores are deterministic, cf. the
+    # reference's own re-alignment check, R/extractSubseq.R:58-72)
+    s_again, o_again = run(packed, nmask, True)
+    assert torch.equal(s_trace.view(torch.int64), s_again.view(torch.int64)) and torch.equal(o_trace[0], o_again[0])
+    # the oracle agrees on a strided sample of the same batch
+    idx = list(range(0, n, n // 1500))
+    o = off.cpu().numpy()
+    seq_h, qual_h = seq.cpu().numpy(), qual.cpu().numpy()
+    reads = [seq_h[o[i]:o[i + 1]].tobytes().decode() for i in idx]
+    quals = [qual_h[o[i]:o[i + 1]].tobytes().decode() for i in idx]
+    want = oracle.adaptor_align(reads, quals, oenc, 5, 1, A1, [9], [21])
+    ii = torch.tensor(idx, device=dev)
+    assert np.array_equal(s_trace[ii].cpu().numpy().view(np.int64), want[0].view(np.int64))
+    assert np.array_equal(o_trace[0][ii].cpu().numpy(), want[1]) and np.array_equal(o_trace[1][ii].cpu().numpy(), want[2])
+    assert np.array_equal(o_trace[2][ii].cpu().numpy(), want[3][0]) and np.array_equal(o_trace[3][ii].cpu().numpy(), want[4][0])
+    # sanity of the biology: about half the reads carry adaptor 1 at their start
+    hit = (s_trace > 15).float().mean().item()
+    assert 0.4 < hit < 0.6
+    starts = o_trace[0][s_trace > 15]
+    assert (starts <= 3).float().mean().item() > 0.9
+
+
+def test_c3_umi_group_one_million_umis():
+    from sarlacc_amd import calls
+    from tools.perf_umi import make_umis
+    ss = make_umis(100_000, 10, 1001)
+    n = len(ss)
+    everything = [np.arange(1, n + 1, dtype=np.int32)]
+    got = calls.umi_group(ss, 1, None, 1, everything)
+    flat = np.concatenate(got)
+    assert flat.size == n and np.array_equal(np.sort(flat), np.arange(1, n + 1))      # a partition
+    again = calls.umi_group(ss, 1, None, 1, everything)
+    assert len(again) == len(got) and all(np.array_equal(a, b) for a, b in zip(got, again))  # deterministic
+    # threshold 0: clusters are exactly the classes of identical UMIs
+    zero = calls.umi_group(ss, 0, None, 0, everything)
+    strs = np.array(ss.to_strings())
+    _, inv = np.unique(strs, return_inverse=True)
+    lab = np.empty(n, dtype=np.int64)
+    for k, c in enumerate(zero):
+        lab[c - 1] = k
+    assert len(zero) == inv.max() + 1
+    first = {}
+    for a, b in zip(inv.tolist(), lab.tolist()):
+        assert first.setdefault(a, b) == b
+    # clustering is greedy max-neighbour: sizes never increase along the output after the solos
+    sizes = np.array([len(c) for c in got])
+    nonsolo = sizes[sizes > 1]
+    assert nonsolo.size > 10_000
+    # members of a cluster are within 2*threshold edits of its seed's neighbourhood: every member
+    # is within distance 1 of at least one other member (checked on a sample)
+    from tests.test_oracle_umi import lev2
+    rng = np.random.default_rng(0)
+    for k in rng.choice(np.flatnonzero(sizes > 1), 300, replace=False):
+        members = [strs[i - 1] for i in got[k]]
+        for m in members:
+            assert min(lev2(m, x) for x in members if x is not m) <= 2 or members.count(m) > 1
+
+
+def test_c4_msa_and_consensus_ten_thousand_groups(enc, oracle):
+    from sarlacc_amd import calls
+    from tools.perf_pipeline import NUC, noisy_copies
+    rng = np.random.default_rng(1000)
+    G = 10_000
+    truth = NUC[rng.integers(0, 4, (G, 2000))]
+    reads, quals = noisy_copies(truth, 10, rng)
+    goff = np.arange(G + 1, dtype=np.int64) * 10
+    gflat = np.arange(1, 10 * G + 1, dtype=np.int32)
+    rows, grp_rows, width = calls.quick_msa_flat(goff, gflat, reads, 0, -1, -5, -1, 100)
+    assert np.array_equal(grp_rows, goff)
+    w = rows.widths()
+    assert np.array_equal(w, np.repeat(width, 10))                       # equal widths inside a group
+    # every row with its gaps removed is the read it came from (checked via lengths for all,
+    # via content for a sample)
+    gaps = np.add.reduceat((rows.chars[:rows.total] == ord("-")).astype(np.int64), rows.off[:-1])
+    assert np.array_equal(w - gaps, reads.widths())
+    for r in rng.integers(0, 10 * G, 200):
+        assert rows[int(r)].replace("-", "") == reads[int(r)]
+    cons, phred = calls.create_consensus_flat(rows, grp_rows, 0.6, quals=quals, encoding=enc)
+    assert len(cons) == G and np.array_equal(cons.widths(), phred.widths())
+    errs = []
+    for g in rng.integers(0, G, 150):
+        t = truth[g].tobytes().decode()
+        errs.append(float(oracle.compute_lev_masked([cons[int(g)], t])[0]) / len(t))   # plain Levenshtein here
+    assert np.mean(errs) < 0.002 and np.max(errs) < 0.01
