@@ -88,6 +88,22 @@ __device__ __forceinline__ double dpp_shr1(double v) {
 // consecutive rows i, i-1, ... whose bit 3 is set) -- exactly 1 + pos - left_jump_point and
 // 1 + i - up_jump_point.  A lane packs the codes of STEPS consecutive steps x K columns
 // into one word: 0.5 B per cell instead of the 2-4 B of a stored length.
+// Shift by one lane towards higher lanes.  ROW16: inside each 16-lane DPP row (row_shr:1); the
+// first lane of every row -- the leader of an alignment when groups are 16 lanes wide -- gets
+// `fill` (its DP column 0 value) for free.  Otherwise across the whole wave (wave_shr:1).
+template <bool ROW16>
+__device__ __forceinline__ int lane_shr1(int v, int fill) {
+    if (ROW16) return __builtin_amdgcn_update_dpp(fill, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+template <bool ROW16>
+__device__ __forceinline__ double lane_shr1(double v, double fill) {
+    const long long b = __double_as_longlong(v), f = __double_as_longlong(fill);
+    const int lo = lane_shr1<ROW16>(static_cast<int>(b), static_cast<int>(f));
+    const int hi = lane_shr1<ROW16>(static_cast<int>(b >> 32), static_cast<int>(f >> 32));
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
 template <int K>
 struct TbSteps { static constexpr int value = (8 / K) > 0 ? 8 / K : 1; };
 template <int K>
@@ -98,7 +114,9 @@ struct TbStore<16> { using type = unsigned long long; };
 // MODE 0: scores only.  MODE 1: scores + reference->read map (adaptor_align).
 // MODE 2: scores + gapped strings + edit distance (general_align).
 // LOCAL: free leading read bases + free vertical gaps in the last column (adaptor mode).
-template <int K, int MODE, bool LOCAL>
+// ROW16: alignments are 16 lanes wide and start on DPP row boundaries.
+// KLAST: index (inside its lane) of reference column R when known at compile time, else -1.
+template <int K, int MODE, bool LOCAL, bool ROW16, int KLAST>
 __global__ void __launch_bounds__(64, 5) k_align(const AlignArgs A) {
     constexpr int UNR = TbSteps<K>::value;
     using Word = typename TbStore<K>::type;
@@ -138,7 +156,7 @@ __global__ void __launch_bounds__(64, 5) k_align(const AlignArgs A) {
         rz[k] = A.rowzero[cc];
     }
     const double rz_left = A.rowzero[c0 - 1 <= R ? c0 - 1 : R];
-    const int jlast = (R - 1) / K, klast = (R - 1) % K;
+    const int jlast = (R - 1) / K, klast = KLAST >= 0 ? KLAST : (R - 1) % K;
     Word* const scr = static_cast<Word*>(A.dirs) + static_cast<size_t>(blockIdx.x) * A.dirs_per_wave;
     const unsigned char* const tab_bytes = reinterpret_cast<const unsigned char*>(s_tab);
     __syncthreads();
@@ -226,12 +244,11 @@ __global__ void __launch_bounds__(64, 5) k_align(const AlignArgs A) {
             for (int u = 0; u < UNR; ++u) {
                 const int t = t0 + u;
                 const int i = t - j;
-                if (leader) {  // column 0 of the DP (src/reference_align.cpp:63-78)
-                    if (LOCAL) s_in = 0.0;
-                    else s_in = (i < 1) ? 0.0 : (-GO - GE * static_cast<double>(i - 1));
-                    lj_in = NEG_INF;
-                    hp_in = 0;
-                }
+                // column 0 of the DP (src/reference_align.cpp:63-78): what a leader lane consumes
+                double col0;
+                if (LOCAL) col0 = 0.0;
+                else col0 = (i < 1) ? 0.0 : (-GO - GE * static_cast<double>(i - 1));
+                if (!ROW16 && leader) { s_in = col0; lj_in = NEG_INF; hp_in = 0; }
                 double left = s_in, lj = lj_in;
                 bool hp = hp_in != 0;
 
@@ -271,10 +288,15 @@ __global__ void __launch_bounds__(64, 5) k_align(const AlignArgs A) {
                         hp = !takem && hv;
                         vneg[k] = !takem && !hv;
                         if (MODE >= 1) {
+                            // small constants stay inline operands; one shift-or places the code
                             const unsigned nib = (takem ? 0u : (hv ? 1u : 2u)) | (hj ? 4u : 0u) | (vj ? 8u : 0u);
                             pk |= static_cast<Word>(nib) << (4 * (u * K + k));
-                            nonvert_last = (k == klast) ? (takem || hv) : nonvert_last;
-                            vj_last = (k == klast) ? vj : vj_last;
+                            if (KLAST >= 0) {
+                                if (k == KLAST) { nonvert_last = takem || hv; vj_last = vj; }
+                            } else {
+                                nonvert_last = (k == klast) ? (takem || hv) : nonvert_last;
+                                vj_last = (k == klast) ? vj : vj_last;
+                            }
                         }
                     }
                     if (MODE >= 1) {
@@ -283,9 +305,14 @@ __global__ void __launch_bounds__(64, 5) k_align(const AlignArgs A) {
                         land_prev = land_i;
                     }
                 }
-                s_in = dpp_shr1(left);
-                lj_in = dpp_shr1(lj);
-                hp_in = dpp_shr1(hp ? 1 : 0);
+                // hand the row state to the next lane; with 16-lane groups the leaders receive the
+                // column-0 values of the NEXT step's row straight from the DPP fill operand
+                double col0_next;
+                if (LOCAL) col0_next = 0.0;
+                else col0_next = (i + 1 < 1) ? 0.0 : (-GO - GE * static_cast<double>(i));
+                s_in = lane_shr1<ROW16>(left, col0_next);
+                lj_in = lane_shr1<ROW16>(lj, NEG_INF);
+                hp_in = lane_shr1<ROW16>(hp ? 1 : 0, 0);
             }
             if (MODE >= 1) __builtin_nontemporal_store(pk, scr + static_cast<size_t>(t0 / UNR) * 64 + lane);
         }
@@ -454,8 +481,11 @@ static Shape pick_shape(int R) {
     Shape best{1, 64, 1};
     double best_u = -1;
     for (int K : {1, 2, 4, 8, 16}) {
-        const int W = (R + K - 1) / K;
+        int W = (R + K - 1) / K;
         if (W > 64) continue;
+        // groups of up to 16 lanes are padded to one DPP row: NGMAX = 4 of them fill the wave
+        // and the leaders get their column-0 inputs for free (lane_shr1<true>)
+        if (W <= 16) W = 16;
         const int ng = std::min(64 / W, NGMAX);
         const double u = static_cast<double>(ng) * R / (64.0 * K);
         if (u > best_u + 1e-9 || (u > best_u - 1e-9 && K > best.K && K <= 2)) { best_u = u; best = {K, W, ng}; }
@@ -463,25 +493,30 @@ static Shape pick_shape(int R) {
     return best;
 }
 
-template <int K>
+template <int K, bool ROW16, int KLAST>
 static int launch_mode(int mode, bool local, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
     // adaptor_align is always local, general_align always global; score-only comes in both
-    if (mode == 0 && local) hipLaunchKernelGGL((k_align<K, 0, true>), dim3(grid), dim3(64), lds, s, a);
-    else if (mode == 0) hipLaunchKernelGGL((k_align<K, 0, false>), dim3(grid), dim3(64), lds, s, a);
-    else if (mode == 1 && local) hipLaunchKernelGGL((k_align<K, 1, true>), dim3(grid), dim3(64), lds, s, a);
-    else if (mode == 2 && !local) hipLaunchKernelGGL((k_align<K, 2, false>), dim3(grid), dim3(64), lds, s, a);
+    if (mode == 0 && local) hipLaunchKernelGGL((k_align<K, 0, true, ROW16, KLAST>), dim3(grid), dim3(64), lds, s, a);
+    else if (mode == 0) hipLaunchKernelGGL((k_align<K, 0, false, ROW16, KLAST>), dim3(grid), dim3(64), lds, s, a);
+    else if (mode == 1 && local) hipLaunchKernelGGL((k_align<K, 1, true, ROW16, KLAST>), dim3(grid), dim3(64), lds, s, a);
+    else if (mode == 2 && !local) hipLaunchKernelGGL((k_align<K, 2, false, ROW16, KLAST>), dim3(grid), dim3(64), lds, s, a);
     else return fail("sarlacc_amd: unsupported alignment mode");
     SL_HIP(hipGetLastError());
     return 0;
 }
 
-static int launch_k(int K, int mode, bool local, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
+static int launch_k(int K, int W, int R, int mode, bool local, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
+    const bool row16 = (W == 16);
+    const int klast = (R - 1) % K;
+    if (K == 1) return row16 ? launch_mode<1, true, 0>(mode, local, a, grid, lds, s) : launch_mode<1, false, 0>(mode, local, a, grid, lds, s);
+    if (K == 2) {
+        if (row16) return klast == 0 ? launch_mode<2, true, 0>(mode, local, a, grid, lds, s) : launch_mode<2, true, 1>(mode, local, a, grid, lds, s);
+        return klast == 0 ? launch_mode<2, false, 0>(mode, local, a, grid, lds, s) : launch_mode<2, false, 1>(mode, local, a, grid, lds, s);
+    }
     switch (K) {
-        case 1: return launch_mode<1>(mode, local, a, grid, lds, s);
-        case 2: return launch_mode<2>(mode, local, a, grid, lds, s);
-        case 4: return launch_mode<4>(mode, local, a, grid, lds, s);
-        case 8: return launch_mode<8>(mode, local, a, grid, lds, s);
-        case 16: return launch_mode<16>(mode, local, a, grid, lds, s);
+        case 4: return row16 ? launch_mode<4, true, -1>(mode, local, a, grid, lds, s) : launch_mode<4, false, -1>(mode, local, a, grid, lds, s);
+        case 8: return row16 ? launch_mode<8, true, -1>(mode, local, a, grid, lds, s) : launch_mode<8, false, -1>(mode, local, a, grid, lds, s);
+        case 16: return row16 ? launch_mode<16, true, -1>(mode, local, a, grid, lds, s) : launch_mode<16, false, -1>(mode, local, a, grid, lds, s);
     }
     return fail("sarlacc_amd: unsupported columns-per-lane %d", K);
 }
@@ -551,7 +586,10 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     if (const char* ek = std::getenv("SARLACC_ALIGN_K")) {  // tuning override
         const int K = std::atoi(ek);
         const int W = (R + K - 1) / K;
-        if ((K == 1 || K == 2 || K == 4 || K == 8 || K == 16) && W <= 64) sh = {K, W, std::min(64 / W, NGMAX)};
+        if ((K == 1 || K == 2 || K == 4 || K == 8 || K == 16) && W <= 64) {
+            const int Wp = W <= 16 ? 16 : W;
+            sh = {K, Wp, std::min(64 / Wp, NGMAX)};
+        }
     }
     const long long nitems = (n + sh.ngroups - 1) / sh.ngroups;
     // traceback tile of one resident wave: one word per lane per TbSteps<K> steps (4 bits per cell)
@@ -581,7 +619,7 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
 
     const size_t lds = sizeof(double) * 5 * enc_n + sizeof(uint16_t) * NGMAX * RING + sizeof(int32_t) * NGMAX * (R + 1) + 16;
     SL_HIP(hipEventRecord(c.ev_start, stream));
-    SL_TRY(launch_k(sh.K, kernel_mode, local, a, static_cast<int>(grid), lds, stream));
+    SL_TRY(launch_k(sh.K, sh.W, R, kernel_mode, local, a, static_cast<int>(grid), lds, stream));
     SL_HIP(hipEventRecord(c.ev_stop, stream));
     c.timed = true;
 

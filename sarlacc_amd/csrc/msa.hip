@@ -120,8 +120,16 @@ __global__ void __launch_bounds__(64) k_msa_pairwise(const MsaArgs A) {
             cw[k] = ctr_at(dlo + lane * C + k - 1);  // centre base of column j = dlo + x at row 0
         }
 
+        // read bases: lane l holds base (chunk start + l); the next 64 are already in flight, so
+        // no row waits on a global load
+        int rchunk = (lane < lr) ? dna5_code(rd[lane]) : 4;
+        int rnext = (64 + lane < lr) ? dna5_code(rd[64 + lane]) : 4;
         for (int i = 0; i <= lr; ++i) {
-            const int rc = (i > 0) ? dna5_code(rd[i - 1]) : 0xfe;
+            if (i > 1 && ((i - 1) & 63) == 0) {
+                rchunk = rnext;
+                rnext = (i - 1 + 64 + lane < lr) ? dna5_code(rd[i - 1 + 64 + lane]) : 4;
+            }
+            const int rc = (i > 0) ? __builtin_amdgcn_readlane(rchunk, (i - 1) & 63) : 0xfe;
             const int upH_r = dpp_int<DPP_WAVE_SHL1>(MSA_NEG, Hp[0]);
             const int upE_r = dpp_int<DPP_WAVE_SHL1>(MSA_NEG, Ep[0]);
             int hq[C], ev[C], dv[C], lp[C];
@@ -443,7 +451,7 @@ extern "C" int sarlacc_quick_msa(const int64_t* grp_off, const int32_t* grp, int
         const int C = max_band <= 256 ? 4 : (max_band <= 512 ? 8 : 16);
         const size_t word = C == 16 ? 8 : 4;
         const size_t per_wave = (static_cast<size_t>(max_lr) + 2) * 64;
-        long long grid = std::min<long long>(static_cast<long long>(jobs.size()), static_cast<long long>(c.num_cu) * 8);
+        long long grid = std::min<long long>(static_cast<long long>(jobs.size()), static_cast<long long>(c.num_cu) * (C == 4 ? 16 : 8));
         const size_t budget = static_cast<size_t>(8) << 30;
         grid = std::min<long long>(grid, std::max<long long>(1, static_cast<long long>(budget / (per_wave * word))));
         void* d_tb;
