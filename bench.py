@@ -56,7 +56,7 @@ def pmc_traffic(n_reads):
         d = json.load(fh)
     kb = sum(d["FETCH_SIZE_KB_per_launch"]) / len(d["FETCH_SIZE_KB_per_launch"]) + \
         sum(d["WRITE_SIZE_KB_per_launch"]) / len(d["WRITE_SIZE_KB_per_launch"])
-    return kb * 1024.0
+    return kb * 1024.0, d.get("derived")
 
 
 def pipeline_sample(groups=4000, read_len=2000, copies=10):
@@ -199,9 +199,10 @@ def main():
             "kernel_ms": k_ms,
             "kernel_gcups": cells / (k_ms * 1e-3) / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": (pmc_traffic(n) or (None, None))[0],
                          "algorithmic_bytes": alg_bytes,
-                         "note": "DP is VALU/latency bound; compulsory traffic is 0.042 B/cell"},
+                         "valu": (pmc_traffic(n) or (None, None))[1],
+                         "note": "the DP kernel is VALU-issue bound (valu.valu_busy_frac from the PMC pass); compulsory traffic is 0.042 B/cell"},
         }
         if not args.no_pipeline:
             out["pipeline"] = pipeline_sample()
