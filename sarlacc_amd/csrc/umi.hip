@@ -166,14 +166,41 @@ struct PairArgs {
     unsigned long long cap;
 };
 
+// Shifted-Hamming lower bound for N-free pairs: a position of `a` that differs from b at every
+// shift -K..K cannot be matched by any alignment within the band, so it costs a substitution or
+// an indel (2 each).  More than `limit` such positions => d2 > 2*limit.
+template <int K>
+__device__ __forceinline__ bool shd_reject(unsigned long long ca, int la, unsigned long long cb, int lb, int limit) {
+    const unsigned long long EVEN = 0x5555555555555555ull;
+    const unsigned long long amask = la >= 32 ? ~0ull : ((1ull << (2 * la)) - 1ull);
+    unsigned long long all = EVEN & amask;
+#pragma unroll
+    for (int s = -K; s <= K; ++s) {
+        const unsigned long long xb = s >= 0 ? (cb >> (2 * s)) : (cb << (-2 * s));
+        const unsigned long long diff = ca ^ xb;
+        unsigned long long m = (diff | (diff >> 1)) & EVEN;
+        // positions whose partner p+s falls outside b count as mismatches
+        const int hi = lb - s;  // p < hi
+        unsigned long long valid = hi >= 32 ? ~0ull : (hi <= 0 ? 0ull : ((1ull << (2 * hi)) - 1ull));
+        if (s < 0) valid &= ~((1ull << (-2 * s)) - 1ull);
+        m |= ~valid;
+        all &= m;
+    }
+    return __popcll(all) > limit;
+}
+
 template <int K>
 __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
     const int bi = blockIdx.x, bj = blockIdx.y;
     if (bj < bi) return;
-    __shared__ unsigned long long s_code[TILE];
-    __shared__ uint32_t s_nmask[TILE], s_comp[TILE], s_meta[TILE];
-    __shared__ int s_gid[TILE];
+    // column tile (c*) and row tile (r*) both live in LDS: survivors of the cheap filters are
+    // queued per wave and evaluated 64 at a time, so the exact DP always runs on full waves
+    __shared__ unsigned long long c_code[TILE], r_code[TILE];
+    __shared__ uint32_t c_nmask[TILE], c_meta[TILE], r_nmask[TILE], r_meta[TILE];
+    __shared__ uint4 c_key[TILE];  // {pre-group, meta, composition, N mask}: one broadcast read per column
+    __shared__ uint32_t s_q1[TILE / 64][128], s_q2[TILE / 64][128];
     const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
     if (A.gid && bj > bi) {
         // elements are sorted by pre-group: the tiles share no group unless the first group of
         // the column tile is still open at the end of the row tile
@@ -182,39 +209,94 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
     }
     const int jcol = bj * TILE + t;
     if (jcol < A.n) {
-        s_code[t] = A.U.code[jcol]; s_nmask[t] = A.U.nmask[jcol]; s_comp[t] = A.U.comp[jcol]; s_meta[t] = A.U.meta[jcol];
-        s_gid[t] = A.gid ? A.gid[jcol] : 0;
+        c_code[t] = A.U.code[jcol]; c_nmask[t] = A.U.nmask[jcol]; c_meta[t] = A.U.meta[jcol];
+        c_key[t] = make_uint4(A.gid ? static_cast<uint32_t>(A.gid[jcol]) : 0u, A.U.meta[jcol], A.U.comp[jcol], A.U.nmask[jcol]);
     } else {
-        s_code[t] = 0; s_nmask[t] = 0; s_comp[t] = 0; s_meta[t] = 0xffffu;  // len 255: never matches
-        s_gid[t] = -1;
+        c_code[t] = 0; c_nmask[t] = 0; c_meta[t] = 0xffffu;  // len 255: never matches
+        c_key[t] = make_uint4(0xffffffffu, 0xffffu, 0u, 0u);
     }
-    __syncthreads();
     const int i = bi * TILE + t;
-    if (i >= A.n) return;
-    const int gi = A.gid ? A.gid[i] : 0;
-    const unsigned long long ca = A.U.code[i];
-    const uint32_t na = A.U.nmask[i], compa = A.U.comp[i], ma = A.U.meta[i];
+    const bool row_on = i < A.n;
+    const unsigned long long ca = row_on ? A.U.code[i] : 0ull;
+    const uint32_t na = row_on ? A.U.nmask[i] : 0u, compa = row_on ? A.U.comp[i] : 0u, ma = row_on ? A.U.meta[i] : 0xffffu;
+    r_code[t] = ca; r_nmask[t] = na; r_meta[t] = ma;
+    __syncthreads();
     const int la = ma & 0xff, nNa = (ma >> 8) & 0xff;
+    const int gi = (row_on && A.gid) ? A.gid[i] : (row_on ? 0 : -2);
+    const int limit = A.lim2 / 2;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t* const q1 = s_q1[wv];   // pairs that passed the length / composition bounds
+    uint32_t* const q2 = s_q2[wv];   // ... and the shifted-Hamming bound: exact DP pending
+    int n1 = 0, n2 = 0;              // wave-uniform fill levels
+
+    // Two-level compaction: each filter runs on full waves of candidates, so a rare survivor
+    // never drags 63 idle lanes through the next, more expensive stage.
+    auto run_dp = [&](int count) {
+        if (lane < count) {
+            const uint32_t e = q2[lane];
+            const int ti = e >> 8, jj = e & 0xff;
+            const uint32_t mra = r_meta[ti], mcb = c_meta[jj];
+            const int d = banded_lev2<K>(r_code[ti], r_nmask[ti], mra & 0xff, c_code[jj], c_nmask[jj], mcb & 0xff, A.lim2);
+            if (d <= A.lim2) {
+                const unsigned long long slot = atomicAdd(A.count, 1ull);
+                if (slot < A.cap)
+                    A.edges[slot] = (static_cast<unsigned long long>(bi * TILE + ti) << 32) | static_cast<unsigned>(bj * TILE + jj);
+            }
+        }
+    };
+    auto push2 = [&](bool keep, uint32_t e) {
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            if (keep) q2[n2 + __popcll(m & lt)] = e;
+            n2 += __popcll(m);
+            if (n2 >= 64) {
+                run_dp(64);
+                const uint32_t moved = (64 + lane < n2) ? q2[64 + lane] : 0u;
+                if (64 + lane < n2) q2[lane] = moved;
+                n2 -= 64;
+            }
+        }
+    };
+    auto run_shd = [&](int count) {
+        bool keep = false;
+        uint32_t e = 0;
+        if (lane < count) {
+            e = q1[lane];
+            const int ti = e >> 8, jj = e & 0xff;
+            keep = true;
+            if (K <= 8 && (r_nmask[ti] | c_nmask[jj]) == 0u)
+                keep = !shd_reject<(K <= 8 ? K : 0)>(r_code[ti], r_meta[ti] & 0xff, c_code[jj], c_meta[jj] & 0xff, limit);
+        }
+        push2(keep, e);
+    };
+
     const int jn = min(TILE, A.n - bj * TILE);
-    const int j0 = (bi == bj) ? t + 1 : 0;
-    for (int jj = j0; jj < jn; ++jj) {
-        if (s_gid[jj] != gi) continue;
-        const uint32_t mb = s_meta[jj];
-        const int lb = mb & 0xff, nNb = (mb >> 8) & 0xff;
-        const int dl = la > lb ? la - lb : lb - la;
-        if (2 * dl > A.lim2) continue;
-        // composition lower bound: every edit costs >= 1 and moves the 5-letter
-        // composition by <= 2 (<= its cost when no N is involved)
-        const int l1 = static_cast<int>(__builtin_amdgcn_sad_u8(compa, s_comp[jj], 0u)) + (nNa > nNb ? nNa - nNb : nNb - nNa);
-        const uint32_t nb = s_nmask[jj];
-        if (l1 > (((na | nb) != 0u) ? 2 * A.lim2 : A.lim2)) continue;
-        const int d = banded_lev2<K>(ca, na, la, s_code[jj], nb, lb, A.lim2);
-        if (d <= A.lim2) {
-            const unsigned long long slot = atomicAdd(A.count, 1ull);
-            if (slot < A.cap)
-                A.edges[slot] = (static_cast<unsigned long long>(i) << 32) | static_cast<unsigned>(bj * TILE + jj);
+    for (int jj = 0; jj < jn; ++jj) {
+        const uint4 ck = c_key[jj];
+        bool pass = row_on && static_cast<int>(ck.x) == gi && (bi != bj || jj > t);
+        {
+            const int lb = ck.y & 0xff, nNb = (ck.y >> 8) & 0xff;
+            const int dl = la > lb ? la - lb : lb - la;
+            // composition lower bound: every edit costs >= 1 and moves the 5-letter composition by
+            // <= 2 (<= its cost when no N is involved)
+            const int l1 = static_cast<int>(__builtin_amdgcn_sad_u8(compa, ck.z, 0u)) + (nNa > nNb ? nNa - nNb : nNb - nNa);
+            const bool anyN = (na | ck.w) != 0u;
+            pass = pass && 2 * dl <= A.lim2 && l1 <= (anyN ? 2 * A.lim2 : A.lim2);
+        }
+        const unsigned long long mask = __ballot(pass);
+        if (mask) {
+            if (pass) q1[n1 + __popcll(mask & lt)] = (static_cast<uint32_t>(t) << 8) | static_cast<uint32_t>(jj);
+            n1 += __popcll(mask);
+            if (n1 >= 64) {
+                run_shd(64);
+                const uint32_t moved = (64 + lane < n1) ? q1[64 + lane] : 0u;
+                if (64 + lane < n1) q1[lane] = moved;
+                n1 -= 64;
+            }
         }
     }
+    run_shd(n1);
+    run_dp(n2);
 }
 
 // Dense distances for compute_lev_masked: out in R 'dist' order (i-major lower triangle),
