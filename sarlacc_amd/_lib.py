@@ -36,9 +36,24 @@ def _preload_shared_hip_runtime():
             pass
 
 
+def _try_build():
+    """Build the in-tree library when it is missing and hipcc is available (fresh checkout)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+    if hipcc is None:
+        return
+    try:
+        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc"), "HIPCC=" + hipcc])
+    except (subprocess.CalledProcessError, OSError):
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            _try_build()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "sarlacc_amd: %s not found -- build it with `make -C sarlacc_amd/csrc` "

@@ -124,3 +124,29 @@ def test_c4_msa_and_consensus_ten_thousand_groups(enc, oracle):
         t = truth[g].tobytes().decode()
         errs.append(float(oracle.compute_lev_masked([cons[int(g)], t])[0]) / len(t))   # plain Levenshtein here
     assert np.mean(errs) < 0.002 and np.max(errs) < 0.01
+
+
+def test_c1_full_pipeline_identical_to_oracle(monkeypatch):
+    """BASELINE config 1 at its stated size: mockReads 100 molecules x 10 reads x 1 kb through
+    adaptorAlign -> umiGroup -> multiReadAlign -> consensusReadSeq; the HIP path and the CPU oracle
+    must agree at every stage (bit-identical scores, identical groups / rows / consensus)."""
+    from sarlacc_amd import generics
+    from sarlacc_amd.mock import mock_reads
+    from tests import oracle_calls
+    from tests.test_gpu_pipeline import run_pipeline
+    sim = mock_reads(A1, A2, nmolecules=100, nreads=10, seqlen=1000, seed=1000)
+    got = run_pipeline(generics, sim)
+    monkeypatch.setattr(generics, "calls", oracle_calls)
+    want = run_pipeline(generics, sim)
+    for ad in ("adaptor1", "adaptor2"):
+        assert np.array_equal(got[0][ad]["score"].view(np.int64), want[0][ad]["score"].view(np.int64))
+        assert np.array_equal(got[0][ad]["start"], want[0][ad]["start"]) and np.array_equal(got[0][ad]["end"], want[0][ad]["end"])
+        assert got[0][ad]["subseq"] == want[0][ad]["subseq"]
+    assert np.array_equal(got[0]["reversed"], want[0]["reversed"])
+    assert (got[0]["reversed"] == sim["flipped"]).mean() > 0.97
+    assert [g.tolist() for g in got[1]] == [g.tolist() for g in want[1]]
+    assert got[2]["alignments"] == want[2]["alignments"]
+    for k in (3, 4):
+        assert got[k].seq.to_strings() == want[k].seq.to_strings()
+        assert got[k].qual.to_strings() == want[k].qual.to_strings()
+    assert len(got[3]) >= 80      # most of the 100 molecules come back as consensus reads
