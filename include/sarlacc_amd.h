@@ -180,6 +180,18 @@ int sarlacc_umi_group(const char* umi1, const int64_t* off1,
                       const int64_t* grp_off, const int32_t* grp, int64_t ngroups,
                       int64_t* nclusters, int64_t* clu_off, int32_t* clu);
 
+/* One giant pre-group across several GPUs: the row tiles of the all-pairs
+ * matrix shard; every shard returns its neighbour pairs (rank_i << 32 | rank_j, i < j, ranks in the
+ * trie order of the whole set, which every shard computes identically), the pair lists are
+ * exchanged (all-gather) and the clustering of umi_group runs on their concatenation.
+ * Two-call sizing protocol for `pairs` as in sarlacc_fast_levdist_test. */
+int sarlacc_umi_pairs_shard(const char* umi, const int64_t* off, int64_t n, int limit,
+                            int shard_index, int shard_count,
+                            uint64_t* pairs, int64_t cap, int64_t* npairs);
+int sarlacc_umi_group_from_pairs(const char* umi, const int64_t* off, int64_t n, int limit,
+                                 const uint64_t* pairs, int64_t npairs,
+                                 int64_t* nclusters, int64_t* clu_off, int32_t* clu);
+
 /* ------------------------------------------------------------------ */
 /* per-group MSA and consensus                                           */
 

@@ -365,3 +365,34 @@ def create_consensus_flat(rows, grp_rows, min_cov, pseudo_count=1.0, quals=None,
             ptr(rows.chars), ptr(rows.off), ptr(grp_rows), C.c_int64(ng), ptr(q.chars), ptr(q.off), ptr(qg),
             C.c_double(min_cov), ptr(enc.errors), enc.names, len(enc), ptr(cons), ptr(phred), ptr(coff), None))
     return StringSet(cons, coff.copy()), StringSet(phred, coff.copy())
+
+
+def umi_pairs_shard(umi, limit, shard_index, shard_count):
+    """sarlacc_umi_pairs_shard: neighbour pairs (rank_i << 32 | rank_j) found in this shard's row
+    tiles of the all-pairs matrix of one pre-group (ranks = positions in the trie order)."""
+    s = StringSet.from_strings(umi)
+    lim = _integer(limit, "limit")
+    need = C.c_int64(0)
+    cap = max(16 * len(s) // max(shard_count, 1), 1024)
+    while True:
+        pairs = np.zeros(cap, np.uint64)
+        check(_lib.lib().sarlacc_umi_pairs_shard(ptr(s.chars), ptr(s.off), C.c_int64(len(s)), lim, int(shard_index),
+                                                 int(shard_count), ptr(pairs), C.c_int64(cap), C.byref(need)))
+        if need.value <= cap:
+            return pairs[:need.value].copy()
+        cap = need.value
+
+
+def umi_group_from_pairs(umi, limit, pairs):
+    """sarlacc_umi_group_from_pairs: umi_group of a single pre-group given its neighbour pairs."""
+    s = StringSet.from_strings(umi)
+    lim = _integer(limit, "limit")
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint64)
+    n = len(s)
+    ncl = C.c_int64(0)
+    co = np.zeros(n + 2, np.int64)
+    cl = np.zeros(max(n, 1), np.int32)
+    pp = pairs if pairs.size else np.zeros(1, np.uint64)
+    check(_lib.lib().sarlacc_umi_group_from_pairs(ptr(s.chars), ptr(s.off), C.c_int64(n), lim, ptr(pp), C.c_int64(pairs.size),
+                                                  C.byref(ncl), ptr(co), ptr(cl)))
+    return lists_from_csr(co, cl, ncl.value)

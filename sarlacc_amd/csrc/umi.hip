@@ -164,6 +164,7 @@ struct PairArgs {
     unsigned long long* edges;      // (rank_i << 32 | rank_j), rank_i < rank_j
     unsigned long long* count;
     unsigned long long cap;
+    int tile_lo;                    // first row tile of this launch (row tiles shard across GPUs)
 };
 
 // Shifted-Hamming lower bound for N-free pairs: a position of `a` that differs from b at every
@@ -191,7 +192,7 @@ __device__ __forceinline__ bool shd_reject(unsigned long long ca, int la, unsign
 
 template <int K>
 __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
-    const int bi = blockIdx.x, bj = blockIdx.y;
+    const int bi = blockIdx.x + A.tile_lo, bj = blockIdx.y;
     if (bj < bi) return;
     // column tile (c*) and row tile (r*) both live in LDS: survivors of the cheap filters are
     // queued per wave and evaluated 64 at a time, so the exact DP always runs on full waves
@@ -634,9 +635,10 @@ static int encode_and_rank(const std::string& p, const uint8_t* d_chars, const i
 }
 
 template <int K>
-static void launch_pairs(const PairArgs& a, hipStream_t s) {
+static void launch_pairs(const PairArgs& a, int tile_hi, hipStream_t s) {
     const unsigned nt = nblk(a.n, TILE);
-    hipLaunchKernelGGL(k_umi_pairs<K>, dim3(nt, nt), dim3(TILE), 0, s, a);
+    if (tile_hi <= a.tile_lo) return;
+    hipLaunchKernelGGL(k_umi_pairs<K>, dim3(static_cast<unsigned>(tile_hi - a.tile_lo), nt), dim3(TILE), 0, s, a);
 }
 
 struct DirectedKeys {
@@ -645,34 +647,45 @@ struct DirectedKeys {
 };
 
 // All neighbour pairs within `limit`, as sorted directed keys (self links included).
-static int neighbour_keys(const std::string& p, const SortedUmis& S, int limit, const uint8_t* d_single, DirectedKeys* out, hipStream_t s) {
+// Undirected neighbour pairs (rank_i << 32 | rank_j) of the row tiles [tile_lo, tile_hi)
+// (tile_hi < 0: all tiles).  The buffer stays on the device: *d_edges_out, *m_out.
+static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int tile_lo, int tile_hi,
+                      unsigned long long** d_edges_out, unsigned long long* m_out, hipStream_t s) {
     Context& c = ctx();
     const int n = S.n;
-    if (limit < 0) limit = -1;  // nothing can match a negative limit
+    const int nt = static_cast<int>(nblk(n, TILE));
+    if (tile_hi < 0) { tile_lo = 0; tile_hi = nt; }
+    tile_lo = std::max(0, std::min(tile_lo, nt));
+    tile_hi = std::max(tile_lo, std::min(tile_hi, nt));
     const int lim2 = 2 * limit;
     unsigned long long* d_count;
     SL_TRY(scratch((p + ".ecount").c_str(), 1, &d_count));
     unsigned long long cap = std::max<unsigned long long>(1u << 20, 32ull * n);
     unsigned long long m = 0;
     unsigned long long* d_edges = nullptr;
-    if (n > static_cast<long long>(65535) * TILE) return fail("sarlacc_amd: more than %d UMIs in one pre-group", 65535 * TILE);
+    if (n > static_cast<long long>(65535) * TILE) return fail("sarlacc_amd: more than %d UMIs in one call", 65535 * TILE);
+    {   // make sure a buffer exists even when nothing is launched
+        void* pe;
+        SL_TRY(c.buffer((p + ".edges").c_str(), cap * sizeof(unsigned long long), &pe));
+        d_edges = static_cast<unsigned long long*>(pe);
+    }
     for (int attempt = 0; attempt < 2 && limit >= 0; ++attempt) {
         void* pe;
         SL_TRY(c.buffer((p + ".edges").c_str(), cap * sizeof(unsigned long long), &pe));
         d_edges = static_cast<unsigned long long*>(pe);
         SL_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
-        PairArgs a{S.U, S.gid, n, lim2, d_edges, d_count, cap};
+        PairArgs a{S.U, S.gid, n, lim2, d_edges, d_count, cap, tile_lo};
         SL_HIP(hipEventRecord(c.ev_start, s));
         const int K = std::min(limit, UMI_MAXLEN);
-        if (K <= 0) launch_pairs<0>(a, s);
-        else if (K == 1) launch_pairs<1>(a, s);
-        else if (K == 2) launch_pairs<2>(a, s);
-        else if (K == 3) launch_pairs<3>(a, s);
-        else if (K == 4) launch_pairs<4>(a, s);
-        else if (K == 5) launch_pairs<5>(a, s);
-        else if (K <= 8) launch_pairs<8>(a, s);
-        else if (K <= 16) launch_pairs<16>(a, s);
-        else launch_pairs<UMI_MAXLEN>(a, s);
+        if (K <= 0) launch_pairs<0>(a, tile_hi, s);
+        else if (K == 1) launch_pairs<1>(a, tile_hi, s);
+        else if (K == 2) launch_pairs<2>(a, tile_hi, s);
+        else if (K == 3) launch_pairs<3>(a, tile_hi, s);
+        else if (K == 4) launch_pairs<4>(a, tile_hi, s);
+        else if (K == 5) launch_pairs<5>(a, tile_hi, s);
+        else if (K <= 8) launch_pairs<8>(a, tile_hi, s);
+        else if (K <= 16) launch_pairs<16>(a, tile_hi, s);
+        else launch_pairs<UMI_MAXLEN>(a, tile_hi, s);
         SL_HIP(hipGetLastError());
         SL_HIP(hipEventRecord(c.ev_stop, s));
         c.timed = true;
@@ -681,7 +694,16 @@ static int neighbour_keys(const std::string& p, const SortedUmis& S, int limit, 
         if (m <= cap) break;
         cap = m;  // the kernel kept counting: second attempt has the exact size
     }
-    // self links
+    *d_edges_out = d_edges;
+    *m_out = m;
+    return 0;
+}
+
+// Directed, sorted adjacency keys (self links included) from undirected rank pairs.
+static int keys_from_edges(const std::string& p, const SortedUmis& S, int limit, const uint8_t* d_single,
+                           const unsigned long long* d_edges, unsigned long long m, DirectedKeys* out, hipStream_t s) {
+    const int n = S.n;
+    const int lim2 = 2 * limit;
     int* d_flag; long long* d_pos;
     SL_TRY(scratch((p + ".sflag").c_str(), static_cast<size_t>(n) + 1, &d_flag));
     SL_TRY(scratch((p + ".spos").c_str(), static_cast<size_t>(n) + 1, &d_pos));
@@ -702,6 +724,15 @@ static int neighbour_keys(const std::string& p, const SortedUmis& S, int limit, 
     out->keys = d_k1;
     out->nk = nk;
     return 0;
+}
+
+// All neighbour pairs within `limit`, as sorted directed keys (self links included).
+static int neighbour_keys(const std::string& p, const SortedUmis& S, int limit, const uint8_t* d_single, DirectedKeys* out, hipStream_t s) {
+    if (limit < 0) limit = -1;  // nothing can match a negative limit
+    unsigned long long* d_edges;
+    unsigned long long m;
+    SL_TRY(pair_edges(p, S, limit, 0, -1, &d_edges, &m, s));
+    return keys_from_edges(p, S, limit, d_single, d_edges, m, out, s);
 }
 
 struct DevAdj {
@@ -1027,6 +1058,81 @@ int sarlacc_umi_group(const char* umi1, const int64_t* off1, const char* umi2, c
         nc = res.nclu;
     }
     *nclusters = nc;
+    return 0;
+}
+
+// Row tiles of the all-pairs matrix owned by shard `index` of `count`: boundaries balance the
+// triangular work (row tile b meets nt - b column tiles).
+static void shard_tiles(int nt, int index, int count, int* lo, int* hi) {
+    const double total = 0.5 * nt * (nt + 1.0);
+    auto bound = [&](int k) -> int {  // smallest b with work(0..b) >= k/count of the total
+        if (k <= 0) return 0;
+        if (k >= count) return nt;
+        const double want = total * k / count;
+        int b = 0;
+        double acc = 0;
+        while (b < nt && acc < want) { acc += nt - b; ++b; }
+        return b;
+    };
+    *lo = bound(index);
+    *hi = bound(index + 1);
+}
+
+int sarlacc_umi_pairs_shard(const char* umi, const int64_t* off, int64_t n, int limit, int shard_index,
+                            int shard_count, uint64_t* pairs, int64_t cap, int64_t* npairs) {
+    if (n < 0 || shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail("sarlacc_amd: bad shard request");
+    *npairs = 0;
+    if (n == 0 || limit < 0) return 0;
+    SL_TRY(ensure_device());
+    hipStream_t s = nullptr;
+    uint8_t* d_c; int64_t* d_o;
+    SL_TRY(upload_strings("ps", umi, off, n, &d_c, &d_o, s));
+    SortedUmis S;
+    SL_TRY(encode_and_rank("u1", d_c, d_o, nullptr, nullptr, 1, static_cast<int>(n), &S, s));
+    int lo, hi;
+    shard_tiles(static_cast<int>(nblk(n, TILE)), shard_index, shard_count, &lo, &hi);
+    unsigned long long* d_edges;
+    unsigned long long m;
+    SL_TRY(pair_edges("u1", S, limit, lo, hi, &d_edges, &m, s));
+    *npairs = static_cast<int64_t>(m);
+    if (!pairs || cap < static_cast<int64_t>(m)) return 0;  // sizing call
+    if (m) SL_HIP(hipMemcpy(pairs, d_edges, sizeof(uint64_t) * m, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sarlacc_umi_group_from_pairs(const char* umi, const int64_t* off, int64_t n, int limit, const uint64_t* pairs,
+                                 int64_t npairs, int64_t* nclusters, int64_t* clu_off, int32_t* clu) {
+    if (n < 0 || npairs < 0) return fail("sarlacc_amd: negative sizes");
+    *nclusters = 0;
+    clu_off[0] = 0;
+    if (n == 0) return 0;
+    if (n == 1) {  // a pre-group of one read passes through (src/umi_group.cpp:39-42)
+        clu[0] = 1; clu_off[1] = 1; *nclusters = 1;
+        return 0;
+    }
+    for (int64_t e = 0; e < npairs; ++e) {
+        const uint64_t a = pairs[e] >> 32, b = pairs[e] & 0xffffffffull;
+        if (a >= static_cast<uint64_t>(n) || b >= static_cast<uint64_t>(n) || a >= b) return fail("sarlacc_amd: malformed neighbour pair");
+    }
+    SL_TRY(ensure_device());
+    hipStream_t s = nullptr;
+    uint8_t* d_c; int64_t* d_o;
+    SL_TRY(upload_strings("ps", umi, off, n, &d_c, &d_o, s));
+    SortedUmis S;
+    SL_TRY(encode_and_rank("u1", d_c, d_o, nullptr, nullptr, 1, static_cast<int>(n), &S, s));
+    unsigned long long* d_edges;
+    SL_TRY(upload("u1.edges_in", reinterpret_cast<const unsigned long long*>(pairs), static_cast<size_t>(npairs), &d_edges, s));
+    DirectedKeys K;
+    SL_TRY(keys_from_edges("u1", S, limit < 0 ? -1 : limit, nullptr, d_edges, static_cast<unsigned long long>(npairs), &K, s));
+    DevAdj adj;
+    SL_TRY(adjacency_from_keys("adj", K.keys, K.nk, S.perm, static_cast<int>(n), &adj, s));
+    ClusterResult res;
+    SL_TRY(cluster_dev(adj, static_cast<int>(n), nullptr, nullptr, 1, false, &res, s));
+    std::vector<long long> co(static_cast<size_t>(res.nclu) + 1);
+    SL_HIP(hipMemcpy(co.data(), res.d_coff, sizeof(long long) * co.size(), hipMemcpyDeviceToHost));
+    if (res.total) SL_HIP(hipMemcpy(clu, res.d_out, sizeof(int32_t) * static_cast<size_t>(res.total), hipMemcpyDeviceToHost));
+    for (long long c = 0; c <= res.nclu; ++c) clu_off[c] = co[c];
+    *nclusters = res.nclu;
     return 0;
 }
 }

@@ -118,3 +118,28 @@ def sharded_over_reads(fn, n, dist=None):
         return 0, n, fn(0, n)
     lo, hi = shard_range(n, dist.get_rank(), dist.get_world_size())
     return lo, hi, fn(lo, hi)
+
+
+def sharded_umi_group_tiles(umi, threshold, calls, dist=None, device=None):
+    """umi_group of ONE giant pre-group with the row tiles of the all-pairs matrix spread over the
+    ranks.  Every rank holds all UMIs (they are 12 bytes each), searches its
+    share of the tiles, all-gathers the neighbour pairs (counts first, then the padded lists) and
+    runs the clustering on the concatenation -- replicated, deterministic, identical to the
+    single-GPU result."""
+    if dist is None or dist.get_world_size() == 1:
+        return calls.umi_group_from_pairs(umi, threshold, calls.umi_pairs_shard(umi, threshold, 0, 1))
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = calls.umi_pairs_shard(umi, threshold, rank, world).astype(np.int64)  # values < 2^63: safe as int64
+    counts = _all_gather(np.array([mine.size], dtype=np.int32), dist, device)
+    counts = [int(c[0]) for c in counts]
+    width = max(max(counts), 1)
+    padded = np.zeros(width, dtype=np.int64)
+    padded[:mine.size] = mine
+    t = torch.from_numpy(padded)
+    if device is not None:
+        t = t.to(device)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    allpairs = np.concatenate([p.cpu().numpy()[:c] for p, c in zip(parts, counts)]).astype(np.uint64)
+    return calls.umi_group_from_pairs(umi, threshold, allpairs)

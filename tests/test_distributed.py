@@ -101,3 +101,46 @@ def test_partition_helpers():
     loads = [sum(s * s for s, o in zip([100, 1, 1, 1, 90, 50, 50], own) if o == r) for r in range(2)]
     assert max(loads) <= 1.35 * min(loads)
     assert shard.assign_groups([], 4).size == 0
+
+
+def _worker_tiles(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from sarlacc_amd import shard
+    from tests import oracle_calls
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        from tests.test_oracle_umi import umisim
+        rng = np.random.default_rng(3)
+        umis = []
+        for _ in range(70):
+            umis += umisim(rng, 9, 10)
+        out = shard.sharded_umi_group_tiles(umis, 1, oracle_calls, dist)
+        q.put((rank, [c.tolist() for c in out]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_tile_sharding_of_one_giant_group():
+    """Row tiles of the all-pairs matrix split over two ranks, neighbour pairs all-gathered:
+    both ranks must reproduce the unsharded umi_group of the single pre-group."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_tiles, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from tests import oracle_calls
+    from tests.test_oracle_umi import umisim
+    rng = np.random.default_rng(3)
+    umis = []
+    for _ in range(70):
+        umis += umisim(rng, 9, 10)
+    want = [c.tolist() for c in oracle_calls.umi_group(umis, 1, None, 1, [list(range(1, len(umis) + 1))])]
+    assert results[0][1] == want and results[1][1] == want

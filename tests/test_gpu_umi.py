@@ -194,3 +194,26 @@ def test_mask_bad_bases(oracle, oenc, enc):
         calls.mask_bad_bases(["ACGT"], ["III"], enc, 0.1)
     with pytest.raises(SarlaccError, match="quality cannot be lower"):
         calls.mask_bad_bases(["ACGT"], ["II I"], enc, 0.1)
+
+
+def test_tile_sharded_pairs_reproduce_umi_group(oracle):
+    """The row-tile shards of the all-pairs search (what each GPU of a node would compute) put
+    together give exactly umi_group's result; shard boundaries balance the triangular work."""
+    from sarlacc_amd import calls
+    rng = np.random.default_rng(21)
+    umis = []
+    for _ in range(300):
+        umis += umisim(rng, 8, 12, rate=0.06)
+    umis = [umis[i] for i in rng.permutation(len(umis))]
+    g = [list(range(1, len(umis) + 1))]
+    for limit in (1, 2):
+        want = calls.umi_group(umis, limit, None, limit, g)
+        same_lists(want, oracle.umi_group(umis, limit, None, limit, g, fast=True))
+        for world in (1, 3, 8):
+            parts = [calls.umi_pairs_shard(umis, limit, r, world) for r in range(world)]
+            allp = np.concatenate(parts)
+            assert len(np.unique(allp)) == allp.size            # no pair is found twice
+            same_lists(calls.umi_group_from_pairs(umis, limit, allp), want)
+            if world == 8:
+                sizes = [p.size for p in parts]
+                assert max(sizes) > 0
