@@ -65,8 +65,12 @@ __global__ void __launch_bounds__(64) k_consensus(const ConsArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* s_right = reinterpret_cast<double*>(smem);
     double* s_wrong = s_right + (QUALITY ? A.navail : 0);
-    int* s_pos = reinterpret_cast<int*>(s_wrong + (QUALITY ? A.navail : 0));
+    long long* s_roff = reinterpret_cast<long long*>(s_wrong + (QUALITY ? A.navail : 0));
+    long long* s_qoff = s_roff + A.max_rows;
+    int* s_pos = reinterpret_cast<int*>(s_qoff + A.max_rows);
     int* s_bad = s_pos + A.max_rows;
+    int* s_qlen = s_bad + A.max_rows;
+    constexpr int RB = 8;
 
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -84,7 +88,17 @@ __global__ void __launch_bounds__(64) k_consensus(const ConsArgs A) {
         const long long W = A.aln_off[row0 + 1] - A.aln_off[row0];
         const double thresh = static_cast<double>(nrows) * A.mincov;
         const long long obase = A.out_off[g];
-        for (int r = lane; r < nrows; r += 64) { s_pos[r] = 0; s_bad[r] = 0; }
+        // per-row offsets once per group: no dependent scalar loads inside the column loop
+        for (int r = lane; r < nrows; r += 64) {
+            s_pos[r] = 0;
+            s_bad[r] = 0;
+            s_roff[r] = A.aln_off[row0 + r];
+            if (QUALITY) {
+                s_qoff[r] = A.qual_off[row0 + r];
+                s_qlen[r] = static_cast<int>(A.qual_off[row0 + r + 1] - A.qual_off[row0 + r]);
+            }
+        }
+        __syncthreads();
         int outpos = 0;
 
         for (long long c0 = 0; c0 < W; c0 += 64) {
@@ -92,37 +106,60 @@ __global__ void __launch_bounds__(64) k_consensus(const ConsArgs A) {
             const bool active = col < W;
             double sA = 0, sC = 0, sG = 0, sT = 0;
             int inc = 0;
-            for (int r = 0; r < nrows; ++r) {
-                const long long roff = A.aln_off[row0 + r];
-                const uint8_t ch = active ? A.aln[roff + col] : static_cast<uint8_t>('-');
-                const bool nongap = ch != '-';
-                const unsigned long long mask = __ballot(nongap);
-                int p = 0;
-                if (QUALITY) {
-                    p = s_pos[r] + __popcll(mask & lt);
-                    if (lane == 0) s_pos[r] += __popcll(mask);
+            // rows in batches of RB: all alignment bytes of a batch are requested before any is
+            // used, then all quality bytes -- two memory round trips per batch instead of per row.
+            // Accumulation stays in row order, so the fp64 sums are the reference's.
+            for (int r0 = 0; r0 < nrows; r0 += RB) {
+                uint8_t ch[RB];
+#pragma unroll
+                for (int b = 0; b < RB; ++b) {
+                    const int r = r0 + b;
+                    ch[b] = (active && r < nrows) ? A.aln[s_roff[r < nrows ? r : 0] + col] : static_cast<uint8_t>('-');
                 }
-                if (nongap) {
+                int pq[RB];
+                uint8_t qv8[RB];
+#pragma unroll
+                for (int b = 0; b < RB; ++b) {
+                    const int r = r0 + b;
+                    const bool nongap = ch[b] != '-';
+                    const unsigned long long mask = __ballot(nongap);
+                    pq[b] = -1;
+                    if (QUALITY && r < nrows) {
+                        const int p = s_pos[r] + __popcll(mask & lt);
+                        if (lane == 0) s_pos[r] += __popcll(mask);
+                        if (nongap && ch[b] != 'N' && p < s_qlen[r]) pq[b] = p;
+                    }
+                }
+                if (QUALITY) {
+#pragma unroll
+                    for (int b = 0; b < RB; ++b) {
+                        const int r = r0 + b;
+                        qv8[b] = (pq[b] >= 0) ? A.qual[s_qoff[r < nrows ? r : 0] + pq[b]] : static_cast<uint8_t>(0);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < RB; ++b) {
+                    const int r = r0 + b;
+                    const uint8_t c = ch[b];
+                    if (c == '-') continue;
                     ++inc;
                     if (QUALITY) {
-                        const long long qo = A.qual_off[row0 + r];
-                        const int qlen = static_cast<int>(A.qual_off[row0 + r + 1] - qo);
-                        if (ch != 'N' && p < qlen) {
-                            int qi = static_cast<int>(static_cast<signed char>(A.qual[qo + p])) - A.qoffset;
+                        if (pq[b] >= 0) {
+                            int qi = static_cast<int>(static_cast<signed char>(qv8[b])) - A.qoffset;
                             if (qi < 0) { s_bad[r] = 1; qi = 0; }
                             if (qi >= A.navail) qi = A.navail - 1;
                             const double right = s_right[qi], wrong = s_wrong[qi];
-                            sA += (ch == 'A') ? right : wrong;
-                            sC += (ch == 'C') ? right : wrong;
-                            sG += (ch == 'G') ? right : wrong;
-                            sT += (ch == 'T') ? right : wrong;
+                            sA += (c == 'A') ? right : wrong;
+                            sC += (c == 'C') ? right : wrong;
+                            sG += (c == 'G') ? right : wrong;
+                            sT += (c == 'T') ? right : wrong;
                         }
-                    } else if (ch != 'N') {
-                        if (ch == 'A') sA += 1;
-                        else if (ch == 'C') sC += 1;
-                        else if (ch == 'G') sG += 1;
-                        else if (ch == 'T') sT += 1;
-                        else atomicMin(A.first_bad_char, static_cast<unsigned long long>(roff + col));
+                    } else if (c != 'N') {
+                        if (c == 'A') sA += 1;
+                        else if (c == 'C') sC += 1;
+                        else if (c == 'G') sG += 1;
+                        else if (c == 'T') sT += 1;
+                        else atomicMin(A.first_bad_char, static_cast<unsigned long long>(s_roff[r] + col));
                     }
                 }
             }
@@ -186,7 +223,7 @@ __global__ void __launch_bounds__(64) k_consensus(const ConsArgs A) {
         if (lane == 0) A.cons_len[g] = outpos;
         if (QUALITY) {
             for (int r = lane; r < nrows; r += 64) {
-                const int qlen = static_cast<int>(A.qual_off[row0 + r + 1] - A.qual_off[row0 + r]);
+                const int qlen = s_qlen[r];
                 const int used = s_pos[r];
                 A.row_status[row0 + r] = s_bad[r] ? 1 : (used == qlen ? 0 : (used > qlen ? 2 : 3));
             }
@@ -301,7 +338,7 @@ static int run_consensus(bool quality, const char* aln, const int64_t* aln_off, 
     a.first_bad_char = d_badchar; a.fix_count = d_fixn; a.fix_cap = fix_cap; a.fix_pos = d_fixpos; a.fix_val = d_fixval;
 
     if (ng_eval > 0) {
-        const size_t lds = (quality ? 2 * sizeof(double) * enc_n : 0) + 2 * sizeof(int) * static_cast<size_t>(max_rows) + 16;
+        const size_t lds = (quality ? 2 * sizeof(double) * enc_n : 0) + (2 * sizeof(long long) + 3 * sizeof(int)) * static_cast<size_t>(max_rows) + 16;
         if (lds > 160 * 1024) return fail("sarlacc_amd: alignment with %d rows does not fit the consensus kernel", max_rows);
         const int grid = static_cast<int>(std::min<int64_t>(ng_eval, static_cast<int64_t>(c.num_cu) * 32));
         SL_HIP(hipEventRecord(c.ev_start, s));
