@@ -1,0 +1,201 @@
+"""Randomised differential fuzzing of every C-ABI entry point against the CPU oracle.
+Usage: python tools/fuzz.py [seconds] [seed].  Prints the first mismatch (with a reproducer seed)
+or a summary of the cases run."""
+import os, sys, time, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import sarlacc_amd
+from sarlacc_amd import calls
+from oracle import oracle as O
+
+IUPAC = "ACGTMRWSYKVHDBN"
+enc, oenc = sarlacc_amd.phred_encoding(), O.phred_encoding()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+def rstr(rng, n, alphabet):
+    return "".join(rng.choice(list(alphabet), n)) if n else ""
+
+
+def rqual(rng, n, lo=33, hi=126):
+    return "".join(chr(int(x)) for x in rng.integers(lo, hi + 1, n)) if n else ""
+
+
+def both(f_gpu, f_orc):
+    """Run both; equal exceptions (by message) count as agreement."""
+    try:
+        g = f_gpu()
+        ge = None
+    except sarlacc_amd.SarlaccError as e:
+        g, ge = None, str(e)
+    try:
+        o = f_orc()
+        oe = None
+    except O.OracleError as e:
+        o, oe = None, str(e)
+    if (ge is None) != (oe is None) or (ge is not None and oe not in ge and ge not in oe):
+        raise AssertionError("error behaviour differs: gpu=%r oracle=%r" % (ge, oe))
+    return g, o, ge is not None
+
+
+def case_align(rng):
+    R = int(rng.choice([0, 1, 2, 5, 12, 16, 17, 22, 30, 31, 33, 48, 64, 65, 90, 130, 257, 700]))
+    n = int(rng.integers(1, 40))
+    Lmax = int(rng.choice([0, 3, 30, 150, 700]))
+    alpha_r = IUPAC if rng.random() < 0.5 else "ACGT"
+    adaptor = rstr(rng, R, alpha_r)
+    read_alpha = "ACGT" if rng.random() < 0.7 else "ACGTN"
+    reads = [rstr(rng, int(rng.integers(0, Lmax + 1)), read_alpha) for _ in range(n)]
+    if R and rng.random() < 0.7:   # plant a noisy copy
+        k = int(rng.integers(0, n))
+        core = "".join(c if c in "ACGT" else "ACGT"[int(rng.integers(0, 4))] for c in adaptor)
+        pos = int(rng.integers(0, len(reads[k]) + 1))
+        reads[k] = reads[k][:pos] + core + reads[k][pos:]
+    qlo = 33 if rng.random() < 0.5 else 40
+    quals = [rqual(rng, len(r), qlo, int(rng.choice([75, 126]))) for r in reads]
+    go, ge = [(5, 1), (20, 1), (1, 1), (2.5, 0.75), (0, 1), (3, 0), (7.25, 2.5)][int(rng.integers(0, 7))]
+    nsec = int(rng.integers(0, 4)) if R else 0
+    ss = sorted(int(x) for x in rng.integers(0, max(R, 1), nsec))
+    se = [int(rng.integers(s, R) + 1) for s in ss]
+    g, o, err = both(lambda: calls.adaptor_align(reads, quals, enc, go, ge, adaptor, ss, se),
+                     lambda: O.adaptor_align(reads, quals, oenc, go, ge, adaptor, ss, se))
+    if not err:
+        assert np.array_equal(bits(g[0]), bits(o[0])), "adaptor scores"
+        assert np.array_equal(g[1], o[1]) and np.array_equal(g[2], o[2]), "adaptor positions"
+        for a, b in zip(g[3] + g[4], o[3] + o[4]):
+            assert np.array_equal(a, b), "sections"
+    g, o, err = both(lambda: calls.barcode_align(reads, quals, enc, go, ge, adaptor),
+                     lambda: O.barcode_align(reads, quals, oenc, go, ge, adaptor))
+    if not err:
+        assert np.array_equal(bits(g), bits(o)), "barcode scores"
+    if R <= 130 and Lmax <= 150:
+        g, o, err = both(lambda: calls.general_align(reads, quals, enc, go, ge, adaptor, False),
+                         lambda: O.general_align(reads, quals, oenc, go, ge, adaptor))
+        if not err:
+            assert np.array_equal(bits(g[0]), bits(o[0])) and np.array_equal(g[1], o[1]), "general scores/edits"
+            assert g[2] == o[2] and g[3] == o[3], "general strings"
+
+
+def case_umi(rng):
+    n = int(rng.integers(2, 400))
+    length = int(rng.choice([0, 3, 8, 12, 20, 32]))
+    base = [rstr(rng, min(31, max(0, length + int(rng.integers(-2, 3)))), "ACGT") for _ in range(max(1, n // 8))]  # <= 32 after one insertion (documented limit)
+    alpha = "ACGT" if rng.random() < 0.7 else "ACGTN"
+    umis = []
+    for _ in range(n):
+        b = list(base[int(rng.integers(0, len(base)))])
+        for k in range(len(b)):
+            if rng.random() < 0.08:
+                b[k] = alpha[int(rng.integers(0, len(alpha)))]
+        if b and rng.random() < 0.1:
+            del b[int(rng.integers(0, len(b)))]
+        if len(b) < 32 and rng.random() < 0.1:
+            b.insert(int(rng.integers(0, len(b) + 1)), "ACGT"[int(rng.integers(0, 4))])
+        umis.append("".join(b))
+    limit = int(rng.integers(0, 5))
+    ngr = int(rng.choice([1, 1, 3, 20]))
+    lab = rng.integers(0, ngr, n)
+    groups = [(np.flatnonzero(lab == k) + 1).astype(np.int32) for k in range(ngr)]
+    use2 = rng.random() < 0.3
+    umi2 = [rstr(rng, 5, "ACGT") if rng.random() < 0.5 else "ACGTA" for _ in range(n)] if use2 else None
+    l2 = int(rng.integers(0, 3))
+    g, o, err = both(lambda: calls.umi_group(umis, limit, umi2, l2, groups), lambda: O.umi_group(umis, limit, umi2, l2, groups, fast=True))
+    if not err:
+        assert len(g) == len(o) and all(np.array_equal(a, b) for a, b in zip(g, o)), "umi_group"
+    g, o, err = both(lambda: calls.fast_levdist_test(umis, limit), lambda: O.fast_levdist_test(umis, limit))
+    if not err:
+        assert all(np.array_equal(a, b) for a, b in zip(g, o)), "fast_levdist"
+    if n <= 120:
+        g, o, err = both(lambda: calls.compute_lev_masked(umis), lambda: O.compute_lev_masked(umis))
+        if not err:
+            assert g.tolist() == o.tolist(), "lev dense"
+
+
+def case_consensus(rng):
+    ngroups = int(rng.integers(1, 12))
+    alns, quals = [], []
+    for _ in range(ngroups):
+        nrows = int(rng.integers(0, 30))
+        W = int(rng.integers(0, 400))
+        truth = rng.choice(list("ACGT"), W) if W else np.array([], dtype="<U1")
+        rows, qs = [], []
+        for _ in range(nrows):
+            r = truth.copy()
+            if W:
+                sub = rng.random(W) < 0.1
+                r[sub] = rng.choice(list("ACGT"), int(sub.sum()))
+                r[rng.random(W) < 0.03] = "N"
+                r[rng.random(W) < rng.choice([0.05, 0.4])] = "-"
+            row = "".join(r)
+            rows.append(row)
+            qs.append(rqual(rng, len(row.replace("-", ""))))
+        alns.append(rows)
+        quals.append(qs)
+    cov = float(rng.choice([0.0, 0.2, 0.5, 0.6, 0.9, 1.0]))
+    pc = float(rng.choice([0.5, 1.0, 2.0, 4.0]))
+    g, o, err = both(lambda: calls.create_consensus_quality_loop(alns, cov, quals, enc),
+                     lambda: O.create_consensus_quality_loop(alns, cov, quals, oenc))
+    if not err:
+        assert g[0] == list(o[0]) and g[1] == list(o[1]), "consensus quality"
+    g, o, err = both(lambda: calls.create_consensus_basic_loop(alns, cov, pc), lambda: O.create_consensus_basic_loop(alns, cov, pc))
+    if not err:
+        assert g[0] == list(o[0]) and g[1] == list(o[1]), "consensus basic"
+
+
+def case_msa(rng):
+    from sarlacc_amd.mock import NUC, mutate
+    reads, groups = [], []
+    for _ in range(int(rng.integers(1, 6))):
+        L = int(rng.choice([0, 5, 60, 300, 900]))
+        truth = NUC[rng.integers(0, 4, L)]
+        idx = []
+        for _ in range(int(rng.integers(0, 9))):
+            r = mutate(truth, rng, 0.08, 0.03).tobytes().decode() if L else ""
+            if rng.random() < 0.1:
+                r = r[: len(r) // 2]
+            reads.append(r)
+            idx.append(len(reads))
+        groups.append(idx)
+    if not reads:
+        reads = ["ACGT"]
+    params = [(0, -1, -5, -1), (0, -1, -1, -5), (1, -2, -2, -2), (2, -3, -1, -4), (0, -1, -1, -1)][int(rng.integers(0, 5))]
+    bw = int(rng.choice([0, 3, 20, 100, 180]))
+    g, o, err = both(lambda: calls.quick_msa(groups, reads, *params, bw), lambda: O.quick_msa(groups, reads, *params, bw))
+    if not err:
+        assert g == o, "msa rows"
+
+
+def case_mask(rng):
+    n = int(rng.integers(0, 50))
+    seqs = [rstr(rng, int(rng.integers(0, 80)), "ACGTN") for _ in range(n)]
+    quals = [rqual(rng, len(s)) for s in seqs]
+    thr = float(rng.choice([0.0, 0.001, 0.01, 0.1, 0.5, 1.0]))
+    g, o, err = both(lambda: calls.mask_bad_bases(seqs, quals, enc, thr), lambda: O.mask_bad_bases(seqs, quals, oenc, thr))
+    if not err:
+        assert g == o, "mask"
+
+
+CASES = [case_align, case_align, case_umi, case_consensus, case_msa, case_mask]
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    t0 = time.time()
+    counts = {}
+    k = 0
+    while time.time() - t0 < budget:
+        seed = seed0 * 1_000_003 + k
+        rng = np.random.default_rng(seed)
+        fn = CASES[k % len(CASES)]
+        try:
+            fn(rng)
+        except Exception:
+            print("MISMATCH in %s with seed %d" % (fn.__name__, seed))
+            traceback.print_exc()
+            sys.exit(1)
+        counts[fn.__name__] = counts.get(fn.__name__, 0) + 1
+        k += 1
+    print("fuzz ok: %d cases in %.0f s: %s" % (k, time.time() - t0, counts))
