@@ -331,10 +331,19 @@ def quick_msa_flat(grp_off, grp, seqs, match, mismatch, gapExtension, gapOpening
     args = (ptr(goff), ptr(gvals), C.c_int64(ng), ptr(s.chars), ptr(s.off), C.c_int64(len(s)),
             C.c_double(match), C.c_double(mismatch), C.c_double(gapExtension), C.c_double(gapOpening), int(bandwidth),
             ptr(width), ptr(ooff))
-    check(_lib.lib().sarlacc_quick_msa(*args, None, C.c_int64(0)))      # sizing call
-    cap = int(ooff[ng])
-    out = np.zeros(max(cap, 1), np.uint8)
-    check(_lib.lib().sarlacc_quick_msa(*args, ptr(out), C.c_int64(cap)))
+    # one pass in the common case: rows are rarely more than 1.5x the reads they hold; the
+    # library reports the exact size (out_off) when the guess was too small
+    cap = int(1.5 * s.widths()[gvals[:int(goff[-1])].astype(np.int64) - 1].sum()) + 1024 if goff[-1] else 1
+    for attempt in range(2):
+        out = np.zeros(max(cap, 1), np.uint8)
+        try:
+            check(_lib.lib().sarlacc_quick_msa(*args, ptr(out), C.c_int64(cap)))
+            break
+        except SarlaccError as e:
+            if attempt == 0 and "buffer too small" in str(e):
+                cap = int(ooff[ng])
+                continue
+            raise
     sizes = np.diff(goff)
     grp_rows = np.zeros(ng + 1, np.int64)
     np.cumsum(sizes, out=grp_rows[1:])

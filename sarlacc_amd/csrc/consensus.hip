@@ -231,6 +231,20 @@ __global__ void __launch_bounds__(64) k_consensus(const ConsArgs A) {
     }
 }
 
+// kept columns of every alignment -> contiguous output (one block per alignment)
+__global__ void k_consensus_compact(const uint8_t* cons, const uint8_t* phred, const double* lerr, const int64_t* out_off,
+                                    const int32_t* len, const long long* dst_off, long long ngroups, uint8_t* dcons,
+                                    uint8_t* dphred, double* dlerr) {
+    const long long g = blockIdx.x;
+    if (g >= ngroups) return;
+    const long long src = out_off[g], dst = dst_off[g];
+    for (int p = threadIdx.x; p < len[g]; p += blockDim.x) {
+        dcons[dst + p] = cons[src + p];
+        dphred[dst + p] = phred[src + p];
+        if (lerr) dlerr[dst + p] = lerr[src + p];
+    }
+}
+
 // ---------------------------------------------------------------------------
 static double host_log1pexp(double x) {
     if (x <= 18.) return std::log1p(std::exp(x));
@@ -376,14 +390,26 @@ static int run_consensus(bool quality, const char* aln, const int64_t* aln_off, 
     if (struct_err_kind == 2) return fail("alignments and qualities have different numbers of entries");
     if (fixn > fix_cap) return fail("sarlacc_amd: too many Phred values on a rounding boundary (%d)", fixn);
 
-    std::vector<uint8_t> hc(static_cast<size_t>(total)), hp(static_cast<size_t>(total));
+    // compact the kept columns on the device, then copy only those back
+    std::vector<long long> dst(static_cast<size_t>(ngroups) + 1, 0);
+    for (int64_t g = 0; g < ngroups; ++g) dst[g + 1] = dst[g] + len[g];
+    const long long kept = dst[ngroups];
+    std::vector<uint8_t> hc(static_cast<size_t>(kept) + 1), hp(static_cast<size_t>(kept) + 1);
     std::vector<double> hl;
-    if (total) {
-        SL_HIP(hipMemcpy(hc.data(), d_cons, static_cast<size_t>(total), hipMemcpyDeviceToHost));
-        SL_HIP(hipMemcpy(hp.data(), d_phred, static_cast<size_t>(total), hipMemcpyDeviceToHost));
+    if (kept) {
+        long long* d_dst; uint8_t* d_cc; uint8_t* d_cp; double* d_cl = nullptr;
+        SL_TRY(upload("cons.dst", dst.data(), dst.size(), &d_dst, s));
+        SL_TRY(scratch("cons.cc", static_cast<size_t>(kept), &d_cc));
+        SL_TRY(scratch("cons.cp", static_cast<size_t>(kept), &d_cp));
+        if (lerr) SL_TRY(scratch("cons.cl", static_cast<size_t>(kept), &d_cl));
+        hipLaunchKernelGGL(k_consensus_compact, dim3(static_cast<unsigned>(ng_eval)), dim3(256), 0, s, d_cons, d_phred, d_lerr,
+                           d_ooff, d_len, d_dst, static_cast<long long>(ng_eval), d_cc, d_cp, d_cl);
+        SL_HIP(hipGetLastError());
+        SL_HIP(hipMemcpy(hc.data(), d_cc, static_cast<size_t>(kept), hipMemcpyDeviceToHost));
+        SL_HIP(hipMemcpy(hp.data(), d_cp, static_cast<size_t>(kept), hipMemcpyDeviceToHost));
         if (lerr) {
-            hl.resize(static_cast<size_t>(total));
-            SL_HIP(hipMemcpy(hl.data(), d_lerr, sizeof(double) * static_cast<size_t>(total), hipMemcpyDeviceToHost));
+            hl.resize(static_cast<size_t>(kept));
+            SL_HIP(hipMemcpy(hl.data(), d_cl, sizeof(double) * static_cast<size_t>(kept), hipMemcpyDeviceToHost));
         }
     }
     if (fixn > 0) {  // exact host-libm re-evaluation of boundary columns
@@ -403,19 +429,18 @@ static int run_consensus(bool quality, const char* aln, const int64_t* aln_off, 
             } else {
                 le = std::log1p(-((fv[4 * k] + pseudo / 4) / (fv[4 * k + 1] + pseudo)));
             }
-            hp[static_cast<size_t>(fp[k])] = static_cast<uint8_t>(phred_char(le));
-            if (lerr) hl[static_cast<size_t>(fp[k])] = le;
+            // fix_pos is an index into the uncompacted layout: find its alignment, then its slot
+            const long long pos = fp[k];
+            const int64_t g = static_cast<int64_t>(std::upper_bound(out_off.begin(), out_off.begin() + ng_eval, pos) - out_off.begin()) - 1;
+            const size_t at = static_cast<size_t>(dst[g] + (pos - out_off[g]));
+            hp[at] = static_cast<uint8_t>(phred_char(le));
+            if (lerr) hl[at] = le;
         }
     }
-    int64_t used = 0;
-    for (int64_t g = 0; g < ngroups; ++g) {
-        const int64_t ob = out_off[g];
-        std::memcpy(cons + used, hc.data() + ob, static_cast<size_t>(len[g]));
-        std::memcpy(phred + used, hp.data() + ob, static_cast<size_t>(len[g]));
-        if (lerr) std::memcpy(lerr + used, hl.data() + ob, sizeof(double) * static_cast<size_t>(len[g]));
-        used += len[g];
-        cons_off[g + 1] = used;
-    }
+    std::memcpy(cons, hc.data(), static_cast<size_t>(kept));
+    std::memcpy(phred, hp.data(), static_cast<size_t>(kept));
+    if (lerr && kept) std::memcpy(lerr, hl.data(), sizeof(double) * static_cast<size_t>(kept));
+    for (int64_t g = 0; g < ngroups; ++g) cons_off[g + 1] = dst[g + 1];
     return 0;
 }
 
