@@ -9,15 +9,18 @@
 //   * one wavefront = up to NGMAX alignments side by side; inside one alignment a
 //     lane owns K consecutive reference (adaptor) columns, lanes are skewed by one
 //     read row (anti-diagonal wavefront);
-//   * per-column state (vertical jump score/point, previous score of the column)
-//     lives in VGPRs; per-row state (score of the column to the left, horizontal
-//     jump score/point, "left cell was a horizontal gap" flag) travels to the next
-//     lane with DPP wave_shr:1 moves -- no LDS on the recurrence path;
+//   * per-column state (vertical jump score, previous score of the column) lives in
+//     VGPRs; per-row state (score of the column to the left, horizontal jump score,
+//     "left cell was a horizontal gap" flag) travels to the next lane with DPP moves
+//     (row_shr:1 for 16-lane groups, whose leaders get their column-0 inputs from the
+//     DPP fill operand; wave_shr:1 otherwise) -- no LDS on the recurrence path;
 //   * read bases + qualities are staged 64 rows at a time into an LDS ring, the
 //     5 x navail fp64 cost tables sit in LDS;
-//   * traceback directions (jump lengths, as the reference stores them) are
-//     streamed to a per-wave scratch tile in HBM in anti-diagonal order (one
-//     coalesced store per step) and walked by the group's leader lane afterwards.
+//   * traceback needs 4 bits per cell (move + "jump continued" flags; the jump lengths
+//     the reference stores are rebuilt during the walk), streamed with nontemporal
+//     stores to a per-wave tile in HBM in anti-diagonal order and walked by the group's
+//     leader lane afterwards; the walk up the last column is replaced by its landing
+//     row, tracked online.
 //
 // All arithmetic is fp64 add/sub/compare in the reference's order, compiled with
 // -ffp-contract=off, so scores are bit-identical to the CPU path.
@@ -66,18 +69,6 @@ struct AlignArgs {
     int32_t* edits;
 };
 
-__device__ __forceinline__ int dpp_shr1(int v) {
-    // lane l receives lane l-1; lane 0 keeps its own value
-    return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-}
-__device__ __forceinline__ double dpp_shr1(double v) {
-    long long b = __double_as_longlong(v);
-    int lo = dpp_shr1(static_cast<int>(b));
-    int hi = dpp_shr1(static_cast<int>(b >> 32));
-    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
-}
-
-// Directions of UNR consecutive steps x K columns of one lane, stored with one instruction.
 // Traceback code of one cell, 4 bits:
 //   bits 0-1  move taken: 0 diagonal, 1 horizontal gap, 2 vertical gap
 //   bit  2    the horizontal jump was continued here (left_jump_point kept)

@@ -52,7 +52,6 @@ struct MsaArgs {
     uint8_t* aln;           // per pair: 1 if the centre base is matched to a read base
     void* tb;               // per-wave traceback tile
     unsigned long long tb_per_wave;  // in tile words
-    int ctr_cap;            // bytes reserved for the staged centre
 };
 
 __device__ __forceinline__ uint8_t dna5_code(uint8_t c) {
@@ -477,7 +476,6 @@ extern "C" int sarlacc_quick_msa(const int64_t* grp_off, const int32_t* grp, int
         // SeqAn's Score(match, mismatch, gap_extend, gap_open): gap of length k = open + (k-1)*extend
         a.go = static_cast<int>(gap_opening); a.ge = static_cast<int>(gap_extension);
         a.bw = bandwidth; a.ins = d_ins; a.aln = d_aln; a.tb = d_tb; a.tb_per_wave = per_wave;
-        a.ctr_cap = max_lc + 16;
         const size_t lds = TB_ROWS * 64 * word + static_cast<size_t>(max_lc) + 64;
         SL_HIP(hipEventRecord(c.ev_start, s));
         if (C == 4) SL_TRY(launch_pairwise<4>(a, static_cast<int>(grid), lds, s));
