@@ -31,11 +31,13 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
 
 namespace sarlacc {
 
 constexpr int NGMAX = 4;   // alignments processed side by side in one wavefront
+constexpr int NWAVES = 4;  // wavefronts per workgroup: they share one copy of the cost table in LDS
 constexpr int RING = 128;  // staged read positions per alignment (2 x 64)
 constexpr int MAX_REF = 1024;
 
@@ -48,9 +50,11 @@ struct AlignArgs {
     int R, W, ngroups, local;
     int qoffset, navail;
     double GO, GE;
-    const double* tables;     // [5][navail]: exact-match, exact-mismatch, 2-fold, 3-fold, N
+    const double* tables;     // cost table rows of navail doubles, laid out by build_cost_rows
+    int tab_doubles;          // size of `tables`
+    int row_bytes;            // navail * sizeof(double)
     const double* rowzero;    // [R+1] scores of DP row 0
-    const uint32_t* colinfo;  // [R+1] refcode | match-table << 8 | mismatch-table << 16
+    const uint32_t* colbase;  // [R+1] byte offset (inside `tables`) of the rows a column reads
     const uint8_t* refchars;  // [R]
     double* scores;
     int32_t* starts;
@@ -61,7 +65,7 @@ struct AlignArgs {
     int32_t* sec_so;
     int32_t* sec_wo;
     void* dirs;
-    unsigned long long dirs_per_wave;  // elements
+    unsigned long long dirs_per_wave;  // elements per wavefront
     int* badqual;                      // min index of a read holding a quality below the offset
     uint8_t* aln_ref;                  // MODE 2: reversed gapped strings, stride L+R per read
     uint8_t* aln_qry;
@@ -69,30 +73,55 @@ struct AlignArgs {
     int32_t* edits;
 };
 
-// Traceback code of one cell, 4 bits:
-//   bits 0-1  move taken: 0 diagonal, 1 horizontal gap, 2 vertical gap
-//   bit  2    the horizontal jump was continued here (left_jump_point kept)
-//   bit  3    the vertical jump was continued here (up_jump_point kept)
+// Traceback code of one cell, 4 bits -- the raw outcomes of the cell's four comparisons:
+//   bit 0  H > V            (horizontal beats vertical)
+//   bit 1  M > max(H, V)    (diagonal move; otherwise bit 0 picks horizontal / vertical)
+//   bit 2  the horizontal jump was continued here (left_jump_point kept)
+//   bit 3  the vertical jump was continued here (up_jump_point kept)
 // The reference stores jump LENGTHS (src/reference_align.cpp:139,154,170-177); they are
 // recovered during the walk: a horizontal step at column c is 1 + (number of consecutive
 // columns c, c-1, ... whose bit 2 is set), a vertical step at row i is 1 + (number of
 // consecutive rows i, i-1, ... whose bit 3 is set) -- exactly 1 + pos - left_jump_point and
 // 1 + i - up_jump_point.  A lane packs the codes of STEPS consecutive steps x K columns
-// into one word: 0.5 B per cell instead of the 2-4 B of a stored length.
+// into one word, first cell in the top nibble: 0.5 B per cell instead of the 2-4 B of a
+// stored length.
+// Lane masks (one bit per lane) live in SGPR pairs.  The selects and the traceback-bit packing
+// below take them as scalar operands, so all flag logic (and / andn2 / nor) runs on the scalar
+// unit and the vector unit sees exactly one instruction per select and one per packed bit.
+using mask_t = unsigned long long;
+typedef const double __attribute__((address_space(3))) lds_cdouble;
+typedef const uint16_t __attribute__((address_space(3))) lds_cu16;
+
+__device__ __forceinline__ int sel32(int if0, int if1, mask_t m) {
+    int r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(m));
+    return r;
+}
+// pk = 2 * pk + bit: shifts the word left and drops the lane's mask bit in at the bottom
+__device__ __forceinline__ uint32_t push_bit(uint32_t pk, mask_t m) {
+    uint32_t r;
+    mask_t carry_out;
+    asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(pk), "s"(m));
+    return r;
+}
+__device__ __forceinline__ int hi32(double v) { return static_cast<int>(__double_as_longlong(v) >> 32); }
+__device__ __forceinline__ int lo32(double v) { return static_cast<int>(__double_as_longlong(v)); }
+__device__ __forceinline__ double mk64(int hi, int lo) {
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
 // Shift by one lane towards higher lanes.  ROW16: inside each 16-lane DPP row (row_shr:1); the
-// first lane of every row -- the leader of an alignment when groups are 16 lanes wide -- gets
-// `fill` (its DP column 0 value) for free.  Otherwise across the whole wave (wave_shr:1).
+// first lane of every row -- the leader of an alignment when groups are 16 lanes wide -- has no
+// source lane and keeps `keep` (its DP column 0 value: pass the destination itself and the
+// constant set before the loop stays there for free).  Otherwise across the whole wave.
 template <bool ROW16>
-__device__ __forceinline__ int lane_shr1(int v, int fill) {
-    if (ROW16) return __builtin_amdgcn_update_dpp(fill, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+__device__ __forceinline__ int lane_shr1(int v, int keep) {
+    if (ROW16) return __builtin_amdgcn_update_dpp(keep, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
     return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 template <bool ROW16>
-__device__ __forceinline__ double lane_shr1(double v, double fill) {
-    const long long b = __double_as_longlong(v), f = __double_as_longlong(fill);
-    const int lo = lane_shr1<ROW16>(static_cast<int>(b), static_cast<int>(f));
-    const int hi = lane_shr1<ROW16>(static_cast<int>(b >> 32), static_cast<int>(f >> 32));
-    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+__device__ __forceinline__ double lane_shr1(double v, double keep) {
+    return mk64(lane_shr1<ROW16>(hi32(v), hi32(keep)), lane_shr1<ROW16>(lo32(v), lo32(keep)));
 }
 
 template <int K>
@@ -102,21 +131,43 @@ struct TbStore { using type = uint32_t; };
 template <>
 struct TbStore<16> { using type = unsigned long long; };
 
+template <bool B>
+struct Flag { static constexpr bool value = B; };
+
 // MODE 0: scores only.  MODE 1: scores + reference->read map (adaptor_align).
 // MODE 2: scores + gapped strings + edit distance (general_align).
 // LOCAL: free leading read bases + free vertical gaps in the last column (adaptor mode).
 // ROW16: alignments are 16 lanes wide and start on DPP row boundaries.
 // KLAST: index (inside its lane) of reference column R when known at compile time, else -1.
-template <int K, int MODE, bool LOCAL, bool ROW16, int KLAST>
-__global__ void __launch_bounds__(64, 5) k_align(const AlignArgs A) {
+// PENSEL: select the gap penalty of every step explicitly (only needed when gapopen < 0).
+//
+// Penalty selection.  The reference charges a gap step "extension" instead of "open +
+// extension" when the cell it leaves was itself reached by a gap of the same kind
+// (src/reference_align.cpp:125-158).  In that case the cell's score IS the running jump
+// score (best == H == lj, bit for bit), so the reference's candidate `left - GE` equals the
+// jump continuation `lj - GE` exactly, the comparison `continuation > candidate` is false and
+// the maximum is the continuation.  With gapopen >= 0 the candidate `left - GO` is <= that
+// continuation, so max(continuation, left - GO) is the same double: the kernel always
+// subtracts the opening penalty and selects nothing.  Only the "jump continued" flag differs
+// (true instead of false), and the true flag is raw && !(previous cell's move is the same gap
+// kind) -- the traceback applies that from the neighbour's code, which it reads anyway.
+template <int K, int MODE, bool LOCAL, bool ROW16, int KLAST, bool PENSEL>
+__global__ void __launch_bounds__(64 * NWAVES, 5) k_align(const AlignArgs A) {
     constexpr int UNR = TbSteps<K>::value;
+    constexpr int CELLS = UNR * K;
     using Word = typename TbStore<K>::type;
-    extern __shared__ __align__(16) unsigned char smem[];
-    double* s_tab = reinterpret_cast<double*>(smem);
-    uint16_t* s_ring = reinterpret_cast<uint16_t*>(s_tab + 5 * A.navail);
-    int32_t* s_map = reinterpret_cast<int32_t*>(s_ring + NGMAX * RING);
+    constexpr bool ADDC = sizeof(Word) == 4;
+    // LDS: read rings first (256 B per alignment, so a ring address is base | offset), then the
+    // cost table shared by the waves of the workgroup, then the per-wave reference->read maps
+    extern __shared__ __align__(256) unsigned char smem[];
+    static_assert(RING * sizeof(uint16_t) == 256, "ring addressing assumes 256 B per alignment");
+    constexpr int RING_BYTES = NWAVES * NGMAX * RING * static_cast<int>(sizeof(uint16_t));
+    double* const s_tab = reinterpret_cast<double*>(smem + RING_BYTES);
+    // LDS byte address of smem (256-aligned), for hand-built LDS addresses
+    const int lds0 = static_cast<int>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)smem));
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // tell the compiler it is wave-uniform
     const int W = A.W, R = A.R;
     const int g = lane / W;
     const int j = lane - g * W;
@@ -125,35 +176,36 @@ __global__ void __launch_bounds__(64, 5) k_align(const AlignArgs A) {
     const int c0 = j * K + 1;
     const double NEG_INF = -__builtin_huge_val();
     const double GO = A.GO, GE = A.GE;
-    constexpr bool local = LOCAL;
+    const int GOhi = hi32(GO), GOlo = lo32(GO), GEhi = hi32(GE), GElo = lo32(GE);
 
-    for (int x = lane; x < 5 * A.navail; x += 64) s_tab[x] = A.tables[x];
+    for (int x = threadIdx.x; x < A.tab_doubles; x += 64 * NWAVES) s_tab[x] = A.tables[x];
+    uint16_t* const s_ring = reinterpret_cast<uint16_t*>(smem) + wave * NGMAX * RING;
+    int32_t* const s_map = reinterpret_cast<int32_t*>(s_tab + A.tab_doubles) + wave * A.ngroups * (R + 1);
 
     double vgo[K], vge[K], rz[K];
-    int refcode[K], tm[K], tmm[K];
+    int colbase[K];  // LDS byte address of the table rows this column reads (see build_tables)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int c = c0 + k;
         // columns past R (last lane when K does not divide R) reuse column R's tables: they
         // compute garbage that nothing reads (their outputs only feed a leader or an idle lane)
         const int cc = c <= R ? c : R;
-        const uint32_t info = A.colinfo[cc];
-        refcode[k] = info & 0xff;
-        tm[k] = static_cast<int>(((info >> 8) & 0xff) * A.navail * sizeof(double));    // byte offsets into s_tab
-        tmm[k] = static_cast<int>(((info >> 16) & 0xff) * A.navail * sizeof(double));
-        const bool last = local && cc == R;
+        colbase[k] = lds0 + RING_BYTES + static_cast<int>(A.colbase[cc]);
+        const bool last = LOCAL && cc == R;
         vgo[k] = last ? 0.0 : GO;
         vge[k] = last ? 0.0 : GE;
         rz[k] = A.rowzero[cc];
     }
     const double rz_left = A.rowzero[c0 - 1 <= R ? c0 - 1 : R];
     const int jlast = (R - 1) / K, klast = KLAST >= 0 ? KLAST : (R - 1) % K;
-    Word* const scr = static_cast<Word*>(A.dirs) + static_cast<size_t>(blockIdx.x) * A.dirs_per_wave;
-    const unsigned char* const tab_bytes = reinterpret_cast<const unsigned char*>(s_tab);
+    const long long gwave = static_cast<long long>(blockIdx.x) * NWAVES + wave;
+    const long long nwaves = static_cast<long long>(gridDim.x) * NWAVES;
+    Word* const scr = static_cast<Word*>(A.dirs) + static_cast<size_t>(gwave) * A.dirs_per_wave;
+    const int ring_g = lds0 + (wave * NGMAX + g) * static_cast<int>(RING * sizeof(uint16_t));  // byte address of this alignment's ring
     __syncthreads();
 
     const long long nitems = (A.n + A.ngroups - 1) / A.ngroups;
-    for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
+    for (long long item = gwave; item < nitems; item += nwaves) {
         const long long read = item * A.ngroups + g;
         const bool valid = lane_on && read < A.n;
         long long start = 0;
@@ -165,7 +217,7 @@ __global__ void __launch_bounds__(64, 5) k_align(const AlignArgs A) {
         // wave-uniform description of the (up to NGMAX) reads of this work item, kept in SGPRs
         long long gstart[NGMAX];
         int glen[NGMAX];
-        int Lmax = 0;
+        int Lmax = 0, Lmin = 0x7fffffff;
 #pragma unroll
         for (int gg = 0; gg < NGMAX; ++gg) {
             const int src = gg < A.ngroups ? gg * W : 0;
@@ -175,23 +227,27 @@ __global__ void __launch_bounds__(64, 5) k_align(const AlignArgs A) {
             gstart[gg] = (static_cast<long long>(hi) << 32) | lo;
             glen[gg] = gg < A.ngroups ? len : 0;
             Lmax = max(Lmax, glen[gg]);
+            // reads past the end of the batch (last work item) compute garbage nobody stores
+            if (gg < A.ngroups && item * A.ngroups + gg < A.n) Lmin = min(Lmin, glen[gg]);
         }
 
-        // read staging: fetch 64 positions per alignment one refill ahead of use
+        // read staging: fetch 64 positions per alignment one refill ahead of use;
+        // a staged entry is quality | base code << 8 (0-3 = ACGT, 4 = anything else)
         auto fetch = [&](int gg, int r0) -> uint32_t {
             const int r = r0 + lane;
             uint32_t v = 0;
             if (r < glen[gg]) {
                 const long long idx = gstart[gg] + r;
-                uint32_t b;
+                uint32_t code;
                 if (A.nmask) {  // 2-bit packed bases + exception mask (sarlacc_dev_pack_reads)
                     const uint32_t two = (A.seq[idx >> 2] >> ((idx & 3) * 2)) & 3u;
                     const uint32_t exc = (A.nmask[idx >> 3] >> (idx & 7)) & 1u;
-                    b = exc ? 'N' : static_cast<uint32_t>("ACGT"[two]);
+                    code = exc ? 4u : two;
                 } else {
-                    b = A.seq[idx];
+                    const uint32_t b = A.seq[idx];
+                    code = b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u;
                 }
-                v = A.qual[idx] | (b << 8);
+                v = A.qual[idx] | (code << 8);
             }
             return v;
         };
@@ -200,113 +256,170 @@ __global__ void __launch_bounds__(64, 5) k_align(const AlignArgs A) {
             int qi = static_cast<int>(static_cast<signed char>(v & 0xff)) - A.qoffset;
             if (r < glen[gg] && qi < 0) atomicMin(A.badqual, static_cast<int>(item * A.ngroups + gg));
             qi = qi < 0 ? 0 : (qi >= A.navail ? A.navail - 1 : qi);
-            const uint32_t b = v >> 8;
-            const uint32_t code = b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u;
-            // quality index pre-scaled to a byte offset into an fp64 table
-            s_ring[gg * RING + (r & (RING - 1))] = static_cast<uint16_t>((qi << 3) | (code << 12));
+            // byte offset of (base code, quality) inside a block of table rows
+            s_ring[gg * RING + (r & (RING - 1))] = static_cast<uint16_t>((v >> 8) * A.row_bytes + (qi << 3));
         };
         uint32_t pf[NGMAX];
 #pragma unroll
         for (int gg = 0; gg < NGMAX; ++gg) pf[gg] = fetch(gg, 0);
 
+        // per-column state: score of the previous row, vertical jump score (and, PENSEL only,
+        // the penalty the next vertical step pays)
         double S[K], UJ[K];
-        bool vneg[K];
+        int vp_hi[K], vp_lo[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) { S[k] = rz[k]; UJ[k] = NEG_INF; vneg[k] = false; }
+        for (int k = 0; k < K; ++k) { S[k] = rz[k]; UJ[k] = NEG_INF; vp_hi[k] = hi32(vgo[k]); vp_lo[k] = lo32(vgo[k]); }
+        // per-row state arriving from the lane to the left: score, horizontal jump score (PENSEL:
+        // and the penalty a horizontal step from that cell pays).  Leaders keep column-0 constants.
         double s_in = 0.0, lj_in = NEG_INF, diag_prev = rz_left;
-        int hp_in = 0;  // the cell to the left is a horizontal gap
+        int ph_in = GOhi, pl_in = GOlo;
+        // Row position as x2 = 2 * (i - 1), i = t - j: doubles as the ring byte offset.
+        int x2 = -2 * j - 2;
+        const int x2max = valid ? 2 * L - 2 : -2;
         // Landing row of the upward walk the traceback performs in column R (tracked by the lane
-        // owning that column): land[i] = i if the move at (i,R) is not vertical, else the landing
-        // row of the cell the vertical jump leads to.  Without it the walk up the last column
-        // (free vertical gaps => ~L single steps in local mode) costs ~L dependent loads per read.
-        int land_prev = 0, land_up = 0;
+        // owning that column, in x2 units): land[i] = i if the move at (i,R) is not vertical, else
+        // the landing row of the cell the vertical jump leads to.  Without it the walk up the last
+        // column (free vertical gaps => ~L single steps in local mode) costs ~L dependent loads.
+        int land_prev = -2, land_up = -2;
+        int vnl = 0;  // the move at (i-1, R) was a vertical gap
 
-        const int nsteps = ((Lmax + W + UNR - 1) / UNR) * UNR;
-        for (int t0 = 0; t0 < nsteps; t0 += UNR) {
-            if ((t0 & 63) == 0) {
+        // Steps [t_begin, t_end).  GUARD = false is the steady state: every lane of every
+        // alignment of the wave is inside its read, nothing is predicated and all flags are
+        // lane masks in SGPRs.
+        auto run = [&](auto guard_tag, int t_begin, int t_end) {
+            constexpr bool GUARD = decltype(guard_tag)::value;
+            mask_t m_vnl = GUARD ? 0 : __builtin_amdgcn_ballot_w64(vnl != 0);
+            for (int t0 = t_begin; t0 < t_end; t0 += UNR) {
+                if ((t0 & 63) == 0) {
 #pragma unroll
-                for (int gg = 0; gg < NGMAX; ++gg) {
-                    stage(gg, t0, pf[gg]);
-                    pf[gg] = fetch(gg, t0 + 64);
+                    for (int gg = 0; gg < NGMAX; ++gg) {
+                        stage(gg, t0, pf[gg]);
+                        pf[gg] = fetch(gg, t0 + 64);
+                    }
                 }
-            }
-            Word pk = 0;
+                Word pk = 0;
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int t = t0 + u;
-                const int i = t - j;
-                // column 0 of the DP (src/reference_align.cpp:63-78): what a leader lane consumes
-                double col0;
-                if (LOCAL) col0 = 0.0;
-                else col0 = (i < 1) ? 0.0 : (-GO - GE * static_cast<double>(i - 1));
-                if (!ROW16 && leader) { s_in = col0; lj_in = NEG_INF; hp_in = 0; }
-                double left = s_in, lj = lj_in;
-                bool hp = hp_in != 0;
-
-                if (valid && i >= 1 && i <= L) {
-                    const uint32_t rd = s_ring[g * RING + ((i - 1) & (RING - 1))];
-                    const int qoff = rd & 0xfff;   // byte offset of the quality inside a table
-                    const int code = rd >> 12;
-                    double diag = diag_prev;
-                    diag_prev = s_in;
-                    bool nonvert_last = true, vj_last = false;
+                for (int u = 0; u < UNR; ++u) {
+                    if (!ROW16) {
+                        // column 0 of the DP (src/reference_align.cpp:63-78): what a leader lane consumes
+                        const int im1 = x2 >> 1;
+                        const double col0 = (LOCAL || im1 < 0) ? 0.0 : (-GO - GE * static_cast<double>(im1));
+                        if (leader) { s_in = col0; lj_in = NEG_INF; ph_in = GOhi; pl_in = GOlo; }
+                    }
+                    double left = s_in, lj = lj_in;
+                    int ph = ph_in, pl = pl_in;
+                    const double s_two_back = diag_prev;  // what s_in held two steps ago
+                    bool act = true;
+                    if (GUARD) act = x2 >= 0 && x2 <= x2max;
+                    if (act) {
+                        const int rd = *reinterpret_cast<lds_cu16*>(static_cast<uint32_t>(ring_g | (x2 & 0xff)));
+                        double diag = diag_prev;
+                        diag_prev = s_in;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        // Every "if (a > b) {x = a} else {a = b}" pair of the reference leaves
-                        // max(a, b) in both; no NaN or -0 can occur on this path, so fmax is the
-                        // same value bit for bit (src/reference_align.cpp:125-158).
-                        const double hcand = left - (hp ? GE : GO);
-                        const double ljm = lj - GE;
-                        const bool hj = ljm > hcand;
-                        const double H = fmax(ljm, hcand);
-                        lj = H;
-                        const double vcand = S[k] - (vneg[k] ? vge[k] : vgo[k]);
-                        const double ujm = UJ[k] - vge[k];
-                        const bool vj = ujm > vcand;
-                        const double V = fmax(ujm, vcand);
-                        UJ[k] = V;
-                        const double w = *reinterpret_cast<const double*>(
-                            tab_bytes + (code == refcode[k] ? tm[k] : tmm[k]) + qoff);
-                        const double M = diag + w;
-                        diag = S[k];
-                        // (:164-174): M only if greater than both, else H only if greater than V
-                        const bool hv = H > V;
-                        const double G = fmax(H, V);
-                        const bool takem = M > G;
-                        const double best = fmax(M, G);
-                        S[k] = best;
-                        left = best;
-                        hp = !takem && hv;
-                        vneg[k] = !takem && !hv;
-                        if (MODE >= 1) {
-                            // small constants stay inline operands; one shift-or places the code
-                            const unsigned nib = (takem ? 0u : (hv ? 1u : 2u)) | (hj ? 4u : 0u) | (vj ? 8u : 0u);
-                            pk |= static_cast<Word>(nib) << (4 * (u * K + k));
-                            if (KLAST >= 0) {
-                                if (k == KLAST) { nonvert_last = takem || hv; vj_last = vj; }
+                        for (int k = 0; k < K; ++k) {
+                            // Every "if (a > b) {x = a} else {a = b}" pair of the reference leaves
+                            // max(a, b) in both; no NaN or -0 can occur on this path, so fmax is the
+                            // same value bit for bit (src/reference_align.cpp:125-158).
+                            const double hcand = left - (PENSEL ? mk64(ph, pl) : GO);
+                            const double ljm = lj - GE;
+                            const bool b_hj = ljm > hcand;
+                            const double H = fmax(ljm, hcand);
+                            lj = H;
+                            const double vcand = S[k] - (PENSEL ? mk64(vp_hi[k], vp_lo[k]) : vgo[k]);
+                            const double ujm = UJ[k] - vge[k];
+                            const bool b_vj = ujm > vcand;
+                            const double V = fmax(ujm, vcand);
+                            UJ[k] = V;
+                            const double w = *reinterpret_cast<lds_cdouble*>(static_cast<uint32_t>(colbase[k] + rd));
+                            const double M = diag + w;
+                            diag = S[k];
+                            // (:164-174): M only if greater than both, else H only if greater than V
+                            const bool b_hv = H > V;
+                            const double G = fmax(H, V);
+                            const bool b_tm = M > G;
+                            const double best = fmax(M, G);
+                            S[k] = best;
+                            left = best;
+                            const bool is_last = KLAST >= 0 ? (k == KLAST) : (k == klast);
+                            if (!GUARD) {
+                                const mask_t m_hj = __builtin_amdgcn_ballot_w64(b_hj), m_vj = __builtin_amdgcn_ballot_w64(b_vj);
+                                const mask_t m_hv = __builtin_amdgcn_ballot_w64(b_hv), m_tm = __builtin_amdgcn_ballot_w64(b_tm);
+                                const mask_t m_vn = ~(m_hv | m_tm);  // the move here is a vertical gap
+                                if (PENSEL) {
+                                    const mask_t m_hp = m_hv & ~m_tm;  // the move here is a horizontal gap
+                                    ph = sel32(GOhi, GEhi, m_hp);
+                                    pl = sel32(GOlo, GElo, m_hp);
+                                    vp_hi[k] = sel32(hi32(vgo[k]), hi32(vge[k]), m_vn);
+                                    vp_lo[k] = sel32(lo32(vgo[k]), lo32(vge[k]), m_vn);
+                                }
+                                if (MODE >= 1) {
+                                    if (ADDC) {
+                                        pk = push_bit(push_bit(push_bit(push_bit(static_cast<uint32_t>(pk), m_vj), m_hj), m_tm), m_hv);
+                                    } else {
+                                        const unsigned raw = (b_hv ? 1u : 0u) | (b_tm ? 2u : 0u) | (b_hj ? 4u : 0u) | (b_vj ? 8u : 0u);
+                                        pk |= static_cast<Word>(raw) << (4 * (CELLS - 1 - (u * K + k)));
+                                    }
+                                    if (is_last) {
+                                        const mask_t m_cont = m_vj & ~m_vnl;  // the vertical jump really continued
+                                        land_up = sel32(land_prev, land_up, m_cont);  // continued: same landing row
+                                        land_prev = sel32(land_up, x2, ~m_vn);
+                                        m_vnl = m_vn;
+                                    }
+                                }
                             } else {
-                                nonvert_last = (k == klast) ? (takem || hv) : nonvert_last;
-                                vj_last = (k == klast) ? vj : vj_last;
+                                const bool hp = b_hv && !b_tm, vn = !b_hv && !b_tm;
+                                if (PENSEL) {
+                                    ph = hp ? GEhi : GOhi;
+                                    pl = hp ? GElo : GOlo;
+                                    vp_hi[k] = vn ? hi32(vge[k]) : hi32(vgo[k]);
+                                    vp_lo[k] = vn ? lo32(vge[k]) : lo32(vgo[k]);
+                                }
+                                if (MODE >= 1) {
+                                    const unsigned raw = (b_hv ? 1u : 0u) | (b_tm ? 2u : 0u) | (b_hj ? 4u : 0u) | (b_vj ? 8u : 0u);
+                                    pk |= static_cast<Word>(raw) << (4 * (CELLS - 1 - (u * K + k)));
+                                    if (is_last) {
+                                        const bool cont = b_vj && vnl == 0;
+                                        land_up = cont ? land_up : land_prev;
+                                        land_prev = vn ? land_up : x2;
+                                        vnl = vn ? 1 : 0;
+                                    }
+                                }
                             }
                         }
                     }
-                    if (MODE >= 1) {
-                        const int land_i = nonvert_last ? i : (vj_last ? land_up : land_prev);
-                        land_up = vj_last ? land_up : land_prev;
-                        land_prev = land_i;
+                    // hand the row state to the next lane; with 16-lane groups the leaders have no
+                    // source lane and keep their column-0 values
+                    if (ROW16 && !LOCAL) {
+                        const int i = (x2 >> 1) + 1;  // global mode: column 0 changes with the row
+                        const double col0_next = (i < 0) ? 0.0 : (-GO - GE * static_cast<double>(i));
+                        s_in = lane_shr1<ROW16>(left, col0_next);
+                    } else if (ROW16 && !GUARD) {
+                        // s_in itself stays live as the next step's diagonal; the register that
+                        // held it two steps ago is free and, on leader lanes, holds the same 0.0
+                        s_in = lane_shr1<ROW16>(left, s_two_back);
+                    } else {
+                        s_in = lane_shr1<ROW16>(left, s_in);
                     }
+                    lj_in = lane_shr1<ROW16>(lj, lj_in);
+                    if (PENSEL) {
+                        ph_in = lane_shr1<ROW16>(ph, ph_in);
+                        pl_in = lane_shr1<ROW16>(pl, pl_in);
+                    }
+                    x2 += 2;
                 }
-                // hand the row state to the next lane; with 16-lane groups the leaders receive the
-                // column-0 values of the NEXT step's row straight from the DPP fill operand
-                double col0_next;
-                if (LOCAL) col0_next = 0.0;
-                else col0_next = (i + 1 < 1) ? 0.0 : (-GO - GE * static_cast<double>(i));
-                s_in = lane_shr1<ROW16>(left, col0_next);
-                lj_in = lane_shr1<ROW16>(lj, NEG_INF);
-                hp_in = lane_shr1<ROW16>(hp ? 1 : 0, 0);
+                if (MODE >= 1) __builtin_nontemporal_store(pk, scr + static_cast<size_t>(t0 / UNR) * 64 + lane);
             }
-            if (MODE >= 1) __builtin_nontemporal_store(pk, scr + static_cast<size_t>(t0 / UNR) * 64 + lane);
-        }
+            if (!GUARD) vnl = sel32(0, 1, m_vnl);
+        };
+
+        const int nsteps = ((Lmax + W + UNR - 1) / UNR) * UNR;
+        int t_a = ((W + UNR - 1) / UNR) * UNR;                 // every lane has entered its read
+        int t_b = Lmin == 0x7fffffff ? 0 : ((Lmin + 1) / UNR) * UNR;  // first block leaving the shortest read
+        t_a = min(t_a, nsteps);
+        t_b = min(max(t_b, t_a), nsteps);
+        run(Flag<true>{}, 0, t_a);
+        run(Flag<false>{}, t_a, t_b);
+        run(Flag<true>{}, t_b, nsteps);
 
         if (valid && j == jlast) {
             double sc = S[0];
@@ -319,28 +432,39 @@ __global__ void __launch_bounds__(64, 5) k_align(const AlignArgs A) {
             // make this wave's traceback stores visible to its leader lanes
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const int land = __shfl(land_prev, g * W + jlast);  // where the walk up column R ends
+            const int land = (__shfl(land_prev, g * W + jlast) >> 1) + 1;  // where the walk up column R ends
             if (valid && leader) {
+                // raw compare bits of cell (row, c): 1 H>V, 2 M>max(H,V), 4 horizontal jump
+                // continuation beat the step from the left, 8 same for the vertical jump
                 auto nibble = [&](int c, int row) -> unsigned {  // 1 <= c <= R, 1 <= row <= L
                     const int jj = (c - 1) / K, kk = (c - 1) % K;
                     const int tt = row + jj;
                     const Word w = scr[static_cast<size_t>(tt / UNR) * 64 + (g * W + jj)];
-                    return static_cast<unsigned>(w >> (4 * ((tt % UNR) * K + kk))) & 15u;
+                    return static_cast<unsigned>(w >> (4 * (CELLS - 1 - ((tt % UNR) * K + kk)))) & 15u;
                 };
-                // direction value the reference would have stored at (row, c)
+                // direction value the reference would have stored at (row, c); a jump continues
+                // through a cell only if the cell it came from was not itself entered by the
+                // same kind of gap (see "Penalty selection" above)
                 auto loadD = [&](int c, int row) -> int {
                     if (row <= 0) return 1;  // D[c][0] = 1 (src/reference_align.cpp:118)
                     unsigned nb = nibble(c, row);
-                    const unsigned move = nb & 3u;
-                    if (move == 0) return 0;
+                    if (nb & 2u) return 0;
                     int n = 0;
-                    if (move == 1) {
+                    if (nb & 1u) {
                         int x = c;
-                        while ((nb & 4u) && x > 1) { ++n; --x; nb = nibble(x, row); }
+                        while ((nb & 4u) && x > 1) {
+                            const unsigned prev = nibble(x - 1, row);
+                            if ((prev & 3u) == 1u) break;
+                            ++n; --x; nb = prev;
+                        }
                         return 1 + n;
                     }
                     int y = row;
-                    while ((nb & 8u) && y > 1) { ++n; --y; nb = nibble(c, y); }
+                    while ((nb & 8u) && y > 1) {
+                        const unsigned prev = nibble(c, y - 1);
+                        if ((prev & 3u) == 0u) break;
+                        ++n; --y; nb = prev;
+                    }
                     return -(1 + n);
                 };
                 int row = L, c = R;
@@ -463,6 +587,34 @@ static void build_tables(const double* errors, int n, std::vector<double>& tab) 
     }
 }
 
+// Device layout of the cost table: rows of n doubles, addressed as
+//     colbase[column] + (read base code * n + quality) * 8          (one add per cell)
+// with read base codes 0-3 = ACGT, 4 = anything else.
+//   * columns holding A/C/G/T share eight rows "mis mis mis MATCH mis mis mis mis"; the column
+//     of reference base r starts 3 - r rows in, so code == r lands on the match row and every
+//     other code (including 4) on a mismatch row;
+//   * each ambiguity class present in the reference (2-fold, 3-fold, N) gets five identical
+//     rows: its score does not depend on the read base (src/reference_align.cpp:184-212).
+static void build_cost_rows(const std::vector<double>& tab, int n, const uint32_t* colinfo, int R,
+                            std::vector<double>& rows, std::vector<uint32_t>& colbase) {
+    rows.clear();
+    auto append = [&](int t) { rows.insert(rows.end(), tab.begin() + static_cast<size_t>(t) * n, tab.begin() + static_cast<size_t>(t + 1) * n); };
+    for (int r = 0; r < 8; ++r) append(r == 3 ? 0 : 1);
+    uint32_t class_base[5] = {0, 0, 0, 0, 0};
+    colbase.assign(static_cast<size_t>(R) + 1, 0);
+    const uint32_t row_bytes = static_cast<uint32_t>(n * sizeof(double));
+    for (int col = 1; col <= R; ++col) {
+        const uint32_t code = colinfo[col] & 0xff, tmatch = (colinfo[col] >> 8) & 0xff;
+        if (code < 4) { colbase[col] = (3 - code) * row_bytes; continue; }
+        if (!class_base[tmatch]) {
+            class_base[tmatch] = static_cast<uint32_t>(rows.size() * sizeof(double));
+            for (int r = 0; r < 5; ++r) append(static_cast<int>(tmatch));
+        }
+        colbase[col] = class_base[tmatch];
+    }
+    colbase[0] = colbase[R ? 1 : 0];
+}
+
 struct Shape { int K, W, ngroups; };
 
 // Columns per lane / lanes per alignment / alignments per wave for a reference
@@ -484,30 +636,37 @@ static Shape pick_shape(int R) {
     return best;
 }
 
-template <int K, bool ROW16, int KLAST>
+template <int K, bool ROW16, int KLAST, bool PENSEL>
 static int launch_mode(int mode, bool local, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
     // adaptor_align is always local, general_align always global; score-only comes in both
-    if (mode == 0 && local) hipLaunchKernelGGL((k_align<K, 0, true, ROW16, KLAST>), dim3(grid), dim3(64), lds, s, a);
-    else if (mode == 0) hipLaunchKernelGGL((k_align<K, 0, false, ROW16, KLAST>), dim3(grid), dim3(64), lds, s, a);
-    else if (mode == 1 && local) hipLaunchKernelGGL((k_align<K, 1, true, ROW16, KLAST>), dim3(grid), dim3(64), lds, s, a);
-    else if (mode == 2 && !local) hipLaunchKernelGGL((k_align<K, 2, false, ROW16, KLAST>), dim3(grid), dim3(64), lds, s, a);
+    if (mode == 0 && local) hipLaunchKernelGGL((k_align<K, 0, true, ROW16, KLAST, PENSEL>), dim3(grid), dim3(64 * NWAVES), lds, s, a);
+    else if (mode == 0) hipLaunchKernelGGL((k_align<K, 0, false, ROW16, KLAST, PENSEL>), dim3(grid), dim3(64 * NWAVES), lds, s, a);
+    else if (mode == 1 && local) hipLaunchKernelGGL((k_align<K, 1, true, ROW16, KLAST, PENSEL>), dim3(grid), dim3(64 * NWAVES), lds, s, a);
+    else if (mode == 2 && !local) hipLaunchKernelGGL((k_align<K, 2, false, ROW16, KLAST, PENSEL>), dim3(grid), dim3(64 * NWAVES), lds, s, a);
     else return fail("sarlacc_amd: unsupported alignment mode");
     SL_HIP(hipGetLastError());
     return 0;
 }
 
-static int launch_k(int K, int W, int R, int mode, bool local, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
+template <int K, bool ROW16, int KLAST>
+static int launch_pen(bool pensel, int mode, bool local, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
+    return pensel ? launch_mode<K, ROW16, KLAST, true>(mode, local, a, grid, lds, s)
+                  : launch_mode<K, ROW16, KLAST, false>(mode, local, a, grid, lds, s);
+}
+
+static int launch_k(int K, int W, int R, bool pensel, int mode, bool local, const AlignArgs& a, int grid, size_t lds,
+                    hipStream_t s) {
     const bool row16 = (W == 16);
     const int klast = (R - 1) % K;
-    if (K == 1) return row16 ? launch_mode<1, true, 0>(mode, local, a, grid, lds, s) : launch_mode<1, false, 0>(mode, local, a, grid, lds, s);
+    if (K == 1) return row16 ? launch_pen<1, true, 0>(pensel, mode, local, a, grid, lds, s) : launch_pen<1, false, 0>(pensel, mode, local, a, grid, lds, s);
     if (K == 2) {
-        if (row16) return klast == 0 ? launch_mode<2, true, 0>(mode, local, a, grid, lds, s) : launch_mode<2, true, 1>(mode, local, a, grid, lds, s);
-        return klast == 0 ? launch_mode<2, false, 0>(mode, local, a, grid, lds, s) : launch_mode<2, false, 1>(mode, local, a, grid, lds, s);
+        if (row16) return klast == 0 ? launch_pen<2, true, 0>(pensel, mode, local, a, grid, lds, s) : launch_pen<2, true, 1>(pensel, mode, local, a, grid, lds, s);
+        return klast == 0 ? launch_pen<2, false, 0>(pensel, mode, local, a, grid, lds, s) : launch_pen<2, false, 1>(pensel, mode, local, a, grid, lds, s);
     }
     switch (K) {
-        case 4: return row16 ? launch_mode<4, true, -1>(mode, local, a, grid, lds, s) : launch_mode<4, false, -1>(mode, local, a, grid, lds, s);
-        case 8: return row16 ? launch_mode<8, true, -1>(mode, local, a, grid, lds, s) : launch_mode<8, false, -1>(mode, local, a, grid, lds, s);
-        case 16: return row16 ? launch_mode<16, true, -1>(mode, local, a, grid, lds, s) : launch_mode<16, false, -1>(mode, local, a, grid, lds, s);
+        case 4: return row16 ? launch_pen<4, true, -1>(pensel, mode, local, a, grid, lds, s) : launch_pen<4, false, -1>(pensel, mode, local, a, grid, lds, s);
+        case 8: return row16 ? launch_pen<8, true, -1>(pensel, mode, local, a, grid, lds, s) : launch_pen<8, false, -1>(pensel, mode, local, a, grid, lds, s);
+        case 16: return row16 ? launch_pen<16, true, -1>(pensel, mode, local, a, grid, lds, s) : launch_pen<16, false, -1>(pensel, mode, local, a, grid, lds, s);
     }
     return fail("sarlacc_amd: unsupported columns-per-lane %d", K);
 }
@@ -560,11 +719,16 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     for (int col = 1; col <= R; ++col)
         if (column_info(ref[col - 1], &colinfo[col])) colinfo[col] = 7u | (4u << 8) | (4u << 16);  // caller reports the error
 
+    std::vector<double> rows;
+    std::vector<uint32_t> colbase;
+    build_cost_rows(tab, enc_n, colinfo.data(), R, rows, colbase);
+    if (4u * enc_n * sizeof(double) + enc_n * sizeof(double) > 0xffffu) return fail("sarlacc_amd: encoding vector too long for the staged read format");
+
     AlignArgs a{};
-    double* d_tab; double* d_rz; uint32_t* d_ci; uint8_t* d_ref; int32_t* d_ss = nullptr; int32_t* d_se = nullptr; int* d_bad;
-    SL_TRY(upload("align.tab", tab.data(), tab.size(), &d_tab, stream));
+    double* d_tab; double* d_rz; uint32_t* d_cb; uint8_t* d_ref; int32_t* d_ss = nullptr; int32_t* d_se = nullptr; int* d_bad;
+    SL_TRY(upload("align.tab", rows.data(), rows.size(), &d_tab, stream));
     SL_TRY(upload("align.rz", rowzero.data(), rowzero.size(), &d_rz, stream));
-    SL_TRY(upload("align.ci", colinfo.data(), colinfo.size(), &d_ci, stream));
+    SL_TRY(upload("align.cb", colbase.data(), colbase.size(), &d_cb, stream));
     SL_TRY(upload("align.ref", reinterpret_cast<const uint8_t*>(ref), static_cast<size_t>(R), &d_ref, stream));
     if (nsec) {
         SL_TRY(upload("align.ss", sec_starts, static_cast<size_t>(nsec), &d_ss, stream));
@@ -589,28 +753,36 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     const size_t per_wave_elems = kernel_mode ? ((static_cast<size_t>(max_len) + sh.W + 16) / tb_steps + 2) * 64 : 0;
     int waves_per_cu = 20;
     if (const char* ew = std::getenv("SARLACC_ALIGN_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(ew));
-    long long grid = std::min<long long>(nitems, static_cast<long long>(c.num_cu) * waves_per_cu);
+    // workgroups of NWAVES wavefronts; every wavefront owns a traceback tile
+    long long grid = std::min<long long>((nitems + NWAVES - 1) / NWAVES,
+                                         (static_cast<long long>(c.num_cu) * waves_per_cu + NWAVES - 1) / NWAVES);
     if (kernel_mode) {
         const size_t budget = static_cast<size_t>(6) << 30;
-        const long long fit = std::max<long long>(1, static_cast<long long>(budget / std::max<size_t>(1, per_wave_elems * word_bytes)));
+        const long long fit = std::max<long long>(1, static_cast<long long>(budget / std::max<size_t>(1, per_wave_elems * word_bytes * NWAVES)));
         grid = std::min(grid, fit);
     }
     void* d_dirs = nullptr;
-    if (kernel_mode) SL_TRY(c.buffer("align.dirs", static_cast<size_t>(grid) * per_wave_elems * word_bytes, &d_dirs));
+    if (kernel_mode) SL_TRY(c.buffer("align.dirs", static_cast<size_t>(grid) * NWAVES * per_wave_elems * word_bytes, &d_dirs));
 
     a.seq = d_seq; a.nmask = d_nmask; a.qual = d_qual; a.off = d_off; a.n = n;
     a.R = R; a.W = sh.W; a.ngroups = sh.ngroups; a.local = local ? 1 : 0;
     a.qoffset = static_cast<int>(enc_names[0]); a.navail = enc_n;
     a.GO = GO; a.GE = GE;
-    a.tables = d_tab; a.rowzero = d_rz; a.colinfo = d_ci; a.refchars = d_ref;
+    a.tables = d_tab; a.tab_doubles = static_cast<int>(rows.size()); a.row_bytes = static_cast<int>(enc_n * sizeof(double));
+    a.rowzero = d_rz; a.colbase = d_cb; a.refchars = d_ref;
     a.scores = out.d_scores; a.starts = out.d_starts; a.ends = out.d_ends;
     a.sec_s = d_ss; a.sec_e = d_se; a.nsec = nsec; a.sec_so = out.d_sec_so; a.sec_wo = out.d_sec_wo;
     a.dirs = d_dirs; a.dirs_per_wave = per_wave_elems; a.badqual = d_bad;
     a.aln_ref = out.d_aln_ref; a.aln_qry = out.d_aln_qry; a.aln_len = out.d_aln_len; a.edits = out.d_edits;
 
-    const size_t lds = sizeof(double) * 5 * enc_n + sizeof(uint16_t) * NGMAX * RING + sizeof(int32_t) * NGMAX * (R + 1) + 16;
+    const size_t lds = sizeof(uint16_t) * NWAVES * NGMAX * RING + sizeof(double) * rows.size() +
+                       sizeof(int32_t) * NWAVES * sh.ngroups * (R + 1) + 16;
+    if (lds > 64 * 1024) return fail("sarlacc_amd: alignment tables do not fit in LDS");
+    // gapopen >= 0 (GO >= GE): no penalty selects on the device, see k_align
+    bool pensel = !(GO >= GE);
+    if (const char* ep = std::getenv("SARLACC_ALIGN_PENSEL")) pensel = pensel || std::atoi(ep) != 0;  // testing: force the general path
     SL_HIP(hipEventRecord(c.ev_start, stream));
-    SL_TRY(launch_k(sh.K, sh.W, R, kernel_mode, local, a, static_cast<int>(grid), lds, stream));
+    SL_TRY(launch_k(sh.K, sh.W, R, pensel, kernel_mode, local, a, static_cast<int>(grid), lds, stream));
     SL_HIP(hipEventRecord(c.ev_stop, stream));
     c.timed = true;
 
