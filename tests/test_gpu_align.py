@@ -117,6 +117,42 @@ def test_random_differential(oracle, oenc, enc, R):
     compare_adaptor(oracle, oenc, enc, reads, quals, adaptor, go, ge, ss, se)
 
 
+def _penalty_batch(oracle, oenc, enc, R, go, ge, seed):
+    from sarlacc_amd import calls
+    from sarlacc_amd.mock import random_reads
+    rng = np.random.default_rng(seed)
+    adaptor = "".join(rng.choice(list(IUPAC if R % 2 else "ACGT"), R))
+    reads, quals = random_reads(21, 0, 140, seed=seed)
+    core = "".join(c if c in "ACGT" else "C" for c in adaptor)
+    reads[2] = reads[2][:10] + core[: R // 2] + "GG" + core[R // 2:] + reads[2][10:]   # insertion in the read
+    reads[4] = reads[4][:15] + core[: R // 3] + core[R // 3 + 2:] + reads[4][15:]      # deletion from the read
+    quals[2] = rand_quals([reads[2]], seed)[0]
+    quals[4] = rand_quals([reads[4]], seed + 1)[0]
+    ss, se = ([R // 3], [max(R // 3, (2 * R) // 3)]) if R > 2 else ([], [])
+    compare_adaptor(oracle, oenc, enc, reads, quals, adaptor, go, ge, ss, se)
+    a = oracle.general_align(reads[:8], quals[:8], oenc, go, ge, core)
+    b = calls.general_align(reads[:8], quals[:8], enc, go, ge, core, False)
+    assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
+    assert np.array_equal(bits(oracle.barcode_align(reads, quals, oenc, go, ge, core)),
+                          bits(calls.barcode_align(reads, quals, enc, go, ge, core)))
+
+
+@pytest.mark.parametrize("R", [5, 30, 33, 70, 129, 600])
+@pytest.mark.parametrize("go,ge", [(0, 1), (0, 0.3), (-1, 2), (-0.25, 0.25), (0.1, 0.7), (3, 0)])
+def test_gap_penalty_variants(oracle, oenc, enc, R, go, ge):
+    """gapopen == 0 (open == extend), gapopen < 0 (the kernel variant that selects penalties
+    explicitly), penalties with non-zero low mantissa bits, free extension."""
+    _penalty_batch(oracle, oenc, enc, R, go, ge, seed=7000 + R)
+
+
+@pytest.mark.parametrize("R", [3, 16, 30, 31, 64, 100, 300])
+def test_forced_penalty_select_kernel(oracle, oenc, enc, R, monkeypatch):
+    """Both kernel variants must agree with the oracle for ordinary penalties."""
+    monkeypatch.setenv("SARLACC_ALIGN_PENSEL", "1")
+    _penalty_batch(oracle, oenc, enc, R, 5, 1, seed=8000 + R)
+    _penalty_batch(oracle, oenc, enc, R, 2.5, 0.75, seed=8100 + R)
+
+
 def test_c2_shape_sample(oracle, oenc, enc):
     # BASELINE config 2 shape on a sample the oracle finishes in seconds:
     # 2 kb mock reads vs a 30-bp adaptor (9 fixed + 12 N + 9 fixed), go=5, ge=1

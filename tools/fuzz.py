@@ -56,7 +56,7 @@ def case_align(rng):
         reads[k] = reads[k][:pos] + core + reads[k][pos:]
     qlo = 33 if rng.random() < 0.5 else 40
     quals = [rqual(rng, len(r), qlo, int(rng.choice([75, 126]))) for r in reads]
-    go, ge = [(5, 1), (20, 1), (1, 1), (2.5, 0.75), (0, 1), (3, 0), (7.25, 2.5)][int(rng.integers(0, 7))]
+    go, ge = [(5, 1), (20, 1), (1, 1), (2.5, 0.75), (0, 1), (3, 0), (7.25, 2.5), (-1, 2), (0.1, 0.7), (-0.5, 0.5)][int(rng.integers(0, 10))]
     nsec = int(rng.integers(0, 4)) if R else 0
     ss = sorted(int(x) for x in rng.integers(0, max(R, 1), nsec))
     se = [int(rng.integers(s, R) + 1) for s in ss]
