@@ -44,12 +44,12 @@ def cpu_baseline(sample_seq, sample_qual):
 
 def pmc_traffic(n_reads):
     """HBM bytes per launch of the DP kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_1M_*.json; FETCH_SIZE and WRITE_SIZE are collected in separate passes and
+    (profiles/r*_pmc_1M_*.json; FETCH_SIZE and WRITE_SIZE are collected in separate passes and
     cannot be collected from inside this process).  Returned only for the configuration the
     passes were run on; FETCH_SIZE is taken at face value (the guide's possible 2x under-count
     for wide reads is noted in the file)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_pmc_1M_*.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_1M_*.json")))
     if not files or n_reads != 1_000_000:
         return None
     with open(files[-1]) as fh:
