@@ -66,6 +66,7 @@ struct AlignArgs {
     int32_t* sec_wo;
     void* dirs;
     unsigned long long dirs_per_wave;  // elements per wavefront
+    int snap_head, snap_win;           // MODE 3: see SNAP_P
     int* badqual;                      // min index of a read holding a quality below the offset
     uint8_t* aln_ref;                  // MODE 2: reversed gapped strings, stride L+R per read
     uint8_t* aln_qry;
@@ -133,9 +134,26 @@ struct TbStore<16> { using type = unsigned long long; };
 
 template <bool B>
 struct Flag { static constexpr bool value = B; };
+template <int V>
+struct Int { static constexpr int value = V; };
 
-// MODE 0: scores only.  MODE 1: scores + reference->read map (adaptor_align).
+// MODE 3 (adaptor_align, local, gapopen >= 0): no traceback stream at all.  The fill keeps only
+// scores, the landing row of column R and, every SNAP_P steps, a snapshot of the complete lane
+// state (column scores, jump scores, the row state in flight between lanes).  Afterwards each
+// alignment restores the snapshot just above its landing row and recomputes a window of at
+// most SNAP_WIN steps with traceback codes; the leader walks the window and, should the path
+// leave it through the top, the next window up is recomputed.  A snapshot is the exact state
+// of the recurrence, so the recomputed cells are the cells of the first pass, bit for bit.
+constexpr int SNAP_P = 64;      // steps between snapshots (multiple of the 64-row staging block)
+// rows above the row a walk asks for that its window must cover: an alignment of R columns
+// rarely spans more than R + R/4 rows, and a longer one only costs another window
+static inline int snap_head(int R) { return R + R / 4 + 4; }
+// steps per window: SNAP_P - 1 + head + W lanes + 1, rounded up to the 8-step store granule
+static inline int snap_win(int R, int W) { return (SNAP_P + snap_head(R) + W + 7) / 8 * 8; }
+
+// MODE 0: scores only.  MODE 1: scores + reference->read map (adaptor_align), codes streamed.
 // MODE 2: scores + gapped strings + edit distance (general_align).
+// MODE 3: as MODE 1 by snapshots + windowed recompute (LOCAL, !PENSEL only; see SNAP_P).
 // LOCAL: free leading read bases + free vertical gaps in the last column (adaptor mode).
 // ROW16: alignments are 16 lanes wide and start on DPP row boundaries.
 // KLAST: index (inside its lane) of reference column R when known at compile time, else -1.
@@ -201,6 +219,9 @@ __global__ void __launch_bounds__(64 * NWAVES, 5) k_align(const AlignArgs A) {
     const long long gwave = static_cast<long long>(blockIdx.x) * NWAVES + wave;
     const long long nwaves = static_cast<long long>(gridDim.x) * NWAVES;
     Word* const scr = static_cast<Word*>(A.dirs) + static_cast<size_t>(gwave) * A.dirs_per_wave;
+    // MODE 3: the tile holds the codes of one window, the snapshots follow it
+    constexpr int NSV = 2 * K + 3;  // doubles per lane in a snapshot
+    double* const snap = reinterpret_cast<double*>(scr + static_cast<size_t>(A.snap_win / UNR) * 64);
     const int ring_g = lds0 + (wave * NGMAX + g) * static_cast<int>(RING * sizeof(uint16_t));  // byte address of this alignment's ring
     __syncthreads();
 
@@ -260,8 +281,9 @@ __global__ void __launch_bounds__(64 * NWAVES, 5) k_align(const AlignArgs A) {
             s_ring[gg * RING + (r & (RING - 1))] = static_cast<uint16_t>((v >> 8) * A.row_bytes + (qi << 3));
         };
         uint32_t pf[NGMAX];
+        int toff[NGMAX];  // first step of the window being recomputed (MODE 3), per alignment; 0 in the fill
 #pragma unroll
-        for (int gg = 0; gg < NGMAX; ++gg) pf[gg] = fetch(gg, 0);
+        for (int gg = 0; gg < NGMAX; ++gg) { pf[gg] = fetch(gg, 0); toff[gg] = 0; }
 
         // per-column state: score of the previous row, vertical jump score (and, PENSEL only,
         // the penalty the next vertical step pays)
@@ -275,26 +297,47 @@ __global__ void __launch_bounds__(64 * NWAVES, 5) k_align(const AlignArgs A) {
         int ph_in = GOhi, pl_in = GOlo;
         // Row position as x2 = 2 * (i - 1), i = t - j: doubles as the ring byte offset.
         int x2 = -2 * j - 2;
-        const int x2max = valid ? 2 * L - 2 : -2;
+        int x2max = valid ? 2 * L - 2 : -2;
         // Landing row of the upward walk the traceback performs in column R (tracked by the lane
         // owning that column, in x2 units): land[i] = i if the move at (i,R) is not vertical, else
         // the landing row of the cell the vertical jump leads to.  Without it the walk up the last
         // column (free vertical gaps => ~L single steps in local mode) costs ~L dependent loads.
         int land_prev = -2, land_up = -2;
         int vnl = 0;  // the move at (i-1, R) was a vertical gap
+        // MODE 3 tracks the landing row directly: in local mode the vertical gaps of column R are
+        // free, every row of a vertical run resets the jump (its candidate S[i-1] equals the
+        // running jump score, and the comparison is strict), so the walk up column R stops at the
+        // last row whose move is not vertical, i.e. the last row with best > V.
+        int land_x2 = -2;
 
         // Steps [t_begin, t_end).  GUARD = false is the steady state: every lane of every
         // alignment of the wave is inside its read, nothing is predicated and all flags are
         // lane masks in SGPRs.
-        auto run = [&](auto guard_tag, int t_begin, int t_end) {
+        // TR: 0 no traceback, 1 codes streamed to the per-wave tile (MODE 1/2), 2 landing row +
+        // snapshots (MODE 3 fill), 3 codes of a recomputed window (MODE 3; t counts from toff[])
+        auto run = [&](auto guard_tag, auto trace_tag, int t_begin, int t_end) {
             constexpr bool GUARD = decltype(guard_tag)::value;
+            constexpr int TR = decltype(trace_tag)::value;
+            constexpr bool CODES = TR == 1 || TR == 3;
             mask_t m_vnl = GUARD ? 0 : __builtin_amdgcn_ballot_w64(vnl != 0);
             for (int t0 = t_begin; t0 < t_end; t0 += UNR) {
                 if ((t0 & 63) == 0) {
 #pragma unroll
                     for (int gg = 0; gg < NGMAX; ++gg) {
-                        stage(gg, t0, pf[gg]);
-                        pf[gg] = fetch(gg, t0 + 64);
+                        stage(gg, toff[gg] + t0, pf[gg]);
+                        pf[gg] = fetch(gg, toff[gg] + t0 + 64);
+                    }
+                    if (TR == 2 && (t0 & (SNAP_P - 1)) == 0) {
+                        // complete lane state before step t0
+                        double* sp = snap + static_cast<size_t>(t0 / SNAP_P) * (NSV * 64) + lane;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            __builtin_nontemporal_store(S[k], sp + (2 * k) * 64);
+                            __builtin_nontemporal_store(UJ[k], sp + (2 * k + 1) * 64);
+                        }
+                        __builtin_nontemporal_store(s_in, sp + (2 * K) * 64);
+                        __builtin_nontemporal_store(lj_in, sp + (2 * K + 1) * 64);
+                        __builtin_nontemporal_store(diag_prev, sp + (2 * K + 2) * 64);
                     }
                 }
                 Word pk = 0;
@@ -352,14 +395,17 @@ __global__ void __launch_bounds__(64 * NWAVES, 5) k_align(const AlignArgs A) {
                                     vp_hi[k] = sel32(hi32(vgo[k]), hi32(vge[k]), m_vn);
                                     vp_lo[k] = sel32(lo32(vgo[k]), lo32(vge[k]), m_vn);
                                 }
-                                if (MODE >= 1) {
+                                if (TR == 2) {
+                                    if (is_last) land_x2 = sel32(land_x2, x2, __builtin_amdgcn_ballot_w64(best > V));
+                                }
+                                if (CODES) {
                                     if (ADDC) {
                                         pk = push_bit(push_bit(push_bit(push_bit(static_cast<uint32_t>(pk), m_vj), m_hj), m_tm), m_hv);
                                     } else {
                                         const unsigned raw = (b_hv ? 1u : 0u) | (b_tm ? 2u : 0u) | (b_hj ? 4u : 0u) | (b_vj ? 8u : 0u);
                                         pk |= static_cast<Word>(raw) << (4 * (CELLS - 1 - (u * K + k)));
                                     }
-                                    if (is_last) {
+                                    if (TR == 1 && is_last) {
                                         const mask_t m_cont = m_vj & ~m_vnl;  // the vertical jump really continued
                                         land_up = sel32(land_prev, land_up, m_cont);  // continued: same landing row
                                         land_prev = sel32(land_up, x2, ~m_vn);
@@ -374,10 +420,13 @@ __global__ void __launch_bounds__(64 * NWAVES, 5) k_align(const AlignArgs A) {
                                     vp_hi[k] = vn ? hi32(vge[k]) : hi32(vgo[k]);
                                     vp_lo[k] = vn ? lo32(vge[k]) : lo32(vgo[k]);
                                 }
-                                if (MODE >= 1) {
+                                if (TR == 2) {
+                                    if (is_last && best > V) land_x2 = x2;
+                                }
+                                if (CODES) {
                                     const unsigned raw = (b_hv ? 1u : 0u) | (b_tm ? 2u : 0u) | (b_hj ? 4u : 0u) | (b_vj ? 8u : 0u);
                                     pk |= static_cast<Word>(raw) << (4 * (CELLS - 1 - (u * K + k)));
-                                    if (is_last) {
+                                    if (TR == 1 && is_last) {
                                         const bool cont = b_vj && vnl == 0;
                                         land_up = cont ? land_up : land_prev;
                                         land_prev = vn ? land_up : x2;
@@ -407,7 +456,8 @@ __global__ void __launch_bounds__(64 * NWAVES, 5) k_align(const AlignArgs A) {
                     }
                     x2 += 2;
                 }
-                if (MODE >= 1) __builtin_nontemporal_store(pk, scr + static_cast<size_t>(t0 / UNR) * 64 + lane);
+                if (TR == 1) __builtin_nontemporal_store(pk, scr + static_cast<size_t>(t0 / UNR) * 64 + lane);
+                if (TR == 3) scr[static_cast<size_t>(t0 / UNR) * 64 + lane] = pk;
             }
             if (!GUARD) vnl = sel32(0, 1, m_vnl);
         };
@@ -417,9 +467,10 @@ __global__ void __launch_bounds__(64 * NWAVES, 5) k_align(const AlignArgs A) {
         int t_b = Lmin == 0x7fffffff ? 0 : ((Lmin + 1) / UNR) * UNR;  // first block leaving the shortest read
         t_a = min(t_a, nsteps);
         t_b = min(max(t_b, t_a), nsteps);
-        run(Flag<true>{}, 0, t_a);
-        run(Flag<false>{}, t_a, t_b);
-        run(Flag<true>{}, t_b, nsteps);
+        constexpr int TR_FILL = MODE == 3 ? 2 : (MODE >= 1 ? 1 : 0);
+        run(Flag<true>{}, Int<TR_FILL>{}, 0, t_a);
+        run(Flag<false>{}, Int<TR_FILL>{}, t_a, t_b);
+        run(Flag<true>{}, Int<TR_FILL>{}, t_b, nsteps);
 
         if (valid && j == jlast) {
             double sc = S[0];
@@ -428,7 +479,134 @@ __global__ void __launch_bounds__(64 * NWAVES, 5) k_align(const AlignArgs A) {
             A.scores[read] = sc;
         }
 
-        if (MODE >= 1) {
+        if (MODE == 3) {
+            int32_t* map = s_map + g * (R + 1);
+            const Word* const wtile = scr;
+            // walk state of the group's leader: position, and the jump chain being measured
+            int row = (__shfl(land_x2, g * W + jlast) >> 1) + 1, c = R;
+            int phase = 0, chain_n = 0, chain_at = 0;
+            unsigned cur = 0;
+            int want = row;         // lowest row the next window has to hold
+            int pending = valid ? 1 : 0;
+            while (__builtin_amdgcn_ballot_w64(pending != 0)) {
+                // ---- recompute the window that holds row `want` (per alignment) ----
+                const int ts = pending ? (max(want - A.snap_head, 0) / SNAP_P) * SNAP_P : 0;
+                // steps [0, nwin) of the window; [t_wa, t_wb) of them have every lane of every
+                // pending alignment inside its read (the others compute garbage nobody reads)
+                int nwin = 0, t_wa = 0, t_wb = 0x7fffffff;
+#pragma unroll
+                for (int gg = 0; gg < NGMAX; ++gg) {
+                    const int src = gg < A.ngroups ? gg * W : 0;
+                    toff[gg] = __builtin_amdgcn_readlane(ts, src);
+                    const int pend = __builtin_amdgcn_readlane(pending, src);
+                    const int need = __builtin_amdgcn_readlane(want + W + 1 - ts, src);
+                    if (gg < A.ngroups && pend) {
+                        nwin = max(nwin, need);
+                        if (toff[gg] < W) t_wa = W;                 // lanes still entering the read
+                        t_wb = min(t_wb, glen[gg] + 1 - toff[gg]);  // first step leaving it
+                    }
+                }
+                nwin = min(((nwin + UNR - 1) / UNR) * UNR, A.snap_win);
+                t_wa = min(((t_wa + UNR - 1) / UNR) * UNR, nwin);
+                t_wb = min(max((t_wb / UNR) * UNR, t_wa), nwin);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const double* sp = snap + static_cast<size_t>(ts / SNAP_P) * (NSV * 64) + lane;
+#pragma unroll
+                for (int k = 0; k < K; ++k) { S[k] = sp[(2 * k) * 64]; UJ[k] = sp[(2 * k + 1) * 64]; }
+                s_in = sp[(2 * K) * 64];
+                lj_in = sp[(2 * K + 1) * 64];
+                diag_prev = sp[(2 * K + 2) * 64];
+                x2 = 2 * (ts - j - 1);
+                x2max = pending ? 2 * L - 2 : -2;
+#pragma unroll
+                for (int gg = 0; gg < NGMAX; ++gg) {
+                    if (toff[gg] >= 64) stage(gg, toff[gg] - 64, fetch(gg, toff[gg] - 64));
+                    pf[gg] = fetch(gg, toff[gg]);
+                }
+                run(Flag<true>{}, Int<3>{}, 0, t_wa);
+                run(Flag<false>{}, Int<3>{}, t_wa, t_wb);
+                run(Flag<true>{}, Int<3>{}, t_wb, nwin);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+
+                // ---- leaders walk (src/reference_align.cpp:231-278) until done or out of window ----
+                if (pending && leader) {
+                    // raw compare bits of cell (rr, cc), see nibble() below; false: above the window
+                    auto code_at = [&](int cc, int rr, unsigned& out) -> bool {
+                        const int jj = (cc - 1) / K, kk = (cc - 1) % K;
+                        const int tt = rr + jj - ts;
+                        if (tt < 0) return false;
+                        const Word w = wtile[static_cast<size_t>(tt / UNR) * 64 + (g * W + jj)];
+                        out = static_cast<unsigned>(w >> (4 * (CELLS - 1 - ((tt % UNR) * K + kk)))) & 15u;
+                        return true;
+                    };
+                    bool stalled = false;
+                    while (c > 0 && !stalled) {
+                        if (phase == 0) {
+                            if (row <= 0) { map[c] = (row + 1) * 2; --c; continue; }  // D[c][0] = 1
+                            unsigned nb;
+                            if (!code_at(c, row, nb)) { want = row; stalled = true; break; }
+                            if (nb & 2u) { map[c] = row * 2 + 1; --row; --c; continue; }
+                            cur = nb;
+                            chain_n = 0;
+                            phase = (nb & 1u) ? 1 : 2;
+                            chain_at = (nb & 1u) ? c : row;
+                        }
+                        if (phase == 1) {  // horizontal jump: count the columns it continued through
+                            while ((cur & 4u) && chain_at > 1) {
+                                unsigned prev;
+                                if (!code_at(chain_at - 1, row, prev)) { want = row; stalled = true; break; }
+                                if ((prev & 3u) == 1u) break;
+                                ++chain_n; --chain_at; cur = prev;
+                            }
+                            if (stalled) break;
+                            for (int x = 0; x <= chain_n; ++x) { map[c] = (row + 1) * 2; --c; }
+                            phase = 0;
+                        } else {           // vertical jump: count the rows it continued through
+                            while ((cur & 8u) && chain_at > 1) {
+                                unsigned prev;
+                                if (!code_at(c, chain_at - 1, prev)) { want = chain_at - 1; stalled = true; break; }
+                                if ((prev & 3u) == 0u) break;
+                                ++chain_n; --chain_at; cur = prev;
+                            }
+                            if (stalled) break;
+                            row -= 1 + chain_n;  // up moves leave the map untouched (:286)
+                            phase = 0;
+                        }
+                    }
+                    if (!stalled) {
+                        pending = 0;
+                        // (src/reference_align.cpp:307-351), size_t wrap kept via unsigned
+                        auto interval = [&](int a, int b, bool gaps, unsigned& s, unsigned& e) {
+                            if (!gaps) {
+                                s = map[a + 1] >> 1;
+                                e = (map[b] >> 1) + (map[b] & 1);
+                            } else {
+                                s = (a == 0) ? 1u : static_cast<unsigned>((map[a] >> 1) + (map[a] & 1));
+                                e = (b + 1 == R + 1) ? static_cast<unsigned>(L + 1) : static_cast<unsigned>(map[b + 1] >> 1);
+                            }
+                            s -= 1;
+                            e -= 1;
+                        };
+                        unsigned s, e;
+                        interval(0, R, false, s, e);
+                        const bool nonempty = s < e;
+                        A.starts[read] = nonempty ? static_cast<int32_t>(s + 1) : 0;
+                        A.ends[read] = nonempty ? static_cast<int32_t>(e) : 0;
+                        for (int x = 0; x < A.nsec; ++x) {
+                            interval(A.sec_s[x], A.sec_e[x], true, s, e);
+                            A.sec_so[static_cast<long long>(x) * A.n + read] = static_cast<int32_t>(s + 1);
+                            A.sec_wo[static_cast<long long>(x) * A.n + read] = static_cast<int32_t>(e - s);
+                        }
+                    }
+                }
+                pending = __shfl(pending, g * W);
+                want = __shfl(want, g * W);
+            }
+        }
+
+        if (MODE == 1 || MODE == 2) {
             // make this wave's traceback stores visible to its leader lanes
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -642,6 +820,7 @@ static int launch_mode(int mode, bool local, const AlignArgs& a, int grid, size_
     if (mode == 0 && local) hipLaunchKernelGGL((k_align<K, 0, true, ROW16, KLAST, PENSEL>), dim3(grid), dim3(64 * NWAVES), lds, s, a);
     else if (mode == 0) hipLaunchKernelGGL((k_align<K, 0, false, ROW16, KLAST, PENSEL>), dim3(grid), dim3(64 * NWAVES), lds, s, a);
     else if (mode == 1 && local) hipLaunchKernelGGL((k_align<K, 1, true, ROW16, KLAST, PENSEL>), dim3(grid), dim3(64 * NWAVES), lds, s, a);
+    else if (mode == 3 && local && !PENSEL) hipLaunchKernelGGL((k_align<K, 3, true, ROW16, KLAST, false>), dim3(grid), dim3(64 * NWAVES), lds, s, a);
     else if (mode == 2 && !local) hipLaunchKernelGGL((k_align<K, 2, false, ROW16, KLAST, PENSEL>), dim3(grid), dim3(64 * NWAVES), lds, s, a);
     else return fail("sarlacc_amd: unsupported alignment mode");
     SL_HIP(hipGetLastError());
@@ -750,7 +929,17 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     // traceback tile of one resident wave: one word per lane per TbSteps<K> steps (4 bits per cell)
     const int tb_steps = std::max(1, 8 / sh.K);
     const size_t word_bytes = sh.K == 16 ? 8 : 4;
-    const size_t per_wave_elems = kernel_mode ? ((static_cast<size_t>(max_len) + sh.W + 16) / tb_steps + 2) * 64 : 0;
+    size_t per_wave_elems = kernel_mode ? ((static_cast<size_t>(max_len) + sh.W + 16) / tb_steps + 2) * 64 : 0;
+    // gapopen >= 0 (GO >= GE): no penalty selects on the device, see k_align
+    bool pensel = !(GO >= GE);
+    if (const char* ep = std::getenv("SARLACC_ALIGN_PENSEL")) pensel = pensel || std::atoi(ep) != 0;  // testing: force the general path
+    // adaptor_align without penalty selects: snapshots + windowed recompute instead of the code stream
+    if (kernel_mode == 1 && local && !pensel && !std::getenv("SARLACC_ALIGN_STREAM")) {
+        kernel_mode = 3;
+        const size_t nsnap = (static_cast<size_t>(max_len) + sh.W + 16) / SNAP_P + 2;
+        per_wave_elems = static_cast<size_t>(snap_win(R, sh.W) / tb_steps) * 64 +
+                         nsnap * (2 * sh.K + 3) * 64 * (sizeof(double) / word_bytes);
+    }
     int waves_per_cu = 20;
     if (const char* ew = std::getenv("SARLACC_ALIGN_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(ew));
     // workgroups of NWAVES wavefronts; every wavefront owns a traceback tile
@@ -773,14 +962,12 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     a.scores = out.d_scores; a.starts = out.d_starts; a.ends = out.d_ends;
     a.sec_s = d_ss; a.sec_e = d_se; a.nsec = nsec; a.sec_so = out.d_sec_so; a.sec_wo = out.d_sec_wo;
     a.dirs = d_dirs; a.dirs_per_wave = per_wave_elems; a.badqual = d_bad;
+    a.snap_head = snap_head(R); a.snap_win = snap_win(R, sh.W);
     a.aln_ref = out.d_aln_ref; a.aln_qry = out.d_aln_qry; a.aln_len = out.d_aln_len; a.edits = out.d_edits;
 
     const size_t lds = sizeof(uint16_t) * NWAVES * NGMAX * RING + sizeof(double) * rows.size() +
                        sizeof(int32_t) * NWAVES * sh.ngroups * (R + 1) + 16;
     if (lds > 64 * 1024) return fail("sarlacc_amd: alignment tables do not fit in LDS");
-    // gapopen >= 0 (GO >= GE): no penalty selects on the device, see k_align
-    bool pensel = !(GO >= GE);
-    if (const char* ep = std::getenv("SARLACC_ALIGN_PENSEL")) pensel = pensel || std::atoi(ep) != 0;  // testing: force the general path
     SL_HIP(hipEventRecord(c.ev_start, stream));
     SL_TRY(launch_k(sh.K, sh.W, R, pensel, kernel_mode, local, a, static_cast<int>(grid), lds, stream));
     SL_HIP(hipEventRecord(c.ev_stop, stream));
