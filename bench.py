@@ -49,7 +49,9 @@ def pmc_traffic(n_reads):
     passes were run on; FETCH_SIZE is taken at face value (the guide's possible 2x under-count
     for wide reads is noted in the file)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_1M_*.json")))
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_1M_v*.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
     if not files or n_reads != 1_000_000:
         return None
     with open(files[-1]) as fh:
