@@ -77,22 +77,16 @@ def pipeline_sample(groups=4000, read_len=2000, copies=10):
     best = None
     for _ in range(2):
         t0 = time.perf_counter()
-        clusters = calls.umi_group(umis, 1, None, 1, [np.arange(1, n + 1, dtype=np.int32)])
-        t1 = time.perf_counter()
-        big = [g for g in clusters if len(g) >= 2]
-        goff = np.zeros(len(big) + 1, np.int64)
-        goff[1:] = np.cumsum([len(g) for g in big])
-        gflat = np.concatenate(big).astype(np.int32)
+        coff, cmem = calls.umi_group_flat(umis, 1, None, 1, np.array([0, n], np.int64), np.arange(1, n + 1, dtype=np.int32))
+        goff, gflat = calls.csr_select(coff, cmem, np.diff(coff) >= 2)
         qsub = quals.subset(gflat.astype(np.int64) - 1)
-        t2 = time.perf_counter()
         rows, grp_rows, _ = calls.quick_msa_flat(goff, gflat, reads, 0, -1, -5, -1, 100)
         cons, _ = calls.create_consensus_flat(rows, grp_rows, 0.6, quals=qsub, encoding=enc)
-        t3 = time.perf_counter()
-        dt = (t1 - t0) + (t3 - t2)
+        dt = time.perf_counter() - t0   # everything between the UMI strings and the consensus strings
         best = dt if best is None else min(best, dt)
     return {"reads_per_min": n / best * 60.0, "reads": n, "consensus_reads": len(cons),
             "workload": "%d molecules x %d reads x %d bp, 12-bp UMIs: umi_group(threshold 1) -> quick_msa(bandwidth 100) "
-                        "-> create_consensus_quality_loop, host-pointer C ABI incl. PCIe" % (groups, copies, read_len)}
+                        "-> create_consensus_quality_loop, host-pointer C ABI incl. PCIe and the host glue between the calls" % (groups, copies, read_len)}
 
 
 def main():
@@ -102,7 +96,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=2000)
-    ap.add_argument("--cpu-sample", type=int, default=6000)
+    ap.add_argument("--cpu-sample", type=int, default=25000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
     args = ap.parse_args()

@@ -276,6 +276,36 @@ def umi_group(umi1, thresh1, umi2, thresh2, pregroup):
     return lists_from_csr(co, cl, ncl.value)
 
 
+def umi_group_flat(umi1, thresh1, umi2, thresh2, pregroup_off, pregroup):
+    """umi_group on CSR pre-groups, CSR clusters out: (cluster_off int64[nclusters+1], members
+    int32[...]) -- same clusters, same order as umi_group, without building Python lists."""
+    s1 = StringSet.from_strings(umi1)
+    s2 = StringSet.from_strings(umi2) if umi2 is not None else None
+    if s2 is not None and len(s2) != len(s1):
+        raise SarlaccError("'umi1' and 'umi2' should have the same length")
+    goff = np.ascontiguousarray(pregroup_off, dtype=np.int64)
+    gvals = np.ascontiguousarray(pregroup, dtype=np.int32)
+    if gvals.size == 0:
+        gvals = np.zeros(1, np.int32)
+    total = int(goff[-1])
+    ncl = C.c_int64(0)
+    co = np.zeros(total + 2, np.int64)
+    cl = np.zeros(max(total, 1), np.int32)
+    check(_lib.lib().sarlacc_umi_group(
+        ptr(s1.chars), ptr(s1.off), ptr(s2.chars) if s2 is not None else None,
+        ptr(s2.off) if s2 is not None else None, C.c_int64(len(s1)), _integer(thresh1, "threshold 1"),
+        _integer(thresh2, "threshold 2"), ptr(goff), ptr(gvals), C.c_int64(goff.size - 1), C.byref(ncl), ptr(co), ptr(cl)))
+    return co[:ncl.value + 1], cl[:int(co[ncl.value])]
+
+
+def csr_select(off, vals, keep):
+    """Rows of a CSR list selected by the boolean mask `keep` (numpy only)."""
+    sizes = np.diff(off)
+    noff = np.zeros(int(keep.sum()) + 1, np.int64)
+    np.cumsum(sizes[keep], out=noff[1:])
+    return noff, vals[np.repeat(keep, sizes)]
+
+
 def quick_msa(groupings, sequences, match, mismatch, gapExtension, gapOpening, bandwidth):
     """.Call quick_msa (src/quick_msa.cpp:15-80), same argument order (the R caller passes
     -gapOpening as gapExtension and -gapExtension as gapOpening, R/multiReadAlign.R:47).

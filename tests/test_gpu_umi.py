@@ -217,3 +217,19 @@ def test_tile_sharded_pairs_reproduce_umi_group(oracle):
             if world == 8:
                 sizes = [p.size for p in parts]
                 assert max(sizes) > 0
+
+
+def test_umi_group_flat_matches_lists():
+    """CSR in / CSR out variant used by the large-batch pipeline: same clusters, same order."""
+    from sarlacc_amd import calls
+    rng = np.random.default_rng(77)
+    umis = umisim(rng, 400, 12, 0.15)
+    pre = [list(range(1, 151)), [151], list(range(152, 401))]
+    want = calls.umi_group(umis, 1, None, 1, pre)
+    poff = np.cumsum([0] + [len(p) for p in pre])
+    coff, mem = calls.umi_group_flat(umis, 1, None, 1, poff, np.concatenate(pre))
+    got = [mem[coff[k]:coff[k + 1]] for k in range(len(coff) - 1)]
+    same_lists(got, want)
+    keep = np.diff(coff) >= 2
+    soff, smem = calls.csr_select(coff, mem, keep)
+    same_lists([smem[soff[k]:soff[k + 1]] for k in range(len(soff) - 1)], [w for w in want if len(w) >= 2])

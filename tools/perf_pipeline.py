@@ -44,26 +44,22 @@ def main():
 
     for rep in range(2):
         t0 = time.perf_counter()
-        groups = calls.umi_group(umis, 1, None, 1, [np.arange(1, n + 1, dtype=np.int32)])
+        coff, cmem = calls.umi_group_flat(umis, 1, None, 1, np.array([0, n], np.int64), np.arange(1, n + 1, dtype=np.int32))
         t1 = time.perf_counter()
-        big = [g for g in groups if len(g) >= 2]
-        goff = np.zeros(len(big) + 1, np.int64)
-        goff[1:] = np.cumsum([len(g) for g in big])
-        gflat = np.concatenate(big).astype(np.int32)
+        goff, gflat = calls.csr_select(coff, cmem, np.diff(coff) >= 2)   # clusters of >= 2 reads
+        qsub = quals.subset(gflat.astype(np.int64) - 1)
         t2 = time.perf_counter()
         rows, grp_rows, width = calls.quick_msa_flat(goff, gflat, reads, 0, -1, -5, -1, 100)
         t3 = time.perf_counter()
         msa_ms = sarlacc_amd.last_kernel_ms()
-        qsub = quals.subset(gflat.astype(np.int64) - 1)
-        t4 = time.perf_counter()
         cons, phred = calls.create_consensus_flat(rows, grp_rows, 0.6, quals=qsub, encoding=enc)
         t5 = time.perf_counter()
         cons_ms = sarlacc_amd.last_kernel_ms()
-        total = (t1 - t0) + (t3 - t2) + (t5 - t4)
-        print("rep %d: umi_group %.2fs | quick_msa %.2fs (pairwise kernel %.1f ms) | consensus %.2fs (kernel %.1f ms) | "
-              "python glue %.2fs | %d clusters>=2 covering %d reads | %.2f M reads/min (GPU stages), consensus mean len %.0f"
-              % (rep, t1 - t0, t3 - t2, msa_ms, t5 - t4, cons_ms, (t2 - t1) + (t4 - t3), len(big), gflat.size,
-                 n / total * 60 / 1e6, np.mean(np.diff(cons.off))), flush=True)
+        big = [gflat[goff[k]:goff[k + 1]] for k in range(len(goff) - 1)]
+        print("rep %d: umi_group %.2fs | numpy glue %.2fs | quick_msa %.2fs (pairwise kernel %.1f ms) | consensus %.2fs (kernel %.1f ms) | "
+              "%d clusters>=2 covering %d reads | %.2f M reads/min end to end, consensus mean len %.0f"
+              % (rep, t1 - t0, t2 - t1, t3 - t2, msa_ms, t5 - t3, cons_ms, len(big), gflat.size,
+                 n / (t5 - t0) * 60 / 1e6, np.mean(np.diff(cons.off))), flush=True)
     # accuracy of the consensus vs truth for pure clusters
     from tests.test_oracle_umi import lev2
     mol = np.repeat(np.arange(G), 10)
