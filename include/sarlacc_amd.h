@@ -150,6 +150,18 @@ int sarlacc_dev_windows(const uint8_t* d_seq, const uint8_t* d_qual, const int64
 int sarlacc_dev_scramble(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
                          uint64_t seed, uint8_t* d_oseq, uint8_t* d_oqual, void* stream);
 
+/* FASTQ text already in device memory -> resident read batch.  Replaces the
+ * host-side ShortRead::FastqStreamer + .FASTQ2QSDS conversion (R/adaptorAlign.R:26-37,:104-110;
+ * R/realizeReads.R:15-26).  4-line records, LF or CRLF, trailing blank lines ignored; sequences
+ * are upper-cased, read names are the header lines without the '@'.
+ * Step 1 indexes the text and reports the sizes the caller has to allocate; step 2 fills
+ * d_seq/d_qual (total_bases bytes each), d_off (n+1), d_names (total_name_bytes, may be NULL
+ * together with d_name_off) for the text indexed last on this thread. */
+int sarlacc_dev_fastq_index(const uint8_t* d_text, int64_t nbytes, int64_t* n_records, int64_t* total_bases,
+                            int64_t* total_name_bytes, void* stream);
+int sarlacc_dev_fastq_extract(const uint8_t* d_text, uint8_t* d_seq, uint8_t* d_qual, int64_t* d_off,
+                              uint8_t* d_names, int64_t* d_name_off, void* stream);
+
 /* ------------------------------------------------------------------ */
 /* masked Levenshtein, neighbour search, clustering                      */
 

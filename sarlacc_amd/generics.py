@@ -12,6 +12,8 @@ Only orchestration lives here -- every arithmetic step is a call into the HIP li
 """
 import re
 
+import os
+
 import numpy as np
 
 from . import calls
@@ -45,13 +47,15 @@ class Reads:
 
 def read_fastq(path):
     """4-line FASTQ -> Reads (the reference streams with ShortRead::FastqStreamer,
-    R/adaptorAlign.R:26-37; ingest is host IO and stays on the host)."""
+    R/adaptorAlign.R:26-37).  Host reader; resident.DeviceReads.from_fastq parses on the device."""
     names, seqs, quals = [], [], []
     with open(path, "rb") as fh:
         while True:
             h = fh.readline()
             if not h:
                 break
+            if not h.strip():   # blank lines after the last record
+                continue
             s = fh.readline().rstrip(b"\r\n")
             fh.readline()
             q = fh.readline().rstrip(b"\r\n")
@@ -145,20 +149,42 @@ def _swap_rows(a, b, mask):
         a["subseq"][k] = [y if m else x for x, y, m in zip(a["subseq"][k], b["subseq"][k], mask)]
 
 
+def _align_and_extract_resident(adaptor, dev, host_seq, gap_opening, gap_extension, subseq_starts, subseq_ends):
+    """.align_and_extract on a resident window batch (DeviceReads + the host copy of its bases)."""
+    out = dev.align_map(adaptor, gap_opening, gap_extension, np.asarray(subseq_starts, dtype=np.int32) - 1, subseq_ends)
+    res = {"score": out[0], "start": out[1], "end": out[2], "subseq": {}}
+    for i, (st, wd) in enumerate(zip(out[3], out[4])):
+        res["subseq"]["Sub%d" % (i + 1)] = _subseq(host_seq, st, wd).to_strings()
+    return res
+
+
 def adaptorAlign(adaptor1, adaptor2, reads, tolerance=250, gapOpening=5, gapExtension=1):
-    """adaptorAlign (R/adaptorAlign.R:7-78).  `reads` is a Reads object or a FASTQ path."""
+    """adaptorAlign (R/adaptorAlign.R:7-78).  `reads` is a Reads object or, as in the reference, the
+    path of a FASTQ file: the text is then parsed on the device, the front/back windows are cut
+    there and the four alignments run on the resident windows (no host pass over the bases)."""
     adaptor1, adaptor2 = str(adaptor1).upper(), str(adaptor2).upper()
     filepath = None
-    if isinstance(reads, str):
-        filepath = reads
-        reads = read_fastq(reads)
     sub1, sub2 = _setup_subseqs(adaptor1), _setup_subseqs(adaptor2)
-    front, back = _get_front_and_back(reads, tolerance)
     args = (gapOpening, gapExtension)
-    cur_starts = _align_and_extract(adaptor1, front, *args, sub1["starts"], sub1["ends"])
-    cur_ends = _align_and_extract(adaptor2, back, *args, sub2["starts"], sub2["ends"])
-    rc_starts = _align_and_extract(adaptor1, back, *args, sub1["starts"], sub1["ends"])
-    rc_ends = _align_and_extract(adaptor2, front, *args, sub2["starts"], sub2["ends"])
+    if isinstance(reads, (str, os.PathLike)):
+        from .resident import DeviceReads
+        filepath = os.fspath(reads)
+        dev = DeviceReads.from_fastq(filepath)
+        dfront, dback = dev.front_and_back(tolerance)
+        hfront, hback = dfront.download()[0], dback.download()[0]   # only the windows, for the sub-sequences
+        cur_starts = _align_and_extract_resident(adaptor1, dfront, hfront, *args, sub1["starts"], sub1["ends"])
+        cur_ends = _align_and_extract_resident(adaptor2, dback, hback, *args, sub2["starts"], sub2["ends"])
+        rc_starts = _align_and_extract_resident(adaptor1, dback, hback, *args, sub1["starts"], sub1["ends"])
+        rc_ends = _align_and_extract_resident(adaptor2, dfront, hfront, *args, sub2["starts"], sub2["ends"])
+        reads = Reads.__new__(Reads)
+        reads.seq = StringSet(np.zeros(1, np.uint8), dev.off_host.copy())   # widths only; bases stay on the device
+        reads.qual, reads.names, reads.encoding = None, dev.names, dev.encoding
+    else:
+        front, back = _get_front_and_back(reads, tolerance)
+        cur_starts = _align_and_extract(adaptor1, front, *args, sub1["starts"], sub1["ends"])
+        cur_ends = _align_and_extract(adaptor2, back, *args, sub2["starts"], sub2["ends"])
+        rc_starts = _align_and_extract(adaptor1, back, *args, sub1["starts"], sub1["ends"])
+        rc_ends = _align_and_extract(adaptor2, front, *args, sub2["starts"], sub2["ends"])
     rev, _ = _resolve_strand(cur_starts["score"], cur_ends["score"], rc_starts["score"], rc_ends["score"])
     _swap_rows(cur_starts, rc_starts, rev)
     _swap_rows(cur_ends, rc_ends, rev)

@@ -44,6 +44,7 @@ class DeviceReads:
 
     def __init__(self, seq, qual, off_dev, off_host, encoding):
         self.seq, self.qual, self.off, self.off_host, self.encoding = seq, qual, off_dev, off_host, encoding
+        self.names = None
 
     @classmethod
     def upload(cls, reads):
@@ -53,6 +54,29 @@ class DeviceReads:
             raise _lib.SarlaccError("sequence and quality strings should have the same length")
         return cls(DevBuffer.from_numpy(s.chars), DevBuffer.from_numpy(q.chars), DevBuffer.from_numpy(s.off), s.off.copy(),
                    reads.encoding)
+
+    @classmethod
+    def from_fastq(cls, source, encoding=None):
+        """FASTQ text (path, bytes or uint8 array) -> resident batch, parsed on the device
+        (sarlacc_dev_fastq_index / _extract; replaces FastqStreamer + .FASTQ2QSDS,
+        R/adaptorAlign.R:26-37,:104-110).  Read names are kept on the host in `.names`."""
+        if isinstance(source, (bytes, bytearray)):
+            text = np.frombuffer(bytes(source), dtype=np.uint8)
+        elif isinstance(source, np.ndarray):
+            text = np.ascontiguousarray(source, dtype=np.uint8)
+        else:
+            text = np.fromfile(source, dtype=np.uint8)
+        d_text = DevBuffer.from_numpy(text if text.size else np.zeros(1, np.uint8))
+        nrec, tb, tn = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(_lib.lib().sarlacc_dev_fastq_index(d_text.ptr, C.c_int64(text.size), C.byref(nrec), C.byref(tb), C.byref(tn), None))
+        n = nrec.value
+        seq, qual = DevBuffer(max(tb.value, 1)), DevBuffer(max(tb.value, 1))
+        off, names, noff = DevBuffer(8 * (n + 1)), DevBuffer(max(tn.value, 1)), DevBuffer(8 * (n + 1))
+        check(_lib.lib().sarlacc_dev_fastq_extract(d_text.ptr, seq.ptr, qual.ptr, off.ptr, names.ptr, noff.ptr, None))
+        out = cls(seq, qual, off, off.to_numpy(np.int64, n + 1), encoding)
+        nraw, no = names.to_numpy(np.uint8, tn.value).tobytes(), noff.to_numpy(np.int64, n + 1)
+        out.names = [nraw[no[i]:no[i + 1]].decode() for i in range(n)]
+        return out
 
     def __len__(self):
         return len(self.off_host) - 1
@@ -92,6 +116,29 @@ class DeviceReads:
         check(_lib.lib().sarlacc_dev_scramble(self.seq.ptr, self.qual.ptr, self.off.ptr, C.c_int64(len(self)),
                                               C.c_uint64(int(seed)), d.seq.ptr, d.qual.ptr, None))
         return d
+
+    def align_map(self, adaptor, gap_opening, gap_extension, sec_starts=(), sec_ends=()):
+        """adaptor_align (src/adaptor_align.cpp:11-77) on the resident batch: (scores, starts, ends,
+        [section starts], [section widths]) as numpy arrays, same conventions as calls.adaptor_align."""
+        n = len(self)
+        ss = np.ascontiguousarray(sec_starts, dtype=np.int32).reshape(-1)
+        se = np.ascontiguousarray(sec_ends, dtype=np.int32).reshape(-1)
+        ns = ss.size
+        if n == 0:
+            return np.zeros(0), np.zeros(0, np.int32), np.zeros(0, np.int32), [np.zeros(0, np.int32)] * ns, [np.zeros(0, np.int32)] * ns
+        enc = as_encoding(self.encoding if self.encoding is not None else phred_encoding())
+        rf = adaptor.encode() if isinstance(adaptor, str) else bytes(adaptor)
+        scores, starts, ends = DevBuffer(8 * n), DevBuffer(4 * n), DevBuffer(4 * n)
+        so, sw = DevBuffer(4 * n * max(ns, 1)), DevBuffer(4 * n * max(ns, 1))
+        pad = np.zeros(1, np.int32)
+        check(_lib.lib().sarlacc_dev_align(
+            self.seq.ptr, self.qual.ptr, self.off.ptr, C.c_int64(n), C.c_int32(self.max_len),
+            ptr(enc.errors), enc.names, len(enc), C.c_double(gap_opening), C.c_double(gap_extension),
+            rf, len(rf), 0, ptr(ss if ns else pad), ptr(se if ns else pad), ns,
+            scores.ptr, starts.ptr, ends.ptr, so.ptr, sw.ptr, None))
+        so_h, sw_h = so.to_numpy(np.int32, n * ns), sw.to_numpy(np.int32, n * ns)
+        return (scores.to_numpy(np.float64, n), starts.to_numpy(np.int32, n), ends.to_numpy(np.int32, n),
+                [so_h[k * n:(k + 1) * n] for k in range(ns)], [sw_h[k * n:(k + 1) * n] for k in range(ns)])
 
     def align_scores(self, adaptor, gap_opening, gap_extension, local=True):
         """adaptor_align_score_only / barcode_align on the resident batch."""

@@ -1,0 +1,91 @@
+"""Device FASTQ ingest: the parser on the GPU against the host reader, and
+adaptorAlign on a FASTQ path (text parsed, windowed and aligned on the device) against
+adaptorAlign on host Reads.  Byte work: everything must be identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+A1 = "ACGATCAGC" + "N" * 12 + "GTCAGTCAG"
+A2 = "CACACTGAGCAGCGACTAGACA"
+
+
+def fastq_text(rng, n, lo, hi, eol="\n", lower=False, final_eol=True):
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        s = "".join(rng.choice(list("ACGTN"), L, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+        if lower and i % 3 == 0:
+            s = s.lower()
+        q = "".join(chr(int(c)) for c in rng.integers(33, 127, L))
+        recs.append("@read_%d some description/%d%s%s%s+%s%s" % (i + 1, i, eol, s, eol, eol, q))
+    text = eol.join(recs)
+    return (text + (eol if final_eol else "")).encode()
+
+
+@pytest.mark.parametrize("eol,lower,final_eol,extra", [("\n", False, True, b""), ("\r\n", True, True, b""),
+                                                      ("\n", True, False, b""), ("\n", False, True, b"\n\n\r\n")])
+def test_device_parser_matches_host_reader(tmp_path, eol, lower, final_eol, extra):
+    from sarlacc_amd.generics import read_fastq
+    from sarlacc_amd.resident import DeviceReads
+    rng = np.random.default_rng(len(eol) * 10 + lower + 2 * final_eol + len(extra))
+    # lengths straddle the 8-KB tile and 32-byte thread granules of the line passes; includes empty reads
+    text = fastq_text(rng, 300, 0, 700, eol, lower, final_eol) + extra
+    path = tmp_path / "r.fastq"
+    path.write_bytes(text)
+    host = read_fastq(str(path))
+    dev = DeviceReads.from_fastq(str(path))
+    assert len(dev) == len(host) == 300
+    seq, qual = dev.download()
+    assert seq.to_strings() == host.seq.to_strings()
+    assert qual.to_strings() == host.qual.to_strings()
+    assert dev.names == host.names
+    # same through bytes / arrays
+    d2 = DeviceReads.from_fastq(text)
+    assert d2.download()[0].to_strings() == host.seq.to_strings()
+
+
+def test_device_parser_long_reads_and_empty_input():
+    from sarlacc_amd.resident import DeviceReads
+    rng = np.random.default_rng(5)
+    text = fastq_text(rng, 40, 5000, 30000)
+    dev = DeviceReads.from_fastq(text)
+    lines = text.decode().split("\n")
+    assert dev.download()[0].to_strings() == lines[1::4][:40]
+    assert dev.download()[1].to_strings() == lines[3::4][:40]
+    for empty in (b"", b"\n", b"\r\n\n"):
+        d = DeviceReads.from_fastq(empty)
+        assert len(d) == 0 and d.names == []
+
+
+@pytest.mark.parametrize("text,msg", [
+    (b"@a\nACGT\n+\nIIII\nb\nAC\n+\nII\n", "record 2 does not start with '@'"),
+    (b"@a\nACGT\n-\nIIII\n", "record 1 has no '+' line"),
+    (b"@a\nACGT\n+\nIII\n", "record 1: sequence and quality lengths differ"),
+    (b"@a\nACGT\n+\nIIII\n@b\nAC\n", "ends inside a record"),
+])
+def test_device_parser_errors(text, msg):
+    from sarlacc_amd._lib import SarlaccError
+    from sarlacc_amd.resident import DeviceReads
+    import re
+    with pytest.raises(SarlaccError, match=re.escape(msg)):
+        DeviceReads.from_fastq(text)
+
+
+def test_adaptor_align_from_fastq_path(tmp_path):
+    """adaptorAlign(filepath) as in the reference (R/adaptorAlign.R:7-37): identical to the
+    host-Reads route in every column."""
+    from sarlacc_amd import generics as G
+    from sarlacc_amd.mock import mock_reads
+    sim = mock_reads(A1, A2, nmolecules=20, nreads=6, seqlen=400, seed=1000)
+    reads = G.Reads(sim["reads"], sim["quals"], ["READ_%d" % (i + 1) for i in range(len(sim["reads"]))])
+    path = tmp_path / "mock.fastq"
+    G.write_fastq(str(path), reads)
+    a = G.adaptorAlign(A1, A2, reads, tolerance=120)
+    b = G.adaptorAlign(A1, A2, str(path), tolerance=120)
+    assert b["metadata"]["filepath"] == str(path) and b["names"] == a["names"]
+    assert np.array_equal(a["read.width"], b["read.width"]) and np.array_equal(a["reversed"], b["reversed"])
+    for key in ("adaptor1", "adaptor2"):
+        assert np.array_equal(a[key]["score"].view(np.int64), b[key]["score"].view(np.int64))
+        assert np.array_equal(a[key]["start"], b[key]["start"]) and np.array_equal(a[key]["end"], b[key]["end"])
+        assert a[key]["subseq"] == b[key]["subseq"]
