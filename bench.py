@@ -79,14 +79,12 @@ def pipeline_sample(groups=4000, read_len=2000, copies=10):
         t0 = time.perf_counter()
         coff, cmem = calls.umi_group_flat(umis, 1, None, 1, np.array([0, n], np.int64), np.arange(1, n + 1, dtype=np.int32))
         goff, gflat = calls.csr_select(coff, cmem, np.diff(coff) >= 2)
-        qsub = quals.subset(gflat.astype(np.int64) - 1)
-        rows, grp_rows, _ = calls.quick_msa_flat(goff, gflat, reads, 0, -1, -5, -1, 100)
-        cons, _ = calls.create_consensus_flat(rows, grp_rows, 0.6, quals=qsub, encoding=enc)
+        cons, _ = calls.msa_consensus_flat(goff, gflat, reads, 0, -1, -5, -1, 100, 0.6, quals=quals, encoding=enc)
         dt = time.perf_counter() - t0   # everything between the UMI strings and the consensus strings
         best = dt if best is None else min(best, dt)
     return {"reads_per_min": n / best * 60.0, "reads": n, "consensus_reads": len(cons),
-            "workload": "%d molecules x %d reads x %d bp, 12-bp UMIs: umi_group(threshold 1) -> quick_msa(bandwidth 100) "
-                        "-> create_consensus_quality_loop, host-pointer C ABI incl. PCIe and the host glue between the calls" % (groups, copies, read_len)}
+            "workload": "%d molecules x %d reads x %d bp, 12-bp UMIs: umi_group(threshold 1) -> msa_consensus (quick_msa bandwidth 100 + quality consensus, rows stay in HBM), "
+                        "host-pointer C ABI incl. PCIe and the host glue between the calls" % (groups, copies, read_len)}
 
 
 def main():

@@ -241,6 +241,22 @@ int sarlacc_create_consensus_quality_loop(const char* aln, const int64_t* aln_of
                                           const double* enc_errors, const char* enc_names, int enc_n,
                                           char* cons, char* phred, int64_t* cons_off, double* lerr);
 
+/* multiReadAlign + consensusReadSeq in one call (R/multiReadAlign.R:16-47 followed by
+ * R/consensusReadSeq.R:14-21; i.e. .Call quick_msa then .Call create_consensus_*_loop): the
+ * gapped rows never leave HBM and the quality strings stay in read order (rows find theirs
+ * through the group lists), so nothing is re-marshalled between the two stages.  Results are
+ * those of sarlacc_quick_msa + sarlacc_create_consensus_{quality,basic}_loop on the same input.
+ * qual == NULL selects the basic vote (pseudo_count used), otherwise the quality-weighted vote.
+ * cons/phred need sum over groups of the alignment width (reported in the error message when
+ * cons_cap is too small; 1.5 x the longest member per group is a safe first guess). */
+int sarlacc_msa_consensus(const int64_t* grp_off, const int32_t* grp, int64_t ngroups,
+                          const char* seq, const int64_t* seq_off,
+                          const char* qual, const int64_t* qual_off, int64_t nseq,
+                          double match, double mismatch, double gap_extension, double gap_opening,
+                          int bandwidth, double min_cov, double pseudo_count,
+                          const double* enc_errors, const char* enc_names, int enc_n,
+                          char* cons, char* phred, int64_t* cons_off, int64_t cons_cap);
+
 #ifdef __cplusplus
 }
 #endif

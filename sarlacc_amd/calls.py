@@ -406,6 +406,50 @@ def create_consensus_flat(rows, grp_rows, min_cov, pseudo_count=1.0, quals=None,
     return StringSet(cons, coff.copy()), StringSet(phred, coff.copy())
 
 
+def msa_consensus_flat(grp_off, grp, seqs, match, mismatch, gapExtension, gapOpening, bandwidth, min_cov,
+                       pseudo_count=1.0, quals=None, encoding=None):
+    """quick_msa_flat followed by create_consensus_flat in one native call (sarlacc_msa_consensus):
+    the gapped rows stay in HBM and `quals` are the quality strings of ALL reads, in read order.
+    Returns (consensus StringSet, phred StringSet), one entry per group."""
+    import re
+    s = StringSet.from_strings(seqs)
+    goff = np.ascontiguousarray(grp_off, dtype=np.int64)
+    gvals = np.ascontiguousarray(grp, dtype=np.int32)
+    if gvals.size == 0:
+        gvals = np.zeros(1, np.int32)
+    ng = goff.size - 1
+    q = enc = None
+    if quals is not None:
+        q = StringSet.from_strings(quals)
+        if len(q) != len(s):
+            raise SarlaccError("sequence and quality vectors should have the same length")
+        enc = as_encoding(encoding)
+    coff = np.zeros(ng + 1, np.int64)
+    w = s.widths()
+    sizes = np.diff(goff)
+    longest = np.maximum.reduceat(w[gvals[:int(goff[-1])].astype(np.int64) - 1], goff[:-1][sizes > 0]) if goff[-1] else np.zeros(0)
+    cap = int(1.5 * longest.sum()) + 1024
+    for attempt in range(2):
+        cons = np.zeros(cap, np.uint8)
+        phred = np.zeros(cap, np.uint8)
+        try:
+            check(_lib.lib().sarlacc_msa_consensus(
+                ptr(goff), ptr(gvals), C.c_int64(ng), ptr(s.chars), ptr(s.off),
+                ptr(q.chars) if q is not None else None, ptr(q.off) if q is not None else None, C.c_int64(len(s)),
+                C.c_double(match), C.c_double(mismatch), C.c_double(gapExtension), C.c_double(gapOpening), int(bandwidth),
+                C.c_double(min_cov), C.c_double(pseudo_count), ptr(enc.errors) if enc is not None else None,
+                enc.names if enc is not None else None, len(enc) if enc is not None else 0,
+                ptr(cons), ptr(phred), ptr(coff), C.c_int64(cap)))
+            break
+        except SarlaccError as e:
+            m = re.search(r"buffer too small \((\d+) needed\)", str(e))
+            if attempt == 0 and m:
+                cap = int(m.group(1)) + 16
+                continue
+            raise
+    return StringSet(cons, coff.copy()), StringSet(phred, coff.copy())
+
+
 def umi_pairs_shard(umi, limit, shard_index, shard_count):
     """sarlacc_umi_pairs_shard: neighbour pairs (rank_i << 32 | rank_j) found in this shard's row
     tiles of the all-pairs matrix of one pre-group (ranks = positions in the trie order)."""

@@ -74,6 +74,17 @@ int scratch(const char* name, size_t count, T** dev) {
     return 0;
 }
 
+// ---- MSA stage with the rows left on the device (msa.hip) ---------------------
+struct MsaResult {
+    std::vector<int32_t> width;     // per group (caller sizes it: ngroups)
+    std::vector<int64_t> out_off;   // per group start of its rows in d_out (caller sizes it: ngroups + 1)
+    uint8_t* d_out = nullptr;       // gapped rows, group after group, equal width inside a group
+    int32_t* d_members = nullptr;   // flattened 1-based read ids, one per row
+};
+int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq, const int64_t* seq_off,
+            int64_t nseq, double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
+            bool want_rows, int64_t out_cap, MsaResult* res);
+
 // ---- quality encoding (reference src/quality_encoding.cpp:5-33) -------------
 int check_encoding(const double* errors, const char* names, int n);
 

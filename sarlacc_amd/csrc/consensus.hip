@@ -34,7 +34,8 @@ struct ConsArgs {
     const int64_t* grp_rows;   // [ngroups+1]
     long long ngroups;
     const uint8_t* qual;       // quality mode only
-    const int64_t* qual_off;   // per row (same row numbering as aln)
+    const int64_t* qual_off;   // per row (same row numbering as aln), or per read when row_read is set
+    const int32_t* row_read;   // optional: 1-based read id of every row (qualities stay in read order)
     const double* right;       // [navail] log1p(-e)
     const double* wrong;       // [navail] log(e/3)
     int qoffset, navail, max_rows;
@@ -94,8 +95,9 @@ __global__ void __launch_bounds__(64) k_consensus(const ConsArgs A) {
             s_bad[r] = 0;
             s_roff[r] = A.aln_off[row0 + r];
             if (QUALITY) {
-                s_qoff[r] = A.qual_off[row0 + r];
-                s_qlen[r] = static_cast<int>(A.qual_off[row0 + r + 1] - A.qual_off[row0 + r]);
+                const long long q = A.row_read ? A.row_read[row0 + r] - 1 : row0 + r;
+                s_qoff[r] = A.qual_off[q];
+                s_qlen[r] = static_cast<int>(A.qual_off[q + 1] - A.qual_off[q]);
             }
         }
         __syncthreads();
@@ -257,66 +259,19 @@ static char phred_char(double le) {
     return static_cast<char>(static_cast<int>(q) + 33);
 }
 
-static int run_consensus(bool quality, const char* aln, const int64_t* aln_off, const int64_t* grp_rows,
-                         int64_t ngroups, const char* qual, const int64_t* qual_off, const int64_t* qgrp_rows,
-                         double min_cov, double pseudo, const double* enc_errors, const char* enc_names, int enc_n,
-                         char* cons, char* phred, int64_t* cons_off, double* lerr) {
-    if (ngroups < 0) return fail("sarlacc_amd: negative number of alignments");
-    if (quality) SL_TRY(check_encoding(enc_errors, enc_names, enc_n));
-    cons_off[0] = 0;
-    if (ngroups == 0) return 0;
-    const int64_t nrows_total = grp_rows[ngroups];
-
-    // host-side structural checks, in the reference's order (group by group):
-    // equal row widths (src/DNA_input.cpp:90-104), then matching entry counts (:186-190)
-    int64_t struct_err_group = -1;
-    int struct_err_kind = 0;
-    int max_rows = 1;
-    for (int64_t g = 0; g < ngroups && struct_err_group < 0; ++g) {
-        const int64_t r0 = grp_rows[g], r1 = grp_rows[g + 1];
-        max_rows = static_cast<int>(std::max<int64_t>(max_rows, r1 - r0));
-        for (int64_t r = r0 + 1; r < r1; ++r)
-            if (aln_off[r + 1] - aln_off[r] != aln_off[r0 + 1] - aln_off[r0]) { struct_err_group = g; struct_err_kind = 1; break; }
-        if (struct_err_group < 0 && quality && (qgrp_rows[g + 1] - qgrp_rows[g]) != (r1 - r0)) {
-            struct_err_group = g;
-            struct_err_kind = 2;
-        }
-    }
-    // Only groups before the first structural error are evaluated on the device.
-    const int64_t ng_eval = struct_err_group >= 0 ? struct_err_group : ngroups;
-    const int64_t rows_eval = grp_rows[ng_eval];
-    if (quality)
-        for (int64_t g = 0; g < ng_eval; ++g)
-            if (qgrp_rows[g] != grp_rows[g]) return fail("sarlacc_amd: alignment and quality row numbering differ");
-
-    SL_TRY(ensure_device());
-    hipStream_t s = nullptr;
+// Device part of the consensus: `a` arrives with the alignment rows, their offsets, the group
+// table, the output offsets and (quality mode) the quality strings already in HBM; this adds
+// the tables and scratch, launches the vote and resolves results and errors on the host.
+// aln_host (optional) is the host copy of the rows, used only to quote an unknown character.
+static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_eval, int64_t rows_eval, int64_t total,
+                          const std::vector<int64_t>& out_off, const char* aln_host, int struct_err_kind,
+                          double min_cov, double pseudo, const double* enc_errors, const char* enc_names, int enc_n,
+                          char* cons, char* phred, int64_t* cons_off, double* lerr, hipStream_t s) {
     Context& c = ctx();
-    const int64_t total = aln_off[nrows_total] - aln_off[0];
-    const int64_t base = aln_off[0];
-
-    std::vector<int64_t> rel(static_cast<size_t>(nrows_total) + 1), out_off(static_cast<size_t>(std::max<int64_t>(ngroups, 1)));
-    for (int64_t r = 0; r <= nrows_total; ++r) rel[r] = aln_off[r] - base;
-    for (int64_t g = 0; g < ngroups; ++g) out_off[g] = rel[grp_rows[g]];
-
-    ConsArgs a{};
-    uint8_t* d_aln; int64_t* d_aoff; int64_t* d_grows; int64_t* d_ooff;
-    SL_TRY(upload("cons.aln", reinterpret_cast<const uint8_t*>(aln) + base, static_cast<size_t>(total), &d_aln, s));
-    SL_TRY(upload("cons.aoff", rel.data(), rel.size(), &d_aoff, s));
-    SL_TRY(upload("cons.grows", grp_rows, static_cast<size_t>(ngroups) + 1, &d_grows, s));
-    SL_TRY(upload("cons.ooff", out_off.data(), out_off.size(), &d_ooff, s));
-    a.aln = d_aln; a.aln_off = d_aoff; a.grp_rows = d_grows; a.ngroups = ng_eval; a.out_off = d_ooff;
-
+    int64_t* d_ooff = const_cast<int64_t*>(a.out_off);
     std::vector<double> right, wrong;
     if (quality) {
-        const int64_t qrows = qgrp_rows[ng_eval];
-        const int64_t qbase = qual_off[0];
-        const int64_t qtotal = qual_off[qrows] - qbase;
-        std::vector<int64_t> qrel(static_cast<size_t>(qrows) + 1);
-        for (int64_t r = 0; r <= qrows; ++r) qrel[r] = qual_off[r] - qbase;
-        uint8_t* d_q; int64_t* d_qoff; double* d_r; double* d_w;
-        SL_TRY(upload("cons.qual", reinterpret_cast<const uint8_t*>(qual) + qbase, static_cast<size_t>(qtotal), &d_q, s));
-        SL_TRY(upload("cons.qoff", qrel.data(), qrel.size(), &d_qoff, s));
+        double* d_r; double* d_w;
         right.resize(enc_n);
         wrong.resize(enc_n);
         for (int k = 0; k < enc_n; ++k) {  // (src/create_consensus.cpp:14,:218-226)
@@ -328,10 +283,12 @@ static int run_consensus(bool quality, const char* aln, const int64_t* aln_off, 
         }
         SL_TRY(upload("cons.right", right.data(), right.size(), &d_r, s));
         SL_TRY(upload("cons.wrong", wrong.data(), wrong.size(), &d_w, s));
-        a.qual = d_q; a.qual_off = d_qoff; a.right = d_r; a.wrong = d_w;
+        a.right = d_r; a.wrong = d_w;
         a.qoffset = static_cast<int>(enc_names[0]); a.navail = enc_n;
     }
-    a.mincov = min_cov; a.pseudo = pseudo; a.ln10 = std::log(10); a.max_rows = max_rows;
+    a.ngroups = ng_eval;
+    a.mincov = min_cov; a.pseudo = pseudo; a.ln10 = std::log(10);
+    const int max_rows = a.max_rows;
 
     uint8_t* d_cons; uint8_t* d_phred; double* d_lerr = nullptr; int32_t* d_len; int8_t* d_status;
     unsigned long long* d_badchar; int* d_fixn; long long* d_fixpos; double* d_fixval;
@@ -376,8 +333,11 @@ static int run_consensus(bool quality, const char* aln, const int64_t* aln_off, 
     }
     // earliest error in the reference's processing order
     if (!quality && badchar != ~0ull) {
+        char bc = '?';
+        if (aln_host) bc = aln_host[static_cast<int64_t>(badchar)];
+        else SL_HIP(hipMemcpy(&bc, a.aln + badchar, 1, hipMemcpyDeviceToHost));
         char msg[96];
-        snprintf(msg, sizeof msg, "unknown character '%c' in alignment string", aln[base + static_cast<int64_t>(badchar)]);
+        snprintf(msg, sizeof msg, "unknown character '%c' in alignment string", bc);
         return fail("%s", msg);
     }
     if (quality)
@@ -444,6 +404,69 @@ static int run_consensus(bool quality, const char* aln, const int64_t* aln_off, 
     return 0;
 }
 
+static int run_consensus(bool quality, const char* aln, const int64_t* aln_off, const int64_t* grp_rows,
+                         int64_t ngroups, const char* qual, const int64_t* qual_off, const int64_t* qgrp_rows,
+                         double min_cov, double pseudo, const double* enc_errors, const char* enc_names, int enc_n,
+                         char* cons, char* phred, int64_t* cons_off, double* lerr) {
+    if (ngroups < 0) return fail("sarlacc_amd: negative number of alignments");
+    if (quality) SL_TRY(check_encoding(enc_errors, enc_names, enc_n));
+    cons_off[0] = 0;
+    if (ngroups == 0) return 0;
+    const int64_t nrows_total = grp_rows[ngroups];
+
+    // host-side structural checks, in the reference's order (group by group):
+    // equal row widths (src/DNA_input.cpp:90-104), then matching entry counts (:186-190)
+    int64_t struct_err_group = -1;
+    int struct_err_kind = 0;
+    int max_rows = 1;
+    for (int64_t g = 0; g < ngroups && struct_err_group < 0; ++g) {
+        const int64_t r0 = grp_rows[g], r1 = grp_rows[g + 1];
+        max_rows = static_cast<int>(std::max<int64_t>(max_rows, r1 - r0));
+        for (int64_t r = r0 + 1; r < r1; ++r)
+            if (aln_off[r + 1] - aln_off[r] != aln_off[r0 + 1] - aln_off[r0]) { struct_err_group = g; struct_err_kind = 1; break; }
+        if (struct_err_group < 0 && quality && (qgrp_rows[g + 1] - qgrp_rows[g]) != (r1 - r0)) {
+            struct_err_group = g;
+            struct_err_kind = 2;
+        }
+    }
+    // Only groups before the first structural error are evaluated on the device.
+    const int64_t ng_eval = struct_err_group >= 0 ? struct_err_group : ngroups;
+    const int64_t rows_eval = grp_rows[ng_eval];
+    if (quality)
+        for (int64_t g = 0; g < ng_eval; ++g)
+            if (qgrp_rows[g] != grp_rows[g]) return fail("sarlacc_amd: alignment and quality row numbering differ");
+
+    SL_TRY(ensure_device());
+    hipStream_t s = nullptr;
+    const int64_t total = aln_off[nrows_total] - aln_off[0];
+    const int64_t base = aln_off[0];
+
+    std::vector<int64_t> rel(static_cast<size_t>(nrows_total) + 1), out_off(static_cast<size_t>(std::max<int64_t>(ngroups, 1)));
+    for (int64_t r = 0; r <= nrows_total; ++r) rel[r] = aln_off[r] - base;
+    for (int64_t g = 0; g < ngroups; ++g) out_off[g] = rel[grp_rows[g]];
+
+    ConsArgs a{};
+    uint8_t* d_aln; int64_t* d_aoff; int64_t* d_grows; int64_t* d_ooff;
+    SL_TRY(upload("cons.aln", reinterpret_cast<const uint8_t*>(aln) + base, static_cast<size_t>(total), &d_aln, s));
+    SL_TRY(upload("cons.aoff", rel.data(), rel.size(), &d_aoff, s));
+    SL_TRY(upload("cons.grows", grp_rows, static_cast<size_t>(ngroups) + 1, &d_grows, s));
+    SL_TRY(upload("cons.ooff", out_off.data(), out_off.size(), &d_ooff, s));
+    a.aln = d_aln; a.aln_off = d_aoff; a.grp_rows = d_grows; a.out_off = d_ooff; a.max_rows = max_rows;
+    if (quality) {
+        const int64_t qrows = qgrp_rows[ng_eval];
+        const int64_t qbase = qual_off[0];
+        const int64_t qtotal = qual_off[qrows] - qbase;
+        std::vector<int64_t> qrel(static_cast<size_t>(qrows) + 1);
+        for (int64_t r = 0; r <= qrows; ++r) qrel[r] = qual_off[r] - qbase;
+        uint8_t* d_q; int64_t* d_qoff;
+        SL_TRY(upload("cons.qual", reinterpret_cast<const uint8_t*>(qual) + qbase, static_cast<size_t>(qtotal), &d_q, s));
+        SL_TRY(upload("cons.qoff", qrel.data(), qrel.size(), &d_qoff, s));
+        a.qual = d_q; a.qual_off = d_qoff;
+    }
+    return consensus_core(quality, a, ngroups, ng_eval, rows_eval, total, out_off, aln + base, struct_err_kind, min_cov, pseudo,
+                          enc_errors, enc_names, enc_n, cons, phred, cons_off, lerr, s);
+}
+
 }  // namespace sarlacc
 
 using namespace sarlacc;
@@ -455,6 +478,64 @@ int sarlacc_create_consensus_basic_loop(const char* aln, const int64_t* aln_off,
                                         char* phred, int64_t* cons_off, double* lerr) {
     return run_consensus(false, aln, aln_off, grp_rows, ngroups, nullptr, nullptr, nullptr, min_cov, pseudo_count,
                          nullptr, nullptr, 0, cons, phred, cons_off, lerr);
+}
+
+int sarlacc_msa_consensus(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq,
+                          const int64_t* seq_off, const char* qual, const int64_t* qual_off, int64_t nseq, double match,
+                          double mismatch, double gap_extension, double gap_opening, int bandwidth, double min_cov,
+                          double pseudo_count, const double* enc_errors, const char* enc_names, int enc_n, char* cons,
+                          char* phred, int64_t* cons_off, int64_t cons_cap) {
+    if (ngroups < 0 || nseq < 0) return fail("sarlacc_amd: negative sizes");
+    const bool quality = qual != nullptr;
+    if (quality) SL_TRY(check_encoding(enc_errors, enc_names, enc_n));
+    cons_off[0] = 0;
+    if (ngroups == 0) return 0;
+    MsaResult res;
+    res.width.assign(static_cast<size_t>(ngroups), 0);
+    res.out_off.assign(static_cast<size_t>(ngroups) + 1, 0);
+    SL_TRY(msa_run(grp_off, grp, ngroups, seq, seq_off, nseq, match, mismatch, gap_extension, gap_opening, bandwidth, true, -1, &res));
+    const int64_t total = res.out_off[ngroups];
+    int64_t need = 0;
+    for (int64_t g = 0; g < ngroups; ++g) need += res.width[g];
+    if (cons_cap < need) return fail("sarlacc_amd: consensus output buffer too small (%lld needed)", static_cast<long long>(need));
+    if (total == 0) {
+        for (int64_t g = 0; g < ngroups; ++g) cons_off[g + 1] = 0;
+        return 0;
+    }
+    hipStream_t s = nullptr;
+    // row table of the alignments the MSA stage left in HBM
+    const int64_t nrows = grp_off[ngroups] - grp_off[0];
+    std::vector<int64_t> rel(static_cast<size_t>(nrows) + 1), grows(static_cast<size_t>(ngroups) + 1);
+    std::vector<int64_t> out_off(static_cast<size_t>(ngroups));
+    int max_rows = 1;
+    int64_t row = 0;
+    for (int64_t g = 0; g < ngroups; ++g) {
+        const int64_t m = grp_off[g + 1] - grp_off[g];
+        grows[g] = row;
+        out_off[g] = res.out_off[g];
+        max_rows = static_cast<int>(std::max<int64_t>(max_rows, m));
+        for (int64_t r = 0; r < m; ++r) rel[row++] = res.out_off[g] + r * res.width[g];
+    }
+    grows[ngroups] = row;
+    rel[nrows] = total;
+    ConsArgs a{};
+    int64_t* d_aoff; int64_t* d_grows; int64_t* d_ooff;
+    SL_TRY(upload("cons.aoff", rel.data(), rel.size(), &d_aoff, s));
+    SL_TRY(upload("cons.grows", grows.data(), grows.size(), &d_grows, s));
+    SL_TRY(upload("cons.ooff", out_off.data(), out_off.size(), &d_ooff, s));
+    a.aln = res.d_out; a.aln_off = d_aoff; a.grp_rows = d_grows; a.out_off = d_ooff; a.max_rows = max_rows;
+    if (quality) {
+        // qualities stay in read order; every row finds its string through the member list
+        const int64_t qbase = qual_off[0];
+        std::vector<int64_t> qrel(static_cast<size_t>(nseq) + 1);
+        for (int64_t r = 0; r <= nseq; ++r) qrel[r] = qual_off[r] - qbase;
+        uint8_t* d_q; int64_t* d_qoff;
+        SL_TRY(upload("cons.qual", reinterpret_cast<const uint8_t*>(qual) + qbase, static_cast<size_t>(qrel[nseq]), &d_q, s));
+        SL_TRY(upload("cons.qoff", qrel.data(), qrel.size(), &d_qoff, s));
+        a.qual = d_q; a.qual_off = d_qoff; a.row_read = res.d_members;
+    }
+    return consensus_core(quality, a, ngroups, ngroups, nrows, total, out_off, nullptr, 0, min_cov, pseudo_count, enc_errors,
+                          enc_names, enc_n, cons, phred, cons_off, nullptr, s);
 }
 
 int sarlacc_create_consensus_quality_loop(const char* aln, const int64_t* aln_off, const int64_t* grp_rows,

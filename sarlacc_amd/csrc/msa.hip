@@ -374,17 +374,18 @@ static int launch_pairwise(const MsaArgs& a, int grid, size_t lds, hipStream_t s
     return 0;
 }
 
-}  // namespace sarlacc
-
-using namespace sarlacc;
-
-extern "C" int sarlacc_quick_msa(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq,
-                                 const int64_t* seq_off, int64_t nseq, double match, double mismatch,
-                                 double gap_extension, double gap_opening, int bandwidth, int32_t* width_out,
-                                 int64_t* out_off, char* out, int64_t out_cap) {
-    if (ngroups < 0 || nseq < 0) return fail("sarlacc_amd: negative sizes");
+// The whole MSA stage with the gapped rows left in HBM (res->d_out): shared by sarlacc_quick_msa,
+// which copies them back, and sarlacc_msa_consensus, which votes on them where they are.
+// out_cap: < 0 no limit; otherwise the rows are only written when they fit (sizing protocol of
+// sarlacc_quick_msa: widths and offsets are always filled in).
+int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq, const int64_t* seq_off,
+            int64_t nseq, double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
+            bool want_rows, int64_t out_cap, MsaResult* res) {
+    int32_t* width_out = res->width.data();
+    int64_t* out_off = res->out_off.data();
+    res->d_out = nullptr;
+    res->d_members = nullptr;
     out_off[0] = 0;
-    if (ngroups == 0) return 0;
     if (bandwidth < 0) return fail("sarlacc_amd: negative bandwidth");
     const int64_t nmemb = grp_off[ngroups] - grp_off[0];
     for (int64_t i = 0; i < nmemb; ++i) {
@@ -497,8 +498,9 @@ extern "C" int sarlacc_quick_msa(const int64_t* grp_off, const int32_t* grp, int
         ooff[g + 1] = ooff[g] + static_cast<long long>(width[g]) * groups[g].nreads;
         out_off[g + 1] = ooff[g + 1];
     }
-    if (!out) return 0;  // sizing call
-    if (out_cap < ooff[ngroups]) return fail("sarlacc_amd: MSA output buffer too small (%lld needed)", ooff[ngroups]);
+    res->d_members = d_mem;
+    if (!want_rows) return 0;  // sizing call
+    if (out_cap >= 0 && out_cap < ooff[ngroups]) return fail("sarlacc_amd: MSA output buffer too small (%lld needed)", ooff[ngroups]);
     if (ooff[ngroups] == 0) return 0;
     long long* d_ooff; long long* d_rg; int* d_rp; uint8_t* d_out;
     SL_TRY(upload("msa.ooff", ooff.data(), ooff.size(), &d_ooff, s));
@@ -509,6 +511,29 @@ extern "C" int sarlacc_quick_msa(const int64_t* grp_off, const int32_t* grp, int
     const long long nrows = static_cast<long long>(row_group.size());
     hipLaunchKernelGGL(k_msa_write, dim3(static_cast<unsigned>(nrows)), dim3(256), 0, s, m, d_rg, d_rp, nrows);
     SL_HIP(hipGetLastError());
-    SL_HIP(hipMemcpy(out, d_out, static_cast<size_t>(ooff[ngroups]), hipMemcpyDeviceToHost));
+    res->d_out = d_out;
+    return 0;
+}
+
+}  // namespace sarlacc
+
+using namespace sarlacc;
+
+extern "C" int sarlacc_quick_msa(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq,
+                                 const int64_t* seq_off, int64_t nseq, double match, double mismatch,
+                                 double gap_extension, double gap_opening, int bandwidth, int32_t* width_out,
+                                 int64_t* out_off, char* out, int64_t out_cap) {
+    if (ngroups < 0 || nseq < 0) return fail("sarlacc_amd: negative sizes");
+    out_off[0] = 0;
+    if (ngroups == 0) return 0;
+    MsaResult res;
+    res.width.assign(static_cast<size_t>(ngroups), 0);
+    res.out_off.assign(static_cast<size_t>(ngroups) + 1, 0);
+    const int rc = msa_run(grp_off, grp, ngroups, seq, seq_off, nseq, match, mismatch, gap_extension, gap_opening, bandwidth,
+                           out != nullptr, out_cap, &res);
+    std::copy(res.width.begin(), res.width.end(), width_out);
+    std::copy(res.out_off.begin(), res.out_off.end(), out_off);
+    if (rc) return rc;
+    if (res.d_out) SL_HIP(hipMemcpy(out, res.d_out, static_cast<size_t>(out_off[ngroups]), hipMemcpyDeviceToHost));
     return 0;
 }

@@ -79,3 +79,31 @@ def test_msa_then_consensus_recovers_molecule(oracle, oenc, enc):
     cons, _ = calls.create_consensus_basic_loop(aln, 0.6, 1)
     for c, t in zip(cons, truths):
         assert lev2(c, t) / 2 <= 0.02 * len(t)
+
+
+@pytest.mark.parametrize("quality", [True, False])
+def test_fused_msa_consensus_equals_two_calls(quality):
+    """sarlacc_msa_consensus (rows stay in HBM, qualities in read order) against quick_msa_flat
+    followed by create_consensus_flat on the same groups: identical consensus and Phred strings.
+    Groups include singletons, an empty group and reads shared by no group."""
+    import sarlacc_amd
+    from sarlacc_amd import calls
+    from sarlacc_amd.strset import StringSet, csr_from_lists
+    rng = np.random.default_rng(21)
+    reads, groups, _ = sim_groups(rng, 30, 7, 350)
+    groups.insert(5, [])
+    groups.append([3])   # a read used twice (also in its own cluster)
+    quals = ["".join(chr(int(c)) for c in rng.integers(40, 90, len(r))) for r in reads]
+    goff, gvals = csr_from_lists(groups)
+    enc = sarlacc_amd.phred_encoding()
+    rows, grp_rows, _ = calls.quick_msa_flat(goff, gvals, reads, 0, -1, -5, -1, 100)
+    if quality:
+        qsub = StringSet.from_strings(quals).subset(gvals[:int(goff[-1])].astype(np.int64) - 1)
+        want = calls.create_consensus_flat(rows, grp_rows, 0.6, quals=qsub, encoding=enc)
+        got = calls.msa_consensus_flat(goff, gvals, reads, 0, -1, -5, -1, 100, 0.6, quals=quals, encoding=enc)
+    else:
+        want = calls.create_consensus_flat(rows, grp_rows, 0.6, pseudo_count=1.0)
+        got = calls.msa_consensus_flat(goff, gvals, reads, 0, -1, -5, -1, 100, 0.6, pseudo_count=1.0)
+    assert got[0].to_strings() == want[0].to_strings()
+    assert got[1].to_strings() == want[1].to_strings()
+    assert len(got[0]) == len(groups) and got[0][5] == ""

@@ -47,18 +47,13 @@ def main():
         coff, cmem = calls.umi_group_flat(umis, 1, None, 1, np.array([0, n], np.int64), np.arange(1, n + 1, dtype=np.int32))
         t1 = time.perf_counter()
         goff, gflat = calls.csr_select(coff, cmem, np.diff(coff) >= 2)   # clusters of >= 2 reads
-        qsub = quals.subset(gflat.astype(np.int64) - 1)
         t2 = time.perf_counter()
-        rows, grp_rows, width = calls.quick_msa_flat(goff, gflat, reads, 0, -1, -5, -1, 100)
-        t3 = time.perf_counter()
-        msa_ms = sarlacc_amd.last_kernel_ms()
-        cons, phred = calls.create_consensus_flat(rows, grp_rows, 0.6, quals=qsub, encoding=enc)
+        cons, phred = calls.msa_consensus_flat(goff, gflat, reads, 0, -1, -5, -1, 100, 0.6, quals=quals, encoding=enc)
         t5 = time.perf_counter()
-        cons_ms = sarlacc_amd.last_kernel_ms()
         big = [gflat[goff[k]:goff[k + 1]] for k in range(len(goff) - 1)]
-        print("rep %d: umi_group %.2fs | numpy glue %.2fs | quick_msa %.2fs (pairwise kernel %.1f ms) | consensus %.2fs (kernel %.1f ms) | "
+        print("rep %d: umi_group %.2fs | numpy glue %.2fs | msa+consensus (fused, rows stay in HBM) %.2fs | "
               "%d clusters>=2 covering %d reads | %.2f M reads/min end to end, consensus mean len %.0f"
-              % (rep, t1 - t0, t2 - t1, t3 - t2, msa_ms, t5 - t3, cons_ms, len(big), gflat.size,
+              % (rep, t1 - t0, t2 - t1, t5 - t2, len(big), gflat.size,
                  n / (t5 - t0) * 60 / 1e6, np.mean(np.diff(cons.off))), flush=True)
     # accuracy of the consensus vs truth for pure clusters
     from tests.test_oracle_umi import lev2
