@@ -11,20 +11,33 @@ from sarlacc_amd.strset import StringSet
 NUC = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 
-def noisy_copies(truth, copies, rng, sub=0.05, indel=0.01):
-    """truth: (G, L) uint8 -> StringSet of G*copies noisy reads (mockReads error process), + quals"""
+def noisy_copies(truth, copies, rng, sub=0.05, indel=0.01, chunk=5000):
+    """truth: (G, L) uint8 -> StringSet of G*copies noisy reads (mockReads error process), + quals.
+    Generated `chunk` molecules at a time so that 10^6 x 2 kb stays within a few GB of host memory."""
+    if truth.shape[0] > chunk:
+        parts = [_noisy_copies(truth[i:i + chunk], copies, rng, sub, indel) for i in range(0, truth.shape[0], chunk)]
+        chars = np.concatenate([p[0].chars[:p[0].total] for p in parts])
+        qchars = np.concatenate([p[1].chars[:p[1].total] for p in parts])
+        lens = np.concatenate([np.diff(p[0].off) for p in parts])
+        off = np.zeros(lens.size + 1, np.int64)
+        np.cumsum(lens, out=off[1:])
+        return StringSet(chars, off), StringSet(qchars, off.copy())
+    return _noisy_copies(truth, copies, rng, sub, indel)
+
+
+def _noisy_copies(truth, copies, rng, sub, indel):
     r = np.repeat(truth, copies, axis=0)
-    s = rng.random(r.shape) < sub
+    s = rng.random(r.shape, dtype=np.float32) < sub
     r[s] = NUC[rng.integers(0, 4, int(s.sum()))]
-    counts = np.ones(r.shape, np.int64)
-    ind = rng.random(r.shape) < indel
+    counts = np.ones(r.shape, np.int8)
+    ind = rng.random(r.shape, dtype=np.float32) < indel
     ch = np.array([0, 2, 3, 4, 5])
     counts[ind] = ch[rng.integers(0, 5, int(ind.sum()))]
     flat = np.repeat(r.reshape(-1), counts.reshape(-1))
     lens = counts.sum(1)
     off = np.zeros(len(lens) + 1, np.int64)
     off[1:] = np.cumsum(lens)
-    p = rng.random(flat.size) * 0.06
+    p = rng.random(flat.size, dtype=np.float32) * np.float32(0.06)
     q = (np.clip(np.round(-10 * np.log10(np.maximum(p, 1e-30))), 0, 93) + 33).astype(np.uint8)
     return StringSet(flat, off), StringSet(q, off.copy())
 
