@@ -35,6 +35,8 @@ namespace sarlacc {
 
 constexpr int MSA_NEG = -(1 << 28);
 constexpr int TB_ROWS = 32;
+template <bool B>
+struct Flag2 { static constexpr bool value = B; };
 
 struct MsaJob {
     long long read_off;   // into seq
@@ -46,6 +48,7 @@ struct MsaJob {
 struct MsaArgs {
     const uint8_t* seq;
     const MsaJob* jobs;
+    const int* order;       // optional: the njobs job indices this launch works on
     int njobs;
     int ma, mm, go, ge, bw;
     uint16_t* ins;          // per pair: insertions before each centre position
@@ -99,8 +102,8 @@ __global__ void __launch_bounds__(64) k_msa_pairwise(const MsaArgs A) {
     const int fadd = go - step;
     Word* const tile = static_cast<Word*>(A.tb) + static_cast<size_t>(blockIdx.x) * A.tb_per_wave;
 
-    for (int job = blockIdx.x; job < A.njobs; job += gridDim.x) {
-        const MsaJob J = A.jobs[job];
+    for (int jobn = blockIdx.x; jobn < A.njobs; jobn += gridDim.x) {
+        const MsaJob J = A.jobs[A.order ? A.order[jobn] : jobn];
         const int lr = J.lr, lc = J.lc;
         const int dlo = min(0, lc - lr) - A.bw;
         const int dhi = max(0, lc - lr) + A.bw;
@@ -253,6 +256,221 @@ __global__ void __launch_bounds__(64) k_msa_pairwise(const MsaArgs A) {
 }
 
 // ---------------------------------------------------------------------------
+// k_msa_pairwise_ad: the same banded Gotoh, scheduled along anti-diagonals of the BAND.
+//
+// Band coordinates: cell (i, x), x = j - i - dlo in [0, B).  Its inputs are
+//   diagonal (i-1, x)      vertical (i-1, x+1)      horizontal (i, x-1)
+// so with the time step  t = 2 i + x  every input was produced at step t-1 or t-2: no prefix
+// scan over the row is needed (the row-by-row kernel above spends most of its instructions
+// on that scan and on per-cell validity tests).  Lane l owns the C consecutive diagonals
+// x = C l + k; at step t it updates its cells with k = t (mod 2) -- C/2 cells per lane per step,
+// every lane busy on every step -- reading the neighbouring diagonals k-1 / k+1 from its own
+// registers, or from the adjacent lane with one DPP shift (H and F from the left on even steps,
+// H and E from the right on odd steps).  Two steps ("sub-block") advance every diagonal by one
+// row.  Read and centre codes sit in LDS; a lane needs C/2 + 1 consecutive read bases and
+// C/2 + 2 consecutive centre bases per sub-block.
+//
+// Traceback: 4 bits per cell as before; a sub-block yields C nibbles per lane, packed into
+// words of 8 (C = 4: two sub-blocks per dword) or C nibbles and stored coalesced.  The walk
+// descends in t, so it runs through an LDS window of the last MSA_WIN word rows; runs of
+// diagonal moves stay on one band diagonal and are consumed up to 64 rows per step.
+constexpr int MSA_WIN = 24;  // word rows of traceback codes held in LDS during the walk
+
+template <int C>
+struct AdWord { using type = uint32_t; static constexpr int SPW = 8 / C; };
+template <>
+struct AdWord<16> { using type = unsigned long long; static constexpr int SPW = 1; };
+
+template <int C>
+__global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
+    using Word = typename AdWord<C>::type;
+    constexpr int SPW = AdWord<C>::SPW;   // sub-blocks per stored word
+    constexpr int H2 = C / 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Word* const s_tb = reinterpret_cast<Word*>(smem);
+    uint8_t* const s_ct = reinterpret_cast<uint8_t*>(s_tb + MSA_WIN * 64);   // centre codes, 2 bytes of padding in front
+    const int lane = threadIdx.x;
+    const int ma = A.ma, mm = A.mm, go = A.go, ge = A.ge;
+    Word* const tile = static_cast<Word*>(A.tb) + static_cast<size_t>(blockIdx.x) * A.tb_per_wave;
+
+    for (int jobn = blockIdx.x; jobn < A.njobs; jobn += gridDim.x) {
+        const MsaJob J = A.jobs[A.order ? A.order[jobn] : jobn];
+        const int lr = J.lr, lc = J.lc;
+        const int dlo = min(0, lc - lr) - A.bw;
+        const int dhi = max(0, lc - lr) + A.bw;
+        const int B = dhi - dlo + 1;
+        const uint8_t* rd = A.seq + J.read_off;
+        const uint8_t* ct = A.seq + J.ctr_off;
+        uint8_t* const s_rd = s_ct + ((lc + 8 + 3) & ~3);   // read codes after the centre codes
+        __syncthreads();
+        for (int p = lane; p < lc; p += 64) s_ct[4 + p] = dna5_code(ct[p]);
+        for (int p = lane; p < lr; p += 64) s_rd[4 + p] = dna5_code(rd[p]);
+        if (lane < 4) { s_ct[lane] = 0xf0; s_rd[lane] = 0xf1; s_ct[4 + lc + lane] = 0xf0; s_rd[4 + lr + lane] = 0xf1; }
+        __syncthreads();
+
+        int Hc[C], Ec[C], Fc[C];
+        bool kvalid[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) { Hc[k] = MSA_NEG; Ec[k] = MSA_NEG; Fc[k] = MSA_NEG; kvalid[k] = lane * C + k < B; }
+
+        // One sub-block: steps t0 (even k) and t0 + 1 (odd k), t0 even.  Row and column of cell k:
+        //   i = t0/2 - (C/2) l - (k >> 1),   j = i + dlo + C l + k
+        auto subblock = [&](auto guard_tag, int t0) -> unsigned long long {
+            constexpr bool GUARD = decltype(guard_tag)::value;
+            const int ib = (t0 >> 1) - H2 * lane;            // row of cells k = 0, 1
+            const int jb = ib + dlo + C * lane;              // column of cell k = 0
+            // codes: read bases of rows ib - H2 + 1 .. ib  (s_rd[4 + i - 1]), centre bases of
+            // columns jb .. jb + H2 (s_ct[4 + j - 1]); out-of-range indices are clamped, the
+            // cells that would use them are invalid and discarded
+            int rc[H2], cc[H2 + 1];
+#pragma unroll
+            for (int h = 0; h < H2; ++h) {
+                int idx = ib - h - 1;
+                if (GUARD) idx = min(max(idx, -4), lr + 3);
+                rc[h] = s_rd[4 + idx];
+            }
+#pragma unroll
+            for (int h = 0; h <= H2; ++h) {
+                int idx = jb + h - 1;
+                if (GUARD) idx = min(max(idx, -4), lc + 3);
+                cc[h] = s_ct[4 + idx];
+            }
+            unsigned long long bits = 0;
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                // neighbours across the lane boundary (values of the previous step)
+                int xlH = MSA_NEG, xlF = MSA_NEG, xrH = MSA_NEG, xrE = MSA_NEG;
+                if (par == 0) { xlH = dpp_int<DPP_WAVE_SHR1>(MSA_NEG, Hc[C - 1]); xlF = dpp_int<DPP_WAVE_SHR1>(MSA_NEG, Fc[C - 1]); }
+                else { xrH = dpp_int<DPP_WAVE_SHL1>(MSA_NEG, Hc[0]); xrE = dpp_int<DPP_WAVE_SHL1>(MSA_NEG, Ec[0]); }
+                int nH[H2], nE[H2], nF[H2];
+#pragma unroll
+                for (int h = 0; h < H2; ++h) {
+                    const int k = 2 * h + par;
+                    const int uH = (k + 1 < C) ? Hc[k + 1] : xrH, uE = (k + 1 < C) ? Ec[k + 1] : xrE;
+                    const int lH = (k > 0) ? Hc[k - 1] : xlH, lF = (k > 0) ? Fc[k - 1] : xlF;
+                    const int eop = uH + go, eex = uE + ge;
+                    int e = max(max(eop, eex), MSA_NEG);
+                    const bool eo = eop >= eex;
+                    // cell k: row ib - h, column jb + h + par
+                    int d = max(Hc[k] + (rc[h] == cc[h + par] ? ma : mm), MSA_NEG);
+                    const int fop = lH + go, fex = lF + ge;
+                    int f = max(max(fop, fex), MSA_NEG);
+                    const bool fo = fop >= fex;
+                    bool valid = kvalid[k];
+                    if (GUARD) {
+                        const int i = ib - h, j = jb + h + par;
+                        valid = valid && i >= 0 && i <= lr && j >= 0 && j <= lc;
+                        if (i == 0) { e = MSA_NEG; d = (j == 0) ? 0 : MSA_NEG; }
+                        if (j < 1) f = MSA_NEG;
+                        if (!valid) { e = MSA_NEG; d = MSA_NEG; f = MSA_NEG; }
+                    }
+                    const int m = max(e, f);
+                    int hv = max(d, m);
+                    unsigned hd;
+                    if (d >= m) hd = 0;
+                    else if (e >= f) hd = 1;
+                    else hd = 2;
+                    const unsigned t4 = hd | (eo ? 4u : 0u) | (fo ? 8u : 0u);
+                    bits |= static_cast<unsigned long long>(t4) << (4 * k);
+                    nH[h] = valid ? hv : MSA_NEG;
+                    nE[h] = valid ? e : MSA_NEG;
+                    nF[h] = f;
+                }
+#pragma unroll
+                for (int h = 0; h < H2; ++h) { Hc[2 * h + par] = nH[h]; Ec[2 * h + par] = nE[h]; Fc[2 * h + par] = nF[h]; }
+            }
+            return bits;
+        };
+
+        // steps 0 .. 2 lr + B - 1, in word blocks of 2 SPW steps
+        const int tsteps = 2 * lr + B;
+        const int nwords = (tsteps + 2 * SPW - 1) / (2 * SPW);
+        // sub-blocks [sb_lo, sb_hi) have every cell with x < B inside the matrix (i >= 1, 1 <= j <= lc, i <= lr)
+        int sb_lo = (max(B + 1, 2 - 2 * dlo) + 1) / 2 + 1;
+        int sb_hi = min(2 * lr, 2 * (lc - dlo) - B) / 2 - 1;
+        int w_lo = (sb_lo + SPW - 1) / SPW, w_hi = sb_hi / SPW;
+        w_lo = min(w_lo, nwords);
+        w_hi = min(max(w_hi, w_lo), nwords);
+        auto words = [&](auto guard_tag, int wb, int we) {
+            for (int w = wb; w < we; ++w) {
+                Word out = 0;
+#pragma unroll
+                for (int sbk = 0; sbk < SPW; ++sbk) {
+                    const unsigned long long bits = subblock(guard_tag, 2 * (w * SPW + sbk));
+                    out |= static_cast<Word>(bits) << (4 * C * sbk * (SPW > 1 ? 1 : 0));
+                }
+                tile[static_cast<size_t>(w) * 64 + lane] = out;
+            }
+        };
+        words(Flag2<true>{}, 0, w_lo);
+        words(Flag2<false>{}, w_lo, w_hi);
+        words(Flag2<true>{}, w_hi, nwords);
+
+        // ---- traceback through an LDS window (wave-uniform walk) ----
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        uint16_t* ins = A.ins + J.out_off;
+        uint8_t* aln = A.aln + J.out_off;
+        int i = lr, j = lc, state = 0, cnt = 0;
+        int wlo = nwords;   // first word row held in the window (none yet)
+        // code of cell (ii, xx): sub-block ws = ii + (xx + C l ... ) -- t = 2 ii + xx, ws = t >> 1
+        auto locate = [&](int ii, int xx, int& wrow, int& shift, int& ln) {
+            const int t = 2 * ii + xx;
+            const int ws = t >> 1;
+            ln = xx / C;
+            wrow = ws / SPW;
+            shift = 4 * ((ws % SPW) * C + (xx % C));
+        };
+        while (i > 0 || j > 0) {
+            const int x = j - i - dlo;
+            int wrow, shift, ln;
+            locate(i, x, wrow, shift, ln);
+            if (wrow < wlo) {
+                wlo = max(0, wrow - (MSA_WIN - 1));
+                __syncthreads();
+                for (int r = 0; r < MSA_WIN; ++r)
+                    if (wlo + r < nwords) s_tb[r * 64 + lane] = tile[static_cast<size_t>(wlo + r) * 64 + lane];
+                __syncthreads();
+            }
+            if (state == 0) {
+                // run of diagonal moves: cell (i - m, j - m) keeps x; lane m inspects it
+                const int reach = min(min(i, j), ((2 * i + x) >> 1) - wlo * SPW + 1);
+                unsigned tl = 1;
+                if (lane < reach) {
+                    int wr, sh, l2;
+                    locate(i - lane, x, wr, sh, l2);
+                    tl = static_cast<unsigned>(s_tb[(wr - wlo) * 64 + l2] >> sh) & 3u;
+                }
+                const unsigned long long nd = __ballot(tl != 0);
+                const int run = nd ? static_cast<int>(__builtin_ctzll(nd)) : 64;
+                if (run > 0) {
+                    if (lane < run) { ins[j - lane] = (lane == 0) ? static_cast<uint16_t>(cnt) : static_cast<uint16_t>(0); aln[j - lane - 1] = 1; }
+                    cnt = 0; i -= run; j -= run;
+                    continue;
+                }
+            }
+            const unsigned t = static_cast<unsigned>(s_tb[(wrow - wlo) * 64 + ln] >> shift) & 15u;
+            if (state == 0) {
+                state = t & 3;
+                continue;
+            }
+            if (state == 1) {               // read base inserted before centre position j
+                ++cnt;
+                state = (t & 4) ? 0 : 1;
+                --i;
+            } else {                        // centre base j-1 opposite a gap
+                if (lane == 0) { ins[j] = static_cast<uint16_t>(cnt); aln[j - 1] = 0; }
+                cnt = 0;
+                state = (t & 8) ? 0 : 2;
+                --j;
+            }
+        }
+        if (lane == 0) ins[0] = static_cast<uint16_t>(cnt);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
 struct MsaGroup {
     long long first_job;   // jobs of this group are first_job .. first_job + nreads - 2 (centre has none)
     long long read0;       // index of the group's first entry in the flattened member list
@@ -374,6 +592,13 @@ static int launch_pairwise(const MsaArgs& a, int grid, size_t lds, hipStream_t s
     return 0;
 }
 
+template <int C>
+static int launch_pairwise_ad(const MsaArgs& a, int grid, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL(k_msa_pairwise_ad<C>, dim3(grid), dim3(64), lds, s, a);
+    SL_HIP(hipGetLastError());
+    return 0;
+}
+
 // The whole MSA stage with the gapped rows left in HBM (res->d_out): shared by sarlacc_quick_msa,
 // which copies them back, and sarlacc_msa_consensus, which votes on them where they are.
 // out_cap: < 0 no limit; otherwise the rows are only written when they fit (sizing protocol of
@@ -463,25 +688,60 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     SL_TRY(scratch("msa.width", static_cast<size_t>(ngroups), &d_width));
 
     if (!jobs.empty()) {
-        const int C = max_band <= 256 ? 4 : (max_band <= 512 ? 8 : 16);
-        const size_t word = C == 16 ? 8 : 4;
-        const size_t per_wave = (static_cast<size_t>(max_lr) + 2) * 64;
-        long long grid = std::min<long long>(static_cast<long long>(jobs.size()), static_cast<long long>(c.num_cu) * (C == 4 ? 16 : 8));
-        const size_t budget = static_cast<size_t>(8) << 30;
-        grid = std::min<long long>(grid, std::max<long long>(1, static_cast<long long>(budget / (per_wave * word))));
-        void* d_tb;
-        SL_TRY(c.buffer("msa.tb", static_cast<size_t>(grid) * per_wave * word, &d_tb));
+        const bool scan_kernel = std::getenv("SARLACC_MSA_SCAN") != nullptr;   // the row-by-row kernel, kept for A/B runs
+        // jobs by band class: 4, 8 or 16 diagonals per lane (bands up to 256 / 512 / 1024); one launch per
+        // class, so the common narrow bands are not dragged to the widest job's shape
+        std::vector<int> order[3];
+        int cls_lr[3] = {0, 0, 0}, cls_lc[3] = {0, 0, 0}, cls_band[3] = {1, 1, 1};
+        for (size_t q = 0; q < jobs.size(); ++q) {
+            const int band = std::abs(jobs[q].lc - jobs[q].lr) + 2 * bandwidth + 1;
+            const int cls = scan_kernel ? (max_band <= 256 ? 0 : (max_band <= 512 ? 1 : 2)) : (band <= 256 ? 0 : (band <= 512 ? 1 : 2));
+            order[cls].push_back(static_cast<int>(q));
+            cls_lr[cls] = std::max(cls_lr[cls], jobs[q].lr);
+            cls_lc[cls] = std::max(cls_lc[cls], jobs[q].lc);
+            cls_band[cls] = std::max(cls_band[cls], band);
+        }
         MsaArgs a{};
-        a.seq = d_seq; a.jobs = d_jobs; a.njobs = static_cast<int>(jobs.size());
+        a.seq = d_seq; a.jobs = d_jobs;
         a.ma = static_cast<int>(match); a.mm = static_cast<int>(mismatch);
         // SeqAn's Score(match, mismatch, gap_extend, gap_open): gap of length k = open + (k-1)*extend
         a.go = static_cast<int>(gap_opening); a.ge = static_cast<int>(gap_extension);
-        a.bw = bandwidth; a.ins = d_ins; a.aln = d_aln; a.tb = d_tb; a.tb_per_wave = per_wave;
-        const size_t lds = TB_ROWS * 64 * word + static_cast<size_t>(max_lc) + 64;
+        a.bw = bandwidth; a.ins = d_ins; a.aln = d_aln;
         SL_HIP(hipEventRecord(c.ev_start, s));
-        if (C == 4) SL_TRY(launch_pairwise<4>(a, static_cast<int>(grid), lds, s));
-        else if (C == 8) SL_TRY(launch_pairwise<8>(a, static_cast<int>(grid), lds, s));
-        else SL_TRY(launch_pairwise<16>(a, static_cast<int>(grid), lds, s));
+        for (int cls = 0; cls < 3; ++cls) {
+            if (order[cls].empty()) continue;
+            const int C = 4 << cls;
+            const size_t word = C == 16 ? 8 : 4;
+            // traceback tile of one resident wave: row-by-row kernel one word row per read row; anti-diagonal
+            // kernel one word row per 2 * SPW steps of the 2 lr + B steps
+            const size_t spw = C == 4 ? 2 : 1;
+            const size_t per_wave = scan_kernel ? (static_cast<size_t>(cls_lr[cls]) + 2) * 64
+                                                : ((2 * static_cast<size_t>(cls_lr[cls]) + cls_band[cls]) / (2 * spw) + 2) * 64;
+            const size_t lds = scan_kernel ? TB_ROWS * 64 * word + static_cast<size_t>(cls_lc[cls]) + 64
+                                           : MSA_WIN * 64 * word + static_cast<size_t>(cls_lc[cls]) + static_cast<size_t>(cls_lr[cls]) + 32;
+            if (lds > 160 * 1024) return fail("sarlacc_amd: reads of %d bases do not fit the MSA kernel's LDS staging", std::max(cls_lr[cls], cls_lc[cls]));
+            const long long by_lds = std::max<long long>(1, static_cast<long long>((160 * 1024) / lds));
+            long long grid = std::min<long long>(static_cast<long long>(order[cls].size()),
+                                                 static_cast<long long>(c.num_cu) * std::min<long long>(C == 4 ? 16 : 8, by_lds));
+            const size_t budget = static_cast<size_t>(8) << 30;
+            grid = std::min<long long>(grid, std::max<long long>(1, static_cast<long long>(budget / (per_wave * word))));
+            void* d_tb; int* d_order;
+            const char* tb_name[3] = {"msa.tb0", "msa.tb1", "msa.tb2"};
+            const char* ord_name[3] = {"msa.ord0", "msa.ord1", "msa.ord2"};
+            SL_TRY(c.buffer(tb_name[cls], static_cast<size_t>(grid) * per_wave * word, &d_tb));
+            SL_TRY(upload(ord_name[cls], order[cls].data(), order[cls].size(), &d_order, s));
+            a.order = d_order; a.njobs = static_cast<int>(order[cls].size());
+            a.tb = d_tb; a.tb_per_wave = per_wave;
+            if (scan_kernel) {
+                if (C == 4) SL_TRY(launch_pairwise<4>(a, static_cast<int>(grid), lds, s));
+                else if (C == 8) SL_TRY(launch_pairwise<8>(a, static_cast<int>(grid), lds, s));
+                else SL_TRY(launch_pairwise<16>(a, static_cast<int>(grid), lds, s));
+            } else {
+                if (C == 4) SL_TRY(launch_pairwise_ad<4>(a, static_cast<int>(grid), lds, s));
+                else if (C == 8) SL_TRY(launch_pairwise_ad<8>(a, static_cast<int>(grid), lds, s));
+                else SL_TRY(launch_pairwise_ad<16>(a, static_cast<int>(grid), lds, s));
+            }
+        }
         SL_HIP(hipEventRecord(c.ev_stop, s));
         c.timed = true;
     }
