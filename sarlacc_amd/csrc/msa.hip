@@ -276,6 +276,14 @@ __global__ void __launch_bounds__(64) k_msa_pairwise(const MsaArgs A) {
 // diagonal moves stay on one band diagonal and are consumed up to 64 rows per step.
 constexpr int MSA_WIN = 24;  // word rows of traceback codes held in LDS during the walk
 
+// pk = 2 * pk + (this lane's bit of the SGPR mask m)
+__device__ __forceinline__ uint32_t msa_push_bit(uint32_t pk, unsigned long long m) {
+    uint32_t r;
+    unsigned long long carry_out;
+    asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(pk), "s"(m));
+    return r;
+}
+
 template <int C>
 struct AdWord { using type = uint32_t; static constexpr int SPW = 8 / C; };
 template <>
@@ -310,12 +318,24 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
 
         int Hc[C], Ec[C], Fc[C];
         bool kvalid[C];
+        // Band edge: the vertical input of diagonal B - 1 lies outside the band.  Instead of
+        // masking the cells beyond the band after every update, the gap penalties a cell adds to
+        // its vertical input are per (lane, k) values that sink the candidate below MSA_NEG.
+        int gou[C], geu[C];
 #pragma unroll
-        for (int k = 0; k < C; ++k) { Hc[k] = MSA_NEG; Ec[k] = MSA_NEG; Fc[k] = MSA_NEG; kvalid[k] = lane * C + k < B; }
+        for (int k = 0; k < C; ++k) {
+            Hc[k] = MSA_NEG; Ec[k] = MSA_NEG; Fc[k] = MSA_NEG;
+            kvalid[k] = lane * C + k < B;
+            gou[k] = (lane * C + k + 1 < B) ? go : MSA_NEG;
+            geu[k] = (lane * C + k + 1 < B) ? ge : MSA_NEG;
+        }
 
         // One sub-block: steps t0 (even k) and t0 + 1 (odd k), t0 even.  Row and column of cell k:
         //   i = t0/2 - (C/2) l - (k >> 1),   j = i + dlo + C l + k
-        auto subblock = [&](auto guard_tag, int t0) -> unsigned long long {
+        // Traceback nibble of a cell (raw outcomes, pushed most significant first):
+        //   bit 3 F opened (H_left + go >= F_left + ge)   bit 2 E opened   bit 1 e >= f   bit 0 d >= max(e, f)
+        // Cells are pushed in the order (parity, h); 8 cells fill one 32-bit chunk `pk`.
+        auto subblock = [&](auto guard_tag, int t0, uint32_t& pk, uint32_t& pk_hi) {
             constexpr bool GUARD = decltype(guard_tag)::value;
             const int ib = (t0 >> 1) - H2 * lane;            // row of cells k = 0, 1
             const int jb = ib + dlo + C * lane;              // column of cell k = 0
@@ -335,7 +355,6 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
                 if (GUARD) idx = min(max(idx, -4), lc + 3);
                 cc[h] = s_ct[4 + idx];
             }
-            unsigned long long bits = 0;
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
                 // neighbours across the lane boundary (values of the previous step)
@@ -348,7 +367,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
                     const int k = 2 * h + par;
                     const int uH = (k + 1 < C) ? Hc[k + 1] : xrH, uE = (k + 1 < C) ? Ec[k + 1] : xrE;
                     const int lH = (k > 0) ? Hc[k - 1] : xlH, lF = (k > 0) ? Fc[k - 1] : xlF;
-                    const int eop = uH + go, eex = uE + ge;
+                    const int eop = uH + gou[k], eex = uE + geu[k];
                     int e = max(max(eop, eex), MSA_NEG);
                     const bool eo = eop >= eex;
                     // cell k: row ib - h, column jb + h + par
@@ -356,30 +375,27 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
                     const int fop = lH + go, fex = lF + ge;
                     int f = max(max(fop, fex), MSA_NEG);
                     const bool fo = fop >= fex;
-                    bool valid = kvalid[k];
+                    bool valid = true;
                     if (GUARD) {
                         const int i = ib - h, j = jb + h + par;
-                        valid = valid && i >= 0 && i <= lr && j >= 0 && j <= lc;
+                        valid = kvalid[k] && i >= 0 && i <= lr && j >= 0 && j <= lc;
                         if (i == 0) { e = MSA_NEG; d = (j == 0) ? 0 : MSA_NEG; }
                         if (j < 1) f = MSA_NEG;
                         if (!valid) { e = MSA_NEG; d = MSA_NEG; f = MSA_NEG; }
                     }
                     const int m = max(e, f);
-                    int hv = max(d, m);
-                    unsigned hd;
-                    if (d >= m) hd = 0;
-                    else if (e >= f) hd = 1;
-                    else hd = 2;
-                    const unsigned t4 = hd | (eo ? 4u : 0u) | (fo ? 8u : 0u);
-                    bits |= static_cast<unsigned long long>(t4) << (4 * k);
-                    nH[h] = valid ? hv : MSA_NEG;
-                    nE[h] = valid ? e : MSA_NEG;
+                    const int hv = max(d, m);
+                    const unsigned long long m_fo = __builtin_amdgcn_ballot_w64(fo), m_eo = __builtin_amdgcn_ballot_w64(eo);
+                    const unsigned long long m_ef = __builtin_amdgcn_ballot_w64(e >= f), m_dm = __builtin_amdgcn_ballot_w64(d >= m);
+                    pk = msa_push_bit(msa_push_bit(msa_push_bit(msa_push_bit(pk, m_fo), m_eo), m_ef), m_dm);
+                    if (C == 16 && par == 0 && h == H2 - 1) { pk_hi = pk; pk = 0; }   // 8 cells done: first chunk of a 64-bit word
+                    nH[h] = (GUARD && !valid) ? MSA_NEG : hv;
+                    nE[h] = e;
                     nF[h] = f;
                 }
 #pragma unroll
                 for (int h = 0; h < H2; ++h) { Hc[2 * h + par] = nH[h]; Ec[2 * h + par] = nE[h]; Fc[2 * h + par] = nF[h]; }
             }
-            return bits;
         };
 
         // steps 0 .. 2 lr + B - 1, in word blocks of 2 SPW steps
@@ -393,12 +409,12 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
         w_hi = min(max(w_hi, w_lo), nwords);
         auto words = [&](auto guard_tag, int wb, int we) {
             for (int w = wb; w < we; ++w) {
-                Word out = 0;
+                uint32_t pk = 0, pk_hi = 0;
 #pragma unroll
-                for (int sbk = 0; sbk < SPW; ++sbk) {
-                    const unsigned long long bits = subblock(guard_tag, 2 * (w * SPW + sbk));
-                    out |= static_cast<Word>(bits) << (4 * C * sbk * (SPW > 1 ? 1 : 0));
-                }
+                for (int sbk = 0; sbk < SPW; ++sbk) subblock(guard_tag, 2 * (w * SPW + sbk), pk, pk_hi);
+                Word out;
+                if (C == 16) out = static_cast<Word>((static_cast<unsigned long long>(pk_hi) << 32) | pk);
+                else out = static_cast<Word>(pk);
                 tile[static_cast<size_t>(w) * 64 + lane] = out;
             }
         };
@@ -417,9 +433,12 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
         auto locate = [&](int ii, int xx, int& wrow, int& shift, int& ln) {
             const int t = 2 * ii + xx;
             const int ws = t >> 1;
+            const int k = xx % C;
             ln = xx / C;
             wrow = ws / SPW;
-            shift = 4 * ((ws % SPW) * C + (xx % C));
+            // cells are pushed in the order (sub-block, parity, h), the first one ends up on top
+            const int q = (ws % SPW) * C + (k & 1) * H2 + (k >> 1);
+            shift = 4 * (SPW * C - 1 - q);
         };
         while (i > 0 || j > 0) {
             const int x = j - i - dlo;
@@ -439,7 +458,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
                 if (lane < reach) {
                     int wr, sh, l2;
                     locate(i - lane, x, wr, sh, l2);
-                    tl = static_cast<unsigned>(s_tb[(wr - wlo) * 64 + l2] >> sh) & 3u;
+                    tl = (static_cast<unsigned>(s_tb[(wr - wlo) * 64 + l2] >> sh) & 1u) ^ 1u;   // bit 0: diagonal
                 }
                 const unsigned long long nd = __ballot(tl != 0);
                 const int run = nd ? static_cast<int>(__builtin_ctzll(nd)) : 64;
@@ -451,7 +470,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
             }
             const unsigned t = static_cast<unsigned>(s_tb[(wrow - wlo) * 64 + ln] >> shift) & 15u;
             if (state == 0) {
-                state = t & 3;
+                state = (t & 1u) ? 0 : ((t & 2u) ? 1 : 2);   // diagonal, else vertical if e >= f, else horizontal
                 continue;
             }
             if (state == 1) {               // read base inserted before centre position j
