@@ -150,6 +150,12 @@ int sarlacc_dev_windows(const uint8_t* d_seq, const uint8_t* d_qual, const int64
 int sarlacc_dev_scramble(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
                          uint64_t seed, uint8_t* d_oseq, uint8_t* d_oqual, void* stream);
 
+/* replaces .Call unmask_alignment  (src/unmask_alignment.cpp:12-59): every 'N'/'n'
+ * of a gapped row becomes the base at the same ungapped position of the original sequence.
+ * out has the layout of aln. */
+int sarlacc_unmask_alignment(const char* aln, const int64_t* aln_off, int64_t naln,
+                             const char* orig, const int64_t* orig_off, int64_t norig, char* out);
+
 /* FASTQ text already in device memory -> resident read batch.  Replaces the
  * host-side ShortRead::FastqStreamer + .FASTQ2QSDS conversion (R/adaptorAlign.R:26-37,:104-110;
  * R/realizeReads.R:15-26).  4-line records, LF or CRLF, trailing blank lines ignored; sequences

@@ -415,6 +415,35 @@ int orc_mask_bad_bases(const char* seq, const int64_t* seq_off,
 }
 
 /* ------------------------------------------------------------------ */
+/* (reference src/unmask_alignment.cpp:12-59): copy each gapped row, replacing every 'N'/'n' by
+ * the base at the same ungapped position of the original sequence.  Errors in the reference's
+ * order: entry counts, row widths (check_alignment_width, src/DNA_input.cpp:90-104), then row by
+ * row "longer than the original" (at the first masked base past the end) or "different lengths". */
+int orc_unmask_alignment(const char* aln, const int64_t* aln_off, int64_t naln, const char* orig,
+                         const int64_t* orig_off, int64_t norig, char* out) {
+    if (naln != norig) return orc_fail("alignment and original sequences should have the same number of entries");
+    for (int64_t i = 1; i < naln; ++i)
+        if (aln_off[i + 1] - aln_off[i] != aln_off[1] - aln_off[0]) return orc_fail("alignment strings should have the same length");
+    for (int64_t i = 0; i < naln; ++i) {
+        const int64_t W = aln_off[i + 1] - aln_off[i], L = orig_off[i + 1] - orig_off[i];
+        int64_t pos_nominal = 0;
+        for (int64_t p = 0; p < W; ++p) {
+            char c = aln[aln_off[i] + p];
+            if (c != '-') {
+                if (c == 'N' || c == 'n') {
+                    if (pos_nominal >= L) return orc_fail("sequence in alignment string is longer than the original");
+                    c = orig[orig_off[i] + pos_nominal];
+                }
+                ++pos_nominal;
+            }
+            out[aln_off[i] + p] = c;
+        }
+        if (pos_nominal != L) return orc_fail("original sequence and that in the alignment string have different lengths");
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
 /* Per-read shuffle used by the scrambled-control callers.  The reference shuffles with R's
  * sample() (R/getAdaptorThresholds.R:68-92), which cannot be reproduced without R; this
  * restates OUR generator (sarlacc_amd/csrc/resident.hip:k_scramble) so the device shuffle can

@@ -79,6 +79,10 @@ int orc_mask_bad_bases(const char* seq, const int64_t* seq_off,
                        const double* errors, const char* names, int nenc,
                        double threshold, char* out);
 
+/* ---- unmasking (reference src/unmask_alignment.cpp:12-59) ---- */
+int orc_unmask_alignment(const char* aln, const int64_t* aln_off, int64_t naln, const char* orig,
+                         const int64_t* orig_off, int64_t norig, char* out);
+
 /* per-read shuffle of the scrambled-control callers (our generator, see align.c) */
 int orc_scramble(const char* seq, const char* qual, const int64_t* off, int64_t n, uint64_t seed,
                  char* oseq, char* oqual);

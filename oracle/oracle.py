@@ -180,6 +180,14 @@ def mask_bad_bases(seq, qual, encoding, threshold):
     return unpack(out, so)
 
 
+def unmask_alignment(alignments, originals):
+    ab, ao = pack(alignments)
+    ob, oo = pack(originals)
+    out = np.zeros_like(ab)
+    _check(lib().orc_unmask_alignment(_p(ab), _p(ao), C.c_int64(len(ao) - 1), _p(ob), _p(oo), C.c_int64(len(oo) - 1), _p(out)))
+    return unpack(out, ao)
+
+
 def scramble(seq, qual, seed):
     sb, so = pack(seq)
     qb, _ = pack(qual)

@@ -211,6 +211,17 @@ def mask_bad_bases(sequences, qualities, encoding, threshold):
     return StringSet(out, s.off.copy()).to_strings()
 
 
+def unmask_alignment(alignments, originals):
+    """.Call unmask_alignment (src/unmask_alignment.cpp:12-59): alignment rows with the masked
+    bases ('N'/'n') restored from the original sequences."""
+    a = StringSet.from_strings(alignments)
+    o = StringSet.from_strings(originals)
+    out = np.zeros(max(a.total, 1), np.uint8)
+    check(_lib.lib().sarlacc_unmask_alignment(ptr(a.chars), ptr(a.off), C.c_int64(len(a)), ptr(o.chars), ptr(o.off),
+                                              C.c_int64(len(o)), ptr(out)))
+    return StringSet(out, a.off.copy()).to_strings()
+
+
 def compute_lev_masked(sequences):
     """.Call compute_lev_masked (src/compute_lev_masked.cpp:13-64): lower triangle, R 'dist' order."""
     s = StringSet.from_strings(sequences)

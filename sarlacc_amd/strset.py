@@ -56,6 +56,12 @@ class StringSet:
     def __getitem__(self, i):
         return self.chars[self.off[i]:self.off[i + 1]].tobytes().decode()
 
+    def slice(self, lo, hi):
+        """Contiguous range [lo, hi) without a gather (views the same bytes)."""
+        o = self.off[lo:hi + 1]
+        chars = self.chars[int(o[0]):int(o[-1])]
+        return StringSet(chars if chars.size else np.zeros(1, np.uint8), o - o[0])
+
     def subset(self, idx):
         idx = np.asarray(idx, dtype=np.int64)
         w = self.off[idx + 1] - self.off[idx]

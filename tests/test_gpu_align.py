@@ -290,3 +290,36 @@ def test_device_resident_and_packed_paths(oracle, oenc, enc):
                        stream, d_nmask=mask)
         torch.cuda.synchronize()
         assert np.array_equal(bits(sc2.cpu().numpy()), bits(oracle.barcode_align(reads, quals, oenc, 5, 1, adaptor)))
+
+
+def test_unmask_alignment(oracle):
+    """unmask_alignment (src/unmask_alignment.cpp): reference literals, random rows wider than one
+    wave step, and the reference's error cases (tests/testthat/test-masking.R:45-100)."""
+    from sarlacc_amd import calls
+    from sarlacc_amd._lib import SarlaccError
+    from tests.test_oracle_align import UNMASK_CASES, unmask_inputs
+    for seq_in in UNMASK_CASES:
+        masked, original = unmask_inputs(seq_in)
+        assert calls.unmask_alignment(masked, original) == [s.upper() for s in seq_in]
+    rng = np.random.default_rng(12)
+    W = 700
+    rows, originals = [], []
+    for _ in range(40):
+        row = rng.choice(list("ACGT-"), W, p=[0.22, 0.22, 0.22, 0.22, 0.12])
+        originals.append("".join(c for c in row if c != "-"))
+        m = row.copy()
+        hit = (rng.random(W) < 0.3) & (row != "-")
+        m[hit] = rng.choice(list("Nn"), int(hit.sum()))
+        rows.append("".join(m))
+    assert calls.unmask_alignment(rows, originals) == oracle.unmask_alignment(rows, originals)
+    assert calls.unmask_alignment([], []) == []
+    for aln, orig, msg in ((["AA-AA"], ["AAA"], "different lengths"),
+                           (["NNNNN"], ["AAA"], "sequence in alignment string is longer than the original"),
+                           (["AAAA", "GGGG"], ["AAA"], "same number of entries"),
+                           (["AAAA", "GGG"], ["AAAA", "GGG"], "alignment strings should have the same length"),
+                           (["ANAA", "GGNNN"[:4] + "N"], ["AAAA", "GG"], "alignment strings should have the same length")):
+        with pytest.raises(SarlaccError, match=msg):
+            calls.unmask_alignment(aln, orig)
+    # first failing row decides the message
+    with pytest.raises(SarlaccError, match="longer than the original"):
+        calls.unmask_alignment(["AAAA", "NNNN", "AA-A"], ["AAAA", "GG", "A"])

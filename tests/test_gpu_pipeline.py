@@ -128,3 +128,33 @@ def test_extract_subseq_and_resident_barcodes(monkeypatch):
     monkeypatch.setattr(generics, "calls", oracle_calls)
     want = generics.extractSubseq(aligned, rd, subseq1={"starts": [1, 22], "ends": [9, 30]}, subseq2={"starts": [5], "ends": [11]})
     assert want == sub
+
+
+def test_two_rank_pipeline_driver_matches_single_rank():
+    """tools/run_pipeline.py (BASELINE config 5 in miniature) with two ranks sharing this GPU
+    over gloo: read-range DP shards, tile-sharded UMI search + all-gather of neighbour pairs,
+    clusters bin-packed over the ranks for MSA + consensus.  Rank 0 recomputes everything
+    unsharded (--check): clusters identical, same consensus reads and bases."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SARLACC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tools", "run_pipeline.py"), "--molecules", "400", "--copies", "6",
+           "--read-len", "300", "--check"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [x for x in res.stdout.splitlines() if x.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["reads"] == 2400
+    chk = out["check"]
+    assert chk["clusters_identical"]
+    assert out["consensus_reads"] == chk["consensus_reads"] and out["consensus_bases"] == chk["consensus_bases"]
+    assert abs(out["score_checksum"] - chk["score_checksum"]) < 1e-6 * max(1.0, abs(chk["score_checksum"]))

@@ -196,3 +196,43 @@ def test_mask_bad_bases(oracle, oenc):
         for s, q, o in zip(seqs, quals, out):
             want = "".join("N" if err[ord(c) - 33] > thr else b for b, c in zip(s, q))
             assert o == want
+
+
+# the literals of tests/testthat/test-masking.R:45-100: upper case = masked position
+UNMASK_CASES = [
+    ["acacgtagtgtcagtctaacatcagctacgttacat", "ACACGTAGTGTCAGTCTAACATCAGCTACGTTACAT", "acacgtcgtgtcagtctaaCatcagctacgttacat",
+     "Acacgttgtgtcagtctaacatcagctacgttacat", "acacgtggtgtcagtctaacatcagctacgttacaT"],
+    ["acacgtagtgtcagtc-taacatcagctacgttacat", "ACACGTAGTGTCAGTC-TAACATCAGCTACGTTACAT", "acacgtcgtgtcagtc-taaCatcagctacgttacat",
+     "Acacgttgtgtcagtc-taacatcagctacgttacat", "acacgtggtgtcagtc-taacatcagctacgttacaT"],
+    ["-acacgtcgtgtcagtctaacatcagctacgttacat", "-ACACGTAGTGTCAGTCTAACATCAGCTACGTTACAT", "-acacgtcgtgtcagtctaaCatcagctacgttacat",
+     "-Acacgtcgtgtcagtctaacatcagctacgttacat", "-acacgtcgtgtcagtctaacatcagctacgttacaT"],
+    ["acacgtcgtgtcagtctaacatcagctacgttacat-", "ACACGTAGTGTCAGTCTAACATCAGCTACGTTACAT-", "acacgtcgtgtcagtctaaCatcagctacgttacat-",
+     "Acacgtcgtgtcagtctaacatcagctacgttacat-", "acacgtcgtgtcagtctaacatcagctacgttacaT-"],
+]
+
+
+def unmask_inputs(seq_in):
+    """MASKFUN / ORIGINAL of the reference's test (DNAStringSet upper-cases what is left)."""
+    import re
+    masked = [re.sub("[ACTG]", "N", s).upper() for s in seq_in]
+    original = [s.replace("-", "").upper() for s in seq_in]
+    return masked, original
+
+
+@pytest.mark.parametrize("case", range(len(UNMASK_CASES)))
+def test_unmask_alignment_reference_literals(oracle, case):
+    seq_in = UNMASK_CASES[case]
+    masked, original = unmask_inputs(seq_in)
+    assert oracle.unmask_alignment(masked, original) == [s.upper() for s in seq_in]
+
+
+def test_unmask_alignment_errors(oracle):
+    # tests/testthat/test-masking.R:93-98
+    with pytest.raises(oracle.OracleError, match="different lengths"):
+        oracle.unmask_alignment(["AA-AA"], ["AAA"])
+    with pytest.raises(oracle.OracleError, match="sequence in alignment string is longer than the original"):
+        oracle.unmask_alignment(["NNNNN"], ["AAA"])
+    with pytest.raises(oracle.OracleError, match="alignment and original sequences should have the same number of entries"):
+        oracle.unmask_alignment(["AAAA", "GGGG"], ["AAA"])
+    assert oracle.unmask_alignment(["AA-A"], ["AAA"]) == ["AA-A"]
+    assert oracle.unmask_alignment([], []) == []
