@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise(const MsaArgs A) {
 // words of 8 (C = 4: two sub-blocks per dword) or C nibbles and stored coalesced.  The walk
 // descends in t, so it runs through an LDS window of the last MSA_WIN word rows; runs of
 // diagonal moves stay on one band diagonal and are consumed up to 64 rows per step.
-constexpr int MSA_WIN = 24;  // word rows of traceback codes held in LDS during the walk
+constexpr int MSA_WIN = 16;  // word rows of traceback codes held in LDS during the walk
 
 // pk = 2 * pk + (this lane's bit of the SGPR mask m)
 __device__ __forceinline__ uint32_t msa_push_bit(uint32_t pk, unsigned long long m) {
@@ -741,7 +741,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
             if (lds > 160 * 1024) return fail("sarlacc_amd: reads of %d bases do not fit the MSA kernel's LDS staging", std::max(cls_lr[cls], cls_lc[cls]));
             const long long by_lds = std::max<long long>(1, static_cast<long long>((160 * 1024) / lds));
             long long grid = std::min<long long>(static_cast<long long>(order[cls].size()),
-                                                 static_cast<long long>(c.num_cu) * std::min<long long>(C == 4 ? 16 : 8, by_lds));
+                                                 static_cast<long long>(c.num_cu) * std::min<long long>(scan_kernel ? (C == 4 ? 16 : 8) : (C == 4 ? 20 : (C == 8 ? 16 : 8)), by_lds));
             const size_t budget = static_cast<size_t>(8) << 30;
             grid = std::min<long long>(grid, std::max<long long>(1, static_cast<long long>(budget / (per_wave * word))));
             void* d_tb; int* d_order;
