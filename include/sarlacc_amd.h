@@ -146,6 +146,12 @@ int sarlacc_dev_download(void* h, const void* d, int64_t bytes);
  * min(tol,width) bases with reversed qualities.  d_woff: offsets of the windows (n+1). */
 int sarlacc_dev_windows(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
                         const int64_t* d_woff, int which, uint8_t* d_oseq, uint8_t* d_oqual, void* stream);
+/* realizeReads on resident reads (R/realizeReads.R:28-43): output r = read d_idx[r] (0-based),
+ * reverse-complemented when d_rev[r] != 0 (qualities reversed), cut to the oriented positions
+ * d_tstart[r] .. d_tstart[r] + width - 1 (1-based), widths given by the output offsets d_ooff. */
+int sarlacc_dev_realize(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, const int64_t* d_idx,
+                        const uint8_t* d_rev, const int32_t* d_tstart, int64_t n_out, const int64_t* d_ooff,
+                        uint8_t* d_oseq, uint8_t* d_oqual, void* stream);
 /* Per-read Fisher-Yates shuffle (bases and qualities together), splitmix64 stream per read. */
 int sarlacc_dev_scramble(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
                          uint64_t seed, uint8_t* d_oseq, uint8_t* d_oqual, void* stream);

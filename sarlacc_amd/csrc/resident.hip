@@ -40,6 +40,31 @@ __global__ void k_windows(const uint8_t* seq, const uint8_t* qual, const int64_t
     }
 }
 
+// realizeReads (R/realizeReads.R:28-43): output r is read idx[r], reverse-complemented when
+// rev[r] (qualities reversed), then cut to the 1-based inclusive range [tstart[r], tend[r]] of
+// the oriented read; ooff are the offsets of the outputs.
+__global__ void k_realize(const uint8_t* seq, const uint8_t* qual, const int64_t* off, const int64_t* idx,
+                          const uint8_t* rev, const int32_t* tstart, long long nout, const int64_t* ooff,
+                          uint8_t* oseq, uint8_t* oqual) {
+    const long long r = blockIdx.x;
+    if (r >= nout) return;
+    const long long src = idx[r];
+    const long long s = off[src], L = off[src + 1] - s;
+    const long long o0 = ooff[r], w = ooff[r + 1] - o0;
+    const long long q0 = tstart[r] - 1;
+    const bool flip = rev[r] != 0;
+    for (long long p = threadIdx.x; p < w; p += blockDim.x) {
+        const long long q = q0 + p;   // position in the oriented read
+        if (flip) {
+            oseq[o0 + p] = complement_base(seq[s + L - 1 - q]);
+            oqual[o0 + p] = qual[s + L - 1 - q];
+        } else {
+            oseq[o0 + p] = seq[s + q];
+            oqual[o0 + p] = qual[s + q];
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long& x) {
     x += 0x9E3779B97F4A7C15ull;
     unsigned long long z = x;
@@ -95,6 +120,18 @@ int sarlacc_dev_upload(void* d, const void* h, int64_t bytes) {
 int sarlacc_dev_download(void* h, const void* d, int64_t bytes) {
     SL_TRY(ensure_device());
     if (bytes > 0) SL_HIP(hipMemcpy(h, d, static_cast<size_t>(bytes), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sarlacc_dev_realize(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, const int64_t* d_idx,
+                        const uint8_t* d_rev, const int32_t* d_tstart, int64_t n_out, const int64_t* d_ooff,
+                        uint8_t* d_oseq, uint8_t* d_oqual, void* stream) {
+    if (n_out < 0) return fail("sarlacc_amd: bad realize request");
+    if (n_out == 0) return 0;
+    SL_TRY(ensure_device());
+    hipLaunchKernelGGL(k_realize, dim3(static_cast<unsigned>(n_out)), dim3(128), 0, static_cast<hipStream_t>(stream), d_seq,
+                       d_qual, d_off, d_idx, d_rev, d_tstart, static_cast<long long>(n_out), d_ooff, d_oseq, d_oqual);
+    SL_HIP(hipGetLastError());
     return 0;
 }
 

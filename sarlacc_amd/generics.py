@@ -199,6 +199,80 @@ def adaptorAlign(adaptor1, adaptor2, reads, tolerance=250, gapOpening=5, gapExte
 
 
 # ---------------------------------------------------------------------------
+def _subset_aligned(aligned, keep):
+    """aligned[keep, ] of the reference's DataFrame (rows of every column, nested ones included)."""
+    keep = np.asarray(keep, dtype=bool)
+    out = {"metadata": aligned["metadata"], "read.width": aligned["read.width"][keep], "reversed": aligned["reversed"][keep],
+           "names": None if aligned.get("names") is None else [x for x, k in zip(aligned["names"], keep) if k]}
+    for key in ("adaptor1", "adaptor2"):
+        a = aligned[key]
+        out[key] = {"score": a["score"][keep], "start": a["start"][keep], "end": a["end"][keep], "metadata": a.get("metadata"),
+                    "subseq": {k: [x for x, kk in zip(v, keep) if kk] for k, v in a["subseq"].items()}}
+    for extra in ("trim.start", "trim.end"):
+        if extra in aligned:
+            out[extra] = aligned[extra][keep]
+    return out
+
+
+def filterReads(aligned, score1, score2, essential1=True, essential2=True):
+    """filterReads (R/filterReads.R:2-43): drop reads whose essential adaptors score below the
+    thresholds, then record the cut points between the adaptors as trim.start / trim.end."""
+    n = len(aligned["read.width"])
+    id1 = aligned["adaptor1"]["score"] >= score1 if essential1 else np.ones(n, bool)
+    id2 = aligned["adaptor2"]["score"] >= score2 if essential2 else np.ones(n, bool)
+    aligned = _subset_aligned(aligned, id1 & id2)
+    start_point = np.ones(len(aligned["read.width"]), np.int32)
+    has1 = aligned["adaptor1"]["score"] >= score1
+    start_point[has1] = aligned["adaptor1"]["end"][has1] + 1
+    end_point = aligned["read.width"].astype(np.int32).copy()
+    has2 = aligned["adaptor2"]["score"] >= score2
+    end_point[has2] = aligned["adaptor2"]["end"][has2] - 1
+    keep = start_point < end_point
+    out = _subset_aligned(aligned, keep)
+    out["trim.start"], out["trim.end"] = start_point[keep], end_point[keep]
+    return out
+
+
+def realizeReads(aligned, trim=True, resident=False):
+    """realizeReads (R/realizeReads.R:5-46): the reads named in `aligned`, re-read from its FASTQ
+    file, reverse-complemented where `reversed` and trimmed to [trim.start, trim.end].  The file is
+    parsed on the device and the orientation / trimming happen there (DeviceReads.realize); the
+    result comes back as Reads, or stays in HBM with resident=True."""
+    import warnings
+    from .resident import DeviceReads
+    dev = DeviceReads.from_fastq(aligned["metadata"]["filepath"])
+    where = {}
+    for i, nm in enumerate(dev.names):
+        where.setdefault(nm, i)   # match(): first occurrence
+    try:
+        idx = np.array([where[nm] for nm in aligned["names"]], dtype=np.int64)
+    except KeyError:
+        raise ValueError("read names in 'aligned' not present in FASTQ file")
+    ts = te = None
+    if trim:
+        if "trim.start" in aligned:
+            ts, te = aligned["trim.start"], aligned["trim.end"]
+        else:
+            warnings.warn("no 'trim.start' detected, run 'filterReads' first")
+    out = dev.realize(idx, aligned["reversed"], ts, te)
+    out.names = list(aligned["names"])
+    if resident:
+        return out
+    seq, qual = out.download()
+    return Reads(seq, qual, out.names, dev.encoding)
+
+
+def getBarcodeThresholds(baligned, nmads=3):
+    """getBarcodeThresholds (R/getBarcodeThresholds.R:2-15): outlier thresholds on the barcode
+    score and on its gap to the next best, median - nmads * MAD (R's mad(): constant 1.4826)."""
+    def lower(x):
+        x = np.asarray(x, dtype=np.float64)
+        med = np.median(x)
+        return med - nmads * 1.4826 * np.median(np.abs(x - med))
+    return {"score": lower(baligned["score"]), "gap": lower(baligned["gap"])}
+
+
+# ---------------------------------------------------------------------------
 def barcodeAlign(sequences, barcodes, gapOpening=5, gapExtension=1):
     """barcodeAlign (R/barcodeAlign.R:4-40): best barcode, its score, and the gap to the next best.
     The barcode reads are uploaded once and stay resident while every candidate is aligned

@@ -110,6 +110,27 @@ class DeviceReads:
             out.append(d)
         return out[0], out[1]
 
+    def realize(self, idx, reversed_, trim_start=None, trim_end=None):
+        """Reads `idx` (0-based) of this batch, reverse-complemented where `reversed_`, cut to the
+        1-based inclusive [trim_start, trim_end] of the oriented read (whole read when None):
+        the device half of realizeReads (R/realizeReads.R:28-43)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        rev = np.ascontiguousarray(reversed_, dtype=np.uint8)
+        w = np.diff(self.off_host)[idx]
+        ts = np.ones(idx.size, np.int32) if trim_start is None else np.ascontiguousarray(trim_start, dtype=np.int32)
+        te = w.astype(np.int32) if trim_end is None else np.ascontiguousarray(trim_end, dtype=np.int32)
+        if idx.size and ((ts < 1).any() or (te > w).any()):
+            raise _lib.SarlaccError("trim coordinates outside the read")
+        ow = np.maximum(te.astype(np.int64) - ts + 1, 0)
+        ooff = np.zeros(idx.size + 1, np.int64)
+        np.cumsum(ow, out=ooff[1:])
+        d = self._like(ooff)
+        if idx.size:
+            d_idx, d_rev, d_ts = DevBuffer.from_numpy(idx), DevBuffer.from_numpy(rev), DevBuffer.from_numpy(ts)   # kept alive over the call
+            check(_lib.lib().sarlacc_dev_realize(self.seq.ptr, self.qual.ptr, self.off.ptr, d_idx.ptr, d_rev.ptr, d_ts.ptr,
+                                                 C.c_int64(idx.size), d.off.ptr, d.seq.ptr, d.qual.ptr, None))
+        return d
+
     def scramble(self, seed):
         """.scramble_input (R/getAdaptorThresholds.R:68-92) on the device, deterministic in `seed`."""
         d = self._like(self.off_host.copy())

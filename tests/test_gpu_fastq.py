@@ -89,3 +89,47 @@ def test_adaptor_align_from_fastq_path(tmp_path):
         assert np.array_equal(a[key]["score"].view(np.int64), b[key]["score"].view(np.int64))
         assert np.array_equal(a[key]["start"], b[key]["start"]) and np.array_equal(a[key]["end"], b[key]["end"])
         assert a[key]["subseq"] == b[key]["subseq"]
+
+
+def test_filter_and_realize_reads(tmp_path):
+    """filterReads + realizeReads (R/filterReads.R, R/realizeReads.R) on the adaptorAlign(filepath)
+    result: the device orientation + trimming against the same operations on host strings."""
+    from sarlacc_amd import generics as G
+    from sarlacc_amd.mock import _COMP, mock_reads
+    sim = mock_reads(A1, A2, nmolecules=15, nreads=6, seqlen=300, seed=7)
+    reads = G.Reads(sim["reads"], sim["quals"], ["READ_%d" % (i + 1) for i in range(len(sim["reads"]))])
+    path = tmp_path / "mock.fastq"
+    G.write_fastq(str(path), reads)
+    aln = G.adaptorAlign(A1, A2, str(path), tolerance=120)
+    filt = G.filterReads(aln, 6, 6)
+    n0, n1 = len(aln["read.width"]), len(filt["read.width"])
+    assert 0 < n1 <= n0
+    # restatement of R/filterReads.R on the unfiltered table
+    s1, s2 = aln["adaptor1"]["score"], aln["adaptor2"]["score"]
+    keep = (s1 >= 6) & (s2 >= 6)
+    start = np.where(s1 >= 6, aln["adaptor1"]["end"] + 1, 1)
+    end = np.where(s2 >= 6, aln["adaptor2"]["end"] - 1, aln["read.width"])
+    keep &= start < end
+    assert filt["names"] == [nm for nm, k in zip(aln["names"], keep) if k]
+    assert np.array_equal(filt["trim.start"], start[keep]) and np.array_equal(filt["trim.end"], end[keep])
+    # realizeReads: reverse-complement + trim
+    seqs, quals = reads.seq.to_strings(), reads.qual.to_strings()
+    where = {nm: i for i, nm in enumerate(reads.names)}
+    comp = {chr(i): chr(_COMP[i]) for i in range(256)}
+    got = G.realizeReads(filt)
+    assert got.names == filt["names"]
+    for k, nm in enumerate(filt["names"]):
+        s, q = seqs[where[nm]], quals[where[nm]]
+        if filt["reversed"][k]:
+            s, q = "".join(comp[c] for c in reversed(s)), q[::-1]
+        a, b = int(filt["trim.start"][k]), int(filt["trim.end"][k])
+        assert got.seq[k] == s[a - 1:b] and got.qual[k] == q[a - 1:b], (k, nm)
+    # untrimmed, resident
+    with pytest.warns(UserWarning, match="run 'filterReads' first"):
+        whole = G.realizeReads(aln)
+    assert [len(x) for x in whole.seq.to_strings()] == aln["read.width"].tolist()
+    res = G.realizeReads(filt, resident=True)
+    assert res.download()[0].to_strings() == got.seq.to_strings()
+    bad = dict(filt, names=["nope"] + filt["names"][1:])
+    with pytest.raises(ValueError, match="not present in FASTQ file"):
+        G.realizeReads(bad)
