@@ -38,6 +38,7 @@ struct ConsArgs {
     const int32_t* row_read;   // optional: 1-based read id of every row (qualities stay in read order)
     const double* right;       // [navail] log1p(-e)
     const double* wrong;       // [navail] log(e/3)
+    const double* vec;         // k_consensus_q4: [(5 * navail + 1)][4] per-(read character, quality) additions to the A,C,G,T scores
     int qoffset, navail, max_rows;
     double mincov, pseudo, ln10;
     const int64_t* out_off;    // [ngroups] start of the group's output (= offset of its first row)
@@ -233,6 +234,221 @@ __global__ void __launch_bounds__(64) k_consensus(const ConsArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_consensus_q4: the quality-weighted vote with 4 columns per lane.
+//
+// Same arithmetic as k_consensus<true> (rows in order, so every per-column fp64 sum adds the
+// reference's terms in the reference's order) but laid out for bandwidth: a wavefront covers
+// 256 columns per step, a lane reads its 4 alignment characters of a row with one (unaligned)
+// dword load and, because the non-gap characters of a lane are consecutive in the ungapped
+// quality string, their qualities with one more; rows are fetched in batches so several loads
+// are in flight.  The (character, quality) -> four additions map is a table of 32-byte vectors
+// in LDS shared by the 4 wavefronts of a workgroup (two ds_read_b128 + four v_add_f64 per cell;
+// gaps, N and out-of-range positions read a zero vector, which leaves the sums bit-identical).
+// The per-column error needs three log1pexp: they are first evaluated with the hardware fp32
+// exp/log (absolute error < 1e-5 in the log-error), which decides the Phred character unless
+// the value lies within 2e-4 of a rounding boundary; only those columns take the fp64 path,
+// and columns within 1e-9 of a boundary go to the host libm as before.
+typedef uint32_t __attribute__((aligned(1))) cons_u32_unaligned;
+
+__device__ __forceinline__ double fast_log1pexp(double x) {
+    if (x > 33.3) return x;
+    if (x > 18.) return x + static_cast<double>(__expf(static_cast<float>(-x)));
+    const float y = __expf(static_cast<float>(x));
+    return static_cast<double>(__logf(1.0f + y));
+}
+
+constexpr int Q4_RB = 5;   // rows fetched per batch
+
+__global__ void __launch_bounds__(256) k_consensus_q4(const ConsArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int nvec = 5 * A.navail + 1;
+    double* const s_vec = reinterpret_cast<double*>(smem);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    long long* const s_roff = reinterpret_cast<long long*>(s_vec + 4 * nvec) + wave * 2 * A.max_rows;
+    long long* const s_qoff = s_roff + A.max_rows;
+    int* const s_int = reinterpret_cast<int*>(reinterpret_cast<long long*>(s_vec + 4 * nvec) + 4 * 2 * A.max_rows) + wave * 3 * A.max_rows;
+    int* const s_qlen = s_int;
+    int* const s_pos = s_int + A.max_rows;
+    int* const s_bad = s_int + 2 * A.max_rows;
+    for (int x = threadIdx.x; x < 4 * nvec; x += 256) s_vec[x] = A.vec[x];
+    __syncthreads();
+    const int zero_entry = 5 * A.navail;
+
+    for (long long g = static_cast<long long>(blockIdx.x) * 4 + wave; g < A.ngroups; g += static_cast<long long>(gridDim.x) * 4) {
+        const long long row0 = A.grp_rows[g];
+        const int nrows = static_cast<int>(A.grp_rows[g + 1] - row0);
+        if (nrows == 0) {
+            if (lane == 0) A.cons_len[g] = 0;
+            continue;
+        }
+        const long long W = A.aln_off[row0 + 1] - A.aln_off[row0];
+        const double thresh = static_cast<double>(nrows) * A.mincov;
+        const long long obase = A.out_off[g];
+        for (int r = lane; r < nrows; r += 64) {
+            s_pos[r] = 0;
+            s_bad[r] = 0;
+            s_roff[r] = A.aln_off[row0 + r];
+            const long long q = A.row_read ? A.row_read[row0 + r] - 1 : row0 + r;
+            s_qoff[r] = A.qual_off[q];
+            s_qlen[r] = static_cast<int>(A.qual_off[q + 1] - A.qual_off[q]);
+        }
+        int outpos = 0;
+
+        for (long long c0 = 0; c0 < W; c0 += 256) {
+            const long long col = c0 + 4 * lane;
+            const long long remain = W - col;          // characters of the row at and after `col`
+            double acc[4][4];
+            int inc[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { inc[k] = 0; acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0; }
+
+            for (int r0 = 0; r0 < nrows; r0 += Q4_RB) {
+                uint32_t aw[Q4_RB], qw[Q4_RB];
+                int pq[Q4_RB];
+#pragma unroll
+                for (int b = 0; b < Q4_RB; ++b) {
+                    const int r = r0 + b;
+                    uint32_t v = 0x2d2d2d2du;   // "----"
+                    if (r < nrows && remain > 0) {
+                        const uint8_t* src = A.aln + s_roff[r] + col;
+                        if (remain >= 4) v = *reinterpret_cast<const cons_u32_unaligned*>(src);
+                        else
+                            for (int k = 0; k < remain; ++k) v = (v & ~(0xffu << (8 * k))) | (static_cast<uint32_t>(src[k]) << (8 * k));
+                    }
+                    aw[b] = v;
+                }
+#pragma unroll
+                for (int b = 0; b < Q4_RB; ++b) {
+                    const int r = r0 + b;
+                    // position of this lane's first non-gap character in the row's ungapped string
+                    int below = 0, total = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned long long m = __ballot(((aw[b] >> (8 * k)) & 0xffu) != 0x2du);
+                        below += __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), 0));
+                        total += __popcll(m);
+                    }
+                    pq[b] = 0;
+                    if (r < nrows) {
+                        pq[b] = s_pos[r] + below;
+                        if (lane == 0) s_pos[r] += total;
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < Q4_RB; ++b) {
+                    const int r = r0 + b;
+                    uint32_t v = 0;
+                    if (r < nrows) {
+                        const int avail = s_qlen[r] - pq[b];
+                        if (avail > 0) {
+                            const uint8_t* src = A.qual + s_qoff[r] + pq[b];
+                            if (avail >= 4) v = *reinterpret_cast<const cons_u32_unaligned*>(src);
+                            else
+                                for (int k = 0; k < avail; ++k) v |= static_cast<uint32_t>(src[k]) << (8 * k);
+                        }
+                    }
+                    qw[b] = v;
+                }
+#pragma unroll
+                for (int b = 0; b < Q4_RB; ++b) {
+                    const int r = r0 + b;
+                    if (r >= nrows) break;
+                    const int avail = s_qlen[r] - pq[b];
+                    int jq = 0;   // non-gap characters of this lane seen so far
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t c = (aw[b] >> (8 * k)) & 0xffu;
+                        int entry = zero_entry;
+                        if (c != 0x2du) {
+                            ++inc[k];
+                            if (c != 'N' && jq < avail) {
+                                int qi = static_cast<int>(static_cast<signed char>((qw[b] >> (8 * jq)) & 0xffu)) - A.qoffset;
+                                if (qi < 0) { s_bad[r] = 1; qi = 0; }
+                                if (qi >= A.navail) qi = A.navail - 1;
+                                const int code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
+                                entry = code * A.navail + qi;
+                            }
+                            ++jq;
+                        }
+                        const double* vp = s_vec + 4 * entry;
+                        acc[k][0] += vp[0]; acc[k][1] += vp[1]; acc[k][2] += vp[2]; acc[k][3] += vp[3];
+                    }
+                }
+            }
+
+            // ---- per-column result ----
+            int nkept = 0;
+            int below_kept = 0;
+            bool keepk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                keepk[k] = (k < remain) && !(inc[k] < thresh);
+                const unsigned long long m = __ballot(keepk[k]);
+                below_kept += __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), 0));
+                nkept += __popcll(m);
+            }
+            int o = outpos + below_kept;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!keepk[k]) continue;
+                const double sA = acc[k][0], sC = acc[k][1], sG = acc[k][2], sT = acc[k][3];
+                int best = 0;
+                double bv = sA;
+                if (sC > bv) { bv = sC; best = 1; }
+                if (sG > bv) { bv = sG; best = 2; }
+                if (sT > bv) { bv = sT; best = 3; }
+                double a = sA, b = sC, c = sG, d = sT, t;
+                if (a > b) { t = a; a = b; b = t; }
+                if (c > d) { t = c; c = d; d = t; }
+                if (a > c) { t = a; a = c; c = t; }
+                if (b > d) { t = b; b = d; d = t; }
+                if (b > c) { t = b; b = c; c = t; }
+                double denom = a;
+                denom += fast_log1pexp(b - denom);
+                denom += fast_log1pexp(c - denom);
+                double err3 = denom;
+                denom += fast_log1pexp(d - denom);
+                double le = err3 - denom;
+                double x = -10 * le / A.ln10;
+                double frac = x - floor(x);
+                bool near = false;
+                if (x < 93.4 && fabs(frac - 0.5) < 2e-4) {   // too close for the fp32 estimate: exact fp64 evaluation
+                    denom = a;
+                    denom += dev_log1pexp(b - denom);
+                    denom += dev_log1pexp(c - denom);
+                    err3 = denom;
+                    denom += dev_log1pexp(d - denom);
+                    le = err3 - denom;
+                    x = -10 * le / A.ln10;
+                    frac = x - floor(x);
+                    near = x < 93.4 && fabs(frac - 0.5) < 1e-9;
+                }
+                double qv = round(x);
+                if (qv > 93.0) qv = 93.0;
+                A.cons[obase + o] = "ACGT"[best];
+                A.phred[obase + o] = static_cast<uint8_t>(static_cast<int>(qv) + 33);
+                if (near) {
+                    const int slot = atomicAdd(A.fix_count, 1);
+                    if (slot < A.fix_cap) {
+                        A.fix_pos[slot] = obase + o;
+                        A.fix_val[4 * slot + 0] = a; A.fix_val[4 * slot + 1] = b;
+                        A.fix_val[4 * slot + 2] = c; A.fix_val[4 * slot + 3] = d;
+                    }
+                }
+                ++o;
+            }
+            outpos += nkept;
+        }
+        if (lane == 0) A.cons_len[g] = outpos;
+        for (int r = lane; r < nrows; r += 64) {
+            const int qlen = s_qlen[r];
+            const int used = s_pos[r];
+            A.row_status[row0 + r] = s_bad[r] ? 1 : (used == qlen ? 0 : (used > qlen ? 2 : 3));
+        }
+    }
+}
+
 // kept columns of every alignment -> contiguous output (one block per alignment)
 __global__ void k_consensus_compact(const uint8_t* cons, const uint8_t* phred, const double* lerr, const int64_t* out_off,
                                     const int32_t* len, const long long* dst_off, long long ngroups, uint8_t* dcons,
@@ -284,6 +500,16 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         SL_TRY(upload("cons.right", right.data(), right.size(), &d_r, s));
         SL_TRY(upload("cons.wrong", wrong.data(), wrong.size(), &d_w, s));
         a.right = d_r; a.wrong = d_w;
+        // k_consensus_q4: what a cell adds to (A, C, G, T) by read character (A, C, G, T, other) and
+        // quality; the last entry (gap, N, no quality left) adds nothing
+        std::vector<double> vec(static_cast<size_t>(5 * enc_n + 1) * 4, 0.0);
+        for (int code = 0; code < 5; ++code)
+            for (int k = 0; k < enc_n; ++k)
+                for (int bidx = 0; bidx < 4; ++bidx)
+                    vec[(static_cast<size_t>(code) * enc_n + k) * 4 + bidx] = (bidx == code) ? right[k] : wrong[k];
+        double* d_vec;
+        SL_TRY(upload("cons.vec", vec.data(), vec.size(), &d_vec, s));
+        a.vec = d_vec;
         a.qoffset = static_cast<int>(enc_names[0]); a.navail = enc_n;
     }
     a.ngroups = ng_eval;
@@ -312,8 +538,14 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         const size_t lds = (quality ? 2 * sizeof(double) * enc_n : 0) + (2 * sizeof(long long) + 3 * sizeof(int)) * static_cast<size_t>(max_rows) + 16;
         if (lds > 160 * 1024) return fail("sarlacc_amd: alignment with %d rows does not fit the consensus kernel", max_rows);
         const int grid = static_cast<int>(std::min<int64_t>(ng_eval, static_cast<int64_t>(c.num_cu) * 32));
+        // quality vote without the per-column log errors: 4 columns per lane, 4 alignments per workgroup
+        const size_t lds4 = sizeof(double) * 4 * (5 * static_cast<size_t>(enc_n) + 1) + 4 * (2 * sizeof(long long) + 3 * sizeof(int)) * static_cast<size_t>(max_rows) + 16;
+        const bool q4 = quality && !lerr && lds4 <= 48 * 1024 && !std::getenv("SARLACC_CONSENSUS_NARROW");
         SL_HIP(hipEventRecord(c.ev_start, s));
-        if (quality) hipLaunchKernelGGL(k_consensus<true>, dim3(grid), dim3(64), lds, s, a);
+        if (q4) {
+            const int grid4 = static_cast<int>(std::min<int64_t>((ng_eval + 3) / 4, static_cast<int64_t>(c.num_cu) * 8));
+            hipLaunchKernelGGL(k_consensus_q4, dim3(grid4), dim3(256), lds4, s, a);
+        } else if (quality) hipLaunchKernelGGL(k_consensus<true>, dim3(grid), dim3(64), lds, s, a);
         else hipLaunchKernelGGL(k_consensus<false>, dim3(grid), dim3(64), lds, s, a);
         SL_HIP(hipGetLastError());
         SL_HIP(hipEventRecord(c.ev_stop, s));
