@@ -165,7 +165,91 @@ struct PairArgs {
     unsigned long long* count;
     unsigned long long cap;
     int tile_lo;                    // first row tile of this launch (row tiles shard across GPUs)
+    const uint32_t* tile_list;      // optional: the (row tile << 16 | column tile) pairs to search, one per block
 };
+
+// ---------------------------------------------------------------------------
+// Tile-level prefilter.  Inside a pre-group the elements are in trie (lexicographic) order, so
+// the 256 strings of a tile share the common prefix of its first and last element.  A pair
+// (s in row tile, t in column tile) within `L` edits aligns s[0..m) with some t[0..m'),
+// |m - m'| <= L, at a cost <= L; with m <= |P_R| and m + L <= |P_C| both prefixes are known from
+// the tiles alone, so whole tile pairs are discarded when no such m' exists -- exactly, because
+// only pairs that cannot be neighbours are skipped.  Tiles that hold an N (a masked base costs
+// half an edit) or span two pre-groups carry no prefix and are never discarded.
+struct TileInfo {
+    unsigned long long pcode;   // common prefix, 2 bits per base from bit 0
+    int plen;                   // its length; -1: no information
+};
+
+__global__ void __launch_bounds__(TILE) k_tile_info(UmiArrays U, const int* gid, int n, TileInfo* info) {
+    const int t0 = blockIdx.x * TILE, t1 = min(t0 + TILE, n) - 1;
+    const int i = t0 + threadIdx.x;
+    const uint32_t nm = i < n ? U.nmask[i] : 0u;
+    const int anyN = __syncthreads_or(nm != 0u);
+    if (threadIdx.x != 0) return;
+    TileInfo ti{0ull, -1};
+    if (!anyN && (!gid || gid[t0] == gid[t1])) {
+        const unsigned long long a = U.code[t0], b = U.code[t1];
+        const int la = U.meta[t0] & 0xff, lb = U.meta[t1] & 0xff;
+        const unsigned long long x = a ^ b;
+        int cp = x ? (__builtin_ctzll(x) >> 1) : 32;
+        cp = min(cp, min(la, lb));
+        ti.plen = cp;
+        ti.pcode = cp >= 32 ? a : (a & ((1ull << (2 * cp)) - 1ull));
+    }
+    info[blockIdx.x] = ti;
+}
+
+// min over m' in [m - L, m + L] of the edit distance between x[0..m) and y[0..m') (unit costs),
+// y known to at least m + L bases; > L is reported as L + 1.
+template <int L>
+__device__ __forceinline__ int prefix_dist(unsigned long long x, int m, unsigned long long y) {
+    constexpr int BW = 2 * L + 1;
+    int v[BW];   // v[d]: D[i][i + d - L]
+#pragma unroll
+    for (int d = 0; d < BW; ++d) v[d] = (d >= L) ? d - L : (L + 1);   // row 0: D[0][j] = j
+    for (int i = 1; i <= m; ++i) {
+        const unsigned xi = static_cast<unsigned>(x >> (2 * (i - 1))) & 3u;
+        int left = L + 1;
+#pragma unroll
+        for (int d = 0; d < BW; ++d) {
+            const int j = i + d - L;
+            int best = L + 1;
+            if (j == 0) best = i;
+            else if (j > 0) {
+                const unsigned yj = static_cast<unsigned>(y >> (2 * (j - 1))) & 3u;
+                best = v[d] + (xi == yj ? 0 : 1);                 // D[i-1][j-1]
+                if (d + 1 < BW) best = min(best, v[d + 1] + 1);   // D[i-1][j]
+                best = min(best, left + 1);                        // D[i][j-1]
+            }
+            best = min(best, L + 1);
+            v[d] = best;
+            left = best;
+        }
+    }
+    int res = L + 1;
+#pragma unroll
+    for (int d = 0; d < BW; ++d) res = min(res, v[d]);
+    return res;
+}
+
+template <int L>
+__global__ void k_tile_pairs(const TileInfo* info, int nt, int tile_lo, int tile_hi, uint32_t* list, unsigned int* count) {
+    const int bj = blockIdx.x * blockDim.x + threadIdx.x;
+    const int bi = blockIdx.y + tile_lo;
+    if (bi >= tile_hi || bj >= nt || bj < bi) return;
+    bool keep = true;
+    if (bj != bi) {
+        const TileInfo R = info[bi], C = info[bj];
+        if (R.plen >= 0 && C.plen >= 0) {
+            // either orientation may prove that the tiles hold no neighbours
+            const int m1 = min(R.plen, C.plen - L), m2 = min(C.plen, R.plen - L);
+            if (m1 > L && prefix_dist<L>(R.pcode, m1, C.pcode) > L) keep = false;
+            if (keep && m2 > L && prefix_dist<L>(C.pcode, m2, R.pcode) > L) keep = false;
+        }
+    }
+    if (keep) list[atomicAdd(count, 1u)] = (static_cast<uint32_t>(bi) << 16) | static_cast<uint32_t>(bj);
+}
 
 // Shifted-Hamming lower bound for N-free pairs: a position of `a` that differs from b at every
 // shift -K..K cannot be matched by any alignment within the band, so it costs a substitution or
@@ -192,7 +276,8 @@ __device__ __forceinline__ bool shd_reject(unsigned long long ca, int la, unsign
 
 template <int K>
 __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
-    const int bi = blockIdx.x + A.tile_lo, bj = blockIdx.y;
+    int bi = blockIdx.x + A.tile_lo, bj = blockIdx.y;
+    if (A.tile_list) { const uint32_t e = A.tile_list[blockIdx.x]; bi = static_cast<int>(e >> 16); bj = static_cast<int>(e & 0xffffu); }
     if (bj < bi) return;
     // column tile (c*) and row tile (r*) both live in LDS: survivors of the cheap filters are
     // queued per wave and evaluated 64 at a time, so the exact DP always runs on full waves
@@ -635,10 +720,20 @@ static int encode_and_rank(const std::string& p, const uint8_t* d_chars, const i
 }
 
 template <int K>
-static void launch_pairs(const PairArgs& a, int tile_hi, hipStream_t s) {
+static void launch_pairs(const PairArgs& a, int tile_hi, unsigned ntiles_listed, hipStream_t s) {
     const unsigned nt = nblk(a.n, TILE);
     if (tile_hi <= a.tile_lo) return;
+    if (a.tile_list) {
+        if (ntiles_listed) hipLaunchKernelGGL(k_umi_pairs<K>, dim3(ntiles_listed), dim3(TILE), 0, s, a);
+        return;
+    }
     hipLaunchKernelGGL(k_umi_pairs<K>, dim3(static_cast<unsigned>(tile_hi - a.tile_lo), nt), dim3(TILE), 0, s, a);
+}
+
+template <int L>
+static void launch_tile_pairs(const TileInfo* info, int nt, int tile_lo, int tile_hi, uint32_t* list, unsigned int* count, hipStream_t s) {
+    hipLaunchKernelGGL(k_tile_pairs<L>, dim3(nblk(nt, 256), static_cast<unsigned>(tile_hi - tile_lo)), dim3(256), 0, s, info, nt,
+                       tile_lo, tile_hi, list, count);
 }
 
 struct DirectedKeys {
@@ -669,23 +764,49 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
         SL_TRY(c.buffer((p + ".edges").c_str(), cap * sizeof(unsigned long long), &pe));
         d_edges = static_cast<unsigned long long*>(pe);
     }
+    // tile pairs that can hold neighbours (see k_tile_pairs); worth it from a few dozen tiles on
+    const uint32_t* d_list = nullptr;
+    unsigned int nlisted = 0;
+    const long long ntp = static_cast<long long>(tile_hi - tile_lo) * nt;
+    if (limit >= 0 && limit <= 5 && nt >= 16 && ntp <= (1ll << 31) && !std::getenv("SARLACC_UMI_ALLTILES")) {
+        TileInfo* d_info; uint32_t* d_l; unsigned int* d_lc;
+        SL_TRY(scratch((p + ".tinfo").c_str(), static_cast<size_t>(nt), &d_info));
+        // the list is bounded by the upper triangle of the launch
+        const size_t max_list = static_cast<size_t>(tile_hi - tile_lo) * static_cast<size_t>(nt);
+        SL_TRY(scratch((p + ".tlist").c_str(), max_list, &d_l));
+        SL_TRY(scratch((p + ".tcount").c_str(), 1, &d_lc));
+        SL_HIP(hipMemsetAsync(d_lc, 0, sizeof(unsigned int), s));
+        hipLaunchKernelGGL(k_tile_info, dim3(static_cast<unsigned>(nt)), dim3(TILE), 0, s, S.U, S.gid, n, d_info);
+        switch (limit) {
+            case 0: launch_tile_pairs<0>(d_info, nt, tile_lo, tile_hi, d_l, d_lc, s); break;
+            case 1: launch_tile_pairs<1>(d_info, nt, tile_lo, tile_hi, d_l, d_lc, s); break;
+            case 2: launch_tile_pairs<2>(d_info, nt, tile_lo, tile_hi, d_l, d_lc, s); break;
+            case 3: launch_tile_pairs<3>(d_info, nt, tile_lo, tile_hi, d_l, d_lc, s); break;
+            case 4: launch_tile_pairs<4>(d_info, nt, tile_lo, tile_hi, d_l, d_lc, s); break;
+            default: launch_tile_pairs<5>(d_info, nt, tile_lo, tile_hi, d_l, d_lc, s); break;
+        }
+        SL_HIP(hipGetLastError());
+        SL_HIP(hipMemcpyAsync(&nlisted, d_lc, sizeof nlisted, hipMemcpyDeviceToHost, s));
+        SL_HIP(hipStreamSynchronize(s));
+        d_list = d_l;
+    }
     for (int attempt = 0; attempt < 2 && limit >= 0; ++attempt) {
         void* pe;
         SL_TRY(c.buffer((p + ".edges").c_str(), cap * sizeof(unsigned long long), &pe));
         d_edges = static_cast<unsigned long long*>(pe);
         SL_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
-        PairArgs a{S.U, S.gid, n, lim2, d_edges, d_count, cap, tile_lo};
+        PairArgs a{S.U, S.gid, n, lim2, d_edges, d_count, cap, tile_lo, d_list};
         SL_HIP(hipEventRecord(c.ev_start, s));
         const int K = std::min(limit, UMI_MAXLEN);
-        if (K <= 0) launch_pairs<0>(a, tile_hi, s);
-        else if (K == 1) launch_pairs<1>(a, tile_hi, s);
-        else if (K == 2) launch_pairs<2>(a, tile_hi, s);
-        else if (K == 3) launch_pairs<3>(a, tile_hi, s);
-        else if (K == 4) launch_pairs<4>(a, tile_hi, s);
-        else if (K == 5) launch_pairs<5>(a, tile_hi, s);
-        else if (K <= 8) launch_pairs<8>(a, tile_hi, s);
-        else if (K <= 16) launch_pairs<16>(a, tile_hi, s);
-        else launch_pairs<UMI_MAXLEN>(a, tile_hi, s);
+        if (K <= 0) launch_pairs<0>(a, tile_hi, nlisted, s);
+        else if (K == 1) launch_pairs<1>(a, tile_hi, nlisted, s);
+        else if (K == 2) launch_pairs<2>(a, tile_hi, nlisted, s);
+        else if (K == 3) launch_pairs<3>(a, tile_hi, nlisted, s);
+        else if (K == 4) launch_pairs<4>(a, tile_hi, nlisted, s);
+        else if (K == 5) launch_pairs<5>(a, tile_hi, nlisted, s);
+        else if (K <= 8) launch_pairs<8>(a, tile_hi, nlisted, s);
+        else if (K <= 16) launch_pairs<16>(a, tile_hi, nlisted, s);
+        else launch_pairs<UMI_MAXLEN>(a, tile_hi, nlisted, s);
         SL_HIP(hipGetLastError());
         SL_HIP(hipEventRecord(c.ev_stop, s));
         c.timed = true;
