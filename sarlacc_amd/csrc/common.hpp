@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -81,9 +82,11 @@ struct MsaResult {
     uint8_t* d_out = nullptr;       // gapped rows, group after group, equal width inside a group
     int32_t* d_members = nullptr;   // flattened 1-based read ids, one per row
 };
+// `overlap` (optional) runs on the host right after the pairwise kernels are launched, i.e. while
+// they execute: the place for transfers the next stage needs (on a stream of their own).
 int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq, const int64_t* seq_off,
             int64_t nseq, double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
-            bool want_rows, int64_t out_cap, MsaResult* res);
+            bool want_rows, int64_t out_cap, MsaResult* res, const std::function<int()>* overlap = nullptr);
 
 // ---- quality encoding (reference src/quality_encoding.cpp:5-33) -------------
 int check_encoding(const double* errors, const char* names, int n);

@@ -725,7 +725,29 @@ int sarlacc_msa_consensus(const int64_t* grp_off, const int32_t* grp, int64_t ng
     MsaResult res;
     res.width.assign(static_cast<size_t>(ngroups), 0);
     res.out_off.assign(static_cast<size_t>(ngroups) + 1, 0);
-    SL_TRY(msa_run(grp_off, grp, ngroups, seq, seq_off, nseq, match, mismatch, gap_extension, gap_opening, bandwidth, true, -1, &res));
+    // the quality strings travel to the device on a stream of their own while the pairwise
+    // alignments run (qualities stay in read order; every row finds its string through the member list)
+    uint8_t* d_q = nullptr; int64_t* d_qoff = nullptr;
+    hipStream_t copy_stream = nullptr;
+    std::vector<int64_t> qrel;
+    const std::function<int()> upload_quals = [&]() -> int {
+        if (!quality) return 0;
+        const int64_t qbase = qual_off[0];
+        qrel.resize(static_cast<size_t>(nseq) + 1);
+        for (int64_t r = 0; r <= nseq; ++r) qrel[r] = qual_off[r] - qbase;
+        SL_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        SL_TRY(upload("cons.qual", reinterpret_cast<const uint8_t*>(qual) + qbase, static_cast<size_t>(qrel[nseq]), &d_q, copy_stream));
+        SL_TRY(upload("cons.qoff", qrel.data(), qrel.size(), &d_qoff, copy_stream));
+        return 0;
+    };
+    const int msa_rc = msa_run(grp_off, grp, ngroups, seq, seq_off, nseq, match, mismatch, gap_extension, gap_opening, bandwidth, true,
+                               -1, &res, &upload_quals);
+    if (copy_stream) {
+        const hipError_t e1 = hipStreamSynchronize(copy_stream), e2 = hipStreamDestroy(copy_stream);
+        if (!msa_rc && (e1 != hipSuccess || e2 != hipSuccess)) return fail("HIP error while uploading the quality strings");
+    }
+    if (msa_rc) return msa_rc;
+    if (quality && !d_q) return fail("sarlacc_amd: quality upload did not run");
     const int64_t total = res.out_off[ngroups];
     int64_t need = 0;
     for (int64_t g = 0; g < ngroups; ++g) need += res.width[g];
@@ -756,16 +778,7 @@ int sarlacc_msa_consensus(const int64_t* grp_off, const int32_t* grp, int64_t ng
     SL_TRY(upload("cons.grows", grows.data(), grows.size(), &d_grows, s));
     SL_TRY(upload("cons.ooff", out_off.data(), out_off.size(), &d_ooff, s));
     a.aln = res.d_out; a.aln_off = d_aoff; a.grp_rows = d_grows; a.out_off = d_ooff; a.max_rows = max_rows;
-    if (quality) {
-        // qualities stay in read order; every row finds its string through the member list
-        const int64_t qbase = qual_off[0];
-        std::vector<int64_t> qrel(static_cast<size_t>(nseq) + 1);
-        for (int64_t r = 0; r <= nseq; ++r) qrel[r] = qual_off[r] - qbase;
-        uint8_t* d_q; int64_t* d_qoff;
-        SL_TRY(upload("cons.qual", reinterpret_cast<const uint8_t*>(qual) + qbase, static_cast<size_t>(qrel[nseq]), &d_q, s));
-        SL_TRY(upload("cons.qoff", qrel.data(), qrel.size(), &d_qoff, s));
-        a.qual = d_q; a.qual_off = d_qoff; a.row_read = res.d_members;
-    }
+    if (quality) { a.qual = d_q; a.qual_off = d_qoff; a.row_read = res.d_members; }
     return consensus_core(quality, a, ngroups, ngroups, nrows, total, out_off, nullptr, 0, min_cov, pseudo_count, enc_errors,
                           enc_names, enc_n, cons, phred, cons_off, nullptr, s);
 }

@@ -624,7 +624,7 @@ static int launch_pairwise_ad(const MsaArgs& a, int grid, size_t lds, hipStream_
 // sarlacc_quick_msa: widths and offsets are always filled in).
 int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq, const int64_t* seq_off,
             int64_t nseq, double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
-            bool want_rows, int64_t out_cap, MsaResult* res) {
+            bool want_rows, int64_t out_cap, MsaResult* res, const std::function<int()>* overlap) {
     int32_t* width_out = res->width.data();
     int64_t* out_off = res->out_off.data();
     res->d_out = nullptr;
@@ -764,6 +764,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         SL_HIP(hipEventRecord(c.ev_stop, s));
         c.timed = true;
     }
+    if (overlap) SL_TRY((*overlap)());
     MergeArgs m{};
     m.seq = d_seq; m.seq_off = d_soff; m.members = d_mem; m.groups = d_groups; m.jobs = d_jobs; m.ngroups = ngroups;
     m.ins = d_ins; m.aln = d_aln; m.maxins = d_maxins; m.mi_off = d_mioff; m.width = d_width;
