@@ -335,6 +335,10 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
         // Traceback nibble of a cell (raw outcomes, pushed most significant first):
         //   bit 3 F opened (H_left + go >= F_left + ge)   bit 2 E opened   bit 1 e >= f   bit 0 d >= max(e, f)
         // Cells are pushed in the order (parity, h); 8 cells fill one 32-bit chunk `pk`.
+        // Values arriving from the neighbouring lanes.  They are also the DPP destinations: lane 0
+        // (63) has no source lane for the shift, keeps what the register held, and that is the
+        // MSA_NEG it was initialised with -- no re-initialisation per step.
+        int xlH = MSA_NEG, xlF = MSA_NEG, xrH = MSA_NEG, xrE = MSA_NEG;
         auto subblock = [&](auto guard_tag, int t0, uint32_t& pk, uint32_t& pk_hi) {
             constexpr bool GUARD = decltype(guard_tag)::value;
             const int ib = (t0 >> 1) - H2 * lane;            // row of cells k = 0, 1
@@ -358,9 +362,8 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
                 // neighbours across the lane boundary (values of the previous step)
-                int xlH = MSA_NEG, xlF = MSA_NEG, xrH = MSA_NEG, xrE = MSA_NEG;
-                if (par == 0) { xlH = dpp_int<DPP_WAVE_SHR1>(MSA_NEG, Hc[C - 1]); xlF = dpp_int<DPP_WAVE_SHR1>(MSA_NEG, Fc[C - 1]); }
-                else { xrH = dpp_int<DPP_WAVE_SHL1>(MSA_NEG, Hc[0]); xrE = dpp_int<DPP_WAVE_SHL1>(MSA_NEG, Ec[0]); }
+                if (par == 0) { xlH = dpp_int<DPP_WAVE_SHR1>(xlH, Hc[C - 1]); xlF = dpp_int<DPP_WAVE_SHR1>(xlF, Fc[C - 1]); }
+                else { xrH = dpp_int<DPP_WAVE_SHL1>(xrH, Hc[0]); xrE = dpp_int<DPP_WAVE_SHL1>(xrE, Ec[0]); }
                 int nH[H2], nE[H2], nF[H2];
 #pragma unroll
                 for (int h = 0; h < H2; ++h) {
@@ -368,12 +371,16 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
                     const int uH = (k + 1 < C) ? Hc[k + 1] : xrH, uE = (k + 1 < C) ? Ec[k + 1] : xrE;
                     const int lH = (k > 0) ? Hc[k - 1] : xlH, lF = (k > 0) ? Fc[k - 1] : xlF;
                     const int eop = uH + gou[k], eex = uE + geu[k];
-                    int e = max(max(eop, eex), MSA_NEG);
+                    // Interior cells are reachable inside the band, so their scores are finite; the
+                    // "minus infinity" inputs from outside the band are re-derived from constants every
+                    // step and cannot drift, hence no clamping in the unguarded path.
+                    int e = max(eop, eex);
                     const bool eo = eop >= eex;
                     // cell k: row ib - h, column jb + h + par
-                    int d = max(Hc[k] + (rc[h] == cc[h + par] ? ma : mm), MSA_NEG);
+                    int d = Hc[k] + (rc[h] == cc[h + par] ? ma : mm);
                     const int fop = lH + go, fex = lF + ge;
-                    int f = max(max(fop, fex), MSA_NEG);
+                    int f = max(fop, fex);
+                    if (GUARD) { e = max(e, MSA_NEG); d = max(d, MSA_NEG); f = max(f, MSA_NEG); }
                     const bool fo = fop >= fex;
                     bool valid = true;
                     if (GUARD) {
