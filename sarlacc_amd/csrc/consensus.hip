@@ -586,8 +586,10 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
     std::vector<long long> dst(static_cast<size_t>(ngroups) + 1, 0);
     for (int64_t g = 0; g < ngroups; ++g) dst[g + 1] = dst[g] + len[g];
     const long long kept = dst[ngroups];
-    std::vector<uint8_t> hc(static_cast<size_t>(kept) + 1), hp(static_cast<size_t>(kept) + 1);
-    std::vector<double> hl;
+    // results land directly in the caller's buffers (no intermediate host copies)
+    uint8_t* const hc = reinterpret_cast<uint8_t*>(cons);
+    uint8_t* const hp = reinterpret_cast<uint8_t*>(phred);
+    double* const hl = lerr;
     if (kept) {
         long long* d_dst; uint8_t* d_cc; uint8_t* d_cp; double* d_cl = nullptr;
         SL_TRY(upload("cons.dst", dst.data(), dst.size(), &d_dst, s));
@@ -597,12 +599,9 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         hipLaunchKernelGGL(k_consensus_compact, dim3(static_cast<unsigned>(ng_eval)), dim3(256), 0, s, d_cons, d_phred, d_lerr,
                            d_ooff, d_len, d_dst, static_cast<long long>(ng_eval), d_cc, d_cp, d_cl);
         SL_HIP(hipGetLastError());
-        SL_HIP(hipMemcpy(hc.data(), d_cc, static_cast<size_t>(kept), hipMemcpyDeviceToHost));
-        SL_HIP(hipMemcpy(hp.data(), d_cp, static_cast<size_t>(kept), hipMemcpyDeviceToHost));
-        if (lerr) {
-            hl.resize(static_cast<size_t>(kept));
-            SL_HIP(hipMemcpy(hl.data(), d_cl, sizeof(double) * static_cast<size_t>(kept), hipMemcpyDeviceToHost));
-        }
+        SL_HIP(hipMemcpy(hc, d_cc, static_cast<size_t>(kept), hipMemcpyDeviceToHost));
+        SL_HIP(hipMemcpy(hp, d_cp, static_cast<size_t>(kept), hipMemcpyDeviceToHost));
+        if (lerr) SL_HIP(hipMemcpy(hl, d_cl, sizeof(double) * static_cast<size_t>(kept), hipMemcpyDeviceToHost));
     }
     if (fixn > 0) {  // exact host-libm re-evaluation of boundary columns
         std::vector<long long> fp(static_cast<size_t>(fixn));
@@ -629,9 +628,6 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
             if (lerr) hl[at] = le;
         }
     }
-    std::memcpy(cons, hc.data(), static_cast<size_t>(kept));
-    std::memcpy(phred, hp.data(), static_cast<size_t>(kept));
-    if (lerr && kept) std::memcpy(lerr, hl.data(), sizeof(double) * static_cast<size_t>(kept));
     for (int64_t g = 0; g < ngroups; ++g) cons_off[g + 1] = dst[g + 1];
     return 0;
 }

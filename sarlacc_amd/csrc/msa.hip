@@ -18,6 +18,7 @@
 //                   LDS window of 32 rows.
 //   k_msa_width     per group: column budget (max insertions before each centre base).
 //   k_msa_write     per group: emits the gapped rows.
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 
@@ -643,6 +644,9 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         const int32_t v = grp[grp_off[0] + i];
         if (v < 1 || v > nseq) return fail("sarlacc_amd: group index %d outside 1..%lld", v, static_cast<long long>(nseq));
     }
+    const bool timing = std::getenv("SARLACC_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tm0 = now();
     // ---- host-side job list: centre = lower median by (length, position) ----
     std::vector<MsaGroup> groups(static_cast<size_t>(ngroups));
     std::vector<MsaJob> jobs;
@@ -695,6 +699,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     SL_TRY(ensure_device());
     hipStream_t s = nullptr;
     Context& c = ctx();
+    const double tm1 = now();
     const int64_t total = nseq ? seq_off[nseq] - seq_off[0] : 0;
     std::vector<int64_t> rel(static_cast<size_t>(nseq) + 1);
     for (int64_t i = 0; i <= nseq; ++i) rel[i] = (nseq ? seq_off[i] : 0) - (nseq ? seq_off[0] : 0);
@@ -771,7 +776,9 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         SL_HIP(hipEventRecord(c.ev_stop, s));
         c.timed = true;
     }
+    const double tm2 = now();
     if (overlap) SL_TRY((*overlap)());
+    const double tm3 = now();
     MergeArgs m{};
     m.seq = d_seq; m.seq_off = d_soff; m.members = d_mem; m.groups = d_groups; m.jobs = d_jobs; m.ngroups = ngroups;
     m.ins = d_ins; m.aln = d_aln; m.maxins = d_maxins; m.mi_off = d_mioff; m.width = d_width;
@@ -799,6 +806,11 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     hipLaunchKernelGGL(k_msa_write, dim3(static_cast<unsigned>(nrows)), dim3(256), 0, s, m, d_rg, d_rp, nrows);
     SL_HIP(hipGetLastError());
     res->d_out = d_out;
+    if (timing) {
+        SL_HIP(hipStreamSynchronize(s));
+        fprintf(stderr, "msa_run: job list %.3f s | uploads + launches %.3f s | overlap hook %.3f s | kernels + row write %.3f s\n",
+                tm1 - tm0, tm2 - tm1, tm3 - tm2, now() - tm3);
+    }
     return 0;
 }
 
