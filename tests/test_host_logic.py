@@ -192,3 +192,56 @@ def test_oracle_scramble_is_a_permutation(oracle):
     for s, q, x, y in zip(seqs, quals, a, b):
         assert sorted(zip(s, q)) == sorted(zip(x, y))
     assert oracle.scramble(seqs, quals, 7) == (a, b) and oracle.scramble(seqs, quals, 8) != (a, b)
+
+
+def _fake_aligned(n, rng):
+    width = rng.integers(200, 400, n).astype(np.int32)
+    def side(lo):
+        start = rng.integers(1, 20, n).astype(np.int32) + lo
+        return {"score": rng.normal(8, 4, n), "start": start, "end": start + rng.integers(15, 30, n).astype(np.int32),
+                "subseq": {"Sub1": ["ACGT"[i % 4] * 3 for i in range(n)]}, "metadata": {"sequence": "X"}}
+    a1 = side(0)
+    a2 = side(0)
+    a2["start"], a2["end"] = width - a2["start"] + 1, width - a2["end"] + 1    # reported in read coordinates
+    return {"read.width": width, "adaptor1": a1, "adaptor2": a2, "reversed": rng.random(n) < 0.5,
+            "names": ["r%d" % i for i in range(n)], "metadata": {"filepath": None}}
+
+
+def test_filter_reads_matches_the_r_logic():
+    """filterReads (R/filterReads.R:2-43) on a synthetic alignment table, against a line-by-line
+    restatement with plain loops; covers essential / non-essential adaptors."""
+    from sarlacc_amd.generics import filterReads
+    rng = np.random.default_rng(3)
+    aln = _fake_aligned(200, rng)
+    for ess1, ess2 in ((True, True), (True, False), (False, True), (False, False)):
+        got = filterReads(aln, 6, 9, ess1, ess2)
+        names, ts, te = [], [], []
+        for i in range(200):
+            s1, s2 = aln["adaptor1"]["score"][i], aln["adaptor2"]["score"][i]
+            if (ess1 and not s1 >= 6) or (ess2 and not s2 >= 9):
+                continue
+            start = aln["adaptor1"]["end"][i] + 1 if s1 >= 6 else 1
+            end = aln["adaptor2"]["end"][i] - 1 if s2 >= 9 else aln["read.width"][i]
+            if start < end:
+                names.append(aln["names"][i]); ts.append(start); te.append(end)
+        assert got["names"] == names
+        assert got["trim.start"].tolist() == ts and got["trim.end"].tolist() == te
+        assert len(got["adaptor1"]["subseq"]["Sub1"]) == len(names) == len(got["reversed"])
+    assert len(filterReads(aln, 1e9, 1e9)["names"]) == 0
+
+
+def test_barcode_thresholds_and_flat_helpers():
+    from sarlacc_amd import calls
+    from sarlacc_amd.generics import getBarcodeThresholds
+    from sarlacc_amd.strset import StringSet
+    x = np.array([1.0, 2.0, 3.0, 4.0, 100.0])
+    thr = getBarcodeThresholds({"score": x, "gap": x / 2}, nmads=3)
+    # R: median 3, mad = 1.4826 * median(|x - 3|) = 1.4826
+    assert abs(thr["score"] - (3 - 3 * 1.4826)) < 1e-12 and abs(thr["gap"] - (1.5 - 3 * 1.4826 * 0.5)) < 1e-12
+    off = np.array([0, 2, 2, 5, 6], np.int64)
+    vals = np.array([7, 8, 1, 2, 3, 9], np.int32)
+    noff, nvals = calls.csr_select(off, vals, np.diff(off) >= 2)
+    assert noff.tolist() == [0, 2, 5] and nvals.tolist() == [7, 8, 1, 2, 3]
+    ss = StringSet.from_strings(["AC", "", "GGT", "T", "CCCC"])
+    assert ss.slice(1, 4).to_strings() == ["", "GGT", "T"] and ss.slice(0, 5).to_strings() == ss.to_strings()
+    assert ss.slice(2, 2).to_strings() == []
