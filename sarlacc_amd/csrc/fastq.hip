@@ -246,16 +246,18 @@ int sarlacc_dev_fastq_index(const uint8_t* d_text, int64_t nbytes, int64_t* n_re
     long long newlines = 0;
     SL_HIP(hipMemcpyAsync(&newlines, d_base + ntiles, sizeof newlines, hipMemcpyDeviceToHost, s));
     SL_HIP(hipStreamSynchronize(s));
-    // the text no longer ends in a newline, so there is one more line than newlines
+    // the text no longer ends in a newline, so there is one more line than newlines.  A last
+    // record whose quality line is empty lost that line with the trailing newlines: it is put
+    // back as an empty virtual line (the record check still compares the two lengths).
     const long long nlines = newlines + 1;
-    if (nlines % 4 != 0) return fail("FASTQ text ends inside a record (%lld lines)", nlines);
-    const long long nrec = nlines / 4;
+    if (nlines % 4 != 0 && nlines % 4 != 3) return fail("FASTQ text ends inside a record (%lld lines)", nlines);
+    const long long nrec = (nlines + 1) / 4;
 
     long long* d_lines;
-    SL_TRY(scratch("fq.lines", static_cast<size_t>(nlines) + 1, &d_lines));
-    const long long zero = 0, end = nbytes + 1;
+    SL_TRY(scratch("fq.lines", static_cast<size_t>(nlines) + 2, &d_lines));
+    const long long zero = 0, ends[2] = {nbytes + 1, nbytes + 2};
     SL_HIP(hipMemcpyAsync(d_lines, &zero, sizeof zero, hipMemcpyHostToDevice, s));
-    SL_HIP(hipMemcpyAsync(d_lines + nlines, &end, sizeof end, hipMemcpyHostToDevice, s));
+    SL_HIP(hipMemcpyAsync(d_lines + nlines, ends, sizeof ends, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_fq_lines, dim3(static_cast<unsigned>(ntiles)), dim3(FQ_THREADS), 0, s, d_text, static_cast<long long>(nbytes), d_base, d_lines);
     SL_HIP(hipGetLastError());
 

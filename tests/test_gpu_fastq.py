@@ -56,6 +56,10 @@ def test_device_parser_long_reads_and_empty_input():
     for empty in (b"", b"\n", b"\r\n\n"):
         d = DeviceReads.from_fastq(empty)
         assert len(d) == 0 and d.names == []
+    # a last record with an empty sequence and quality, with and without its final newlines
+    for tail in (b"", b"\n", b"\n\n", b"\r\n\r\n"):
+        d = DeviceReads.from_fastq(b"@a\nAC\n+\nII\n@b x\n\n+" + tail)
+        assert d.names == ["a", "b x"] and d.download()[0].to_strings() == ["AC", ""]
 
 
 @pytest.mark.parametrize("text,msg", [

@@ -178,7 +178,115 @@ def case_mask(rng):
         assert g == o, "mask"
 
 
-CASES = [case_align, case_align, case_umi, case_consensus, case_msa, case_mask]
+def case_umi_large(rng):
+    """Enough UMIs for the tile-prefix prefilter (>= 16 tiles of 256): few pre-groups, variable
+    lengths, occasional N, limits 0-3; umi_group and the neighbour lists against the oracle."""
+    n = int(rng.integers(4200, 9000))
+    length = int(rng.choice([6, 8, 10, 12, 16]))
+    nbase = int(rng.choice([n // 10, n // 3, n]))
+    NUCS = np.frombuffer(b"ACGT", dtype=np.uint8)
+    base = NUCS[rng.integers(0, 4, (nbase, length))]
+    pick = base[rng.integers(0, nbase, n)].copy()
+    sub = rng.random(pick.shape) < 0.04
+    pick[sub] = NUCS[rng.integers(0, 4, int(sub.sum()))]
+    if rng.random() < 0.3:
+        pick[rng.random(pick.shape) < 0.002] = ord("N")
+    umis = []
+    for row in pick:
+        t = row.tobytes().decode()
+        r = rng.random()
+        if r < 0.05 and len(t) > 1:
+            k = int(rng.integers(0, len(t)))
+            t = t[:k] + t[k + 1:]
+        elif r < 0.1:
+            k = int(rng.integers(0, len(t) + 1))
+            t = t[:k] + "ACGT"[int(rng.integers(0, 4))] + t[k:]
+        umis.append(t)
+    limit = int(rng.integers(0, 4))
+    ngr = int(rng.choice([1, 1, 2, 5]))
+    lab = np.sort(rng.integers(0, ngr, n)) if rng.random() < 0.5 else rng.integers(0, ngr, n)
+    groups = [(np.flatnonzero(lab == k) + 1).astype(np.int32) for k in range(ngr)]
+    g, o, err = both(lambda: calls.umi_group(umis, limit, None, limit, groups), lambda: O.umi_group(umis, limit, None, limit, groups, fast=True))
+    if not err:
+        assert len(g) == len(o) and all(np.array_equal(a, b) for a, b in zip(g, o)), "umi_group (large)"
+
+
+def case_unmask(rng):
+    n = int(rng.integers(0, 30))
+    W = int(rng.integers(0, 300))
+    rows, orig = [], []
+    for _ in range(n):
+        row = rng.choice(list("ACGT-"), W, p=[0.2, 0.2, 0.2, 0.2, 0.2]) if W else np.array([], dtype="<U1")
+        o = "".join(c for c in row if c != "-")
+        m = row.copy()
+        if W:
+            hit = (rng.random(W) < 0.3) & (row != "-")
+            m[hit] = rng.choice(list("Nn"), int(hit.sum()))
+        r = rng.random()
+        if r < 0.05:
+            o = o[:-1] if o else o + "A"          # original too short
+        elif r < 0.1:
+            o = o + "C"                            # original too long
+        rows.append("".join(m))
+        orig.append(o)
+    if n and rng.random() < 0.05:
+        orig = orig[:-1]                           # entry counts differ
+    if n > 1 and rng.random() < 0.05:
+        rows[-1] = rows[-1] + "A"                  # ragged alignment
+    g, o, err = both(lambda: calls.unmask_alignment(rows, orig), lambda: O.unmask_alignment(rows, orig))
+    if not err:
+        assert g == o, "unmask"
+
+
+def case_fused(rng):
+    """sarlacc_msa_consensus against the oracle's quick_msa followed by its consensus."""
+    from sarlacc_amd.mock import NUC, mutate
+    from sarlacc_amd.strset import csr_from_lists
+    reads, groups = [], []
+    for _ in range(int(rng.integers(1, 8))):
+        L = int(rng.choice([0, 5, 60, 300, 700]))
+        truth = NUC[rng.integers(0, 4, L)]
+        idx = []
+        for _ in range(int(rng.integers(0, 9))):
+            reads.append(mutate(truth, rng, 0.08, 0.03).tobytes().decode() if L else "")
+            idx.append(len(reads))
+        groups.append(idx)
+    if not reads:
+        reads = ["ACGT"]
+    quals = [rqual(rng, len(r), 40, 90) for r in reads]
+    params = [(0, -1, -5, -1), (0, -1, -1, -5), (1, -2, -2, -2)][int(rng.integers(0, 3))]
+    bw = int(rng.choice([3, 20, 100]))
+    cov = float(rng.choice([0.0, 0.5, 0.6, 1.0]))
+    goff, gvals = csr_from_lists(groups)
+    rows = O.quick_msa(groups, reads, *params, bw)
+    if rng.random() < 0.5:
+        got = calls.msa_consensus_flat(goff, gvals, reads, *params, bw, cov, quals=quals, encoding=enc)
+        want = O.create_consensus_quality_loop(rows, cov, [[quals[i - 1] for i in g] for g in groups], oenc)
+    else:
+        got = calls.msa_consensus_flat(goff, gvals, reads, *params, bw, cov, pseudo_count=1.0)
+        want = O.create_consensus_basic_loop(rows, cov, 1.0)
+    assert got[0].to_strings() == list(want[0]) and got[1].to_strings() == list(want[1]), "fused msa+consensus"
+
+
+def case_fastq(rng):
+    from sarlacc_amd.resident import DeviceReads
+    n = int(rng.integers(0, 60))
+    eol = "\r\n" if rng.random() < 0.3 else "\n"
+    recs, seqs, quals, names = [], [], [], []
+    for i in range(n):
+        L = int(rng.integers(0, int(rng.choice([5, 80, 900, 9000])) + 1))
+        sq = rstr(rng, L, "ACGTNacgt")
+        q = rqual(rng, L)
+        nm = "r%d %s" % (i, rstr(rng, int(rng.integers(0, 12)), "abc:/ =0123"))
+        recs.append("@%s%s%s%s+%s%s" % (nm, eol, sq, eol, eol, q))
+        seqs.append(sq.upper()); quals.append(q); names.append(nm)
+    text = eol.join(recs) + (eol if (n and rng.random() < 0.7) else "") + ("\n" * int(rng.integers(0, 3)) if n else "")
+    dev = DeviceReads.from_fastq(text.encode())
+    s_, q_ = dev.download()
+    assert len(dev) == n and s_.to_strings() == seqs and q_.to_strings() == quals and dev.names == names, "fastq"
+
+
+CASES = [case_align, case_align, case_umi, case_consensus, case_msa, case_mask, case_unmask, case_fused, case_fastq]
 
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
@@ -189,7 +297,7 @@ if __name__ == "__main__":
     while time.time() - t0 < budget:
         seed = seed0 * 1_000_003 + k
         rng = np.random.default_rng(seed)
-        fn = CASES[k % len(CASES)]
+        fn = case_umi_large if k % 97 == 96 else CASES[k % len(CASES)]
         try:
             fn(rng)
         except Exception:
