@@ -544,6 +544,17 @@ __global__ void __launch_bounds__(64 * NWAVES, 5) k_align(const AlignArgs A) {
                     bool stalled = false;
                     while (c > 0 && !stalled) {
                         if (phase == 0) {
+                            // runs of diagonal moves (most of the path) in a loop of their own
+                            while (c > 0 && row > 0) {
+                                const int jj = (c - 1) / K, kk = (c - 1) % K;
+                                const int tt = row + jj - ts;
+                                if (tt < 0) break;
+                                const Word w = wtile[static_cast<unsigned>(tt / UNR) * 64u + static_cast<unsigned>(g * W + jj)];
+                                if (!((w >> (4 * (CELLS - 1 - ((tt % UNR) * K + kk)))) & 2u)) break;
+                                map[c] = row * 2 + 1;
+                                --row; --c;
+                            }
+                            if (c <= 0) break;
                             if (row <= 0) { map[c] = (row + 1) * 2; --c; continue; }  // D[c][0] = 1
                             unsigned nb;
                             if (!code_at(c, row, nb)) { want = row; stalled = true; break; }
