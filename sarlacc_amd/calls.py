@@ -477,8 +477,9 @@ def umi_pairs_shard(umi, limit, shard_index, shard_count):
         cap = need.value
 
 
-def umi_group_from_pairs(umi, limit, pairs):
-    """sarlacc_umi_group_from_pairs: umi_group of a single pre-group given its neighbour pairs."""
+def umi_group_from_pairs(umi, limit, pairs, flat=False):
+    """sarlacc_umi_group_from_pairs: umi_group of a single pre-group given its neighbour pairs.
+    flat=True returns the clusters as CSR (offsets, members) instead of a list of arrays."""
     s = StringSet.from_strings(umi)
     lim = _integer(limit, "limit")
     pairs = np.ascontiguousarray(pairs, dtype=np.uint64)
@@ -489,4 +490,6 @@ def umi_group_from_pairs(umi, limit, pairs):
     pp = pairs if pairs.size else np.zeros(1, np.uint64)
     check(_lib.lib().sarlacc_umi_group_from_pairs(ptr(s.chars), ptr(s.off), C.c_int64(n), lim, ptr(pp), C.c_int64(pairs.size),
                                                   C.byref(ncl), ptr(co), ptr(cl)))
+    if flat:
+        return co[:ncl.value + 1], cl[:int(co[ncl.value])]
     return lists_from_csr(co, cl, ncl.value)

@@ -41,6 +41,18 @@ def assign_groups(sizes, world, power=2.0):
     return owner
 
 
+def assign_groups_snake(cost, world):
+    """Vectorised near-balanced assignment for many groups of similar cost: groups sorted by cost
+    (ties by index) are dealt to the ranks in snake order 0..w-1, w-1..0, ...  Deterministic."""
+    cost = np.asarray(cost, dtype=np.float64)
+    order = np.lexsort((np.arange(cost.size), -cost))
+    pos = np.arange(cost.size)
+    lap, k = pos // world, pos % world
+    owner = np.empty(cost.size, dtype=np.int64)
+    owner[order] = np.where(lap % 2 == 0, k, world - 1 - k)
+    return owner
+
+
 def _all_gather(vec, dist, device=None):
     """all_gather of a 1-D int32 numpy array of identical length on every rank."""
     import torch
@@ -120,14 +132,14 @@ def sharded_over_reads(fn, n, dist=None):
     return lo, hi, fn(lo, hi)
 
 
-def sharded_umi_group_tiles(umi, threshold, calls, dist=None, device=None):
+def sharded_umi_group_tiles(umi, threshold, calls, dist=None, device=None, flat=False):
     """umi_group of ONE giant pre-group with the row tiles of the all-pairs matrix spread over the
     ranks.  Every rank holds all UMIs (they are 12 bytes each), searches its
     share of the tiles, all-gathers the neighbour pairs (counts first, then the padded lists) and
     runs the clustering on the concatenation -- replicated, deterministic, identical to the
     single-GPU result."""
     if dist is None or dist.get_world_size() == 1:
-        return calls.umi_group_from_pairs(umi, threshold, calls.umi_pairs_shard(umi, threshold, 0, 1))
+        return calls.umi_group_from_pairs(umi, threshold, calls.umi_pairs_shard(umi, threshold, 0, 1), **({"flat": True} if flat else {}))
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
     mine = calls.umi_pairs_shard(umi, threshold, rank, world).astype(np.int64)  # values < 2^63: safe as int64
@@ -142,4 +154,4 @@ def sharded_umi_group_tiles(umi, threshold, calls, dist=None, device=None):
     parts = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(parts, t)
     allpairs = np.concatenate([p.cpu().numpy()[:c] for p, c in zip(parts, counts)]).astype(np.uint64)
-    return calls.umi_group_from_pairs(umi, threshold, allpairs)
+    return calls.umi_group_from_pairs(umi, threshold, allpairs, **({"flat": True} if flat else {}))

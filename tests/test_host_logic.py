@@ -245,3 +245,18 @@ def test_barcode_thresholds_and_flat_helpers():
     ss = StringSet.from_strings(["AC", "", "GGT", "T", "CCCC"])
     assert ss.slice(1, 4).to_strings() == ["", "GGT", "T"] and ss.slice(0, 5).to_strings() == ss.to_strings()
     assert ss.slice(2, 2).to_strings() == []
+
+
+def test_assign_groups_snake_is_balanced_and_deterministic():
+    from sarlacc_amd.shard import assign_groups_snake
+    rng = np.random.default_rng(4)
+    cost = rng.integers(15000, 25000, 10001).astype(float)
+    for world in (1, 2, 3, 8):
+        owner = assign_groups_snake(cost, world)
+        assert np.array_equal(owner, assign_groups_snake(cost.copy(), world))
+        assert owner.min() == 0 and owner.max() == world - 1
+        load = np.bincount(owner, weights=cost, minlength=world)
+        assert load.max() - load.min() <= cost.max()          # within one group of each other
+        counts = np.bincount(owner, minlength=world)
+        assert counts.max() - counts.min() <= 1
+    assert assign_groups_snake(np.zeros(0), 4).size == 0

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=2000)
     ap.add_argument("--threshold", type=int, default=1)
     ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--repeat", type=int, default=2, help="passes over the stages; the last one is reported, the first as first_pass_s")
     ap.add_argument("--check", action="store_true", help="rank 0 recomputes everything unsharded and compares")
     args = ap.parse_args()
 
@@ -81,52 +82,61 @@ def main():
             dist.barrier()
 
     calls.umi_group(["ACGT", "ACGA"], 1, None, 1, [[1, 2]])   # context and workspace warm-up, untimed
-    fence()
-    t0 = time.perf_counter()
-    # 1. adaptor DP on the local read range
-    lo, hi = shard.shard_range(n, rank, world)
-    local = DeviceReads.upload(Reads(reads.slice(lo, hi), quals.slice(lo, hi), encoding=enc))
-    scores = local.align_map(ADAPTOR1, 5, 1, [9], [21])[0]
-    fence()
-    t1 = time.perf_counter()
-    # 2. one giant pre-group: tile shards + all-gather of neighbour pairs + replicated clustering
-    clusters = shard.sharded_umi_group_tiles(umis, args.threshold, calls, D, gather_device)
-    fence()
-    t2 = time.perf_counter()
-    # 3. clusters of >= 2 reads, bin-packed by bases; MSA + consensus on the owned ones
-    sizes = np.array([len(c) for c in clusters])
-    big = np.flatnonzero(sizes >= 2)
-    w = reads.widths()
-    cost = np.array([w[clusters[k] - 1].sum() for k in big])
-    owner = shard.assign_groups(cost, world, power=1.0)
-    mine = big[owner == rank]
-    goff = np.zeros(mine.size + 1, np.int64)
-    np.cumsum(sizes[mine], out=goff[1:])
-    gflat = np.concatenate([clusters[k] for k in mine]).astype(np.int32) if mine.size else np.zeros(0, np.int32)
-    cons, phred = calls.msa_consensus_flat(goff, gflat, reads, 0, -1, -5, -1, 100, 0.6, quals=quals, encoding=enc)
-    fence()
-    t3 = time.perf_counter()
+    def stages():
+        fence()
+        t0 = time.perf_counter()
+        # 1. adaptor DP on the local read range
+        lo, hi = shard.shard_range(n, rank, world)
+        local = DeviceReads.upload(Reads(reads.slice(lo, hi), quals.slice(lo, hi), encoding=enc))
+        scores = local.align_map(ADAPTOR1, 5, 1, [9], [21])[0]
+        fence()
+        t1 = time.perf_counter()
+        # 2. one giant pre-group: tile shards + all-gather of neighbour pairs + replicated clustering
+        coff, cmem = shard.sharded_umi_group_tiles(umis, args.threshold, calls, D, gather_device, flat=True)
+        fence()
+        t2 = time.perf_counter()
+        # 3. clusters of >= 2 reads, dealt to the ranks by their bases; MSA + consensus on the owned ones
+        sizes = np.diff(coff)
+        big = np.flatnonzero(sizes >= 2)
+        w = reads.widths()
+        bases = np.add.reduceat(w[cmem.astype(np.int64) - 1], coff[:-1][sizes > 0]) if cmem.size else np.zeros(0)
+        cost = np.zeros(sizes.size)
+        cost[sizes > 0] = bases
+        owner = shard.assign_groups_snake(cost[big], world)
+        keep = np.zeros(sizes.size, bool)
+        keep[big[owner == rank]] = True
+        goff, gflat = calls.csr_select(coff, cmem, keep)
+        cons, phred = calls.msa_consensus_flat(goff, gflat, reads, 0, -1, -5, -1, 100, 0.6, quals=quals, encoding=enc)
+        fence()
+        t3 = time.perf_counter()
 
+        return (t1 - t0, t2 - t1, t3 - t2, t3 - t0), scores, coff, cmem, sizes, big, gflat, cons
+
+    runs = [stages() for _ in range(max(1, args.repeat))]
+    (d1, d2, d3, dall), scores, coff, cmem, sizes, big, gflat, cons = runs[-1]
+    cold = runs[0][0]
     stats = torch.tensor([float(len(cons)), float(cons.total), float(gflat.size), float(scores.sum())],
                          dtype=torch.float64, device=red_device)
-    times = torch.tensor([t1 - t0, t2 - t1, t3 - t2, t3 - t0], dtype=torch.float64, device=red_device)
+    times = torch.tensor([d1, d2, d3, dall, cold[0], cold[1], cold[2], cold[3]], dtype=torch.float64, device=red_device)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     if rank == 0:
         st, tm = stats.cpu().tolist(), times.cpu().tolist()
         out = {"metric": "reads/min through adaptor_align -> umiGroup -> multiReadAlign -> consensusReadSeq",
-               "value": n / tm[3] * 60.0, "unit": "reads/min", "n_gpus": world, "reads": n, "clusters": int(len(clusters)),
+               "value": n / tm[3] * 60.0, "unit": "reads/min", "n_gpus": world, "reads": n, "clusters": int(sizes.size),
                "consensus_reads": int(st[0]), "consensus_bases": int(st[1]), "reads_in_clusters": int(st[2]),
                "score_checksum": st[3], "stage_s": {"adaptor_align": tm[0], "umi_group": tm[1], "msa_consensus": tm[2]},
-               "backend": backend, "scaling": "strong"}
+               "first_pass_s": {"adaptor_align": tm[4], "umi_group": tm[5], "msa_consensus": tm[6], "total": tm[7]},
+               "passes": max(1, args.repeat), "backend": backend, "scaling": "strong"}
         if args.check:
             ref_scores = DeviceReads.upload(Reads(reads, quals, encoding=enc)).align_map(ADAPTOR1, 5, 1, [9], [21])[0]
-            ref_clusters = calls.umi_group(umis, args.threshold, None, args.threshold, [np.arange(1, n + 1, dtype=np.int32)])
-            same = len(ref_clusters) == len(clusters) and all(np.array_equal(a, b) for a, b in zip(ref_clusters, clusters))
-            goff_all = np.zeros(big.size + 1, np.int64)
-            np.cumsum(sizes[big], out=goff_all[1:])
-            gflat_all = np.concatenate([clusters[k] for k in big]).astype(np.int32)
+            ref_off, ref_mem = calls.umi_group_flat(umis, args.threshold, None, args.threshold, np.array([0, n], np.int64),
+                                                    np.arange(1, n + 1, dtype=np.int32))
+            same = np.array_equal(ref_off, coff) and np.array_equal(ref_mem, cmem)
+            allbig = np.zeros(sizes.size, bool)
+            allbig[big] = True
+            goff_all, gflat_all = calls.csr_select(coff, cmem, allbig)
             ref_cons, _ = calls.msa_consensus_flat(goff_all, gflat_all, reads, 0, -1, -5, -1, 100, 0.6, quals=quals, encoding=enc)
             out["check"] = {"clusters_identical": bool(same), "consensus_reads": len(ref_cons), "consensus_bases": ref_cons.total,
                             "score_checksum": float(ref_scores.sum())}
