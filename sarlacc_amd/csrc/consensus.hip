@@ -251,6 +251,16 @@ __global__ void __launch_bounds__(64) k_consensus(const ConsArgs A) {
 // and columns within 1e-9 of a boundary go to the host libm as before.
 typedef uint32_t __attribute__((aligned(1))) cons_u32_unaligned;
 
+// exact fp64 log error of a column from its four sorted scores (out of line: rare, register-hungry)
+__device__ __noinline__ double exact_log_error(double a, double b, double c, double d) {
+    double denom = a;
+    denom += dev_log1pexp(b - denom);
+    denom += dev_log1pexp(c - denom);
+    const double err3 = denom;
+    denom += dev_log1pexp(d - denom);
+    return err3 - denom;
+}
+
 __device__ __forceinline__ double fast_log1pexp(double x) {
     if (x > 33.3) return x;
     if (x > 18.) return x + static_cast<double>(__expf(static_cast<float>(-x)));
@@ -260,7 +270,7 @@ __device__ __forceinline__ double fast_log1pexp(double x) {
 
 constexpr int Q4_RB = 5;   // rows fetched per batch
 
-__global__ void __launch_bounds__(256) k_consensus_q4(const ConsArgs A) {
+__global__ void __launch_bounds__(256, 4) k_consensus_q4(const ConsArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int nvec = 5 * A.navail + 1;
     double* const s_vec = reinterpret_cast<double*>(smem);
@@ -414,12 +424,7 @@ __global__ void __launch_bounds__(256) k_consensus_q4(const ConsArgs A) {
                 double frac = x - floor(x);
                 bool near = false;
                 if (x < 93.4 && fabs(frac - 0.5) < 2e-4) {   // too close for the fp32 estimate: exact fp64 evaluation
-                    denom = a;
-                    denom += dev_log1pexp(b - denom);
-                    denom += dev_log1pexp(c - denom);
-                    err3 = denom;
-                    denom += dev_log1pexp(d - denom);
-                    le = err3 - denom;
+                    le = exact_log_error(a, b, c, d);
                     x = -10 * le / A.ln10;
                     frac = x - floor(x);
                     near = x < 93.4 && fabs(frac - 0.5) < 1e-9;
