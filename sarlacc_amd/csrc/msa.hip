@@ -436,7 +436,10 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
         uint16_t* ins = A.ins + J.out_off;
         uint8_t* aln = A.aln + J.out_off;
         int i = lr, j = lc, state = 0, cnt = 0;
-        int wlo = nwords;   // first word row held in the window (none yet)
+        // The LDS window holds MSA_WL lanes x MSA_WR word rows of codes around the path (the path
+        // stays near one band diagonal, so a narrow strip covers many more rows than full rows would).
+        constexpr int MSA_WL = 8, MSA_WR = MSA_WIN * 64 / MSA_WL;
+        int wlo = nwords, llo = 0;   // first word row / first lane held in the window (none yet)
         // code of cell (ii, xx): sub-block ws = ii + (xx + C l ... ) -- t = 2 ii + xx, ws = t >> 1
         auto locate = [&](int ii, int xx, int& wrow, int& shift, int& ln) {
             const int t = 2 * ii + xx;
@@ -452,11 +455,14 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
             const int x = j - i - dlo;
             int wrow, shift, ln;
             locate(i, x, wrow, shift, ln);
-            if (wrow < wlo) {
-                wlo = max(0, wrow - (MSA_WIN - 1));
+            if (wrow < wlo || ln < llo || ln >= llo + MSA_WL) {
+                wlo = max(0, wrow - (MSA_WR - 1));
+                llo = min(max(ln - MSA_WL / 2, 0), 64 - MSA_WL);
                 __syncthreads();
-                for (int r = 0; r < MSA_WIN; ++r)
-                    if (wlo + r < nwords) s_tb[r * 64 + lane] = tile[static_cast<size_t>(wlo + r) * 64 + lane];
+                for (int idx = lane; idx < MSA_WR * MSA_WL; idx += 64) {
+                    const int r = idx / MSA_WL, cl = idx % MSA_WL;
+                    if (wlo + r < nwords) s_tb[idx] = tile[static_cast<size_t>(wlo + r) * 64 + llo + cl];
+                }
                 __syncthreads();
             }
             if (state == 0) {
@@ -466,7 +472,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
                 if (lane < reach) {
                     int wr, sh, l2;
                     locate(i - lane, x, wr, sh, l2);
-                    tl = (static_cast<unsigned>(s_tb[(wr - wlo) * 64 + l2] >> sh) & 1u) ^ 1u;   // bit 0: diagonal
+                    tl = (static_cast<unsigned>(s_tb[(wr - wlo) * MSA_WL + (l2 - llo)] >> sh) & 1u) ^ 1u;   // bit 0: diagonal
                 }
                 const unsigned long long nd = __ballot(tl != 0);
                 const int run = nd ? static_cast<int>(__builtin_ctzll(nd)) : 64;
@@ -476,7 +482,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
                     continue;
                 }
             }
-            const unsigned t = static_cast<unsigned>(s_tb[(wrow - wlo) * 64 + ln] >> shift) & 15u;
+            const unsigned t = static_cast<unsigned>(s_tb[(wrow - wlo) * MSA_WL + (ln - llo)] >> shift) & 15u;
             if (state == 0) {
                 state = (t & 1u) ? 0 : ((t & 2u) ? 1 : 2);   // diagonal, else vertical if e >= f, else horizontal
                 continue;
