@@ -61,7 +61,7 @@ def pmc_traffic(n_reads):
     return kb * 1024.0, d.get("derived")
 
 
-def pipeline_sample(groups=4000, read_len=2000, copies=10):
+def pipeline_sample(groups=10000, read_len=2000, copies=10):
     """Second half of the headline metric on a bounded sample: reads/min through
     umi_group -> quick_msa -> create_consensus_quality_loop (host-pointer C ABI, PCIe included)."""
     import numpy as np
