@@ -17,10 +17,12 @@
 //   * read bases + qualities are staged 64 rows at a time into an LDS ring, the
 //     5 x navail fp64 cost tables sit in LDS;
 //   * traceback needs 4 bits per cell (move + "jump continued" flags; the jump lengths
-//     the reference stores are rebuilt during the walk), streamed with nontemporal
-//     stores to a per-wave tile in HBM in anti-diagonal order and walked by the group's
-//     leader lane afterwards; the walk up the last column is replaced by its landing
-//     row, tracked online.
+//     the reference stores are rebuilt during the walk).  adaptor_align (MODE 3) does not
+//     produce them in the fill at all: it snapshots the lane state every SNAP_P steps and
+//     afterwards recomputes, with codes, only the window above each alignment's landing
+//     row (tracked online; it replaces the walk up the last column), which the group's
+//     leader lane then walks.  MODE 1/2 stream the codes of every cell with nontemporal
+//     stores to a per-wave tile in HBM (general_align's strings; gapopen < 0).
 //
 // All arithmetic is fp64 add/sub/compare in the reference's order, compiled with
 // -ffp-contract=off, so scores are bit-identical to the CPU path.

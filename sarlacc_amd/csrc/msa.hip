@@ -9,10 +9,12 @@
 // group order, equal widths, '-' for gaps, non-ACGT shown as N, singletons verbatim.
 //
 // Kernels:
-//   k_msa_pairwise  one wavefront per (read, centre) pair: banded Gotoh filled row by
-//                   row, lanes own C consecutive band cells; vertical/diagonal inputs
-//                   are in-lane or one DPP shift away, the horizontal gap chain is a
-//                   max-plus prefix scan across the wave (DPP row_shr / row_bcast);
+//   k_msa_pairwise_ad  (default) one wavefront per (read, centre) pair: banded Gotoh
+//                   scheduled along anti-diagonals of the band (t = 2i + x), no scan,
+//                   every lane busy on every step; see the comment above the kernel.
+//   k_msa_pairwise  (SARLACC_MSA_SCAN=1, kept for A/B runs) the same recurrences row by
+//                   row, lanes own C consecutive band cells; the horizontal gap chain is
+//                   a max-plus prefix scan across the wave (DPP row_shr / row_bcast);
 //                   4 traceback bits per cell stream to a per-wave HBM tile (one
 //                   coalesced dword per lane per row) and are walked back through an
 //                   LDS window of 32 rows.
