@@ -156,6 +156,7 @@ __device__ __forceinline__ int banded_lev2(unsigned long long ca, uint32_t na, i
     return res;
 }
 
+struct TileInfo;
 struct PairArgs {
     UmiArrays U;                    // in (pre-group, trie) order
     const int* gid;                 // pre-group of every element in that order (nullptr: one group)
@@ -166,6 +167,7 @@ struct PairArgs {
     unsigned long long cap;
     int tile_lo;                    // first row tile of this launch (row tiles shard across GPUs)
     const uint32_t* tile_list;      // optional: the (row tile << 16 | column tile) pairs to search, one per block
+    const TileInfo* sub_info;       // optional: common prefixes of the 64-element blocks (4 per tile)
 };
 
 // ---------------------------------------------------------------------------
@@ -181,8 +183,9 @@ struct TileInfo {
     int plen;                   // its length; -1: no information
 };
 
-__global__ void __launch_bounds__(TILE) k_tile_info(UmiArrays U, const int* gid, int n, TileInfo* info) {
-    const int t0 = blockIdx.x * TILE, t1 = min(t0 + TILE, n) - 1;
+template <int BLK>
+__global__ void __launch_bounds__(BLK) k_tile_info(UmiArrays U, const int* gid, int n, TileInfo* info) {
+    const int t0 = blockIdx.x * BLK, t1 = min(t0 + BLK, n) - 1;
     const int i = t0 + threadIdx.x;
     const uint32_t nm = i < n ? U.nmask[i] : 0u;
     const int anyN = __syncthreads_or(nm != 0u);
@@ -357,7 +360,28 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
     };
 
     const int jn = min(TILE, A.n - bj * TILE);
+    // Sub-tile prefilter: the 64 rows of this wave and each 64-column block of the tile have
+    // longer common prefixes than the 256-element tiles; a block whose prefix cannot align with
+    // the wave's within `limit` edits holds no neighbour of these rows (same argument as k_tile_pairs).
+    unsigned sub_ok = 0xfu;
+    if (K >= 1 && K <= 5 && A.sub_info && bi != bj) {
+        bool ok = true;
+        if (lane < 4) {
+            const int rb = bi * 4 + wv, cb = bj * 4 + lane;
+            if (rb * 64 < A.n && cb * 64 < A.n) {
+                const TileInfo R = A.sub_info[rb], C = A.sub_info[cb];
+                if (R.plen >= 0 && C.plen >= 0) {
+                    constexpr int L = (K >= 1 && K <= 5) ? K : 1;
+                    const int m1 = min(R.plen, C.plen - L), m2 = min(C.plen, R.plen - L);
+                    if (m1 > L && prefix_dist<L>(R.pcode, m1, C.pcode) > L) ok = false;
+                    if (ok && m2 > L && prefix_dist<L>(C.pcode, m2, R.pcode) > L) ok = false;
+                }
+            }
+        }
+        sub_ok = static_cast<unsigned>(__ballot(ok)) & 0xfu;
+    }
     for (int jj = 0; jj < jn; ++jj) {
+        if (!((sub_ok >> (jj >> 6)) & 1u)) { jj |= 63; continue; }   // skip the whole 64-column block
         const uint4 ck = c_key[jj];
         bool pass = row_on && static_cast<int>(ck.x) == gi && (bi != bj || jj > t);
         {
@@ -766,6 +790,7 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
     }
     // tile pairs that can hold neighbours (see k_tile_pairs); worth it from a few dozen tiles on
     const uint32_t* d_list = nullptr;
+    const TileInfo* d_subinfo = nullptr;
     unsigned int nlisted = 0;
     const long long ntp = static_cast<long long>(tile_hi - tile_lo) * nt;
     if (limit >= 0 && limit <= 5 && nt >= 16 && ntp <= (1ll << 31) && !std::getenv("SARLACC_UMI_ALLTILES")) {
@@ -776,7 +801,13 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
         SL_TRY(scratch((p + ".tlist").c_str(), max_list, &d_l));
         SL_TRY(scratch((p + ".tcount").c_str(), 1, &d_lc));
         SL_HIP(hipMemsetAsync(d_lc, 0, sizeof(unsigned int), s));
-        hipLaunchKernelGGL(k_tile_info, dim3(static_cast<unsigned>(nt)), dim3(TILE), 0, s, S.U, S.gid, n, d_info);
+        hipLaunchKernelGGL(k_tile_info<TILE>, dim3(static_cast<unsigned>(nt)), dim3(TILE), 0, s, S.U, S.gid, n, d_info);
+        // prefixes of the 64-element blocks for the sub-tile filter inside the pair kernel
+        TileInfo* d_sub;
+        const unsigned nsub = nblk(n, 64);
+        SL_TRY(scratch((p + ".tsub").c_str(), static_cast<size_t>(nsub), &d_sub));
+        hipLaunchKernelGGL(k_tile_info<64>, dim3(nsub), dim3(64), 0, s, S.U, S.gid, n, d_sub);
+        d_subinfo = d_sub;
         switch (limit) {
             case 0: launch_tile_pairs<0>(d_info, nt, tile_lo, tile_hi, d_l, d_lc, s); break;
             case 1: launch_tile_pairs<1>(d_info, nt, tile_lo, tile_hi, d_l, d_lc, s); break;
@@ -795,7 +826,7 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
         SL_TRY(c.buffer((p + ".edges").c_str(), cap * sizeof(unsigned long long), &pe));
         d_edges = static_cast<unsigned long long*>(pe);
         SL_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
-        PairArgs a{S.U, S.gid, n, lim2, d_edges, d_count, cap, tile_lo, d_list};
+        PairArgs a{S.U, S.gid, n, lim2, d_edges, d_count, cap, tile_lo, d_list, d_subinfo};
         SL_HIP(hipEventRecord(c.ev_start, s));
         const int K = std::min(limit, UMI_MAXLEN);
         if (K <= 0) launch_pairs<0>(a, tile_hi, nlisted, s);
