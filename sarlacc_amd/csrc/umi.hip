@@ -380,10 +380,20 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
         }
         sub_ok = static_cast<unsigned>(__ballot(ok)) & 0xfu;
     }
+    bool row_ok = true;   // this row can have neighbours in the current 64-column block
     for (int jj = 0; jj < jn; ++jj) {
         if (!((sub_ok >> (jj >> 6)) & 1u)) { jj |= 63; continue; }   // skip the whole 64-column block
+        if (K >= 1 && K <= 3 && A.sub_info && bi != bj && (jj & 63) == 0) {
+            // the row's own string is fully known: the block's whole prefix has to align with its
+            // first plen +- limit bases within `limit` edits
+            constexpr int L = (K >= 1 && K <= 3) ? K : 1;
+            const TileInfo C = A.sub_info[bj * 4 + (jj >> 6)];
+            const int m2 = min(C.plen, la - L);
+            row_ok = !(row_on && na == 0u && C.plen >= 0 && m2 > L && prefix_dist<L>(C.pcode, m2, ca) > L);
+            if (!__ballot(row_ok)) { jj |= 63; continue; }
+        }
         const uint4 ck = c_key[jj];
-        bool pass = row_on && static_cast<int>(ck.x) == gi && (bi != bj || jj > t);
+        bool pass = row_ok && row_on && static_cast<int>(ck.x) == gi && (bi != bj || jj > t);
         {
             const int lb = ck.y & 0xff, nNb = (ck.y >> 8) & 0xff;
             const int dl = la > lb ? la - lb : lb - la;
