@@ -70,6 +70,8 @@ struct AlignArgs {
     unsigned long long dirs_per_wave;  // elements per wavefront
     int snap_head, snap_win;           // MODE 3: see SNAP_P
     int* badqual;                      // min index of a read holding a quality below the offset
+    int read_base;                     // index of this launch's first read in the caller's batch (chunked host calls)
+    long long sec_stride;              // reads per section row of sec_so / sec_wo (the caller's whole batch)
     uint8_t* aln_ref;                  // MODE 2: reversed gapped strings, stride L+R per read
     uint8_t* aln_qry;
     int32_t* aln_len;
@@ -277,7 +279,7 @@ __global__ void __launch_bounds__(64 * NWAVES, 5) k_align(const AlignArgs A) {
         auto stage = [&](int gg, int r0, uint32_t v) {
             const int r = r0 + lane;
             int qi = static_cast<int>(static_cast<signed char>(v & 0xff)) - A.qoffset;
-            if (r < glen[gg] && qi < 0) atomicMin(A.badqual, static_cast<int>(item * A.ngroups + gg));
+            if (r < glen[gg] && qi < 0) atomicMin(A.badqual, A.read_base + static_cast<int>(item * A.ngroups + gg));
             qi = qi < 0 ? 0 : (qi >= A.navail ? A.navail - 1 : qi);
             // byte offset of (base code, quality) inside a block of table rows
             s_ring[gg * RING + (r & (RING - 1))] = static_cast<uint16_t>((v >> 8) * A.row_bytes + (qi << 3));
@@ -609,8 +611,8 @@ __global__ void __launch_bounds__(64 * NWAVES, 5) k_align(const AlignArgs A) {
                         A.ends[read] = nonempty ? static_cast<int32_t>(e) : 0;
                         for (int x = 0; x < A.nsec; ++x) {
                             interval(A.sec_s[x], A.sec_e[x], true, s, e);
-                            A.sec_so[static_cast<long long>(x) * A.n + read] = static_cast<int32_t>(s + 1);
-                            A.sec_wo[static_cast<long long>(x) * A.n + read] = static_cast<int32_t>(e - s);
+                            A.sec_so[static_cast<long long>(x) * A.sec_stride + read] = static_cast<int32_t>(s + 1);
+                            A.sec_wo[static_cast<long long>(x) * A.sec_stride + read] = static_cast<int32_t>(e - s);
                         }
                     }
                 }
@@ -687,8 +689,8 @@ __global__ void __launch_bounds__(64 * NWAVES, 5) k_align(const AlignArgs A) {
                     A.ends[read] = nonempty ? static_cast<int32_t>(e) : 0;
                     for (int x = 0; x < A.nsec; ++x) {
                         interval(A.sec_s[x], A.sec_e[x], true, s, e);
-                        A.sec_so[static_cast<long long>(x) * A.n + read] = static_cast<int32_t>(s + 1);
-                        A.sec_wo[static_cast<long long>(x) * A.n + read] = static_cast<int32_t>(e - s);
+                        A.sec_so[static_cast<long long>(x) * A.sec_stride + read] = static_cast<int32_t>(s + 1);
+                        A.sec_wo[static_cast<long long>(x) * A.sec_stride + read] = static_cast<int32_t>(e - s);
                     }
                 } else {
                     // gapped strings, emitted from the end (src/reference_align.cpp:353-389)
@@ -878,13 +880,22 @@ struct AlignOut {
 
 // kernel_mode: 0 scores, 1 map, 2 strings.  Returns in *bad_qual_read the smallest
 // index of a read with a quality character below the encoding offset (or INT_MAX).
+// A host call may hand its batch over in chunks so that the upload of chunk k+1 overlaps the
+// kernel of chunk k: every chunk is one run_align on a slice of the same device arrays.
+struct ChunkOpts {
+    int64_t sec_stride = 0;   // 0: n (stand-alone launch)
+    int read_base = 0;        // index of the slice's first read in the whole batch
+    bool init_bad = true;     // reset the bad-quality flag (first chunk only)
+    bool finish = true;       // read the flag back and wait for the stream (last chunk only)
+};
+
 static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
                      int32_t max_len, const double* enc_errors, const char* enc_names, int enc_n,
                      double gapopen, double gapext, const char* ref, int R, bool local, int kernel_mode,
                      const int32_t* sec_starts, const int32_t* sec_ends, int nsec, const AlignOut& out,
-                     hipStream_t stream, int* bad_qual_read) {
+                     hipStream_t stream, int* bad_qual_read, const ChunkOpts& co = ChunkOpts()) {
     Context& c = ctx();
-    *bad_qual_read = std::numeric_limits<int>::max();
+    if (co.init_bad) *bad_qual_read = std::numeric_limits<int>::max();
     if (n <= 0) return 0;
     if (R > MAX_REF) return fail("sarlacc_amd: reference longer than %d columns is not supported", MAX_REF);
     if (enc_n > 256) return fail("sarlacc_amd: encoding vector longer than 256 entries");
@@ -918,16 +929,31 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
 
     AlignArgs a{};
     double* d_tab; double* d_rz; uint32_t* d_cb; uint8_t* d_ref; int32_t* d_ss = nullptr; int32_t* d_se = nullptr; int* d_bad;
-    SL_TRY(upload("align.tab", rows.data(), rows.size(), &d_tab, stream));
-    SL_TRY(upload("align.rz", rowzero.data(), rowzero.size(), &d_rz, stream));
-    SL_TRY(upload("align.cb", colbase.data(), colbase.size(), &d_cb, stream));
-    SL_TRY(upload("align.ref", reinterpret_cast<const uint8_t*>(ref), static_cast<size_t>(R), &d_ref, stream));
-    if (nsec) {
-        SL_TRY(upload("align.ss", sec_starts, static_cast<size_t>(nsec), &d_ss, stream));
-        SL_TRY(upload("align.se", sec_ends, static_cast<size_t>(nsec), &d_se, stream));
+    if (co.init_bad) {
+        SL_TRY(upload("align.tab", rows.data(), rows.size(), &d_tab, stream));
+        SL_TRY(upload("align.rz", rowzero.data(), rowzero.size(), &d_rz, stream));
+        SL_TRY(upload("align.cb", colbase.data(), colbase.size(), &d_cb, stream));
+        SL_TRY(upload("align.ref", reinterpret_cast<const uint8_t*>(ref), static_cast<size_t>(R), &d_ref, stream));
+        if (nsec) {
+            SL_TRY(upload("align.ss", sec_starts, static_cast<size_t>(nsec), &d_ss, stream));
+            SL_TRY(upload("align.se", sec_ends, static_cast<size_t>(nsec), &d_se, stream));
+        }
+        const int sentinel = std::numeric_limits<int>::max();
+        SL_TRY(upload("align.bad", &sentinel, 1, &d_bad, stream));
+        // a chunk that returns without waiting for its kernel must not leave copies from this
+        // frame's vectors in flight (nothing else is queued on the stream yet)
+        if (!co.finish) SL_HIP(hipStreamSynchronize(stream));
+    } else {   // later chunks of the same call: the tables of the first chunk are still in place
+        SL_TRY(scratch("align.tab", rows.size(), &d_tab));
+        SL_TRY(scratch("align.rz", rowzero.size(), &d_rz));
+        SL_TRY(scratch("align.cb", colbase.size(), &d_cb));
+        SL_TRY(scratch("align.ref", static_cast<size_t>(R), &d_ref));
+        if (nsec) {
+            SL_TRY(scratch("align.ss", static_cast<size_t>(nsec), &d_ss));
+            SL_TRY(scratch("align.se", static_cast<size_t>(nsec), &d_se));
+        }
+        SL_TRY(scratch("align.bad", 1, &d_bad));
     }
-    const int sentinel = std::numeric_limits<int>::max();
-    SL_TRY(upload("align.bad", &sentinel, 1, &d_bad, stream));
 
     Shape sh = pick_shape(R);
     if (const char* ek = std::getenv("SARLACC_ALIGN_K")) {  // tuning override
@@ -975,6 +1001,7 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     a.scores = out.d_scores; a.starts = out.d_starts; a.ends = out.d_ends;
     a.sec_s = d_ss; a.sec_e = d_se; a.nsec = nsec; a.sec_so = out.d_sec_so; a.sec_wo = out.d_sec_wo;
     a.dirs = d_dirs; a.dirs_per_wave = per_wave_elems; a.badqual = d_bad;
+    a.read_base = co.read_base; a.sec_stride = co.sec_stride ? co.sec_stride : n;
     a.snap_head = snap_head(R); a.snap_win = snap_win(R, sh.W);
     a.aln_ref = out.d_aln_ref; a.aln_qry = out.d_aln_qry; a.aln_len = out.d_aln_len; a.edits = out.d_edits;
 
@@ -986,6 +1013,7 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     SL_HIP(hipEventRecord(c.ev_stop, stream));
     c.timed = true;
 
+    if (!co.finish) return 0;
     SL_HIP(hipMemcpyAsync(bad_qual_read, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
     SL_HIP(hipStreamSynchronize(stream));
     return 0;
@@ -1034,7 +1062,7 @@ struct HostBatch {
 // different length make the whole call fail later (first_error), so qualities
 // are copied with the sequence offsets only when every length agrees.
 static int upload_batch(const char* seq, const int64_t* seq_off, const char* qual, const int64_t* qual_off,
-                        int64_t n, HostBatch* hb, hipStream_t s) {
+                        int64_t n, HostBatch* hb, hipStream_t s, bool defer_data = false) {
     int64_t mx = 0;
     bool same = true;
     for (int64_t i = 0; i < n; ++i) {
@@ -1049,9 +1077,15 @@ static int upload_batch(const char* seq, const int64_t* seq_off, const char* qua
     const int64_t total = n ? seq_off[n] - base : 0;
     std::vector<int64_t> rel(static_cast<size_t>(n) + 1);
     for (int64_t i = 0; i <= n; ++i) rel[i] = (n ? seq_off[i] : 0) - base;
-    SL_TRY(upload("batch.seq", reinterpret_cast<const uint8_t*>(seq) + base, static_cast<size_t>(total), &hb->d_seq, s));
-    SL_TRY(upload("batch.qual", reinterpret_cast<const uint8_t*>(qual) + (n ? qual_off[0] : 0), static_cast<size_t>(total), &hb->d_qual, s));
+    if (defer_data) {   // the caller copies the bases and qualities chunk by chunk
+        SL_TRY(scratch("batch.seq", static_cast<size_t>(total), &hb->d_seq));
+        SL_TRY(scratch("batch.qual", static_cast<size_t>(total), &hb->d_qual));
+    } else {
+        SL_TRY(upload("batch.seq", reinterpret_cast<const uint8_t*>(seq) + base, static_cast<size_t>(total), &hb->d_seq, s));
+        SL_TRY(upload("batch.qual", reinterpret_cast<const uint8_t*>(qual) + (n ? qual_off[0] : 0), static_cast<size_t>(total), &hb->d_qual, s));
+    }
     SL_TRY(upload("batch.off", rel.data(), rel.size(), &hb->d_off, s));
+    if (defer_data) SL_HIP(hipStreamSynchronize(s));   // `rel` goes out of scope
     return 0;
 }
 
@@ -1075,8 +1109,17 @@ static int host_align(const char* seq, const int64_t* seq_off, const char* qual,
     hipStream_t s = nullptr;
     if (n == 0) { if (aln_off) aln_off[0] = 0; return 0; }
 
+    // Large score / map calls go to the device in chunks: the bases and qualities of chunk k+1
+    // cross PCIe on a stream of their own while chunk k is aligned.
+    const int64_t total_bytes = seq_off[n] - seq_off[0];
+    int64_t nchunks = 1;
+    if (kernel_mode != 2 && R > 0) {
+        if (total_bytes >= (static_cast<int64_t>(512) << 20)) nchunks = std::min<int64_t>(8, total_bytes / (static_cast<int64_t>(256) << 20));
+        if (const char* ec = std::getenv("SARLACC_ALIGN_CHUNKS")) nchunks = std::max(1, std::atoi(ec));   // testing
+        nchunks = std::max<int64_t>(1, std::min<int64_t>(nchunks, n));
+    }
     HostBatch hb;
-    SL_TRY(upload_batch(seq, seq_off, qual, qual_off, n, &hb, s));
+    SL_TRY(upload_batch(seq, seq_off, qual, qual_off, n, &hb, s, nchunks > 1));
     if (hb.len_bad >= 0) {
         // reads before the offending one could still raise an earlier error, but
         // only a bad reference character is detectable without the qualities
@@ -1100,8 +1143,46 @@ static int host_align(const char* seq, const int64_t* seq_off, const char* qual,
         SL_TRY(scratch("out.edits", nn, &out.d_edits));
     }
     int bad = 0;
-    SL_TRY(run_align(hb.d_seq, nullptr, hb.d_qual, hb.d_off, n, hb.max_len, enc_errors, enc_names, enc_n, gapopen, gapext,
-                     ref, R, local, kernel_mode, sec_starts, sec_ends, nsec, out, s, &bad));
+    if (nchunks == 1) {
+        SL_TRY(run_align(hb.d_seq, nullptr, hb.d_qual, hb.d_off, n, hb.max_len, enc_errors, enc_names, enc_n, gapopen, gapext,
+                         ref, R, local, kernel_mode, sec_starts, sec_ends, nsec, out, s, &bad));
+    } else {
+        hipStream_t copy_stream = nullptr;
+        SL_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        std::vector<hipEvent_t> ready(static_cast<size_t>(nchunks), nullptr);
+        const int64_t sbase = seq_off[0], qbase = qual_off[0];
+        auto bound = [&](int64_t k) { return n * k / nchunks; };
+        auto send = [&](int64_t k) -> int {   // bases and qualities of the reads of chunk k
+            const int64_t lo = seq_off[bound(k)] - sbase, hi = seq_off[bound(k + 1)] - sbase;
+            if (hi > lo) {
+                SL_HIP(hipMemcpyAsync(hb.d_seq + lo, seq + sbase + lo, static_cast<size_t>(hi - lo), hipMemcpyHostToDevice, copy_stream));
+                SL_HIP(hipMemcpyAsync(hb.d_qual + lo, qual + qbase + lo, static_cast<size_t>(hi - lo), hipMemcpyHostToDevice, copy_stream));
+            }
+            SL_HIP(hipEventCreateWithFlags(&ready[k], hipEventDisableTiming));
+            SL_HIP(hipEventRecord(ready[k], copy_stream));
+            return 0;
+        };
+        int rc = send(0);
+        for (int64_t k = 0; k < nchunks && !rc; ++k) {
+            const int64_t lo = bound(k), hi = bound(k + 1);
+            rc = hipStreamWaitEvent(s, ready[k], 0) == hipSuccess ? 0 : fail("HIP error waiting for a chunk upload");
+            if (rc) break;
+            AlignOut co_out = out;
+            co_out.d_scores = out.d_scores + lo;
+            if (out.d_starts) { co_out.d_starts = out.d_starts + lo; co_out.d_ends = out.d_ends + lo; }
+            if (out.d_sec_so) { co_out.d_sec_so = out.d_sec_so + lo; co_out.d_sec_wo = out.d_sec_wo + lo; }
+            ChunkOpts co;
+            co.sec_stride = n; co.read_base = static_cast<int>(lo); co.init_bad = (k == 0); co.finish = (k + 1 == nchunks);
+            rc = run_align(hb.d_seq, nullptr, hb.d_qual, hb.d_off + lo, hi - lo, hb.max_len, enc_errors, enc_names, enc_n, gapopen,
+                           gapext, ref, R, local, kernel_mode, sec_starts, sec_ends, nsec, co_out, s, &bad, co);
+            if (!rc && k + 1 < nchunks) rc = send(k + 1);   // travels while chunk k is being aligned
+        }
+        (void)hipStreamSynchronize(copy_stream);
+        (void)hipStreamSynchronize(s);
+        for (hipEvent_t e : ready) if (e) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(copy_stream);
+        if (rc) return rc;
+    }
     SL_TRY(first_error(n, seq_off, nullptr, ref, R, bad));
 
     SL_HIP(hipMemcpy(scores, out.d_scores, nn * sizeof(double), hipMemcpyDeviceToHost));

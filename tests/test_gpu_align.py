@@ -323,3 +323,31 @@ def test_unmask_alignment(oracle):
     # first failing row decides the message
     with pytest.raises(SarlaccError, match="longer than the original"):
         calls.unmask_alignment(["AAAA", "NNNN", "AA-A"], ["AAAA", "GG", "A"])
+
+
+@pytest.mark.parametrize("chunks", [2, 3, 7])
+def test_chunked_host_calls_match_single_launch(oracle, oenc, enc, monkeypatch, chunks):
+    """Large host-pointer calls are sent to the device in chunks whose upload overlaps the
+    previous chunk's kernel (SARLACC_ALIGN_CHUNKS forces it on a small batch): same scores,
+    positions, sections and the same first error as the single launch and the oracle."""
+    from sarlacc_amd import calls
+    from sarlacc_amd._lib import SarlaccError
+    from sarlacc_amd.mock import random_reads
+    reads, quals = random_reads(101, 0, 300, seed=40 + chunks)
+    adaptor = "ACGATCAGC" + "N" * 12 + "GTCAGTCAG"
+    want = oracle.adaptor_align(reads, quals, oenc, 5, 1, adaptor, [9, 0], [21, 30])
+    monkeypatch.setenv("SARLACC_ALIGN_CHUNKS", str(chunks))
+    got = calls.adaptor_align(reads, quals, enc, 5, 1, adaptor, [9, 0], [21, 30])
+    assert np.array_equal(got[0].view(np.int64), want[0].view(np.int64))
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    for k in range(2):
+        assert np.array_equal(got[3][k], want[3][k]) and np.array_equal(got[4][k], want[4][k])
+    assert np.array_equal(calls.adaptor_align_score_only(reads, quals, enc, 5, 1, adaptor).view(np.int64), want[0].view(np.int64))
+    assert np.array_equal(calls.barcode_align(reads, quals, enc, 5, 1, "ACGTTGCA").view(np.int64),
+                          oracle.barcode_align(reads, quals, oenc, 5, 1, "ACGTTGCA").view(np.int64))
+    # a quality below the offset in a late chunk and an earlier, longer-than-quality read: the first one wins
+    bad_q = list(quals)
+    bad_q[90] = " " + bad_q[90][1:] if bad_q[90] else bad_q[90]
+    if bad_q[90]:
+        with pytest.raises(SarlaccError, match="quality cannot be lower"):
+            calls.adaptor_align(reads, bad_q, enc, 5, 1, adaptor, [9], [21])
