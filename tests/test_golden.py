@@ -33,6 +33,11 @@ def _check(impl, enc, err_type):
         assert [np.asarray(c).tolist() for c in got] == case["clusters"], case["source"]
     for case in GOLD["create_consensus_basic"]:
         assert impl.create_consensus_basic(case["aln"], case["min_cov"], case["pseudo"])[0] == case["consensus"], case["source"]
+    for case in GOLD["unmask_alignment"]:
+        assert impl.unmask_alignment(case["alignments"], case["originals"]) == case["unmasked"], case["source"]
+    for case in GOLD["unmask_errors"]:
+        with pytest.raises(err_type, match=case["message"]):
+            impl.unmask_alignment(case["alignments"], case["originals"])
     for case in GOLD["errors"]:
         with pytest.raises(err_type, match=case["message"]):
             impl.create_consensus_quality(case["aln"], 0.6, case["quals"], enc)
