@@ -1,6 +1,6 @@
 """GPU: a fixed-seed slice of the differential fuzzer (tools/fuzz.py) -- every C-ABI entry point
 against the oracle on randomised shapes, parameters and error cases.  The full fuzzer ran
-54 223 cases over the current kernels without a mismatch (profiles/r01_fuzz_v2.txt; 59 633 on the
+72 168 cases over the final kernels without a mismatch (profiles/r01_fuzz_v3.txt, incl. the chunked host path; 59 633 on the
 earlier ones, profiles/r01_fuzz.txt)."""
 import numpy as np
 import pytest

@@ -291,7 +291,7 @@ CASES = [case_align, case_align, case_umi, case_consensus, case_msa, case_mask, 
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    t0 = time.time()
+    t0 = last_note = time.time()
     counts = {}
     k = 0
     while time.time() - t0 < budget:
@@ -306,4 +306,7 @@ if __name__ == "__main__":
             sys.exit(1)
         counts[fn.__name__] = counts.get(fn.__name__, 0) + 1
         k += 1
+        if time.time() - last_note > 60:   # a long run has to show signs of life
+            last_note = time.time()
+            print("... %d cases after %.0f s" % (k, last_note - t0), flush=True)
     print("fuzz ok: %d cases in %.0f s: %s" % (k, time.time() - t0, counts))
