@@ -550,8 +550,14 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         if (q4) {
             const int grid4 = static_cast<int>(std::min<int64_t>((ng_eval + 3) / 4, static_cast<int64_t>(c.num_cu) * 8));
             hipLaunchKernelGGL(k_consensus_q4, dim3(grid4), dim3(256), lds4, s, a);
-        } else if (quality) hipLaunchKernelGGL(k_consensus<true>, dim3(grid), dim3(64), lds, s, a);
-        else hipLaunchKernelGGL(k_consensus<false>, dim3(grid), dim3(64), lds, s, a);
+        } else {
+            if (lds > 48 * 1024) {   // alignments of thousands of rows: more than the default 64 KB of dynamic LDS
+                SL_HIP(hipFuncSetAttribute(quality ? reinterpret_cast<const void*>(&k_consensus<true>) : reinterpret_cast<const void*>(&k_consensus<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            }
+            if (quality) hipLaunchKernelGGL(k_consensus<true>, dim3(grid), dim3(64), lds, s, a);
+            else hipLaunchKernelGGL(k_consensus<false>, dim3(grid), dim3(64), lds, s, a);
+        }
         SL_HIP(hipGetLastError());
         SL_HIP(hipEventRecord(c.ev_stop, s));
         c.timed = true;

@@ -629,6 +629,10 @@ static int launch_pairwise(const MsaArgs& a, int grid, size_t lds, hipStream_t s
 
 template <int C>
 static int launch_pairwise_ad(const MsaArgs& a, int grid, size_t lds, hipStream_t s) {
+    // long reads stage more than the default 64 KB of dynamic LDS (gfx950 has 160 KB per CU)
+    if (lds > 48 * 1024)
+        SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msa_pairwise_ad<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(lds)));
     hipLaunchKernelGGL(k_msa_pairwise_ad<C>, dim3(grid), dim3(64), lds, s, a);
     SL_HIP(hipGetLastError());
     return 0;

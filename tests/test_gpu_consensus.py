@@ -115,3 +115,25 @@ def test_random_batches(oracle, oenc, enc, seed, ngroups, nrows, width):
         w = oracle.create_consensus_basic_loop(alns, cov, 1.0)
         g = calls.create_consensus_basic_loop(alns, cov, 1.0)
         assert g[0] == w[0] and g[1] == w[1]
+
+
+def test_consensus_of_a_very_deep_alignment(oracle, oenc, enc):
+    """3 000 rows: the per-row offsets of the one-column kernel need more than 64 KB of LDS."""
+    from sarlacc_amd import calls
+    rng = np.random.default_rng(17)
+    truth = rng.choice(list("ACGT"), 90)
+    rows, quals = [], []
+    for _ in range(3000):
+        r = truth.copy()
+        sub = rng.random(90) < 0.1
+        r[sub] = rng.choice(list("ACGT"), int(sub.sum()))
+        r[rng.random(90) < 0.05] = "-"
+        row = "".join(r)
+        rows.append(row)
+        quals.append("".join(chr(int(c)) for c in rng.integers(40, 80, len(row.replace("-", "")))))
+    got = calls.create_consensus_quality_loop([rows], 0.6, [quals], enc)
+    want = oracle.create_consensus_quality_loop([rows], 0.6, [quals], oenc)
+    assert got[0] == list(want[0]) and got[1] == list(want[1])
+    gb = calls.create_consensus_basic_loop([rows], 0.6, 1.0)
+    wb = oracle.create_consensus_basic_loop([rows], 0.6, 1.0)
+    assert gb[0] == list(wb[0]) and gb[1] == list(wb[1])

@@ -107,3 +107,16 @@ def test_fused_msa_consensus_equals_two_calls(quality):
     assert got[0].to_strings() == want[0].to_strings()
     assert got[1].to_strings() == want[1].to_strings()
     assert len(got[0]) == len(groups) and got[0][5] == ""
+
+
+def test_msa_long_reads(oracle):
+    """40-kb reads: read and centre codes take more than the default 64 KB of dynamic LDS."""
+    from sarlacc_amd import calls
+    from sarlacc_amd.mock import NUC, mutate
+    rng = np.random.default_rng(8)
+    truth = NUC[rng.integers(0, 4, 40000)]
+    reads = [mutate(truth, rng, 0.03, 0.005).tobytes().decode() for _ in range(3)]
+    groups = [[1, 2, 3]]
+    got = calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)
+    assert got == oracle.quick_msa(groups, reads, 0, -1, -5, -1, 100)
+    assert len({len(r) for r in got[0]}) == 1
