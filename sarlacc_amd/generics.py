@@ -19,7 +19,7 @@ import numpy as np
 from . import calls
 from .encoding import Encoding, phred_encoding
 from .mock import _COMP
-from .strset import StringSet
+from .strset import StringSet, StrList
 
 
 class Reads:
@@ -146,7 +146,10 @@ def _swap_rows(a, b, mask):
     for key in ("score", "start", "end"):
         a[key] = np.where(mask, b[key], a[key])
     for k in a["subseq"]:
-        a["subseq"][k] = [y if m else x for x, y, m in zip(a["subseq"][k], b["subseq"][k], mask)]
+        if isinstance(a["subseq"][k], StrList):
+            a["subseq"][k] = StrList.where(mask, b["subseq"][k], a["subseq"][k])
+        else:
+            a["subseq"][k] = [y if m else x for x, y, m in zip(a["subseq"][k], b["subseq"][k], mask)]
 
 
 def _align_and_extract_resident(adaptor, dev, host_seq, gap_opening, gap_extension, subseq_starts, subseq_ends):
@@ -154,7 +157,7 @@ def _align_and_extract_resident(adaptor, dev, host_seq, gap_opening, gap_extensi
     out = dev.align_map(adaptor, gap_opening, gap_extension, np.asarray(subseq_starts, dtype=np.int32) - 1, subseq_ends)
     res = {"score": out[0], "start": out[1], "end": out[2], "subseq": {}}
     for i, (st, wd) in enumerate(zip(out[3], out[4])):
-        res["subseq"]["Sub%d" % (i + 1)] = _subseq(host_seq, st, wd).to_strings()
+        res["subseq"]["Sub%d" % (i + 1)] = StrList(_subseq(host_seq, st, wd))   # decoded on demand
     return res
 
 
@@ -199,15 +202,20 @@ def adaptorAlign(adaptor1, adaptor2, reads, tolerance=250, gapOpening=5, gapExte
 
 
 # ---------------------------------------------------------------------------
+def _select(col, keep):
+    """Rows of a character column (list or StrList) where `keep` is set."""
+    return col.select(keep) if isinstance(col, StrList) else [x for x, k in zip(col, keep) if k]
+
+
 def _subset_aligned(aligned, keep):
     """aligned[keep, ] of the reference's DataFrame (rows of every column, nested ones included)."""
     keep = np.asarray(keep, dtype=bool)
     out = {"metadata": aligned["metadata"], "read.width": aligned["read.width"][keep], "reversed": aligned["reversed"][keep],
-           "names": None if aligned.get("names") is None else [x for x, k in zip(aligned["names"], keep) if k]}
+           "names": None if aligned.get("names") is None else _select(aligned["names"], keep)}
     for key in ("adaptor1", "adaptor2"):
         a = aligned[key]
         out[key] = {"score": a["score"][keep], "start": a["start"][keep], "end": a["end"][keep], "metadata": a.get("metadata"),
-                    "subseq": {k: [x for x, kk in zip(v, keep) if kk] for k, v in a["subseq"].items()}}
+                    "subseq": {k: _select(v, keep) for k, v in a["subseq"].items()}}
     for extra in ("trim.start", "trim.end"):
         if extra in aligned:
             out[extra] = aligned[extra][keep]

@@ -74,8 +74,9 @@ class DeviceReads:
         off, names, noff = DevBuffer(8 * (n + 1)), DevBuffer(max(tn.value, 1)), DevBuffer(8 * (n + 1))
         check(_lib.lib().sarlacc_dev_fastq_extract(d_text.ptr, seq.ptr, qual.ptr, off.ptr, names.ptr, noff.ptr, None))
         out = cls(seq, qual, off, off.to_numpy(np.int64, n + 1), encoding)
-        nraw, no = names.to_numpy(np.uint8, tn.value).tobytes(), noff.to_numpy(np.int64, n + 1)
-        out.names = [nraw[no[i]:no[i + 1]].decode() for i in range(n)]
+        from .strset import StrList
+        nraw = names.to_numpy(np.uint8, tn.value)
+        out.names = StrList(StringSet(nraw if nraw.size else np.zeros(1, np.uint8), noff.to_numpy(np.int64, n + 1)))   # decoded on demand
         return out
 
     def __len__(self):

@@ -76,6 +76,74 @@ class StringSet:
         return StringSet(chars, off)
 
 
+class StrList:
+    """Read-only list of strings backed by a StringSet: the stand-in for an R character vector
+    column (read names, extracted sub-sequences) that is only decoded when someone looks.
+    Compares equal to a Python list with the same strings."""
+
+    __slots__ = ("ss",)
+
+    def __init__(self, ss):
+        self.ss = ss if isinstance(ss, StringSet) else StringSet.from_strings(ss)
+
+    def __len__(self):
+        return len(self.ss)
+
+    def __iter__(self):
+        return iter(self.ss.to_strings())
+
+    def __getitem__(self, i):
+        if isinstance(i, (int, np.integer)):
+            n = len(self.ss)
+            if i < 0:
+                i += n
+            if not 0 <= i < n:
+                raise IndexError("index out of range")
+            return self.ss[int(i)]
+        if isinstance(i, slice):
+            return StrList(self.ss.subset(np.arange(len(self.ss))[i]))
+        i = np.asarray(i)
+        return self.select(i) if i.dtype == bool else StrList(self.ss.subset(i))
+
+    def __eq__(self, other):
+        if isinstance(other, StrList):
+            o = other.ss
+            return (len(o) == len(self.ss) and np.array_equal(o.off, self.ss.off)
+                    and np.array_equal(o.chars[:o.total], self.ss.chars[:self.ss.total]))
+        if isinstance(other, (list, tuple)):
+            return len(other) == len(self.ss) and self.ss.to_strings() == list(other)
+        return NotImplemented
+
+    def __ne__(self, other):
+        r = self.__eq__(other)
+        return r if r is NotImplemented else not r
+
+    def __repr__(self):
+        return "StrList(%d strings)" % len(self.ss)
+
+    def tolist(self):
+        return self.ss.to_strings()
+
+    def __add__(self, other):       # list concatenation yields a plain list
+        return self.tolist() + list(other)
+
+    def __radd__(self, other):
+        return list(other) + self.tolist()
+
+    def select(self, keep):
+        """Rows where the boolean mask `keep` is set."""
+        return StrList(self.ss.subset(np.flatnonzero(np.asarray(keep, dtype=bool))))
+
+    @staticmethod
+    def where(mask, a, b):
+        """Element-wise a[i] if mask[i] else b[i] (both StrList of the same length)."""
+        mask = np.asarray(mask, dtype=bool)
+        n = len(a)
+        both = StringSet(np.concatenate([a.ss.chars[:a.ss.total], b.ss.chars[:b.ss.total], np.zeros(1, np.uint8)]),
+                         np.concatenate([a.ss.off, b.ss.off[1:] + a.ss.off[-1]]))
+        return StrList(both.subset(np.where(mask, np.arange(n), n + np.arange(n))))
+
+
 def csr_from_lists(lists):
     """list of integer sequences -> (int64 offsets, int32 values)"""
     off = np.zeros(len(lists) + 1, dtype=np.int64)

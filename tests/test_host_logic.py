@@ -260,3 +260,20 @@ def test_assign_groups_snake_is_balanced_and_deterministic():
         counts = np.bincount(owner, minlength=world)
         assert counts.max() - counts.min() <= 1
     assert assign_groups_snake(np.zeros(0), 4).size == 0
+
+
+def test_strlist_behaves_like_a_list_of_strings():
+    from sarlacc_amd.strset import StrList
+    words = ["ACGT", "", "GG", "TTTTT", "A"]
+    sl = StrList(words)
+    assert len(sl) == 5 and list(sl) == words and sl == words and words == sl and sl == StrList(words)
+    assert sl != words[:-1] and not (sl == ["ACGT", "", "GG", "TTTTT", "C"])
+    assert sl[3] == "TTTTT" and sl[-1] == "A" and sl[1:4] == words[1:4]
+    mask = np.array([True, False, True, False, True])
+    assert sl.select(mask) == ["ACGT", "GG", "A"] and sl[mask] == ["ACGT", "GG", "A"]
+    assert sl[np.array([4, 0])] == ["A", "ACGT"]
+    other = StrList(["x1", "x2", "x3", "x4", "x5"])
+    assert StrList.where(mask, other, sl) == ["x1", "", "x3", "TTTTT", "x5"]
+    assert StrList([]) == [] and len(StrList([]).select(np.zeros(0, bool))) == 0
+    with pytest.raises(IndexError):
+        sl[5]
