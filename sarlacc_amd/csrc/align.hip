@@ -174,7 +174,7 @@ static inline int snap_win(int R, int W) { return (SNAP_P + snap_head(R) + W + 7
 // (true instead of false), and the true flag is raw && !(previous cell's move is the same gap
 // kind) -- the traceback applies that from the neighbour's code, which it reads anyway.
 template <int K, int MODE, bool LOCAL, bool ROW16, int KLAST, bool PENSEL>
-__global__ void __launch_bounds__(64 * NWAVES, 5) k_align(const AlignArgs A) {
+__global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const AlignArgs A) {
     constexpr int UNR = TbSteps<K>::value;
     constexpr int CELLS = UNR * K;
     using Word = typename TbStore<K>::type;
@@ -979,7 +979,11 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
         per_wave_elems = static_cast<size_t>(snap_win(R, sh.W) / tb_steps) * 64 +
                          nsnap * (2 * sh.K + 3) * 64 * (sizeof(double) / word_bytes);
     }
-    int waves_per_cu = 20;
+    // Far more workgroups than fit at once: each wave then owns only a few work items and the
+    // hardware hands out workgroups as CUs free up, which balances the load much better than an
+    // exactly resident grid with a static stride (1.74 -> 2.07 TCUPS at 1M x 2kb; flat from 128 to
+    // 384 waves per CU).  The per-wave scratch tiles scale with the grid and are capped below.
+    int waves_per_cu = 128;
     if (const char* ew = std::getenv("SARLACC_ALIGN_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(ew));
     // workgroups of NWAVES wavefronts; every wavefront owns a traceback tile
     long long grid = std::min<long long>((nitems + NWAVES - 1) / NWAVES,

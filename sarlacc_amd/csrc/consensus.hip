@@ -548,7 +548,7 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         const bool q4 = quality && !lerr && lds4 <= 48 * 1024 && !std::getenv("SARLACC_CONSENSUS_NARROW");
         SL_HIP(hipEventRecord(c.ev_start, s));
         if (q4) {
-            const int grid4 = static_cast<int>(std::min<int64_t>((ng_eval + 3) / 4, static_cast<int64_t>(c.num_cu) * 8));
+            const int grid4 = static_cast<int>(std::min<int64_t>((ng_eval + 3) / 4, static_cast<int64_t>(c.num_cu) * 64));
             hipLaunchKernelGGL(k_consensus_q4, dim3(grid4), dim3(256), lds4, s, a);
         } else {
             if (lds > 48 * 1024) {   // alignments of thousands of rows: more than the default 64 KB of dynamic LDS

@@ -765,8 +765,10 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
             if (lds > 160 * 1024) return fail("sarlacc_amd: reads of %d bases do not fit the MSA kernel's LDS staging", std::max(cls_lr[cls], cls_lc[cls]));
             const long long by_lds = std::max<long long>(1, static_cast<long long>((160 * 1024) / lds));
             long long grid = std::min<long long>(static_cast<long long>(order[cls].size()),
-                                                 static_cast<long long>(c.num_cu) * std::min<long long>(scan_kernel ? (C == 4 ? 16 : 8) : (C == 4 ? 20 : (C == 8 ? 16 : 8)), by_lds));
-            const size_t budget = static_cast<size_t>(8) << 30;
+                                                 static_cast<long long>(c.num_cu) * (scan_kernel ? std::min<long long>(C == 4 ? 16 : 8, by_lds) : 128));
+            // many more single-wave workgroups than fit at once (a wave then aligns only a few pairs and the
+            // hardware balances the load); their traceback tiles are the price, capped at 24 GB of HBM
+            const size_t budget = static_cast<size_t>(24) << 30;
             grid = std::min<long long>(grid, std::max<long long>(1, static_cast<long long>(budget / (per_wave * word))));
             void* d_tb; int* d_order;
             const char* tb_name[3] = {"msa.tb0", "msa.tb1", "msa.tb2"};
