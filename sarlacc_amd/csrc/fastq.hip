@@ -22,6 +22,7 @@
 #include "../../include/sarlacc_amd.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <limits>
 
 namespace sarlacc {
@@ -315,7 +316,8 @@ int sarlacc_dev_fastq_extract(const uint8_t* d_text, uint8_t* d_seq, uint8_t* d_
     SL_HIP(hipMemcpyAsync(d_off, off, sizeof(int64_t) * (static_cast<size_t>(nrec) + 1), hipMemcpyDeviceToDevice, s));
     if (d_name_off) SL_HIP(hipMemcpyAsync(d_name_off, noff, sizeof(int64_t) * (static_cast<size_t>(nrec) + 1), hipMemcpyDeviceToDevice, s));
     Context& c = ctx();
-    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(nrec, static_cast<int64_t>(c.num_cu) * 64));
+    // one workgroup per record (up to 1024 per CU): dynamic dispatch beats a resident grid with a stride
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(nrec, static_cast<int64_t>(c.num_cu) * 1024));
     SL_HIP(hipEventRecord(c.ev_start, s));
     hipLaunchKernelGGL(k_fq_copy, dim3(grid), dim3(128), 0, s, d_text, d_rec, off, noff, static_cast<long long>(nrec), d_seq, d_qual,
                        d_names);
