@@ -345,6 +345,7 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
                     }
                 }
                 Word pk = 0;
+                double v_first = 0.0;   // TR 2: vertical candidate of column R at the block's first step
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     if (!ROW16) {
@@ -399,8 +400,14 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
                                     vp_hi[k] = sel32(hi32(vgo[k]), hi32(vge[k]), m_vn);
                                     vp_lo[k] = sel32(lo32(vgo[k]), lo32(vge[k]), m_vn);
                                 }
-                                if (TR == 2) {
-                                    if (is_last) land_x2 = sel32(land_x2, x2, __builtin_amdgcn_ballot_w64(best > V));
+                                if (TR == 2 && is_last) {
+                                    // Column R's score never decreases down the rows (free vertical gaps), so
+                                    // "some row of this block improved it" is one comparison per block: the
+                                    // score after the block against the running maximum before it.  The
+                                    // block's last row is recorded; the walk steps up the <= UNR - 1 vertical
+                                    // moves to the exact landing row through the recomputed codes.
+                                    if (u == 0) v_first = V;
+                                    if (u == UNR - 1) land_x2 = sel32(land_x2, x2, __builtin_amdgcn_ballot_w64(best > v_first));
                                 }
                                 if (CODES) {
                                     if (ADDC) {
