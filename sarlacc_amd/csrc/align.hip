@@ -148,7 +148,7 @@ struct Int { static constexpr int value = V; };
 // most SNAP_WIN steps with traceback codes; the leader walks the window and, should the path
 // leave it through the top, the next window up is recomputed.  A snapshot is the exact state
 // of the recurrence, so the recomputed cells are the cells of the first pass, bit for bit.
-constexpr int SNAP_P = 64;      // steps between snapshots (multiple of the 64-row staging block)
+constexpr int SNAP_P = 128;     // steps between snapshots (multiple of the 64-row staging block)
 // rows above the row a walk asks for that its window must cover: an alignment of R columns
 // rarely spans more than R + R/4 rows, and a longer one only costs another window
 static inline int snap_head(int R) { return R + R / 4 + 4; }
