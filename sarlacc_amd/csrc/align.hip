@@ -499,7 +499,14 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
             unsigned cur = 0;
             int want = row;         // lowest row the next window has to hold
             int pending = valid ? 1 : 0;
+            // every round moves at least one alignment to an earlier snapshot, so the number of rounds
+            // is bounded; the explicit bound guarantees that the wave leaves the loop whatever the codes say
+            int rounds_left = (Lmax + W) / SNAP_P + 8;
             while (__builtin_amdgcn_ballot_w64(pending != 0)) {
+                if (--rounds_left < 0) {
+                    if (lane == 0) atomicExch(A.badqual + 1, 1);
+                    break;
+                }
                 // ---- recompute the window that holds row `want` (per alignment) ----
                 const int ts = pending ? (max(want - A.snap_head, 0) / SNAP_P) * SNAP_P : 0;
                 // steps [0, nwin) of the window; [t_wa, t_wb) of them have every lane of every
@@ -945,8 +952,8 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
             SL_TRY(upload("align.ss", sec_starts, static_cast<size_t>(nsec), &d_ss, stream));
             SL_TRY(upload("align.se", sec_ends, static_cast<size_t>(nsec), &d_se, stream));
         }
-        const int sentinel = std::numeric_limits<int>::max();
-        SL_TRY(upload("align.bad", &sentinel, 1, &d_bad, stream));
+        const int sentinel[2] = {std::numeric_limits<int>::max(), 0};   // [0] bad-quality read, [1] walk exceeded its bound
+        SL_TRY(upload("align.bad", sentinel, 2, &d_bad, stream));
         // a chunk that returns without waiting for its kernel must not leave copies from this
         // frame's vectors in flight (nothing else is queued on the stream yet)
         if (!co.finish) SL_HIP(hipStreamSynchronize(stream));
@@ -959,7 +966,7 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
             SL_TRY(scratch("align.ss", static_cast<size_t>(nsec), &d_ss));
             SL_TRY(scratch("align.se", static_cast<size_t>(nsec), &d_se));
         }
-        SL_TRY(scratch("align.bad", 1, &d_bad));
+        SL_TRY(scratch("align.bad", 2, &d_bad));
     }
 
     Shape sh = pick_shape(R);
@@ -1025,8 +1032,11 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     c.timed = true;
 
     if (!co.finish) return 0;
-    SL_HIP(hipMemcpyAsync(bad_qual_read, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+    int flags[2] = {0, 0};
+    SL_HIP(hipMemcpyAsync(flags, d_bad, sizeof flags, hipMemcpyDeviceToHost, stream));
     SL_HIP(hipStreamSynchronize(stream));
+    *bad_qual_read = flags[0];
+    if (flags[1]) return fail("sarlacc_amd: internal error: an alignment traceback exceeded its bound");
     return 0;
 }
 

@@ -58,6 +58,8 @@ struct MsaArgs {
     uint8_t* aln;           // per pair: 1 if the centre base is matched to a read base
     void* tb;               // per-wave traceback tile
     unsigned long long tb_per_wave;  // in tile words
+    int* stuck;             // set when a traceback exceeds its step bound (cannot happen with consistent codes;
+                            // the bound is what guarantees that every wave leaves the walk)
 };
 
 __device__ __forceinline__ uint8_t dna5_code(uint8_t c) {
@@ -209,7 +211,8 @@ __global__ void __launch_bounds__(64) k_msa_pairwise(const MsaArgs A) {
         uint8_t* aln = A.aln + J.out_off;
         int i = lr, j = lc, state = 0, cnt = 0;
         int cb = lr + 1;  // first row held in the window (none yet)
-        while (i > 0 || j > 0) {
+        int walk_budget = 2 * (lr + lc) + 64;   // every iteration consumes a row, a column or changes state once
+        while ((i > 0 || j > 0) && --walk_budget >= 0) {
             if (i < cb) {
                 cb = max(0, i - (TB_ROWS - 1));
                 __syncthreads();
@@ -254,6 +257,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise(const MsaArgs A) {
             }
         }
         if (lane == 0) ins[0] = static_cast<uint16_t>(cnt);
+        if (walk_budget < 0 && lane == 0) atomicExch(A.stuck, 1);
         __syncthreads();
     }
 }
@@ -453,7 +457,8 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
             const int q = (ws % SPW) * C + (k & 1) * H2 + (k >> 1);
             shift = 4 * (SPW * C - 1 - q);
         };
-        while (i > 0 || j > 0) {
+        int walk_budget = 2 * (lr + lc) + 64;   // every iteration consumes a row, a column or changes state once
+        while ((i > 0 || j > 0) && --walk_budget >= 0) {
             const int x = j - i - dlo;
             int wrow, shift, ln;
             locate(i, x, wrow, shift, ln);
@@ -501,6 +506,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
             }
         }
         if (lane == 0) ins[0] = static_cast<uint16_t>(cnt);
+        if (walk_budget < 0 && lane == 0) atomicExch(A.stuck, 1);
         __syncthreads();
     }
 }
@@ -750,6 +756,10 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         // SeqAn's Score(match, mismatch, gap_extend, gap_open): gap of length k = open + (k-1)*extend
         a.go = static_cast<int>(gap_opening); a.ge = static_cast<int>(gap_extension);
         a.bw = bandwidth; a.ins = d_ins; a.aln = d_aln;
+        int* d_stuck;
+        SL_TRY(scratch("msa.stuck", 1, &d_stuck));
+        SL_HIP(hipMemsetAsync(d_stuck, 0, sizeof(int), s));
+        a.stuck = d_stuck;
         SL_HIP(hipEventRecord(c.ev_start, s));
         for (int cls = 0; cls < 3; ++cls) {
             if (order[cls].empty()) continue;
@@ -800,6 +810,12 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     SL_HIP(hipGetLastError());
     std::vector<int32_t> width(static_cast<size_t>(ngroups));
     SL_HIP(hipMemcpy(width.data(), d_width, sizeof(int32_t) * width.size(), hipMemcpyDeviceToHost));
+    if (!jobs.empty()) {
+        int* d_stuck; int stuck = 0;
+        SL_TRY(scratch("msa.stuck", 1, &d_stuck));
+        SL_HIP(hipMemcpy(&stuck, d_stuck, sizeof stuck, hipMemcpyDeviceToHost));
+        if (stuck) return fail("sarlacc_amd: internal error: an MSA traceback exceeded its step bound");
+    }
     std::vector<long long> ooff(static_cast<size_t>(ngroups) + 1, 0);
     for (int64_t g = 0; g < ngroups; ++g) {
         width_out[g] = width[g];
