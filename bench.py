@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): adaptorAlign at the `.Call` level --
+Headline workload (BASELINE.json configs[1]): adaptorAlign at the `.Call` level --
 10^6 synthetic 2-kb Nanopore-like reads (mockReads recipe) against the 30-bp
 adaptor (9 fixed + 12 N + 9 fixed), quality-aware local DP with traceback and one
 section (the UMI), go=5, ge=1.  A "step" is one pass of adaptor_align over the
-whole read batch, which is generated once and stays resident in HBM.
+whole read batch, which is generated once and stays resident in HBM; `value` = GCUPS.
+
+Second half of the headline metric (configs[2] + configs[3]), reported under "pipeline":
+10^5 molecules x 10 reads x 2 kb generated in HBM, umiGroup (threshold 1, one pre-group
+per GPU) -> multiReadAlign (bandwidth 100) -> consensusReadSeq (quality vote), reads/min
+from the UMI strings to the consensus strings, with per-stage seconds, per-kernel
+milliseconds (HIP events on the launch stream) and a roofline entry for the two dominant
+kernels.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--read-len L]
 
-For N > 1 launch with torch.distributed.run (one rank per GPU); reads shard
-across ranks with no data-path collective (weak scaling: --reads is per GPU).
+For N > 1 launch with torch.distributed.run (one rank per GPU).  Reads shard across ranks
+(weak scaling: --reads and --molecules are per GPU); the DP has no data-path collective,
+the pipeline all-gathers the UMI cluster labels over RCCL (configs[4] in miniature).
 Rank 0 prints one JSON line.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -26,65 +37,75 @@ ADAPTOR1 = "ACGATCAGC" + "N" * 12 + "GTCAGTCAG"  # 30 bp, UMI = the N run
 ADAPTOR2 = "CACACTGAGCAGCGACTAGACA"              # 22 bp
 UMI_SECTION = ([9], [21])                        # 0-based start, 1-based end
 GAP_OPEN, GAP_EXT = 5.0, 1.0
-HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); 256 CUs x 4 SIMD-32 at 2.4 GHz: a wave64 32-bit VALU
+# instruction issues in 2 cycles (32 lanes/clk/SIMD), an fp64 one in 4 (16 lanes/clk/SIMD)
+HBM_PEAK_GBS = 8000.0
+VALU32_PEAK_TLOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 78.6 T lane-ops/s, 32-bit
+VALU64_PEAK_TLOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # 39.3 T lane-ops/s, fp64
+# algorithmic work per DP cell: quality DP = 10 fp64 add/sub/max/compare
+# (Appendix A of SURVEY.md: H, LJ, V, UJ updates, M, three compares); integer Gotoh of the MSA
+# pairwise stage = 5 add + 4 max + 2 for the match score = 11 int32 ops (traceback bits excluded)
+ALIGN_OPS_PER_CELL = 10
+MSA_OPS_PER_CELL = 11
 
 
-def cpu_baseline(sample_seq, sample_qual):
-    """Oracle (bit-exact CPU port of the reference's loop) on a bounded sample, 1 core."""
+def source_sha(names):
+    h = hashlib.sha256()
+    for nm in names:
+        with open(os.path.join(ROOT, "sarlacc_amd", "csrc", nm), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(kernel, sources):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*_pmc_<kernel>*.json,
+    written by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE passes; counters cannot be
+    collected from inside this process).  Returned only while the kernel's source files still hash to
+    what was profiled, so stale counters never sit next to fresh timings."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s*.json" % kernel)),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    for f in reversed(files):
+        with open(f) as fh:
+            d = json.load(fh)
+        if d.get("source_sha") != source_sha(sources):
+            continue
+        fe, wr = d.get("FETCH_SIZE_KB_per_launch") or [], d.get("WRITE_SIZE_KB_per_launch") or []
+        if not fe or not wr:
+            continue
+        return {"traffic": (sum(fe) / len(fe) + sum(wr) / len(wr)) * 1024.0, "traffic_source": os.path.relpath(f, ROOT),
+                "workload": d.get("workload"), "derived": d.get("derived")}
+    return {"traffic": None, "traffic_source": None}
+
+
+def cpu_baseline(seq_strings, qual_strings, cores):
+    """Oracle (bit-exact CPU port of the reference's loop, oracle/align.c) on a bounded sample of the
+    same batch: one thread, and all host cores (threads over read chunks = the analogue of the
+    reference's BiocParallel chunking, R/adaptorAlign.R:126-134; ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.build()
     enc = O.phred_encoding()
+    R = len(ADAPTOR1)
+
+    def run(lo, hi):
+        O.adaptor_align(seq_strings[lo:hi], qual_strings[lo:hi], enc, GAP_OPEN, GAP_EXT, ADAPTOR1, *UMI_SECTION)
+        return sum(len(s) for s in seq_strings[lo:hi]) * R
+
+    n = len(seq_strings)
+    n1 = max(1, min(n, n // max(cores, 1)))
     t0 = time.perf_counter()
-    O.adaptor_align(sample_seq, sample_qual, enc, GAP_OPEN, GAP_EXT, ADAPTOR1, *UMI_SECTION)
+    cells1 = run(0, n1)
+    dt1 = time.perf_counter() - t0
+    chunks = [(n * k // (4 * cores), n * (k + 1) // (4 * cores)) for k in range(4 * cores)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        cells = sum(ex.map(lambda c: run(*c), chunks))
     dt = time.perf_counter() - t0
-    cells = sum(len(s) for s in sample_seq) * len(ADAPTOR1)
-    return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
-            "sample": "%d reads of the same batch (%.1f s of oracle adaptor_align, 1 thread)" % (len(sample_seq), dt)}
-
-
-def pmc_traffic(n_reads):
-    """HBM bytes per launch of the DP kernel from the committed rocprofv3 PMC passes
-    (profiles/r*_pmc_1M_*.json; FETCH_SIZE and WRITE_SIZE are collected in separate passes and
-    cannot be collected from inside this process).  Returned only for the configuration the
-    passes were run on; FETCH_SIZE is taken at face value (the guide's possible 2x under-count
-    for wide reads is noted in the file)."""
-    import glob
-    import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_1M_v*.json")),
-                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
-    if not files or n_reads != 1_000_000:
-        return None
-    with open(files[-1]) as fh:
-        d = json.load(fh)
-    kb = sum(d["FETCH_SIZE_KB_per_launch"]) / len(d["FETCH_SIZE_KB_per_launch"]) + \
-        sum(d["WRITE_SIZE_KB_per_launch"]) / len(d["WRITE_SIZE_KB_per_launch"])
-    return kb * 1024.0, d.get("derived")
-
-
-def pipeline_sample(groups=10000, read_len=2000, copies=10):
-    """Second half of the headline metric on a bounded sample: reads/min through
-    umi_group -> quick_msa -> create_consensus_quality_loop (host-pointer C ABI, PCIe included)."""
-    import numpy as np
-    import sarlacc_amd
-    from sarlacc_amd import calls
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from perf_pipeline import NUC, noisy_copies
-    rng = np.random.default_rng(1000)
-    umis, _ = noisy_copies(NUC[rng.integers(0, 4, (groups, 12))], copies, rng)
-    reads, quals = noisy_copies(NUC[rng.integers(0, 4, (groups, read_len))], copies, rng)
-    n = len(reads)
-    enc = sarlacc_amd.phred_encoding()
-    best = None
-    for _ in range(2):
-        t0 = time.perf_counter()
-        coff, cmem = calls.umi_group_flat(umis, 1, None, 1, np.array([0, n], np.int64), np.arange(1, n + 1, dtype=np.int32))
-        goff, gflat = calls.csr_select(coff, cmem, np.diff(coff) >= 2)
-        cons, _ = calls.msa_consensus_flat(goff, gflat, reads, 0, -1, -5, -1, 100, 0.6, quals=quals, encoding=enc)
-        dt = time.perf_counter() - t0   # everything between the UMI strings and the consensus strings
-        best = dt if best is None else min(best, dt)
-    return {"reads_per_min": n / best * 60.0, "reads": n, "consensus_reads": len(cons),
-            "workload": "%d molecules x %d reads x %d bp, 12-bp UMIs: umi_group(threshold 1) -> msa_consensus (quick_msa bandwidth 100 + quality consensus, rows stay in HBM), "
-                        "host-pointer C ABI incl. PCIe and the host glue between the calls" % (groups, copies, read_len)}
+    return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
+            "sample": "%d reads of the same batch, %d threads over read chunks (%.1f s of oracle adaptor_align)" % (n, cores, dt),
+            "single_core": {"value": cells1 / dt1 / 1e9, "unit": "GCUPS", "cores": 1,
+                            "sample": "%d reads, 1 thread (%.1f s)" % (n1, dt1)},
+            "note": "the reference's C++ needs Rcpp/Biostrings headers absent from the image, hence a port"}
 
 
 def main():
@@ -92,13 +113,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (DP workload)")
     ap.add_argument("--read-len", type=int, default=2000)
-    ap.add_argument("--cpu-sample", type=int, default=25000)
+    ap.add_argument("--molecules", type=int, default=100_000, help="molecules per GPU (pipeline workload, x --copies reads)")
+    ap.add_argument("--copies", type=int, default=10)
+    ap.add_argument("--threshold", type=int, default=1, help="umiGroup threshold of the pipeline workload")
+    ap.add_argument("--cpu-sample", type=int, default=3000, help="reads per host core in the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
+    ap.add_argument("--no-host-pointer", action="store_true", help="skip the PCIe-inclusive host-pointer figures")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -118,16 +144,30 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     red_device = device if backend == "nccl" else torch.device("cpu")
+    D = dist if world > 1 else None
 
     import sarlacc_amd
+    from sarlacc_amd import calls, devsynth, pipeline
     from sarlacc_amd import device as sdev
-    from sarlacc_amd import devsynth
+    from sarlacc_amd.strset import StringSet
     sarlacc_amd.set_device(dev_index)
     enc = sarlacc_amd.phred_encoding()
 
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def reduce(vals, op):
+        t = torch.tensor(vals, dtype=torch.float64, device=red_device)
+        if world > 1:
+            dist.all_reduce(t, op=op)
+        return t.cpu().tolist()
+
+    # ------------------------------------------------------------------ DP (configs[1]) -------
     n = args.reads
-    seq, qual, off, max_len = devsynth.make_reads(n, args.read_len, ADAPTOR1, ADAPTOR2,
-                                                  seed=1000 + rank, device=device)
+    seq, qual, off, max_len = devsynth.make_reads(n, args.read_len, ADAPTOR1, ADAPTOR2, seed=1000 + rank, device=device)
     total_bases = int(off[-1].item())
     R = len(ADAPTOR1)
     cells = total_bases * R
@@ -148,12 +188,6 @@ def main():
                        UMI_SECTION[0], UMI_SECTION[1], scores, starts, ends, sso, swo, stream, d_nmask=nmask)
         return sarlacc_amd.last_kernel_ms()
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
     fence()
@@ -163,22 +197,19 @@ def main():
         kern_ms.append(step())
     fence()
     elapsed = time.perf_counter() - t0
+    elapsed = reduce([elapsed], dist.ReduceOp.MAX)[0]
+    all_cells = reduce([float(cells)], dist.ReduceOp.SUM)[0]
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
-    tot_cells = torch.tensor([float(cells)], dtype=torch.float64, device=red_device)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot_cells, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
-    all_cells = float(tot_cells.item())
-
+    out = None
     if rank == 0:
         gcups = all_cells * args.steps / elapsed / 1e9
         # algorithmic bytes per alignment: 2-bit packed bases + 1 B
         # quality per base in, 8 B score + 8 B start/end + 8 B per section out
         alg_bytes = total_bases / 4.0 + total_bases + n * 24.0
         k_ms = sum(kern_ms) / len(kern_ms)
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        hbm = alg_bytes / (k_ms * 1e-3) / 1e9
+        ops = cells * ALIGN_OPS_PER_CELL / (k_ms * 1e-3) / 1e12
+        pmc = pmc_record("k_align", ["align.hip"]) if n == 1_000_000 and args.read_len == 2000 else {"traffic": None, "traffic_source": None}
         out = {
             "metric": "GCUPS (quality-aware pairwise DP cell updates/s), adaptor_align .Call level",
             "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -192,18 +223,113 @@ def main():
             "reads_per_s": n * world * args.steps / elapsed,
             "kernel_ms": k_ms,
             "kernel_gcups": cells / (k_ms * 1e-3) / 1e9,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": (pmc_traffic(n) or (None, None))[0],
-                         "algorithmic_bytes": alg_bytes,
-                         "valu": (pmc_traffic(n) or (None, None))[1],
-                         "note": "the DP kernel is VALU-issue bound (valu.valu_busy_frac from the PMC pass); compulsory traffic is 0.042 B/cell"},
+            "roofline": {"kernel": "k_align", "bound": "valu", "achieved": ops, "peak": VALU64_PEAK_TLOPS,
+                         "unit": "T lane-op/s (fp64)", "frac": ops / VALU64_PEAK_TLOPS,
+                         "algorithmic_ops_per_cell": ALIGN_OPS_PER_CELL,
+                         "traffic": pmc["traffic"], "traffic_source": pmc["traffic_source"], "pmc": pmc.get("derived"),
+                         "hbm": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": hbm / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes},
+                         "note": "fp64 DP recurrence: vector-issue bound; compulsory traffic is 0.042 B/cell, so the HBM "
+                                 "fraction is small by construction and reported as a second entry"},
         }
-        if not args.no_pipeline:
-            out["pipeline"] = pipeline_sample()
-        if not args.no_cpu:
-            m = min(args.cpu_sample, n)
-            s_s, s_q = devsynth.to_host_strings(seq, qual, off, m)
-            out["cpu_baseline"] = cpu_baseline(s_s, s_q)
+
+    # PCIe-inclusive `.Call`-level figure: host pointers in, host pointers out (never `value`)
+    if rank == 0 and not args.no_host_pointer:
+        h_off = off.cpu().numpy()
+        hs = StringSet(seq.cpu().numpy(), h_off)
+        hq = StringSet(qual.cpu().numpy(), h_off.copy())
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            calls.adaptor_align(hs, hq, enc, GAP_OPEN, GAP_EXT, ADAPTOR1, *UMI_SECTION)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out["host_pointer"] = {"gcups": cells / best / 1e9, "seconds": best,
+                               "note": "sarlacc_adaptor_align on host buffers: chunked upload overlapped with the kernels, results downloaded"}
+        del hs, hq
+    cpu_sample = None
+    if rank == 0 and not args.no_cpu:
+        cores = os.cpu_count() or 1
+        cpu_sample = devsynth.to_host_strings(seq, qual, off, min(n, args.cpu_sample * cores)) + (cores,)
+    del seq, qual, off, packed, nmask, scores, starts, ends, sso, swo
+    torch.cuda.empty_cache()
+    sarlacc_amd._lib.lib().sarlacc_release_workspace()
+
+    # ------------------------------------------------------------ pipeline (configs[2..4]) -----
+    if not args.no_pipeline:
+        mol = devsynth.make_molecule_reads(args.molecules, args.copies, args.read_len, seed=2000 + rank, device=device)
+        nr = mol["off"].numel() - 1
+        off_host = mol["off"].cpu().numpy()
+        umis = StringSet(mol["umi"].cpu().numpy(), mol["umi_off"].cpu().numpy())
+        gather_device = device if backend == "nccl" else None
+        runs = []
+        for _ in range(2):
+            fence()
+            t0 = time.perf_counter()
+            r = pipeline.run_resident(umis, mol["seq"], mol["qual"], off_host, enc, threshold=args.threshold, dist=D,
+                                      gather_device=gather_device)
+            fence()
+            r["wall"] = time.perf_counter() - t0
+            runs.append(r)
+        first, last = runs[0], runs[-1]
+        names = ["umi_group", "label_exchange", "host_glue", "msa_consensus", "total"]
+        kn = ["umi_pairs", "msa_pairwise", "msa_merge", "consensus"]
+        mx = reduce([last["wall"], first["wall"], last["all_gather_s"]] + [last["stage_s"][k] for k in names]
+                    + [last["kernel_ms"][k] for k in kn], dist.ReduceOp.MAX)
+        sm = reduce([float(nr), float(len(last["cons"])), float(last["cons"].total), float(last["gflat"].size),
+                     float(last["all_gather_bytes"])], dist.ReduceOp.SUM)
+        if rank == 0:
+            wall = mx[0]
+            kms = dict(zip(kn, mx[3 + len(names):]))
+            cnt = last["counts"]
+            cons_cols = last["cons"].total
+            msa_ops = cnt["msa_cells"] * MSA_OPS_PER_CELL / (kms["msa_pairwise"] * 1e-3) / 1e12
+            cons_bytes = 2.0 * cnt["consensus_cells"] + 2.0 * cons_cols
+            cons_gbs = cons_bytes / (kms["consensus"] * 1e-3) / 1e9
+            pm = pmc_record("k_msa_pairwise", ["msa.hip"])
+            pc = pmc_record("k_consensus", ["consensus.hip"])
+            n_seen = dist.get_world_size() if world > 1 else 1
+            out["pipeline"] = {
+                "reads": int(sm[0]), "reads_per_min": sm[0] / wall * 60.0, "seconds": wall, "first_pass_seconds": mx[1],
+                "consensus_reads": int(sm[1]), "consensus_bases": int(sm[2]), "reads_in_clusters": int(sm[3]),
+                "stage_s": dict(zip(names, mx[3:3 + len(names)])), "kernel_ms": kms,
+                "all_gather": {"seconds": mx[2], "bytes_received_total": int(sm[4]), "backend": backend if world > 1 else None},
+                "n_ranks_seen": n_seen,
+                "workload": "%d molecules x %d reads x %d bp per GPU generated in HBM, %d-bp UMIs: umi_group(threshold %d, one "
+                            "pre-group per GPU) -> label all-gather -> msa_consensus (quick_msa bandwidth 100 + quality "
+                            "consensus, rows stay in HBM); reads and qualities resident, UMIs / group lists / consensus "
+                            "strings cross PCIe" % (args.molecules, args.copies, args.read_len, 12, args.threshold),
+                "msa_pairs": cnt["msa_pairs"], "msa_cells": cnt["msa_cells"], "consensus_cells": cnt["consensus_cells"],
+                "rooflines": {
+                    "k_msa_pairwise_ad": {"bound": "valu", "achieved": msa_ops, "peak": VALU32_PEAK_TLOPS, "unit": "T lane-op/s (int32)",
+                                          "frac": msa_ops / VALU32_PEAK_TLOPS, "algorithmic_ops_per_cell": MSA_OPS_PER_CELL,
+                                          "tcups": cnt["msa_cells"] / (kms["msa_pairwise"] * 1e-3) / 1e12,
+                                          "traffic": pm["traffic"], "traffic_source": pm["traffic_source"], "pmc": pm.get("derived")},
+                    "k_consensus_q4": {"bound": "hbm", "achieved": cons_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": cons_gbs / HBM_PEAK_GBS, "algorithmic_bytes": cons_bytes,
+                                       "traffic": pc["traffic"], "traffic_source": pc["traffic_source"], "pmc": pc.get("derived")},
+                },
+            }
+            if not args.no_host_pointer:
+                hs = StringSet(mol["seq"].cpu().numpy(), off_host)
+                hq = StringSet(mol["qual"].cpu().numpy(), off_host.copy())
+                t0 = time.perf_counter()
+                coff, cmem = calls.umi_group_flat(umis, args.threshold, None, args.threshold, np.array([0, nr], np.int64),
+                                                  np.arange(1, nr + 1, dtype=np.int32))
+                goff, gflat = calls.csr_select(coff, cmem, np.diff(coff) >= 2)
+                hc, _ = calls.msa_consensus_flat(goff, gflat, hs, 0, -1, -5, -1, 100, 0.6, quals=hq, encoding=enc)
+                dt = time.perf_counter() - t0
+                same = np.array_equal(hc.off, last["cons"].off) and np.array_equal(hc.chars[:hc.total], last["cons"].chars[:hc.total])
+                out["pipeline"]["host_pointer"] = {"reads_per_min": nr / dt * 60.0, "seconds": dt,
+                                                   "identical_to_resident": bool(same),
+                                                   "note": "same stages through the host-pointer C ABI (reads + qualities cross PCIe), rank 0 only"}
+                del hs, hq
+        del mol
+        torch.cuda.empty_cache()
+
+    if rank == 0:
+        if cpu_sample is not None:
+            out["cpu_baseline"] = cpu_baseline(*cpu_sample)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -46,6 +46,12 @@ int sarlacc_device_count(void);
 int sarlacc_set_device(int device);
 /* Release cached device workspaces. */
 void sarlacc_release_workspace(void);
+/* Duration in ms of a named group of kernel launches of the last call that ran it (HIP events on
+ * the launch stream): "msa_pairwise", "msa_merge", "consensus", "umi_pairs"; <0 if it never ran. */
+double sarlacc_stage_ms(const char* name);
+/* Work counters of the last call that set them (for rooflines): "msa_pairs", "msa_cells" (banded DP
+ * cells of the pairwise alignments), "consensus_cells" (rows x width), "consensus_columns"; <0 if unset. */
+double sarlacc_stage_count(const char* name);
 /* Duration in ms of the DP kernel launches recorded by the last
  * sarlacc_dev_* align call (HIP events on the launch stream); <0 if none. */
 double sarlacc_last_kernel_ms(void);
@@ -268,6 +274,18 @@ int sarlacc_msa_consensus(const int64_t* grp_off, const int32_t* grp, int64_t ng
                           int bandwidth, double min_cov, double pseudo_count,
                           const double* enc_errors, const char* enc_names, int enc_n,
                           char* cons, char* phred, int64_t* cons_off, int64_t cons_cap);
+
+/* sarlacc_msa_consensus with the reads (and, for the quality vote, their quality strings) already
+ * resident in HBM, e.g. left there by sarlacc_dev_fastq_extract / sarlacc_dev_realize: d_seq and
+ * d_qual are device pointers to the concatenated strings, `off` the HOST copy of their n+1 offsets
+ * (byte 0 of d_seq is off[0]; the job list is built from the lengths on the host).  d_qual == NULL
+ * selects the basic vote.  Group lists and outputs are host arrays as in sarlacc_msa_consensus. */
+int sarlacc_dev_msa_consensus(const int64_t* grp_off, const int32_t* grp, int64_t ngroups,
+                              const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* off, int64_t nseq,
+                              double match, double mismatch, double gap_extension, double gap_opening,
+                              int bandwidth, double min_cov, double pseudo_count,
+                              const double* enc_errors, const char* enc_names, int enc_n,
+                              char* cons, char* phred, int64_t* cons_off, int64_t cons_cap);
 
 #ifdef __cplusplus
 }

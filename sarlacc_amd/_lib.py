@@ -44,9 +44,13 @@ def _try_build():
     if hipcc is None:
         return
     try:
-        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc"), "HIPCC=" + hipcc])
-    except (subprocess.CalledProcessError, OSError):
-        pass
+        subprocess.run(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc"), "HIPCC=" + hipcc],
+                       check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    except subprocess.CalledProcessError as e:
+        tail = (e.stdout or b"").decode(errors="replace")[-2000:]
+        raise ImportError("sarlacc_amd: building %s failed (make exit %d):\n%s" % (LIB_PATH, e.returncode, tail))
+    except OSError as e:
+        raise ImportError("sarlacc_amd: cannot run make to build %s: %s" % (LIB_PATH, e))
 
 
 def lib():
@@ -62,6 +66,8 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.sarlacc_last_error.restype = C.c_char_p
         _lib.sarlacc_last_kernel_ms.restype = C.c_double
+        _lib.sarlacc_stage_ms.restype = C.c_double
+        _lib.sarlacc_stage_count.restype = C.c_double
     return _lib
 
 
@@ -83,6 +89,16 @@ def device_count():
 
 def set_device(device):
     check(lib().sarlacc_set_device(int(device)))
+
+
+def stage_ms(name):
+    """Milliseconds of the named kernel group in the last call that ran it (HIP events), <0 if none."""
+    return float(lib().sarlacc_stage_ms(name.encode()))
+
+
+def stage_count(name):
+    """Work counter (cells, pairs ...) recorded by the last call that set it, <0 if unset."""
+    return float(lib().sarlacc_stage_count(name.encode()))
 
 
 def last_kernel_ms():

@@ -66,6 +66,25 @@ int Context::buffer(const char* name, size_t bytes, void** out) {
     return 0;
 }
 
+int Context::stage_begin(const char* name, hipStream_t s) {
+    StageTimer& t = stages[name];
+    if (!t.a) {
+        SL_HIP(hipEventCreate(&t.a));
+        SL_HIP(hipEventCreate(&t.b));
+    }
+    t.armed = false;
+    SL_HIP(hipEventRecord(t.a, s));
+    return 0;
+}
+
+int Context::stage_end(const char* name, hipStream_t s) {
+    StageTimer& t = stages[name];
+    if (!t.a) return fail("sarlacc_amd: stage timer '%s' was never started", name);
+    SL_HIP(hipEventRecord(t.b, s));
+    t.armed = true;
+    return 0;
+}
+
 void Context::release() {
     for (auto& kv : ws)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
@@ -100,6 +119,11 @@ int sarlacc_set_device(int device) {
     sarlacc::Context& c = sarlacc::ctx();
     if (c.ready && c.device != device) {
         c.release();
+        for (auto& kv : c.stages) {   // events belong to the device they were created on
+            if (kv.second.a) (void)hipEventDestroy(kv.second.a);
+            if (kv.second.b) (void)hipEventDestroy(kv.second.b);
+        }
+        c.stages.clear();
         c.ready = false;
     }
     c.device = device;
@@ -107,6 +131,24 @@ int sarlacc_set_device(int device) {
 }
 
 void sarlacc_release_workspace(void) { sarlacc::ctx().release(); }
+
+double sarlacc_stage_ms(const char* name) {
+    sarlacc::Context& c = sarlacc::ctx();
+    if (!c.ready || !name) return -1.0;
+    auto it = c.stages.find(name);
+    if (it == c.stages.end() || !it->second.armed) return -1.0;
+    if (hipEventSynchronize(it->second.b) != hipSuccess) return -1.0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, it->second.a, it->second.b) != hipSuccess) return -1.0;
+    return ms;
+}
+
+double sarlacc_stage_count(const char* name) {
+    sarlacc::Context& c = sarlacc::ctx();
+    if (!name) return -1.0;
+    auto it = c.counts.find(name);
+    return it == c.counts.end() ? -1.0 : it->second;
+}
 
 double sarlacc_last_kernel_ms(void) {
     sarlacc::Context& c = sarlacc::ctx();

@@ -48,6 +48,12 @@ struct Context {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
     std::map<std::string, Workspace> ws;
+    // named stage timers (HIP events on the launch stream; read back by sarlacc_stage_ms)
+    struct StageTimer { hipEvent_t a = nullptr, b = nullptr; bool armed = false; };
+    std::map<std::string, StageTimer> stages;
+    std::map<std::string, double> counts;   // work counters of the last call (cells, jobs ...), sarlacc_stage_count
+    int stage_begin(const char* name, hipStream_t s);
+    int stage_end(const char* name, hipStream_t s);
 
     // Returns a cached device buffer of at least `bytes` (grown geometrically).
     int buffer(const char* name, size_t bytes, void** out);
@@ -82,11 +88,14 @@ struct MsaResult {
     uint8_t* d_out = nullptr;       // gapped rows, group after group, equal width inside a group
     int32_t* d_members = nullptr;   // flattened 1-based read ids, one per row
 };
+// d_seq_resident (optional): the concatenated reads already in HBM (byte 0 = seq_off[0]); `seq` is then
+// not read and nothing is uploaded but the offsets.
 // `overlap` (optional) runs on the host right after the pairwise kernels are launched, i.e. while
 // they execute: the place for transfers the next stage needs (on a stream of their own).
 int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq, const int64_t* seq_off,
             int64_t nseq, double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
-            bool want_rows, int64_t out_cap, MsaResult* res, const std::function<int()>* overlap = nullptr);
+            bool want_rows, int64_t out_cap, MsaResult* res, const std::function<int()>* overlap = nullptr,
+            const uint8_t* d_seq_resident = nullptr);
 
 // ---- quality encoding (reference src/quality_encoding.cpp:5-33) -------------
 int check_encoding(const double* errors, const char* names, int n);

@@ -547,6 +547,8 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         const size_t lds4 = sizeof(double) * 4 * (5 * static_cast<size_t>(enc_n) + 1) + 4 * (2 * sizeof(long long) + 3 * sizeof(int)) * static_cast<size_t>(max_rows) + 16;
         const bool q4 = quality && !lerr && lds4 <= 48 * 1024 && !std::getenv("SARLACC_CONSENSUS_NARROW");
         SL_HIP(hipEventRecord(c.ev_start, s));
+        c.counts["consensus_cells"] = static_cast<double>(total);
+        SL_TRY(c.stage_begin("consensus", s));
         if (q4) {
             const int grid4 = static_cast<int>(std::min<int64_t>((ng_eval + 3) / 4, static_cast<int64_t>(c.num_cu) * 64));
             hipLaunchKernelGGL(k_consensus_q4, dim3(grid4), dim3(256), lds4, s, a);
@@ -560,6 +562,7 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         }
         SL_HIP(hipGetLastError());
         SL_HIP(hipEventRecord(c.ev_stop, s));
+        SL_TRY(c.stage_end("consensus", s));
         c.timed = true;
     }
 
@@ -719,13 +722,15 @@ int sarlacc_create_consensus_basic_loop(const char* aln, const int64_t* aln_off,
                          nullptr, nullptr, 0, cons, phred, cons_off, lerr);
 }
 
-int sarlacc_msa_consensus(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq,
-                          const int64_t* seq_off, const char* qual, const int64_t* qual_off, int64_t nseq, double match,
-                          double mismatch, double gap_extension, double gap_opening, int bandwidth, double min_cov,
-                          double pseudo_count, const double* enc_errors, const char* enc_names, int enc_n, char* cons,
-                          char* phred, int64_t* cons_off, int64_t cons_cap) {
+// Shared body of sarlacc_msa_consensus (host pointers) and sarlacc_dev_msa_consensus (reads and
+// qualities already in HBM: d_seq / d_qual non-null, seq / qual unused).
+static int msa_consensus_impl(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq,
+                              const int64_t* seq_off, const char* qual, const int64_t* qual_off, int64_t nseq, double match,
+                              double mismatch, double gap_extension, double gap_opening, int bandwidth, double min_cov,
+                              double pseudo_count, const double* enc_errors, const char* enc_names, int enc_n, char* cons,
+                              char* phred, int64_t* cons_off, int64_t cons_cap, const uint8_t* d_seq_res, const uint8_t* d_qual_res,
+                              bool quality) {
     if (ngroups < 0 || nseq < 0) return fail("sarlacc_amd: negative sizes");
-    const bool quality = qual != nullptr;
     if (quality) SL_TRY(check_encoding(enc_errors, enc_names, enc_n));
     cons_off[0] = 0;
     if (ngroups == 0) return 0;
@@ -743,12 +748,13 @@ int sarlacc_msa_consensus(const int64_t* grp_off, const int32_t* grp, int64_t ng
         qrel.resize(static_cast<size_t>(nseq) + 1);
         for (int64_t r = 0; r <= nseq; ++r) qrel[r] = qual_off[r] - qbase;
         SL_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-        SL_TRY(upload("cons.qual", reinterpret_cast<const uint8_t*>(qual) + qbase, static_cast<size_t>(qrel[nseq]), &d_q, copy_stream));
+        if (d_qual_res) d_q = const_cast<uint8_t*>(d_qual_res);
+        else SL_TRY(upload("cons.qual", reinterpret_cast<const uint8_t*>(qual) + qbase, static_cast<size_t>(qrel[nseq]), &d_q, copy_stream));
         SL_TRY(upload("cons.qoff", qrel.data(), qrel.size(), &d_qoff, copy_stream));
         return 0;
     };
     const int msa_rc = msa_run(grp_off, grp, ngroups, seq, seq_off, nseq, match, mismatch, gap_extension, gap_opening, bandwidth, true,
-                               -1, &res, &upload_quals);
+                               -1, &res, &upload_quals, d_seq_res);
     if (copy_stream) {
         const hipError_t e1 = hipStreamSynchronize(copy_stream), e2 = hipStreamDestroy(copy_stream);
         if (!msa_rc && (e1 != hipSuccess || e2 != hipSuccess)) return fail("HIP error while uploading the quality strings");
@@ -788,6 +794,27 @@ int sarlacc_msa_consensus(const int64_t* grp_off, const int32_t* grp, int64_t ng
     if (quality) { a.qual = d_q; a.qual_off = d_qoff; a.row_read = res.d_members; }
     return consensus_core(quality, a, ngroups, ngroups, nrows, total, out_off, nullptr, 0, min_cov, pseudo_count, enc_errors,
                           enc_names, enc_n, cons, phred, cons_off, nullptr, s);
+}
+
+int sarlacc_msa_consensus(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq,
+                          const int64_t* seq_off, const char* qual, const int64_t* qual_off, int64_t nseq, double match,
+                          double mismatch, double gap_extension, double gap_opening, int bandwidth, double min_cov,
+                          double pseudo_count, const double* enc_errors, const char* enc_names, int enc_n, char* cons,
+                          char* phred, int64_t* cons_off, int64_t cons_cap) {
+    return msa_consensus_impl(grp_off, grp, ngroups, seq, seq_off, qual, qual_off, nseq, match, mismatch, gap_extension,
+                              gap_opening, bandwidth, min_cov, pseudo_count, enc_errors, enc_names, enc_n, cons, phred,
+                              cons_off, cons_cap, nullptr, nullptr, qual != nullptr);
+}
+
+int sarlacc_dev_msa_consensus(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const uint8_t* d_seq,
+                              const uint8_t* d_qual, const int64_t* off, int64_t nseq, double match, double mismatch,
+                              double gap_extension, double gap_opening, int bandwidth, double min_cov, double pseudo_count,
+                              const double* enc_errors, const char* enc_names, int enc_n, char* cons, char* phred,
+                              int64_t* cons_off, int64_t cons_cap) {
+    if (!d_seq) return fail("sarlacc_amd: sarlacc_dev_msa_consensus needs the reads in device memory");
+    return msa_consensus_impl(grp_off, grp, ngroups, nullptr, off, nullptr, off, nseq, match, mismatch, gap_extension,
+                              gap_opening, bandwidth, min_cov, pseudo_count, enc_errors, enc_names, enc_n, cons, phred,
+                              cons_off, cons_cap, d_seq, d_qual, d_qual != nullptr);
 }
 
 int sarlacc_create_consensus_quality_loop(const char* aln, const int64_t* aln_off, const int64_t* grp_rows,

@@ -650,7 +650,8 @@ static int launch_pairwise_ad(const MsaArgs& a, int grid, size_t lds, hipStream_
 // sarlacc_quick_msa: widths and offsets are always filled in).
 int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq, const int64_t* seq_off,
             int64_t nseq, double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
-            bool want_rows, int64_t out_cap, MsaResult* res, const std::function<int()>* overlap) {
+            bool want_rows, int64_t out_cap, MsaResult* res, const std::function<int()>* overlap,
+            const uint8_t* d_seq_resident) {
     int32_t* width_out = res->width.data();
     int64_t* out_off = res->out_off.data();
     res->d_out = nullptr;
@@ -723,7 +724,8 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     for (int64_t i = 0; i <= nseq; ++i) rel[i] = (nseq ? seq_off[i] : 0) - (nseq ? seq_off[0] : 0);
 
     uint8_t* d_seq; int64_t* d_soff; int32_t* d_mem; MsaGroup* d_groups; MsaJob* d_jobs; long long* d_mioff;
-    SL_TRY(upload("msa.seq", reinterpret_cast<const uint8_t*>(seq) + (nseq ? seq_off[0] : 0), static_cast<size_t>(total), &d_seq, s));
+    if (d_seq_resident) d_seq = const_cast<uint8_t*>(d_seq_resident);
+    else SL_TRY(upload("msa.seq", reinterpret_cast<const uint8_t*>(seq) + (nseq ? seq_off[0] : 0), static_cast<size_t>(total), &d_seq, s));
     SL_TRY(upload("msa.soff", rel.data(), rel.size(), &d_soff, s));
     SL_TRY(upload("msa.mem", grp + grp_off[0], static_cast<size_t>(nmemb), &d_mem, s));
     SL_TRY(upload("msa.groups", groups.data(), groups.size(), &d_groups, s));
@@ -760,7 +762,12 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         SL_TRY(scratch("msa.stuck", 1, &d_stuck));
         SL_HIP(hipMemsetAsync(d_stuck, 0, sizeof(int), s));
         a.stuck = d_stuck;
+        double cells = 0;
+        for (const MsaJob& J : jobs) cells += static_cast<double>(J.lr) * (std::abs(J.lc - J.lr) + 2 * bandwidth + 1);
+        c.counts["msa_pairs"] = static_cast<double>(jobs.size());
+        c.counts["msa_cells"] = cells;
         SL_HIP(hipEventRecord(c.ev_start, s));
+        SL_TRY(c.stage_begin("msa_pairwise", s));
         for (int cls = 0; cls < 3; ++cls) {
             if (order[cls].empty()) continue;
             const int C = 4 << cls;
@@ -798,6 +805,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
             }
         }
         SL_HIP(hipEventRecord(c.ev_stop, s));
+        SL_TRY(c.stage_end("msa_pairwise", s));
         c.timed = true;
     }
     const double tm2 = now();
@@ -806,6 +814,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     MergeArgs m{};
     m.seq = d_seq; m.seq_off = d_soff; m.members = d_mem; m.groups = d_groups; m.jobs = d_jobs; m.ngroups = ngroups;
     m.ins = d_ins; m.aln = d_aln; m.maxins = d_maxins; m.mi_off = d_mioff; m.width = d_width;
+    SL_TRY(c.stage_begin("msa_merge", s));
     hipLaunchKernelGGL(k_msa_width, dim3(static_cast<unsigned>(ngroups)), dim3(256), 0, s, m);
     SL_HIP(hipGetLastError());
     std::vector<int32_t> width(static_cast<size_t>(ngroups));
@@ -835,6 +844,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     const long long nrows = static_cast<long long>(row_group.size());
     hipLaunchKernelGGL(k_msa_write, dim3(static_cast<unsigned>(nrows)), dim3(256), 0, s, m, d_rg, d_rp, nrows);
     SL_HIP(hipGetLastError());
+    SL_TRY(c.stage_end("msa_merge", s));
     res->d_out = d_out;
     if (timing) {
         SL_HIP(hipStreamSynchronize(s));

@@ -52,3 +52,45 @@ def dev_align(d_seq, d_qual, d_off, n, max_len, encoding, gapopen, gapext, refer
         rf, len(rf), 0 if local else 1, ptr(ss), ptr(se), ns,
         _dp(d_scores), _dp(d_starts), _dp(d_ends), _dp(d_sec_start), _dp(d_sec_width),
         C.c_void_p(int(stream))))
+
+
+def dev_msa_consensus(grp_off, grp, d_seq, d_qual, off_host, match, mismatch, gapExtension, gapOpening, bandwidth,
+                      min_cov, pseudo_count=1.0, encoding=None):
+    """sarlacc_dev_msa_consensus: multiReadAlign + consensusReadSeq on reads (and qualities) already in
+    HBM.  `off_host` is the host copy (numpy int64[n+1]) of the read offsets, grp_off/grp the CSR of
+    1-based group lists.  d_qual None -> basic vote.  Returns (consensus StringSet, phred StringSet)."""
+    import re
+
+    from ._lib import SarlaccError
+    from .strset import StringSet
+    goff = np.ascontiguousarray(grp_off, dtype=np.int64)
+    gvals = np.ascontiguousarray(grp, dtype=np.int32)
+    if gvals.size == 0:
+        gvals = np.zeros(1, np.int32)
+    off = np.ascontiguousarray(off_host, dtype=np.int64)
+    n = off.size - 1
+    ng = goff.size - 1
+    enc = as_encoding(encoding) if d_qual is not None else None
+    coff = np.zeros(ng + 1, np.int64)
+    w = np.diff(off)
+    sizes = np.diff(goff)
+    longest = np.maximum.reduceat(w[gvals[:int(goff[-1])].astype(np.int64) - 1], goff[:-1][sizes > 0]) if goff[-1] else np.zeros(0)
+    cap = int(1.5 * longest.sum()) + 1024
+    for attempt in range(2):
+        cons = np.zeros(cap, np.uint8)
+        phred = np.zeros(cap, np.uint8)
+        try:
+            check(_lib.lib().sarlacc_dev_msa_consensus(
+                ptr(goff), ptr(gvals), C.c_int64(ng), _dp(d_seq), _dp(d_qual), ptr(off), C.c_int64(n),
+                C.c_double(match), C.c_double(mismatch), C.c_double(gapExtension), C.c_double(gapOpening), int(bandwidth),
+                C.c_double(min_cov), C.c_double(pseudo_count), ptr(enc.errors) if enc is not None else None,
+                enc.names if enc is not None else None, len(enc) if enc is not None else 0,
+                ptr(cons), ptr(phred), ptr(coff), C.c_int64(cap)))
+            break
+        except SarlaccError as e:
+            m = re.search(r"buffer too small \((\d+) needed\)", str(e))
+            if attempt == 0 and m:
+                cap = int(m.group(1)) + 16
+                continue
+            raise
+    return StringSet(cons, coff.copy()), StringSet(phred, coff.copy())

@@ -73,3 +73,49 @@ def to_host_strings(seq, qual, off, count):
     q = qual[:end].cpu().numpy().tobytes()
     return ([s[o[i]:o[i + 1]].decode() for i in range(count)],
             [q[o[i]:o[i + 1]].decode() for i in range(count)])
+
+
+def make_molecule_reads(molecules, copies, read_len, seed, device, umi_len=12, sub_rate=0.05, indel_rate=0.01,
+                        max_insert=5, chunk=8192):
+    """BASELINE configs C3 + C4 generated in HBM: `molecules` random bodies of `read_len` bases and
+    random `umi_len`-base UMIs, each observed `copies` times through the mockReads error process
+    (5 % substitutions by a uniform base, 1 % indel events with k in {0,2..5} copies, qualities from
+    error probabilities ~ U(0, 0.06)); reads are in molecule order (read r comes from molecule r // copies).
+    Returns dict(seq, qual, off, umi, umi_off, max_len) of device tensors (uint8 / int64)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    nuc = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    choices = torch.tensor([0] + list(range(2, max_insert + 1)), dtype=torch.int64, device=device)
+
+    def noisy(truth):
+        r = truth.repeat_interleave(copies, dim=0)
+        sub = torch.rand(r.shape, generator=g, device=device) < sub_rate
+        r = torch.where(sub, nuc[torch.randint(0, 4, r.shape, generator=g, device=device)], r)
+        counts = torch.ones(r.shape, dtype=torch.int64, device=device)
+        ind = torch.rand(r.shape, generator=g, device=device) < indel_rate
+        k = choices[torch.randint(0, choices.numel(), r.shape, generator=g, device=device)]
+        counts = torch.where(ind, k, counts)
+        flat = torch.repeat_interleave(r.reshape(-1), counts.reshape(-1))
+        return flat, counts.sum(dim=1)
+
+    seqs, quals, lens, umis, ulens = [], [], [], [], []
+    for lo in range(0, molecules, chunk):
+        m = min(chunk, molecules - lo)
+        body = nuc[torch.randint(0, 4, (m, read_len), generator=g, device=device)]
+        flat, ln = noisy(body)
+        seqs.append(flat)
+        quals.append(_phred_from_uniform(torch.rand(flat.numel(), generator=g, device=device), sub_rate + indel_rate))
+        lens.append(ln)
+        u = nuc[torch.randint(0, 4, (m, umi_len), generator=g, device=device)]
+        uf, ul = noisy(u)
+        umis.append(uf)
+        ulens.append(ul)
+    lens = torch.cat(lens)
+    ulens = torch.cat(ulens)
+    n = lens.numel()
+    off = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    off[1:] = torch.cumsum(lens, 0)
+    uoff = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    uoff[1:] = torch.cumsum(ulens, 0)
+    return {"seq": torch.cat(seqs), "qual": torch.cat(quals), "off": off, "umi": torch.cat(umis), "umi_off": uoff,
+            "max_len": int(lens.max().item())}

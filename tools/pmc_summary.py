@@ -1,17 +1,33 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 passes written by tools/profile_round.sh.
+"""Summarise the rocprofv3 passes written by tools/profile_round.sh for one kernel.
 
     python tools/pmc_summary.py gpurun_out/<tag> [kernel-name-substring]
 
-Prints one JSON object: per-launch FETCH_SIZE / WRITE_SIZE (KB, as rocprofv3 reports
-them) and the SQ/GRBM counters of the dominant kernel (default: k_align), plus the
-derived VALU-issue occupancy.  bench.py reads the committed copy under profiles/.
+Prints one JSON object: per-launch FETCH_SIZE / WRITE_SIZE (KB, as rocprofv3 reports them), the
+SQ/GRBM counters of the kernel (averaged over its launches), derived figures, and `source_sha`, the
+hash of the kernel's source file at profiling time -- bench.py quotes the committed copy under
+profiles/ only while the source still hashes to it.
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOURCES = {"k_align": ["align.hip"], "k_msa_pairwise": ["msa.hip"], "k_consensus": ["consensus.hip"]}
+# share of fp64 instructions (4 issue cycles per wave64 instruction on a SIMD-32; everything else
+# 2) in the kernel's VALU stream, from the disassembly of its main loop
+FP64_SHARE = {"k_align": 0.75, "k_msa_pairwise": 0.0, "k_consensus": 0.12}
+
+
+def source_sha(names):
+    h = hashlib.sha256()
+    for nm in names:
+        with open(os.path.join(ROOT, "sarlacc_amd", "csrc", nm), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def counter_rows(d):
@@ -31,43 +47,67 @@ def per_launch(rows, kernel, counter):
 
 
 def kernel_stats(d, kernel):
+    best = None
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         with open(f, newline="") as fh:
             for r in csv.DictReader(fh):
                 if kernel in r["Name"]:
-                    return {"name": r["Name"], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
-                            "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6}
-    return None
+                    rec = {"name": r["Name"], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                           "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6,
+                           "total_ms": float(r["TotalDurationNs"]) / 1e6}
+                    if best is None or rec["total_ms"] > best["total_ms"]:
+                        best = rec
+    return best
 
 
 def main():
     out_dir = sys.argv[1]
     kernel = sys.argv[2] if len(sys.argv) > 2 else "k_align"
-    res = {"kernel_substring": kernel}
+    res = {"kernel_substring": kernel, "source_sha": source_sha(SOURCES.get(kernel, []))}
+    bj = os.path.join(out_dir, "bench.json")
+    if os.path.exists(bj):
+        try:
+            with open(bj) as fh:
+                b = json.loads(fh.read().strip().splitlines()[-1])
+            res["workload"] = b["config"]["workload"] if kernel == "k_align" else b.get("pipeline", {}).get("workload")
+        except (ValueError, KeyError, IndexError):
+            pass
     res["kernel_stats"] = kernel_stats(os.path.join(out_dir, "stats"), kernel)
-    fetch = per_launch(counter_rows(os.path.join(out_dir, "pmc_fetch")), kernel, "FETCH_SIZE")
-    write = per_launch(counter_rows(os.path.join(out_dir, "pmc_write")), kernel, "WRITE_SIZE")
-    res["FETCH_SIZE_KB_per_launch"] = fetch
-    res["WRITE_SIZE_KB_per_launch"] = write
-    sq_rows = counter_rows(os.path.join(out_dir, "pmc_sq"))
+    name = res["kernel_stats"]["name"] if res["kernel_stats"] else kernel
+    # counters of the dominant instantiation only (band classes / template variants are separate kernels)
+    key = name.split("(")[0] if res["kernel_stats"] else kernel
+    res["FETCH_SIZE_KB_per_launch"] = per_launch(counter_rows(os.path.join(out_dir, "pmc_fetch")), key, "FETCH_SIZE")
+    res["WRITE_SIZE_KB_per_launch"] = per_launch(counter_rows(os.path.join(out_dir, "pmc_write")), key, "WRITE_SIZE")
     sq = {}
-    for c in ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
-              "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
-        v = per_launch(sq_rows, kernel, c)
-        if v:
-            sq[c] = sum(v) / len(v)
-    res["valu_pass"] = sq
-    if res["kernel_stats"] and "GRBM_GUI_ACTIVE" in sq and "SQ_ACTIVE_INST_VALU" in sq:
+    for sub, names in (("pmc_sq", ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
+                                   "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")),
+                       ("pmc_sq2", ("SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
+                                    "SQ_WAIT_INST_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM"))):
+        rows = counter_rows(os.path.join(out_dir, sub))
+        for c in names:
+            v = per_launch(rows, key, c)
+            if v:
+                sq[c] = sum(v) / len(v)
+    res["sq"] = sq
+    if res["kernel_stats"] and "GRBM_GUI_ACTIVE" in sq:
         ms = res["kernel_stats"]["avg_ms"]
-        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_ACTIVE_INST_* count quad-cycles
-        clk = sq["GRBM_GUI_ACTIVE"] / 8.0 / (ms * 1e-3) / 1e9
-        res["derived"] = {
-            "effective_clock_GHz": clk,
-            "valu_busy_frac": 4.0 * sq["SQ_ACTIVE_INST_VALU"] / (1024.0 * sq["GRBM_GUI_ACTIVE"] / 8.0),
-            "valu_wave_instr_per_launch": sq.get("SQ_INSTS_VALU"),
-            "note": "SQ_ACTIVE_INST_VALU counts quad-cycles; busy fraction = 4*SQ_ACTIVE_INST_VALU / "
-                    "(1024 SIMDs * GRBM_GUI_ACTIVE/8)",
-        }
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        cyc = sq["GRBM_GUI_ACTIVE"] / 8.0
+        d = {"effective_clock_GHz": cyc / (ms * 1e-3) / 1e9}
+        if "SQ_INSTS_VALU" in sq:
+            share = FP64_SHARE.get(kernel, 0.0)
+            per_instr = 2.0 + 2.0 * share
+            d["valu_wave_instr_per_launch"] = sq["SQ_INSTS_VALU"]
+            d["valu_issue_frac"] = sq["SQ_INSTS_VALU"] * per_instr / (1024.0 * cyc)
+            d["valu_issue_model"] = ("wave64 VALU instruction = 2 issue cycles on a SIMD-32, fp64 = 4; fp64 share %.2f of the "
+                                     "stream; fraction = instructions x cycles / (1024 SIMDs x GRBM_GUI_ACTIVE/8)" % share)
+        if "SQ_WAVE_CYCLES" in sq and sq["SQ_WAVE_CYCLES"] > 0:
+            for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
+                if c in sq:
+                    d[c.lower() + "_per_wave_cycle"] = sq[c] / sq["SQ_WAVE_CYCLES"]
+        if "SQ_LDS_IDX_ACTIVE" in sq and sq.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
+            d["lds_bank_conflict_frac"] = sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / sq["SQ_LDS_IDX_ACTIVE"]
+        res["derived"] = d
     res["note"] = ("FETCH_SIZE on gfx950 reports half the bytes of wide (16 B/lane) coalesced reads "
                    "(MI355X_MICROARCH.md, HBM); narrower accesses are uncalibrated, value taken at face")
     print(json.dumps(res, indent=1))

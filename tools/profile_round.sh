@@ -1,17 +1,18 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): bench line, rocprofv3 kernel stats and the three PMC
-# passes (FETCH_SIZE, WRITE_SIZE, SQ/GRBM in separate runs, MI355X_MICROARCH.md "rocprofv3
-# PMC slots"), all into gpurun_out/<tag>/.  tools/pmc_summary.py turns the counter CSVs
-# into the JSON bench.py reads from profiles/.
+# Runs on the GPU box (via gpurun): the default bench line, then rocprofv3 kernel stats and separate
+# PMC passes (FETCH_SIZE, WRITE_SIZE, two SQ/GRBM sets -- MI355X_MICROARCH.md "rocprofv3 PMC
+# slots") of the SAME bench command (DP steps + the 10^6-read pipeline), all into gpurun_out/<tag>/.
+# tools/pmc_summary.py turns the counter CSVs into one JSON per dominant kernel
+# (k_align, k_msa_pairwise, k_consensus) -- the files bench.py reads from profiles/.
 #   usage: tools/profile_round.sh <tag> [extra bench.py args]
 set -e
 TAG=${1:-prof}; shift || true
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 3 --warmup 1 --no-cpu --no-pipeline $*"
+BENCH="python3 $PWD/bench.py --steps 2 --warmup 1 --no-cpu --no-host-pointer $*"
 python3 bench.py "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
-echo "bench done"; tail -c 600 "$OUT/bench.json"
+echo "bench done"; tail -c 1500 "$OUT/bench.json"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
 echo "stats done"
@@ -22,9 +23,15 @@ echo "write done"
 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
     -d "$OUT/pmc_sq" -o pmc -- $BENCH > "$OUT/pmc_sq.log" 2>&1
 echo "sq done"
+rocprofv3 --output-format csv --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE \
+    -d "$OUT/pmc_sq2" -o pmc -- $BENCH > "$OUT/pmc_sq2.log" 2>&1 || echo "sq2 pass failed (counter names?)"
+echo "sq2 done"
 cd - > /dev/null
-python3 tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.json"
-cat "$OUT/pmc_summary.json"
+for K in k_align k_msa_pairwise k_consensus; do
+    python3 tools/pmc_summary.py "$OUT" $K > "$OUT/pmc_$K.json"
+done
+cat "$OUT"/pmc_k_*.json
 # keep the merge-back small: drop everything but the stats and counter CSVs
 find "$OUT" -type f ! -name '*.csv' ! -name '*.json' ! -name '*.log' ! -name '*.err' -delete
 find "$OUT" -name '*kernel_trace.csv' -size +20M -delete
+find "$OUT" -name '*counter_collection.csv' -size +30M -delete
