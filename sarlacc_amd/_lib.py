@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsarlacc_amd.so")
+LIB_PATH = os.environ.get("SARLACC_LIB_PATH") or os.path.join(_HERE, "libsarlacc_amd.so")   # override: experiment builds
 _lib = None
 
 

@@ -1,0 +1,56 @@
+// msa_common.hpp -- job descriptors shared by the pairwise kernels (msa_pairwise.hip) and the two
+// MSA drivers built on them (msa.hip: spec v1 centre-star; msa2.hip: spec v2 consistency-based
+// progressive alignment).  Both stand in for /root/reference/src/quick_msa.cpp:15-80.
+#pragma once
+
+#include "common.hpp"
+
+namespace sarlacc {
+
+// One banded global alignment: `read` (rows i) against `centre` (columns j).
+struct MsaJob {
+    long long read_off;   // into seq
+    long long ctr_off;
+    long long out_off;    // OUT 0: into ins[] (lc+1 entries) and aln[] (lc entries, same base)
+                          // OUT 1: into map[]: lc entries, centre position -> read position (0xFFFF = gap)
+    long long out2_off;   // OUT 1: into map[]: lr entries, read position -> centre position
+    int lr, lc;
+};
+
+struct MsaArgs {
+    const uint8_t* seq;
+    const MsaJob* jobs;
+    const int* order;       // optional: the njobs job indices this launch works on
+    int njobs;
+    int ma, mm, go, ge, bw;
+    uint16_t* ins;          // OUT 0: per pair, insertions before each centre position
+    uint8_t* aln;           // OUT 0: per pair, 1 if the centre base is matched to a read base
+    uint16_t* map;          // OUT 1: position maps of both directions
+    int2* stats;            // OUT 1: per job (aligned pairs with equal bases, aligned pairs)
+    void* tb;               // per-wave traceback tile
+    unsigned long long tb_per_wave;  // in tile words
+    int dbg;                // timing experiments only (SARLACC_MSA_DBG): 1 no walk, 2 no guarded rows, 4 no code stores
+    int* stuck;             // set when a traceback exceeds its step bound (cannot happen with consistent codes;
+                            // the bound is what guarantees that every wave leaves the walk)
+};
+
+// Launches the pairwise kernels for `jobs` (host copy, for sizing and band classes; d_jobs the same on
+// the device) on stream s.  out_mode 0: ins/aln (spec v1), 1: maps + stats (spec v2).  Jobs whose band
+// exceeds 1024 diagonals are skipped and their indices appended to `too_wide` (the caller degrades
+// those groups instead of failing the batch).
+int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, const uint8_t* d_seq,
+                        double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
+                        int out_mode, uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats,
+                        std::vector<int>* too_wide, hipStream_t s);
+
+__device__ __forceinline__ uint8_t dna5_code(uint8_t c) {
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+    }
+    return 4;
+}
+
+}  // namespace sarlacc

@@ -1,0 +1,750 @@
+// msa_pairwise.hip -- banded global Gotoh of one read against one centre per wavefront (gfx950).
+//
+// The pairwise stage of quick_msa (/root/reference/src/quick_msa.cpp:25-35: Score<int, Simple>,
+// global, banded) for both MSA drivers (msa.hip spec v1, msa2.hip spec v2).  Recurrences, band and
+// tie rules are DESIGN.md section 5's: E = max(H_up + open, E_up + ext), F likewise from the left,
+// H = max(diag, E, F); ties: diagonal >= vertical >= horizontal, open >= extend; band on the
+// diagonals j - i in [min(0, lc - lr) - bw, max(0, lc - lr) + bw].
+//
+// Scheduling (both kernels): band coordinates (i, x), x = j - i - dlo.  The inputs of a cell are
+//   diagonal (i-1, x)      vertical (i-1, x+1)      horizontal (i, x-1)
+// so with the time step  t = 2 i + x  every input was produced at step t-1 or t-2: no prefix scan
+// over the row.  Lane l owns the C consecutive diagonals x = C l + k; at step t it updates its cells
+// with k = t (mod 2) -- C/2 cells per lane per step, every lane busy on every step -- reading the
+// neighbouring diagonals k-1 / k+1 from its own registers, or from the adjacent lane with one DPP
+// shift (H and F from the left on even steps, H and E from the right on odd steps).
+//
+//   k_msa_pairwise_pk<C>  (default) scores as packed 16-bit pairs: the two cells a lane updates in
+//       one step sit in the halves of one VGPR and every add / max is a v_pk_*_i16, so the
+//       recurrence costs half the instructions; traceback flags come from equality of the packed
+//       max with its first operand (no v_cmp -> SGPR -> v_addc chains).  Scores are kept in a cost
+//       domain (match 0, everything else <= 0, see cost_domain()) relative to a base that is moved
+//       every 128 steps, so 16 bits suffice for any read length; the penalties only have to satisfy
+//       the spread bound checked in pk_range_ok().
+//   k_msa_pairwise_ad<C>  the same schedule on 32-bit scores, for penalty sets outside that bound
+//       (and SARLACC_MSA_INT32=1 for A/B runs).
+// Both write 4 traceback bits per cell into a per-wave HBM tile (coalesced dwords) and walk it back
+// through an LDS window; runs of diagonal moves stay on one band diagonal and are consumed up to 64
+// rows per step.
+#include <cstdlib>
+#include <cstring>
+
+#include "msa_common.hpp"
+
+#include <algorithm>
+#include <type_traits>
+#include <vector>
+
+namespace sarlacc {
+
+constexpr int MSA_NEG = -(1 << 28);
+constexpr int PK_SPREAD_MAX = 11000;  // largest score spread inside one anti-diagonal the packed kernel accepts
+constexpr int PK_REBASE_ROWS = 32;    // word rows (of 4 steps) between two moves of the score base
+constexpr int MSA_WIN = 8;            // tile rows x 64 lanes of traceback codes held in LDS during the walk
+template <bool B>
+struct Flag2 { static constexpr bool value = B; };
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_int(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false);
+}
+#ifdef MSA_EXP_ROWDPP   // timing experiment: row shifts instead of wave shifts (wrong results)
+constexpr int DPP_WAVE_SHL1 = 0x101, DPP_WAVE_SHR1 = 0x111;
+#else
+constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;
+#endif
+
+__device__ __forceinline__ int wave_max(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(MSA_NEG, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(MSA_NEG, v, 0x112 /* row_shr:2 */, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(MSA_NEG, v, 0x114 /* row_shr:4 */, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(MSA_NEG, v, 0x118 /* row_shr:8 */, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(MSA_NEG, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(MSA_NEG, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Traceback walk shared by both kernels (wave-uniform state machine).
+//   Tile layout: groups of RG tile rows (64 words each) hold the codes of TSTEP consecutive steps;
+//   locate(i, x) -> (row group, row inside the group, bit shift of the 4-bit code, lane).
+//   Code bits after the optional inversion: bit 0 d >= max(e, f); bit 1 e >= f; bit 2 E opened;
+//   bit 3 F opened.
+//   OUT 0 (spec v1): ins[p] = read bases inserted before centre position p, aln[p] = centre base p matched.
+//   OUT 1 (spec v2): position maps of both directions (0xFFFF = opposite a gap) + (equal, aligned) counts.
+//   RDREV: the read codes in LDS are stored last base first (packed kernel).
+template <int OUT, bool INV, bool RDREV, int TSTEP, int RG, typename Word, typename Locate>
+__device__ __forceinline__ void msa_walk(const MsaArgs& A, const MsaJob& J, int jobidx, int dlo, const Word* tile, int ngrp,
+                                         Word* s_tb, const uint8_t* s_rd, const uint8_t* s_ct, Locate locate) {
+    const int lane = threadIdx.x;
+    const int lr = J.lr, lc = J.lc;
+    constexpr int WL = 8, WR = MSA_WIN * 64 / WL, WG = WR / RG;
+    uint16_t* ins = nullptr; uint8_t* aln = nullptr; uint16_t* mapA = nullptr; uint16_t* mapB = nullptr;
+    if (OUT == 0) { ins = A.ins + J.out_off; aln = A.aln + J.out_off; }
+    else { mapA = A.map + J.out_off; mapB = A.map + J.out2_off; }
+    int i = lr, j = lc, state = 0, cnt = 0, nequal = 0, ndiag = 0;
+    int glo = ngrp, llo = 0;   // first row group / first lane held in the window (none yet)
+    int walk_budget = 2 * (lr + lc) + 64;   // every iteration consumes a row, a column or changes state once
+    while ((i > 0 || j > 0) && --walk_budget >= 0) {
+        const int x = j - i - dlo;
+        int grp, rin, shift, ln;
+        locate(i, x, grp, rin, shift, ln);
+        if (grp < glo || ln < llo || ln >= llo + WL) {
+            glo = max(0, grp - (WG - 1));
+            llo = min(max(ln - WL / 2, 0), 64 - WL);
+            __syncthreads();
+            for (int idx = lane; idx < WG * RG * WL; idx += 64) {
+                const int r = idx / WL, cl = idx % WL;
+                if (glo * RG + r < ngrp * RG) s_tb[idx] = tile[static_cast<size_t>(glo * RG + r) * 64 + llo + cl];
+            }
+            __syncthreads();
+        }
+        if (state == 0) {
+            // run of diagonal moves: cell (i - m, j - m) keeps x; lane m inspects it
+            const int reach = min(min(i, j), ((2 * i + x - glo * TSTEP) >> 1) + 1);
+            unsigned tl = 1;
+            if (lane < reach) {
+                int g2, r2, sh2, l2;
+                locate(i - lane, x, g2, r2, sh2, l2);
+                unsigned c = static_cast<unsigned>(s_tb[((g2 - glo) * RG + r2) * WL + (l2 - llo)] >> sh2) & 1u;
+                if (INV) c ^= 1u;
+                tl = c ^ 1u;   // bit 0: diagonal
+            }
+            const unsigned long long nd = __ballot(tl != 0);
+            const int run = nd ? static_cast<int>(__builtin_ctzll(nd)) : 64;
+            if (run > 0) {
+                if (OUT == 0) {
+                    if (lane < run) { ins[j - lane] = (lane == 0) ? static_cast<uint16_t>(cnt) : static_cast<uint16_t>(0); aln[j - lane - 1] = 1; }
+                } else {
+                    bool eq = false;
+                    if (lane < run) {
+                        mapA[j - 1 - lane] = static_cast<uint16_t>(i - 1 - lane);
+                        mapB[i - 1 - lane] = static_cast<uint16_t>(j - 1 - lane);
+                        eq = s_rd[4 + (RDREV ? lr - i + lane : i - 1 - lane)] == s_ct[4 + j - 1 - lane];
+                    }
+                    nequal += __popcll(__ballot(eq));
+                    ndiag += run;
+                }
+                cnt = 0; i -= run; j -= run;
+                continue;
+            }
+        }
+        unsigned t = static_cast<unsigned>(s_tb[((grp - glo) * RG + rin) * WL + (ln - llo)] >> shift) & 15u;
+        if (INV) t ^= 15u;
+        if (state == 0) {
+            state = (t & 1u) ? 0 : ((t & 2u) ? 1 : 2);   // diagonal, else vertical if e >= f, else horizontal
+            continue;
+        }
+        if (state == 1) {               // read base i-1 inserted before centre position j
+            if (OUT == 0) ++cnt;
+            else if (lane == 0) mapB[i - 1] = 0xFFFF;
+            state = (t & 4) ? 0 : 1;
+            --i;
+        } else {                        // centre base j-1 opposite a gap
+            if (lane == 0) {
+                if (OUT == 0) { ins[j] = static_cast<uint16_t>(cnt); aln[j - 1] = 0; }
+                else mapA[j - 1] = 0xFFFF;
+            }
+            cnt = 0;
+            state = (t & 8) ? 0 : 2;
+            --j;
+        }
+    }
+    if (lane == 0) {
+        if (OUT == 0) ins[0] = static_cast<uint16_t>(cnt);
+        else A.stats[jobidx] = make_int2(nequal, ndiag);
+        if (walk_budget < 0) atomicExch(A.stuck, 1);
+    }
+}
+
+// stages the Dna5 codes (<< SHIFT) of centre and read into LDS (4 bytes of padding on either side)
+template <bool RDREV, int SHIFT>
+__device__ __forceinline__ void stage_codes(const MsaArgs& A, const MsaJob& J, uint8_t* s_ct, uint8_t*& s_rd) {
+    const int lane = threadIdx.x;
+    const int lr = J.lr, lc = J.lc;
+    const uint8_t* rd = A.seq + J.read_off;
+    const uint8_t* ct = A.seq + J.ctr_off;
+    s_rd = s_ct + ((lc + 8 + 3) & ~3);   // read codes after the centre codes
+    __syncthreads();
+    for (int p = lane; p < lc; p += 64) s_ct[4 + p] = dna5_code(ct[p]) << SHIFT;
+    for (int p = lane; p < lr; p += 64) s_rd[4 + (RDREV ? lr - 1 - p : p)] = dna5_code(rd[p]) << SHIFT;
+    if (lane < 4) { s_ct[lane] = 0xf0; s_rd[lane] = 0xf1; s_ct[4 + lc + lane] = 0xf0; s_rd[4 + lr + lane] = 0xf1; }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// 32-bit kernel.  Traceback nibble of a cell (raw outcomes, pushed most significant first):
+//   bit 3 F opened (H_left + go >= F_left + ge)   bit 2 E opened   bit 1 e >= f   bit 0 d >= max(e, f)
+// A sub-block (2 steps) yields C nibbles per lane, packed into words of 8 (C = 4: two sub-blocks per
+// dword) or C nibbles and stored coalesced.
+
+// pk = 2 * pk + (this lane's bit of the SGPR mask m)
+__device__ __forceinline__ uint32_t msa_push_bit(uint32_t pk, unsigned long long m) {
+    uint32_t r;
+    unsigned long long carry_out;
+    asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(pk), "s"(m));
+    return r;
+}
+
+template <int C>
+struct AdWord { using type = uint32_t; static constexpr int SPW = 8 / C; };
+template <>
+struct AdWord<16> { using type = unsigned long long; static constexpr int SPW = 1; };
+
+template <int C, int OUT>
+__global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
+    using Word = typename AdWord<C>::type;
+    constexpr int SPW = AdWord<C>::SPW;   // sub-blocks per stored word
+    constexpr int H2 = C / 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Word* const s_tb = reinterpret_cast<Word*>(smem);
+    uint8_t* const s_ct = reinterpret_cast<uint8_t*>(s_tb + MSA_WIN * 64);   // centre codes, padding in front
+    const int lane = threadIdx.x;
+    const int ma = A.ma, mm = A.mm, go = A.go, ge = A.ge;
+    Word* const tile = static_cast<Word*>(A.tb) + static_cast<size_t>(blockIdx.x) * A.tb_per_wave;
+
+    for (int jobn = blockIdx.x; jobn < A.njobs; jobn += gridDim.x) {
+        const int jobidx = A.order ? A.order[jobn] : jobn;
+        const MsaJob J = A.jobs[jobidx];
+        const int lr = J.lr, lc = J.lc;
+        const int dlo = min(0, lc - lr) - A.bw;
+        const int dhi = max(0, lc - lr) + A.bw;
+        const int B = dhi - dlo + 1;
+        uint8_t* s_rd;
+        stage_codes<false, 0>(A, J, s_ct, s_rd);
+
+        int Hc[C], Ec[C], Fc[C];
+        bool kvalid[C];
+        // Band edge: the vertical input of diagonal B - 1 lies outside the band.  Instead of
+        // masking the cells beyond the band after every update, the gap penalties a cell adds to
+        // its vertical input are per (lane, k) values that sink the candidate below MSA_NEG.
+        int gou[C], geu[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            Hc[k] = MSA_NEG; Ec[k] = MSA_NEG; Fc[k] = MSA_NEG;
+            kvalid[k] = lane * C + k < B;
+            gou[k] = (lane * C + k + 1 < B) ? go : MSA_NEG;
+            geu[k] = (lane * C + k + 1 < B) ? ge : MSA_NEG;
+        }
+
+        // One sub-block: steps t0 (even k) and t0 + 1 (odd k), t0 even.  Row and column of cell k:
+        //   i = t0/2 - (C/2) l - (k >> 1),   j = i + dlo + C l + k
+        // Cells are pushed in the order (parity, h); 8 cells fill one 32-bit chunk `pk`.
+        // Values arriving from the neighbouring lanes.  They are also the DPP destinations: lane 0
+        // (63) has no source lane for the shift, keeps what the register held, and that is the
+        // MSA_NEG it was initialised with -- no re-initialisation per step.
+        int xlH = MSA_NEG, xlF = MSA_NEG, xrH = MSA_NEG, xrE = MSA_NEG;
+        auto subblock = [&](auto guard_tag, int t0, uint32_t& pk, uint32_t& pk_hi) {
+            constexpr bool GUARD = decltype(guard_tag)::value;
+            const int ib = (t0 >> 1) - H2 * lane;            // row of cells k = 0, 1
+            const int jb = ib + dlo + C * lane;              // column of cell k = 0
+            // codes: read bases of rows ib - H2 + 1 .. ib  (s_rd[4 + i - 1]), centre bases of
+            // columns jb .. jb + H2 (s_ct[4 + j - 1]); out-of-range indices are clamped, the
+            // cells that would use them are invalid and discarded
+            int rc[H2], cc[H2 + 1];
+#pragma unroll
+            for (int h = 0; h < H2; ++h) {
+                int idx = ib - h - 1;
+                if (GUARD) idx = min(max(idx, -4), lr + 3);
+                rc[h] = s_rd[4 + idx];
+            }
+#pragma unroll
+            for (int h = 0; h <= H2; ++h) {
+                int idx = jb + h - 1;
+                if (GUARD) idx = min(max(idx, -4), lc + 3);
+                cc[h] = s_ct[4 + idx];
+            }
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                // neighbours across the lane boundary (values of the previous step)
+                if (par == 0) { xlH = dpp_int<DPP_WAVE_SHR1>(xlH, Hc[C - 1]); xlF = dpp_int<DPP_WAVE_SHR1>(xlF, Fc[C - 1]); }
+                else { xrH = dpp_int<DPP_WAVE_SHL1>(xrH, Hc[0]); xrE = dpp_int<DPP_WAVE_SHL1>(xrE, Ec[0]); }
+                int nH[H2], nE[H2], nF[H2];
+#pragma unroll
+                for (int h = 0; h < H2; ++h) {
+                    const int k = 2 * h + par;
+                    const int uH = (k + 1 < C) ? Hc[k + 1] : xrH, uE = (k + 1 < C) ? Ec[k + 1] : xrE;
+                    const int lH = (k > 0) ? Hc[k - 1] : xlH, lF = (k > 0) ? Fc[k - 1] : xlF;
+                    const int eop = uH + gou[k], eex = uE + geu[k];
+                    // Interior cells are reachable inside the band, so their scores are finite; the
+                    // "minus infinity" inputs from outside the band are re-derived from constants every
+                    // step and cannot drift, hence no clamping in the unguarded path.
+                    int e = max(eop, eex);
+                    const bool eo = eop >= eex;
+                    // cell k: row ib - h, column jb + h + par
+                    int d = Hc[k] + (rc[h] == cc[h + par] ? ma : mm);
+                    const int fop = lH + go, fex = lF + ge;
+                    int f = max(fop, fex);
+                    if (GUARD) { e = max(e, MSA_NEG); d = max(d, MSA_NEG); f = max(f, MSA_NEG); }
+                    const bool fo = fop >= fex;
+                    bool valid = true;
+                    if (GUARD) {
+                        const int i = ib - h, j = jb + h + par;
+                        valid = kvalid[k] && i >= 0 && i <= lr && j >= 0 && j <= lc;
+                        if (i == 0) { e = MSA_NEG; d = (j == 0) ? 0 : MSA_NEG; }
+                        if (j < 1) f = MSA_NEG;
+                        if (!valid) { e = MSA_NEG; d = MSA_NEG; f = MSA_NEG; }
+                    }
+                    const int m = max(e, f);
+                    const int hv = max(d, m);
+                    const unsigned long long m_fo = __builtin_amdgcn_ballot_w64(fo), m_eo = __builtin_amdgcn_ballot_w64(eo);
+                    const unsigned long long m_ef = __builtin_amdgcn_ballot_w64(e >= f), m_dm = __builtin_amdgcn_ballot_w64(d >= m);
+                    pk = msa_push_bit(msa_push_bit(msa_push_bit(msa_push_bit(pk, m_fo), m_eo), m_ef), m_dm);
+                    if (C == 16 && par == 0 && h == H2 - 1) { pk_hi = pk; pk = 0; }   // 8 cells done: first chunk of a 64-bit word
+                    nH[h] = (GUARD && !valid) ? MSA_NEG : hv;
+                    nE[h] = e;
+                    nF[h] = f;
+                }
+#pragma unroll
+                for (int h = 0; h < H2; ++h) { Hc[2 * h + par] = nH[h]; Ec[2 * h + par] = nE[h]; Fc[2 * h + par] = nF[h]; }
+            }
+        };
+
+        // steps 0 .. 2 lr + B - 1, in word blocks of 2 SPW steps
+        const int tsteps = 2 * lr + B;
+        const int nwords = (tsteps + 2 * SPW - 1) / (2 * SPW);
+        // sub-blocks [sb_lo, sb_hi) have every cell with x < B inside the matrix (i >= 1, 1 <= j <= lc, i <= lr)
+        int sb_lo = (max(B + 1, 2 - 2 * dlo) + 1) / 2 + 1;
+        int sb_hi = min(2 * lr, 2 * (lc - dlo) - B) / 2 - 1;
+        int w_lo = (sb_lo + SPW - 1) / SPW, w_hi = sb_hi / SPW;
+        w_lo = min(w_lo, nwords);
+        w_hi = min(max(w_hi, w_lo), nwords);
+        auto words = [&](auto guard_tag, int wb, int we) {
+            for (int w = wb; w < we; ++w) {
+                uint32_t pk = 0, pk_hi = 0;
+#pragma unroll
+                for (int sbk = 0; sbk < SPW; ++sbk) subblock(guard_tag, 2 * (w * SPW + sbk), pk, pk_hi);
+                Word out;
+                if (C == 16) out = static_cast<Word>((static_cast<unsigned long long>(pk_hi) << 32) | pk);
+                else out = static_cast<Word>(pk);
+                tile[static_cast<size_t>(w) * 64 + lane] = out;
+            }
+        };
+        words(Flag2<true>{}, 0, w_lo);
+        words(Flag2<false>{}, w_lo, w_hi);
+        words(Flag2<true>{}, w_hi, nwords);
+
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // code of cell (ii, xx): t = 2 ii + xx, sub-block ws = t >> 1
+        auto locate = [&](int ii, int xx, int& grp, int& rin, int& shift, int& ln) {
+            const int t = 2 * ii + xx;
+            const int ws = t >> 1;
+            const int k = xx % C;
+            ln = xx / C;
+            grp = ws / SPW;
+            rin = 0;
+            // cells are pushed in the order (sub-block, parity, h), the first one ends up on top
+            const int q = (ws % SPW) * C + (k & 1) * H2 + (k >> 1);
+            shift = 4 * (SPW * C - 1 - q);
+        };
+        msa_walk<OUT, false, false, 2 * SPW, 1, Word>(A, J, jobidx, dlo, tile, nwords, s_tb, s_rd, s_ct, locate);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed 16-bit kernel.
+//
+// Cost domain.  For a global alignment the number of aligned pairs is (lr + lc - gap characters) / 2,
+// so with k = 2 (k = 1 when match == 0) the scores  match' = 0, mismatch' = k (mismatch - match),
+// open' = k open - match, extend' = k extend - match  (open = cost of the first gap character)
+// give every alignment the score k S - match (lr + lc): the same optimum, and -- since the two
+// candidates of every max in the recurrence end at the same cell, i.e. have consumed the same number
+// of characters -- the same outcome of every comparison, ties included.  All steps are then <= 0 and
+// the kernel works on their negations: unsigned COSTS, min instead of max, "infinity" = PK_INF.
+// Measured on MI355X (tools/ubench_valu.hip): v_add_u32 / v_xor_b32 issue in ~2.7 cycles per wave64,
+// every VOP3 / packed / DPP instruction in ~4.2 -- so the additions are plain 32-bit adds on both
+// halves at once (no carry can cross: every sum stays below 2^16, see pk_range_ok()), only the
+// minima and the flag normalisation are packed instructions.
+//
+// Registers (per lane, M = C / 4 VGPRs each): the cells of one parity, two per register --
+//   even cells k = 2h: Hev[h >> 1], half h & 1;  odd cells k = 2h + 1: Hod[h >> 1], half h & 1.
+// Even step: the vertical neighbours (k + 1) are the odd registers as they are; the horizontal
+// neighbours (k - 1) are the odd registers shifted by one half (v_alignbit with the previous
+// register, or with the left lane's last register delivered by DPP).  Odd step: mirrored.
+// Flags: with e = min(eop, eex), "E opened" (eop <= eex) is e == eop; likewise f == fop, m == e for
+// "e at least as good as f" and h == d for the diagonal; min(x ^ y, 1) turns each into one bit per half
+// and a packed mad shifts it into the lane's code accumulator: after 4 steps each half holds 4 codes,
+// one dword per register is stored.  Stored codes are the complements of the 32-bit kernel's
+// (1 = "not equal").
+// Mismatch cost: the code bytes (stored as code << 4) are widened into the HIGH byte of each half, so
+// the xor of two different codes is >= 4096 and min(xor, mismatch cost) is the cost itself.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned PK_INF = 0x5000;   // per half
+
+__device__ __forceinline__ unsigned pk_splat(unsigned v) { return (v & 0xffffu) * 0x10001u; }
+__device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+// 1 per half where a != b.  Inline asm: written as min(a ^ b, 1) in C the compiler recognises a packed
+// "not equal", has no packed compare to select and falls back to two v_cmp + v_cndmask + v_perm per flag.
+__device__ __forceinline__ unsigned pk_ne(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(a ^ b));
+    return r;
+}
+// per half: 2 * acc + bit
+__device__ __forceinline__ unsigned pk_push(unsigned acc, unsigned bit) {
+    unsigned r;
+    asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(acc), "v"(bit));
+    return r;
+}
+// bytes B, B + 1 of the 8 code bytes (hi : lo) as the HIGH bytes of the two halves of a register
+template <int B>
+__device__ __forceinline__ unsigned pk_widen(unsigned hi, unsigned lo) {
+    return __builtin_amdgcn_perm(hi, lo, 0x000c000cu | (static_cast<unsigned>(B) << 8) | (static_cast<unsigned>(B + 1) << 24));
+}
+// NW dwords of code bytes from LDS (any alignment)
+template <int NW>
+__device__ __forceinline__ void lds_load_words(const uint8_t* p, unsigned (&w)[NW]) {
+#pragma unroll
+    for (int q = 0; q < NW; ++q) __builtin_memcpy(&w[q], p + 4 * q, 4);
+}
+// (hi : lo) >> 16, i.e. halves (lo.hi, hi.lo)
+__device__ __forceinline__ unsigned pk_shift_in(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+__device__ __forceinline__ unsigned pk_half(unsigned v, int hf) { return (v >> (16 * hf)) & 0xffffu; }
+
+__device__ __forceinline__ int wave_min(int v) {
+    constexpr int BIG = 0x7fffffff;
+    v = min(v, __builtin_amdgcn_update_dpp(BIG, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(BIG, v, 0x112 /* row_shr:2 */, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(BIG, v, 0x114 /* row_shr:4 */, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(BIG, v, 0x118 /* row_shr:8 */, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(BIG, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(BIG, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+template <int C, int OUT>
+__global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
+    constexpr int H2 = C / 2, M = C / 4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* const s_tb = reinterpret_cast<uint32_t*>(smem);
+    uint8_t* const s_ct = reinterpret_cast<uint8_t*>(s_tb + MSA_WIN * 64);
+    const int lane = threadIdx.x;
+    // costs (A.mm .. A.ge arrive transformed and negated by the host, see cost_domain())
+    const unsigned mmc = A.mm, goc = A.go, gec = A.ge;
+    const unsigned GO = pk_splat(goc), GE = pk_splat(gec), MM = pk_splat(mmc);
+    uint32_t* const tile = static_cast<uint32_t*>(A.tb) + static_cast<size_t>(blockIdx.x) * A.tb_per_wave;
+
+    for (int jobn = blockIdx.x; jobn < A.njobs; jobn += gridDim.x) {
+        const int jobidx = A.order ? A.order[jobn] : jobn;
+        const MsaJob J = A.jobs[jobidx];
+        const int lr = J.lr, lc = J.lc;
+        const int dlo = min(0, lc - lr) - A.bw;
+        const int dhi = max(0, lc - lr) + A.bw;
+        const int B = dhi - dlo + 1;
+        uint8_t* s_rd;
+        stage_codes<true, 4>(A, J, s_ct, s_rd);
+
+        unsigned Hev[M], Hod[M], Eev[M], Eod[M], Fev[M], Fod[M];
+        unsigned gouEv[M], geuEv[M], gouOd[M], geuOd[M];   // vertical costs; PK_INF sinks the candidate at the band edge
+        unsigned vmEv[M], vmOd[M];                         // 0xffff per half where the cell's diagonal is inside the band
+        unsigned acc[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            Hev[m] = Hod[m] = Eev[m] = Eod[m] = Fev[m] = Fod[m] = pk_splat(PK_INF);
+            acc[m] = 0;
+            gouEv[m] = geuEv[m] = gouOd[m] = geuOd[m] = vmEv[m] = vmOd[m] = 0;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int xe = lane * C + 2 * (2 * m + hf), xo = xe + 1;
+                gouEv[m] |= (xe + 1 < B ? goc : PK_INF) << (16 * hf);
+                geuEv[m] |= (xe + 1 < B ? gec : PK_INF) << (16 * hf);
+                gouOd[m] |= (xo + 1 < B ? goc : PK_INF) << (16 * hf);
+                geuOd[m] |= (xo + 1 < B ? gec : PK_INF) << (16 * hf);
+                vmEv[m] |= (xe < B ? 0xffffu : 0u) << (16 * hf);
+                vmOd[m] |= (xo < B ? 0xffffu : 0u) << (16 * hf);
+            }
+        }
+        // values arriving from the neighbouring lanes; as DPP destinations lane 0 (63) keeps the PK_INF pair
+        int xlH = static_cast<int>(pk_splat(PK_INF)), xlF = xlH, xrH = xlH, xrE = xlH;
+
+        // ---- one step (one parity) on the packed state ----
+        auto step_pk = [&](auto par_tag, const unsigned (&pen)[M], int inject) {
+            constexpr int par = decltype(par_tag)::value;
+            if (par == 0) { xlH = dpp_int<DPP_WAVE_SHR1>(xlH, static_cast<int>(Hod[M - 1])); xlF = dpp_int<DPP_WAVE_SHR1>(xlF, static_cast<int>(Fod[M - 1])); }
+            else { xrH = dpp_int<DPP_WAVE_SHL1>(xrH, static_cast<int>(Hev[0])); xrE = dpp_int<DPP_WAVE_SHL1>(xrE, static_cast<int>(Eev[0])); }
+            unsigned nH[M], nE[M], nF[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                unsigned upH, upE, lfH, lfF, same;
+                if (par == 0) {
+                    upH = Hod[m]; upE = Eod[m];
+                    lfH = pk_shift_in(Hod[m], m > 0 ? Hod[m > 0 ? m - 1 : 0] : static_cast<unsigned>(xlH));
+                    lfF = pk_shift_in(Fod[m], m > 0 ? Fod[m > 0 ? m - 1 : 0] : static_cast<unsigned>(xlF));
+                    same = Hev[m];
+                } else {
+                    lfH = Hev[m]; lfF = Fev[m];
+                    upH = pk_shift_in(m + 1 < M ? Hev[m + 1 < M ? m + 1 : 0] : static_cast<unsigned>(xrH), Hev[m]);
+                    upE = pk_shift_in(m + 1 < M ? Eev[m + 1 < M ? m + 1 : 0] : static_cast<unsigned>(xrE), Eev[m]);
+                    same = Hod[m];
+                }
+                const unsigned eop = upH + (par == 0 ? gouEv[m] : gouOd[m]);
+                const unsigned eex = upE + (par == 0 ? geuEv[m] : geuOd[m]);
+                const unsigned e = pk_min(eop, eex);
+                const unsigned fop = lfH + GO, fex = lfF + GE;
+                const unsigned f = pk_min(fop, fex);
+                const unsigned d = same + pen[m];
+                const unsigned mn = pk_min(e, f);
+                const unsigned hv = pk_min(d, mn);
+                acc[m] = pk_push(pk_push(pk_push(pk_push(acc[m], pk_ne(f, fop)), pk_ne(e, eop)), pk_ne(mn, e)), pk_ne(hv, d));
+                nH[m] = hv; nE[m] = e; nF[m] = f;
+            }
+            // first row of the job only: the step that computes cell (0, 0) sets H(0, 0) = 0 in its lane
+            // (inject = 2 (register index) + half, -1 otherwise)
+            if (inject >= 0) {
+#pragma unroll
+                for (int m = 0; m < M; ++m)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+                        if (inject == 2 * m + hf) nH[m] &= ~(0xffffu << (16 * hf));
+            }
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                if (par == 0) { Hev[m] = nH[m]; Eev[m] = nE[m]; Fev[m] = nF[m]; }
+                else { Hod[m] = nH[m]; Eod[m] = nE[m]; Fod[m] = nF[m]; }
+            }
+        };
+
+        // Code words of one word row (2 sub-blocks): rw = read codes from s_rd + 4 + lr - ib2 (ib2 = row of cells
+        // k = 0, 1 in the SECOND sub-block; the first one starts one byte higher), cw = centre codes from
+        // s_ct + 4 + jb1 - 1 (jb1 = column of cell k = 0 in the FIRST sub-block).  H2 + 1 and H2 + 2 bytes are used.
+        // One sub-block: steps t0 (even cells) and t0 + 1 (odd cells), t0 even.  Row and column of cell k:
+        //   i = t0/2 - (C/2) l - (k >> 1),   j = i + dlo + C l + k
+        constexpr int NW = (H2 + 2 + 3) / 4;
+        // bytes Bx, Bx + 1 of a code word array as (high bytes of the) halves
+        auto widen = [&](auto b_tag, const unsigned (&w)[NW]) -> unsigned {
+            constexpr int Bx = decltype(b_tag)::value;
+            constexpr int q = Bx / 4, r = Bx % 4;
+            return pk_widen<r>(q + 1 < NW ? w[q + 1 < NW ? q + 1 : q] : 0u, w[q]);
+        };
+        auto subblock_pk = [&](auto sb_tag, const unsigned (&rw)[NW], const unsigned (&cw)[NW], int inj_even, int inj_odd) {
+            constexpr int SB = decltype(sb_tag)::value;   // 0: first sub-block of the word row, 1: second
+            unsigned pen0[M], pen1[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                // cells h = 2m, 2m + 1: read byte (1 - SB) + h, centre byte SB + h (even step) / SB + h + 1 (odd step)
+                unsigned r2 = 0, c2 = 0, c3 = 0;
+                if constexpr (M > 0) if (m == 0) { r2 = widen(std::integral_constant<int, 1 - SB>{}, rw); c2 = widen(std::integral_constant<int, SB>{}, cw); c3 = widen(std::integral_constant<int, SB + 1>{}, cw); }
+                if constexpr (M > 1) if (m == 1) { r2 = widen(std::integral_constant<int, 3 - SB>{}, rw); c2 = widen(std::integral_constant<int, SB + 2>{}, cw); c3 = widen(std::integral_constant<int, SB + 3>{}, cw); }
+                if constexpr (M > 2) if (m == 2) { r2 = widen(std::integral_constant<int, 5 - SB>{}, rw); c2 = widen(std::integral_constant<int, SB + 4>{}, cw); c3 = widen(std::integral_constant<int, SB + 5>{}, cw); }
+                if constexpr (M > 3) if (m == 3) { r2 = widen(std::integral_constant<int, 7 - SB>{}, rw); c2 = widen(std::integral_constant<int, SB + 6>{}, cw); c3 = widen(std::integral_constant<int, SB + 7>{}, cw); }
+                pen0[m] = pk_min(r2 ^ c2, MM);   // 0 where the codes agree, the mismatch cost where they differ
+                pen1[m] = pk_min(r2 ^ c3, MM);
+            }
+            step_pk(std::integral_constant<int, 0>{}, pen0, inj_even);
+            step_pk(std::integral_constant<int, 1>{}, pen1, inj_odd);
+        };
+
+        // Steps 0 .. 2 lr + B - 1, in word rows of 4 steps (2 sub-blocks).  No boundary tests anywhere: every
+        // cell starts at "infinity", a cell outside the matrix only ever sees such neighbours (its inputs
+        // have a smaller row or column) and so stays there, and no cell inside the matrix depends on one with a
+        // larger row or column.  The single exception is H(0, 0) = 0, set by the step that computes that cell
+        // (t = x0 = -dlo); the word rows before it hold nothing the walk can reach and are skipped.
+        const int tsteps = 2 * lr + B;
+        const int nwr = (tsteps + 3) / 4;
+        const int x0 = -dlo;
+        const int w0 = x0 >> 2;
+        const int inj_code = (lane == x0 / C) ? (((x0 % C) >> 1) >> 1) * 2 + (((x0 % C) >> 1) & 1) : -1;   // register index, half
+        auto code_ptrs = [&](int w, const uint8_t*& rp, const uint8_t*& cp) {
+            rp = s_rd + 4 + lr - (2 * w + 1 - H2 * lane);              // read codes of the second sub-block's row ib2 ..
+            cp = s_ct + 4 + (2 * w - H2 * lane) + dlo + C * lane - 1;   // centre codes from the first sub-block's jb1 - 1
+        };
+        unsigned rnext[NW], cnext[NW];
+        {
+            const uint8_t *rp, *cp;
+            code_ptrs(w0, rp, cp);
+            lds_load_words<NW>(rp, rnext);
+            lds_load_words<NW>(cp, cnext);
+        }
+        for (int w = w0; w < nwr; ++w) {
+            if (((w - w0) % PK_REBASE_ROWS) == PK_REBASE_ROWS - 1) {
+                // move the cost base: the best H of the wave goes back to 0 (comparisons are between cells of
+                // the same neighbourhood and do not see a common offset).  E, F >= H in every cell and H >= the
+                // minimum, so the 32-bit subtraction borrows nothing across the halves.
+                int best = 0x7fffffff;
+#pragma unroll
+                for (int m = 0; m < M; ++m)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        if (pk_half(vmEv[m], hf)) best = min(best, static_cast<int>(pk_half(Hev[m], hf)));
+                        if (pk_half(vmOd[m], hf)) best = min(best, static_cast<int>(pk_half(Hod[m], hf)));
+                    }
+                best = wave_min(best);
+                const unsigned delta = pk_splat(best < static_cast<int>(PK_INF) ? static_cast<unsigned>(best) : 0u);
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const unsigned de = delta & vmEv[m], dd = delta & vmOd[m];
+                    Hev[m] -= de; Eev[m] -= de; Fev[m] -= de;
+                    Hod[m] -= dd; Eod[m] -= dd; Fod[m] -= dd;
+                }
+            }
+            unsigned rw[NW], cw[NW];
+#pragma unroll
+            for (int q = 0; q < NW; ++q) { rw[q] = rnext[q]; cw[q] = cnext[q]; }
+            {   // the next word row's codes are fetched now and used one iteration later
+                const uint8_t *rp, *cp;
+                code_ptrs(w + 1, rp, cp);
+                lds_load_words<NW>(rp, rnext);
+                lds_load_words<NW>(cp, cnext);
+            }
+            if (w == w0) {
+                const int s0 = x0 & 3;   // step of the row that computes cell (0, 0)
+                subblock_pk(std::integral_constant<int, 0>{}, rw, cw, s0 == 0 ? inj_code : -1, s0 == 1 ? inj_code : -1);
+                subblock_pk(std::integral_constant<int, 1>{}, rw, cw, s0 == 2 ? inj_code : -1, s0 == 3 ? inj_code : -1);
+            } else {
+                subblock_pk(std::integral_constant<int, 0>{}, rw, cw, -1, -1);
+                subblock_pk(std::integral_constant<int, 1>{}, rw, cw, -1, -1);
+            }
+            if (!(A.dbg & 4)) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) tile[static_cast<size_t>(w * M + m) * 64 + lane] = acc[m];
+            }
+        }
+
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // code of cell (ii, xx): step t = 2 ii + xx, word row t >> 2, register (k >> 1) >> 1, half (k >> 1) & 1,
+        // code t & 3 of the half counted from the top
+        auto locate = [&](int ii, int xx, int& grp, int& rin, int& shift, int& ln) {
+            const int t = 2 * ii + xx;
+            const int k = xx % C, h = k >> 1;
+            ln = xx / C;
+            grp = t >> 2;
+            rin = h >> 1;
+            shift = 16 * (h & 1) + 4 * (3 - (t & 3));
+        };
+        if (!(A.dbg & 1)) msa_walk<OUT, true, true, 4, M, uint32_t>(A, J, jobidx, dlo, tile, nwr, s_tb, s_rd, s_ct, locate);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+
+// scores -> non-negative costs of the packed kernel; false when they do not fit it
+static bool cost_domain(int ma, int mm, int go, int ge, int* mmc, int* goc, int* gec) {
+    const int k = ma != 0 ? 2 : 1;
+    const long long m2 = static_cast<long long>(k) * (mm - ma), g2 = static_cast<long long>(k) * go - (k == 2 ? ma : 0),
+                    e2 = static_cast<long long>(k) * ge - (k == 2 ? ma : 0);
+    if (m2 > 0 || g2 > 0 || e2 > 0 || m2 < -4000 || g2 < -4000 || e2 < -4000) return false;
+    *mmc = static_cast<int>(-m2); *goc = static_cast<int>(-g2); *gec = static_cast<int>(-e2);
+    return true;
+}
+
+// The packed kernel adds both halves of a register with one 32-bit addition, so no 16-bit sum may reach
+// 2^16.  Finite costs stay below `spread` (a cell is reached from the best cell of its step through a gap
+// of at most `band` characters plus as many mismatches, and the base moves every 4 * PK_REBASE_ROWS steps);
+// the cells that are still "infinite" at the start drift up by at most one penalty per step until their
+// diagonal enters the matrix (<= band + 8 steps).  The largest sum is infinity + drift + infinity (band
+// edge) + one penalty; with PK_INF = 0x5000 it fits when spread and drift stay below PK_SPREAD_MAX.
+static bool pk_range_ok(int mmc, int goc, int gec, int band) {
+    const long long step = std::max(std::max(mmc, goc), gec);
+    const long long spread = goc + (static_cast<long long>(gec) + mmc) * (band + 2) + step * (4 * PK_REBASE_ROWS + 8);
+    const long long drift = step * (band + 8);
+    return spread < PK_SPREAD_MAX && drift < PK_SPREAD_MAX;
+}
+
+template <int C, int OUT>
+static int launch_ad(const MsaArgs& a, int grid, size_t lds, hipStream_t s) {
+    // long reads stage more than the default 64 KB of dynamic LDS (gfx950 has 160 KB per CU)
+    if (lds > 48 * 1024)
+        SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msa_pairwise_ad<C, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(lds)));
+    hipLaunchKernelGGL((k_msa_pairwise_ad<C, OUT>), dim3(grid), dim3(64), lds, s, a);
+    SL_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int C, int OUT>
+static int launch_pk(const MsaArgs& a, int grid, size_t lds, hipStream_t s) {
+    if (lds > 48 * 1024)
+        SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msa_pairwise_pk<C, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(lds)));
+    hipLaunchKernelGGL((k_msa_pairwise_pk<C, OUT>), dim3(grid), dim3(64), lds, s, a);
+    SL_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int OUT>
+static int launch_class(bool packed, int C, const MsaArgs& a, int grid, size_t lds, hipStream_t s) {
+    if (packed) {
+        if (C == 4) return launch_pk<4, OUT>(a, grid, lds, s);
+        if (C == 8) return launch_pk<8, OUT>(a, grid, lds, s);
+        return launch_pk<16, OUT>(a, grid, lds, s);
+    }
+    if (C == 4) return launch_ad<4, OUT>(a, grid, lds, s);
+    if (C == 8) return launch_ad<8, OUT>(a, grid, lds, s);
+    return launch_ad<16, OUT>(a, grid, lds, s);
+}
+
+int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, const uint8_t* d_seq, double match,
+                        double mismatch, double gap_extension, double gap_opening, int bandwidth, int out_mode,
+                        uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats, std::vector<int>* too_wide,
+                        hipStream_t s) {
+    if (jobs.empty()) return 0;
+    Context& c = ctx();
+    // jobs by band class: 4, 8 or 16 diagonals per lane (bands up to 256 / 512 / 1024); one launch per
+    // class, so the common narrow bands are not dragged to the widest job's shape
+    std::vector<int> order[3];
+    int cls_lr[3] = {0, 0, 0}, cls_lc[3] = {0, 0, 0}, cls_band[3] = {1, 1, 1};
+    for (size_t q = 0; q < jobs.size(); ++q) {
+        const long long band = std::llabs(static_cast<long long>(jobs[q].lc) - jobs[q].lr) + 2LL * bandwidth + 1;
+        if (band > 1024) {
+            if (too_wide) { too_wide->push_back(static_cast<int>(q)); continue; }
+            return fail("sarlacc_amd: alignment band of %lld diagonals exceeds 1024 (length difference + 2*bandwidth + 1)", band);
+        }
+        const int cls = band <= 256 ? 0 : (band <= 512 ? 1 : 2);
+        order[cls].push_back(static_cast<int>(q));
+        cls_lr[cls] = std::max(cls_lr[cls], jobs[q].lr);
+        cls_lc[cls] = std::max(cls_lc[cls], jobs[q].lc);
+        cls_band[cls] = std::max(cls_band[cls], static_cast<int>(band));
+    }
+    MsaArgs a{};
+    a.seq = d_seq; a.jobs = d_jobs;
+    // SeqAn's Score(match, mismatch, gap_extend, gap_open): gap of length k = open + (k-1)*extend
+    const int ma = static_cast<int>(match), mm = static_cast<int>(mismatch), go = static_cast<int>(gap_opening),
+              ge = static_cast<int>(gap_extension);
+    a.bw = bandwidth; a.ins = d_ins; a.aln = d_aln; a.map = d_map; a.stats = d_stats;
+    int* d_stuck;
+    SL_TRY(scratch("msa.stuck", 1, &d_stuck));
+    SL_HIP(hipMemsetAsync(d_stuck, 0, sizeof(int), s));
+    a.stuck = d_stuck;
+    if (const char* dbg = std::getenv("SARLACC_MSA_DBG")) a.dbg = std::atoi(dbg);
+    int mmc = 0, goc = 0, gec = 0;
+    const bool domain_ok = cost_domain(ma, mm, go, ge, &mmc, &goc, &gec) && !std::getenv("SARLACC_MSA_INT32");
+    for (int cls = 0; cls < 3; ++cls) {
+        if (order[cls].empty()) continue;
+        const int C = 4 << cls;
+        const bool packed = domain_ok && pk_range_ok(mmc, goc, gec, cls_band[cls]);
+        if (packed) { a.ma = 0; a.mm = mmc; a.go = goc; a.ge = gec; }
+        else { a.ma = ma; a.mm = mm; a.go = go; a.ge = ge; }
+        // traceback tile of one resident wave, 4 bits per cell: packed kernel C/4 dwords per lane per 4 steps,
+        // 32-bit kernel one (C = 16: 64-bit) word per lane per 2 SPW steps
+        const size_t steps = 2 * static_cast<size_t>(cls_lr[cls]) + cls_band[cls];
+        const size_t word = (!packed && C == 16) ? 8 : 4;
+        const size_t spw = C == 4 ? 2 : 1;
+        const size_t per_wave = packed ? ((steps + 3) / 4 + 1) * (C / 4) * 64 : (steps / (2 * spw) + 2) * 64;
+        const size_t lds = MSA_WIN * 64 * word + static_cast<size_t>(cls_lc[cls]) + static_cast<size_t>(cls_lr[cls]) + 32;
+        if (lds > 160 * 1024) return fail("sarlacc_amd: reads of %d bases do not fit the MSA kernel's LDS staging", std::max(cls_lr[cls], cls_lc[cls]));
+        // many more single-wave workgroups than fit at once (a wave then aligns only a few pairs and the
+        // hardware balances the load); their traceback tiles are the price, capped at 24 GB of HBM
+        long long grid = std::min<long long>(static_cast<long long>(order[cls].size()), static_cast<long long>(c.num_cu) * 128);
+        const size_t budget = static_cast<size_t>(24) << 30;
+        grid = std::min<long long>(grid, std::max<long long>(1, static_cast<long long>(budget / (per_wave * word))));
+        void* d_tb; int* d_order;
+        const char* tb_name[3] = {"msa.tb0", "msa.tb1", "msa.tb2"};
+        const char* ord_name[3] = {"msa.ord0", "msa.ord1", "msa.ord2"};
+        SL_TRY(c.buffer(tb_name[cls], static_cast<size_t>(grid) * per_wave * word, &d_tb));
+        SL_TRY(upload(ord_name[cls], order[cls].data(), order[cls].size(), &d_order, s));
+        a.order = d_order; a.njobs = static_cast<int>(order[cls].size());
+        a.tb = d_tb; a.tb_per_wave = per_wave;
+        if (out_mode == 0) SL_TRY(launch_class<0>(packed, C, a, static_cast<int>(grid), lds, s));
+        else SL_TRY(launch_class<1>(packed, C, a, static_cast<int>(grid), lds, s));
+    }
+    return 0;
+}
+
+}  // namespace sarlacc
