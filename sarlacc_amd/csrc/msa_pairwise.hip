@@ -129,7 +129,8 @@ __device__ __forceinline__ void msa_walk(const MsaArgs& A, const MsaJob& J, int 
                 continue;
             }
         }
-        unsigned t = static_cast<unsigned>(s_tb[((grp - glo) * RG + rin) * WL + (ln - llo)] >> shift) & 15u;
+        // the walk's state is the same in every lane: telling the compiler so keeps it in SGPRs / on the scalar unit
+        unsigned t = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(s_tb[((grp - glo) * RG + rin) * WL + (ln - llo)] >> shift))) & 15u;
         if (INV) t ^= 15u;
         if (state == 0) {
             state = (t & 1u) ? 0 : ((t & 2u) ? 1 : 2);   // diagonal, else vertical if e >= f, else horizontal
@@ -158,13 +159,15 @@ __device__ __forceinline__ void msa_walk(const MsaArgs& A, const MsaJob& J, int 
 }
 
 // stages the Dna5 codes (<< SHIFT) of centre and read into LDS (4 bytes of padding on either side)
+// pad_c / pad_r (0 or 1) shift the two arrays by one byte (the packed kernel makes its read addresses even).
 template <bool RDREV, int SHIFT>
-__device__ __forceinline__ void stage_codes(const MsaArgs& A, const MsaJob& J, uint8_t* s_ct, uint8_t*& s_rd) {
+__device__ __forceinline__ void stage_codes(const MsaArgs& A, const MsaJob& J, uint8_t*& s_ct, uint8_t*& s_rd, int pad_c = 0, int pad_r = 0) {
     const int lane = threadIdx.x;
     const int lr = J.lr, lc = J.lc;
     const uint8_t* rd = A.seq + J.read_off;
     const uint8_t* ct = A.seq + J.ctr_off;
-    s_rd = s_ct + ((lc + 8 + 3) & ~3);   // read codes after the centre codes
+    s_rd = s_ct + ((lc + 12 + 3) & ~3) + pad_r;   // read codes after the centre codes
+    s_ct += pad_c;
     __syncthreads();
     for (int p = lane; p < lc; p += 64) s_ct[4 + p] = dna5_code(ct[p]) << SHIFT;
     for (int p = lane; p < lr; p += 64) s_rd[4 + (RDREV ? lr - 1 - p : p)] = dna5_code(rd[p]) << SHIFT;
@@ -198,7 +201,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
     constexpr int H2 = C / 2;
     extern __shared__ __align__(16) unsigned char smem[];
     Word* const s_tb = reinterpret_cast<Word*>(smem);
-    uint8_t* const s_ct = reinterpret_cast<uint8_t*>(s_tb + MSA_WIN * 64);   // centre codes, padding in front
+    uint8_t* const s_ct0 = reinterpret_cast<uint8_t*>(s_tb + MSA_WIN * 64);   // centre codes, padding in front
     const int lane = threadIdx.x;
     const int ma = A.ma, mm = A.mm, go = A.go, ge = A.ge;
     Word* const tile = static_cast<Word*>(A.tb) + static_cast<size_t>(blockIdx.x) * A.tb_per_wave;
@@ -210,6 +213,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
         const int dlo = min(0, lc - lr) - A.bw;
         const int dhi = max(0, lc - lr) + A.bw;
         const int B = dhi - dlo + 1;
+        uint8_t* s_ct = s_ct0;
         uint8_t* s_rd;
         stage_codes<false, 0>(A, J, s_ct, s_rd);
 
@@ -384,10 +388,11 @@ __device__ __forceinline__ unsigned pk_ne(unsigned a, unsigned b) {
     asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(a ^ b));
     return r;
 }
-// per half: 2 * acc + bit
-__device__ __forceinline__ unsigned pk_push(unsigned acc, unsigned bit) {
+// per half: K * a + b
+template <int K>
+__device__ __forceinline__ unsigned pk_mad(unsigned a, unsigned b) {
     unsigned r;
-    asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(acc), "v"(bit));
+    asm("v_pk_mad_u16 %0, %1, %3, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "n"(K));
     return r;
 }
 // bytes B, B + 1 of the 8 code bytes (hi : lo) as the HIGH bytes of the two halves of a register
@@ -395,11 +400,32 @@ template <int B>
 __device__ __forceinline__ unsigned pk_widen(unsigned hi, unsigned lo) {
     return __builtin_amdgcn_perm(hi, lo, 0x000c000cu | (static_cast<unsigned>(B) << 8) | (static_cast<unsigned>(B + 1) << 24));
 }
-// NW dwords of code bytes from LDS (any alignment)
+// NW dwords of code bytes from LDS at an EVEN address, as aligned 16-bit reads.  Misaligned LDS reads are
+// legal but slow on gfx950: with one misaligned ds_read_b32 per lane per word the LDS array (SQ_LDS_IDX_ACTIVE
+// 45 cycles per read), not the VALU, set the pace of this kernel.  Inline asm keeps the halves separate loads
+// (fused they would be a 2-byte aligned ds_read_b32 again); the compiler does not track the counters of loads
+// issued from inline asm, so lds_words_ready() waits and hands the registers back THROUGH the wait statement --
+// nothing that uses them can be scheduled above it.
+struct LdsHalves { unsigned lo, hi; };
 template <int NW>
-__device__ __forceinline__ void lds_load_words(const uint8_t* p, unsigned (&w)[NW]) {
+__device__ __forceinline__ void lds_issue_words(const uint8_t* p, LdsHalves (&h)[NW]) {
+    typedef __attribute__((address_space(3))) const uint16_t lds_u16;
+    lds_u16* q16 = (lds_u16*)p;
 #pragma unroll
-    for (int q = 0; q < NW; ++q) __builtin_memcpy(&w[q], p + 4 * q, 4);
+    for (int q = 0; q < NW; ++q)
+        asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %2 offset:2" : "=&v"(h[q].lo), "=&v"(h[q].hi) : "v"(q16 + 2 * q) : "memory");
+}
+template <int NW>
+__device__ __forceinline__ void lds_words_ready(LdsHalves (&a)[NW], LdsHalves (&b)[NW], unsigned (&wa)[NW], unsigned (&wb)[NW]) {
+    if constexpr (NW == 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0].lo), "+v"(a[0].hi), "+v"(b[0].lo), "+v"(b[0].hi));
+    else if constexpr (NW == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0].lo), "+v"(a[0].hi), "+v"(b[0].lo), "+v"(b[0].hi), "+v"(a[1].lo), "+v"(a[1].hi), "+v"(b[1].lo), "+v"(b[1].hi));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0].lo), "+v"(a[0].hi), "+v"(b[0].lo), "+v"(b[0].hi), "+v"(a[1].lo), "+v"(a[1].hi), "+v"(b[1].lo), "+v"(b[1].hi),
+                                              "+v"(a[2].lo), "+v"(a[2].hi), "+v"(b[2].lo), "+v"(b[2].hi));
+#pragma unroll
+    for (int q = 0; q < NW; ++q) { wa[q] = a[q].lo | (a[q].hi << 16); wb[q] = b[q].lo | (b[q].hi << 16); }
 }
 // (hi : lo) >> 16, i.e. halves (lo.hi, hi.lo)
 __device__ __forceinline__ unsigned pk_shift_in(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
@@ -421,7 +447,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
     constexpr int H2 = C / 2, M = C / 4;
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* const s_tb = reinterpret_cast<uint32_t*>(smem);
-    uint8_t* const s_ct = reinterpret_cast<uint8_t*>(s_tb + MSA_WIN * 64);
+    uint8_t* const s_ct0 = reinterpret_cast<uint8_t*>(s_tb + MSA_WIN * 64);
     const int lane = threadIdx.x;
     // costs (A.mm .. A.ge arrive transformed and negated by the host, see cost_domain())
     const unsigned mmc = A.mm, goc = A.go, gec = A.ge;
@@ -435,8 +461,11 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
         const int dlo = min(0, lc - lr) - A.bw;
         const int dhi = max(0, lc - lr) + A.bw;
         const int B = dhi - dlo + 1;
+        // code arrays placed so that every lane's code-word address is even (see lds_load_words):
+        //   centre words start at s_ct + 3 + 2 w + dlo + (C/2) lane, read words at s_rd + 3 + lr - 2 w + (C/2) lane
+        uint8_t* s_ct = s_ct0;
         uint8_t* s_rd;
-        stage_codes<true, 4>(A, J, s_ct, s_rd);
+        stage_codes<true, 4>(A, J, s_ct, s_rd, (dlo + 1) & 1, (lr + 1) & 1);
 
         unsigned Hev[M], Hod[M], Eev[M], Eod[M], Fev[M], Fod[M];
         unsigned gouEv[M], geuEv[M], gouOd[M], geuOd[M];   // vertical costs; PK_INF sinks the candidate at the band edge
@@ -464,8 +493,13 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
         // ---- one step (one parity) on the packed state ----
         auto step_pk = [&](auto par_tag, const unsigned (&pen)[M], int inject) {
             constexpr int par = decltype(par_tag)::value;
+#ifdef MSA_EXP_NODPP   // timing experiment (wrong results)
+            if (par == 0) { xlH = static_cast<int>(Hod[M - 1]) + 1; xlF = static_cast<int>(Fod[M - 1]) + 1; }
+            else { xrH = static_cast<int>(Hev[0]) + 1; xrE = static_cast<int>(Eev[0]) + 1; }
+#else
             if (par == 0) { xlH = dpp_int<DPP_WAVE_SHR1>(xlH, static_cast<int>(Hod[M - 1])); xlF = dpp_int<DPP_WAVE_SHR1>(xlF, static_cast<int>(Fod[M - 1])); }
             else { xrH = dpp_int<DPP_WAVE_SHL1>(xrH, static_cast<int>(Hev[0])); xrE = dpp_int<DPP_WAVE_SHL1>(xrE, static_cast<int>(Eev[0])); }
+#endif
             unsigned nH[M], nE[M], nF[M];
 #pragma unroll
             for (int m = 0; m < M; ++m) {
@@ -489,7 +523,12 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
                 const unsigned d = same + pen[m];
                 const unsigned mn = pk_min(e, f);
                 const unsigned hv = pk_min(d, mn);
-                acc[m] = pk_push(pk_push(pk_push(pk_push(acc[m], pk_ne(f, fop)), pk_ne(e, eop)), pk_ne(mn, e)), pk_ne(hv, d));
+#ifdef MSA_EXP_NOFLAGS   // timing experiment (wrong results)
+                acc[m] ^= hv;
+#else
+                // code = 8 [f != fop] + 4 [e != eop] + 2 [mn != e] + [hv != d], shifted into the accumulator
+                acc[m] = pk_mad<16>(acc[m], pk_mad<4>(pk_mad<2>(pk_ne(f, fop), pk_ne(e, eop)), pk_mad<2>(pk_ne(mn, e), pk_ne(hv, d))));
+#endif
                 nH[m] = hv; nE[m] = e; nF[m] = f;
             }
             // first row of the job only: the step that computes cell (0, 0) sets H(0, 0) = 0 in its lane
@@ -552,56 +591,64 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
             rp = s_rd + 4 + lr - (2 * w + 1 - H2 * lane);              // read codes of the second sub-block's row ib2 ..
             cp = s_ct + 4 + (2 * w - H2 * lane) + dlo + C * lane - 1;   // centre codes from the first sub-block's jb1 - 1
         };
-        unsigned rnext[NW], cnext[NW];
-        {
-            const uint8_t *rp, *cp;
-            code_ptrs(w0, rp, cp);
-            lds_load_words<NW>(rp, rnext);
-            lds_load_words<NW>(cp, cnext);
-        }
-        for (int w = w0; w < nwr; ++w) {
-            if (((w - w0) % PK_REBASE_ROWS) == PK_REBASE_ROWS - 1) {
-                // move the cost base: the best H of the wave goes back to 0 (comparisons are between cells of
-                // the same neighbourhood and do not see a common offset).  E, F >= H in every cell and H >= the
-                // minimum, so the 32-bit subtraction borrows nothing across the halves.
-                int best = 0x7fffffff;
+        auto rebase = [&]() {
+            // move the cost base: the best H of the wave goes back to 0 (comparisons are between cells of
+            // the same neighbourhood and do not see a common offset).  E, F >= H in every cell and H >= the
+            // minimum, so the 32-bit subtraction borrows nothing across the halves.
+            int best = 0x7fffffff;
 #pragma unroll
-                for (int m = 0; m < M; ++m)
+            for (int m = 0; m < M; ++m)
 #pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
-                        if (pk_half(vmEv[m], hf)) best = min(best, static_cast<int>(pk_half(Hev[m], hf)));
-                        if (pk_half(vmOd[m], hf)) best = min(best, static_cast<int>(pk_half(Hod[m], hf)));
-                    }
-                best = wave_min(best);
-                const unsigned delta = pk_splat(best < static_cast<int>(PK_INF) ? static_cast<unsigned>(best) : 0u);
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const unsigned de = delta & vmEv[m], dd = delta & vmOd[m];
-                    Hev[m] -= de; Eev[m] -= de; Fev[m] -= de;
-                    Hod[m] -= dd; Eod[m] -= dd; Fod[m] -= dd;
+                for (int hf = 0; hf < 2; ++hf) {
+                    if (pk_half(vmEv[m], hf)) best = min(best, static_cast<int>(pk_half(Hev[m], hf)));
+                    if (pk_half(vmOd[m], hf)) best = min(best, static_cast<int>(pk_half(Hod[m], hf)));
                 }
-            }
-            unsigned rw[NW], cw[NW];
+            best = wave_min(best);
+            const unsigned delta = pk_splat(best < static_cast<int>(PK_INF) ? static_cast<unsigned>(best) : 0u);
 #pragma unroll
-            for (int q = 0; q < NW; ++q) { rw[q] = rnext[q]; cw[q] = cnext[q]; }
-            {   // the next word row's codes are fetched now and used one iteration later
-                const uint8_t *rp, *cp;
-                code_ptrs(w + 1, rp, cp);
-                lds_load_words<NW>(rp, rnext);
-                lds_load_words<NW>(cp, cnext);
+            for (int m = 0; m < M; ++m) {
+                const unsigned de = delta & vmEv[m], dd = delta & vmOd[m];
+                Hev[m] -= de; Eev[m] -= de; Fev[m] -= de;
+                Hod[m] -= dd; Eod[m] -= dd; Fod[m] -= dd;
             }
-            if (w == w0) {
-                const int s0 = x0 & 3;   // step of the row that computes cell (0, 0)
-                subblock_pk(std::integral_constant<int, 0>{}, rw, cw, s0 == 0 ? inj_code : -1, s0 == 1 ? inj_code : -1);
-                subblock_pk(std::integral_constant<int, 1>{}, rw, cw, s0 == 2 ? inj_code : -1, s0 == 3 ? inj_code : -1);
-            } else {
-                subblock_pk(std::integral_constant<int, 0>{}, rw, cw, -1, -1);
-                subblock_pk(std::integral_constant<int, 1>{}, rw, cw, -1, -1);
-            }
+        };
+        // one word row on the code halves (rh, ch) issued one row earlier; those of row w + 1 are issued into (rn, cn)
+        auto row = [&](int w, LdsHalves (&rh)[NW], LdsHalves (&ch)[NW], LdsHalves (&rn)[NW], LdsHalves (&cn)[NW],
+                       int inj0, int inj1, int inj2, int inj3) {
+            unsigned rw[NW], cw[NW];
+            lds_words_ready<NW>(rh, ch, rw, cw);
+            const uint8_t *rp, *cp;
+            code_ptrs(w + 1, rp, cp);
+            lds_issue_words<NW>(rp, rn);
+            lds_issue_words<NW>(cp, cn);
+            subblock_pk(std::integral_constant<int, 0>{}, rw, cw, inj0, inj1);
+            subblock_pk(std::integral_constant<int, 1>{}, rw, cw, inj2, inj3);
             if (!(A.dbg & 4)) {
 #pragma unroll
                 for (int m = 0; m < M; ++m) tile[static_cast<size_t>(w * M + m) * 64 + lane] = acc[m];
             }
+        };
+        LdsHalves ra[NW], ca[NW], rb[NW], cb[NW];   // code words in flight, double buffered
+        {
+            const uint8_t *rp, *cp;
+            code_ptrs(w0, rp, cp);
+            lds_issue_words<NW>(rp, ra);
+            lds_issue_words<NW>(cp, ca);
+        }
+        {
+            const int s0 = x0 & 3;   // step of row w0 that computes cell (0, 0)
+            row(w0, ra, ca, rb, cb, s0 == 0 ? inj_code : -1, s0 == 1 ? inj_code : -1, s0 == 2 ? inj_code : -1, s0 == 3 ? inj_code : -1);
+        }
+        int w = w0 + 1;
+        for (int blk = 0; w + 1 < nwr; w += 2, ++blk) {
+            if ((blk % (PK_REBASE_ROWS / 2)) == PK_REBASE_ROWS / 2 - 1) rebase();
+            row(w, rb, cb, ra, ca, -1, -1, -1, -1);
+            row(w + 1, ra, ca, rb, cb, -1, -1, -1, -1);
+        }
+        if (w < nwr) row(w, rb, cb, ra, ca, -1, -1, -1, -1);
+        {   // the halves issued by the last row are still in flight: drain them before the walk uses the LDS counters
+            unsigned t0[NW], t1[NW];
+            if ((nwr - w0) & 1) lds_words_ready<NW>(rb, cb, t0, t1); else lds_words_ready<NW>(ra, ca, t0, t1);
         }
 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -727,7 +774,8 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
         const size_t word = (!packed && C == 16) ? 8 : 4;
         const size_t spw = C == 4 ? 2 : 1;
         const size_t per_wave = packed ? ((steps + 3) / 4 + 1) * (C / 4) * 64 : (steps / (2 * spw) + 2) * 64;
-        const size_t lds = MSA_WIN * 64 * word + static_cast<size_t>(cls_lc[cls]) + static_cast<size_t>(cls_lr[cls]) + 32;
+        size_t lds = MSA_WIN * 64 * word + static_cast<size_t>(cls_lc[cls]) + static_cast<size_t>(cls_lr[cls]) + 48;
+        if (const char* pad = std::getenv("SARLACC_MSA_LDSPAD")) lds += static_cast<size_t>(std::atoi(pad));   // occupancy experiments
         if (lds > 160 * 1024) return fail("sarlacc_amd: reads of %d bases do not fit the MSA kernel's LDS staging", std::max(cls_lr[cls], cls_lc[cls]));
         // many more single-wave workgroups than fit at once (a wave then aligns only a few pairs and the
         // hardware balances the load); their traceback tiles are the price, capped at 24 GB of HBM

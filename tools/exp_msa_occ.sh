@@ -1,10 +1,7 @@
-# timing experiments of the pairwise MSA kernel (fill only: SARLACC_MSA_DBG=7 skips walk, guard rows, stores)
 cd tools
-for V in "" $EXP_VARIANTS; do
-  if [ -n "$V" ]; then export SARLACC_LIB_PATH=$PWD/../build/exp/libsarlacc_amd_$V.so; else unset SARLACC_LIB_PATH; fi
-  for DBG in 7 1 0; do
-  echo "== variant ${V:-base} dbg $DBG"
-  SARLACC_MSA_DBG=$DBG python - <<'PY'
+for PAD in 0 4000 10000 20000 40000 80000; do
+  echo "== LDS pad $PAD"
+  SARLACC_MSA_LDSPAD=$PAD SARLACC_MSA_DBG=7 python - <<'PY'
 import os, sys
 sys.path.insert(0, "..")
 import numpy as np
@@ -21,7 +18,6 @@ for rep in range(3):
         calls.msa_consensus_flat(goff, gflat, reads, 0, -1, -5, -1, 100, 0.6, quals=quals, encoding=enc)
     except Exception as e:
         pass
-    print("  pairwise: %.2f ms" % _lib.stage_ms("msa_pairwise"), flush=True)
+    if rep: print("  fill only: %.2f ms" % _lib.stage_ms("msa_pairwise"), flush=True)
 PY
-  done
 done
