@@ -54,7 +54,7 @@ static int cmp_lenidx(const void* a, const void* b) {
  * before p; aligned[p] (p<lc) = read position matched to centre p or -1.
  * Insertions are consecutive read positions ending just before the next
  * matched/after position, so only counts are needed plus the walk order. */
-static int pairwise(const char* r, int64_t lr, const char* c, int64_t lc,
+int orc_msa_pairwise(const char* r, int64_t lr, const char* c, int64_t lc,
                     int ma, int mm, int go, int ge, int bw,
                     int32_t* ins_cnt, int64_t* aligned) {
     const int64_t dlo = (lc - lr < 0 ? lc - lr : 0) - bw;
@@ -159,7 +159,7 @@ int orc_msa_group(const char* seq, const int64_t* off, int64_t m,
             for (int64_t p = 0; p < lc; ++p) alg[r * lc + p] = p;
             continue;
         }
-        rc = pairwise(RD(r), LEN(r), RD(ctr), lc, match, mismatch, gapopen, gapext, bandwidth,
+        rc = orc_msa_pairwise(RD(r), LEN(r), RD(ctr), lc, match, mismatch, gapopen, gapext, bandwidth,
                       ins + r * (lc + 1), alg + r * (lc ? lc : 1));
         for (int64_t p = 0; p <= lc; ++p)
             if (ins[r * (lc + 1) + p] > maxins[p]) maxins[p] = ins[r * (lc + 1) + p];

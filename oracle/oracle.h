@@ -134,6 +134,26 @@ int orc_msa_group(const char* seq, const int64_t* off, int64_t nreads,
                   int match, int mismatch, int gapopen, int gapext, int bandwidth,
                   char* out, int64_t cap, int64_t* width);
 
+/* Banded global Gotoh of read r (rows) against centre c (columns), both already Dna5: the pairwise
+ * stage shared by spec v1 and spec v2.  ins_cnt[p] (p <= lc): read characters inserted before centre
+ * position p; aligned[p] (p < lc): read position matched to centre position p, or -1. */
+int orc_msa_pairwise(const char* r, int64_t lr, const char* c, int64_t lc,
+                     int ma, int mm, int go, int ge, int bw, int32_t* ins_cnt, int64_t* aligned);
+
+/* ---- MSA spec v2: T-Coffee as SeqAn's globalMsaAlignment runs it for small
+ * groups, at base resolution -- all-pairs banded global alignments, primary library, full triplet
+ * extension, neighbour-joining guide tree, progressive heaviest-common-subsequence alignment.
+ * PARITY UNPINNED (SeqAn is absent, the reference has no test of quick_msa).  Same interface as
+ * orc_msa_group. */
+int orc_msa2_group(const char* seq, const int64_t* off, int64_t nreads,
+                   int match, int mismatch, int gapopen, int gapext, int bandwidth,
+                   char* out, int64_t cap, int64_t* width);
+/* Inspection hooks for the tests: the guide tree (joins[2*k], joins[2*k+1] = node ids merged by join k;
+ * leaves 0..n-1, join k creates node n+k) and the pairwise distances (n*n doubles). */
+int orc_msa2_tree(const char* seq, const int64_t* off, int64_t nreads,
+                  int match, int mismatch, int gapopen, int gapext, int bandwidth,
+                  int32_t* joins, double* dist);
+
 #ifdef __cplusplus
 }
 #endif

@@ -315,10 +315,23 @@ def create_consensus_quality_loop(aln_list, min_cov, qual_list, encoding):
     return cons, quals
 
 
-def quick_msa(groupings, sequences, match, mismatch, gap_extension, gap_opening, bandwidth):
+def msa2_tree(reads, match, mismatch, gap_extension, gap_opening, bandwidth):
+    """Guide tree and distances of spec v2 for one group: (joins int32[n-1, 2], dist float64[n, n])."""
+    sb, so = pack(reads)
+    n = len(reads)
+    joins = np.zeros((max(n - 1, 1), 2), np.int32)
+    dist = np.zeros((n, n), np.float64)
+    _check(lib().orc_msa2_tree(_p(sb), _p(so), C.c_int64(n), int(match), int(mismatch), int(gap_opening),
+                               int(gap_extension), int(bandwidth), _p(joins), _p(dist)))
+    return joins[:max(n - 1, 0)], dist
+
+
+def quick_msa(groupings, sequences, match, mismatch, gap_extension, gap_opening, bandwidth, spec=2, tcoffee_max=32):
     """Same argument order as the reference .Call (src/quick_msa.cpp:15): note that
     the R caller passes (-gapOpening, -gapExtension) into (gap_extension, gap_opening)
-    (R/multiReadAlign.R:47, SURVEY App.B Q15)."""
+    (R/multiReadAlign.R:47, SURVEY App.B Q15).  spec 2 (default): consistency-based progressive
+    alignment (msa2.c) for groups of up to `tcoffee_max` reads, spec 1 (centre-star, msa.c) beyond
+    that and when spec == 1 -- the same policy as the product."""
     out = []
     for g in groupings:
         reads = [sequences[i - 1] for i in g]
@@ -330,8 +343,9 @@ def quick_msa(groupings, sequences, match, mismatch, gap_extension, gap_opening,
         cap = m * (int(so[-1]) + 16) + 16
         buf = np.zeros(cap, np.uint8)
         width = C.c_int64()
-        _check(lib().orc_msa_group(_p(sb), _p(so), C.c_int64(m), int(match), int(mismatch), int(gap_opening),
-                                   int(gap_extension), int(bandwidth), _p(buf), C.c_int64(cap), C.byref(width)))
+        fn = lib().orc_msa2_group if (spec == 2 and m <= tcoffee_max) else lib().orc_msa_group
+        _check(fn(_p(sb), _p(so), C.c_int64(m), int(match), int(mismatch), int(gap_opening),
+                  int(gap_extension), int(bandwidth), _p(buf), C.c_int64(cap), C.byref(width)))
         W = width.value
         out.append([buf[r * W:(r + 1) * W].tobytes().decode() for r in range(m)])
     return out
