@@ -47,10 +47,11 @@ int sarlacc_set_device(int device);
 /* Release cached device workspaces. */
 void sarlacc_release_workspace(void);
 /* Duration in ms of a named group of kernel launches of the last call that ran it (HIP events on
- * the launch stream): "msa_pairwise", "msa_merge", "consensus", "umi_pairs"; <0 if it never ran. */
+ * the launch stream, summed over the batches of the call): "msa_pairwise", "msa_merge", "consensus", "umi_pairs";
+ * <0 if it never ran. */
 double sarlacc_stage_ms(const char* name);
 /* Work counters of the last call that set them (for rooflines): "msa_pairs", "msa_cells" (banded DP
- * cells of the pairwise alignments), "consensus_cells" (rows x width), "consensus_columns"; <0 if unset. */
+ * cells of the pairwise alignments), "consensus_cells" (rows x width); <0 if unset. */
 double sarlacc_stage_count(const char* name);
 /* Duration in ms of the DP kernel launches recorded by the last
  * sarlacc_dev_* align call (HIP events on the launch stream); <0 if none. */
@@ -224,6 +225,13 @@ int sarlacc_umi_group_from_pairs(const char* umi, const int64_t* off, int64_t n,
 
 /* ------------------------------------------------------------------ */
 /* per-group MSA and consensus                                           */
+
+/* Which written specification the MSA stage follows (the reference delegates to SeqAn's
+ * T-Coffee, which cannot be run or pinned here): 2 (default) = consistency-based progressive alignment --
+ * all-pairs banded alignments, primary library, triplet extension, neighbour-joining guide tree, progressive
+ * heaviest-common-subsequence merging -- for groups of up to 32 reads, 1 = centre-star (also used by spec 2 for
+ * larger groups and for reads beyond 32 735 bases).  0 restores the default (or SARLACC_MSA_SPEC). */
+int sarlacc_set_msa_spec(int spec);
 
 /* replaces .Call quick_msa  (src/quick_msa.cpp:15-80); argument order as there
  * (the R caller passes -gapOpening as gap_extension and -gapExtension as

@@ -35,6 +35,7 @@
 #include "oracle.h"
 
 #include <limits.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -304,6 +305,19 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
         for (int64_t j = 0; j < nB; ++j)
             if (bestAt[j] >= 0 && BETTER(bestAt[j], tail)) tail = bestAt[j];
 #undef BETTER
+        if (getenv("ORC_MSA2_DEBUG")) {
+            fprintf(stderr, "ORC round %d: join %d %d nA %d nB %d\n", (int)k, joins[2 * k], joins[2 * k + 1], (int)nA, (int)nB);
+            int64_t* pdbg = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nA ? nA : 1));
+            for (int64_t i = 0; i < nA; ++i) pdbg[i] = -1;
+            for (int64_t m = tail; m >= 0; m = pred[m]) pdbg[mi[m]] = mj[m];
+            int64_t m = 0;
+            for (int64_t i = 0; i < nA; ++i) {
+                fprintf(stderr, "  row %d part %d :", (int)i, (int)pdbg[i]);
+                for (; m < nm && mi[m] == i; ++m) fprintf(stderr, " (%d w %d f %d)", (int)mj[m], (int)mw[m], (int)f[m]);
+                fprintf(stderr, "\n");
+            }
+            free(pdbg);
+        }
         /* matched column pairs, ascending */
         int64_t* pa = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nA ? nA : 1));   /* partner column in B of column i of A, or -1 */
         for (int64_t i = 0; i < nA; ++i) pa[i] = -1;

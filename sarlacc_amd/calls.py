@@ -317,6 +317,11 @@ def csr_select(off, vals, keep):
     return noff, vals[np.repeat(keep, sizes)]
 
 
+def set_msa_spec(spec):
+    """sarlacc_set_msa_spec: 2 = consistency-based progressive alignment (default), 1 = centre-star, 0 = default."""
+    check(_lib.lib().sarlacc_set_msa_spec(int(spec)))
+
+
 def quick_msa(groupings, sequences, match, mismatch, gapExtension, gapOpening, bandwidth):
     """.Call quick_msa (src/quick_msa.cpp:15-80), same argument order (the R caller passes
     -gapOpening as gapExtension and -gapExtension as gapOpening, R/multiReadAlign.R:47).

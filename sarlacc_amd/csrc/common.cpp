@@ -66,22 +66,31 @@ int Context::buffer(const char* name, size_t bytes, void** out) {
     return 0;
 }
 
+void Context::stage_reset(const char* name) {
+    StageTimer& t = stages[name];
+    t.used = 0;
+    t.open = false;
+}
+
 int Context::stage_begin(const char* name, hipStream_t s) {
     StageTimer& t = stages[name];
-    if (!t.a) {
-        SL_HIP(hipEventCreate(&t.a));
-        SL_HIP(hipEventCreate(&t.b));
+    if (t.used == t.segs.size()) {
+        hipEvent_t a, b;
+        SL_HIP(hipEventCreate(&a));
+        SL_HIP(hipEventCreate(&b));
+        t.segs.emplace_back(a, b);
     }
-    t.armed = false;
-    SL_HIP(hipEventRecord(t.a, s));
+    SL_HIP(hipEventRecord(t.segs[t.used].first, s));
+    t.open = true;
     return 0;
 }
 
 int Context::stage_end(const char* name, hipStream_t s) {
     StageTimer& t = stages[name];
-    if (!t.a) return fail("sarlacc_amd: stage timer '%s' was never started", name);
-    SL_HIP(hipEventRecord(t.b, s));
-    t.armed = true;
+    if (!t.open) return fail("sarlacc_amd: stage timer '%s' was never started", name);
+    SL_HIP(hipEventRecord(t.segs[t.used].second, s));
+    ++t.used;
+    t.open = false;
     return 0;
 }
 
@@ -119,10 +128,11 @@ int sarlacc_set_device(int device) {
     sarlacc::Context& c = sarlacc::ctx();
     if (c.ready && c.device != device) {
         c.release();
-        for (auto& kv : c.stages) {   // events belong to the device they were created on
-            if (kv.second.a) (void)hipEventDestroy(kv.second.a);
-            if (kv.second.b) (void)hipEventDestroy(kv.second.b);
-        }
+        for (auto& kv : c.stages)   // events belong to the device they were created on
+            for (auto& seg : kv.second.segs) {
+                (void)hipEventDestroy(seg.first);
+                (void)hipEventDestroy(seg.second);
+            }
         c.stages.clear();
         c.ready = false;
     }
@@ -136,11 +146,15 @@ double sarlacc_stage_ms(const char* name) {
     sarlacc::Context& c = sarlacc::ctx();
     if (!c.ready || !name) return -1.0;
     auto it = c.stages.find(name);
-    if (it == c.stages.end() || !it->second.armed) return -1.0;
-    if (hipEventSynchronize(it->second.b) != hipSuccess) return -1.0;
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, it->second.a, it->second.b) != hipSuccess) return -1.0;
-    return ms;
+    if (it == c.stages.end() || it->second.used == 0) return -1.0;
+    double total = 0;
+    for (size_t k = 0; k < it->second.used; ++k) {
+        if (hipEventSynchronize(it->second.segs[k].second) != hipSuccess) return -1.0;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, it->second.segs[k].first, it->second.segs[k].second) != hipSuccess) return -1.0;
+        total += ms;
+    }
+    return total;
 }
 
 double sarlacc_stage_count(const char* name) {

@@ -49,9 +49,11 @@ struct Context {
     bool timed = false;
     std::map<std::string, Workspace> ws;
     // named stage timers (HIP events on the launch stream; read back by sarlacc_stage_ms)
-    struct StageTimer { hipEvent_t a = nullptr, b = nullptr; bool armed = false; };
+    // A stage may run in several segments (batches); sarlacc_stage_ms adds them up.  stage_reset starts a new call.
+    struct StageTimer { std::vector<std::pair<hipEvent_t, hipEvent_t>> segs; size_t used = 0; bool open = false; };
     std::map<std::string, StageTimer> stages;
     std::map<std::string, double> counts;   // work counters of the last call (cells, jobs ...), sarlacc_stage_count
+    void stage_reset(const char* name);
     int stage_begin(const char* name, hipStream_t s);
     int stage_end(const char* name, hipStream_t s);
 
@@ -96,6 +98,12 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
             int64_t nseq, double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
             bool want_rows, int64_t out_cap, MsaResult* res, const std::function<int()>* overlap = nullptr,
             const uint8_t* d_seq_resident = nullptr);
+// spec v1 (centre-star, msa.hip) with the same interface; msa_run (msa2.hip) applies spec v2 and hands the
+// groups v2 does not take to it
+int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq, const int64_t* seq_off,
+             int64_t nseq, double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
+             bool want_rows, int64_t out_cap, MsaResult* res, const std::function<int()>* overlap = nullptr,
+             const uint8_t* d_seq_resident = nullptr);
 
 // ---- quality encoding (reference src/quality_encoding.cpp:5-33) -------------
 int check_encoding(const double* errors, const char* names, int n);

@@ -548,6 +548,7 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         const bool q4 = quality && !lerr && lds4 <= 48 * 1024 && !std::getenv("SARLACC_CONSENSUS_NARROW");
         SL_HIP(hipEventRecord(c.ev_start, s));
         c.counts["consensus_cells"] = static_cast<double>(total);
+        c.stage_reset("consensus");
         SL_TRY(c.stage_begin("consensus", s));
         if (q4) {
             const int grid4 = static_cast<int>(std::min<int64_t>((ng_eval + 3) / 4, static_cast<int64_t>(c.num_cu) * 64));

@@ -148,7 +148,7 @@ __global__ void k_msa_write(MergeArgs A, const long long* row_group, const int* 
 // which copies them back, and sarlacc_msa_consensus, which votes on them where they are.
 // out_cap: < 0 no limit; otherwise the rows are only written when they fit (sizing protocol of
 // sarlacc_quick_msa: widths and offsets are always filled in).
-int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq, const int64_t* seq_off,
+int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq, const int64_t* seq_off,
             int64_t nseq, double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
             bool want_rows, int64_t out_cap, MsaResult* res, const std::function<int()>* overlap,
             const uint8_t* d_seq_resident) {
@@ -244,6 +244,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         c.counts["msa_pairs"] = static_cast<double>(jobs.size());
         c.counts["msa_cells"] = cells;
         SL_HIP(hipEventRecord(c.ev_start, s));
+        c.stage_reset("msa_pairwise");
         SL_TRY(c.stage_begin("msa_pairwise", s));
         SL_TRY(msa_pairwise_launch(jobs, d_jobs, d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, 0, d_ins, d_aln,
                                    nullptr, nullptr, nullptr, s));
@@ -257,7 +258,8 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     MergeArgs m{};
     m.seq = d_seq; m.seq_off = d_soff; m.members = d_mem; m.groups = d_groups; m.jobs = d_jobs; m.ngroups = ngroups;
     m.ins = d_ins; m.aln = d_aln; m.maxins = d_maxins; m.mi_off = d_mioff; m.width = d_width;
-    SL_TRY(c.stage_begin("msa_merge", s));
+    c.stage_reset("msa_merge");
+        SL_TRY(c.stage_begin("msa_merge", s));
     hipLaunchKernelGGL(k_msa_width, dim3(static_cast<unsigned>(ngroups)), dim3(256), 0, s, m);
     SL_HIP(hipGetLastError());
     std::vector<int32_t> width(static_cast<size_t>(ngroups));

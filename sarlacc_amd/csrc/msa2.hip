@@ -1,0 +1,1037 @@
+// msa2.hip -- per-group multiple sequence alignment, "MSA spec v2" (DESIGN.md section 5), on gfx950.
+//
+// Stands in for the reference's quick_msa (/root/reference/src/quick_msa.cpp:15-80), which hands each
+// group to SeqAn's T-Coffee (globalMsaAlignment, :66).  Spec v2 is that pipeline restated at base
+// resolution (checker: oracle/msa2.c, where every step is written down with the SeqAn routine it
+// follows): all-pairs banded global alignments -> distances -> neighbour-joining guide tree ->
+// primary library + full triplet extension -> progressive merging of profiles by the heaviest common
+// subsequence of their columns.  PARITY UNPINNED (SeqAn is absent from the reference tree and the
+// image, the reference has no test of quick_msa).
+//
+// Data per batch of groups (all in HBM):
+//   map   uint16  for every ordered pair (a, b) of a group: position of b aligned to position p of a
+//                 (0xFFFF = gap) -- both directions of every pairwise alignment, written by the walk of
+//                 msa_pairwise.hip (OUT 1);
+//   col   int32   column of every base in the profile that currently holds its read;
+//   pos   uint16  per group n x wcap: position of read a at column c of its profile (0xFFFF = gap);
+//   rows  per profile column of the first child of a merge: up to `cap` (partner column, weight) entries.
+// Kernels, per merge round k (every group performs its k-th join in the same launches):
+//   k_m2_gather  lane = column i of the first child; walks the library (map -> map -> col) for every
+//                member pair and third sequence, sums the weights per partner column in a private list
+//                (LDS), writes the list sorted by column;
+//   k_m2_chain   one wavefront per group: heaviest chain over the lists in row order with a Fenwick tree
+//                of prefix maxima in LDS (16 lanes read / update the <= 16 nodes of one match in one
+//                instruction), then the traceback through the stored predecessors;
+//   k_m2_merge   one workgroup per group: new column numbers (first child's unmatched columns before the
+//                second child's between two matched pairs), col / pos of every member updated.
+// Groups whose lists or profiles outgrow the fast capacities are redone with exact worst-case capacities.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+
+#include "msa_common.hpp"
+
+#include "../../include/sarlacc_amd.h"
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+namespace sarlacc {
+
+constexpr int M2_MAXN = 32;          // group sizes aligned by spec v2 (member sets are 32-bit masks)
+constexpr int M2_CAP = 16;           // partner columns per row on the fast path (private lists in LDS)
+constexpr int M2_STAGE = 4;          // entries per row staged in LDS by the chain kernel
+constexpr unsigned M2_NONE = 0xFFFFu;
+
+struct M2Member {         // one read of a group
+    long long seq_off;    // into d_seq
+    long long map_base;   // into d_map: (n - 1) arrays of `len` entries, the other members in member order
+    long long col_base;   // into d_col
+    int len;
+    int pad;
+};
+struct M2Group {
+    int first_member;     // member a of the group is members[first_member + a]; joins at first_member + k,
+                          // tree nodes (leaves 0..n-1, join k creates n + k) at 2 * first_member + node
+    int n;
+    int wcap;             // capacity of a profile in columns
+    int cap;              // entries per row list
+    long long row_base;   // into the per-column arrays (lists, partners, renumbering): wcap entries
+    long long pos_base;   // into d_pos: n * wcap
+    long long first_job;  // pairwise job of (a, b), a < b: first_job + a n - a (a + 1) / 2 + b - a - 1
+    long long dist_base;  // into the tree kernel's scratch: n * n + n doubles
+    long long out_off;    // the group's rows in the row buffer
+};
+
+struct M2Args {
+    const uint8_t* seq;
+    const M2Group* groups;
+    const M2Member* members;
+    int ngroups;
+    int ma, mm;
+    const uint16_t* map;
+    const int2* stats;
+    double* dist;
+    int2* joins;
+    uint32_t* nodemask;
+    int* ncols;
+    int* col;
+    uint16_t* pos;
+    uint16_t* row_cnt;             // entries in a row's list
+    unsigned long long* row_ent;   // (partner column << 32) | weight, later | predecessor id
+    int* part;                     // partner column of column i of the first child, -1 if unmatched
+    int* ovf;                      // per group: a capacity was exceeded
+    int32_t* width;                // per group: columns of the final profile
+    uint8_t* out;                  // gapped rows
+};
+
+__device__ __forceinline__ int m2_w0(int x, int y, int ma, int mm) {
+    const int s = (x == y) ? ma : mm;
+    return s > 1 ? s : 1;
+}
+
+// ---- guide tree: one thread per group (oracle/msa2.c nj_tree, operation for operation) ----
+__global__ void k_m2_tree(M2Args A) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= A.ngroups) return;
+    const M2Group G = A.groups[g];
+    const int n = G.n;
+    const int fm = G.first_member;
+    for (int a = 0; a < n; ++a) {
+        A.nodemask[2 * fm + a] = 1u << a;
+        A.ncols[2 * fm + a] = A.members[fm + a].len;
+    }
+    if (n < 2) return;
+    double* D = A.dist + G.dist_base;
+    double* R = D + static_cast<long long>(n) * n;
+    for (int a = 0; a < n; ++a) {
+        D[a * n + a] = 0.0;
+        for (int b = a + 1; b < n; ++b) {
+            const int2 st = A.stats[G.first_job + static_cast<long long>(a) * n - static_cast<long long>(a) * (a + 1) / 2 + b - a - 1];
+            const long long alen = static_cast<long long>(A.members[fm + a].len) + A.members[fm + b].len - st.y;
+            const double d = alen > 0 ? 1.0 - static_cast<double>(st.x) / static_cast<double>(alen) : 0.0;
+            D[a * n + b] = d;
+            D[b * n + a] = d;
+        }
+    }
+    unsigned active = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+    int node[M2_MAXN];
+    for (int i = 0; i < n; ++i) node[i] = i;
+    int r = n, nj = 0;
+    while (r > 3) {
+        for (int i = 0; i < n; ++i) {
+            if (!((active >> i) & 1u)) continue;
+            double sum = 0.0;
+            for (int k = 0; k < n; ++k)
+                if (((active >> k) & 1u) && k != i) sum = sum + D[i * n + k];
+            R[i] = sum;
+        }
+        int bi = -1, bj = -1;
+        double best = 0.0;
+        const double rm2 = static_cast<double>(r - 2);
+        for (int i = 0; i < n; ++i) {
+            if (!((active >> i) & 1u)) continue;
+            for (int j = i + 1; j < n; ++j) {
+                if (!((active >> j) & 1u)) continue;
+                const double q = (rm2 * D[i * n + j] - R[i]) - R[j];
+                if (bi < 0 || q < best) { best = q; bi = i; bj = j; }
+            }
+        }
+        A.joins[fm + nj] = make_int2(node[bi], node[bj]);
+        const double dij = D[bi * n + bj];
+        for (int k = 0; k < n; ++k) {
+            if (!((active >> k) & 1u) || k == bi || k == bj) continue;
+            const double v = ((D[bi * n + k] + D[bj * n + k]) - dij) * 0.5;
+            D[bi * n + k] = v;
+            D[k * n + bi] = v;
+        }
+        active &= ~(1u << bj);
+        node[bi] = n + nj;
+        ++nj; --r;
+    }
+    int l[3], c = 0;
+    for (int i = 0; i < n && c < 3; ++i)
+        if ((active >> i) & 1u) l[c++] = i;
+    if (c >= 2) {
+        A.joins[fm + nj] = make_int2(node[l[0]], node[l[1]]);
+        node[l[0]] = n + nj;
+        ++nj;
+    }
+    if (c == 3) A.joins[fm + nj] = make_int2(node[l[0]], node[l[2]]);
+}
+
+// ---- leaves: col = position, pos = identity ----
+__global__ void k_m2_init(M2Args A, const int* member_group, int nmembers) {
+    const int m = blockIdx.y;
+    if (m >= nmembers) return;
+    const M2Group G = A.groups[member_group[m]];
+    const M2Member Me = A.members[m];
+    const int a = m - G.first_member;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < Me.len; p += gridDim.x * blockDim.x) {
+        A.col[Me.col_base + p] = p;
+        A.pos[G.pos_base + static_cast<long long>(a) * G.wcap + p] = static_cast<uint16_t>(p);
+    }
+}
+
+// ---- match lists of one merge round ----
+// LDSLIST: private lists of M2_CAP entries in LDS (fast path); otherwise the lists are built in place in
+// row_ent with the group's own capacity (exact redo of groups that overflowed).
+template <bool UNITW, bool LDSLIST>
+__global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
+    __shared__ unsigned long long s_ent[LDSLIST ? M2_CAP : 1][64];
+    const int g = blockIdx.y;
+    const M2Group G = A.groups[g];
+    if (round >= G.n - 1) return;
+    const int n = G.n, fm = G.first_member;
+    const int2 jn = A.joins[fm + round];
+    const unsigned maskA = A.nodemask[2 * fm + jn.x], maskB = A.nodemask[2 * fm + jn.y];
+    const int nA = A.ncols[2 * fm + jn.x];
+    if (blockIdx.x * 64 >= nA) return;
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * 64 + lane;
+    const int cap = LDSLIST ? M2_CAP : G.cap;
+    unsigned long long* const mine = A.row_ent + (G.row_base + i) * static_cast<long long>(G.cap);
+    int cnt = 0;
+    bool over = false;
+    auto ent_get = [&](int k) -> unsigned long long { return LDSLIST ? s_ent[LDSLIST ? k : 0][lane] : mine[k]; };
+    auto ent_set = [&](int k, unsigned long long v) { if (LDSLIST) s_ent[LDSLIST ? k : 0][lane] = v; else mine[k] = v; };
+    auto add = [&](int j, int w) {
+        for (int k = 0; k < cnt; ++k) {
+            const unsigned long long e = ent_get(k);
+            if (static_cast<int>(e >> 32) == j) { ent_set(k, e + static_cast<unsigned>(w)); return; }
+        }
+        if (cnt < cap) ent_set(cnt++, (static_cast<unsigned long long>(static_cast<unsigned>(j)) << 32) | static_cast<unsigned>(w));
+        else over = true;
+    };
+    if (i < nA) {
+        for (int a = 0; a < n; ++a) {
+            if (!((maskA >> a) & 1u)) continue;
+            const unsigned p = A.pos[G.pos_base + static_cast<long long>(a) * G.wcap + i];
+            if (p == M2_NONE) continue;
+            const M2Member Ma = A.members[fm + a];
+            const int xa = UNITW ? 0 : dna5_code(A.seq[Ma.seq_off + p]);
+            for (int c = 0; c < n; ++c) {
+                if (c == a) continue;
+                const unsigned r = A.map[Ma.map_base + static_cast<long long>(c < a ? c : c - 1) * Ma.len + p];
+                if (r == M2_NONE) continue;
+                const M2Member Mc = A.members[fm + c];
+                const int xc = UNITW ? 0 : dna5_code(A.seq[Mc.seq_off + r]);
+                const int wac = UNITW ? 1 : m2_w0(xa, xc, A.ma, A.mm);
+                if ((maskB >> c) & 1u) add(A.col[Mc.col_base + r], wac);   // the direct edge a - c
+                for (int b = 0; b < n; ++b) {
+                    if (!((maskB >> b) & 1u) || b == c) continue;
+                    const unsigned q = A.map[Mc.map_base + static_cast<long long>(b < c ? b : b - 1) * Mc.len + r];
+                    if (q == M2_NONE) continue;
+                    const M2Member Mb = A.members[fm + b];
+                    int w = 1;
+                    if (!UNITW) {
+                        const int wcb = m2_w0(xc, dna5_code(A.seq[Mb.seq_off + q]), A.ma, A.mm);
+                        w = wac < wcb ? wac : wcb;
+                    }
+                    add(A.col[Mb.col_base + q], w);                         // a - c - b
+                }
+            }
+        }
+        // sort by column (insertion sort; the lists are short)
+        for (int k = 1; k < cnt; ++k) {
+            const unsigned long long e = ent_get(k);
+            int q = k - 1;
+            while (q >= 0 && (ent_get(q) >> 32) > (e >> 32)) { ent_set(q + 1, ent_get(q)); --q; }
+            ent_set(q + 1, e);
+        }
+        A.row_cnt[G.row_base + i] = static_cast<uint16_t>(cnt);
+        if (LDSLIST)
+            for (int k = 0; k < cnt; ++k) mine[k] = s_ent[LDSLIST ? k : 0][lane];
+        if (over) A.ovf[g] = 1;
+    }
+}
+
+// ---- heaviest chain of one merge round: one wavefront per group ----
+// Fenwick tree over the second child's columns in LDS: node = (f << 32) | ~id, so that the maximum prefers
+// the larger f and then the earlier match (id = row * cap + index in the row + 1; 0 = no match).  A match
+// with column j reads the prefix maximum of nodes j, j - lowbit(j), .. (columns < j) and afterwards raises
+// nodes j + 1, (j + 1) + lowbit, ..; sub-groups of 16 lanes serve one match each, one node per lane.  All
+// matches of a row are queried before any of them is entered.
+__device__ __forceinline__ unsigned long long m2_rowmax16(unsigned long long v) {
+    // maximum over the 16 lanes of a DPP row, delivered to every lane of the row (row_ror 8, 4, 2, 1)
+#define M2_STEP(CTRL)                                                                                                         \
+    {                                                                                                                         \
+        const unsigned lo = static_cast<unsigned>(v), hi = static_cast<unsigned>(v >> 32);                                    \
+        const unsigned olo = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(lo), CTRL, 0xf, 0xf, false)); \
+        const unsigned ohi = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(hi), CTRL, 0xf, 0xf, false)); \
+        const unsigned long long o = (static_cast<unsigned long long>(ohi) << 32) | olo;                                      \
+        v = o > v ? o : v;                                                                                                    \
+    }
+    M2_STEP(0x128) M2_STEP(0x124) M2_STEP(0x122) M2_STEP(0x121)
+#undef M2_STEP
+    return v;
+}
+
+struct M2ChainTmp {   // (column, new node value) of the matches of one row between the query and the update pass
+    int* j;
+    unsigned long long* nv;
+};
+
+__global__ void __launch_bounds__(64) k_m2_chain(M2Args A, int round, int* tmp_j, unsigned long long* tmp_nv, const long long* tmp_base) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int g = blockIdx.x;
+    const M2Group G = A.groups[g];
+    if (round >= G.n - 1) return;
+    const int fm = G.first_member;
+    const int2 jn = A.joins[fm + round];
+    const int nA = A.ncols[2 * fm + jn.x], nB = A.ncols[2 * fm + jn.y];
+    const int lane = threadIdx.x;
+    const int cap = G.cap;
+    unsigned long long* const s_stage = reinterpret_cast<unsigned long long*>(smem);            // [64][M2_STAGE]
+    unsigned long long* const s_nv = s_stage + 64 * M2_STAGE;                                     // [M2_CAP]
+    int* const s_j = reinterpret_cast<int*>(s_nv + M2_CAP);                                      // [M2_CAP]
+    int* const s_cnt = s_j + M2_CAP;                                                             // [64]
+    unsigned long long* const bit = reinterpret_cast<unsigned long long*>(s_cnt + 64);            // [nB + 1]
+    for (int x = lane; x <= nB; x += 64) bit[x] = 0;
+    for (int i = lane; i < nA; i += 64) A.part[G.row_base + i] = -1;
+    unsigned long long* const ent = A.row_ent + G.row_base * static_cast<long long>(cap);
+    int* const gj = tmp_j ? tmp_j + tmp_base[g] : nullptr;                   // rows longer than M2_CAP (exact redo only)
+    unsigned long long* const gnv = tmp_nv ? tmp_nv + tmp_base[g] : nullptr;
+    const int sub = lane >> 4, t = lane & 15;   // 4 sub-groups of 16 lanes: one match each
+    const unsigned nBu = static_cast<unsigned>(nB);
+    unsigned long long best = 0;                // per sub-group running maximum (the chain's last match)
+    __syncthreads();
+    for (int i0 = 0; i0 < nA; i0 += 64) {
+        // stage the counts and the first M2_STAGE entries of 64 rows
+        __syncthreads();
+        s_cnt[lane] = (i0 + lane < nA) ? static_cast<int>(A.row_cnt[G.row_base + i0 + lane]) : 0;
+        __syncthreads();
+        for (int idx = lane; idx < 64 * M2_STAGE; idx += 64) {
+            const int r = idx / M2_STAGE, k = idx % M2_STAGE;
+            if (k < s_cnt[r]) s_stage[idx] = ent[static_cast<long long>(i0 + r) * cap + k];
+        }
+        __syncthreads();
+        const int rows = min(64, nA - i0);
+        for (int r = 0; r < rows; ++r) {
+            const int c = min(__builtin_amdgcn_readfirstlane(s_cnt[r]), cap);
+            if (c == 0) continue;
+            const int i = i0 + r;
+            for (int k0 = 0; k0 < c; k0 += 4) {          // queries
+                const int k = k0 + sub;
+                const bool act = k < c;
+                unsigned long long e = 0;
+                if (act) e = k < M2_STAGE ? s_stage[r * M2_STAGE + k] : ent[static_cast<long long>(i) * cap + k];
+                const int j = static_cast<int>(e >> 32);
+                unsigned x = act ? static_cast<unsigned>(j) : 0u;
+#pragma unroll
+                for (int s = 0; s < 15; ++s) x = (s < t) ? (x & (x - 1u)) : x;
+                unsigned long long v = x ? bit[x] : 0ull;
+                v = m2_rowmax16(v);
+                const unsigned f = static_cast<unsigned>(e) + static_cast<unsigned>(v >> 32);
+                const unsigned pred = v ? ~static_cast<unsigned>(v) : 0u;
+                const unsigned id = static_cast<unsigned>(i) * static_cast<unsigned>(cap) + static_cast<unsigned>(k) + 1u;
+                const unsigned long long nv = (static_cast<unsigned long long>(f) << 32) | static_cast<unsigned>(~id);
+                if (act) {
+                    best = nv > best ? nv : best;
+                    if (t == 0) {
+                        ent[static_cast<long long>(i) * cap + k] = (e & 0xffffffff00000000ull) | pred;
+                        if (k < M2_CAP) { s_j[k] = j; s_nv[k] = nv; }
+                        else { gj[k] = j; gnv[k] = nv; }
+                    }
+                }
+            }
+            if (c > M2_CAP) __threadfence();
+            __syncthreads();
+            for (int k0 = 0; k0 < c; k0 += 4) {          // updates
+                const int k = k0 + sub;
+                if (k < c) {
+                    const int j = k < M2_CAP ? s_j[k] : gj[k];
+                    const unsigned long long nv = k < M2_CAP ? s_nv[k] : gnv[k];
+                    unsigned y = static_cast<unsigned>(j) + 1u;
+#pragma unroll
+                    for (int s = 0; s < 15; ++s) y = (s < t && y <= nBu) ? y + (y & (0u - y)) : y;
+                    if (y <= nBu) atomicMax(&bit[y], nv);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // the chain's last match: maximum over the four sub-groups
+    {
+        const unsigned long long o1 = (static_cast<unsigned long long>(static_cast<unsigned>(__shfl_xor(static_cast<int>(best >> 32), 16))) << 32) |
+                                      static_cast<unsigned>(__shfl_xor(static_cast<int>(best), 16));
+        best = o1 > best ? o1 : best;
+        const unsigned long long o2 = (static_cast<unsigned long long>(static_cast<unsigned>(__shfl_xor(static_cast<int>(best >> 32), 32))) << 32) |
+                                      static_cast<unsigned>(__shfl_xor(static_cast<int>(best), 32));
+        best = o2 > best ? o2 : best;
+    }
+    best = (static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(best >> 32)))) << 32) |
+           static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(best)));
+    // traceback through the stored predecessors, 64 rows staged at a time
+    __threadfence();
+    unsigned id = best ? ~static_cast<unsigned>(best) : 0u;
+    int steps = 2 * nA + 64;   // a chain has at most one match per row; staging a block also counts one step
+    while (id && --steps >= 0) {
+        const int itop = static_cast<int>((id - 1u) / static_cast<unsigned>(cap));
+        const int i0 = max(0, itop - 63);
+        __syncthreads();
+        s_cnt[lane] = (i0 + lane <= itop) ? static_cast<int>(A.row_cnt[G.row_base + i0 + lane]) : 0;
+        __syncthreads();
+        for (int idx = lane; idx < 64 * M2_STAGE; idx += 64) {
+            const int r = idx / M2_STAGE, k = idx % M2_STAGE;
+            if (k < s_cnt[r]) s_stage[idx] = ent[static_cast<long long>(i0 + r) * cap + k];
+        }
+        __syncthreads();
+        while (id && --steps >= 0) {
+            const int i = static_cast<int>((id - 1u) / static_cast<unsigned>(cap)), k = static_cast<int>((id - 1u) % static_cast<unsigned>(cap));
+            if (i < i0) break;
+            unsigned long long e = k < M2_STAGE ? s_stage[(i - i0) * M2_STAGE + k] : ent[static_cast<long long>(i) * cap + k];
+            e = (static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(e >> 32)))) << 32) |
+                static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(e)));
+            if (lane == 0) A.part[G.row_base + i] = static_cast<int>(e >> 32);
+            id = static_cast<unsigned>(e);
+        }
+    }
+}
+
+// ---- wave helpers for the renumbering (performance is irrelevant here) ----
+__device__ __forceinline__ int m2_excl_max(int v, int identity) {   // exclusive prefix maximum over the lanes
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(x, d);
+        if (static_cast<int>(threadIdx.x & 63) >= d) x = max(x, o);
+    }
+    const int e = __shfl_up(x, 1);
+    return (threadIdx.x & 63) == 0 ? identity : e;
+}
+__device__ __forceinline__ int m2_suffix_min_incl(int v) {          // inclusive suffix minimum over the lanes
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_down(x, d);
+        if (static_cast<int>(threadIdx.x & 63) + d < 64) x = min(x, o);
+    }
+    return x;
+}
+
+// ---- new column numbers, col / pos of every member: one workgroup of 256 threads per group ----
+__global__ void __launch_bounds__(256) k_m2_merge(M2Args A, int round, int* ncA, int* ncB, int* partB) {
+    const int g = blockIdx.x;
+    const M2Group G = A.groups[g];
+    if (round >= G.n - 1) return;
+    const int n = G.n, fm = G.first_member;
+    const int2 jn = A.joins[fm + round];
+    const unsigned maskA = A.nodemask[2 * fm + jn.x], maskB = A.nodemask[2 * fm + jn.y];
+    const int nA = A.ncols[2 * fm + jn.x], nB = A.ncols[2 * fm + jn.y];
+    const int* part = A.part + G.row_base;
+    int* const nca = ncA + G.row_base;
+    int* const ncb = ncB + G.row_base;
+    int* const pb = partB + G.row_base;
+    __shared__ int s_newW;
+    const int lane = threadIdx.x & 63;
+    // partner rows of the second child's columns
+    for (int j = threadIdx.x; j < nB; j += blockDim.x) pb[j] = -1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nA; i += blockDim.x) {
+        const int pj = part[i];
+        if (pj >= 0) pb[pj] = i;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        // first child: column i -> i + (columns of the second child up to the previous matched partner) - matches before
+        int jprev = -1, t0 = 0;
+        for (int i0 = 0; i0 < nA; i0 += 64) {
+            const int i = i0 + lane;
+            const int pj = i < nA ? part[i] : -1;
+            const unsigned long long ball = __ballot(pj >= 0);
+            const int before = __popcll(ball & ((1ull << lane) - 1ull));
+            const int pm = max(m2_excl_max(pj, -1), jprev);
+            const int t = t0 + before;
+            if (i < nA) nca[i] = pj >= 0 ? i + pj - t : i + (pm + 1) - t;
+            t0 += __popcll(ball);
+            int mx = pj;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
+            jprev = max(jprev, mx);
+        }
+        const int nm = t0;
+        // second child: column j -> (row of the next matched pair, or nA) + j - matches before; descending for "next"
+        int inext = nA;
+        for (int j0 = ((nB - 1) / 64) * 64; j0 >= 0 && nB > 0; j0 -= 64) {
+            const int j = j0 + lane;
+            const int pi = j < nB ? pb[j] : -1;
+            int nx = m2_suffix_min_incl(pi >= 0 ? pi : 0x7fffffff);
+            nx = min(nx, inext);
+            if (j < nB) ncb[j] = nx;          // provisional: the row of the next matched pair at or after j
+            int mn = pi >= 0 ? pi : 0x7fffffff;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mn = min(mn, __shfl_xor(mn, d));
+            inext = min(inext, mn);
+        }
+        int tb = 0;
+        for (int j0 = 0; j0 < nB; j0 += 64) {
+            const int j = j0 + lane;
+            const int pi = j < nB ? pb[j] : -1;
+            const unsigned long long ball = __ballot(pi >= 0);
+            const int before = tb + __popcll(ball & ((1ull << lane) - 1ull));
+            if (j < nB) ncb[j] = ncb[j] + j - before;   // matched: next = its own row
+            tb += __popcll(ball);
+        }
+        if (lane == 0) s_newW = nA + nB - nm;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int newW = s_newW;
+    if (newW > G.wcap) {
+        if (threadIdx.x == 0) { A.ovf[g] = 1; A.nodemask[2 * fm + n + round] = maskA | maskB; A.ncols[2 * fm + n + round] = G.wcap; }
+        return;
+    }
+    // clear the members' rows of pos, then scatter the new columns
+    for (int a = 0; a < n; ++a) {
+        if (!(((maskA | maskB) >> a) & 1u)) continue;
+        uint16_t* row = A.pos + G.pos_base + static_cast<long long>(a) * G.wcap;
+        for (int c = threadIdx.x; c < newW; c += blockDim.x) row[c] = static_cast<uint16_t>(M2_NONE);
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int a = 0; a < n; ++a) {
+        const bool inA = (maskA >> a) & 1u, inB = (maskB >> a) & 1u;
+        if (!inA && !inB) continue;
+        const M2Member Me = A.members[fm + a];
+        const int* nc = inA ? nca : ncb;
+        uint16_t* row = A.pos + G.pos_base + static_cast<long long>(a) * G.wcap;
+        for (int p = threadIdx.x; p < Me.len; p += blockDim.x) {
+            const int c = nc[A.col[Me.col_base + p]];
+            A.col[Me.col_base + p] = c;
+            row[c] = static_cast<uint16_t>(p);
+        }
+    }
+    if (threadIdx.x == 0) { A.nodemask[2 * fm + n + round] = maskA | maskB; A.ncols[2 * fm + n + round] = newW; }
+}
+
+__global__ void k_m2_width(M2Args A) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= A.ngroups) return;
+    const M2Group G = A.groups[g];
+    int w = 0;
+    if (G.n == 1) w = A.members[G.first_member].len;
+    else if (G.n >= 2) w = A.ncols[2 * G.first_member + 2 * G.n - 2];
+    A.width[g] = w;
+}
+
+// one block per (member, chunk of columns): the gapped row of a member
+__global__ void k_m2_write(M2Args A, const int* member_group, int nmembers, const long long* out_off) {
+    const int m = blockIdx.y;
+    if (m >= nmembers) return;
+    const int g = member_group[m];
+    const M2Group G = A.groups[g];
+    const M2Member Me = A.members[m];
+    const int a = m - G.first_member;
+    const int W = A.width[g];
+    uint8_t* dst = A.out + out_off[g] + static_cast<long long>(a) * W;
+    const uint8_t* src = A.seq + Me.seq_off;
+    if (G.n == 1) {   // verbatim (src/quick_msa.cpp:46-50)
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < W; c += gridDim.x * blockDim.x) dst[c] = src[c];
+        return;
+    }
+    const uint16_t* row = A.pos + G.pos_base + static_cast<long long>(a) * G.wcap;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < W; c += gridDim.x * blockDim.x) {
+        const unsigned p = row[c];
+        dst[c] = p == M2_NONE ? '-' : "ACGTN"[dna5_code(src[p])];
+    }
+}
+
+// =============================================================================================
+// host side
+
+static int g_msa_spec = 0;   // 0: not set (SARLACC_MSA_SPEC or 2)
+
+static int msa_spec() {
+    if (g_msa_spec) return g_msa_spec;
+    if (const char* e = std::getenv("SARLACC_MSA_SPEC")) return std::atoi(e) == 1 ? 1 : 2;
+    return 2;
+}
+
+static inline unsigned m2_blocks(long long n, int bs) { return static_cast<unsigned>((n + bs - 1) / bs); }
+
+// One batch of groups (`ids`: indices into the caller's group list) through the v2 kernels.
+// exact = false: fast capacities (lists of M2_CAP entries in LDS, profiles of 2 maxlen + 64 columns); groups
+// that outgrow them come back in `redo`.  exact = true: worst-case capacities, nothing can overflow.
+// Leaves the batch's state (pos, members ...) in the "m2*" workspaces with prefix `pf` for the row writer.
+struct M2Batch {
+    std::vector<int64_t> ids;
+    std::vector<M2Group> groups;
+    std::vector<M2Member> members;
+    std::vector<int> member_group;
+    std::vector<MsaJob> jobs;
+    std::vector<int32_t> width;   // per group of the batch
+    std::vector<int> ovf;
+    M2Args a{};                   // device pointers
+    int* d_member_group = nullptr;
+    int max_len = 0, max_wcap = 0, max_n = 0;
+};
+
+static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const int64_t* rel, bool exact) {
+    long long map_pos = 0, col_pos = 0, row_pos = 0, pos_pos = 0, dist_pos = 0;
+    B.groups.clear(); B.members.clear(); B.member_group.clear(); B.jobs.clear();
+    B.max_len = 0; B.max_wcap = 0; B.max_n = 0;
+    for (size_t q = 0; q < B.ids.size(); ++q) {
+        const int64_t g = B.ids[q];
+        const int32_t* mem = grp + grp_off[g];
+        const int n = static_cast<int>(grp_off[g + 1] - grp_off[g]);
+        M2Group G{};
+        G.first_member = static_cast<int>(B.members.size());
+        G.n = n;
+        long long sum = 0;
+        int mx = 0;
+        for (int a = 0; a < n; ++a) {
+            const int len = static_cast<int>(rel[mem[a]] - rel[mem[a] - 1]);
+            sum += len;
+            mx = std::max(mx, len);
+        }
+        const long long fast_w = 2LL * mx + 64;
+        G.wcap = static_cast<int>(std::min<long long>(sum, exact ? sum : fast_w));
+        if (G.wcap < 1) G.wcap = 1;
+        if (G.wcap > 65535) return fail("sarlacc_amd: an alignment of %d reads would need %d columns; spec v2 handles up to 65535", n, G.wcap);
+        G.cap = exact ? std::max(1, (n / 2) * ((n + 1) / 2) * std::max(1, n - 1)) : M2_CAP;
+        G.row_base = row_pos;
+        G.pos_base = pos_pos;
+        G.first_job = static_cast<long long>(B.jobs.size());
+        G.dist_base = dist_pos;
+        row_pos += G.wcap;
+        pos_pos += static_cast<long long>(n) * G.wcap;
+        dist_pos += static_cast<long long>(n) * n + n;
+        for (int a = 0; a < n; ++a) {
+            M2Member Me{};
+            Me.seq_off = rel[mem[a] - 1];
+            Me.len = static_cast<int>(rel[mem[a]] - rel[mem[a] - 1]);
+            Me.map_base = map_pos;
+            Me.col_base = col_pos;
+            map_pos += static_cast<long long>(std::max(0, n - 1)) * Me.len;
+            col_pos += Me.len;
+            B.members.push_back(Me);
+            B.member_group.push_back(static_cast<int>(q));
+        }
+        if (n >= 2)
+            for (int a = 0; a < n; ++a)
+                for (int b = a + 1; b < n; ++b) {
+                    const M2Member& Ma = B.members[G.first_member + a];
+                    const M2Member& Mb = B.members[G.first_member + b];
+                    MsaJob J{};
+                    J.read_off = Mb.seq_off; J.ctr_off = Ma.seq_off;   // rows = b, columns = a
+                    J.lr = Mb.len; J.lc = Ma.len;
+                    J.out_off = Ma.map_base + static_cast<long long>(b - 1) * Ma.len;    // b among the others of a
+                    J.out2_off = Mb.map_base + static_cast<long long>(a) * Mb.len;       // a among the others of b
+                    B.jobs.push_back(J);
+                }
+        B.max_len = std::max(B.max_len, mx);
+        B.max_wcap = std::max(B.max_wcap, G.wcap);
+        B.max_n = std::max(B.max_n, n);
+        B.groups.push_back(G);
+    }
+    return 0;
+}
+
+static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq, double match, double mismatch, double gap_extension,
+                        double gap_opening, int bandwidth, bool exact, const std::function<int()>* overlap, double* cells, hipStream_t s) {
+    Context& c = ctx();
+    const size_t ng = B.groups.size(), nm = B.members.size();
+    if (ng == 0) return 0;
+    long long map_n = 0, col_n = 0, row_n = 0, pos_n = 0, dist_n = 0, ent_n = 0;
+    for (const M2Member& Me : B.members) col_n += Me.len;
+    for (const M2Group& G : B.groups) {
+        row_n += G.wcap; pos_n += static_cast<long long>(G.n) * G.wcap; dist_n += static_cast<long long>(G.n) * G.n + G.n;
+    }
+    if (!B.members.empty()) { const M2Member& L = B.members.back(); const M2Group& G = B.groups[B.member_group.back()]; map_n = L.map_base + static_cast<long long>(std::max(0, G.n - 1)) * L.len; }
+    // row lists: every group with its own stride
+    std::vector<long long> tmp_base(ng, 0);
+    long long tmp_n = 0;
+    {
+        // row_ent is indexed (row_base + i) * cap: with mixed capacities (exact redo) give every group of the
+        // batch the batch's largest capacity so that the indexing stays uniform
+        int capmax = 1;
+        for (const M2Group& G : B.groups) capmax = std::max(capmax, G.cap);
+        for (M2Group& G : B.groups) G.cap = capmax;
+        ent_n = row_n * static_cast<long long>(capmax);
+        for (size_t q = 0; q < ng; ++q) { tmp_base[q] = tmp_n; tmp_n += capmax; }
+    }
+    M2Args& a = B.a;
+    a = M2Args{};
+    M2Group* d_groups; M2Member* d_members; MsaJob* d_jobs; int* d_mg;
+    SL_TRY(upload((pf + ".groups").c_str(), B.groups.data(), ng, &d_groups, s));
+    SL_TRY(upload((pf + ".members").c_str(), B.members.data(), nm, &d_members, s));
+    SL_TRY(upload((pf + ".mg").c_str(), B.member_group.data(), nm, &d_mg, s));
+    SL_TRY(upload((pf + ".jobs").c_str(), B.jobs.data(), B.jobs.size(), &d_jobs, s));
+    B.d_member_group = d_mg;
+    uint16_t* d_map; int2* d_stats; double* d_dist; int2* d_joins; uint32_t* d_mask; int* d_ncols; int* d_col; uint16_t* d_pos;
+    uint16_t* d_cnt; unsigned long long* d_ent; int* d_part; int* d_nca; int* d_ncb; int* d_pb; int* d_ovf; int32_t* d_width;
+    SL_TRY(scratch((pf + ".map").c_str(), static_cast<size_t>(map_n) + 1, &d_map));
+    SL_TRY(scratch((pf + ".stats").c_str(), B.jobs.size() + 1, &d_stats));
+    SL_TRY(scratch((pf + ".dist").c_str(), static_cast<size_t>(dist_n) + 1, &d_dist));
+    SL_TRY(scratch((pf + ".joins").c_str(), nm + 1, &d_joins));
+    SL_TRY(scratch((pf + ".mask").c_str(), 2 * nm + 2, &d_mask));
+    SL_TRY(scratch((pf + ".ncols").c_str(), 2 * nm + 2, &d_ncols));
+    SL_TRY(scratch((pf + ".col").c_str(), static_cast<size_t>(col_n) + 1, &d_col));
+    SL_TRY(scratch((pf + ".pos").c_str(), static_cast<size_t>(pos_n) + 1, &d_pos));
+    SL_TRY(scratch((pf + ".cnt").c_str(), static_cast<size_t>(row_n) + 1, &d_cnt));
+    SL_TRY(scratch((pf + ".ent").c_str(), static_cast<size_t>(ent_n) + 1, &d_ent));
+    SL_TRY(scratch((pf + ".part").c_str(), static_cast<size_t>(row_n) + 1, &d_part));
+    SL_TRY(scratch((pf + ".nca").c_str(), static_cast<size_t>(row_n) + 1, &d_nca));
+    SL_TRY(scratch((pf + ".ncb").c_str(), static_cast<size_t>(row_n) + 1, &d_ncb));
+    SL_TRY(scratch((pf + ".pb").c_str(), static_cast<size_t>(row_n) + 1, &d_pb));
+    SL_TRY(scratch((pf + ".ovf").c_str(), ng, &d_ovf));
+    SL_TRY(scratch((pf + ".width").c_str(), ng, &d_width));
+    SL_HIP(hipMemsetAsync(d_ovf, 0, sizeof(int) * ng, s));
+    a.seq = d_seq; a.groups = d_groups; a.members = d_members; a.ngroups = static_cast<int>(ng);
+    a.ma = static_cast<int>(match); a.mm = static_cast<int>(mismatch);
+    a.map = d_map; a.stats = d_stats; a.dist = d_dist; a.joins = d_joins; a.nodemask = d_mask; a.ncols = d_ncols;
+    a.col = d_col; a.pos = d_pos; a.row_cnt = d_cnt; a.row_ent = d_ent; a.part = d_part; a.ovf = d_ovf; a.width = d_width;
+
+    // ---- all pairs ----
+    for (const MsaJob& J : B.jobs) *cells += static_cast<double>(J.lr) * (std::abs(J.lc - J.lr) + 2 * bandwidth + 1);
+    SL_TRY(c.stage_begin("msa_pairwise", s));
+    SL_TRY(msa_pairwise_launch(B.jobs, d_jobs, d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, 1, nullptr, nullptr,
+                               d_map, d_stats, nullptr, s));
+    SL_TRY(c.stage_end("msa_pairwise", s));
+    if (overlap) SL_TRY((*overlap)());
+    // ---- guide trees, leaves ----
+    SL_TRY(c.stage_begin("msa_merge", s));
+    hipLaunchKernelGGL(k_m2_tree, dim3(m2_blocks(static_cast<long long>(ng), 64)), dim3(64), 0, s, a);
+    if (nm) hipLaunchKernelGGL(k_m2_init, dim3(std::max(1u, m2_blocks(B.max_len, 256)), static_cast<unsigned>(nm)), dim3(256), 0, s, a, d_mg, static_cast<int>(nm));
+    SL_HIP(hipGetLastError());
+    // ---- progressive merging, one round per join ----
+    const bool unitw = a.ma <= 1 && a.mm <= 1;
+    int* d_tmpj = nullptr; unsigned long long* d_tmpnv = nullptr; long long* d_tmpbase = nullptr;
+    if (exact) {
+        SL_TRY(scratch((pf + ".tmpj").c_str(), static_cast<size_t>(tmp_n) + 1, &d_tmpj));
+        SL_TRY(scratch((pf + ".tmpnv").c_str(), static_cast<size_t>(tmp_n) + 1, &d_tmpnv));
+        SL_TRY(upload((pf + ".tmpbase").c_str(), tmp_base.data(), tmp_base.size(), &d_tmpbase, s));
+    }
+    const size_t chain_lds = sizeof(unsigned long long) * (64 * M2_STAGE + M2_CAP) + sizeof(int) * (M2_CAP + 64) +
+                             sizeof(unsigned long long) * (static_cast<size_t>(B.max_wcap) + 2) + 16;
+    if (chain_lds > 160 * 1024) return fail("sarlacc_amd: an alignment of %d columns does not fit the chain kernel's LDS", B.max_wcap);
+    if (chain_lds > 48 * 1024)
+        SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_m2_chain), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(chain_lds)));
+    for (int round = 0; round + 1 < B.max_n; ++round) {
+        const dim3 ggrid(m2_blocks(B.max_wcap, 64), static_cast<unsigned>(ng));
+        if (!exact) {
+            if (unitw) hipLaunchKernelGGL((k_m2_gather<true, true>), ggrid, dim3(64), 0, s, a, round);
+            else hipLaunchKernelGGL((k_m2_gather<false, true>), ggrid, dim3(64), 0, s, a, round);
+        } else {
+            if (unitw) hipLaunchKernelGGL((k_m2_gather<true, false>), ggrid, dim3(64), 0, s, a, round);
+            else hipLaunchKernelGGL((k_m2_gather<false, false>), ggrid, dim3(64), 0, s, a, round);
+        }
+        hipLaunchKernelGGL(k_m2_chain, dim3(static_cast<unsigned>(ng)), dim3(64), chain_lds, s, a, round, d_tmpj, d_tmpnv, d_tmpbase);
+        hipLaunchKernelGGL(k_m2_merge, dim3(static_cast<unsigned>(ng)), dim3(256), 0, s, a, round, d_nca, d_ncb, d_pb);
+        SL_HIP(hipGetLastError());
+        if (std::getenv("SARLACC_MSA2_DEBUG")) {   // first group of the batch, for comparison with ORC_MSA2_DEBUG of the oracle
+            SL_HIP(hipStreamSynchronize(s));
+            const M2Group& G = B.groups[0];
+            if (round < G.n - 1) {
+                std::vector<int2> hj(G.n);
+                std::vector<int> hn(2 * G.n), hp(G.wcap);
+                std::vector<uint16_t> hc(G.wcap);
+                std::vector<unsigned long long> he(static_cast<size_t>(G.wcap) * G.cap);
+                SL_HIP(hipMemcpy(hj.data(), d_joins + G.first_member, sizeof(int2) * G.n, hipMemcpyDeviceToHost));
+                SL_HIP(hipMemcpy(hn.data(), d_ncols + 2 * G.first_member, sizeof(int) * 2 * G.n, hipMemcpyDeviceToHost));
+                SL_HIP(hipMemcpy(hp.data(), d_part + G.row_base, sizeof(int) * G.wcap, hipMemcpyDeviceToHost));
+                SL_HIP(hipMemcpy(hc.data(), d_cnt + G.row_base, sizeof(uint16_t) * G.wcap, hipMemcpyDeviceToHost));
+                SL_HIP(hipMemcpy(he.data(), d_ent + G.row_base * G.cap, sizeof(unsigned long long) * he.size(), hipMemcpyDeviceToHost));
+                const int nA = hn[hj[round].x];
+                fprintf(stderr, "GPU round %d: join %d %d nA %d nB %d -> %d\n", round, hj[round].x, hj[round].y, nA, hn[hj[round].y], hn[G.n + round]);
+                for (int i = 0; i < nA; ++i) {
+                    fprintf(stderr, "  row %d part %d :", i, hp[i]);
+                    for (int k = 0; k < hc[i]; ++k) fprintf(stderr, " (%d pred %u)", static_cast<int>(he[static_cast<size_t>(i) * G.cap + k] >> 32), static_cast<unsigned>(he[static_cast<size_t>(i) * G.cap + k]));
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
+    }
+    hipLaunchKernelGGL(k_m2_width, dim3(m2_blocks(static_cast<long long>(ng), 256)), dim3(256), 0, s, a);
+    SL_HIP(hipGetLastError());
+    SL_TRY(c.stage_end("msa_merge", s));
+    B.width.resize(ng);
+    B.ovf.resize(ng);
+    SL_HIP(hipMemcpyAsync(B.width.data(), d_width, sizeof(int32_t) * ng, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipMemcpyAsync(B.ovf.data(), d_ovf, sizeof(int) * ng, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    int stuck = 0;
+    if (!B.jobs.empty()) {
+        int* d_stuck;
+        SL_TRY(scratch("msa.stuck", 1, &d_stuck));
+        SL_HIP(hipMemcpy(&stuck, d_stuck, sizeof stuck, hipMemcpyDeviceToHost));
+        if (stuck) return fail("sarlacc_amd: internal error: an MSA traceback exceeded its step bound");
+    }
+    return 0;
+}
+
+// rows of the batch's groups (except those flagged in `skip`) at out + off[group of the caller's list]
+static int m2_write_batch(M2Batch& B, const std::string& pf, const std::vector<long long>& off_of_batch_group, uint8_t* d_out, hipStream_t s) {
+    if (B.members.empty()) return 0;
+    long long* d_off;
+    SL_TRY(upload((pf + ".ooff").c_str(), off_of_batch_group.data(), off_of_batch_group.size(), &d_off, s));
+    B.a.out = d_out;
+    int maxw = 1;
+    for (int32_t w : B.width) maxw = std::max(maxw, static_cast<int>(w));
+    hipLaunchKernelGGL(k_m2_write, dim3(std::max(1u, m2_blocks(maxw, 256)), static_cast<unsigned>(B.members.size())), dim3(256), 0, s, B.a,
+                       B.d_member_group, static_cast<int>(B.members.size()), d_off);
+    SL_HIP(hipGetLastError());
+    return 0;
+}
+
+// spec v2 on the groups `ids` of the caller's list; rows land in *d_rows in `ids` order at off[q] (off has
+// ids.size() + 1 entries), widths in width[q].
+static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vector<int64_t>& ids, const uint8_t* d_seq,
+                     const std::vector<int64_t>& rel, double match, double mismatch, double gap_extension, double gap_opening,
+                     int bandwidth, std::vector<int32_t>& width, std::vector<long long>& off, uint8_t** d_rows,
+                     const std::function<int()>* overlap, hipStream_t s) {
+    Context& c = ctx();
+    width.assign(ids.size(), 0);
+    off.assign(ids.size() + 1, 0);
+    *d_rows = nullptr;
+    // row buffer: grown when a batch does not fit (contents are kept)
+    Workspace& rows_ws = c.ws["msa2.rows"];
+    auto rows_reserve = [&](size_t used, size_t need) -> int {
+        if (rows_ws.cap >= need) return 0;
+        const size_t want = std::max(need, rows_ws.cap + rows_ws.cap / 2) + 4096;
+        void* np = nullptr;
+        if (hipMalloc(&np, want) != hipSuccess) return fail("sarlacc_amd: cannot allocate %zu bytes of device memory for the alignment rows", want);
+        if (rows_ws.ptr) {
+            if (used) SL_HIP(hipMemcpyAsync(np, rows_ws.ptr, used, hipMemcpyDeviceToDevice, s));
+            SL_HIP(hipStreamSynchronize(s));
+            SL_HIP(hipFree(rows_ws.ptr));
+        }
+        rows_ws.ptr = np;
+        rows_ws.cap = want;
+        return 0;
+    };
+    // batches by memory: position maps (2 B x n (n - 1) x length), pairwise jobs, row lists
+    const long long map_budget = 6LL << 30, ent_budget = 6LL << 30, job_budget = 3000000;
+    size_t q0 = 0;
+    double cells = 0, pairs = 0;
+    bool first = true;
+    long long used = 0;
+    while (q0 < ids.size()) {
+        M2Batch B;
+        long long map_b = 0, ent_b = 0, jobs_b = 0;
+        size_t q1 = q0;
+        while (q1 < ids.size()) {
+            const int64_t g = ids[q1];
+            const long long n = grp_off[g + 1] - grp_off[g];
+            long long sum = 0, mx = 0;
+            for (long long a = 0; a < n; ++a) { const long long len = rel[grp[grp_off[g] + a]] - rel[grp[grp_off[g] + a] - 1]; sum += len; mx = std::max(mx, len); }
+            const long long mb = 2 * (n - 1) * sum, eb = std::min(sum, 2 * mx + 64) * M2_CAP * 8, jb = n * (n - 1) / 2;
+            if (q1 > q0 && (map_b + mb > map_budget || ent_b + eb > ent_budget || jobs_b + jb > job_budget)) break;
+            map_b += mb; ent_b += eb; jobs_b += jb;
+            B.ids.push_back(g);
+            ++q1;
+        }
+        SL_TRY(m2_plan(B, grp_off, grp, rel.data(), false));
+        SL_TRY(m2_run_batch(B, "m2", d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, false, first ? overlap : nullptr, &cells, s));
+        first = false;
+        pairs += static_cast<double>(B.jobs.size());
+        // groups that outgrew the fast capacities: exact redo, a few at a time
+        std::vector<size_t> redo;
+        for (size_t q = 0; q < B.groups.size(); ++q)
+            if (B.ovf[q]) redo.push_back(q);
+        std::vector<M2Batch> exact;
+        for (size_t r0 = 0; r0 < redo.size();) {
+            exact.emplace_back();
+            M2Batch& X = exact.back();
+            long long ent_x = 0;
+            size_t r1 = r0;
+            while (r1 < redo.size()) {
+                const M2Group& G = B.groups[redo[r1]];
+                long long sum = 0;
+                for (int a = 0; a < G.n; ++a) sum += B.members[G.first_member + a].len;
+                const long long capx = std::max(1, (G.n / 2) * ((G.n + 1) / 2) * std::max(1, G.n - 1));
+                const long long eb = sum * capx * 8;
+                if (r1 > r0 && ent_x + eb > ent_budget) break;
+                ent_x += eb;
+                X.ids.push_back(B.ids[redo[r1]]);
+                ++r1;
+            }
+            r0 = r1;
+        }
+        // widths and offsets of the batch (exact results replace the flagged ones)
+        std::vector<char> flagged(B.groups.size(), 0);
+        for (size_t q : redo) flagged[q] = 1;
+        size_t xi = 0;
+        for (M2Batch& X : exact) {
+            SL_TRY(m2_plan(X, grp_off, grp, rel.data(), true));
+            // every exact batch keeps its own workspaces until its rows are written
+            const std::string pf = "m2x" + std::to_string(xi++);
+            SL_TRY(m2_run_batch(X, pf, d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, true, nullptr, &cells, s));
+            for (size_t q = 0; q < X.groups.size(); ++q)
+                if (X.ovf[q]) return fail("sarlacc_amd: internal error: exact MSA capacities exceeded");
+        }
+        {
+            size_t xb = 0, xq = 0;
+            for (size_t q = 0; q < B.groups.size(); ++q) {
+                int32_t w = B.width[q];
+                if (flagged[q]) {
+                    while (xq >= exact[xb].groups.size()) { ++xb; xq = 0; }
+                    w = exact[xb].width[xq++];
+                }
+                width[q0 + q] = w;
+                off[q0 + q + 1] = off[q0 + q] + static_cast<long long>(w) * B.groups[q].n;
+            }
+        }
+        const long long need = off[q1];
+        SL_TRY(rows_reserve(static_cast<size_t>(used), static_cast<size_t>(need) + 1));
+        uint8_t* const d_out = static_cast<uint8_t*>(rows_ws.ptr);
+        {
+            // the fast batch writes every unflagged group; flagged ones get width 0 there
+            std::vector<long long> boff(B.groups.size());
+            std::vector<int32_t> bw = B.width;
+            for (size_t q = 0; q < B.groups.size(); ++q) { boff[q] = off[q0 + q]; if (flagged[q]) bw[q] = 0; }
+            int32_t* d_w = B.a.width;
+            SL_HIP(hipMemcpyAsync(d_w, bw.data(), sizeof(int32_t) * bw.size(), hipMemcpyHostToDevice, s));
+            B.width = bw;
+            SL_TRY(m2_write_batch(B, "m2", boff, d_out, s));
+            size_t xb = 0;
+            size_t cursor = 0;
+            for (M2Batch& X : exact) {
+                std::vector<long long> xoff(X.groups.size());
+                for (size_t q = 0; q < X.groups.size(); ++q) {
+                    while (!flagged[cursor]) ++cursor;
+                    xoff[q] = off[q0 + cursor];
+                    ++cursor;
+                }
+                SL_TRY(m2_write_batch(X, "m2x" + std::to_string(xb++), xoff, d_out, s));
+            }
+            SL_HIP(hipStreamSynchronize(s));   // host vectors of this batch go out of scope
+        }
+        used = need;
+        q0 = q1;
+    }
+    c.counts["msa_pairs"] = (c.counts.count("msa_pairs") ? c.counts["msa_pairs"] : 0.0) + pairs;
+    c.counts["msa_cells"] = (c.counts.count("msa_cells") ? c.counts["msa_cells"] : 0.0) + cells;
+    if (!rows_ws.ptr) SL_TRY(rows_reserve(0, 16));
+    *d_rows = static_cast<uint8_t*>(rows_ws.ptr);
+    return 0;
+}
+
+__global__ void k_rows_copy(const uint8_t* src, const long long* src_off, uint8_t* dst, const long long* dst_off, const long long* nbytes) {
+    const long long g = blockIdx.x;
+    const long long n = nbytes[g];
+    const uint8_t* s = src + src_off[g];
+    uint8_t* d = dst + dst_off[g];
+    for (long long k = threadIdx.x; k < n; k += blockDim.x) d[k] = s[k];
+}
+
+// The MSA stage of quick_msa: spec v2 for groups of up to M2_MAXN reads whose profiles fit 65535 columns,
+// spec v1 (msa.hip) for the rest and when spec 1 is selected (sarlacc_set_msa_spec / SARLACC_MSA_SPEC=1).
+int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq, const int64_t* seq_off,
+            int64_t nseq, double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
+            bool want_rows, int64_t out_cap, MsaResult* res, const std::function<int()>* overlap,
+            const uint8_t* d_seq_resident) {
+    if (msa_spec() == 1)
+        return msa1_run(grp_off, grp, ngroups, seq, seq_off, nseq, match, mismatch, gap_extension, gap_opening, bandwidth, want_rows,
+                        out_cap, res, overlap, d_seq_resident);
+    int32_t* width_out = res->width.data();
+    int64_t* out_off = res->out_off.data();
+    res->d_out = nullptr;
+    res->d_members = nullptr;
+    out_off[0] = 0;
+    if (bandwidth < 0) return fail("sarlacc_amd: negative bandwidth");
+    const int64_t nmemb = grp_off[ngroups] - grp_off[0];
+    for (int64_t i = 0; i < nmemb; ++i) {
+        const int32_t v = grp[grp_off[0] + i];
+        if (v < 1 || v > nseq) return fail("sarlacc_amd: group index %d outside 1..%lld", v, static_cast<long long>(nseq));
+    }
+    std::vector<int64_t> rel(static_cast<size_t>(nseq) + 1);
+    for (int64_t i = 0; i <= nseq; ++i) rel[i] = (nseq ? seq_off[i] : 0) - (nseq ? seq_off[0] : 0);
+    // which groups does spec v2 take
+    std::vector<int64_t> v2, v1;
+    for (int64_t g = 0; g < ngroups; ++g) {
+        const int64_t n = grp_off[g + 1] - grp_off[g];
+        int64_t mx = 0;
+        for (int64_t a = 0; a < n; ++a) { const int32_t id = grp[grp_off[g] + a]; mx = std::max<int64_t>(mx, rel[id] - rel[id - 1]); }
+        if (mx > 60000) return fail("sarlacc_amd: reads longer than 60000 bases are not supported by the MSA stage");
+        if (n <= M2_MAXN && 2 * mx + 64 <= 65535) v2.push_back(g); else v1.push_back(g);
+    }
+    SL_TRY(ensure_device());
+    Context& c = ctx();
+    hipStream_t s = nullptr;
+    c.stage_reset("msa_pairwise");
+    c.stage_reset("msa_merge");
+    c.counts["msa_pairs"] = 0;
+    c.counts["msa_cells"] = 0;
+    if (v2.empty())
+        return msa1_run(grp_off, grp, ngroups, seq, seq_off, nseq, match, mismatch, gap_extension, gap_opening, bandwidth, want_rows,
+                        out_cap, res, overlap, d_seq_resident);
+    const int64_t total = rel[nseq];
+    uint8_t* d_seq;
+    if (d_seq_resident) d_seq = const_cast<uint8_t*>(d_seq_resident);
+    else SL_TRY(upload("msa.seq", reinterpret_cast<const uint8_t*>(seq) + (nseq ? seq_off[0] : 0), static_cast<size_t>(total), &d_seq, s));
+    int32_t* d_mem;
+    SL_TRY(upload("msa.mem.all", grp + grp_off[0], static_cast<size_t>(nmemb), &d_mem, s));   // (msa1_run uploads its own "msa.mem")
+    res->d_members = d_mem;
+
+    // spec v1 part first (its stage timers reset themselves), on a compacted group list
+    MsaResult r1;
+    std::vector<int64_t> g1off(v1.size() + 1, 0);
+    std::vector<int32_t> g1;
+    if (!v1.empty()) {
+        for (size_t q = 0; q < v1.size(); ++q) {
+            const int64_t g = v1[q];
+            for (int64_t k = grp_off[g]; k < grp_off[g + 1]; ++k) g1.push_back(grp[k]);
+            g1off[q + 1] = static_cast<int64_t>(g1.size());
+        }
+        r1.width.assign(v1.size(), 0);
+        r1.out_off.assign(v1.size() + 1, 0);
+        SL_TRY(msa1_run(g1off.data(), g1.data(), static_cast<int64_t>(v1.size()), seq, seq_off, nseq, match, mismatch, gap_extension,
+                        gap_opening, bandwidth, true, -1, &r1, nullptr, d_seq));
+    }
+    std::vector<int32_t> w2;
+    std::vector<long long> o2;
+    uint8_t* d_rows2 = nullptr;
+    SL_TRY(msa2_core(grp_off, grp, v2, d_seq, rel, match, mismatch, gap_extension, gap_opening, bandwidth, w2, o2, &d_rows2, overlap, s));
+    if (v1.empty()) {
+        for (int64_t g = 0; g < ngroups; ++g) { width_out[g] = w2[g]; out_off[g + 1] = o2[g + 1]; }
+        if (want_rows && out_cap >= 0 && out_cap < out_off[ngroups]) return fail("sarlacc_amd: MSA output buffer too small (%lld needed)", static_cast<long long>(out_off[ngroups]));
+        res->d_out = d_rows2;
+        return 0;
+    }
+    // both kinds: gather the rows of the two buffers into one in group order
+    std::vector<long long> src_off(static_cast<size_t>(ngroups)), dst_off(static_cast<size_t>(ngroups)), nbytes(static_cast<size_t>(ngroups));
+    std::vector<char> from1(static_cast<size_t>(ngroups), 0);
+    {
+        size_t a1 = 0, a2 = 0;
+        for (int64_t g = 0; g < ngroups; ++g) {
+            const int64_t n = grp_off[g + 1] - grp_off[g];
+            if (a1 < v1.size() && v1[a1] == g) { width_out[g] = r1.width[a1]; src_off[g] = r1.out_off[a1]; from1[g] = 1; ++a1; }
+            else { width_out[g] = w2[a2]; src_off[g] = o2[a2]; ++a2; }
+            nbytes[g] = static_cast<long long>(width_out[g]) * n;
+            dst_off[g] = out_off[g];
+            out_off[g + 1] = out_off[g] + nbytes[g];
+        }
+    }
+    if (want_rows && out_cap >= 0 && out_cap < out_off[ngroups]) return fail("sarlacc_amd: MSA output buffer too small (%lld needed)", static_cast<long long>(out_off[ngroups]));
+    uint8_t* d_final;
+    SL_TRY(scratch("msa.final", static_cast<size_t>(out_off[ngroups]) + 1, &d_final));
+    // two launches, one per source buffer (groups of the other kind copy nothing)
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<long long> nb(nbytes);
+        for (int64_t g = 0; g < ngroups; ++g)
+            if ((from1[g] != 0) != (pass == 0)) nb[g] = 0;
+        long long *d_so, *d_do, *d_nb;
+        SL_TRY(upload(pass == 0 ? "msa.cp.so1" : "msa.cp.so2", src_off.data(), src_off.size(), &d_so, s));
+        SL_TRY(upload(pass == 0 ? "msa.cp.do1" : "msa.cp.do2", dst_off.data(), dst_off.size(), &d_do, s));
+        SL_TRY(upload(pass == 0 ? "msa.cp.nb1" : "msa.cp.nb2", nb.data(), nb.size(), &d_nb, s));
+        hipLaunchKernelGGL(k_rows_copy, dim3(static_cast<unsigned>(ngroups)), dim3(256), 0, s, pass == 0 ? r1.d_out : d_rows2, d_so, d_final, d_do, d_nb);
+        SL_HIP(hipGetLastError());
+    }
+    SL_HIP(hipStreamSynchronize(s));
+    res->d_out = d_final;
+    return 0;
+}
+
+}  // namespace sarlacc
+
+using namespace sarlacc;
+
+extern "C" int sarlacc_set_msa_spec(int spec) {
+    if (spec != 0 && spec != 1 && spec != 2) return fail("sarlacc_amd: MSA spec must be 1 (centre-star) or 2 (consistency-based progressive), 0 = default");
+    sarlacc::g_msa_spec = spec;
+    return 0;
+}

@@ -838,6 +838,7 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
         SL_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
         PairArgs a{S.U, S.gid, n, lim2, d_edges, d_count, cap, tile_lo, d_list, d_subinfo};
         SL_HIP(hipEventRecord(c.ev_start, s));
+        c.stage_reset("umi_pairs");
         SL_TRY(c.stage_begin("umi_pairs", s));
         const int K = std::min(limit, UMI_MAXLEN);
         if (K <= 0) launch_pairs<0>(a, tile_hi, nlisted, s);
