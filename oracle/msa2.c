@@ -24,6 +24,11 @@
  *      when not positive; SeqAn refines matches to common segments, here every segment is one base]
  *   5. full triplet extension: W(a,p,b,q) = w0[direct] + sum over c of min(w0(a_p,c_r), w0(c_r,b_q))
  *      for every c whose pairwise alignments link p - r - q.                    [SeqAn: tripletLibraryExtension]
+ *      Bounded rows: for one column of the first child the candidates are enumerated for a ascending -- first
+ *      the direct edges (b ascending), then the triplets (c ascending, b ascending) -- and a candidate whose
+ *      partner column is not among the first MSA2_ROWCAP (16) distinct columns seen is ignored.  Same-molecule
+ *      reads never come near the bound; it keeps clusters of unrelated reads (UMI collisions), whose library
+ *      is dense noise, from costing orders of magnitude more than real ones.   [own rule]
  *   6. progressive alignment along the tree: two profiles (lists of columns) are merged by the heaviest
  *      common subsequence of their columns, weight(col_i, col_j) = sum of W over the members, no gap
  *      penalties; among equally heavy chains the one built from the earliest matches (row-major) wins;
@@ -40,6 +45,8 @@
 #include <string.h>
 
 int orc_fail(const char* msg);
+
+#define MSA2_ROWCAP 16
 
 static char dna5(char c) {
     switch (c) {
@@ -229,56 +236,66 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
             const int64_t a = A->mem[u];
             for (int64_t p = 0; p < LEN(&L, a); ++p) posA[u * nA + col[L.off[a] + p]] = p;
         }
-        /* matches, row-major */
+        /* matches, row-major; per row at most MSA2_ROWCAP partner columns, in order of first appearance */
         int64_t mcap = 1024, nm = 0;
         int64_t* mi = (int64_t*)malloc(sizeof(int64_t) * (size_t)mcap);
         int64_t* mj = (int64_t*)malloc(sizeof(int64_t) * (size_t)mcap);
         int64_t* mw = (int64_t*)malloc(sizeof(int64_t) * (size_t)mcap);
-        int64_t* W = (int64_t*)calloc((size_t)(nB ? nB : 1), sizeof(int64_t));
+        unsigned inA = 0, inB = 0;
+        for (int64_t u = 0; u < A->nmem; ++u) inA |= 1u << A->mem[u];
+        for (int64_t v = 0; v < B->nmem; ++v) inB |= 1u << B->mem[v];
+        int64_t* idxA = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);   /* member slot of sequence a in posA */
+        for (int64_t u = 0; u < A->nmem; ++u) idxA[A->mem[u]] = u;
         for (int64_t i = 0; i < nA; ++i) {
-            int64_t jlo = nB, jhi = -1;
-            for (int64_t u = 0; u < A->nmem; ++u) {
-                const int64_t a = A->mem[u];
-                const int64_t p = posA[u * nA + i];
+            int64_t lj[MSA2_ROWCAP], lw[MSA2_ROWCAP];
+            int cnt = 0;
+#define ADD(J, Wt) do { int k_; for (k_ = 0; k_ < cnt; ++k_) if (lj[k_] == (J)) { lw[k_] += (Wt); break; } \
+                        if (k_ == cnt && cnt < MSA2_ROWCAP) { lj[cnt] = (J); lw[cnt] = (Wt); ++cnt; } } while (0)
+            for (int64_t a = 0; a < n; ++a) {
+                if (!((inA >> a) & 1u)) continue;
+                const int64_t p = posA[idxA[a] * nA + i];
                 if (p < 0) continue;
                 const char xa = SEQ(&L, a)[p];
-                for (int64_t v = 0; v < B->nmem; ++v) {
-                    const int64_t b = B->mem[v];
-                    for (int64_t c = 0; c < n; ++c) {
-                        if (c == a) continue;
-                        int64_t q, w;
-                        if (c == b) {          /* the direct edge */
-                            q = L.map[a * n + b][p];
-                            if (q < 0) continue;
-                            w = w0(xa, SEQ(&L, b)[q], ma, mm);
-                        } else {               /* through sequence c */
-                            const int64_t r = L.map[a * n + c][p];
-                            if (r < 0) continue;
-                            q = L.map[c * n + b][r];
-                            if (q < 0) continue;
-                            const int w1 = w0(xa, SEQ(&L, c)[r], ma, mm), w2 = w0(SEQ(&L, c)[r], SEQ(&L, b)[q], ma, mm);
-                            w = w1 < w2 ? w1 : w2;
-                        }
-                        const int64_t j = col[L.off[b] + q];
-                        W[j] += w;
-                        if (j < jlo) jlo = j;
-                        if (j > jhi) jhi = j;
+                for (int64_t b = 0; b < n; ++b) {          /* direct edges */
+                    if (!((inB >> b) & 1u)) continue;
+                    const int64_t q = L.map[a * n + b][p];
+                    if (q < 0) continue;
+                    ADD(col[L.off[b] + q], w0(xa, SEQ(&L, b)[q], ma, mm));
+                }
+                for (int64_t c = 0; c < n; ++c) {          /* through sequence c */
+                    if (c == a) continue;
+                    const int64_t r = L.map[a * n + c][p];
+                    if (r < 0) continue;
+                    const int w1 = w0(xa, SEQ(&L, c)[r], ma, mm);
+                    for (int64_t b = 0; b < n; ++b) {
+                        if (!((inB >> b) & 1u) || b == c) continue;
+                        const int64_t q = L.map[c * n + b][r];
+                        if (q < 0) continue;
+                        const int w2 = w0(SEQ(&L, c)[r], SEQ(&L, b)[q], ma, mm);
+                        ADD(col[L.off[b] + q], w1 < w2 ? w1 : w2);
                     }
                 }
             }
-            for (int64_t j = jlo; j <= jhi; ++j) {
-                if (W[j] <= 0) continue;
+#undef ADD
+            /* by column */
+            for (int x = 1; x < cnt; ++x) {
+                const int64_t tj = lj[x], tw = lw[x];
+                int y = x - 1;
+                while (y >= 0 && lj[y] > tj) { lj[y + 1] = lj[y]; lw[y + 1] = lw[y]; --y; }
+                lj[y + 1] = tj; lw[y + 1] = tw;
+            }
+            for (int x = 0; x < cnt; ++x) {
                 if (nm == mcap) {
                     mcap *= 2;
                     mi = (int64_t*)realloc(mi, sizeof(int64_t) * (size_t)mcap);
                     mj = (int64_t*)realloc(mj, sizeof(int64_t) * (size_t)mcap);
                     mw = (int64_t*)realloc(mw, sizeof(int64_t) * (size_t)mcap);
                 }
-                mi[nm] = i; mj[nm] = j; mw[nm] = W[j];
-                W[j] = 0;
+                mi[nm] = i; mj[nm] = lj[x]; mw[nm] = lw[x];
                 ++nm;
             }
         }
+        free(idxA);
         /* heaviest chain: f(m) = w(m) + best f over matches with smaller row and smaller column;
          * "best" = larger f, then smaller match index.  bestAt[j] = best match ending in column j among the
          * processed rows; a row's matches all look at the state before the row. */
@@ -347,7 +364,7 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
             const int64_t b = B->mem[v];
             for (int64_t q = 0; q < LEN(&L, b); ++q) col[L.off[b] + q] = ncB[col[L.off[b] + q]];
         }
-        free(posA); free(mi); free(mj); free(mw); free(W); free(f); free(pred); free(bestAt); free(pa); free(ncA); free(ncB);
+        free(posA); free(mi); free(mj); free(mw); free(f); free(pred); free(bestAt); free(pa); free(ncA); free(ncB);
     }
     if (!rc) {
         const int64_t Wd = prof[2 * n - 2].ncols;

@@ -24,7 +24,8 @@
 //                instruction), then the traceback through the stored predecessors;
 //   k_m2_merge   one workgroup per group: new column numbers (first child's unmatched columns before the
 //                second child's between two matched pairs), col / pos of every member updated.
-// Groups whose lists or profiles outgrow the fast capacities are redone with exact worst-case capacities.
+// A row keeps the first M2_CAP distinct partner columns (spec v2, step 5); groups whose profiles outgrow the
+// fast capacity are redone with profiles as wide as the sum of the read lengths.
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -193,7 +194,6 @@ __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
     const int cap = LDSLIST ? M2_CAP : G.cap;
     unsigned long long* const mine = A.row_ent + (G.row_base + i) * static_cast<long long>(G.cap);
     int cnt = 0;
-    bool over = false;
     auto ent_get = [&](int k) -> unsigned long long { return LDSLIST ? s_ent[LDSLIST ? k : 0][lane] : mine[k]; };
     auto ent_set = [&](int k, unsigned long long v) { if (LDSLIST) s_ent[LDSLIST ? k : 0][lane] = v; else mine[k] = v; };
     auto add = [&](int j, int w) {
@@ -201,8 +201,8 @@ __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
             const unsigned long long e = ent_get(k);
             if (static_cast<int>(e >> 32) == j) { ent_set(k, e + static_cast<unsigned>(w)); return; }
         }
+        // a column beyond the row's first M2_CAP distinct ones is ignored (spec v2, step 5)
         if (cnt < cap) ent_set(cnt++, (static_cast<unsigned long long>(static_cast<unsigned>(j)) << 32) | static_cast<unsigned>(w));
-        else over = true;
     };
     if (i < nA) {
         for (int a = 0; a < n; ++a) {
@@ -211,14 +211,20 @@ __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
             if (p == M2_NONE) continue;
             const M2Member Ma = A.members[fm + a];
             const int xa = UNITW ? 0 : dna5_code(A.seq[Ma.seq_off + p]);
-            for (int c = 0; c < n; ++c) {
+            for (int b = 0; b < n; ++b) {              // the direct edges a - b first
+                if (!((maskB >> b) & 1u)) continue;
+                const unsigned q = A.map[Ma.map_base + static_cast<long long>(b < a ? b : b - 1) * Ma.len + p];
+                if (q == M2_NONE) continue;
+                const M2Member Mb = A.members[fm + b];
+                add(A.col[Mb.col_base + q], UNITW ? 1 : m2_w0(xa, dna5_code(A.seq[Mb.seq_off + q]), A.ma, A.mm));
+            }
+            for (int c = 0; c < n; ++c) {              // then a - c - b
                 if (c == a) continue;
                 const unsigned r = A.map[Ma.map_base + static_cast<long long>(c < a ? c : c - 1) * Ma.len + p];
                 if (r == M2_NONE) continue;
                 const M2Member Mc = A.members[fm + c];
                 const int xc = UNITW ? 0 : dna5_code(A.seq[Mc.seq_off + r]);
                 const int wac = UNITW ? 1 : m2_w0(xa, xc, A.ma, A.mm);
-                if ((maskB >> c) & 1u) add(A.col[Mc.col_base + r], wac);   // the direct edge a - c
                 for (int b = 0; b < n; ++b) {
                     if (!((maskB >> b) & 1u) || b == c) continue;
                     const unsigned q = A.map[Mc.map_base + static_cast<long long>(b < c ? b : b - 1) * Mc.len + r];
@@ -229,7 +235,7 @@ __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
                         const int wcb = m2_w0(xc, dna5_code(A.seq[Mb.seq_off + q]), A.ma, A.mm);
                         w = wac < wcb ? wac : wcb;
                     }
-                    add(A.col[Mb.col_base + q], w);                         // a - c - b
+                    add(A.col[Mb.col_base + q], w);
                 }
             }
         }
@@ -243,7 +249,6 @@ __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
         A.row_cnt[G.row_base + i] = static_cast<uint16_t>(cnt);
         if (LDSLIST)
             for (int k = 0; k < cnt; ++k) mine[k] = s_ent[LDSLIST ? k : 0][lane];
-        if (over) A.ovf[g] = 1;
     }
 }
 
@@ -273,7 +278,10 @@ struct M2ChainTmp {   // (column, new node value) of the matches of one row betw
     unsigned long long* nv;
 };
 
-__global__ void __launch_bounds__(64) k_m2_chain(M2Args A, int round, int* tmp_j, unsigned long long* tmp_nv, const long long* tmp_base) {
+// GBIT: the tree lives in HBM (gbit, wcap + 1 nodes per group at row_base + g) instead of LDS -- profiles too wide for LDS.
+template <bool GBIT>
+__global__ void __launch_bounds__(64) k_m2_chain(M2Args A, int round, int* tmp_j, unsigned long long* tmp_nv, const long long* tmp_base,
+                                                 unsigned long long* gbit) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int g = blockIdx.x;
     const M2Group G = A.groups[g];
@@ -287,8 +295,9 @@ __global__ void __launch_bounds__(64) k_m2_chain(M2Args A, int round, int* tmp_j
     unsigned long long* const s_nv = s_stage + 64 * M2_STAGE;                                     // [M2_CAP]
     int* const s_j = reinterpret_cast<int*>(s_nv + M2_CAP);                                      // [M2_CAP]
     int* const s_cnt = s_j + M2_CAP;                                                             // [64]
-    unsigned long long* const bit = reinterpret_cast<unsigned long long*>(s_cnt + 64);            // [nB + 1]
+    unsigned long long* const bit = GBIT ? gbit + G.row_base + g : reinterpret_cast<unsigned long long*>(s_cnt + 64);   // [nB + 1]
     for (int x = lane; x <= nB; x += 64) bit[x] = 0;
+    if (GBIT) __threadfence();
     for (int i = lane; i < nA; i += 64) A.part[G.row_base + i] = -1;
     unsigned long long* const ent = A.row_ent + G.row_base * static_cast<long long>(cap);
     int* const gj = tmp_j ? tmp_j + tmp_base[g] : nullptr;                   // rows longer than M2_CAP (exact redo only)
@@ -569,7 +578,7 @@ struct M2Batch {
     int max_len = 0, max_wcap = 0, max_n = 0;
 };
 
-static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const int64_t* rel, bool exact) {
+static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const int64_t* rel, bool exact_cap, bool exact_w) {
     long long map_pos = 0, col_pos = 0, row_pos = 0, pos_pos = 0, dist_pos = 0;
     B.groups.clear(); B.members.clear(); B.member_group.clear(); B.jobs.clear();
     B.max_len = 0; B.max_wcap = 0; B.max_n = 0;
@@ -587,11 +596,12 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
             sum += len;
             mx = std::max(mx, len);
         }
-        const long long fast_w = 2LL * mx + 64;
-        G.wcap = static_cast<int>(std::min<long long>(sum, exact ? sum : fast_w));
+        const long long fast_w = 2 * mx + 64;   // profiles of same-molecule reads grow by 10-20 %; two molecules in one cluster still fit
+        // (65535 columns is the ceiling of spec v2: positions and the 16-level Fenwick tree; only reachable when the
+        // sum of the read lengths exceeds it AND the alignment really is that wide)
+        G.wcap = static_cast<int>(std::min<long long>(65535, std::min<long long>(sum, exact_w ? sum : fast_w)));
         if (G.wcap < 1) G.wcap = 1;
-        if (G.wcap > 65535) return fail("sarlacc_amd: an alignment of %d reads would need %d columns; spec v2 handles up to 65535", n, G.wcap);
-        G.cap = exact ? std::max(1, (n / 2) * ((n + 1) / 2) * std::max(1, n - 1)) : M2_CAP;
+        G.cap = exact_cap ? std::max(1, (n / 2) * ((n + 1) / 2) * std::max(1, n - 1)) : M2_CAP;
         G.row_base = row_pos;
         G.pos_base = pos_pos;
         G.first_job = static_cast<long long>(B.jobs.size());
@@ -707,9 +717,11 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     }
     const size_t chain_lds = sizeof(unsigned long long) * (64 * M2_STAGE + M2_CAP) + sizeof(int) * (M2_CAP + 64) +
                              sizeof(unsigned long long) * (static_cast<size_t>(B.max_wcap) + 2) + 16;
-    if (chain_lds > 160 * 1024) return fail("sarlacc_amd: an alignment of %d columns does not fit the chain kernel's LDS", B.max_wcap);
-    if (chain_lds > 48 * 1024)
-        SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_m2_chain), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(chain_lds)));
+    // Fenwick tree in LDS while eight waves still fit a CU, in HBM for wider profiles
+    const bool gbit = chain_lds > 20 * 1024;
+    const size_t chain_lds_used = gbit ? chain_lds - sizeof(unsigned long long) * (static_cast<size_t>(B.max_wcap) + 2) : chain_lds;
+    unsigned long long* d_gbit = nullptr;
+    if (gbit) SL_TRY(scratch((pf + ".gbit").c_str(), static_cast<size_t>(row_n) + ng + 1, &d_gbit));
     for (int round = 0; round + 1 < B.max_n; ++round) {
         const dim3 ggrid(m2_blocks(B.max_wcap, 64), static_cast<unsigned>(ng));
         if (!exact) {
@@ -719,7 +731,8 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
             if (unitw) hipLaunchKernelGGL((k_m2_gather<true, false>), ggrid, dim3(64), 0, s, a, round);
             else hipLaunchKernelGGL((k_m2_gather<false, false>), ggrid, dim3(64), 0, s, a, round);
         }
-        hipLaunchKernelGGL(k_m2_chain, dim3(static_cast<unsigned>(ng)), dim3(64), chain_lds, s, a, round, d_tmpj, d_tmpnv, d_tmpbase);
+        if (gbit) hipLaunchKernelGGL(k_m2_chain<true>, dim3(static_cast<unsigned>(ng)), dim3(64), chain_lds_used, s, a, round, d_tmpj, d_tmpnv, d_tmpbase, d_gbit);
+        else hipLaunchKernelGGL(k_m2_chain<false>, dim3(static_cast<unsigned>(ng)), dim3(64), chain_lds_used, s, a, round, d_tmpj, d_tmpnv, d_tmpbase, d_gbit);
         hipLaunchKernelGGL(k_m2_merge, dim3(static_cast<unsigned>(ng)), dim3(256), 0, s, a, round, d_nca, d_ncb, d_pb);
         SL_HIP(hipGetLastError());
         if (std::getenv("SARLACC_MSA2_DEBUG")) {   // first group of the batch, for comparison with ORC_MSA2_DEBUG of the oracle
@@ -824,81 +837,76 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             B.ids.push_back(g);
             ++q1;
         }
-        SL_TRY(m2_plan(B, grp_off, grp, rel.data(), false));
+        SL_TRY(m2_plan(B, grp_off, grp, rel.data(), false, false));
         SL_TRY(m2_run_batch(B, "m2", d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, false, first ? overlap : nullptr, &cells, s));
         first = false;
         pairs += static_cast<double>(B.jobs.size());
-        // groups that outgrew the fast capacities: exact redo, a few at a time
-        std::vector<size_t> redo;
+        // Groups whose profiles outgrew the fast capacity (unrelated reads in one cluster) are redone with profiles
+        // as wide as the sum of the read lengths.  Every redo batch keeps its own workspaces until its rows are written.
+        std::vector<size_t> cur;
         for (size_t q = 0; q < B.groups.size(); ++q)
-            if (B.ovf[q]) redo.push_back(q);
-        std::vector<M2Batch> exact;
-        for (size_t r0 = 0; r0 < redo.size();) {
-            exact.emplace_back();
-            M2Batch& X = exact.back();
-            long long ent_x = 0;
-            size_t r1 = r0;
-            while (r1 < redo.size()) {
-                const M2Group& G = B.groups[redo[r1]];
-                long long sum = 0;
-                for (int a = 0; a < G.n; ++a) sum += B.members[G.first_member + a].len;
-                const long long capx = std::max(1, (G.n / 2) * ((G.n + 1) / 2) * std::max(1, G.n - 1));
-                const long long eb = sum * capx * 8;
-                if (r1 > r0 && ent_x + eb > ent_budget) break;
-                ent_x += eb;
-                X.ids.push_back(B.ids[redo[r1]]);
-                ++r1;
-            }
-            r0 = r1;
-        }
-        // widths and offsets of the batch (exact results replace the flagged ones)
-        std::vector<char> flagged(B.groups.size(), 0);
-        for (size_t q : redo) flagged[q] = 1;
-        size_t xi = 0;
-        for (M2Batch& X : exact) {
-            SL_TRY(m2_plan(X, grp_off, grp, rel.data(), true));
-            // every exact batch keeps its own workspaces until its rows are written
-            const std::string pf = "m2x" + std::to_string(xi++);
-            SL_TRY(m2_run_batch(X, pf, d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, true, nullptr, &cells, s));
-            for (size_t q = 0; q < X.groups.size(); ++q)
-                if (X.ovf[q]) return fail("sarlacc_amd: internal error: exact MSA capacities exceeded");
-        }
-        {
-            size_t xb = 0, xq = 0;
-            for (size_t q = 0; q < B.groups.size(); ++q) {
-                int32_t w = B.width[q];
-                if (flagged[q]) {
-                    while (xq >= exact[xb].groups.size()) { ++xb; xq = 0; }
-                    w = exact[xb].width[xq++];
+            if (B.ovf[q]) cur.push_back(q);
+        std::vector<M2Batch> xb;
+        std::vector<std::vector<size_t>> xsrc;                 // fast-batch index of every group of a redo batch
+        std::vector<std::pair<int, int>> final_of(B.groups.size(), std::make_pair(-1, -1));   // (redo batch, group in it)
+        for (int level = 1; level < 2 && !cur.empty(); ++level) {   // (one level: the lists are bounded by the spec)
+            std::vector<size_t> next;
+            for (size_t r0 = 0; r0 < cur.size();) {
+                xb.emplace_back();
+                xsrc.emplace_back();
+                M2Batch& X = xb.back();
+                long long ent_x = 0;
+                size_t r1 = r0;
+                while (r1 < cur.size()) {
+                    const M2Group& G = B.groups[cur[r1]];
+                    long long sum = 0, mx = 0;
+                    for (int a = 0; a < G.n; ++a) { sum += B.members[G.first_member + a].len; mx = std::max<long long>(mx, B.members[G.first_member + a].len); }
+                    (void)mx;
+                    const long long eb = sum * M2_CAP * 8;
+                    if (r1 > r0 && ent_x + eb > ent_budget) break;
+                    ent_x += eb;
+                    X.ids.push_back(B.ids[cur[r1]]);
+                    xsrc.back().push_back(cur[r1]);
+                    ++r1;
                 }
-                width[q0 + q] = w;
-                off[q0 + q + 1] = off[q0 + q] + static_cast<long long>(w) * B.groups[q].n;
+                r0 = r1;
+                const int bi = static_cast<int>(xb.size()) - 1;
+                SL_TRY(m2_plan(X, grp_off, grp, rel.data(), false, true));
+                SL_TRY(m2_run_batch(X, "m2x" + std::to_string(bi), d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, false, nullptr, &cells, s));
+                for (size_t q = 0; q < X.groups.size(); ++q) {
+                    if (X.ovf[q]) next.push_back(xsrc[bi][q]);
+                    else final_of[xsrc[bi][q]] = std::make_pair(bi, static_cast<int>(q));
+                }
             }
+            cur.swap(next);
+        }
+        if (!cur.empty()) return fail("sarlacc_amd: an alignment wider than 65535 columns is beyond spec v2 (select spec 1 with sarlacc_set_msa_spec)");
+        for (size_t q = 0; q < B.groups.size(); ++q) {
+            const int32_t w = final_of[q].first >= 0 ? xb[final_of[q].first].width[final_of[q].second] : B.width[q];
+            width[q0 + q] = w;
+            off[q0 + q + 1] = off[q0 + q] + static_cast<long long>(w) * B.groups[q].n;
         }
         const long long need = off[q1];
         SL_TRY(rows_reserve(static_cast<size_t>(used), static_cast<size_t>(need) + 1));
         uint8_t* const d_out = static_cast<uint8_t*>(rows_ws.ptr);
         {
-            // the fast batch writes every unflagged group; flagged ones get width 0 there
-            std::vector<long long> boff(B.groups.size());
-            std::vector<int32_t> bw = B.width;
-            for (size_t q = 0; q < B.groups.size(); ++q) { boff[q] = off[q0 + q]; if (flagged[q]) bw[q] = 0; }
-            int32_t* d_w = B.a.width;
-            SL_HIP(hipMemcpyAsync(d_w, bw.data(), sizeof(int32_t) * bw.size(), hipMemcpyHostToDevice, s));
-            B.width = bw;
-            SL_TRY(m2_write_batch(B, "m2", boff, d_out, s));
-            size_t xb = 0;
-            size_t cursor = 0;
-            for (M2Batch& X : exact) {
-                std::vector<long long> xoff(X.groups.size());
+            // every batch writes the groups it resolved; the others get width 0 there
+            auto write = [&](M2Batch& X, const std::string& pf, const std::vector<size_t>* src, int bi) -> int {
+                std::vector<long long> boff(X.groups.size(), 0);
+                std::vector<int32_t> bw = X.width;
                 for (size_t q = 0; q < X.groups.size(); ++q) {
-                    while (!flagged[cursor]) ++cursor;
-                    xoff[q] = off[q0 + cursor];
-                    ++cursor;
+                    const size_t fq = src ? (*src)[q] : q;
+                    const bool mine = src ? (final_of[fq].first == bi && final_of[fq].second == static_cast<int>(q)) : final_of[fq].first < 0;
+                    if (mine) boff[q] = off[q0 + fq]; else bw[q] = 0;
                 }
-                SL_TRY(m2_write_batch(X, "m2x" + std::to_string(xb++), xoff, d_out, s));
-            }
-            SL_HIP(hipStreamSynchronize(s));   // host vectors of this batch go out of scope
+                SL_HIP(hipMemcpyAsync(X.a.width, bw.data(), sizeof(int32_t) * bw.size(), hipMemcpyHostToDevice, s));
+                X.width = bw;
+                SL_TRY(m2_write_batch(X, pf, boff, d_out, s));
+                SL_HIP(hipStreamSynchronize(s));   // bw / boff are read by the copies above
+                return 0;
+            };
+            SL_TRY(write(B, "m2", nullptr, -1));
+            for (size_t bi = 0; bi < xb.size(); ++bi) SL_TRY(write(xb[bi], "m2x" + std::to_string(bi), &xsrc[bi], static_cast<int>(bi)));
         }
         used = need;
         q0 = q1;
