@@ -42,7 +42,6 @@ namespace sarlacc {
 
 constexpr int M2_MAXN = 32;          // group sizes aligned by spec v2 (member sets are 32-bit masks)
 constexpr int M2_CAP = 16;           // partner columns per row on the fast path (private lists in LDS)
-constexpr int M2_STAGE = 4;          // entries per row staged in LDS by the chain kernel
 constexpr unsigned M2_NONE = 0xFFFFu;
 
 struct M2Member {         // one read of a group
@@ -80,7 +79,8 @@ struct M2Args {
     int* col;
     uint16_t* pos;
     uint16_t* row_cnt;             // entries in a row's list
-    unsigned long long* row_ent;   // (partner column << 32) | weight, later | predecessor id
+    unsigned long long* row_ent;   // (partner column << 32) | weight
+    unsigned* row_pred;            // id of the predecessor of every entry on its best chain (0: none)
     int* part;                     // partner column of column i of the first child, -1 if unmatched
     int* ovf;                      // per group: a capacity was exceeded
     int32_t* width;                // per group: columns of the final profile
@@ -176,11 +176,17 @@ __global__ void k_m2_init(M2Args A, const int* member_group, int nmembers) {
 }
 
 // ---- match lists of one merge round ----
-// LDSLIST: private lists of M2_CAP entries in LDS (fast path); otherwise the lists are built in place in
-// row_ent with the group's own capacity (exact redo of groups that overflowed).
-template <bool UNITW, bool LDSLIST>
+// lane = column i of the first child.  The row's list (first M2_CAP distinct partner columns in the canonical
+// enumeration order of spec v2, step 5: a ascending; direct edges b ascending; then c ascending, b ascending)
+// lives in registers; a candidate is compared with the first entries before anything else (same-molecule reads
+// agree on 1-3 columns).  Loads are issued in independent batches: the positions r_c of every third sequence
+// first (LDS), then up to M2_BATCH (c, b) pairs at a time -- the dependent chain map -> map -> col of one
+// candidate is three memory latencies long, so the pairs of a batch are looked up side by side.
+constexpr int M2_BATCH = 8;
+
+template <bool UNITW>
 __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
-    __shared__ unsigned long long s_ent[LDSLIST ? M2_CAP : 1][64];
+    __shared__ uint16_t s_r[M2_MAXN][64];   // position of the lane's base in every other member (0xFFFF: gap)
     const int g = blockIdx.y;
     const M2Group G = A.groups[g];
     if (round >= G.n - 1) return;
@@ -188,76 +194,130 @@ __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
     const int2 jn = A.joins[fm + round];
     const unsigned maskA = A.nodemask[2 * fm + jn.x], maskB = A.nodemask[2 * fm + jn.y];
     const int nA = A.ncols[2 * fm + jn.x];
-    if (blockIdx.x * 64 >= nA) return;
     const int lane = threadIdx.x;
-    const int i = blockIdx.x * 64 + lane;
-    const int cap = LDSLIST ? M2_CAP : G.cap;
-    unsigned long long* const mine = A.row_ent + (G.row_base + i) * static_cast<long long>(G.cap);
+    for (int i0 = blockIdx.x * 64; i0 < nA; i0 += gridDim.x * 64) {
+    const int i = i0 + lane;
+    int ej[M2_CAP], ew[M2_CAP];
+#pragma unroll
+    for (int k = 0; k < M2_CAP; ++k) { ej[k] = -1; ew[k] = 0; }
     int cnt = 0;
-    auto ent_get = [&](int k) -> unsigned long long { return LDSLIST ? s_ent[LDSLIST ? k : 0][lane] : mine[k]; };
-    auto ent_set = [&](int k, unsigned long long v) { if (LDSLIST) s_ent[LDSLIST ? k : 0][lane] = v; else mine[k] = v; };
-    auto add = [&](int j, int w) {
-        for (int k = 0; k < cnt; ++k) {
-            const unsigned long long e = ent_get(k);
-            if (static_cast<int>(e >> 32) == j) { ent_set(k, e + static_cast<unsigned>(w)); return; }
-        }
-        // a column beyond the row's first M2_CAP distinct ones is ignored (spec v2, step 5)
-        if (cnt < cap) ent_set(cnt++, (static_cast<unsigned long long>(static_cast<unsigned>(j)) << 32) | static_cast<unsigned>(w));
-    };
-    if (i < nA) {
-        for (int a = 0; a < n; ++a) {
-            if (!((maskA >> a) & 1u)) continue;
-            const unsigned p = A.pos[G.pos_base + static_cast<long long>(a) * G.wcap + i];
-            if (p == M2_NONE) continue;
-            const M2Member Ma = A.members[fm + a];
-            const int xa = UNITW ? 0 : dna5_code(A.seq[Ma.seq_off + p]);
-            for (int b = 0; b < n; ++b) {              // the direct edges a - b first
-                if (!((maskB >> b) & 1u)) continue;
-                const unsigned q = A.map[Ma.map_base + static_cast<long long>(b < a ? b : b - 1) * Ma.len + p];
-                if (q == M2_NONE) continue;
-                const M2Member Mb = A.members[fm + b];
-                add(A.col[Mb.col_base + q], UNITW ? 1 : m2_w0(xa, dna5_code(A.seq[Mb.seq_off + q]), A.ma, A.mm));
+    auto add = [&](int j, int w, bool valid) {
+        bool hit = !valid;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (!hit && ej[k] == j) { ew[k] += w; hit = true; }
+        if (__ballot(!hit)) {
+#pragma unroll
+            for (int k = 3; k < M2_CAP; ++k)
+                if (!hit && ej[k] == j) { ew[k] += w; hit = true; }
+            if (!hit && cnt < M2_CAP) {   // a new column; beyond M2_CAP distinct columns it is ignored (spec v2, step 5)
+#pragma unroll
+                for (int k = 0; k < M2_CAP; ++k)
+                    if (k == cnt) { ej[k] = j; ew[k] = w; }
+                ++cnt;
             }
-            for (int c = 0; c < n; ++c) {              // then a - c - b
-                if (c == a) continue;
-                const unsigned r = A.map[Ma.map_base + static_cast<long long>(c < a ? c : c - 1) * Ma.len + p];
-                if (r == M2_NONE) continue;
-                const M2Member Mc = A.members[fm + c];
-                const int xc = UNITW ? 0 : dna5_code(A.seq[Mc.seq_off + r]);
-                const int wac = UNITW ? 1 : m2_w0(xa, xc, A.ma, A.mm);
-                for (int b = 0; b < n; ++b) {
-                    if (!((maskB >> b) & 1u) || b == c) continue;
-                    const unsigned q = A.map[Mc.map_base + static_cast<long long>(b < c ? b : b - 1) * Mc.len + r];
-                    if (q == M2_NONE) continue;
-                    const M2Member Mb = A.members[fm + b];
-                    int w = 1;
-                    if (!UNITW) {
-                        const int wcb = m2_w0(xc, dna5_code(A.seq[Mb.seq_off + q]), A.ma, A.mm);
-                        w = wac < wcb ? wac : wcb;
-                    }
-                    add(A.col[Mb.col_base + q], w);
+        }
+    };
+    const bool row = i < nA;
+    for (int a = 0; a < n; ++a) {
+        if (!((maskA >> a) & 1u)) continue;
+        const unsigned p = row ? A.pos[G.pos_base + static_cast<long long>(a) * G.wcap + i] : M2_NONE;
+        const bool havep = p != M2_NONE;
+        if (!__ballot(havep)) continue;
+        const M2Member Ma = A.members[fm + a];
+        const int xa = (UNITW || !havep) ? 0 : dna5_code(A.seq[Ma.seq_off + p]);
+        // positions in every other member (independent loads)
+        for (int c = 0; c < n; ++c)
+            s_r[c][lane] = (c != a && havep) ? A.map[Ma.map_base + static_cast<long long>(c < a ? c : c - 1) * Ma.len + p] : static_cast<uint16_t>(M2_NONE);
+        // canonical order of the candidates: (c = b, b) for b in B ascending, then (c, b) for c ascending, b in B
+        // ascending, b != c.  Wave-uniform generator, M2_BATCH candidates looked up side by side.
+        int pc = -1, pb = -1;        // state of the generator: phase 0 (direct) uses pc == -1
+        bool more = true;
+        auto next = [&](int& c, int& b) -> bool {   // advances (pc, pb) to the next candidate
+            for (;;) {
+                ++pb;
+                while (pb < n && !((maskB >> pb) & 1u)) ++pb;
+                if (pb < n) {
+                    if (pc < 0) { c = pb; b = pb; return true; }          // direct edge a - b
+                    if (pb == pc) continue;
+                    c = pc; b = pb; return true;
+                }
+                pb = -1;
+                ++pc;
+                while (pc < n && pc == a) ++pc;
+                if (pc >= n) return false;
+            }
+        };
+        while (more) {
+            int cc[M2_BATCH], bb[M2_BATCH];
+            int nb = 0;
+#pragma unroll
+            for (int u = 0; u < M2_BATCH; ++u) {
+                cc[u] = 0; bb[u] = 0;
+                if (more) {
+                    int c, b;
+                    if (next(c, b)) { cc[u] = c; bb[u] = b; nb = u + 1; }
+                    else more = false;
                 }
             }
+            unsigned rr[M2_BATCH], qq[M2_BATCH];
+            int jj[M2_BATCH], ww[M2_BATCH];
+#pragma unroll
+            for (int u = 0; u < M2_BATCH; ++u) {
+                rr[u] = M2_NONE; qq[u] = M2_NONE;
+                if (u < nb) {
+                    rr[u] = s_r[cc[u]][lane];
+                    if (rr[u] != M2_NONE) {
+                        if (cc[u] == bb[u]) qq[u] = rr[u];
+                        else {
+                            const M2Member Mc = A.members[fm + cc[u]];
+                            qq[u] = A.map[Mc.map_base + static_cast<long long>(bb[u] < cc[u] ? bb[u] : bb[u] - 1) * Mc.len + rr[u]];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < M2_BATCH; ++u) {
+                jj[u] = -1; ww[u] = 1;
+                if (u < nb && qq[u] != M2_NONE) {
+                    const M2Member Mb = A.members[fm + bb[u]];
+                    jj[u] = A.col[Mb.col_base + qq[u]];
+                    if (!UNITW) {
+                        const M2Member Mc = A.members[fm + cc[u]];
+                        const int xc = dna5_code(A.seq[Mc.seq_off + rr[u]]);
+                        const int wac = m2_w0(xa, xc, A.ma, A.mm);
+                        if (cc[u] == bb[u]) ww[u] = wac;
+                        else {
+                            const int wcb = m2_w0(xc, dna5_code(A.seq[Mb.seq_off + qq[u]]), A.ma, A.mm);
+                            ww[u] = wac < wcb ? wac : wcb;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < M2_BATCH; ++u)
+                if (u < nb) add(jj[u], ww[u], jj[u] >= 0);
         }
-        // sort by column (insertion sort; the lists are short)
-        for (int k = 1; k < cnt; ++k) {
-            const unsigned long long e = ent_get(k);
-            int q = k - 1;
-            while (q >= 0 && (ent_get(q) >> 32) > (e >> 32)) { ent_set(q + 1, ent_get(q)); --q; }
-            ent_set(q + 1, e);
+    }
+    if (row) {
+        // by column: rank of every entry among the valid ones (the columns of a list are distinct)
+        unsigned long long* const mine = A.row_ent + (G.row_base + i) * static_cast<long long>(G.cap);
+#pragma unroll
+        for (int k = 0; k < M2_CAP; ++k) {
+            if (k < cnt) {
+                int rank = 0;
+#pragma unroll
+                for (int q = 0; q < M2_CAP; ++q)
+                    if (q < cnt && ej[q] < ej[k]) ++rank;
+                mine[rank] = (static_cast<unsigned long long>(static_cast<unsigned>(ej[k])) << 32) | static_cast<unsigned>(ew[k]);
+            }
         }
         A.row_cnt[G.row_base + i] = static_cast<uint16_t>(cnt);
-        if (LDSLIST)
-            for (int k = 0; k < cnt; ++k) mine[k] = s_ent[LDSLIST ? k : 0][lane];
+    }
     }
 }
 
-// ---- heaviest chain of one merge round: one wavefront per group ----
-// Fenwick tree over the second child's columns in LDS: node = (f << 32) | ~id, so that the maximum prefers
-// the larger f and then the earlier match (id = row * cap + index in the row + 1; 0 = no match).  A match
-// with column j reads the prefix maximum of nodes j, j - lowbit(j), .. (columns < j) and afterwards raises
-// nodes j + 1, (j + 1) + lowbit, ..; sub-groups of 16 lanes serve one match each, one node per lane.  All
-// matches of a row are queried before any of them is entered.
+// maximum of a 64-bit value over the 16 lanes of a DPP row
 __device__ __forceinline__ unsigned long long m2_rowmax16(unsigned long long v) {
     // maximum over the 16 lanes of a DPP row, delivered to every lane of the row (row_ror 8, 4, 2, 1)
 #define M2_STEP(CTRL)                                                                                                         \
@@ -273,128 +333,147 @@ __device__ __forceinline__ unsigned long long m2_rowmax16(unsigned long long v) 
     return v;
 }
 
-struct M2ChainTmp {   // (column, new node value) of the matches of one row between the query and the update pass
-    int* j;
-    unsigned long long* nv;
-};
+// ---- heaviest chain of one merge round: four groups per wavefront, 16 lanes each ----
+// Node value = (f << 32) | ~id, so that the maximum prefers the larger f and then the earlier match
+// (id = row * M2_CAP + index in the row + 1; 0 = no match).  All matches of a row are looked up before any of
+// them is entered.
+// P[l] = best node value (f << 32 | ~id) over the matches entered so far with column <= l: a non-decreasing
+// step function of l.  It is stored explicitly up to `top`, the largest column entered so far (beyond it the
+// value is P[top]), so a match with column j reads P[j - 1] -- one access, no tree -- and entering it raises P on
+// the columns from j upwards for as long as they are smaller (a short run: the chain advances with the columns).
+// The 16 lanes of a group serve the 16 entries of one row.  P is a circular window of M2_PWIN columns in LDS
+// (same-molecule profiles stay within a few columns of `top`); a group whose matches reach below the window
+// is flagged (ovf = 3) and redone by the launch with P complete in HBM (GLOBALP).
+constexpr int M2_PWIN = 512;
 
-// GBIT: the tree lives in HBM (gbit, wcap + 1 nodes per group at row_base + g) instead of LDS -- profiles too wide for LDS.
-template <bool GBIT>
-__global__ void __launch_bounds__(64) k_m2_chain(M2Args A, int round, int* tmp_j, unsigned long long* tmp_nv, const long long* tmp_base,
-                                                 unsigned long long* gbit) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int g = blockIdx.x;
-    const M2Group G = A.groups[g];
-    if (round >= G.n - 1) return;
-    const int fm = G.first_member;
-    const int2 jn = A.joins[fm + round];
-    const int nA = A.ncols[2 * fm + jn.x], nB = A.ncols[2 * fm + jn.y];
-    const int lane = threadIdx.x;
-    const int cap = G.cap;
-    unsigned long long* const s_stage = reinterpret_cast<unsigned long long*>(smem);            // [64][M2_STAGE]
-    unsigned long long* const s_nv = s_stage + 64 * M2_STAGE;                                     // [M2_CAP]
-    int* const s_j = reinterpret_cast<int*>(s_nv + M2_CAP);                                      // [M2_CAP]
-    int* const s_cnt = s_j + M2_CAP;                                                             // [64]
-    unsigned long long* const bit = GBIT ? gbit + G.row_base + g : reinterpret_cast<unsigned long long*>(s_cnt + 64);   // [nB + 1]
-    for (int x = lane; x <= nB; x += 64) bit[x] = 0;
-    if (GBIT) __threadfence();
-    for (int i = lane; i < nA; i += 64) A.part[G.row_base + i] = -1;
-    unsigned long long* const ent = A.row_ent + G.row_base * static_cast<long long>(cap);
-    int* const gj = tmp_j ? tmp_j + tmp_base[g] : nullptr;                   // rows longer than M2_CAP (exact redo only)
-    unsigned long long* const gnv = tmp_nv ? tmp_nv + tmp_base[g] : nullptr;
-    const int sub = lane >> 4, t = lane & 15;   // 4 sub-groups of 16 lanes: one match each
-    const unsigned nBu = static_cast<unsigned>(nB);
-    unsigned long long best = 0;                // per sub-group running maximum (the chain's last match)
-    __syncthreads();
-    for (int i0 = 0; i0 < nA; i0 += 64) {
-        // stage the counts and the first M2_STAGE entries of 64 rows
-        __syncthreads();
-        s_cnt[lane] = (i0 + lane < nA) ? static_cast<int>(A.row_cnt[G.row_base + i0 + lane]) : 0;
-        __syncthreads();
-        for (int idx = lane; idx < 64 * M2_STAGE; idx += 64) {
-            const int r = idx / M2_STAGE, k = idx % M2_STAGE;
-            if (k < s_cnt[r]) s_stage[idx] = ent[static_cast<long long>(i0 + r) * cap + k];
-        }
-        __syncthreads();
-        const int rows = min(64, nA - i0);
-        for (int r = 0; r < rows; ++r) {
-            const int c = min(__builtin_amdgcn_readfirstlane(s_cnt[r]), cap);
-            if (c == 0) continue;
-            const int i = i0 + r;
-            for (int k0 = 0; k0 < c; k0 += 4) {          // queries
-                const int k = k0 + sub;
-                const bool act = k < c;
-                unsigned long long e = 0;
-                if (act) e = k < M2_STAGE ? s_stage[r * M2_STAGE + k] : ent[static_cast<long long>(i) * cap + k];
-                const int j = static_cast<int>(e >> 32);
-                unsigned x = act ? static_cast<unsigned>(j) : 0u;
+__device__ __forceinline__ int m2_qmax_i32(int v) {   // maximum over the 16 lanes of a DPP row, in every lane
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+template <bool GLOBALP>
+__global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nactive, unsigned long long* gP, const int* only_flagged) {
+    __shared__ unsigned long long s_buf[4][GLOBALP ? 256 : (M2_PWIN > 256 ? M2_PWIN : 256)];   // P window, later the traceback stage
+    const int lane = threadIdx.x, qd = lane >> 4, t = lane & 15;
+    const int g = blockIdx.x * 4 + qd;
+    bool act = g < nactive;
+    M2Group G{};
+    if (act) G = A.groups[g];
+    if (act && round >= G.n - 1) act = false;
+    if (act && only_flagged && only_flagged[g] != 3) act = false;   // second launch: only the groups the window failed
+    int nA = 0, nB = 0;
+    if (act) {
+        const int2 jn = A.joins[G.first_member + round];
+        nA = A.ncols[2 * G.first_member + jn.x];
+        nB = A.ncols[2 * G.first_member + jn.y];
+    }
+    (void)nB;
+    unsigned long long* const P = GLOBALP ? gP + G.row_base + g : &s_buf[qd][0];
+    auto pidx = [&](int l) -> int { return GLOBALP ? l : (l & (M2_PWIN - 1)); };
+    // HBM form: the loads must not be served by this CU's L1 (the atomics act in L2)
+    auto pload = [&](int l) -> unsigned long long {
+        if (GLOBALP) return __hip_atomic_load(&P[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return P[pidx(l)];
+    };
+    auto pstore = [&](int l, unsigned long long v) {
+        if (GLOBALP) __hip_atomic_store(&P[l], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else P[pidx(l)] = v;
+    };
+    unsigned long long* const ent = A.row_ent + G.row_base * static_cast<long long>(M2_CAP);
+    unsigned* const prd = A.row_pred + G.row_base * static_cast<long long>(M2_CAP);
+    for (int i = t; i < nA; i += 16) A.part[G.row_base + i] = -1;
+    int top = -1;
+    unsigned long long ptop = 0, best = 0;
+    bool bad = false;
+    const int nAmax = max(max(__shfl(nA, 0), __shfl(nA, 16)), max(__shfl(nA, 32), __shfl(nA, 48)));
+    // rows in blocks of 16: lane t holds entry t of each of the block's rows, and the count of row ib + t
+    unsigned long long eb[16];
+    int cb = 0;
+    auto load_block = [&](int ib, unsigned long long (&e)[16], int& c) {
 #pragma unroll
-                for (int s = 0; s < 15; ++s) x = (s < t) ? (x & (x - 1u)) : x;
-                unsigned long long v = x ? bit[x] : 0ull;
-                v = m2_rowmax16(v);
-                const unsigned f = static_cast<unsigned>(e) + static_cast<unsigned>(v >> 32);
-                const unsigned pred = v ? ~static_cast<unsigned>(v) : 0u;
-                const unsigned id = static_cast<unsigned>(i) * static_cast<unsigned>(cap) + static_cast<unsigned>(k) + 1u;
-                const unsigned long long nv = (static_cast<unsigned long long>(f) << 32) | static_cast<unsigned>(~id);
-                if (act) {
-                    best = nv > best ? nv : best;
-                    if (t == 0) {
-                        ent[static_cast<long long>(i) * cap + k] = (e & 0xffffffff00000000ull) | pred;
-                        if (k < M2_CAP) { s_j[k] = j; s_nv[k] = nv; }
-                        else { gj[k] = j; gnv[k] = nv; }
-                    }
+        for (int r = 0; r < 16; ++r) e[r] = (ib + r < nA) ? ent[static_cast<long long>(ib + r) * M2_CAP + t] : 0ull;
+        c = (ib + t < nA) ? static_cast<int>(A.row_cnt[G.row_base + ib + t]) : 0;
+    };
+    load_block(0, eb, cb);
+    for (int ib = 0; ib < nAmax; ib += 16) {
+        unsigned long long en[16];
+        int cn = 0;
+        load_block(ib + 16, en, cn);   // next block in flight while this one is processed
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = ib + r;
+            const int c = __shfl(cb, r, 16);
+            const bool mk = act && !bad && i < nA && t < c;
+            const unsigned long long e = eb[r];
+            const int j = static_cast<int>(e >> 32);
+            // query: best over the columns < j, state before the row
+            unsigned long long v = 0;
+            if (mk && j > 0) {
+                const int l = j - 1;
+                if (l > top) v = ptop;
+                else if (!GLOBALP && l <= top - M2_PWIN) bad = true;
+                else v = pload(l);
+            }
+            const unsigned f = static_cast<unsigned>(e) + static_cast<unsigned>(v >> 32);
+            const unsigned pred = v ? ~static_cast<unsigned>(v) : 0u;
+            const unsigned id = static_cast<unsigned>(i) * M2_CAP + static_cast<unsigned>(t) + 1u;
+            const unsigned long long nv = (static_cast<unsigned long long>(f) << 32) | static_cast<unsigned>(~id);
+            if (mk) {
+                prd[static_cast<long long>(i) * M2_CAP + t] = pred;
+                best = nv > best ? nv : best;
+            }
+            // the explicit part of P grows to the row's largest column (filled with the old plateau value)
+            const int newtop = m2_qmax_i32(mk ? j : -1);
+            if (newtop > top) {
+                for (int l = max(top + 1, GLOBALP ? 0 : newtop - M2_PWIN + 1) + t; l <= newtop; l += 16) pstore(l, ptop);
+                top = newtop;
+            }
+            if (!GLOBALP && mk && j <= top - M2_PWIN) bad = true;
+            bad = m2_qmax_i32(bad ? 1 : 0) != 0;
+            // enter the matches: raise P from column j upwards while it is smaller
+            if (mk && !bad) {
+                for (int l = j; l <= top; ++l) {
+                    if (pload(l) >= nv) break;
+                    atomicMax(&P[pidx(l)], nv);
                 }
             }
-            if (c > M2_CAP) __threadfence();
-            __syncthreads();
-            for (int k0 = 0; k0 < c; k0 += 4) {          // updates
-                const int k = k0 + sub;
-                if (k < c) {
-                    const int j = k < M2_CAP ? s_j[k] : gj[k];
-                    const unsigned long long nv = k < M2_CAP ? s_nv[k] : gnv[k];
-                    unsigned y = static_cast<unsigned>(j) + 1u;
-#pragma unroll
-                    for (int s = 0; s < 15; ++s) y = (s < t && y <= nBu) ? y + (y & (0u - y)) : y;
-                    if (y <= nBu) atomicMax(&bit[y], nv);
-                }
-            }
-            __syncthreads();
+            if (top >= 0 && act && !bad && i < nA) ptop = pload(top);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) eb[r] = en[r];
+        cb = cn;
     }
-    // the chain's last match: maximum over the four sub-groups
-    {
-        const unsigned long long o1 = (static_cast<unsigned long long>(static_cast<unsigned>(__shfl_xor(static_cast<int>(best >> 32), 16))) << 32) |
-                                      static_cast<unsigned>(__shfl_xor(static_cast<int>(best), 16));
-        best = o1 > best ? o1 : best;
-        const unsigned long long o2 = (static_cast<unsigned long long>(static_cast<unsigned>(__shfl_xor(static_cast<int>(best >> 32), 32))) << 32) |
-                                      static_cast<unsigned>(__shfl_xor(static_cast<int>(best), 32));
-        best = o2 > best ? o2 : best;
-    }
-    best = (static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(best >> 32)))) << 32) |
-           static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(best)));
-    // traceback through the stored predecessors, 64 rows staged at a time
+    if (act && bad && t == 0) A.ovf[g] = 3;
+    if (!act || bad) { nA = 0; best = 0; }
+    best = m2_rowmax16(best);   // the chain's last match
+    if (act && !bad && only_flagged && t == 0) A.ovf[g] = 0;   // redone with the complete P
+    // traceback through the stored predecessors, 16 rows staged at a time (the P window is free now)
     __threadfence();
+    unsigned long long* const stage = &s_buf[qd][0];   // [16 rows][16 entries]
     unsigned id = best ? ~static_cast<unsigned>(best) : 0u;
-    int steps = 2 * nA + 64;   // a chain has at most one match per row; staging a block also counts one step
-    while (id && --steps >= 0) {
-        const int itop = static_cast<int>((id - 1u) / static_cast<unsigned>(cap));
-        const int i0 = max(0, itop - 63);
-        __syncthreads();
-        s_cnt[lane] = (i0 + lane <= itop) ? static_cast<int>(A.row_cnt[G.row_base + i0 + lane]) : 0;
-        __syncthreads();
-        for (int idx = lane; idx < 64 * M2_STAGE; idx += 64) {
-            const int r = idx / M2_STAGE, k = idx % M2_STAGE;
-            if (k < s_cnt[r]) s_stage[idx] = ent[static_cast<long long>(i0 + r) * cap + k];
+    int steps = 2 * nA + 64;
+    while (__builtin_amdgcn_ballot_w64(id != 0 && steps > 0)) {
+        const bool go = id != 0 && steps > 0;
+        const int itop = go ? static_cast<int>((id - 1u) / M2_CAP) : 0;
+        const int i0 = max(0, itop - 15);
+        if (go) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stage[r * 16 + t] = (i0 + r <= itop) ? ((ent[static_cast<long long>(i0 + r) * M2_CAP + t] & 0xffffffff00000000ull) | prd[static_cast<long long>(i0 + r) * M2_CAP + t]) : 0ull;
         }
-        __syncthreads();
-        while (id && --steps >= 0) {
-            const int i = static_cast<int>((id - 1u) / static_cast<unsigned>(cap)), k = static_cast<int>((id - 1u) % static_cast<unsigned>(cap));
-            if (i < i0) break;
-            unsigned long long e = k < M2_STAGE ? s_stage[(i - i0) * M2_STAGE + k] : ent[static_cast<long long>(i) * cap + k];
-            e = (static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(e >> 32)))) << 32) |
-                static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(e)));
-            if (lane == 0) A.part[G.row_base + i] = static_cast<int>(e >> 32);
-            id = static_cast<unsigned>(e);
+        --steps;
+        while (__builtin_amdgcn_ballot_w64(go && id != 0 && steps > 0 && static_cast<int>((id - 1u) / M2_CAP) >= i0)) {
+            const bool in = go && id != 0 && steps > 0 && static_cast<int>((id - 1u) / M2_CAP) >= i0;
+            if (in) {
+                const int i = static_cast<int>((id - 1u) / M2_CAP), k = static_cast<int>((id - 1u) % M2_CAP);
+                const unsigned long long e = stage[(i - i0) * 16 + k];
+                if (t == 0) A.part[G.row_base + i] = static_cast<int>(e >> 32);
+                id = static_cast<unsigned>(e);
+                --steps;
+            }
         }
     }
 }
@@ -566,7 +645,8 @@ static inline unsigned m2_blocks(long long n, int bs) { return static_cast<unsig
 // that outgrow them come back in `redo`.  exact = true: worst-case capacities, nothing can overflow.
 // Leaves the batch's state (pos, members ...) in the "m2*" workspaces with prefix `pf` for the row writer.
 struct M2Batch {
-    std::vector<int64_t> ids;
+    std::vector<int64_t> ids;      // caller's group indices, by decreasing group size
+    std::vector<size_t> slot;      // position of each in the caller's order (msa2_core)
     std::vector<M2Group> groups;
     std::vector<M2Member> members;
     std::vector<int> member_group;
@@ -578,7 +658,7 @@ struct M2Batch {
     int max_len = 0, max_wcap = 0, max_n = 0;
 };
 
-static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const int64_t* rel, bool exact_cap, bool exact_w) {
+static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const int64_t* rel, bool exact_w) {
     long long map_pos = 0, col_pos = 0, row_pos = 0, pos_pos = 0, dist_pos = 0;
     B.groups.clear(); B.members.clear(); B.member_group.clear(); B.jobs.clear();
     B.max_len = 0; B.max_wcap = 0; B.max_n = 0;
@@ -601,7 +681,7 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
         // sum of the read lengths exceeds it AND the alignment really is that wide)
         G.wcap = static_cast<int>(std::min<long long>(65535, std::min<long long>(sum, exact_w ? sum : fast_w)));
         if (G.wcap < 1) G.wcap = 1;
-        G.cap = exact_cap ? std::max(1, (n / 2) * ((n + 1) / 2) * std::max(1, n - 1)) : M2_CAP;
+        G.cap = M2_CAP;
         G.row_base = row_pos;
         G.pos_base = pos_pos;
         G.first_job = static_cast<long long>(B.jobs.size());
@@ -651,18 +731,7 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
         row_n += G.wcap; pos_n += static_cast<long long>(G.n) * G.wcap; dist_n += static_cast<long long>(G.n) * G.n + G.n;
     }
     if (!B.members.empty()) { const M2Member& L = B.members.back(); const M2Group& G = B.groups[B.member_group.back()]; map_n = L.map_base + static_cast<long long>(std::max(0, G.n - 1)) * L.len; }
-    // row lists: every group with its own stride
-    std::vector<long long> tmp_base(ng, 0);
-    long long tmp_n = 0;
-    {
-        // row_ent is indexed (row_base + i) * cap: with mixed capacities (exact redo) give every group of the
-        // batch the batch's largest capacity so that the indexing stays uniform
-        int capmax = 1;
-        for (const M2Group& G : B.groups) capmax = std::max(capmax, G.cap);
-        for (M2Group& G : B.groups) G.cap = capmax;
-        ent_n = row_n * static_cast<long long>(capmax);
-        for (size_t q = 0; q < ng; ++q) { tmp_base[q] = tmp_n; tmp_n += capmax; }
-    }
+    ent_n = row_n * static_cast<long long>(M2_CAP);
     M2Args& a = B.a;
     a = M2Args{};
     M2Group* d_groups; M2Member* d_members; MsaJob* d_jobs; int* d_mg;
@@ -683,6 +752,8 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     SL_TRY(scratch((pf + ".pos").c_str(), static_cast<size_t>(pos_n) + 1, &d_pos));
     SL_TRY(scratch((pf + ".cnt").c_str(), static_cast<size_t>(row_n) + 1, &d_cnt));
     SL_TRY(scratch((pf + ".ent").c_str(), static_cast<size_t>(ent_n) + 1, &d_ent));
+    unsigned* d_pred;
+    SL_TRY(scratch((pf + ".pred").c_str(), static_cast<size_t>(ent_n) + 1, &d_pred));
     SL_TRY(scratch((pf + ".part").c_str(), static_cast<size_t>(row_n) + 1, &d_part));
     SL_TRY(scratch((pf + ".nca").c_str(), static_cast<size_t>(row_n) + 1, &d_nca));
     SL_TRY(scratch((pf + ".ncb").c_str(), static_cast<size_t>(row_n) + 1, &d_ncb));
@@ -693,7 +764,7 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     a.seq = d_seq; a.groups = d_groups; a.members = d_members; a.ngroups = static_cast<int>(ng);
     a.ma = static_cast<int>(match); a.mm = static_cast<int>(mismatch);
     a.map = d_map; a.stats = d_stats; a.dist = d_dist; a.joins = d_joins; a.nodemask = d_mask; a.ncols = d_ncols;
-    a.col = d_col; a.pos = d_pos; a.row_cnt = d_cnt; a.row_ent = d_ent; a.part = d_part; a.ovf = d_ovf; a.width = d_width;
+    a.col = d_col; a.pos = d_pos; a.row_cnt = d_cnt; a.row_ent = d_ent; a.row_pred = d_pred; a.part = d_part; a.ovf = d_ovf; a.width = d_width;
 
     // ---- all pairs ----
     for (const MsaJob& J : B.jobs) *cells += static_cast<double>(J.lr) * (std::abs(J.lc - J.lr) + 2 * bandwidth + 1);
@@ -708,32 +779,22 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     if (nm) hipLaunchKernelGGL(k_m2_init, dim3(std::max(1u, m2_blocks(B.max_len, 256)), static_cast<unsigned>(nm)), dim3(256), 0, s, a, d_mg, static_cast<int>(nm));
     SL_HIP(hipGetLastError());
     // ---- progressive merging, one round per join ----
+    // The groups of a batch are ordered by size (m2_plan), so the groups that still have a join to do in round r
+    // are a prefix of the batch.
     const bool unitw = a.ma <= 1 && a.mm <= 1;
-    int* d_tmpj = nullptr; unsigned long long* d_tmpnv = nullptr; long long* d_tmpbase = nullptr;
-    if (exact) {
-        SL_TRY(scratch((pf + ".tmpj").c_str(), static_cast<size_t>(tmp_n) + 1, &d_tmpj));
-        SL_TRY(scratch((pf + ".tmpnv").c_str(), static_cast<size_t>(tmp_n) + 1, &d_tmpnv));
-        SL_TRY(upload((pf + ".tmpbase").c_str(), tmp_base.data(), tmp_base.size(), &d_tmpbase, s));
-    }
-    const size_t chain_lds = sizeof(unsigned long long) * (64 * M2_STAGE + M2_CAP) + sizeof(int) * (M2_CAP + 64) +
-                             sizeof(unsigned long long) * (static_cast<size_t>(B.max_wcap) + 2) + 16;
-    // Fenwick tree in LDS while eight waves still fit a CU, in HBM for wider profiles
-    const bool gbit = chain_lds > 20 * 1024;
-    const size_t chain_lds_used = gbit ? chain_lds - sizeof(unsigned long long) * (static_cast<size_t>(B.max_wcap) + 2) : chain_lds;
-    unsigned long long* d_gbit = nullptr;
-    if (gbit) SL_TRY(scratch((pf + ".gbit").c_str(), static_cast<size_t>(row_n) + ng + 1, &d_gbit));
+    unsigned long long* d_gP;
+    SL_TRY(scratch((pf + ".gP").c_str(), static_cast<size_t>(row_n) + ng + 1, &d_gP));
     for (int round = 0; round + 1 < B.max_n; ++round) {
-        const dim3 ggrid(m2_blocks(B.max_wcap, 64), static_cast<unsigned>(ng));
-        if (!exact) {
-            if (unitw) hipLaunchKernelGGL((k_m2_gather<true, true>), ggrid, dim3(64), 0, s, a, round);
-            else hipLaunchKernelGGL((k_m2_gather<false, true>), ggrid, dim3(64), 0, s, a, round);
-        } else {
-            if (unitw) hipLaunchKernelGGL((k_m2_gather<true, false>), ggrid, dim3(64), 0, s, a, round);
-            else hipLaunchKernelGGL((k_m2_gather<false, false>), ggrid, dim3(64), 0, s, a, round);
-        }
-        if (gbit) hipLaunchKernelGGL(k_m2_chain<true>, dim3(static_cast<unsigned>(ng)), dim3(64), chain_lds_used, s, a, round, d_tmpj, d_tmpnv, d_tmpbase, d_gbit);
-        else hipLaunchKernelGGL(k_m2_chain<false>, dim3(static_cast<unsigned>(ng)), dim3(64), chain_lds_used, s, a, round, d_tmpj, d_tmpnv, d_tmpbase, d_gbit);
-        hipLaunchKernelGGL(k_m2_merge, dim3(static_cast<unsigned>(ng)), dim3(256), 0, s, a, round, d_nca, d_ncb, d_pb);
+        int nactive = 0;
+        while (nactive < static_cast<int>(ng) && B.groups[nactive].n - 1 > round) ++nactive;
+        if (nactive == 0) break;
+        const dim3 ggrid(std::min(16u, m2_blocks(B.max_wcap, 64)), static_cast<unsigned>(nactive));
+        if (unitw) hipLaunchKernelGGL(k_m2_gather<true>, ggrid, dim3(64), 0, s, a, round);
+        else hipLaunchKernelGGL(k_m2_gather<false>, ggrid, dim3(64), 0, s, a, round);
+        hipLaunchKernelGGL(k_m2_chain_q<false>, dim3(m2_blocks(nactive, 4)), dim3(64), 0, s, a, round, nactive, d_gP, static_cast<const int*>(nullptr));
+        // groups whose matches left the LDS window of P: again with P complete in HBM
+        hipLaunchKernelGGL(k_m2_chain_q<true>, dim3(m2_blocks(nactive, 4)), dim3(64), 0, s, a, round, nactive, d_gP, static_cast<const int*>(d_ovf));
+        hipLaunchKernelGGL(k_m2_merge, dim3(static_cast<unsigned>(nactive)), dim3(256), 0, s, a, round, d_nca, d_ncb, d_pb);
         SL_HIP(hipGetLastError());
         if (std::getenv("SARLACC_MSA2_DEBUG")) {   // first group of the batch, for comparison with ORC_MSA2_DEBUG of the oracle
             SL_HIP(hipStreamSynchronize(s));
@@ -752,7 +813,7 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
                 fprintf(stderr, "GPU round %d: join %d %d nA %d nB %d -> %d\n", round, hj[round].x, hj[round].y, nA, hn[hj[round].y], hn[G.n + round]);
                 for (int i = 0; i < nA; ++i) {
                     fprintf(stderr, "  row %d part %d :", i, hp[i]);
-                    for (int k = 0; k < hc[i]; ++k) fprintf(stderr, " (%d pred %u)", static_cast<int>(he[static_cast<size_t>(i) * G.cap + k] >> 32), static_cast<unsigned>(he[static_cast<size_t>(i) * G.cap + k]));
+                    for (int k = 0; k < hc[i]; ++k) fprintf(stderr, " (%d w %u)", static_cast<int>(he[static_cast<size_t>(i) * G.cap + k] >> 32), static_cast<unsigned>(he[static_cast<size_t>(i) * G.cap + k]));
                     fprintf(stderr, "\n");
                 }
             }
@@ -835,9 +896,22 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             if (q1 > q0 && (map_b + mb > map_budget || ent_b + eb > ent_budget || jobs_b + jb > job_budget)) break;
             map_b += mb; ent_b += eb; jobs_b += jb;
             B.ids.push_back(g);
+            B.slot.push_back(q1);
             ++q1;
         }
-        SL_TRY(m2_plan(B, grp_off, grp, rel.data(), false, false));
+        {   // larger groups first: the groups with a join left in round r are then a prefix of the batch
+            std::vector<size_t> ord(B.ids.size());
+            std::iota(ord.begin(), ord.end(), size_t(0));
+            std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
+                return grp_off[B.ids[x] + 1] - grp_off[B.ids[x]] > grp_off[B.ids[y] + 1] - grp_off[B.ids[y]];
+            });
+            std::vector<int64_t> ids2(ord.size());
+            std::vector<size_t> slot2(ord.size());
+            for (size_t k = 0; k < ord.size(); ++k) { ids2[k] = B.ids[ord[k]]; slot2[k] = B.slot[ord[k]]; }
+            B.ids.swap(ids2);
+            B.slot.swap(slot2);
+        }
+        SL_TRY(m2_plan(B, grp_off, grp, rel.data(), false));
         SL_TRY(m2_run_batch(B, "m2", d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, false, first ? overlap : nullptr, &cells, s));
         first = false;
         pairs += static_cast<double>(B.jobs.size());
@@ -870,8 +944,20 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
                     ++r1;
                 }
                 r0 = r1;
+                {   // by decreasing size, as in every batch
+                    std::vector<size_t> ord(X.ids.size());
+                    std::iota(ord.begin(), ord.end(), size_t(0));
+                    std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
+                        return grp_off[X.ids[x] + 1] - grp_off[X.ids[x]] > grp_off[X.ids[y] + 1] - grp_off[X.ids[y]];
+                    });
+                    std::vector<int64_t> ids2(ord.size());
+                    std::vector<size_t> src2(ord.size());
+                    for (size_t k = 0; k < ord.size(); ++k) { ids2[k] = X.ids[ord[k]]; src2[k] = xsrc.back()[ord[k]]; }
+                    X.ids.swap(ids2);
+                    xsrc.back().swap(src2);
+                }
                 const int bi = static_cast<int>(xb.size()) - 1;
-                SL_TRY(m2_plan(X, grp_off, grp, rel.data(), false, true));
+                SL_TRY(m2_plan(X, grp_off, grp, rel.data(), true));
                 SL_TRY(m2_run_batch(X, "m2x" + std::to_string(bi), d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, false, nullptr, &cells, s));
                 for (size_t q = 0; q < X.groups.size(); ++q) {
                     if (X.ovf[q]) next.push_back(xsrc[bi][q]);
@@ -881,11 +967,10 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             cur.swap(next);
         }
         if (!cur.empty()) return fail("sarlacc_amd: an alignment wider than 65535 columns is beyond spec v2 (select spec 1 with sarlacc_set_msa_spec)");
-        for (size_t q = 0; q < B.groups.size(); ++q) {
-            const int32_t w = final_of[q].first >= 0 ? xb[final_of[q].first].width[final_of[q].second] : B.width[q];
-            width[q0 + q] = w;
-            off[q0 + q + 1] = off[q0 + q] + static_cast<long long>(w) * B.groups[q].n;
-        }
+        for (size_t q = 0; q < B.groups.size(); ++q)
+            width[B.slot[q]] = final_of[q].first >= 0 ? xb[final_of[q].first].width[final_of[q].second] : B.width[q];
+        for (size_t k = q0; k < q1; ++k)
+            off[k + 1] = off[k] + static_cast<long long>(width[k]) * (grp_off[ids[k] + 1] - grp_off[ids[k]]);
         const long long need = off[q1];
         SL_TRY(rows_reserve(static_cast<size_t>(used), static_cast<size_t>(need) + 1));
         uint8_t* const d_out = static_cast<uint8_t*>(rows_ws.ptr);
@@ -897,7 +982,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
                 for (size_t q = 0; q < X.groups.size(); ++q) {
                     const size_t fq = src ? (*src)[q] : q;
                     const bool mine = src ? (final_of[fq].first == bi && final_of[fq].second == static_cast<int>(q)) : final_of[fq].first < 0;
-                    if (mine) boff[q] = off[q0 + fq]; else bw[q] = 0;
+                    if (mine) boff[q] = off[B.slot[fq]]; else bw[q] = 0;
                 }
                 SL_HIP(hipMemcpyAsync(X.a.width, bw.data(), sizeof(int32_t) * bw.size(), hipMemcpyHostToDevice, s));
                 X.width = bw;
