@@ -35,6 +35,9 @@
  *      unmatched columns of the first child precede those of the second between two matched columns.
  *                                                                              [SeqAn: progressiveAlignment,
  *                                                                               heaviestCommonSubsequence]
+ *      Coherence guard: when, at some row, a match lies MSA2_WINDOW - 1 or more columns below the largest
+ *      partner column seen up to and including that row, the group is not a set of reads of one molecule (its
+ *      library is noise): the whole group is aligned by spec v1 (centre-star, msa.c) instead.       [own rule]
  *   7. output: one gapped row per read in group order, '-' for gaps.
  */
 #include "oracle.h"
@@ -47,6 +50,7 @@
 int orc_fail(const char* msg);
 
 #define MSA2_ROWCAP 16
+#define MSA2_WINDOW 64
 
 static char dna5(char c) {
     switch (c) {
@@ -224,6 +228,7 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
         prof[a].ncols = LEN(&L, a);
         for (int64_t p = 0; p < LEN(&L, a); ++p) col[L.off[a] + p] = p;
     }
+    int incoherent = 0;
     for (int64_t k = 0; k + 1 < n && !rc; ++k) {
         prof_t* A = &prof[joins[2 * k]];
         prof_t* B = &prof[joins[2 * k + 1]];
@@ -296,6 +301,20 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
             }
         }
         free(idxA);
+        /* coherence guard */
+        {
+            int64_t top = -1;
+            for (int64_t m0 = 0; m0 < nm && !incoherent;) {
+                int64_t m1 = m0, rowmax = -1;
+                while (m1 < nm && mi[m1] == mi[m0]) { if (mj[m1] > rowmax) rowmax = mj[m1]; ++m1; }
+                const int64_t T = rowmax > top ? rowmax : top;
+                for (int64_t m = m0; m < m1; ++m)
+                    if (mj[m] <= T - MSA2_WINDOW + 1) incoherent = 1;
+                top = T;
+                m0 = m1;
+            }
+        }
+        if (incoherent) { free(posA); free(mi); free(mj); free(mw); break; }
         /* heaviest chain: f(m) = w(m) + best f over matches with smaller row and smaller column;
          * "best" = larger f, then smaller match index.  bestAt[j] = best match ending in column j among the
          * processed rows; a row's matches all look at the state before the row. */
@@ -365,6 +384,12 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
             for (int64_t q = 0; q < LEN(&L, b); ++q) col[L.off[b] + q] = ncB[col[L.off[b] + q]];
         }
         free(posA); free(mi); free(mj); free(mw); free(f); free(pred); free(bestAt); free(pa); free(ncA); free(ncB);
+    }
+    if (!rc && incoherent) {
+        for (int64_t x = 0; x < 2 * n - 1; ++x) free(prof[x].mem);
+        free(prof); free(col); free(joins);
+        lib_free(&L);
+        return orc_msa_group(seq, off, n, ma, mm, go, ge, bw, out, cap, width);
     }
     if (!rc) {
         const int64_t Wd = prof[2 * n - 2].ncols;

@@ -103,7 +103,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
 int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq, const int64_t* seq_off,
              int64_t nseq, double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
              bool want_rows, int64_t out_cap, MsaResult* res, const std::function<int()>* overlap = nullptr,
-             const uint8_t* d_seq_resident = nullptr);
+             const uint8_t* d_seq_resident = nullptr, bool accumulate = false);
 
 // ---- quality encoding (reference src/quality_encoding.cpp:5-33) -------------
 int check_encoding(const double* errors, const char* names, int n);

@@ -151,7 +151,7 @@ __global__ void k_msa_write(MergeArgs A, const long long* row_group, const int* 
 int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq, const int64_t* seq_off,
             int64_t nseq, double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
             bool want_rows, int64_t out_cap, MsaResult* res, const std::function<int()>* overlap,
-            const uint8_t* d_seq_resident) {
+            const uint8_t* d_seq_resident, bool accumulate) {
     int32_t* width_out = res->width.data();
     int64_t* out_off = res->out_off.data();
     res->d_out = nullptr;
@@ -241,10 +241,11 @@ int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const 
     if (!jobs.empty()) {
         double cells = 0;
         for (const MsaJob& J : jobs) cells += static_cast<double>(J.lr) * (std::abs(J.lc - J.lr) + 2 * bandwidth + 1);
-        c.counts["msa_pairs"] = static_cast<double>(jobs.size());
-        c.counts["msa_cells"] = cells;
+        // accumulate: part of a spec v2 call (msa2.hip), which has reset the timers and counters itself
+        c.counts["msa_pairs"] = (accumulate ? c.counts["msa_pairs"] : 0.0) + static_cast<double>(jobs.size());
+        c.counts["msa_cells"] = (accumulate ? c.counts["msa_cells"] : 0.0) + cells;
         SL_HIP(hipEventRecord(c.ev_start, s));
-        c.stage_reset("msa_pairwise");
+        if (!accumulate) c.stage_reset("msa_pairwise");
         SL_TRY(c.stage_begin("msa_pairwise", s));
         SL_TRY(msa_pairwise_launch(jobs, d_jobs, d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, 0, d_ins, d_aln,
                                    nullptr, nullptr, nullptr, s));
@@ -258,7 +259,7 @@ int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const 
     MergeArgs m{};
     m.seq = d_seq; m.seq_off = d_soff; m.members = d_mem; m.groups = d_groups; m.jobs = d_jobs; m.ngroups = ngroups;
     m.ins = d_ins; m.aln = d_aln; m.maxins = d_maxins; m.mi_off = d_mioff; m.width = d_width;
-    c.stage_reset("msa_merge");
+    if (!accumulate) c.stage_reset("msa_merge");
         SL_TRY(c.stage_begin("msa_merge", s));
     hipLaunchKernelGGL(k_msa_width, dim3(static_cast<unsigned>(ngroups)), dim3(256), 0, s, m);
     SL_HIP(hipGetLastError());

@@ -70,6 +70,7 @@ struct M2Args {
     const M2Member* members;
     int ngroups;
     int ma, mm;
+    unsigned long long* clk;       // SARLACC_MSA2_CLOCKS: cycles of the chain kernel's phases, first wave of the last launch
     const uint16_t* map;
     const int2* stats;
     double* dist;
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
     __shared__ uint16_t s_r[M2_MAXN][64];   // position of the lane's base in every other member (0xFFFF: gap)
     const int g = blockIdx.y;
     const M2Group G = A.groups[g];
-    if (round >= G.n - 1) return;
+    if (round >= G.n - 1 || A.ovf[g] != 0) return;
     const int n = G.n, fm = G.first_member;
     const int2 jn = A.joins[fm + round];
     const unsigned maskA = A.nodemask[2 * fm + jn.x], maskB = A.nodemask[2 * fm + jn.y];
@@ -341,10 +342,12 @@ __device__ __forceinline__ unsigned long long m2_rowmax16(unsigned long long v) 
 // step function of l.  It is stored explicitly up to `top`, the largest column entered so far (beyond it the
 // value is P[top]), so a match with column j reads P[j - 1] -- one access, no tree -- and entering it raises P on
 // the columns from j upwards for as long as they are smaller (a short run: the chain advances with the columns).
-// The 16 lanes of a group serve the 16 entries of one row.  P is a circular window of M2_PWIN columns in LDS
-// (same-molecule profiles stay within a few columns of `top`); a group whose matches reach below the window
-// is flagged (ovf = 3) and redone by the launch with P complete in HBM (GLOBALP).
-constexpr int M2_PWIN = 512;
+// The 16 lanes of a group serve the 16 entries of one row.  P is a circular window of M2_PWIN columns in LDS:
+// the matches of same-molecule reads stay within a few columns of `top`.  Coherence guard of spec v2 (step 6):
+// a group in which some match lies M2_PWIN - 1 or more columns below the largest column seen up to and
+// including its row is not a set of reads of one molecule (its library is noise); it is flagged (ovf = 3),
+// dropped from the remaining rounds and aligned by spec v1 instead.
+constexpr int M2_PWIN = 64;
 
 __device__ __forceinline__ int m2_qmax_i32(int v) {   // maximum over the 16 lanes of a DPP row, in every lane
     v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));
@@ -354,16 +357,16 @@ __device__ __forceinline__ int m2_qmax_i32(int v) {   // maximum over the 16 lan
     return v;
 }
 
-template <bool GLOBALP>
-__global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nactive, unsigned long long* gP, const int* only_flagged) {
-    __shared__ unsigned long long s_buf[4][GLOBALP ? 256 : (M2_PWIN > 256 ? M2_PWIN : 256)];   // P window, later the traceback stage
+__global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nactive) {
+    constexpr bool GLOBALP = false;
+    __shared__ unsigned long long s_buf[4][M2_PWIN > 256 ? M2_PWIN : 256];   // P window, later the traceback stage
     const int lane = threadIdx.x, qd = lane >> 4, t = lane & 15;
     const int g = blockIdx.x * 4 + qd;
     bool act = g < nactive;
     M2Group G{};
     if (act) G = A.groups[g];
     if (act && round >= G.n - 1) act = false;
-    if (act && only_flagged && only_flagged[g] != 3) act = false;   // second launch: only the groups the window failed
+    if (act && A.ovf[g] != 0) act = false;   // dropped (coherence guard, or a profile outgrew its capacity)
     int nA = 0, nB = 0;
     if (act) {
         const int2 jn = A.joins[G.first_member + round];
@@ -371,98 +374,103 @@ __global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nact
         nB = A.ncols[2 * G.first_member + jn.y];
     }
     (void)nB;
-    unsigned long long* const P = GLOBALP ? gP + G.row_base + g : &s_buf[qd][0];
+    unsigned long long* const P = &s_buf[qd][0];
     auto pidx = [&](int l) -> int { return GLOBALP ? l : (l & (M2_PWIN - 1)); };
-    // HBM form: the loads must not be served by this CU's L1 (the atomics act in L2)
-    auto pload = [&](int l) -> unsigned long long {
-        if (GLOBALP) return __hip_atomic_load(&P[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return P[pidx(l)];
-    };
-    auto pstore = [&](int l, unsigned long long v) {
-        if (GLOBALP) __hip_atomic_store(&P[l], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else P[pidx(l)] = v;
-    };
+    auto pload = [&](int l) -> unsigned long long { return P[pidx(l)]; };
+    auto pstore = [&](int l, unsigned long long v) { P[pidx(l)] = v; };
     unsigned long long* const ent = A.row_ent + G.row_base * static_cast<long long>(M2_CAP);
     unsigned* const prd = A.row_pred + G.row_base * static_cast<long long>(M2_CAP);
     for (int i = t; i < nA; i += 16) A.part[G.row_base + i] = -1;
     int top = -1;
-    unsigned long long ptop = 0, best = 0;
+    unsigned long long ptop = 0;
     bool bad = false;
     const int nAmax = max(max(__shfl(nA, 0), __shfl(nA, 16)), max(__shfl(nA, 32), __shfl(nA, 48)));
-    // rows in blocks of 16: lane t holds entry t of each of the block's rows, and the count of row ib + t
+    // rows in blocks of 16: lane t holds entry t and the count of each of the block's rows (the counts are
+    // broadcast loads: all 16 lanes of a group read the same address)
     unsigned long long eb[16];
-    int cb = 0;
-    auto load_block = [&](int ib, unsigned long long (&e)[16], int& c) {
+    int cb[16];
+    auto load_block = [&](int ib, unsigned long long (&e)[16], int (&c)[16]) {
+        // unconditional loads (a row index clamped into the group's rows): a select around each load would make
+        // the compiler wait for every one of them in turn
+        const int last = max(nA - 1, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) e[r] = (ib + r < nA) ? ent[static_cast<long long>(ib + r) * M2_CAP + t] : 0ull;
-        c = (ib + t < nA) ? static_cast<int>(A.row_cnt[G.row_base + ib + t]) : 0;
+        for (int r = 0; r < 16; ++r) e[r] = ent[static_cast<long long>(min(ib + r, last)) * M2_CAP + t];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = static_cast<int>(A.row_cnt[G.row_base + min(ib + r, last)]);
     };
     load_block(0, eb, cb);
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
     for (int ib = 0; ib < nAmax; ib += 16) {
         unsigned long long en[16];
-        int cn = 0;
+        int cn[16];
         load_block(ib + 16, en, cn);   // next block in flight while this one is processed
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = ib + r;
-            const int c = __shfl(cb, r, 16);
-            const bool mk = act && !bad && i < nA && t < c;
+            const bool mk = act && !bad && i < nA && t < cb[r];
             const unsigned long long e = eb[r];
             const int j = static_cast<int>(e >> 32);
             // query: best over the columns < j, state before the row
             unsigned long long v = 0;
-            if (mk && j > 0) {
-                const int l = j - 1;
-                if (l > top) v = ptop;
-                else if (!GLOBALP && l <= top - M2_PWIN) bad = true;
-                else v = pload(l);
+            // coherence guard: T = largest column up to and including this row; a match at or below T - W + 1 fails
+            const int oldtop = top;
+            const int newtop = m2_qmax_i32(mk ? j : -1);
+            const int T = max(top, newtop);
+            if (mk && j <= T - M2_PWIN + 1) bad = true;
+            if (mk && !bad && j > 0) {
+                const int l = j - 1;   // (> T - W >= top - W: inside the window)
+                v = l > top ? ptop : pload(l);
             }
             const unsigned f = static_cast<unsigned>(e) + static_cast<unsigned>(v >> 32);
             const unsigned pred = v ? ~static_cast<unsigned>(v) : 0u;
             const unsigned id = static_cast<unsigned>(i) * M2_CAP + static_cast<unsigned>(t) + 1u;
-            const unsigned long long nv = (static_cast<unsigned long long>(f) << 32) | static_cast<unsigned>(~id);
-            if (mk) {
-                prd[static_cast<long long>(i) * M2_CAP + t] = pred;
-                best = nv > best ? nv : best;
-            }
+            const unsigned long long nv = mk ? ((static_cast<unsigned long long>(f) << 32) | static_cast<unsigned>(~id)) : 0ull;
+            if (mk) prd[static_cast<long long>(i) * M2_CAP + t] = pred;
             // the explicit part of P grows to the row's largest column (filled with the old plateau value)
-            const int newtop = m2_qmax_i32(mk ? j : -1);
             if (newtop > top) {
                 for (int l = max(top + 1, GLOBALP ? 0 : newtop - M2_PWIN + 1) + t; l <= newtop; l += 16) pstore(l, ptop);
                 top = newtop;
             }
-            if (!GLOBALP && mk && j <= top - M2_PWIN) bad = true;
-            bad = m2_qmax_i32(bad ? 1 : 0) != 0;
-            // enter the matches: raise P from column j upwards while it is smaller
+            // enter the matches: raise P from column j upwards while it is smaller (a column beyond the old top was
+            // just filled with the old plateau, which every new value exceeds: no need to read it)
             if (mk && !bad) {
                 for (int l = j; l <= top; ++l) {
-                    if (pload(l) >= nv) break;
+                    if (l <= oldtop && pload(l) >= nv) break;
                     atomicMax(&P[pidx(l)], nv);
                 }
             }
-            if (top >= 0 && act && !bad && i < nA) ptop = pload(top);
+            // P[top] is the best over everything entered so far
+            const unsigned long long rowbest = m2_rowmax16(nv);
+            ptop = rowbest > ptop ? rowbest : ptop;
         }
+        bad = m2_qmax_i32(bad ? 1 : 0) != 0;   // (a group that failed keeps going on garbage until here; it is redone)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) eb[r] = en[r];
-        cb = cn;
+        for (int r = 0; r < 16; ++r) { eb[r] = en[r]; cb[r] = cn[r]; }
     }
+    unsigned long long best = ptop;
     if (act && bad && t == 0) A.ovf[g] = 3;
     if (!act || bad) { nA = 0; best = 0; }
-    best = m2_rowmax16(best);   // the chain's last match
-    if (act && !bad && only_flagged && t == 0) A.ovf[g] = 0;   // redone with the complete P
     // traceback through the stored predecessors, 16 rows staged at a time (the P window is free now)
     __threadfence();
     unsigned long long* const stage = &s_buf[qd][0];   // [16 rows][16 entries]
+    const unsigned long long clk1 = __builtin_amdgcn_s_memtime();
     unsigned id = best ? ~static_cast<unsigned>(best) : 0u;
     int steps = 2 * nA + 64;
     while (__builtin_amdgcn_ballot_w64(id != 0 && steps > 0)) {
         const bool go = id != 0 && steps > 0;
         const int itop = go ? static_cast<int>((id - 1u) / M2_CAP) : 0;
         const int i0 = max(0, itop - 15);
-        if (go) {
+        {
+            // all loads first, then the LDS writes (interleaved, every load would wait for the write before it)
+            unsigned long long ev[16];
+            unsigned pv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stage[r * 16 + t] = (i0 + r <= itop) ? ((ent[static_cast<long long>(i0 + r) * M2_CAP + t] & 0xffffffff00000000ull) | prd[static_cast<long long>(i0 + r) * M2_CAP + t]) : 0ull;
+            for (int r = 0; r < 16; ++r) {   // (rows above itop are never followed: clamped, not masked)
+                ev[r] = ent[static_cast<long long>(min(i0 + r, itop)) * M2_CAP + t];
+                pv[r] = prd[static_cast<long long>(min(i0 + r, itop)) * M2_CAP + t];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[r * 16 + t] = (ev[r] & 0xffffffff00000000ull) | pv[r];
         }
         --steps;
         while (__builtin_amdgcn_ballot_w64(go && id != 0 && steps > 0 && static_cast<int>((id - 1u) / M2_CAP) >= i0)) {
@@ -475,6 +483,10 @@ __global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nact
                 --steps;
             }
         }
+    }
+    if (A.clk && blockIdx.x == 0 && lane == 0) {
+        const unsigned long long clk2 = __builtin_amdgcn_s_memtime();
+        A.clk[0] = clk1 - clk0; A.clk[1] = clk2 - clk1; A.clk[2] = static_cast<unsigned long long>(nAmax);
     }
 }
 
@@ -503,7 +515,7 @@ __device__ __forceinline__ int m2_suffix_min_incl(int v) {          // inclusive
 __global__ void __launch_bounds__(256) k_m2_merge(M2Args A, int round, int* ncA, int* ncB, int* partB) {
     const int g = blockIdx.x;
     const M2Group G = A.groups[g];
-    if (round >= G.n - 1) return;
+    if (round >= G.n - 1 || A.ovf[g] != 0) return;
     const int n = G.n, fm = G.first_member;
     const int2 jn = A.joins[fm + round];
     const unsigned maskA = A.nodemask[2 * fm + jn.x], maskB = A.nodemask[2 * fm + jn.y];
@@ -763,6 +775,9 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     SL_HIP(hipMemsetAsync(d_ovf, 0, sizeof(int) * ng, s));
     a.seq = d_seq; a.groups = d_groups; a.members = d_members; a.ngroups = static_cast<int>(ng);
     a.ma = static_cast<int>(match); a.mm = static_cast<int>(mismatch);
+    unsigned long long* d_clk = nullptr;
+    if (std::getenv("SARLACC_MSA2_CLOCKS")) { SL_TRY(scratch((pf + ".clk").c_str(), 4, &d_clk)); SL_HIP(hipMemsetAsync(d_clk, 0, 32, s)); }
+    a.clk = d_clk;
     a.map = d_map; a.stats = d_stats; a.dist = d_dist; a.joins = d_joins; a.nodemask = d_mask; a.ncols = d_ncols;
     a.col = d_col; a.pos = d_pos; a.row_cnt = d_cnt; a.row_ent = d_ent; a.row_pred = d_pred; a.part = d_part; a.ovf = d_ovf; a.width = d_width;
 
@@ -782,8 +797,6 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     // The groups of a batch are ordered by size (m2_plan), so the groups that still have a join to do in round r
     // are a prefix of the batch.
     const bool unitw = a.ma <= 1 && a.mm <= 1;
-    unsigned long long* d_gP;
-    SL_TRY(scratch((pf + ".gP").c_str(), static_cast<size_t>(row_n) + ng + 1, &d_gP));
     for (int round = 0; round + 1 < B.max_n; ++round) {
         int nactive = 0;
         while (nactive < static_cast<int>(ng) && B.groups[nactive].n - 1 > round) ++nactive;
@@ -791,9 +804,7 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
         const dim3 ggrid(std::min(16u, m2_blocks(B.max_wcap, 64)), static_cast<unsigned>(nactive));
         if (unitw) hipLaunchKernelGGL(k_m2_gather<true>, ggrid, dim3(64), 0, s, a, round);
         else hipLaunchKernelGGL(k_m2_gather<false>, ggrid, dim3(64), 0, s, a, round);
-        hipLaunchKernelGGL(k_m2_chain_q<false>, dim3(m2_blocks(nactive, 4)), dim3(64), 0, s, a, round, nactive, d_gP, static_cast<const int*>(nullptr));
-        // groups whose matches left the LDS window of P: again with P complete in HBM
-        hipLaunchKernelGGL(k_m2_chain_q<true>, dim3(m2_blocks(nactive, 4)), dim3(64), 0, s, a, round, nactive, d_gP, static_cast<const int*>(d_ovf));
+        hipLaunchKernelGGL(k_m2_chain_q, dim3(m2_blocks(nactive, 4)), dim3(64), 0, s, a, round, nactive);
         hipLaunchKernelGGL(k_m2_merge, dim3(static_cast<unsigned>(nactive)), dim3(256), 0, s, a, round, d_nca, d_ncb, d_pb);
         SL_HIP(hipGetLastError());
         if (std::getenv("SARLACC_MSA2_DEBUG")) {   // first group of the batch, for comparison with ORC_MSA2_DEBUG of the oracle
@@ -818,6 +829,11 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
                 }
             }
         }
+    }
+    if (d_clk) {
+        unsigned long long hc[4];
+        SL_HIP(hipMemcpy(hc, d_clk, sizeof hc, hipMemcpyDeviceToHost));
+        fprintf(stderr, "chain kernel, first wave of the last LDS launch: forward %llu cycles, traceback %llu cycles, %llu rows\n", hc[0], hc[1], hc[2]);
     }
     hipLaunchKernelGGL(k_m2_width, dim3(m2_blocks(static_cast<long long>(ng), 256)), dim3(256), 0, s, a);
     SL_HIP(hipGetLastError());
@@ -856,11 +872,17 @@ static int m2_write_batch(M2Batch& B, const std::string& pf, const std::vector<l
 static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vector<int64_t>& ids, const uint8_t* d_seq,
                      const std::vector<int64_t>& rel, double match, double mismatch, double gap_extension, double gap_opening,
                      int bandwidth, std::vector<int32_t>& width, std::vector<long long>& off, uint8_t** d_rows,
-                     const std::function<int()>* overlap, hipStream_t s) {
+                     std::vector<size_t>* incoherent, const std::function<int()>* overlap, hipStream_t s) {
     Context& c = ctx();
     width.assign(ids.size(), 0);
-    off.assign(ids.size() + 1, 0);
+    off.assign(ids.size() + 1, 0);   // off[k]: start of the rows of ids[k] in the row buffer (processing order, not cumulative in k)
     *d_rows = nullptr;
+    // processing order: by decreasing group size, so that a batch holds groups with about the same number of joins
+    std::vector<size_t> order(ids.size());
+    std::iota(order.begin(), order.end(), size_t(0));
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+        return grp_off[ids[x] + 1] - grp_off[ids[x]] > grp_off[ids[y] + 1] - grp_off[ids[y]];
+    });
     // row buffer: grown when a batch does not fit (contents are kept)
     Workspace& rows_ws = c.ws["msa2.rows"];
     auto rows_reserve = [&](size_t used, size_t need) -> int {
@@ -888,7 +910,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         long long map_b = 0, ent_b = 0, jobs_b = 0;
         size_t q1 = q0;
         while (q1 < ids.size()) {
-            const int64_t g = ids[q1];
+            const int64_t g = ids[order[q1]];
             const long long n = grp_off[g + 1] - grp_off[g];
             long long sum = 0, mx = 0;
             for (long long a = 0; a < n; ++a) { const long long len = rel[grp[grp_off[g] + a]] - rel[grp[grp_off[g] + a] - 1]; sum += len; mx = std::max(mx, len); }
@@ -896,20 +918,8 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             if (q1 > q0 && (map_b + mb > map_budget || ent_b + eb > ent_budget || jobs_b + jb > job_budget)) break;
             map_b += mb; ent_b += eb; jobs_b += jb;
             B.ids.push_back(g);
-            B.slot.push_back(q1);
+            B.slot.push_back(order[q1]);   // (already by decreasing size: the groups with a join left in round r are a prefix)
             ++q1;
-        }
-        {   // larger groups first: the groups with a join left in round r are then a prefix of the batch
-            std::vector<size_t> ord(B.ids.size());
-            std::iota(ord.begin(), ord.end(), size_t(0));
-            std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
-                return grp_off[B.ids[x] + 1] - grp_off[B.ids[x]] > grp_off[B.ids[y] + 1] - grp_off[B.ids[y]];
-            });
-            std::vector<int64_t> ids2(ord.size());
-            std::vector<size_t> slot2(ord.size());
-            for (size_t k = 0; k < ord.size(); ++k) { ids2[k] = B.ids[ord[k]]; slot2[k] = B.slot[ord[k]]; }
-            B.ids.swap(ids2);
-            B.slot.swap(slot2);
         }
         SL_TRY(m2_plan(B, grp_off, grp, rel.data(), false));
         SL_TRY(m2_run_batch(B, "m2", d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, false, first ? overlap : nullptr, &cells, s));
@@ -917,9 +927,13 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         pairs += static_cast<double>(B.jobs.size());
         // Groups whose profiles outgrew the fast capacity (unrelated reads in one cluster) are redone with profiles
         // as wide as the sum of the read lengths.  Every redo batch keeps its own workspaces until its rows are written.
+        // ovf 1: profile capacity exceeded (redo below); 3: coherence guard (the caller aligns the group by spec v1)
         std::vector<size_t> cur;
-        for (size_t q = 0; q < B.groups.size(); ++q)
-            if (B.ovf[q]) cur.push_back(q);
+        std::vector<char> dropped(B.groups.size(), 0);
+        for (size_t q = 0; q < B.groups.size(); ++q) {
+            if (B.ovf[q] == 3) { dropped[q] = 1; incoherent->push_back(B.slot[q]); }
+            else if (B.ovf[q]) cur.push_back(q);
+        }
         std::vector<M2Batch> xb;
         std::vector<std::vector<size_t>> xsrc;                 // fast-batch index of every group of a redo batch
         std::vector<std::pair<int, int>> final_of(B.groups.size(), std::make_pair(-1, -1));   // (redo batch, group in it)
@@ -960,7 +974,8 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
                 SL_TRY(m2_plan(X, grp_off, grp, rel.data(), true));
                 SL_TRY(m2_run_batch(X, "m2x" + std::to_string(bi), d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, false, nullptr, &cells, s));
                 for (size_t q = 0; q < X.groups.size(); ++q) {
-                    if (X.ovf[q]) next.push_back(xsrc[bi][q]);
+                    if (X.ovf[q] == 3) { dropped[xsrc[bi][q]] = 1; incoherent->push_back(B.slot[xsrc[bi][q]]); }
+                    else if (X.ovf[q]) next.push_back(xsrc[bi][q]);
                     else final_of[xsrc[bi][q]] = std::make_pair(bi, static_cast<int>(q));
                 }
             }
@@ -968,10 +983,13 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         }
         if (!cur.empty()) return fail("sarlacc_amd: an alignment wider than 65535 columns is beyond spec v2 (select spec 1 with sarlacc_set_msa_spec)");
         for (size_t q = 0; q < B.groups.size(); ++q)
-            width[B.slot[q]] = final_of[q].first >= 0 ? xb[final_of[q].first].width[final_of[q].second] : B.width[q];
-        for (size_t k = q0; k < q1; ++k)
-            off[k + 1] = off[k] + static_cast<long long>(width[k]) * (grp_off[ids[k] + 1] - grp_off[ids[k]]);
-        const long long need = off[q1];
+            width[B.slot[q]] = dropped[q] ? 0 : (final_of[q].first >= 0 ? xb[final_of[q].first].width[final_of[q].second] : B.width[q]);
+        long long need = used;
+        for (size_t k = q0; k < q1; ++k) {
+            const size_t sl = order[k];
+            off[sl] = need;
+            need += static_cast<long long>(width[sl]) * (grp_off[ids[sl] + 1] - grp_off[ids[sl]]);
+        }
         SL_TRY(rows_reserve(static_cast<size_t>(used), static_cast<size_t>(need) + 1));
         uint8_t* const d_out = static_cast<uint8_t*>(rows_ws.ptr);
         {
@@ -981,7 +999,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
                 std::vector<int32_t> bw = X.width;
                 for (size_t q = 0; q < X.groups.size(); ++q) {
                     const size_t fq = src ? (*src)[q] : q;
-                    const bool mine = src ? (final_of[fq].first == bi && final_of[fq].second == static_cast<int>(q)) : final_of[fq].first < 0;
+                    const bool mine = !dropped[fq] && (src ? (final_of[fq].first == bi && final_of[fq].second == static_cast<int>(q)) : final_of[fq].first < 0);
                     if (mine) boff[q] = off[B.slot[fq]]; else bw[q] = 0;
                 }
                 SL_HIP(hipMemcpyAsync(X.a.width, bw.data(), sizeof(int32_t) * bw.size(), hipMemcpyHostToDevice, s));
@@ -1060,7 +1078,18 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     SL_TRY(upload("msa.mem.all", grp + grp_off[0], static_cast<size_t>(nmemb), &d_mem, s));   // (msa1_run uploads its own "msa.mem")
     res->d_members = d_mem;
 
-    // spec v1 part first (its stage timers reset themselves), on a compacted group list
+    std::vector<int32_t> w2;
+    std::vector<long long> o2;
+    uint8_t* d_rows2 = nullptr;
+    std::vector<size_t> incoherent;   // positions in v2 of the groups the coherence guard dropped
+    SL_TRY(msa2_core(grp_off, grp, v2, d_seq, rel, match, mismatch, gap_extension, gap_opening, bandwidth, w2, o2, &d_rows2, &incoherent, overlap, s));
+    c.counts["msa_v1_fallback"] = static_cast<double>(incoherent.size());
+    if (!incoherent.empty()) {
+        std::sort(incoherent.begin(), incoherent.end());
+        for (size_t q : incoherent) v1.push_back(v2[q]);
+        std::sort(v1.begin(), v1.end());
+    }
+    // spec v1 part on a compacted group list: more than M2_MAXN reads, reads too long, or dropped by the guard
     MsaResult r1;
     std::vector<int64_t> g1off(v1.size() + 1, 0);
     std::vector<int32_t> g1;
@@ -1073,27 +1102,19 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         r1.width.assign(v1.size(), 0);
         r1.out_off.assign(v1.size() + 1, 0);
         SL_TRY(msa1_run(g1off.data(), g1.data(), static_cast<int64_t>(v1.size()), seq, seq_off, nseq, match, mismatch, gap_extension,
-                        gap_opening, bandwidth, true, -1, &r1, nullptr, d_seq));
+                        gap_opening, bandwidth, true, -1, &r1, nullptr, d_seq, true));
     }
-    std::vector<int32_t> w2;
-    std::vector<long long> o2;
-    uint8_t* d_rows2 = nullptr;
-    SL_TRY(msa2_core(grp_off, grp, v2, d_seq, rel, match, mismatch, gap_extension, gap_opening, bandwidth, w2, o2, &d_rows2, overlap, s));
-    if (v1.empty()) {
-        for (int64_t g = 0; g < ngroups; ++g) { width_out[g] = w2[g]; out_off[g + 1] = o2[g + 1]; }
-        if (want_rows && out_cap >= 0 && out_cap < out_off[ngroups]) return fail("sarlacc_amd: MSA output buffer too small (%lld needed)", static_cast<long long>(out_off[ngroups]));
-        res->d_out = d_rows2;
-        return 0;
-    }
-    // both kinds: gather the rows of the two buffers into one in group order
+    // the rows of spec v2 are in processing order, those of spec v1 in a buffer of their own: gather both into one in group order
     std::vector<long long> src_off(static_cast<size_t>(ngroups)), dst_off(static_cast<size_t>(ngroups)), nbytes(static_cast<size_t>(ngroups));
     std::vector<char> from1(static_cast<size_t>(ngroups), 0);
     {
         size_t a1 = 0, a2 = 0;
         for (int64_t g = 0; g < ngroups; ++g) {
             const int64_t n = grp_off[g + 1] - grp_off[g];
+            const bool in2 = a2 < v2.size() && v2[a2] == g;   // (a group dropped by the guard is in both lists: v1 has its rows)
             if (a1 < v1.size() && v1[a1] == g) { width_out[g] = r1.width[a1]; src_off[g] = r1.out_off[a1]; from1[g] = 1; ++a1; }
-            else { width_out[g] = w2[a2]; src_off[g] = o2[a2]; ++a2; }
+            else { width_out[g] = w2[a2]; src_off[g] = o2[a2]; }
+            if (in2) ++a2;
             nbytes[g] = static_cast<long long>(width_out[g]) * n;
             dst_off[g] = out_off[g];
             out_off[g + 1] = out_off[g] + nbytes[g];
@@ -1111,6 +1132,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         SL_TRY(upload(pass == 0 ? "msa.cp.so1" : "msa.cp.so2", src_off.data(), src_off.size(), &d_so, s));
         SL_TRY(upload(pass == 0 ? "msa.cp.do1" : "msa.cp.do2", dst_off.data(), dst_off.size(), &d_do, s));
         SL_TRY(upload(pass == 0 ? "msa.cp.nb1" : "msa.cp.nb2", nb.data(), nb.size(), &d_nb, s));
+        if (pass == 0 && v1.empty()) continue;
         hipLaunchKernelGGL(k_rows_copy, dim3(static_cast<unsigned>(ngroups)), dim3(256), 0, s, pass == 0 ? r1.d_out : d_rows2, d_so, d_final, d_do, d_nb);
         SL_HIP(hipGetLastError());
     }
