@@ -249,7 +249,8 @@ def main():
         del hs, hq
     cpu_sample = None
     if rank == 0 and not args.no_cpu:
-        cores = os.cpu_count() or 1
+        # the GPU box gives a one-GPU job a share of 16 host cores (more threads than that only contend)
+        cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
         cpu_sample = devsynth.to_host_strings(seq, qual, off, min(n, args.cpu_sample * cores)) + (cores,)
     del seq, qual, off, packed, nmask, scores, starts, ends, sso, swo
     torch.cuda.empty_cache()
@@ -299,17 +300,35 @@ def main():
                             "pre-group per GPU) -> label all-gather -> msa_consensus (quick_msa bandwidth 100 + quality "
                             "consensus, rows stay in HBM); reads and qualities resident, UMIs / group lists / consensus "
                             "strings cross PCIe" % (args.molecules, args.copies, args.read_len, 12, args.threshold),
+                "msa_spec": "v2 (all-pairs + consistency library + guide tree + progressive merging; DESIGN.md section 5)",
+                "msa_groups_aligned_by_spec_v1": cnt["msa_v1_fallback"],
                 "msa_pairs": cnt["msa_pairs"], "msa_cells": cnt["msa_cells"], "consensus_cells": cnt["consensus_cells"],
                 "rooflines": {
-                    "k_msa_pairwise_ad": {"bound": "valu", "achieved": msa_ops, "peak": VALU32_PEAK_TLOPS, "unit": "T lane-op/s (int32)",
+                    "k_msa_pairwise_pk": {"bound": "valu", "achieved": msa_ops, "peak": VALU32_PEAK_TLOPS, "unit": "T lane-op/s (int32)",
                                           "frac": msa_ops / VALU32_PEAK_TLOPS, "algorithmic_ops_per_cell": MSA_OPS_PER_CELL,
                                           "tcups": cnt["msa_cells"] / (kms["msa_pairwise"] * 1e-3) / 1e12,
+                                          "issue_peak_measured": 1024 * 64 / 4.2 * 2.4e9 / 1e12,
+                                          "issue_peak_note": "tools/ubench_valu.hip on MI355X: packed 16-bit / VOP3 / DPP instructions issue in ~4.2 cycles per "
+                                                             "wave64 (profiles/r02_ubench_valu_issue_v1.txt); the kernel holds two cells per instruction",
                                           "traffic": pm["traffic"], "traffic_source": pm["traffic_source"], "pmc": pm.get("derived")},
                     "k_consensus_q4": {"bound": "hbm", "achieved": cons_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": cons_gbs / HBM_PEAK_GBS, "algorithmic_bytes": cons_bytes,
                                        "traffic": pc["traffic"], "traffic_source": pc["traffic_source"], "pmc": pc.get("derived")},
                 },
             }
+            # the same pass with the centre-star alignment (spec v1, round 1's algorithm) for comparison
+            calls.set_msa_spec(1)
+            try:
+                fence()
+                t0 = time.perf_counter()
+                r1 = pipeline.run_resident(umis, mol["seq"], mol["qual"], off_host, enc, threshold=args.threshold)
+                fence()
+                dt1 = time.perf_counter() - t0
+            finally:
+                calls.set_msa_spec(0)
+            out["pipeline"]["spec_v1"] = {"reads_per_min": nr / dt1 * 60.0, "seconds": dt1, "kernel_ms": r1["kernel_ms"],
+                                          "msa_pairs": r1["counts"]["msa_pairs"],
+                                          "tcups": r1["counts"]["msa_cells"] / (r1["kernel_ms"]["msa_pairwise"] * 1e-3) / 1e12}
             if not args.no_host_pointer:
                 hs = StringSet(mol["seq"].cpu().numpy(), off_host)
                 hq = StringSet(mol["qual"].cpu().numpy(), off_host.copy())

@@ -230,7 +230,7 @@ int sarlacc_umi_group_from_pairs(const char* umi, const int64_t* off, int64_t n,
  * T-Coffee, which cannot be run or pinned here): 2 (default) = consistency-based progressive alignment --
  * all-pairs banded alignments, primary library, triplet extension, neighbour-joining guide tree, progressive
  * heaviest-common-subsequence merging -- for groups of up to 32 reads, 1 = centre-star (also used by spec 2 for
- * larger groups and for reads beyond 32 735 bases).  0 restores the default (or SARLACC_MSA_SPEC). */
+ * larger groups and for reads beyond 21 823 bases).  0 restores the default (or SARLACC_MSA_SPEC). */
 int sarlacc_set_msa_spec(int spec);
 
 /* replaces .Call quick_msa  (src/quick_msa.cpp:15-80); argument order as there

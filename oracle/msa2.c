@@ -29,15 +29,14 @@
  *      partner column is not among the first MSA2_ROWCAP (16) distinct columns seen is ignored.  Same-molecule
  *      reads never come near the bound; it keeps clusters of unrelated reads (UMI collisions), whose library
  *      is dense noise, from costing orders of magnitude more than real ones.   [own rule]
+ *      Noise filter: of a row's entries those lighter than half the heaviest are dropped -- the partner
+ *      columns reached only through reads unrelated to the rest of the cluster.   [own rule]
  *   6. progressive alignment along the tree: two profiles (lists of columns) are merged by the heaviest
  *      common subsequence of their columns, weight(col_i, col_j) = sum of W over the members, no gap
  *      penalties; among equally heavy chains the one built from the earliest matches (row-major) wins;
  *      unmatched columns of the first child precede those of the second between two matched columns.
  *                                                                              [SeqAn: progressiveAlignment,
  *                                                                               heaviestCommonSubsequence]
- *      Coherence guard: when, at some row, a match lies MSA2_WINDOW - 1 or more columns below the largest
- *      partner column seen up to and including that row, the group is not a set of reads of one molecule (its
- *      library is noise): the whole group is aligned by spec v1 (centre-star, msa.c) instead.       [own rule]
  *   7. output: one gapped row per read in group order, '-' for gaps.
  */
 #include "oracle.h"
@@ -50,7 +49,6 @@
 int orc_fail(const char* msg);
 
 #define MSA2_ROWCAP 16
-#define MSA2_WINDOW 64
 
 static char dna5(char c) {
     switch (c) {
@@ -282,6 +280,15 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
                 }
             }
 #undef ADD
+            /* noise filter */
+            {
+                int64_t wmax = 0;
+                int kept = 0;
+                for (int x = 0; x < cnt; ++x) if (lw[x] > wmax) wmax = lw[x];
+                for (int x = 0; x < cnt; ++x)
+                    if (2 * lw[x] >= wmax) { lj[kept] = lj[x]; lw[kept] = lw[x]; ++kept; }
+                cnt = kept;
+            }
             /* by column */
             for (int x = 1; x < cnt; ++x) {
                 const int64_t tj = lj[x], tw = lw[x];
@@ -301,20 +308,6 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
             }
         }
         free(idxA);
-        /* coherence guard */
-        {
-            int64_t top = -1;
-            for (int64_t m0 = 0; m0 < nm && !incoherent;) {
-                int64_t m1 = m0, rowmax = -1;
-                while (m1 < nm && mi[m1] == mi[m0]) { if (mj[m1] > rowmax) rowmax = mj[m1]; ++m1; }
-                const int64_t T = rowmax > top ? rowmax : top;
-                for (int64_t m = m0; m < m1; ++m)
-                    if (mj[m] <= T - MSA2_WINDOW + 1) incoherent = 1;
-                top = T;
-                m0 = m1;
-            }
-        }
-        if (incoherent) { free(posA); free(mi); free(mj); free(mw); break; }
         /* heaviest chain: f(m) = w(m) + best f over matches with smaller row and smaller column;
          * "best" = larger f, then smaller match index.  bestAt[j] = best match ending in column j among the
          * processed rows; a row's matches all look at the state before the row. */

@@ -330,7 +330,7 @@ def quick_msa(groupings, sequences, match, mismatch, gap_extension, gap_opening,
     """Same argument order as the reference .Call (src/quick_msa.cpp:15): note that
     the R caller passes (-gapOpening, -gapExtension) into (gap_extension, gap_opening)
     (R/multiReadAlign.R:47, SURVEY App.B Q15).  spec 2 (default): consistency-based progressive
-    alignment (msa2.c) for groups of up to `tcoffee_max` reads no longer than 32 735 bases, spec 1
+    alignment (msa2.c) for groups of up to `tcoffee_max` reads no longer than 21 823 bases, spec 1
     (centre-star, msa.c) beyond that and when spec == 1 -- the same policy as the product."""
     out = []
     for g in groupings:
@@ -344,7 +344,7 @@ def quick_msa(groupings, sequences, match, mismatch, gap_extension, gap_opening,
         buf = np.zeros(cap, np.uint8)
         width = C.c_int64()
         longest = int(np.diff(so).max()) if m else 0
-        fn = lib().orc_msa2_group if (spec == 2 and m <= tcoffee_max and 2 * longest + 64 <= 65535) else lib().orc_msa_group
+        fn = lib().orc_msa2_group if (spec == 2 and m <= tcoffee_max and 3 * longest + 64 <= 65535) else lib().orc_msa_group
         _check(fn(_p(sb), _p(so), C.c_int64(m), int(match), int(mismatch), int(gap_opening),
                   int(gap_extension), int(bandwidth), _p(buf), C.c_int64(cap), C.byref(width)))
         W = width.value

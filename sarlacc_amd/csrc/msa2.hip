@@ -43,6 +43,9 @@ namespace sarlacc {
 constexpr int M2_MAXN = 32;          // group sizes aligned by spec v2 (member sets are 32-bit masks)
 constexpr int M2_CAP = 16;           // partner columns per row on the fast path (private lists in LDS)
 constexpr unsigned M2_NONE = 0xFFFFu;
+// profile capacity of the first pass: same-molecule reads grow a profile by 10-20 %, one or two unrelated reads in
+// the cluster by their length each
+#define M2_FASTW(maxlen) (3 * (maxlen) + 64)
 
 struct M2Member {         // one read of a group
     long long seq_off;    // into d_seq
@@ -84,6 +87,7 @@ struct M2Args {
     unsigned* row_pred;            // id of the predecessor of every entry on its best chain (0: none)
     int* part;                     // partner column of column i of the first child, -1 if unmatched
     int* ovf;                      // per group: a capacity was exceeded
+    int* redo;                     // per group: this round's chain has to be done by k_m2_chain_exact
     int32_t* width;                // per group: columns of the final profile
     uint8_t* out;                  // gapped rows
 };
@@ -183,11 +187,14 @@ __global__ void k_m2_init(M2Args A, const int* member_group, int nmembers) {
 // agree on 1-3 columns).  Loads are issued in independent batches: the positions r_c of every third sequence
 // first (LDS), then up to M2_BATCH (c, b) pairs at a time -- the dependent chain map -> map -> col of one
 // candidate is three memory latencies long, so the pairs of a batch are looked up side by side.
-constexpr int M2_BATCH = 8;
+constexpr int M2_BATCH = 16;
 
 template <bool UNITW>
 __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
     __shared__ uint16_t s_r[M2_MAXN][64];   // position of the lane's base in every other member (0xFFFF: gap)
+    __shared__ long long s_mapbase[M2_MAXN], s_colbase[M2_MAXN], s_seqoff[M2_MAXN];   // the members' descriptors
+    __shared__ int s_len[M2_MAXN];
+    __shared__ int s_b[M2_MAXN];   // the second child's members, ascending
     const int g = blockIdx.y;
     const M2Group G = A.groups[g];
     if (round >= G.n - 1 || A.ovf[g] != 0) return;
@@ -196,29 +203,49 @@ __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
     const unsigned maskA = A.nodemask[2 * fm + jn.x], maskB = A.nodemask[2 * fm + jn.y];
     const int nA = A.ncols[2 * fm + jn.x];
     const int lane = threadIdx.x;
+    if (lane < M2_MAXN) {
+        const M2Member Me = A.members[fm + min(lane, n - 1)];
+        s_mapbase[lane] = Me.map_base; s_colbase[lane] = Me.col_base; s_seqoff[lane] = Me.seq_off; s_len[lane] = lane < n ? Me.len : 0;
+        if ((maskB >> lane) & 1u) s_b[__popc(maskB & ((1u << lane) - 1u))] = lane;
+    }
+    const int nbm = __popc(maskB);
+    __syncthreads();
+    const unsigned long long gclk0 = __builtin_amdgcn_s_memtime();
+    unsigned long long gcand = 0;
     for (int i0 = blockIdx.x * 64; i0 < nA; i0 += gridDim.x * 64) {
     const int i = i0 + lane;
     int ej[M2_CAP], ew[M2_CAP];
 #pragma unroll
     for (int k = 0; k < M2_CAP; ++k) { ej[k] = -1; ew[k] = 0; }
     int cnt = 0;
-    auto add = [&](int j, int w, bool valid) {
-        bool hit = !valid;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (!hit && ej[k] == j) { ew[k] += w; hit = true; }
-        if (__ballot(!hit)) {
-#pragma unroll
-            for (int k = 3; k < M2_CAP; ++k)
-                if (!hit && ej[k] == j) { ew[k] += w; hit = true; }
-            if (!hit && cnt < M2_CAP) {   // a new column; beyond M2_CAP distinct columns it is ignored (spec v2, step 5)
-#pragma unroll
-                for (int k = 0; k < M2_CAP; ++k)
-                    if (k == cnt) { ej[k] = j; ew[k] = w; }
-                ++cnt;
-            }
-        }
-    };
+    // add(j, w): selects only, every index a compile-time constant -- the lists must stay in registers (a lambda
+    // capturing the arrays, or an index the compiler cannot resolve, sends them to scratch memory, whose loads
+    // then wait behind every lookup in flight)
+#define M2_ADD(J, W, VALID)                                                                            \
+    {                                                                                                  \
+        const int j_ = (J), w_ = (W);                                                                  \
+        bool hit_ = !(VALID);                                                                          \
+        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                                             \
+            const bool m_ = !hit_ && ej[k_] == j_;                                                     \
+            ew[k_] += m_ ? w_ : 0;                                                                     \
+            hit_ = hit_ || m_;                                                                         \
+        }                                                                                              \
+        if (__ballot(!hit_)) {                                                                         \
+            _Pragma("unroll") for (int k_ = 3; k_ < M2_CAP; ++k_) {                                    \
+                const bool m_ = !hit_ && ej[k_] == j_;                                                 \
+                ew[k_] += m_ ? w_ : 0;                                                                 \
+                hit_ = hit_ || m_;                                                                     \
+            }                                                                                          \
+            /* a new column; beyond M2_CAP distinct columns it is ignored (spec v2, step 5) */         \
+            const bool app_ = !hit_ && cnt < M2_CAP;                                                   \
+            _Pragma("unroll") for (int k_ = 0; k_ < M2_CAP; ++k_) {                                    \
+                const bool s_ = app_ && k_ == cnt;                                                     \
+                ej[k_] = s_ ? j_ : ej[k_];                                                             \
+                ew[k_] = s_ ? w_ : ew[k_];                                                             \
+            }                                                                                          \
+            cnt += app_ ? 1 : 0;                                                                       \
+        }                                                                                              \
+    }
     const bool row = i < nA;
     for (int a = 0; a < n; ++a) {
         if (!((maskA >> a) & 1u)) continue;
@@ -227,95 +254,103 @@ __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
         if (!__ballot(havep)) continue;
         const M2Member Ma = A.members[fm + a];
         const int xa = (UNITW || !havep) ? 0 : dna5_code(A.seq[Ma.seq_off + p]);
-        // positions in every other member (independent loads)
-        for (int c = 0; c < n; ++c)
-            s_r[c][lane] = (c != a && havep) ? A.map[Ma.map_base + static_cast<long long>(c < a ? c : c - 1) * Ma.len + p] : static_cast<uint16_t>(M2_NONE);
-        // canonical order of the candidates: (c = b, b) for b in B ascending, then (c, b) for c ascending, b in B
-        // ascending, b != c.  Wave-uniform generator, M2_BATCH candidates looked up side by side.
-        int pc = -1, pb = -1;        // state of the generator: phase 0 (direct) uses pc == -1
-        bool more = true;
-        auto next = [&](int& c, int& b) -> bool {   // advances (pc, pb) to the next candidate
-            for (;;) {
-                ++pb;
-                while (pb < n && !((maskB >> pb) & 1u)) ++pb;
-                if (pb < n) {
-                    if (pc < 0) { c = pb; b = pb; return true; }          // direct edge a - b
-                    if (pb == pc) continue;
-                    c = pc; b = pb; return true;
+        // positions in every other member: unconditional loads (clamped), selected afterwards -- see below
+        {
+            const unsigned pidx = havep ? p : 0u;
+            for (int c0 = 0; c0 < n; c0 += 8) {
+                uint16_t rv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = min(c0 + u, n - 1);
+                    const int slot = c == a ? 0 : (c < a ? c : c - 1);
+                    rv[u] = A.map[Ma.map_base + static_cast<long long>(slot) * Ma.len + pidx];
                 }
-                pb = -1;
-                ++pc;
-                while (pc < n && pc == a) ++pc;
-                if (pc >= n) return false;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c0 + u < n) s_r[c0 + u][lane] = (c0 + u != a && havep) ? rv[u] : static_cast<uint16_t>(M2_NONE);
             }
-        };
-        while (more) {
-            int cc[M2_BATCH], bb[M2_BATCH];
-            int nb = 0;
+        }
+        // canonical order of the candidates: the direct edges (c = b) for b in B ascending, then for c ascending the
+        // triplets (c, b), b in B ascending, b != c -- a flat list of nbm + (n - 1) nbm entries, looked up M2_BATCH at a
+        // time side by side (the second child is often a single read: batching over its members alone would leave
+        // one candidate per memory latency).
+        const int total = nbm * n;   // direct pass (ci = 0) + the n - 1 third sequences
+        int ci = 0, bi = 0;          // position in the flat list: pass ci (0 = direct; ci >= 1: c = ci - 1, skipping a), member bi
+        for (int f0 = 0; f0 < total; f0 += M2_BATCH) {
+            // every load of the batch is unconditional (indices clamped to valid ones, results selected afterwards):
+            // a branch around a load makes the compiler wait for it before it issues the next one
+            unsigned qq[M2_BATCH];
+            int jj[M2_BATCH], ww[M2_BATCH], bq[M2_BATCH];
+            bool ok[M2_BATCH];
 #pragma unroll
             for (int u = 0; u < M2_BATCH; ++u) {
-                cc[u] = 0; bb[u] = 0;
-                if (more) {
-                    int c, b;
-                    if (next(c, b)) { cc[u] = c; bb[u] = b; nb = u + 1; }
-                    else more = false;
+                const bool in = f0 + u < total;
+                const int b = s_b[bi];
+                const int cu = ci == 0 ? b : ((ci - 1) + ((ci - 1) >= a ? 1 : 0));
+                const unsigned r = s_r[cu][lane];
+                const int bslot = cu == b ? 0 : (b < cu ? b : b - 1);
+                const unsigned ridx = min(r != M2_NONE ? r : 0u, static_cast<unsigned>(max(s_len[cu] - 1, 0)));
+                const unsigned m = A.map[s_mapbase[cu] + static_cast<long long>(bslot) * s_len[cu] + ridx];
+                qq[u] = cu == b ? r : m;
+                ok[u] = in && (ci == 0 || b != cu) && r != M2_NONE && qq[u] != M2_NONE;
+                bq[u] = b;
+                ww[u] = 1;
+                if (!UNITW) {
+                    const int xc = dna5_code(A.seq[s_seqoff[cu] + ridx]);
+                    ww[u] = (xc << 16) | ((cu == b ? 1 : 0) << 15) | m2_w0(xa, xc, A.ma, A.mm);   // (finished below)
                 }
-            }
-            unsigned rr[M2_BATCH], qq[M2_BATCH];
-            int jj[M2_BATCH], ww[M2_BATCH];
-#pragma unroll
-            for (int u = 0; u < M2_BATCH; ++u) {
-                rr[u] = M2_NONE; qq[u] = M2_NONE;
-                if (u < nb) {
-                    rr[u] = s_r[cc[u]][lane];
-                    if (rr[u] != M2_NONE) {
-                        if (cc[u] == bb[u]) qq[u] = rr[u];
-                        else {
-                            const M2Member Mc = A.members[fm + cc[u]];
-                            qq[u] = A.map[Mc.map_base + static_cast<long long>(bb[u] < cc[u] ? bb[u] : bb[u] - 1) * Mc.len + rr[u]];
-                        }
-                    }
-                }
+                if (in) { if (++bi == nbm) { bi = 0; ++ci; } }
             }
 #pragma unroll
             for (int u = 0; u < M2_BATCH; ++u) {
-                jj[u] = -1; ww[u] = 1;
-                if (u < nb && qq[u] != M2_NONE) {
-                    const M2Member Mb = A.members[fm + bb[u]];
-                    jj[u] = A.col[Mb.col_base + qq[u]];
-                    if (!UNITW) {
-                        const M2Member Mc = A.members[fm + cc[u]];
-                        const int xc = dna5_code(A.seq[Mc.seq_off + rr[u]]);
-                        const int wac = m2_w0(xa, xc, A.ma, A.mm);
-                        if (cc[u] == bb[u]) ww[u] = wac;
-                        else {
-                            const int wcb = m2_w0(xc, dna5_code(A.seq[Mb.seq_off + qq[u]]), A.ma, A.mm);
-                            ww[u] = wac < wcb ? wac : wcb;
-                        }
-                    }
+                const int b = bq[u];
+                const unsigned qidx = min(ok[u] ? qq[u] : 0u, static_cast<unsigned>(max(s_len[b] - 1, 0)));
+                jj[u] = A.col[s_colbase[b] + qidx];
+                if (!UNITW) {
+                    const int xc = ww[u] >> 16, wac = ww[u] & 0x7fff;
+                    const bool direct = (ww[u] >> 15) & 1;
+                    const int wcb = m2_w0(xc, dna5_code(A.seq[s_seqoff[b] + qidx]), A.ma, A.mm);
+                    ww[u] = direct ? wac : (wac < wcb ? wac : wcb);
                 }
             }
 #pragma unroll
             for (int u = 0; u < M2_BATCH; ++u)
-                if (u < nb) add(jj[u], ww[u], jj[u] >= 0);
+                if (f0 + u < total) M2_ADD(jj[u], ww[u], ok[u])
         }
+        gcand += total;
     }
     if (row) {
+        // noise filter (spec v2, step 5): entries lighter than half the row's heaviest are dropped -- the partner
+        // columns reached only through reads unrelated to the rest of the cluster
+        int wmax = 0;
+#pragma unroll
+        for (int k = 0; k < M2_CAP; ++k) wmax = max(wmax, ew[k]);
+        {
+            int kept = 0;
+#pragma unroll
+            for (int k = 0; k < M2_CAP; ++k) {
+                const bool keep = k < cnt && 2 * ew[k] >= wmax;
+                if (!keep) ej[k] = 0x7fffffff;   // sorts behind every kept column
+                kept += keep ? 1 : 0;
+            }
+            cnt = kept;
+        }
         // by column: rank of every entry among the valid ones (the columns of a list are distinct)
         unsigned long long* const mine = A.row_ent + (G.row_base + i) * static_cast<long long>(G.cap);
 #pragma unroll
         for (int k = 0; k < M2_CAP; ++k) {
-            if (k < cnt) {
+            if (ej[k] != 0x7fffffff && ej[k] >= 0) {
                 int rank = 0;
 #pragma unroll
                 for (int q = 0; q < M2_CAP; ++q)
-                    if (q < cnt && ej[q] < ej[k]) ++rank;
+                    if (ej[q] >= 0 && ej[q] < ej[k]) ++rank;
                 mine[rank] = (static_cast<unsigned long long>(static_cast<unsigned>(ej[k])) << 32) | static_cast<unsigned>(ew[k]);
             }
         }
         A.row_cnt[G.row_base + i] = static_cast<uint16_t>(cnt);
     }
     }
+    if (A.clk && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { A.clk[4] = __builtin_amdgcn_s_memtime() - gclk0; A.clk[5] = gcand; A.clk[6] = static_cast<unsigned long long>(nA); A.clk[7] = static_cast<unsigned long long>(n); }
 }
 
 // maximum of a 64-bit value over the 16 lanes of a DPP row
@@ -343,10 +378,10 @@ __device__ __forceinline__ unsigned long long m2_rowmax16(unsigned long long v) 
 // value is P[top]), so a match with column j reads P[j - 1] -- one access, no tree -- and entering it raises P on
 // the columns from j upwards for as long as they are smaller (a short run: the chain advances with the columns).
 // The 16 lanes of a group serve the 16 entries of one row.  P is a circular window of M2_PWIN columns in LDS:
-// the matches of same-molecule reads stay within a few columns of `top`.  Coherence guard of spec v2 (step 6):
-// a group in which some match lies M2_PWIN - 1 or more columns below the largest column seen up to and
-// including its row is not a set of reads of one molecule (its library is noise); it is flagged (ovf = 3),
-// dropped from the remaining rounds and aligned by spec v1 instead.
+// the matches of same-molecule reads stay within a few columns of `top`.  When a match lies M2_PWIN - 1 or more
+// columns below the largest column seen up to and including its row (unrelated reads in the cluster), the
+// window cannot answer: the group's round is flagged (redo) and done by k_m2_chain_exact, which keeps the
+// prefix maxima of ALL columns in a Fenwick tree.
 constexpr int M2_PWIN = 64;
 
 __device__ __forceinline__ int m2_qmax_i32(int v) {   // maximum over the 16 lanes of a DPP row, in every lane
@@ -407,17 +442,18 @@ __global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nact
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = ib + r;
-            const bool mk = act && !bad && i < nA && t < cb[r];
+            const bool mk0 = act && i < nA && t < cb[r];
             const unsigned long long e = eb[r];
             const int j = static_cast<int>(e >> 32);
             // query: best over the columns < j, state before the row
             unsigned long long v = 0;
-            // coherence guard: T = largest column up to and including this row; a match at or below T - W + 1 fails
+            // T = largest column up to and including this row; a match at or below T - W + 1 is beyond the window
             const int oldtop = top;
-            const int newtop = m2_qmax_i32(mk ? j : -1);
+            const int newtop = m2_qmax_i32(mk0 ? j : -1);
             const int T = max(top, newtop);
-            if (mk && j <= T - M2_PWIN + 1) bad = true;
-            if (mk && !bad && j > 0) {
+            if (mk0 && j <= T - M2_PWIN + 1) bad = true;
+            const bool mk = mk0 && !bad;
+            if (mk && j > 0) {
                 const int l = j - 1;   // (> T - W >= top - W: inside the window)
                 v = l > top ? ptop : pload(l);
             }
@@ -433,7 +469,7 @@ __global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nact
             }
             // enter the matches: raise P from column j upwards while it is smaller (a column beyond the old top was
             // just filled with the old plateau, which every new value exceeds: no need to read it)
-            if (mk && !bad) {
+            if (mk) {
                 for (int l = j; l <= top; ++l) {
                     if (l <= oldtop && pload(l) >= nv) break;
                     atomicMax(&P[pidx(l)], nv);
@@ -443,13 +479,14 @@ __global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nact
             const unsigned long long rowbest = m2_rowmax16(nv);
             ptop = rowbest > ptop ? rowbest : ptop;
         }
-        bad = m2_qmax_i32(bad ? 1 : 0) != 0;   // (a group that failed keeps going on garbage until here; it is redone)
+        bad = m2_qmax_i32(bad ? 1 : 0) != 0;   // (a failed group keeps going on garbage until here; its round is redone)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { eb[r] = en[r]; cb[r] = cn[r]; }
     }
     unsigned long long best = ptop;
-    if (act && bad && t == 0) A.ovf[g] = 3;
-    if (!act || bad) { nA = 0; best = 0; }
+    if (act && bad && t == 0) A.redo[g] = 1;
+    if (bad) { nA = 0; best = 0; }
+    if (!act) { nA = 0; best = 0; }
     // traceback through the stored predecessors, 16 rows staged at a time (the P window is free now)
     __threadfence();
     unsigned long long* const stage = &s_buf[qd][0];   // [16 rows][16 entries]
@@ -488,6 +525,128 @@ __global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nact
         const unsigned long long clk2 = __builtin_amdgcn_s_memtime();
         A.clk[0] = clk1 - clk0; A.clk[1] = clk2 - clk1; A.clk[2] = static_cast<unsigned long long>(nAmax);
     }
+}
+
+// ---- heaviest chain, exact for any pattern of matches: one wavefront per flagged group ----
+// Fenwick tree over the second child's columns: a match with column j reads the prefix maximum of nodes j,
+// j - lowbit(j), .. (columns < j) and afterwards raises nodes j + 1, (j + 1) + lowbit, ..; sub-groups of 16 lanes
+// serve one match each, one node per lane.  All matches of a row are looked up before any of them is entered.
+// GBIT: the tree lives in HBM (wcap + 1 nodes per group at row_base + g) -- profiles too wide for LDS.
+template <bool GBIT>
+__global__ void __launch_bounds__(64) k_m2_chain_exact(M2Args A, int round, unsigned long long* gbit) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int g = blockIdx.x;
+    if (!A.redo[g]) return;
+    const M2Group G = A.groups[g];
+    const int fm = G.first_member;
+    const int2 jn = A.joins[fm + round];
+    const int nA = A.ncols[2 * fm + jn.x], nB = A.ncols[2 * fm + jn.y];
+    const int lane = threadIdx.x;
+    unsigned long long* const s_stage = reinterpret_cast<unsigned long long*>(smem);   // [64 rows][M2_CAP]
+    unsigned long long* const s_nv = s_stage + 64 * M2_CAP;                              // [M2_CAP]
+    int* const s_j = reinterpret_cast<int*>(s_nv + M2_CAP);                             // [M2_CAP]
+    int* const s_cnt = s_j + M2_CAP;                                                    // [64]
+    unsigned long long* const bit = GBIT ? gbit + G.row_base + g : reinterpret_cast<unsigned long long*>(s_cnt + 64);   // [nB + 1]
+    for (int x = lane; x <= nB; x += 64) bit[x] = 0;
+    if (GBIT) __threadfence();
+    for (int i = lane; i < nA; i += 64) A.part[G.row_base + i] = -1;
+    const unsigned long long* const ent = A.row_ent + G.row_base * static_cast<long long>(M2_CAP);
+    unsigned* const prd = A.row_pred + G.row_base * static_cast<long long>(M2_CAP);
+    const int sub = lane >> 4, t = lane & 15;
+    const unsigned nBu = static_cast<unsigned>(nB);
+    const int last = max(nA - 1, 0);
+    unsigned long long best = 0;
+    auto bit_load = [&](unsigned x) -> unsigned long long {
+        if (GBIT) return __hip_atomic_load(&bit[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the atomics act in L2)
+        return bit[x];
+    };
+    for (int i0 = 0; i0 < nA; i0 += 64) {
+        __syncthreads();
+        {   // 64 rows: lane = row; unconditional loads (clamped row index)
+            const int rowi = min(i0 + lane, last);
+            unsigned long long ev[M2_CAP];
+#pragma unroll
+            for (int k = 0; k < M2_CAP; ++k) ev[k] = ent[static_cast<long long>(rowi) * M2_CAP + k];
+            const int c = static_cast<int>(A.row_cnt[G.row_base + rowi]);
+#pragma unroll
+            for (int k = 0; k < M2_CAP; ++k) s_stage[lane * M2_CAP + k] = ev[k];
+            s_cnt[lane] = (i0 + lane < nA) ? c : 0;
+        }
+        __syncthreads();
+        const int rows = min(64, nA - i0);
+        for (int r = 0; r < rows; ++r) {
+            const int c = min(__builtin_amdgcn_readfirstlane(s_cnt[r]), M2_CAP);
+            if (c == 0) continue;
+            const int i = i0 + r;
+            for (int k0 = 0; k0 < c; k0 += 4) {          // queries
+                const int k = k0 + sub;
+                const bool act = k < c;
+                const unsigned long long e = act ? s_stage[r * M2_CAP + k] : 0ull;
+                const int j = static_cast<int>(e >> 32);
+                unsigned x = act ? static_cast<unsigned>(j) : 0u;
+#pragma unroll
+                for (int q = 0; q < 15; ++q) x = (q < t) ? (x & (x - 1u)) : x;
+                unsigned long long v = x ? bit_load(x) : 0ull;
+                v = m2_rowmax16(v);
+                const unsigned f = static_cast<unsigned>(e) + static_cast<unsigned>(v >> 32);
+                const unsigned pred = v ? ~static_cast<unsigned>(v) : 0u;
+                const unsigned id = static_cast<unsigned>(i) * M2_CAP + static_cast<unsigned>(k) + 1u;
+                const unsigned long long nv = (static_cast<unsigned long long>(f) << 32) | static_cast<unsigned>(~id);
+                if (act) {
+                    best = nv > best ? nv : best;
+                    if (t == 0) { prd[static_cast<long long>(i) * M2_CAP + k] = pred; s_j[k] = j; s_nv[k] = nv; }
+                }
+            }
+            __syncthreads();
+            for (int k0 = 0; k0 < c; k0 += 4) {          // updates
+                const int k = k0 + sub;
+                if (k < c) {
+                    const unsigned long long nv = s_nv[k];
+                    unsigned y = static_cast<unsigned>(s_j[k]) + 1u;
+#pragma unroll
+                    for (int q = 0; q < 15; ++q) y = (q < t && y <= nBu) ? y + (y & (0u - y)) : y;
+                    if (y <= nBu) atomicMax(&bit[y], nv);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    {   // the chain's last match: maximum over the four sub-groups
+        const unsigned long long o1 = (static_cast<unsigned long long>(static_cast<unsigned>(__shfl_xor(static_cast<int>(best >> 32), 16))) << 32) |
+                                      static_cast<unsigned>(__shfl_xor(static_cast<int>(best), 16));
+        best = o1 > best ? o1 : best;
+        const unsigned long long o2 = (static_cast<unsigned long long>(static_cast<unsigned>(__shfl_xor(static_cast<int>(best >> 32), 32))) << 32) |
+                                      static_cast<unsigned>(__shfl_xor(static_cast<int>(best), 32));
+        best = o2 > best ? o2 : best;
+    }
+    // traceback through the stored predecessors, 64 rows staged at a time
+    __threadfence();
+    unsigned id = best ? ~static_cast<unsigned>(best) : 0u;
+    id = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(id)));
+    int steps = 2 * nA + 64;   // a chain has at most one match per row; staging a block also counts one step
+    while (id && --steps >= 0) {
+        const int itop = static_cast<int>((id - 1u) / M2_CAP);
+        const int i0 = max(0, itop - 63);
+        __syncthreads();
+        {
+            const int rowi = min(i0 + lane, itop);
+            unsigned long long ev[M2_CAP];
+            unsigned pv[M2_CAP];
+#pragma unroll
+            for (int k = 0; k < M2_CAP; ++k) { ev[k] = ent[static_cast<long long>(rowi) * M2_CAP + k]; pv[k] = prd[static_cast<long long>(rowi) * M2_CAP + k]; }
+#pragma unroll
+            for (int k = 0; k < M2_CAP; ++k) s_stage[lane * M2_CAP + k] = (ev[k] & 0xffffffff00000000ull) | pv[k];
+        }
+        __syncthreads();
+        while (id && --steps >= 0) {
+            const int i = static_cast<int>((id - 1u) / M2_CAP), k = static_cast<int>((id - 1u) % M2_CAP);
+            if (i < i0) break;
+            const unsigned long long e = s_stage[(i - i0) * M2_CAP + k];
+            if (lane == 0) A.part[G.row_base + i] = static_cast<int>(e >> 32);
+            id = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned>(e))));
+        }
+    }
+    if (lane == 0) A.redo[g] = 0;
 }
 
 // ---- wave helpers for the renumbering (performance is irrelevant here) ----
@@ -688,7 +847,7 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
             sum += len;
             mx = std::max(mx, len);
         }
-        const long long fast_w = 2 * mx + 64;   // profiles of same-molecule reads grow by 10-20 %; two molecules in one cluster still fit
+        const long long fast_w = M2_FASTW(mx);
         // (65535 columns is the ceiling of spec v2: positions and the 16-level Fenwick tree; only reachable when the
         // sum of the read lengths exceeds it AND the alignment really is that wide)
         G.wcap = static_cast<int>(std::min<long long>(65535, std::min<long long>(sum, exact_w ? sum : fast_w)));
@@ -771,15 +930,18 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     SL_TRY(scratch((pf + ".ncb").c_str(), static_cast<size_t>(row_n) + 1, &d_ncb));
     SL_TRY(scratch((pf + ".pb").c_str(), static_cast<size_t>(row_n) + 1, &d_pb));
     SL_TRY(scratch((pf + ".ovf").c_str(), ng, &d_ovf));
+    int* d_redo;
+    SL_TRY(scratch((pf + ".redo").c_str(), ng, &d_redo));
+    SL_HIP(hipMemsetAsync(d_redo, 0, sizeof(int) * ng, s));
     SL_TRY(scratch((pf + ".width").c_str(), ng, &d_width));
     SL_HIP(hipMemsetAsync(d_ovf, 0, sizeof(int) * ng, s));
     a.seq = d_seq; a.groups = d_groups; a.members = d_members; a.ngroups = static_cast<int>(ng);
     a.ma = static_cast<int>(match); a.mm = static_cast<int>(mismatch);
     unsigned long long* d_clk = nullptr;
-    if (std::getenv("SARLACC_MSA2_CLOCKS")) { SL_TRY(scratch((pf + ".clk").c_str(), 4, &d_clk)); SL_HIP(hipMemsetAsync(d_clk, 0, 32, s)); }
+    if (std::getenv("SARLACC_MSA2_CLOCKS")) { SL_TRY(scratch((pf + ".clk").c_str(), 8, &d_clk)); SL_HIP(hipMemsetAsync(d_clk, 0, 64, s)); }
     a.clk = d_clk;
     a.map = d_map; a.stats = d_stats; a.dist = d_dist; a.joins = d_joins; a.nodemask = d_mask; a.ncols = d_ncols;
-    a.col = d_col; a.pos = d_pos; a.row_cnt = d_cnt; a.row_ent = d_ent; a.row_pred = d_pred; a.part = d_part; a.ovf = d_ovf; a.width = d_width;
+    a.col = d_col; a.pos = d_pos; a.row_cnt = d_cnt; a.row_ent = d_ent; a.row_pred = d_pred; a.part = d_part; a.ovf = d_ovf; a.redo = d_redo; a.width = d_width;
 
     // ---- all pairs ----
     for (const MsaJob& J : B.jobs) *cells += static_cast<double>(J.lr) * (std::abs(J.lc - J.lr) + 2 * bandwidth + 1);
@@ -797,6 +959,14 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     // The groups of a batch are ordered by size (m2_plan), so the groups that still have a join to do in round r
     // are a prefix of the batch.
     const bool unitw = a.ma <= 1 && a.mm <= 1;
+    // exact chain kernel: Fenwick tree in LDS while it fits 64 KB, in HBM for wider profiles
+    const size_t exact_base = sizeof(unsigned long long) * (64 * M2_CAP + M2_CAP) + sizeof(int) * (M2_CAP + 64);
+    const bool exact_gbit = exact_base + sizeof(unsigned long long) * (static_cast<size_t>(B.max_wcap) + 2) > 64 * 1024;
+    const size_t exact_lds = exact_gbit ? exact_base : exact_base + sizeof(unsigned long long) * (static_cast<size_t>(B.max_wcap) + 2);
+    unsigned long long* d_gbit = nullptr;
+    if (exact_gbit) SL_TRY(scratch((pf + ".gbit").c_str(), static_cast<size_t>(row_n) + ng + 1, &d_gbit));
+    else if (exact_lds > 48 * 1024)
+        SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_m2_chain_exact<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(exact_lds)));
     for (int round = 0; round + 1 < B.max_n; ++round) {
         int nactive = 0;
         while (nactive < static_cast<int>(ng) && B.groups[nactive].n - 1 > round) ++nactive;
@@ -805,6 +975,9 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
         if (unitw) hipLaunchKernelGGL(k_m2_gather<true>, ggrid, dim3(64), 0, s, a, round);
         else hipLaunchKernelGGL(k_m2_gather<false>, ggrid, dim3(64), 0, s, a, round);
         hipLaunchKernelGGL(k_m2_chain_q, dim3(m2_blocks(nactive, 4)), dim3(64), 0, s, a, round, nactive);
+        // rounds the window could not answer (unrelated reads in the cluster): exact chain search
+        if (exact_gbit) hipLaunchKernelGGL(k_m2_chain_exact<true>, dim3(static_cast<unsigned>(nactive)), dim3(64), exact_lds, s, a, round, d_gbit);
+        else hipLaunchKernelGGL(k_m2_chain_exact<false>, dim3(static_cast<unsigned>(nactive)), dim3(64), exact_lds, s, a, round, d_gbit);
         hipLaunchKernelGGL(k_m2_merge, dim3(static_cast<unsigned>(nactive)), dim3(256), 0, s, a, round, d_nca, d_ncb, d_pb);
         SL_HIP(hipGetLastError());
         if (std::getenv("SARLACC_MSA2_DEBUG")) {   // first group of the batch, for comparison with ORC_MSA2_DEBUG of the oracle
@@ -831,8 +1004,9 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
         }
     }
     if (d_clk) {
-        unsigned long long hc[4];
+        unsigned long long hc[8];
         SL_HIP(hipMemcpy(hc, d_clk, sizeof hc, hipMemcpyDeviceToHost));
+        fprintf(stderr, "gather kernel, block (0,0) of the last launch: %llu cycles, %llu candidate steps (x64 lanes), %llu rows in the profile, n = %llu\n", hc[4], hc[5], hc[6], hc[7]);
         fprintf(stderr, "chain kernel, first wave of the last LDS launch: forward %llu cycles, traceback %llu cycles, %llu rows\n", hc[0], hc[1], hc[2]);
     }
     hipLaunchKernelGGL(k_m2_width, dim3(m2_blocks(static_cast<long long>(ng), 256)), dim3(256), 0, s, a);
@@ -867,22 +1041,16 @@ static int m2_write_batch(M2Batch& B, const std::string& pf, const std::vector<l
     return 0;
 }
 
-// spec v2 on the groups `ids` of the caller's list; rows land in *d_rows in `ids` order at off[q] (off has
-// ids.size() + 1 entries), widths in width[q].
+// spec v2 on the groups `ids` of the caller's list; rows land in *d_rows at off[k] for ids[k] (processing order:
+// the offsets are not cumulative in k), widths in width[k].
 static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vector<int64_t>& ids, const uint8_t* d_seq,
                      const std::vector<int64_t>& rel, double match, double mismatch, double gap_extension, double gap_opening,
                      int bandwidth, std::vector<int32_t>& width, std::vector<long long>& off, uint8_t** d_rows,
-                     std::vector<size_t>* incoherent, const std::function<int()>* overlap, hipStream_t s) {
+                     const std::function<int()>* overlap, hipStream_t s) {
     Context& c = ctx();
     width.assign(ids.size(), 0);
-    off.assign(ids.size() + 1, 0);   // off[k]: start of the rows of ids[k] in the row buffer (processing order, not cumulative in k)
+    off.assign(ids.size() + 1, 0);
     *d_rows = nullptr;
-    // processing order: by decreasing group size, so that a batch holds groups with about the same number of joins
-    std::vector<size_t> order(ids.size());
-    std::iota(order.begin(), order.end(), size_t(0));
-    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
-        return grp_off[ids[x] + 1] - grp_off[ids[x]] > grp_off[ids[y] + 1] - grp_off[ids[y]];
-    });
     // row buffer: grown when a batch does not fit (contents are kept)
     Workspace& rows_ws = c.ws["msa2.rows"];
     auto rows_reserve = [&](size_t used, size_t need) -> int {
@@ -899,120 +1067,67 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         rows_ws.cap = want;
         return 0;
     };
-    // batches by memory: position maps (2 B x n (n - 1) x length), pairwise jobs, row lists
-    const long long map_budget = 6LL << 30, ent_budget = 6LL << 30, job_budget = 3000000;
-    size_t q0 = 0;
+    const long long map_budget = 6LL << 30, ent_budget = 8LL << 30, job_budget = 3000000;
     double cells = 0, pairs = 0;
     bool first = true;
     long long used = 0;
-    while (q0 < ids.size()) {
-        M2Batch B;
-        long long map_b = 0, ent_b = 0, jobs_b = 0;
-        size_t q1 = q0;
-        while (q1 < ids.size()) {
-            const int64_t g = ids[order[q1]];
-            const long long n = grp_off[g + 1] - grp_off[g];
-            long long sum = 0, mx = 0;
-            for (long long a = 0; a < n; ++a) { const long long len = rel[grp[grp_off[g] + a]] - rel[grp[grp_off[g] + a] - 1]; sum += len; mx = std::max(mx, len); }
-            const long long mb = 2 * (n - 1) * sum, eb = std::min(sum, 2 * mx + 64) * M2_CAP * 8, jb = n * (n - 1) / 2;
-            if (q1 > q0 && (map_b + mb > map_budget || ent_b + eb > ent_budget || jobs_b + jb > job_budget)) break;
-            map_b += mb; ent_b += eb; jobs_b += jb;
-            B.ids.push_back(g);
-            B.slot.push_back(order[q1]);   // (already by decreasing size: the groups with a join left in round r are a prefix)
-            ++q1;
-        }
-        SL_TRY(m2_plan(B, grp_off, grp, rel.data(), false));
-        SL_TRY(m2_run_batch(B, "m2", d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, false, first ? overlap : nullptr, &cells, s));
-        first = false;
-        pairs += static_cast<double>(B.jobs.size());
-        // Groups whose profiles outgrew the fast capacity (unrelated reads in one cluster) are redone with profiles
-        // as wide as the sum of the read lengths.  Every redo batch keeps its own workspaces until its rows are written.
-        // ovf 1: profile capacity exceeded (redo below); 3: coherence guard (the caller aligns the group by spec v1)
-        std::vector<size_t> cur;
-        std::vector<char> dropped(B.groups.size(), 0);
-        for (size_t q = 0; q < B.groups.size(); ++q) {
-            if (B.ovf[q] == 3) { dropped[q] = 1; incoherent->push_back(B.slot[q]); }
-            else if (B.ovf[q]) cur.push_back(q);
-        }
-        std::vector<M2Batch> xb;
-        std::vector<std::vector<size_t>> xsrc;                 // fast-batch index of every group of a redo batch
-        std::vector<std::pair<int, int>> final_of(B.groups.size(), std::make_pair(-1, -1));   // (redo batch, group in it)
-        for (int level = 1; level < 2 && !cur.empty(); ++level) {   // (one level: the lists are bounded by the spec)
-            std::vector<size_t> next;
-            for (size_t r0 = 0; r0 < cur.size();) {
-                xb.emplace_back();
-                xsrc.emplace_back();
-                M2Batch& X = xb.back();
-                long long ent_x = 0;
-                size_t r1 = r0;
-                while (r1 < cur.size()) {
-                    const M2Group& G = B.groups[cur[r1]];
-                    long long sum = 0, mx = 0;
-                    for (int a = 0; a < G.n; ++a) { sum += B.members[G.first_member + a].len; mx = std::max<long long>(mx, B.members[G.first_member + a].len); }
-                    (void)mx;
-                    const long long eb = sum * M2_CAP * 8;
-                    if (r1 > r0 && ent_x + eb > ent_budget) break;
-                    ent_x += eb;
-                    X.ids.push_back(B.ids[cur[r1]]);
-                    xsrc.back().push_back(cur[r1]);
-                    ++r1;
-                }
-                r0 = r1;
-                {   // by decreasing size, as in every batch
-                    std::vector<size_t> ord(X.ids.size());
-                    std::iota(ord.begin(), ord.end(), size_t(0));
-                    std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
-                        return grp_off[X.ids[x] + 1] - grp_off[X.ids[x]] > grp_off[X.ids[y] + 1] - grp_off[X.ids[y]];
-                    });
-                    std::vector<int64_t> ids2(ord.size());
-                    std::vector<size_t> src2(ord.size());
-                    for (size_t k = 0; k < ord.size(); ++k) { ids2[k] = X.ids[ord[k]]; src2[k] = xsrc.back()[ord[k]]; }
-                    X.ids.swap(ids2);
-                    xsrc.back().swap(src2);
-                }
-                const int bi = static_cast<int>(xb.size()) - 1;
-                SL_TRY(m2_plan(X, grp_off, grp, rel.data(), true));
-                SL_TRY(m2_run_batch(X, "m2x" + std::to_string(bi), d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, false, nullptr, &cells, s));
-                for (size_t q = 0; q < X.groups.size(); ++q) {
-                    if (X.ovf[q] == 3) { dropped[xsrc[bi][q]] = 1; incoherent->push_back(B.slot[xsrc[bi][q]]); }
-                    else if (X.ovf[q]) next.push_back(xsrc[bi][q]);
-                    else final_of[xsrc[bi][q]] = std::make_pair(bi, static_cast<int>(q));
-                }
+    // Pass 0: every group with the fast profile capacity.  Pass 1: the groups whose profiles outgrew it (several
+    // unrelated reads in one cluster), with profiles as wide as the sum of the read lengths.
+    std::vector<size_t> todo(ids.size());
+    std::iota(todo.begin(), todo.end(), size_t(0));
+    for (int pass = 0; pass < 2 && !todo.empty(); ++pass) {
+        const bool exact_w = pass == 1;
+        // processing order: by decreasing group size, so that a batch holds groups with about the same number of joins
+        std::stable_sort(todo.begin(), todo.end(), [&](size_t x, size_t y) {
+            return grp_off[ids[x] + 1] - grp_off[ids[x]] > grp_off[ids[y] + 1] - grp_off[ids[y]];
+        });
+        std::vector<size_t> again;
+        size_t q0 = 0;
+        while (q0 < todo.size()) {
+            M2Batch B;
+            long long map_b = 0, ent_b = 0, jobs_b = 0;
+            size_t q1 = q0;
+            while (q1 < todo.size()) {
+                const int64_t g = ids[todo[q1]];
+                const long long n = grp_off[g + 1] - grp_off[g];
+                long long sum = 0, mx = 0;
+                for (long long a = 0; a < n; ++a) { const long long len = rel[grp[grp_off[g] + a]] - rel[grp[grp_off[g] + a] - 1]; sum += len; mx = std::max(mx, len); }
+                const long long wc = exact_w ? sum : std::min(sum, M2_FASTW(mx));
+                const long long mb = 2 * (n - 1) * sum, eb = wc * M2_CAP * 12, jb = n * (n - 1) / 2;
+                if (q1 > q0 && (map_b + mb > map_budget || ent_b + eb > ent_budget || jobs_b + jb > job_budget)) break;
+                map_b += mb; ent_b += eb; jobs_b += jb;
+                B.ids.push_back(g);
+                B.slot.push_back(todo[q1]);   // (already by decreasing size: the groups with a join left in round r are a prefix)
+                ++q1;
             }
-            cur.swap(next);
-        }
-        if (!cur.empty()) return fail("sarlacc_amd: an alignment wider than 65535 columns is beyond spec v2 (select spec 1 with sarlacc_set_msa_spec)");
-        for (size_t q = 0; q < B.groups.size(); ++q)
-            width[B.slot[q]] = dropped[q] ? 0 : (final_of[q].first >= 0 ? xb[final_of[q].first].width[final_of[q].second] : B.width[q]);
-        long long need = used;
-        for (size_t k = q0; k < q1; ++k) {
-            const size_t sl = order[k];
-            off[sl] = need;
-            need += static_cast<long long>(width[sl]) * (grp_off[ids[sl] + 1] - grp_off[ids[sl]]);
-        }
-        SL_TRY(rows_reserve(static_cast<size_t>(used), static_cast<size_t>(need) + 1));
-        uint8_t* const d_out = static_cast<uint8_t*>(rows_ws.ptr);
-        {
-            // every batch writes the groups it resolved; the others get width 0 there
-            auto write = [&](M2Batch& X, const std::string& pf, const std::vector<size_t>* src, int bi) -> int {
-                std::vector<long long> boff(X.groups.size(), 0);
-                std::vector<int32_t> bw = X.width;
-                for (size_t q = 0; q < X.groups.size(); ++q) {
-                    const size_t fq = src ? (*src)[q] : q;
-                    const bool mine = !dropped[fq] && (src ? (final_of[fq].first == bi && final_of[fq].second == static_cast<int>(q)) : final_of[fq].first < 0);
-                    if (mine) boff[q] = off[B.slot[fq]]; else bw[q] = 0;
+            SL_TRY(m2_plan(B, grp_off, grp, rel.data(), exact_w));
+            SL_TRY(m2_run_batch(B, "m2", d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, false, first ? overlap : nullptr, &cells, s));
+            first = false;
+            pairs += static_cast<double>(B.jobs.size());
+            long long need = used;
+            std::vector<long long> boff(B.groups.size(), 0);
+            std::vector<int32_t> bw = B.width;
+            for (size_t q = 0; q < B.groups.size(); ++q) {
+                if (B.ovf[q]) {   // profile capacity exceeded: next pass
+                    if (exact_w) return fail("sarlacc_amd: an alignment wider than 65535 columns is beyond spec v2 (select spec 1 with sarlacc_set_msa_spec)");
+                    again.push_back(B.slot[q]);
+                    bw[q] = 0;
+                    continue;
                 }
-                SL_HIP(hipMemcpyAsync(X.a.width, bw.data(), sizeof(int32_t) * bw.size(), hipMemcpyHostToDevice, s));
-                X.width = bw;
-                SL_TRY(m2_write_batch(X, pf, boff, d_out, s));
-                SL_HIP(hipStreamSynchronize(s));   // bw / boff are read by the copies above
-                return 0;
-            };
-            SL_TRY(write(B, "m2", nullptr, -1));
-            for (size_t bi = 0; bi < xb.size(); ++bi) SL_TRY(write(xb[bi], "m2x" + std::to_string(bi), &xsrc[bi], static_cast<int>(bi)));
+                width[B.slot[q]] = bw[q];
+                off[B.slot[q]] = need;
+                boff[q] = need;
+                need += static_cast<long long>(bw[q]) * B.groups[q].n;
+            }
+            SL_TRY(rows_reserve(static_cast<size_t>(used), static_cast<size_t>(need) + 1));
+            SL_HIP(hipMemcpyAsync(B.a.width, bw.data(), sizeof(int32_t) * bw.size(), hipMemcpyHostToDevice, s));
+            B.width = bw;
+            SL_TRY(m2_write_batch(B, "m2", boff, static_cast<uint8_t*>(rows_ws.ptr), s));
+            SL_HIP(hipStreamSynchronize(s));   // the batch's host vectors and workspaces are reused by the next one
+            used = need;
+            q0 = q1;
         }
-        used = need;
-        q0 = q1;
+        todo.swap(again);
     }
     c.counts["msa_pairs"] = (c.counts.count("msa_pairs") ? c.counts["msa_pairs"] : 0.0) + pairs;
     c.counts["msa_cells"] = (c.counts.count("msa_cells") ? c.counts["msa_cells"] : 0.0) + cells;
@@ -1058,7 +1173,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         int64_t mx = 0;
         for (int64_t a = 0; a < n; ++a) { const int32_t id = grp[grp_off[g] + a]; mx = std::max<int64_t>(mx, rel[id] - rel[id - 1]); }
         if (mx > 60000) return fail("sarlacc_amd: reads longer than 60000 bases are not supported by the MSA stage");
-        if (n <= M2_MAXN && 2 * mx + 64 <= 65535) v2.push_back(g); else v1.push_back(g);
+        if (n <= M2_MAXN && M2_FASTW(mx) <= 65535) v2.push_back(g); else v1.push_back(g);
     }
     SL_TRY(ensure_device());
     Context& c = ctx();
@@ -1081,14 +1196,8 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     std::vector<int32_t> w2;
     std::vector<long long> o2;
     uint8_t* d_rows2 = nullptr;
-    std::vector<size_t> incoherent;   // positions in v2 of the groups the coherence guard dropped
-    SL_TRY(msa2_core(grp_off, grp, v2, d_seq, rel, match, mismatch, gap_extension, gap_opening, bandwidth, w2, o2, &d_rows2, &incoherent, overlap, s));
-    c.counts["msa_v1_fallback"] = static_cast<double>(incoherent.size());
-    if (!incoherent.empty()) {
-        std::sort(incoherent.begin(), incoherent.end());
-        for (size_t q : incoherent) v1.push_back(v2[q]);
-        std::sort(v1.begin(), v1.end());
-    }
+    SL_TRY(msa2_core(grp_off, grp, v2, d_seq, rel, match, mismatch, gap_extension, gap_opening, bandwidth, w2, o2, &d_rows2, overlap, s));
+    c.counts["msa_v1_fallback"] = static_cast<double>(v1.size());
     // spec v1 part on a compacted group list: more than M2_MAXN reads, reads too long, or dropped by the guard
     MsaResult r1;
     std::vector<int64_t> g1off(v1.size() + 1, 0);
@@ -1111,7 +1220,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         size_t a1 = 0, a2 = 0;
         for (int64_t g = 0; g < ngroups; ++g) {
             const int64_t n = grp_off[g + 1] - grp_off[g];
-            const bool in2 = a2 < v2.size() && v2[a2] == g;   // (a group dropped by the guard is in both lists: v1 has its rows)
+            const bool in2 = a2 < v2.size() && v2[a2] == g;
             if (a1 < v1.size() && v1[a1] == g) { width_out[g] = r1.width[a1]; src_off[g] = r1.out_off[a1]; from1[g] = 1; ++a1; }
             else { width_out[g] = w2[a2]; src_off[g] = o2[a2]; }
             if (in2) ++a2;
