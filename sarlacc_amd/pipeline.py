@@ -47,15 +47,15 @@ def all_gather_labels(label, pos, dist, device_t=None):
     if device_t is not None:
         msg = msg.to(device_t)
     world = dist.get_world_size()
-    out = torch.empty((world,) + tuple(msg.shape), dtype=msg.dtype, device=msg.device)
+    parts = [torch.empty_like(msg) for _ in range(world)]   # (list form: works on RCCL and on gloo)
     if device_t is not None:
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    dist.all_gather_into_tensor(out, msg)
+    dist.all_gather(parts, msg)
     if device_t is not None:
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    res = out.cpu().numpy()
+    res = np.stack([p.cpu().numpy() for p in parts])
     return res[:, 0, :], res[:, 1, :], dt, int(msg.numel() * msg.element_size() * (world - 1))
 
 

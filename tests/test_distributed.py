@@ -144,3 +144,53 @@ def test_two_rank_tile_sharding_of_one_giant_group():
         umis += umisim(rng, 9, 10)
     want = [c.tolist() for c in oracle_calls.umi_group(umis, 1, None, 1, [list(range(1, len(umis) + 1))])]
     assert results[0][1] == want and results[1][1] == want
+
+
+def _worker_labels(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from sarlacc_amd import pipeline
+    from tests import oracle_calls
+    from tests.test_oracle_umi import umisim
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        # every rank owns one pre-group (its own reads), as bench.py --gpus N does
+        rng = np.random.default_rng(100 + rank)
+        umis = []
+        for _ in range(40):
+            umis += umisim(rng, 5, 10)
+        n = len(umis)
+        clusters = oracle_calls.umi_group(umis, 1, None, 1, [list(range(1, n + 1))])
+        coff = np.zeros(len(clusters) + 1, np.int64)
+        np.cumsum([len(c) for c in clusters], out=coff[1:])
+        cmem = np.concatenate(clusters).astype(np.int32)
+        label, pos = pipeline.labels_from_clusters(coff, cmem, n)
+        labs, poss, secs, nbytes = pipeline.all_gather_labels(label, pos, dist, None)
+        q.put((rank, [c.tolist() for c in clusters], labs.tolist(), poss.tolist(), nbytes))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_label_all_gather():
+    """The pipeline's one exchange step (bench.py --gpus N, BASELINE config 5): every rank clusters its own
+    pre-group and all-gathers (label, position) per read; from the gathered vectors every rank can rebuild
+    every rank's cluster list exactly."""
+    import torch.multiprocessing as mp
+    from sarlacc_amd import pipeline
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_labels, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0][2] == results[1][2] and results[0][3] == results[1][3]   # both ranks hold the same gathered labels
+    for r in range(2):
+        coff, cmem = pipeline.clusters_from_labels(np.array(results[0][2][r]), np.array(results[0][3][r]))
+        rebuilt = [cmem[coff[k]:coff[k + 1]].tolist() for k in range(coff.size - 1)]
+        assert rebuilt == results[r][1]
+        assert results[r][4] == 2 * 4 * len(results[0][2][r])   # bytes received from the one other rank
