@@ -1,0 +1,112 @@
+"""The Rcpp shims under r-glue/src cannot be compiled here (no R toolchain), so they are checked as
+text: each .Call routine of the hot path (/root/reference/src/init.cpp:9-35, names and arities
+restated below) has exactly one shim with that arity, and every sarlacc_* call in the shims names a
+function that include/sarlacc_amd.h declares, with the declared number of arguments."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GLUE = os.path.join(ROOT, "r-glue", "src")
+
+# routine -> number of SEXP arguments (init.cpp:9-35); the three profiling helpers stay in the reference's C++
+ROUTINES = {
+    "adaptor_align": 8, "adaptor_align_score_only": 6, "barcode_align": 6, "general_align": 7,
+    "mask_bad_bases": 4, "unmask_alignment": 2,
+    "create_consensus_basic": 3, "create_consensus_basic_loop": 3,
+    "create_consensus_quality": 4, "create_consensus_quality_loop": 4,
+    "umi_group": 5, "fast_levdist_test": 3, "cluster_umis_test": 1, "compute_lev_masked": 1,
+    "quick_msa": 7,
+}
+
+
+def _strip_comments(text):
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", text)
+
+
+def _split_args(s):
+    """top-level comma split of an argument list"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _calls(text, prefix):
+    """(name, [args]) for every `prefix...(` occurrence, with balanced parentheses"""
+    res = []
+    for m in re.finditer(r"\b(" + prefix + r"\w*)\s*\(", text):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(text[i], 0)
+            i += 1
+        res.append((m.group(1), _split_args(text[m.end():i - 1])))
+    return res
+
+
+def _header_decls():
+    text = _strip_comments(open(os.path.join(ROOT, "include", "sarlacc_amd.h")).read())
+    decls = {}
+    for name, args in _calls(text, "sarlacc_"):
+        decls[name] = 0 if args == ["void"] else len(args)
+    return decls
+
+
+def _glue_sources():
+    return {f: _strip_comments(open(os.path.join(GLUE, f)).read()) for f in sorted(os.listdir(GLUE))
+            if f.endswith((".cpp", ".h"))}
+
+
+def test_every_routine_has_one_shim_with_the_registered_arity():
+    found = {}
+    for fname, text in _glue_sources().items():
+        for m in re.finditer(r"^SEXP\s+(\w+)\s*\(([^)]*)\)\s*\{", text, flags=re.M):
+            args = _split_args(m.group(2))
+            assert all(a.startswith("SEXP") for a in args), (fname, m.group(1))
+            assert m.group(1) not in found, "two shims for " + m.group(1)
+            found[m.group(1)] = len(args)
+    assert found == ROUTINES
+
+
+def test_every_abi_call_matches_the_header():
+    decls = _header_decls()
+    used = set()
+    for fname, text in _glue_sources().items():
+        for name, args in _calls(text, "sarlacc_"):
+            assert name in decls, "%s calls %s, which include/sarlacc_amd.h does not declare" % (fname, name)
+            assert len(args) == decls[name], "%s: %s called with %d arguments, declared with %d" % (
+                fname, name, len(args), decls[name])
+            used.add(name)
+    # one host-pointer entry point per routine family
+    expect = {"sarlacc_adaptor_align", "sarlacc_adaptor_align_score_only", "sarlacc_barcode_align", "sarlacc_general_align",
+              "sarlacc_mask_bad_bases", "sarlacc_unmask_alignment", "sarlacc_umi_group", "sarlacc_fast_levdist_test",
+              "sarlacc_cluster_umis_test", "sarlacc_compute_lev_masked", "sarlacc_quick_msa",
+              "sarlacc_create_consensus_basic_loop", "sarlacc_create_consensus_quality_loop", "sarlacc_last_error"}
+    assert expect <= used
+
+
+def test_shims_wrap_their_bodies_for_rcpp_and_check_status():
+    for fname, text in _glue_sources().items():
+        if not fname.endswith(".cpp"):
+            continue
+        assert text.count("BEGIN_RCPP") == text.count("END_RCPP") == len(re.findall(r"^SEXP\s+\w+\s*\(", text, flags=re.M)), fname
+        # a compute call outside SL_CHECK must be the guarded first attempt of a sizing protocol
+        for m in re.finditer(r"^(.*)\bsarlacc_(?!last_error)\w+\s*\(", text, flags=re.M):
+            assert "SL_CHECK" in m.group(1) or m.group(1).strip().startswith("if ("), (fname, m.group(0))
+
+
+def test_makevars_links_the_library():
+    mk = open(os.path.join(GLUE, "Makevars")).read()
+    assert "-lsarlacc_amd" in mk and "-I$(SARLACC_AMD_HOME)/include" in mk
