@@ -178,6 +178,13 @@ int sarlacc_unmask_alignment(const char* aln, const int64_t* aln_off, int64_t na
  * together with d_name_off) for the text indexed last on this thread. */
 int sarlacc_dev_fastq_index(const uint8_t* d_text, int64_t nbytes, int64_t* n_records, int64_t* total_bases,
                             int64_t* total_name_bytes, void* stream);
+/* Chunked streaming (the `number` argument of adaptorAlign, R/adaptorAlign.R:8,:26: FastqStreamer(filepath, n=number)):
+ * d_text holds a block of the file that may end inside a record.  Reports how many of its leading
+ * complete records (all four lines terminated by a newline), at most max_records, form the next
+ * chunk and how many bytes they occupy; the caller indexes exactly those bytes, then continues at
+ * d_text + consumed_bytes (appending more of the file when n_records < max_records). */
+int sarlacc_dev_fastq_split(const uint8_t* d_text, int64_t nbytes, int64_t max_records, int64_t* n_records,
+                            int64_t* consumed_bytes, void* stream);
 int sarlacc_dev_fastq_extract(const uint8_t* d_text, uint8_t* d_seq, uint8_t* d_qual, int64_t* d_off,
                               uint8_t* d_names, int64_t* d_name_off, void* stream);
 

@@ -13,6 +13,7 @@
 //   k_fq_records  per 4-line record: checks '@' / '+' / equal lengths, strips CR, lengths
 //   (rocPRIM exclusive scans of the sequence and name lengths)
 //   k_fq_copy     sequence (upper-cased), quality and name bytes -> contiguous arrays
+//   k_fq_nth_newline  end of the k-th record of a block of text (chunked streaming, `number` of adaptorAlign)
 //
 // Streaming byte work, HBM-bound: ~2 reads + 1 write of the text.
 #include "common.hpp"
@@ -113,6 +114,42 @@ __global__ void __launch_bounds__(FQ_THREADS) k_fq_lines(const uint8_t* text, lo
             if (((w[k] >> (8 * b)) & 0xffu) == 0x0au && pos + 4 * k + b < nbytes) {
                 line_start[rank + 1] = pos + 4 * k + b + 1;
                 ++rank;
+            }
+        }
+    }
+}
+
+// position just after newline number `target` (1-based): only the tile that holds it does any work
+__global__ void __launch_bounds__(FQ_THREADS) k_fq_nth_newline(const uint8_t* text, long long nbytes, const long long* tile_base,
+                                                               long long target, long long* out) {
+    const long long before_tile = tile_base[blockIdx.x];
+    if (target <= before_tile || target > tile_base[blockIdx.x + 1]) return;   // uniform per block
+    const long long pos = static_cast<long long>(blockIdx.x) * FQ_TILE + threadIdx.x * FQ_PER_THREAD;
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int c = 0;
+    if (pos < nbytes) {
+        load32(text, pos, nbytes, w);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c += newlines4(w[k]);
+    }
+    __shared__ int s_wave[FQ_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    long long rank = before_tile + incl - c;
+    for (int k = 0; k < wave; ++k) rank += s_wave[k];
+    if (target <= rank || target > rank + c) return;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (((w[k] >> (8 * b)) & 0xffu) == 0x0au && pos + 4 * k + b < nbytes) {
+                if (++rank == target) *out = pos + 4 * k + b + 1;
             }
         }
     }
@@ -293,6 +330,39 @@ int sarlacc_dev_fastq_index(const uint8_t* d_text, int64_t nbytes, int64_t* n_re
     }
     g_fq.text = d_text; g_fq.nbytes = nbytes; g_fq.nrec = nrec; g_fq.total_bases = tb; g_fq.total_name = tn;
     *n_records = nrec; *total_bases = tb; *total_name_bytes = tn;
+    return 0;
+}
+
+int sarlacc_dev_fastq_split(const uint8_t* d_text, int64_t nbytes, int64_t max_records, int64_t* n_records,
+                            int64_t* consumed_bytes, void* stream) {
+    SL_TRY(ensure_device());
+    if (nbytes < 0 || max_records < 0) return fail("sarlacc_amd: negative FASTQ size");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    *n_records = 0; *consumed_bytes = 0;
+    if (nbytes == 0 || max_records == 0) return 0;
+    const long long ntiles = (nbytes + FQ_TILE - 1) / FQ_TILE;
+    long long* d_count; long long* d_base; long long* d_pos;
+    SL_TRY(scratch("fq.count", static_cast<size_t>(ntiles) + 1, &d_count));
+    SL_TRY(scratch("fq.base", static_cast<size_t>(ntiles) + 1, &d_base));
+    SL_TRY(scratch("fq.nth", 1, &d_pos));
+    SL_HIP(hipMemsetAsync(d_count + ntiles, 0, sizeof(long long), s));
+    hipLaunchKernelGGL(k_fq_count, dim3(static_cast<unsigned>(ntiles)), dim3(FQ_THREADS), 0, s, d_text, static_cast<long long>(nbytes), d_count);
+    SL_HIP(hipGetLastError());
+    SL_TRY(exclusive_scan_i64("fq.scan", d_count, reinterpret_cast<int64_t*>(d_base), static_cast<size_t>(ntiles) + 1, s));
+    long long newlines = 0;
+    SL_HIP(hipMemcpyAsync(&newlines, d_base + ntiles, sizeof newlines, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    const long long k = std::min<long long>(newlines / 4, max_records);   // records whose four lines all end in a newline
+    if (k == 0) return 0;
+    long long pos = -1;
+    SL_HIP(hipMemsetAsync(d_pos, 0xff, sizeof(long long), s));
+    hipLaunchKernelGGL(k_fq_nth_newline, dim3(static_cast<unsigned>(ntiles)), dim3(FQ_THREADS), 0, s, d_text, static_cast<long long>(nbytes),
+                       d_base, 4 * k, d_pos);
+    SL_HIP(hipGetLastError());
+    SL_HIP(hipMemcpyAsync(&pos, d_pos, sizeof pos, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    if (pos <= 0 || pos > nbytes) return fail("sarlacc_amd: internal error locating the end of FASTQ record %lld", k);
+    *n_records = k; *consumed_bytes = pos;
     return 0;
 }
 

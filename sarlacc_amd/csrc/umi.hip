@@ -35,7 +35,11 @@
 
 namespace sarlacc {
 
-constexpr int UMI_MAXLEN = 32;
+constexpr int UMI_MAXLEN = 32;        // one 64-bit word of 2-bit codes: the fast path (all filters, queued DP)
+constexpr int UMI_LONG_WORDS = 4;     // strings of 33..128 bases: the same search on 4-word codes (k_umi_pairs_long)
+constexpr int UMI_LONG_MAX = 32 * UMI_LONG_WORDS;
+constexpr int UMI_KEY_BASES = 21;     // bases per 64-bit sort key (3 bits each)
+constexpr int UMI_LONG_KEYS = (UMI_LONG_MAX + UMI_KEY_BASES - 1) / UMI_KEY_BASES;
 constexpr int TILE = 256;
 constexpr int INF_D = 1 << 20;
 
@@ -43,24 +47,29 @@ constexpr int INF_D = 1 << 20;
 // encoding
 
 struct UmiArrays {
-    unsigned long long* code;   // 2 bits per base (N stored as 0)
-    uint32_t* nmask;            // bit i set: base i is N
+    unsigned long long* code;   // 2 bits per base (N stored as 0); word w of string s at code[w * stride + s]
+    uint32_t* nmask;            // bit i set: base i is N; same layout
     uint32_t* comp;             // counts of A,C,G,T, one byte each
     uint32_t* meta;             // len | nN << 8
+    long long stride;           // strings per word plane (one plane on the fast path)
 };
 
 // members: optional 1-based ids selecting the strings of one pre-group.
 __global__ void k_umi_encode(const uint8_t* chars, const int64_t* off, const int32_t* members, int n,
                              UmiArrays U, unsigned long long* key_hi, unsigned long long* key_lo, int* idx,
-                             int* bad /* [0]: min local index with unsupported char, [1]: min index too long */) {
+                             const uint8_t* skip /* optional: elements that are never compared (pre-groups of one read pass
+                                                    through unchecked, src/umi_group.cpp:39-42): encoded as empty strings */,
+                             int* bad /* [0]: min local index with unsupported char, [1]: min index too long,
+                                         [2]: max(-length) of the too long ones, i.e. minus the longest */) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     const long long id = members ? static_cast<long long>(members[s]) - 1 : s;
     const long long o = off[id];
-    const int len = static_cast<int>(off[id + 1] - o);
+    const int len = (skip && skip[s]) ? 0 : static_cast<int>(min(off[id + 1] - o, static_cast<int64_t>(1 << 30)));
     idx[s] = s;
     if (len > UMI_MAXLEN) {
         atomicMin(&bad[1], s);
+        atomicMin(&bad[2], -len);
         U.code[s] = 0; U.nmask[s] = 0; U.comp[s] = 0; U.meta[s] = 0; key_hi[s] = 0; key_lo[s] = 0;
         return;
     }
@@ -88,6 +97,53 @@ __global__ void k_umi_encode(const uint8_t* chars, const int64_t* off, const int
     key_hi[s] = khi; key_lo[s] = klo;
 }
 
+// The same for strings of up to UMI_LONG_MAX bases: UMI_LONG_WORDS code / mask words, one sort key per 21 bases.
+__global__ void k_umi_encode_long(const uint8_t* chars, const int64_t* off, const int32_t* members, int n,
+                                  UmiArrays U, unsigned long long* keys /* [UMI_LONG_KEYS][n] */, int* idx,
+                                  const uint8_t* skip, int* bad) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const long long id = members ? static_cast<long long>(members[s]) - 1 : s;
+    const long long o = off[id];
+    const int len = (skip && skip[s]) ? 0 : static_cast<int>(off[id + 1] - o);   // <= UMI_LONG_MAX: checked by the caller
+    idx[s] = s;
+    uint32_t comp = 0;
+    int nN = 0;
+    for (int w = 0; w < UMI_LONG_WORDS; ++w) {
+        unsigned long long code = 0;
+        uint32_t nmask = 0;
+        const int hi = min(len - 32 * w, 32);
+        for (int i = 0; i < hi; ++i) {
+            const uint8_t c = chars[o + 32 * w + i];
+            unsigned v;
+            switch (c) {
+                case 'A': v = 0; break;
+                case 'C': v = 1; break;
+                case 'G': v = 2; break;
+                case 'T': v = 3; break;
+                case 'N': v = 4; break;
+                default: v = 4; atomicMin(&bad[0], s); break;
+            }
+            if (v == 4) { nmask |= 1u << i; ++nN; }
+            else { code |= static_cast<unsigned long long>(v) << (2 * i); comp += 1u << (8 * v); }
+        }
+        U.code[w * U.stride + s] = code;
+        U.nmask[w * U.stride + s] = nmask;
+    }
+    for (int k = 0; k < UMI_LONG_KEYS; ++k) {
+        unsigned long long key = 0;
+        const int hi = min(len - UMI_KEY_BASES * k, UMI_KEY_BASES);
+        for (int i = 0; i < hi; ++i) {
+            const uint8_t c = chars[o + UMI_KEY_BASES * k + i];
+            const unsigned long long v = c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 3 : c == 'T' ? 4 : 5;
+            key |= v << (3 * (UMI_KEY_BASES - 1 - i));
+        }
+        keys[static_cast<long long>(k) * n + s] = key;
+    }
+    U.comp[s] = comp;   // byte counters: at most 128 per letter
+    U.meta[s] = static_cast<uint32_t>(len) | (static_cast<uint32_t>(nN) << 8);
+}
+
 __global__ void k_gather_u64(const unsigned long long* src, const int* perm, unsigned long long* dst, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[perm[i]];
@@ -101,11 +157,15 @@ __global__ void k_gather_gid(const int* gid, const int* perm, unsigned long long
     if (out) out[i] = g;
 }
 
-__global__ void k_gather_umi(UmiArrays src, const int* perm, UmiArrays dst, int n) {
+__global__ void k_gather_umi(UmiArrays src, const int* perm, UmiArrays dst, int n, int words) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int p = perm[i];
-    dst.code[i] = src.code[p]; dst.nmask[i] = src.nmask[p]; dst.comp[i] = src.comp[p]; dst.meta[i] = src.meta[p];
+    for (int w = 0; w < words; ++w) {
+        dst.code[w * dst.stride + i] = src.code[w * src.stride + p];
+        dst.nmask[w * dst.stride + i] = src.nmask[w * src.stride + p];
+    }
+    dst.comp[i] = src.comp[p]; dst.meta[i] = src.meta[p];
 }
 
 // ---------------------------------------------------------------------------
@@ -419,6 +479,153 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
     run_dp(n2);
 }
 
+// ---------------------------------------------------------------------------
+// Strings of 33..UMI_LONG_MAX bases (4-word codes).  Same distance, same tiling, the same exact
+// length / composition bounds; the prefix and shifted-Hamming filters of the one-word path are not
+// carried over (they are only filters: the result is the same set of pairs).
+
+// base i (0-based) of a 4-word string whose word planes lie `plane` elements apart
+struct LongStr {
+    const unsigned long long* code;
+    const uint32_t* nmask;
+    int plane;
+    __device__ __forceinline__ unsigned base(int i) const { return static_cast<unsigned>(code[(i >> 5) * plane] >> (2 * (i & 31))) & 3u; }
+    __device__ __forceinline__ unsigned isn(int i) const { return (nmask[(i >> 5) * plane] >> (i & 31)) & 1u; }
+};
+
+// banded_lev2 with the band in registers (K <= 16) on LongStr operands
+template <int K>
+__device__ __forceinline__ int banded_lev2_long(const LongStr a, int la, const LongStr b, int lb, int lim2) {
+    constexpr int BW = 2 * K + 1;
+    int v[BW];
+#pragma unroll
+    for (int d = 0; d < BW; ++d) {
+        const int i = d - K;
+        v[d] = (i >= 0 && i <= la) ? 2 * i : INF_D;
+    }
+    for (int j = 1; j <= lb; ++j) {
+        const unsigned cbj = b.base(j - 1), nbj = b.isn(j - 1);
+        int rowmin = INF_D, left = INF_D;
+#pragma unroll
+        for (int d = 0; d < BW; ++d) {
+            const int i = j + d - K;
+            int best = INF_D;
+            if (i >= 0 && i <= la) {
+                if (i == 0) {
+                    best = 2 * j;
+                } else {
+                    const int sub = (a.isn(i - 1) | nbj) ? 1 : (a.base(i - 1) == cbj ? 0 : 2);
+                    best = v[d] + sub;
+                    if (d + 1 < BW) best = min(best, v[d + 1] + 2);
+                    best = min(best, left + 2);
+                }
+            }
+            v[d] = best;
+            left = best;
+            rowmin = min(rowmin, best);
+        }
+        if (rowmin > lim2) return INF_D;
+    }
+    const int dd = la - lb + K;
+    int res = INF_D;
+#pragma unroll
+    for (int d = 0; d < BW; ++d) res = (d == dd) ? v[d] : res;
+    return res;
+}
+
+// full (unbanded) doubled masked Levenshtein distance, one row in thread-private memory; gives up with
+// INF_D once a whole row exceeds lim2.  For thresholds beyond 16 and for the dense distances.
+__device__ __forceinline__ int full_lev2_long(const LongStr a, int la, const LongStr b, int lb, int lim2) {
+    int row[UMI_LONG_MAX + 1];
+    for (int i = 0; i <= la; ++i) row[i] = 2 * i;
+    for (int j = 1; j <= lb; ++j) {
+        const unsigned cbj = b.base(j - 1), nbj = b.isn(j - 1);
+        int diag = row[0];
+        row[0] = 2 * j;
+        int rowmin = row[0];
+        for (int i = 1; i <= la; ++i) {
+            const int sub = (a.isn(i - 1) | nbj) ? 1 : (a.base(i - 1) == cbj ? 0 : 2);
+            const int best = min(diag + sub, min(row[i] + 2, row[i - 1] + 2));
+            diag = row[i];
+            row[i] = best;
+            rowmin = min(rowmin, best);
+        }
+        if (rowmin > lim2) return INF_D;
+    }
+    return row[la];
+}
+
+// K: band held in registers; K < 0: full DP
+template <int K>
+__global__ void __launch_bounds__(TILE) k_umi_pairs_long(const PairArgs A) {
+    const int bi = blockIdx.x + A.tile_lo, bj = blockIdx.y;
+    if (bj < bi) return;
+    __shared__ unsigned long long c_code[UMI_LONG_WORDS * TILE], r_code[UMI_LONG_WORDS * TILE];
+    __shared__ uint32_t c_nmask[UMI_LONG_WORDS * TILE], r_nmask[UMI_LONG_WORDS * TILE];
+    __shared__ uint4 c_key[TILE];  // {pre-group, meta, composition, any N}
+    const int t = threadIdx.x;
+    if (A.gid && bj > bi) {
+        const int row_last = min(bi * TILE + TILE, A.n) - 1;
+        if (A.gid[bj * TILE] > A.gid[row_last]) return;
+    }
+    const int jcol = bj * TILE + t, i = bi * TILE + t;
+    const bool row_on = i < A.n;
+    uint32_t anyN_col = 0, na = 0;
+    for (int w = 0; w < UMI_LONG_WORDS; ++w) {
+        const bool on = jcol < A.n;
+        c_code[w * TILE + t] = on ? A.U.code[w * A.U.stride + jcol] : 0ull;
+        const uint32_t m = on ? A.U.nmask[w * A.U.stride + jcol] : 0u;
+        c_nmask[w * TILE + t] = m;
+        anyN_col |= m;
+        r_code[w * TILE + t] = row_on ? A.U.code[w * A.U.stride + i] : 0ull;
+        const uint32_t mr = row_on ? A.U.nmask[w * A.U.stride + i] : 0u;
+        r_nmask[w * TILE + t] = mr;
+        na |= mr;
+    }
+    c_key[t] = jcol < A.n ? make_uint4(A.gid ? static_cast<uint32_t>(A.gid[jcol]) : 0u, A.U.meta[jcol], A.U.comp[jcol], anyN_col)
+                          : make_uint4(0xffffffffu, 0xffffu, 0u, 0u);
+    __syncthreads();
+    const uint32_t compa = row_on ? A.U.comp[i] : 0u, ma = row_on ? A.U.meta[i] : 0xffffu;
+    const int la = ma & 0xff, nNa = (ma >> 8) & 0xff;
+    const int gi = (row_on && A.gid) ? A.gid[i] : (row_on ? 0 : -2);
+    const LongStr sa{r_code + t, r_nmask + t, TILE};
+    const int jn = min(TILE, A.n - bj * TILE);
+    for (int jj = 0; jj < jn; ++jj) {
+        const uint4 ck = c_key[jj];
+        bool pass = row_on && static_cast<int>(ck.x) == gi && (bi != bj || jj > t);
+        const int lb = ck.y & 0xff, nNb = (ck.y >> 8) & 0xff;
+        const int dl = la > lb ? la - lb : lb - la;
+        // the composition bound of k_umi_pairs; the byte counters hold up to 128 per letter, sad_u8 is exact
+        const int l1 = static_cast<int>(__builtin_amdgcn_sad_u8(compa, ck.z, 0u)) + (nNa > nNb ? nNa - nNb : nNb - nNa);
+        const bool anyN = (na | ck.w) != 0u;
+        pass = pass && 2 * dl <= A.lim2 && l1 <= (anyN ? 2 * A.lim2 : A.lim2);
+        if (!pass) continue;
+        const LongStr sb{c_code + jj, c_nmask + jj, TILE};
+        int d;
+        if constexpr (K >= 0) d = banded_lev2_long<(K >= 0 ? K : 0)>(sa, la, sb, lb, A.lim2);
+        else d = full_lev2_long(sa, la, sb, lb, A.lim2);
+        if (d <= A.lim2) {
+            const unsigned long long slot = atomicAdd(A.count, 1ull);
+            if (slot < A.cap)
+                A.edges[slot] = (static_cast<unsigned long long>(bi * TILE + t) << 32) | static_cast<unsigned>(bj * TILE + jj);
+        }
+    }
+}
+
+__global__ void k_lev_dense_long(UmiArrays U, int n, double* out) {
+    const long long p = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    const long long npairs = static_cast<long long>(n) * (n - 1) / 2;
+    if (p >= npairs) return;
+    long long i = static_cast<long long>((2.0 * n - 1 - sqrt((2.0 * n - 1) * (2.0 * n - 1) - 8.0 * p)) / 2);
+    auto start = [&](long long r) { return r * (2LL * n - r - 1) / 2; };
+    while (i > 0 && start(i) > p) --i;
+    while (start(i + 1) <= p) ++i;
+    const long long j = i + 1 + (p - start(i));
+    const LongStr a{U.code + i, U.nmask + i, static_cast<int>(U.stride)}, b{U.code + j, U.nmask + j, static_cast<int>(U.stride)};
+    const int d = full_lev2_long(a, U.meta[i] & 0xff, b, U.meta[j] & 0xff, 8 * UMI_LONG_MAX);
+    out[p] = static_cast<double>(d) / 2.0;
+}
+
 // Dense distances for compute_lev_masked: out in R 'dist' order (i-major lower triangle),
 // value = d2 / 2 (multiples of 0.5 are exact in fp64).
 __global__ void k_lev_dense(UmiArrays U, int n, double* out) {
@@ -693,9 +900,10 @@ static int ceil_log2(unsigned long long x) {
     return b;
 }
 
-static int alloc_umi(const std::string& p, size_t n, UmiArrays* U) {
-    SL_TRY(scratch((p + ".code").c_str(), n, &U->code));
-    SL_TRY(scratch((p + ".nmask").c_str(), n, &U->nmask));
+static int alloc_umi(const std::string& p, size_t n, UmiArrays* U, int words = 1) {
+    U->stride = static_cast<long long>(n);
+    SL_TRY(scratch((p + ".code").c_str(), n * static_cast<size_t>(words), &U->code));
+    SL_TRY(scratch((p + ".nmask").c_str(), n * static_cast<size_t>(words), &U->nmask));
     SL_TRY(scratch((p + ".comp").c_str(), n, &U->comp));
     SL_TRY(scratch((p + ".meta").c_str(), n, &U->meta));
     return 0;
@@ -706,11 +914,12 @@ struct SortedUmis {
     int* perm;     // rank -> local index
     int* gid;      // pre-group per rank (nullptr: a single group)
     int n;
+    int words;     // 1: every string has at most 32 bases; UMI_LONG_WORDS otherwise
 };
 
 // Encode one set of UMIs (optionally the members of a pre-group) and order it like the trie.
 static int encode_and_rank(const std::string& p, const uint8_t* d_chars, const int64_t* d_off, const int32_t* d_members,
-                           const int* d_gid, int ngroups, int n, SortedUmis* out, hipStream_t s) {
+                           const int* d_gid, int ngroups, int n, SortedUmis* out, hipStream_t s, const uint8_t* d_skip = nullptr) {
     UmiArrays raw;
     SL_TRY(alloc_umi(p + ".raw", n, &raw));
     SL_TRY(alloc_umi(p + ".srt", n, &out->U));
@@ -721,21 +930,47 @@ static int encode_and_rank(const std::string& p, const uint8_t* d_chars, const i
     SL_TRY(scratch((p + ".k2").c_str(), n, &k2));
     SL_TRY(scratch((p + ".idx").c_str(), n, &idx));
     SL_TRY(scratch((p + ".idx2").c_str(), n, &idx2));
-    SL_TRY(scratch((p + ".bad").c_str(), 2, &bad));
-    const int init[2] = {std::numeric_limits<int>::max(), std::numeric_limits<int>::max()};
+    SL_TRY(scratch((p + ".bad").c_str(), 3, &bad));
+    const int init[3] = {std::numeric_limits<int>::max(), std::numeric_limits<int>::max(), 0};
     SL_HIP(hipMemcpyAsync(bad, init, sizeof init, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_umi_encode, dim3(nblk(n, 256)), dim3(256), 0, s, d_chars, d_off, d_members, n, raw, khi, klo, idx, bad);
+    hipLaunchKernelGGL(k_umi_encode, dim3(nblk(n, 256)), dim3(256), 0, s, d_chars, d_off, d_members, n, raw, khi, klo, idx, d_skip, bad);
     SL_HIP(hipGetLastError());
-    int hbad[2];
+    int hbad[3];
     SL_HIP(hipMemcpyAsync(hbad, bad, sizeof hbad, hipMemcpyDeviceToHost, s));
     SL_HIP(hipStreamSynchronize(s));
-    if (hbad[1] != init[1]) return fail("sarlacc_amd: UMI longer than %d bases is not supported", UMI_MAXLEN);
-    if (hbad[0] != init[0])
-        return fail("sarlacc_amd: UMI contains a character outside ACGTN (the reference silently drops such strings)");
-    // least-significant key first; both sorts are stable, ties keep the input order
-    SL_TRY(sort_pairs_u64_i32(p.c_str(), klo, k2, idx, idx2, n, 64, s));
-    hipLaunchKernelGGL(k_gather_u64, dim3(nblk(n, 256)), dim3(256), 0, s, khi, idx2, klo, n);
-    SL_TRY(sort_pairs_u64_i32(p.c_str(), klo, k2, idx2, idx, n, 64, s));
+    out->words = 1;
+    if (hbad[1] != init[1]) {
+        // some string has more than 32 bases: the whole call runs on 4-word codes
+        if (-hbad[2] > UMI_LONG_MAX) return fail("sarlacc_amd: UMI longer than %d bases is not supported", UMI_LONG_MAX);
+        out->words = UMI_LONG_WORDS;
+        SL_TRY(alloc_umi(p + ".rawL", n, &raw, UMI_LONG_WORDS));
+        SL_TRY(alloc_umi(p + ".srtL", n, &out->U, UMI_LONG_WORDS));
+        unsigned long long* keys;
+        SL_TRY(scratch((p + ".keysL").c_str(), static_cast<size_t>(n) * UMI_LONG_KEYS, &keys));
+        SL_HIP(hipMemcpyAsync(bad, init, sizeof init, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_umi_encode_long, dim3(nblk(n, 256)), dim3(256), 0, s, d_chars, d_off, d_members, n, raw, keys, idx, d_skip, bad);
+        SL_HIP(hipGetLastError());
+        SL_HIP(hipMemcpyAsync(hbad, bad, sizeof hbad, hipMemcpyDeviceToHost, s));
+        SL_HIP(hipStreamSynchronize(s));
+        if (hbad[0] != init[0])
+            return fail("sarlacc_amd: UMI contains a character outside ACGTN (the reference silently drops such strings)");
+        // stable sorts, least-significant key first (only the keys some string reaches)
+        const int nkeys = (-hbad[2] + UMI_KEY_BASES - 1) / UMI_KEY_BASES;
+        int *from = idx, *to = idx2;
+        for (int k = nkeys - 1; k >= 0; --k) {
+            hipLaunchKernelGGL(k_gather_u64, dim3(nblk(n, 256)), dim3(256), 0, s, keys + static_cast<size_t>(k) * n, from, klo, n);
+            SL_TRY(sort_pairs_u64_i32(p.c_str(), klo, k2, from, to, n, 63, s));
+            std::swap(from, to);
+        }
+        if (from != idx) SL_HIP(hipMemcpyAsync(idx, from, sizeof(int) * static_cast<size_t>(n), hipMemcpyDeviceToDevice, s));
+    } else {
+        if (hbad[0] != init[0])
+            return fail("sarlacc_amd: UMI contains a character outside ACGTN (the reference silently drops such strings)");
+        // least-significant key first; both sorts are stable, ties keep the input order
+        SL_TRY(sort_pairs_u64_i32(p.c_str(), klo, k2, idx, idx2, n, 64, s));
+        hipLaunchKernelGGL(k_gather_u64, dim3(nblk(n, 256)), dim3(256), 0, s, khi, idx2, klo, n);
+        SL_TRY(sort_pairs_u64_i32(p.c_str(), klo, k2, idx2, idx, n, 64, s));
+    }
     out->gid = nullptr;
     if (d_gid && ngroups > 1) {  // most significant key: the pre-group
         int* gsorted;
@@ -746,7 +981,7 @@ static int encode_and_rank(const std::string& p, const uint8_t* d_chars, const i
         hipLaunchKernelGGL(k_gather_gid, dim3(nblk(n, 256)), dim3(256), 0, s, d_gid, idx, static_cast<unsigned long long*>(nullptr), gsorted, n);
         out->gid = gsorted;
     }
-    hipLaunchKernelGGL(k_gather_umi, dim3(nblk(n, 256)), dim3(256), 0, s, raw, idx, out->U, n);
+    hipLaunchKernelGGL(k_gather_umi, dim3(nblk(n, 256)), dim3(256), 0, s, raw, idx, out->U, n, out->words);
     SL_HIP(hipGetLastError());
     out->perm = idx;
     out->n = n;
@@ -803,7 +1038,7 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
     const TileInfo* d_subinfo = nullptr;
     unsigned int nlisted = 0;
     const long long ntp = static_cast<long long>(tile_hi - tile_lo) * nt;
-    if (limit >= 0 && limit <= 5 && nt >= 16 && ntp <= (1ll << 31) && !std::getenv("SARLACC_UMI_ALLTILES")) {
+    if (S.words == 1 && limit >= 0 && limit <= 5 && nt >= 16 && ntp <= (1ll << 31) && !std::getenv("SARLACC_UMI_ALLTILES")) {
         TileInfo* d_info; uint32_t* d_l; unsigned int* d_lc;
         SL_TRY(scratch((p + ".tinfo").c_str(), static_cast<size_t>(nt), &d_info));
         // the list is bounded by the upper triangle of the launch
@@ -841,7 +1076,20 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
         c.stage_reset("umi_pairs");
         SL_TRY(c.stage_begin("umi_pairs", s));
         const int K = std::min(limit, UMI_MAXLEN);
-        if (K <= 0) launch_pairs<0>(a, tile_hi, nlisted, s);
+        if (S.words > 1) {
+            if (tile_hi > tile_lo) {
+                const dim3 grid(static_cast<unsigned>(tile_hi - tile_lo), static_cast<unsigned>(nt));
+                if (limit <= 0) hipLaunchKernelGGL(k_umi_pairs_long<0>, grid, dim3(TILE), 0, s, a);
+                else if (limit == 1) hipLaunchKernelGGL(k_umi_pairs_long<1>, grid, dim3(TILE), 0, s, a);
+                else if (limit == 2) hipLaunchKernelGGL(k_umi_pairs_long<2>, grid, dim3(TILE), 0, s, a);
+                else if (limit == 3) hipLaunchKernelGGL(k_umi_pairs_long<3>, grid, dim3(TILE), 0, s, a);
+                else if (limit <= 5) hipLaunchKernelGGL(k_umi_pairs_long<5>, grid, dim3(TILE), 0, s, a);
+                else if (limit <= 8) hipLaunchKernelGGL(k_umi_pairs_long<8>, grid, dim3(TILE), 0, s, a);
+                else if (limit <= 16) hipLaunchKernelGGL(k_umi_pairs_long<16>, grid, dim3(TILE), 0, s, a);
+                else hipLaunchKernelGGL(k_umi_pairs_long<-1>, grid, dim3(TILE), 0, s, a);
+            }
+        }
+        else if (K <= 0) launch_pairs<0>(a, tile_hi, nlisted, s);
         else if (K == 1) launch_pairs<1>(a, tile_hi, nlisted, s);
         else if (K == 2) launch_pairs<2>(a, tile_hi, nlisted, s);
         else if (K == 3) launch_pairs<3>(a, tile_hi, nlisted, s);
@@ -924,7 +1172,7 @@ static int group_adjacency(const uint8_t* d_c1, const int64_t* d_o1, const uint8
                            int limit1, int limit2, DevAdj* adj, hipStream_t s) {
     SortedUmis S1;
     DirectedKeys K1;
-    SL_TRY(encode_and_rank("u1", d_c1, d_o1, d_members, d_gid, ngroups, n, &S1, s));
+    SL_TRY(encode_and_rank("u1", d_c1, d_o1, d_members, d_gid, ngroups, n, &S1, s, d_single));
     SL_TRY(neighbour_keys("u1", S1, limit1, d_single, &K1, s));
     if (!d_c2) return adjacency_from_keys("adj", K1.keys, K1.nk, S1.perm, n, adj, s);
 
@@ -938,7 +1186,7 @@ static int group_adjacency(const uint8_t* d_c1, const int64_t* d_o1, const uint8
     }
     SortedUmis S2;
     DirectedKeys K2;
-    SL_TRY(encode_and_rank("u2", d_c2, d_o2, d_members, d_gid, ngroups, n, &S2, s));
+    SL_TRY(encode_and_rank("u2", d_c2, d_o2, d_members, d_gid, ngroups, n, &S2, s, d_single));
     SL_TRY(neighbour_keys("u2", S2, limit2, d_single, &K2, s));
     int* d_keep; long long* d_pos;
     SL_TRY(scratch("u2.keep", static_cast<size_t>(K2.nk) + 1, &d_keep));
@@ -1104,21 +1352,32 @@ int sarlacc_compute_lev_masked(const char* seq, const int64_t* off, int64_t n, d
     SL_TRY(scratch("lev.khi", n, &khi));
     SL_TRY(scratch("lev.klo", n, &klo));
     SL_TRY(scratch("lev.idx", n, &idx));
-    SL_TRY(scratch("lev.bad", 2, &bad));
-    const int init[2] = {std::numeric_limits<int>::max(), std::numeric_limits<int>::max()};
+    SL_TRY(scratch("lev.bad", 3, &bad));
+    const int init[3] = {std::numeric_limits<int>::max(), std::numeric_limits<int>::max(), 0};
     SL_HIP(hipMemcpyAsync(bad, init, sizeof init, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_umi_encode, dim3(nblk(n, 256)), dim3(256), 0, s, d_c, d_o, static_cast<const int32_t*>(nullptr), static_cast<int>(n), U, khi, klo, idx, bad);
-    int hbad[2];
+    hipLaunchKernelGGL(k_umi_encode, dim3(nblk(n, 256)), dim3(256), 0, s, d_c, d_o, static_cast<const int32_t*>(nullptr), static_cast<int>(n), U, khi, klo, idx, static_cast<const uint8_t*>(nullptr), bad);
+    int hbad[3];
     SL_HIP(hipMemcpyAsync(hbad, bad, sizeof hbad, hipMemcpyDeviceToHost, s));
     SL_HIP(hipStreamSynchronize(s));
-    if (hbad[1] != init[1]) return fail("sarlacc_amd: sequence longer than %d bases is not supported", UMI_MAXLEN);
+    const bool is_long = hbad[1] != init[1];
+    if (is_long) {
+        if (-hbad[2] > UMI_LONG_MAX) return fail("sarlacc_amd: sequence longer than %d bases is not supported", UMI_LONG_MAX);
+        SL_TRY(alloc_umi("lev.rawL", n, &U, UMI_LONG_WORDS));
+        unsigned long long* keys;
+        SL_TRY(scratch("lev.keysL", static_cast<size_t>(n) * UMI_LONG_KEYS, &keys));
+        SL_HIP(hipMemcpyAsync(bad, init, sizeof init, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_umi_encode_long, dim3(nblk(n, 256)), dim3(256), 0, s, d_c, d_o, static_cast<const int32_t*>(nullptr), static_cast<int>(n), U, keys, idx, static_cast<const uint8_t*>(nullptr), bad);
+        SL_HIP(hipMemcpyAsync(hbad, bad, sizeof hbad, hipMemcpyDeviceToHost, s));
+        SL_HIP(hipStreamSynchronize(s));
+    }
     // characters outside ACGTN behave as ordinary distinct letters in the reference
     // (src/compute_lev_masked.cpp:51); only ACGTN is supported here
     if (hbad[0] != init[0]) return fail("sarlacc_amd: sequence contains a character outside ACGTN");
     const long long npairs = n * (n - 1) / 2;
     double* d_out;
     SL_TRY(scratch("lev.out", static_cast<size_t>(npairs), &d_out));
-    hipLaunchKernelGGL(k_lev_dense, dim3(nblk(npairs, 128)), dim3(128), 0, s, U, static_cast<int>(n), d_out);
+    if (is_long) hipLaunchKernelGGL(k_lev_dense_long, dim3(nblk(npairs, 128)), dim3(128), 0, s, U, static_cast<int>(n), d_out);
+    else hipLaunchKernelGGL(k_lev_dense, dim3(nblk(npairs, 128)), dim3(128), 0, s, U, static_cast<int>(n), d_out);
     SL_HIP(hipGetLastError());
     SL_HIP(hipMemcpy(out, d_out, sizeof(double) * static_cast<size_t>(npairs), hipMemcpyDeviceToHost));
     return 0;

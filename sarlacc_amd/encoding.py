@@ -34,6 +34,35 @@ def phred_encoding():
     return Encoding(np.power(10.0, -q / 10.0), bytes(range(33, 127)))
 
 
+def illumina_encoding():
+    """IlluminaQuality: offset 64, q = 0..62 ('@'..'~'), 10^(-q/10) (Biostrings' IlluminaQuality; like the
+    Phred table the printable range only: Biostrings' maximum of 99 lies beyond '~')."""
+    q = np.arange(63, dtype=np.float64)
+    return Encoding(np.power(10.0, -q / 10.0), bytes(range(64, 127)))
+
+
+def solexa_encoding():
+    """SolexaQuality: offset 64, q = -5..62 (';'..'~'); the Solexa score is -10 log10(p / (1 - p)), so
+    p = 1 - 1 / (1 + 10^(-q/10)) (as.numeric of a SolexaQuality in Biostrings)."""
+    q = np.arange(-5, 63, dtype=np.float64)
+    return Encoding(1.0 - 1.0 / (1.0 + np.power(10.0, -q / 10.0)), bytes(range(59, 127)))
+
+
+QUAL_TYPES = ("phred", "solexa", "illumina")
+
+
+def encoding_for_qual_type(qual_type="phred"):
+    """match.arg(qual.type) + .qual2class + .create_encoding_vector (R/adaptorAlign.R:8,:18-19,:97-99,
+    R/qualityMask.R:19-28): the encoding vector of the quality class a FASTQ file is read with.
+    Unique prefixes are accepted as match.arg does; a tuple selects its first element (the default)."""
+    if isinstance(qual_type, (tuple, list)):
+        qual_type = qual_type[0]
+    hits = [t for t in QUAL_TYPES if isinstance(qual_type, str) and qual_type and t.startswith(qual_type)]
+    if len(hits) != 1:
+        raise ValueError("'arg' should be one of 'phred', 'solexa', 'illumina'")
+    return hits[0], {"phred": phred_encoding, "solexa": solexa_encoding, "illumina": illumina_encoding}[hits[0]]()
+
+
 def as_encoding(enc):
     if isinstance(enc, Encoding):
         return enc

@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 from . import calls
-from .encoding import Encoding, phred_encoding
+from .encoding import QUAL_TYPES, Encoding, encoding_for_qual_type, phred_encoding
 from .mock import _COMP
 from .strset import StringSet, StrList
 
@@ -161,44 +161,84 @@ def _align_and_extract_resident(adaptor, dev, host_seq, gap_opening, gap_extensi
     return res
 
 
-def adaptorAlign(adaptor1, adaptor2, reads, tolerance=250, gapOpening=5, gapExtension=1):
-    """adaptorAlign (R/adaptorAlign.R:7-78).  `reads` is a Reads object or, as in the reference, the
-    path of a FASTQ file: the text is then parsed on the device, the front/back windows are cut
-    there and the four alignments run on the resident windows (no host pass over the bases)."""
-    adaptor1, adaptor2 = str(adaptor1).upper(), str(adaptor2).upper()
-    filepath = None
-    sub1, sub2 = _setup_subseqs(adaptor1), _setup_subseqs(adaptor2)
-    args = (gapOpening, gapExtension)
-    if isinstance(reads, (str, os.PathLike)):
-        from .resident import DeviceReads
-        filepath = os.fspath(reads)
-        dev = DeviceReads.from_fastq(filepath)
+def _concat_aligned(parts):
+    """rbind of the per-chunk alignment tables (R/adaptorAlign.R:59-60)."""
+    if len(parts) == 1:
+        return parts[0]
+    out = {"subseq": {}}
+    for key in ("score", "start", "end"):
+        out[key] = np.concatenate([p[key] for p in parts])
+    for k in parts[0]["subseq"]:
+        cols = [p["subseq"][k] for p in parts]
+        if all(isinstance(c, StrList) for c in cols):
+            out["subseq"][k] = StrList(StringSet.concat([c.ss for c in cols]))
+        else:
+            out["subseq"][k] = [x for c in cols for x in c]
+    return out
+
+
+def _adaptor_align_chunk(adaptor1, adaptor2, sub1, sub2, args, tolerance, reads=None, dev=None):
+    """One yield of the streamer: the four alignments of .align_AA_internal (R/adaptorAlign.R:180-207) and
+    the strand choice, on a host batch (`reads`) or a resident one (`dev`)."""
+    if dev is not None:
         dfront, dback = dev.front_and_back(tolerance)
         hfront, hback = dfront.download()[0], dback.download()[0]   # only the windows, for the sub-sequences
         cur_starts = _align_and_extract_resident(adaptor1, dfront, hfront, *args, sub1["starts"], sub1["ends"])
         cur_ends = _align_and_extract_resident(adaptor2, dback, hback, *args, sub2["starts"], sub2["ends"])
         rc_starts = _align_and_extract_resident(adaptor1, dback, hback, *args, sub1["starts"], sub1["ends"])
         rc_ends = _align_and_extract_resident(adaptor2, dfront, hfront, *args, sub2["starts"], sub2["ends"])
-        reads = Reads.__new__(Reads)
-        reads.seq = StringSet(np.zeros(1, np.uint8), dev.off_host.copy())   # widths only; bases stay on the device
-        reads.qual, reads.names, reads.encoding = None, dev.names, dev.encoding
+        width = np.diff(dev.off_host).astype(np.int32)
     else:
         front, back = _get_front_and_back(reads, tolerance)
         cur_starts = _align_and_extract(adaptor1, front, *args, sub1["starts"], sub1["ends"])
         cur_ends = _align_and_extract(adaptor2, back, *args, sub2["starts"], sub2["ends"])
         rc_starts = _align_and_extract(adaptor1, back, *args, sub1["starts"], sub1["ends"])
         rc_ends = _align_and_extract(adaptor2, front, *args, sub2["starts"], sub2["ends"])
+        width = reads.width().astype(np.int32)
     rev, _ = _resolve_strand(cur_starts["score"], cur_ends["score"], rc_starts["score"], rc_ends["score"])
     _swap_rows(cur_starts, rc_starts, rev)
     _swap_rows(cur_ends, rc_ends, rev)
-    width = reads.width().astype(np.int32)
+    return cur_starts, cur_ends, rev, width
+
+
+def adaptorAlign(adaptor1, adaptor2, reads, tolerance=250, gapOpening=5, gapExtension=1, qual_type=QUAL_TYPES, number=1e5):
+    """adaptorAlign (R/adaptorAlign.R:7-78).  `reads` is, as in the reference, the path of a FASTQ file:
+    it is streamed in chunks of `number` records (FastqStreamer(filepath, n=number), :26), each chunk's
+    text is parsed on the device, the front/back windows are cut there and the four alignments run on
+    the resident windows (no host pass over the bases); `qual_type` ("phred", "solexa" or "illumina",
+    match.arg semantics) names the quality class the file is read with (.qual2class, :97-99) and hence
+    the encoding vector of every alignment.  A Reads object is accepted as well (one chunk; it carries
+    its own encoding, so `qual_type` only lands in the metadata)."""
+    adaptor1, adaptor2 = str(adaptor1).upper(), str(adaptor2).upper()
+    qual_type, enc = encoding_for_qual_type(qual_type)
+    filepath = None
+    sub1, sub2 = _setup_subseqs(adaptor1), _setup_subseqs(adaptor2)
+    args = (gapOpening, gapExtension)
+    parts, names = [], []
+    if isinstance(reads, (str, os.PathLike)):
+        from .resident import DeviceReads
+        filepath = os.fspath(reads)
+        for dev in DeviceReads.stream_fastq(filepath, number, encoding=enc):
+            parts.append(_adaptor_align_chunk(adaptor1, adaptor2, sub1, sub2, args, tolerance, dev=dev))
+            names.append(dev.names)
+        if not parts:   # "Guarantee some value is returned" (:42-50): the empty table, with its columns
+            parts.append(_adaptor_align_chunk(adaptor1, adaptor2, sub1, sub2, args, tolerance, dev=DeviceReads.from_fastq(b"", enc)))
+            names.append(StrList([]))
+        names = names[0] if len(names) == 1 else StrList(StringSet.concat([x.ss for x in names]))
+    else:
+        parts.append(_adaptor_align_chunk(adaptor1, adaptor2, sub1, sub2, args, tolerance, reads=reads))
+        names = reads.names
+    cur_starts = _concat_aligned([p[0] for p in parts])
+    cur_ends = _concat_aligned([p[1] for p in parts])
+    rev = np.concatenate([p[2] for p in parts])
+    width = np.concatenate([p[3] for p in parts])
     # adaptor 2 was aligned on the reverse strand: report in read coordinates (:67-71)
     cur_ends["start"], cur_ends["end"] = (width - cur_ends["start"] + 1).astype(np.int32), (width - cur_ends["end"] + 1).astype(np.int32)
     details = {"gapOpening": gapOpening, "gapExtension": gapExtension}
     cur_starts["metadata"] = dict(sequence=adaptor1, **details)
     cur_ends["metadata"] = dict(sequence=adaptor2, **details)
     return {"read.width": width, "adaptor1": cur_starts, "adaptor2": cur_ends, "reversed": rev,
-            "names": reads.names, "metadata": {"filepath": filepath, "qual.type": "phred", "tolerance": tolerance}}
+            "names": names, "metadata": {"filepath": filepath, "qual.type": qual_type, "tolerance": tolerance}}
 
 
 # ---------------------------------------------------------------------------
@@ -241,33 +281,63 @@ def filterReads(aligned, score1, score2, essential1=True, essential2=True):
     return out
 
 
-def realizeReads(aligned, trim=True, resident=False):
-    """realizeReads (R/realizeReads.R:5-46): the reads named in `aligned`, re-read from its FASTQ
-    file, reverse-complemented where `reversed` and trimmed to [trim.start, trim.end].  The file is
-    parsed on the device and the orientation / trimming happen there (DeviceReads.realize); the
-    result comes back as Reads, or stays in HBM with resident=True."""
+def realizeReads(aligned, number=1e5, trim=True, resident=False):
+    """realizeReads (R/realizeReads.R:5-46): the reads named in `aligned`, re-read from its FASTQ file
+    (streamed in chunks of `number` records with the quality class recorded by adaptorAlign, :11-25),
+    reverse-complemented where `reversed` and trimmed to [trim.start, trim.end].  Every chunk is parsed
+    on the device and the orientation / trimming happen there (DeviceReads.realize); the result comes
+    back as Reads, or stays in HBM with resident=True."""
     import warnings
     from .resident import DeviceReads
-    dev = DeviceReads.from_fastq(aligned["metadata"]["filepath"])
-    where = {}
-    for i, nm in enumerate(dev.names):
-        where.setdefault(nm, i)   # match(): first occurrence
-    try:
-        idx = np.array([where[nm] for nm in aligned["names"]], dtype=np.int64)
-    except KeyError:
-        raise ValueError("read names in 'aligned' not present in FASTQ file")
+    qual_type, enc = encoding_for_qual_type(aligned["metadata"].get("qual.type", "phred"))
+    want = list(aligned["names"])
+    rows_of = {}
+    for r, nm in enumerate(want):
+        rows_of.setdefault(nm, []).append(r)
+    rev_all = np.asarray(aligned["reversed"], dtype=bool)
     ts = te = None
     if trim:
         if "trim.start" in aligned:
-            ts, te = aligned["trim.start"], aligned["trim.end"]
+            ts, te = np.asarray(aligned["trim.start"]), np.asarray(aligned["trim.end"])
         else:
             warnings.warn("no 'trim.start' detected, run 'filterReads' first")
-    out = dev.realize(idx, aligned["reversed"], ts, te)
-    out.names = list(aligned["names"])
+    parts, part_rows, seen = [], [], set()
+    for dev in DeviceReads.stream_fastq(aligned["metadata"]["filepath"], number, encoding=enc):
+        idx, rows = [], []
+        for i, nm in enumerate(dev.names):
+            if nm in rows_of and nm not in seen:   # match(): first occurrence in the file
+                seen.add(nm)
+                for r in rows_of[nm]:
+                    idx.append(i)
+                    rows.append(r)
+        if not rows:
+            continue
+        rows = np.array(rows, dtype=np.int64)
+        parts.append(dev.realize(np.array(idx, dtype=np.int64), rev_all[rows], None if ts is None else ts[rows],
+                                 None if te is None else te[rows]))
+        part_rows.append(rows)
+    if len(seen) != len(rows_of):
+        raise ValueError("read names in 'aligned' not present in FASTQ file")
+    if len(parts) == 1 and np.array_equal(part_rows[0], np.arange(len(want))):
+        out = parts[0]                              # one chunk, already in the order of `aligned`
+        out.names = want
+        if resident:
+            return out
+        seq, qual = out.download()
+        return Reads(seq, qual, want, enc)
+    # several chunks: each realized part comes back, the rows are put in the order of `aligned`
+    back = np.zeros(len(want), np.int64)
+    if part_rows:
+        back[np.concatenate(part_rows)] = np.arange(len(want))
+    host = [p.download() for p in parts]
+    seq = StringSet.concat([h[0] for h in host]).subset(back)
+    qual = StringSet.concat([h[1] for h in host]).subset(back)
+    reads = Reads(seq, qual, want, enc)
     if resident:
+        out = DeviceReads.upload(reads)
+        out.names = want
         return out
-    seq, qual = out.download()
-    return Reads(seq, qual, out.names, dev.encoding)
+    return reads
 
 
 def getBarcodeThresholds(baligned, nmads=3):

@@ -67,17 +67,57 @@ class DeviceReads:
         else:
             text = np.fromfile(source, dtype=np.uint8)
         d_text = DevBuffer.from_numpy(text if text.size else np.zeros(1, np.uint8))
+        return cls._from_device_text(d_text.ptr, text.size, encoding)
+
+    @classmethod
+    def _from_device_text(cls, text_ptr, nbytes, encoding):
         nrec, tb, tn = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        check(_lib.lib().sarlacc_dev_fastq_index(d_text.ptr, C.c_int64(text.size), C.byref(nrec), C.byref(tb), C.byref(tn), None))
+        check(_lib.lib().sarlacc_dev_fastq_index(text_ptr, C.c_int64(nbytes), C.byref(nrec), C.byref(tb), C.byref(tn), None))
         n = nrec.value
         seq, qual = DevBuffer(max(tb.value, 1)), DevBuffer(max(tb.value, 1))
         off, names, noff = DevBuffer(8 * (n + 1)), DevBuffer(max(tn.value, 1)), DevBuffer(8 * (n + 1))
-        check(_lib.lib().sarlacc_dev_fastq_extract(d_text.ptr, seq.ptr, qual.ptr, off.ptr, names.ptr, noff.ptr, None))
+        check(_lib.lib().sarlacc_dev_fastq_extract(text_ptr, seq.ptr, qual.ptr, off.ptr, names.ptr, noff.ptr, None))
         out = cls(seq, qual, off, off.to_numpy(np.int64, n + 1), encoding)
         from .strset import StrList
         nraw = names.to_numpy(np.uint8, tn.value)
         out.names = StrList(StringSet(nraw if nraw.size else np.zeros(1, np.uint8), noff.to_numpy(np.int64, n + 1)))   # decoded on demand
         return out
+
+    @classmethod
+    def stream_fastq(cls, path, number, encoding=None, block_bytes=256 << 20):
+        """Generator over the file in chunks of at most `number` records, each a resident batch: the
+        FastqStreamer(filepath, n=number) + yield() loop of R/adaptorAlign.R:26-37.  The file is read in
+        blocks of `block_bytes`; where a block ends inside a record the device reports the end of the
+        last complete one (sarlacc_dev_fastq_split) and the rest is carried over to the next block, so
+        neither the host nor the device ever holds more than one block plus one chunk."""
+        number = int(number)
+        if number < 1:
+            raise ValueError("'number' must be a positive integer")
+        carry = np.zeros(0, np.uint8)
+        with open(path, "rb") as fh:
+            eof = False
+            while not eof:
+                fresh = np.frombuffer(fh.read(int(block_bytes)), dtype=np.uint8)
+                eof = fresh.size < int(block_bytes)
+                text = np.concatenate([carry, fresh]) if carry.size else fresh
+                if text.size == 0:
+                    break
+                d_text = DevBuffer.from_numpy(text)
+                pos = 0
+                while pos < text.size:
+                    nrec, used = C.c_int64(0), C.c_int64(0)
+                    here = C.c_void_p(d_text.ptr.value + pos)
+                    check(_lib.lib().sarlacc_dev_fastq_split(here, C.c_int64(text.size - pos), C.c_int64(number), C.byref(nrec),
+                                                             C.byref(used), None))
+                    if nrec.value < number and not eof:
+                        break                           # the chunk continues in the next block
+                    if nrec.value < number:
+                        used.value = text.size - pos    # last chunk: may end without a newline, or in blank lines
+                    chunk = cls._from_device_text(here, used.value, encoding)
+                    pos += used.value
+                    if len(chunk):
+                        yield chunk
+                carry = text[pos:].copy()
 
     def __len__(self):
         return len(self.off_host) - 1

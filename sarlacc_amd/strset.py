@@ -62,6 +62,17 @@ class StringSet:
         chars = self.chars[int(o[0]):int(o[-1])]
         return StringSet(chars if chars.size else np.zeros(1, np.uint8), o - o[0])
 
+    @classmethod
+    def concat(cls, sets):
+        """c(...) of string sets."""
+        sets = list(sets)
+        if not sets:
+            return cls(np.zeros(1, np.uint8), np.zeros(1, np.int64))
+        chars = np.concatenate([x.chars[:x.total] for x in sets])
+        base = np.cumsum([0] + [x.total for x in sets[:-1]])
+        off = np.concatenate([np.zeros(1, np.int64)] + [x.off[1:] + b for x, b in zip(sets, base)])
+        return cls(chars if chars.size else np.zeros(1, np.uint8), off.astype(np.int64))
+
     def subset(self, idx):
         idx = np.asarray(idx, dtype=np.int64)
         w = self.off[idx + 1] - self.off[idx]

@@ -137,3 +137,82 @@ def test_filter_and_realize_reads(tmp_path):
     bad = dict(filt, names=["nope"] + filt["names"][1:])
     with pytest.raises(ValueError, match="not present in FASTQ file"):
         G.realizeReads(bad)
+
+
+@pytest.mark.parametrize("eol,final_eol,extra", [("\n", True, b""), ("\r\n", False, b""), ("\n", True, b"\n\r\n")])
+def test_stream_fastq_chunks_equal_the_whole_file(tmp_path, eol, final_eol, extra):
+    """FastqStreamer(filepath, n=number) (R/adaptorAlign.R:26): chunks of `number` records, file read in
+    blocks that end anywhere (inside a header, a CRLF pair, the last line without newline)."""
+    from sarlacc_amd.resident import DeviceReads
+    rng = np.random.default_rng(31 + len(eol) + final_eol + len(extra))
+    text = fastq_text(rng, 157, 0, 300, eol, False, final_eol) + extra
+    path = tmp_path / "s.fastq"
+    path.write_bytes(text)
+    whole = DeviceReads.from_fastq(text)
+    ws, wq = whole.download()
+    for number, block in [(1, 1 << 20), (50, 997), (50, 1 << 20), (157, 4096), (1000, 313), (7, 64)]:
+        sizes, seqs, quals, names = [], [], [], []
+        for chunk in DeviceReads.stream_fastq(str(path), number, block_bytes=block):
+            s, q = chunk.download()
+            sizes.append(len(chunk))
+            seqs += s.to_strings(); quals += q.to_strings(); names += list(chunk.names)
+        assert sizes == [number] * (157 // number) + ([157 % number] if 157 % number else []), (number, block)
+        assert seqs == ws.to_strings() and quals == wq.to_strings() and names == list(whole.names), (number, block)
+    assert list(DeviceReads.stream_fastq(str(path), 10, block_bytes=100)) != []
+    empty = tmp_path / "e.fastq"
+    empty.write_bytes(b"\n\n")
+    assert list(DeviceReads.stream_fastq(str(empty), 10)) == []
+    with pytest.raises(ValueError):
+        list(DeviceReads.stream_fastq(str(path), 0))
+
+
+def test_adaptor_align_number_and_qual_type(tmp_path):
+    """`number` only changes the chunking, never the table (R/adaptorAlign.R:26-60: per-chunk results are
+    rbind-ed); `qual_type` selects the encoding vector the qualities are read with (:18-19)."""
+    from sarlacc_amd import generics as G
+    from sarlacc_amd.encoding import illumina_encoding, solexa_encoding
+    from sarlacc_amd.mock import mock_reads
+    sim = mock_reads(A1, A2, nmolecules=12, nreads=5, seqlen=300, seed=77)
+    names = ["READ_%d" % (i + 1) for i in range(len(sim["reads"]))]
+    reads = G.Reads(sim["reads"], sim["quals"], names)
+    path = tmp_path / "mock.fastq"
+    G.write_fastq(str(path), reads)
+    one = G.adaptorAlign(A1, A2, str(path), tolerance=120)
+
+    def same(a, b):
+        assert list(a["names"]) == list(b["names"])
+        assert np.array_equal(a["read.width"], b["read.width"]) and np.array_equal(a["reversed"], b["reversed"])
+        for key in ("adaptor1", "adaptor2"):
+            assert np.array_equal(a[key]["score"].view(np.int64), b[key]["score"].view(np.int64))
+            assert np.array_equal(a[key]["start"], b[key]["start"]) and np.array_equal(a[key]["end"], b[key]["end"])
+            for k in a[key]["subseq"]:
+                assert list(a[key]["subseq"][k]) == list(b[key]["subseq"][k])
+
+    for number in (1, 7, 59, 60, 1e5):
+        same(one, G.adaptorAlign(A1, A2, str(path), tolerance=120, number=number))
+    assert one["metadata"]["qual.type"] == "phred"
+    # realizeReads streams with the same chunking rule and finds reads in whichever chunk holds them
+    filt = G.filterReads(one, 6, 6)
+    ref = G.realizeReads(filt)
+    for number in (1, 13):
+        got = G.realizeReads(filt, number=number)
+        assert got.names == ref.names and got.seq.to_strings() == ref.seq.to_strings() and got.qual.to_strings() == ref.qual.to_strings()
+    res = G.realizeReads(filt, number=13, resident=True)
+    assert res.download()[0].to_strings() == ref.seq.to_strings()
+    # the same error probabilities written as Illumina (+64) characters: identical table
+    q64 = ["".join(chr(min(ord(c) - 33, 62) + 64) for c in q) for q in sim["quals"]]
+    q33 = ["".join(chr(min(ord(c) - 33, 62) + 33) for c in q) for q in sim["quals"]]
+    p64, p33 = tmp_path / "ill.fastq", tmp_path / "phr.fastq"
+    G.write_fastq(str(p64), G.Reads(sim["reads"], q64, names))
+    G.write_fastq(str(p33), G.Reads(sim["reads"], q33, names))
+    ill = G.adaptorAlign(A1, A2, str(p64), tolerance=120, qual_type="illumina", number=25)
+    assert ill["metadata"]["qual.type"] == "illumina"
+    same(G.adaptorAlign(A1, A2, str(p33), tolerance=120), ill)
+    # Solexa: against the host route with the Solexa encoding vector attached to the Reads
+    sol = G.adaptorAlign(A1, A2, str(p64), tolerance=120, qual_type="sol")
+    assert sol["metadata"]["qual.type"] == "solexa"
+    same(G.adaptorAlign(A1, A2, G.Reads(sim["reads"], q64, names, encoding=solexa_encoding()), tolerance=120), sol)
+    assert not np.array_equal(sol["adaptor1"]["score"], ill["adaptor1"]["score"])
+    with pytest.raises(ValueError, match="should be one of"):
+        G.adaptorAlign(A1, A2, str(path), qual_type="sanger")
+    assert illumina_encoding().names[0] == ord("@")

@@ -177,7 +177,7 @@ def test_c3_shape_sample(oracle):
         truth = NUC[rng.integers(0, 4, 12)]
         umis += [mutate(truth, rng).tobytes().decode() for _ in range(10)]
     g = [list(range(1, len(umis) + 1))]
-    for t in (1, 2):
+    for t in (1, 2, 3):   # 3 is umiGroup's own default (R/umiGroup.R:3)
         got = calls.umi_group(umis, t, None, t, g)
         same_lists(got, oracle.umi_group(umis, t, None, t, g, fast=True))
         assert sorted(x for c in got for x in c.tolist()) == g[0]
@@ -233,3 +233,76 @@ def test_umi_group_flat_matches_lists():
     keep = np.diff(coff) >= 2
     soff, smem = calls.csr_select(coff, mem, keep)
     same_lists([smem[soff[k]:soff[k + 1]] for k in range(len(soff) - 1)], [w for w in want if len(w) >= 2])
+
+
+# ---------------------------------------------------------------------------
+# strings beyond one 64-bit code word (33..128 bases): UMIs can be up to 80 bases long in the reference's
+# own tests (tests/testthat/test-umigroup.R), and expectedDist runs on whole adaptor sub-sequences
+
+@pytest.mark.parametrize("lo,hi,alphabet", [(33, 48, "ACGT"), (60, 80, "ACGTN"), (100, 128, "ACGT"), (5, 70, "ACGT")])
+def test_lev_masked_dense_long(oracle, lo, hi, alphabet):
+    from sarlacc_amd import calls
+    rng = np.random.default_rng(2000 + lo)
+    seqs = seqsim(rng, 20, lo, hi, alphabet) + umisim(rng, 20, hi, 0.1, alphabet)
+    assert calls.compute_lev_masked(seqs).tolist() == oracle.compute_lev_masked(seqs).tolist()
+
+
+@pytest.mark.parametrize("length,alphabet", [(33, "ACGT"), (40, "ACGTN"), (64, "ACGT"), (65, "ACGT"), (80, "ACGTN"), (128, "ACGT")])
+def test_fast_levdist_long(oracle, length, alphabet):
+    """the neighbour lists (content and trie order) for strings of 33..128 bases, lengths varying around
+    `length` so that the trie order is decided beyond base 32, 42, 63 ... (sort key boundaries)"""
+    from sarlacc_amd import calls
+    rng = np.random.default_rng(length)
+    seqs = []
+    for _ in range(12):
+        fam = umisim(rng, 8, length, rate=0.04, alphabet=alphabet)
+        for k, u in enumerate(fam):     # indels near the end, a few shorter relatives
+            if k % 3 == 1:
+                u = u[:-1]
+            if k % 4 == 2:
+                u = u[:length // 2] + u[length // 2 + 1:]
+            seqs.append(u[:128])
+    seqs += seqs[:5]                     # duplicates
+    seqs += seqsim(rng, 10, 1, 20, "ACGT")   # short strings in the same call
+    for limit in (0, 1, 2, 3, 5, 9, 20):
+        same_lists(calls.fast_levdist_test(seqs, limit, True), oracle.fast_levdist_test(seqs, limit))
+
+
+def test_umi_group_long(oracle):
+    from sarlacc_amd import SarlaccError, calls
+    rng = np.random.default_rng(4242)
+    seqs1, seqs2, pre = [], [], []
+    for x in range(8):
+        N = int(rng.integers(10, 21))
+        seqs1 += umisim(rng, N, 50, rate=0.03)
+        seqs2 += umisim(rng, N, 36, rate=0.03)
+        pre += [x % 3] * N
+    o = rng.permutation(len(pre))
+    seqs1 = [seqs1[i] for i in o]
+    seqs2 = [seqs2[i] for i in o]
+    pre = np.array(pre)[o]
+    everything = [list(range(1, len(seqs1) + 1))]
+    by_group = [(np.flatnonzero(pre == g) + 1).tolist() for g in range(3)]
+    for groups in (everything, by_group):
+        for t in (0, 1, 3):
+            same_lists(calls.umi_group(seqs1, t, None, t, groups), oracle.umi_group(seqs1, t, None, t, groups))
+        for t1, t2 in ((1, 1), (3, 1)):
+            same_lists(calls.umi_group(seqs1, t1, seqs2, t2, groups), oracle.umi_group(seqs1, t1, seqs2, t2, groups))
+    # more than one tile of long strings
+    many = []
+    for _ in range(60):
+        many += umisim(rng, 10, 40, rate=0.03)
+    g = [list(range(1, len(many) + 1))]
+    same_lists(calls.umi_group(many, 2, None, 2, g), oracle.umi_group(many, 2, None, 2, g))
+    with pytest.raises(SarlaccError, match="longer than 128 bases"):
+        calls.umi_group(["A" * 129, "C" * 10], 1, None, 1, [[1, 2]])
+
+
+def test_singleton_pregroups_pass_through_unchecked(oracle):
+    """src/umi_group.cpp:39-42: a pre-group of one read is returned as it is, whatever its UMI holds
+    (too long for the search, characters outside ACGTN, empty)."""
+    from sarlacc_amd import calls
+    umis = ["ACGT", "ACGA", "X" * 200, "", "ACNNNNNNGT", "ACGT"]
+    groups = [[1, 2, 6], [3], [4], [5]]
+    same_lists(calls.umi_group(umis, 1, None, 1, groups), oracle.umi_group(umis, 1, None, 1, groups))
+    same_lists(calls.umi_group(umis, 1, umis, 1, groups), oracle.umi_group(umis, 1, umis, 1, groups))

@@ -277,3 +277,22 @@ def test_strlist_behaves_like_a_list_of_strings():
     assert StrList([]) == [] and len(StrList([]).select(np.zeros(0, bool))) == 0
     with pytest.raises(IndexError):
         sl[5]
+
+
+def test_quality_class_encodings():
+    """.qual2class + .create_encoding_vector for the three classes of adaptorAlign's qual.type
+    (R/adaptorAlign.R:8,:97-99; R/qualityMask.R:19-28): offsets, ranges and the score -> error maps."""
+    from sarlacc_amd.encoding import encoding_for_qual_type
+    name, ph = encoding_for_qual_type(("phred", "solexa", "illumina"))   # the default: first choice
+    assert name == "phred" and ph.names[0] == 33 and ph.errors[0] == 1.0 and abs(ph.errors[20] - 0.01) < 1e-15
+    name, il = encoding_for_qual_type("illumina")
+    assert name == "illumina" and il.names[0] == 64 and il.names[-1] == 126 and abs(il.errors[30] - 1e-3) < 1e-18
+    name, so = encoding_for_qual_type("s")                                # unique prefix, as match.arg
+    assert name == "solexa" and so.names[0] == 59 and so.names[5] == 64
+    assert abs(so.errors[5] - 0.5) < 1e-15                                # Solexa score 0: p/(1-p) = 1
+    q = 10.0
+    assert abs(so.errors[15] - (10 ** (-q / 10)) / (1 + 10 ** (-q / 10))) < 1e-15
+    assert (np.diff(so.errors) < 0).all() and (np.diff(il.errors) < 0).all()
+    for bad in ("", "sanger", "x", None, 3):
+        with pytest.raises(ValueError, match="should be one of"):
+            encoding_for_qual_type(bad)
