@@ -941,7 +941,8 @@ static int encode_and_rank(const std::string& p, const uint8_t* d_chars, const i
     out->words = 1;
     if (hbad[1] != init[1]) {
         // some string has more than 32 bases: the whole call runs on 4-word codes
-        if (-hbad[2] > UMI_LONG_MAX) return fail("sarlacc_amd: UMI longer than %d bases is not supported", UMI_LONG_MAX);
+        const int maxlen = -hbad[2];
+        if (maxlen > UMI_LONG_MAX) return fail("sarlacc_amd: UMI longer than %d bases is not supported", UMI_LONG_MAX);
         out->words = UMI_LONG_WORDS;
         SL_TRY(alloc_umi(p + ".rawL", n, &raw, UMI_LONG_WORDS));
         SL_TRY(alloc_umi(p + ".srtL", n, &out->U, UMI_LONG_WORDS));
@@ -955,7 +956,7 @@ static int encode_and_rank(const std::string& p, const uint8_t* d_chars, const i
         if (hbad[0] != init[0])
             return fail("sarlacc_amd: UMI contains a character outside ACGTN (the reference silently drops such strings)");
         // stable sorts, least-significant key first (only the keys some string reaches)
-        const int nkeys = (-hbad[2] + UMI_KEY_BASES - 1) / UMI_KEY_BASES;
+        const int nkeys = (maxlen + UMI_KEY_BASES - 1) / UMI_KEY_BASES;
         int *from = idx, *to = idx2;
         for (int k = nkeys - 1; k >= 0; --k) {
             hipLaunchKernelGGL(k_gather_u64, dim3(nblk(n, 256)), dim3(256), 0, s, keys + static_cast<size_t>(k) * n, from, klo, n);
