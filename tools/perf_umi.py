@@ -33,7 +33,7 @@ if __name__ == "__main__":
     n_check = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
     n_full = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
     from oracle import oracle as O
-    for thr in (1, 2):
+    for thr in (1, 2, 3):   # 3 = umiGroup's default threshold1 (R/umiGroup.R:3)
         ss = make_umis(n_check // 10, 10, 1000)
         strs = ss.to_strings()
         g = [np.arange(1, len(strs) + 1, dtype=np.int32)]
@@ -43,7 +43,7 @@ if __name__ == "__main__":
         print("thr=%d n=%d gpu %.3fs oracle %.3fs clusters %d identical=%s" % (thr, len(strs), t1 - t0, t2 - t1, len(got), same), flush=True)
     ss = make_umis(n_full // 10, 10, 1001)
     g = [np.arange(1, len(ss) + 1, dtype=np.int32)]
-    for thr in (1, 2):
+    for thr in (1, 2, 3):
         for rep in range(2):
             t0 = time.perf_counter(); got = calls.umi_group(ss, thr, None, thr, g); t1 = time.perf_counter()
             tot = sum(len(c) for c in got)
