@@ -57,6 +57,23 @@ static int cmp_lenidx(const void* a, const void* b) {
 int orc_msa_pairwise(const char* r, int64_t lr, const char* c, int64_t lc,
                     int ma, int mm, int go, int ge, int bw,
                     int32_t* ins_cnt, int64_t* aligned) {
+    /* Band cap (MSA spec, both versions): a pair is aligned inside at most ORC_MSA_MAXBAND diagonals.
+     * Where |lc - lr| + 2 bw + 1 exceeds that, the bandwidth of THIS pair shrinks to the largest that
+     * fits; where even |lc - lr| + 1 does not fit (reads differing by >= 1024 bases), the pair gets the
+     * diagonal alignment: position p of the read opposite position p of the centre, the tail of the
+     * longer sequence unaligned.  (SeqAn's banded alignment is undefined for a band that does not
+     * contain both corners; the reference has no rule to follow here.) */
+    {
+        const int64_t dl = lc > lr ? lc - lr : lr - lc;
+        if (dl + 2 * (int64_t)bw + 1 > ORC_MSA_MAXBAND) bw = (int)((ORC_MSA_MAXBAND - 1 - dl) >= 0 ? (ORC_MSA_MAXBAND - 1 - dl) / 2 : -1);
+        if (bw < 0) {
+            const int64_t k = lr < lc ? lr : lc;
+            for (int64_t p = 0; p <= lc; ++p) ins_cnt[p] = 0;
+            for (int64_t p = 0; p < lc; ++p) aligned[p] = p < k ? p : -1;
+            if (lr > lc) ins_cnt[lc] = (int32_t)(lr - lc);
+            return 0;
+        }
+    }
     const int64_t dlo = (lc - lr < 0 ? lc - lr : 0) - bw;
     const int64_t dhi = (lc - lr > 0 ? lc - lr : 0) + bw;
     const int64_t B = dhi - dlo + 1; /* band width */

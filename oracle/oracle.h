@@ -137,6 +137,8 @@ int orc_msa_group(const char* seq, const int64_t* off, int64_t nreads,
 /* Banded global Gotoh of read r (rows) against centre c (columns), both already Dna5: the pairwise
  * stage shared by spec v1 and spec v2.  ins_cnt[p] (p <= lc): read characters inserted before centre
  * position p; aligned[p] (p < lc): read position matched to centre position p, or -1. */
+/* widest band (diagonals) any pairwise alignment of the MSA stage uses; see orc_msa_pairwise */
+#define ORC_MSA_MAXBAND 1024
 int orc_msa_pairwise(const char* r, int64_t lr, const char* c, int64_t lc,
                      int ma, int mm, int go, int ge, int bw, int32_t* ins_cnt, int64_t* aligned);
 

@@ -205,9 +205,7 @@ int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const 
                 pair_out += G.lc + 1;
                 jobs.push_back(J);
                 max_lr = std::max(max_lr, J.lr);
-                const long long band = std::llabs(static_cast<long long>(G.lc) - J.lr) + 2LL * bandwidth + 1;
-                if (band > 1024) return fail("sarlacc_amd: alignment band of %lld diagonals exceeds 1024 (length difference + 2*bandwidth + 1)", band);
-                max_band = std::max(max_band, static_cast<int>(band));
+                max_band = std::max(max_band, msa_pair_band(bandwidth, J.lr, G.lc));
             }
             max_lc = std::max(max_lc, G.lc);
         }
@@ -240,7 +238,7 @@ int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const 
 
     if (!jobs.empty()) {
         double cells = 0;
-        for (const MsaJob& J : jobs) cells += static_cast<double>(J.lr) * (std::abs(J.lc - J.lr) + 2 * bandwidth + 1);
+        for (const MsaJob& J : jobs) cells += static_cast<double>(J.lr) * msa_pair_band(bandwidth, J.lr, J.lc);
         // accumulate: part of a spec v2 call (msa2.hip), which has reset the timers and counters itself
         c.counts["msa_pairs"] = (accumulate ? c.counts["msa_pairs"] : 0.0) + static_cast<double>(jobs.size());
         c.counts["msa_cells"] = (accumulate ? c.counts["msa_cells"] : 0.0) + cells;
@@ -248,7 +246,7 @@ int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const 
         if (!accumulate) c.stage_reset("msa_pairwise");
         SL_TRY(c.stage_begin("msa_pairwise", s));
         SL_TRY(msa_pairwise_launch(jobs, d_jobs, d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, 0, d_ins, d_aln,
-                                   nullptr, nullptr, nullptr, s));
+                                   nullptr, nullptr, s));
         SL_HIP(hipEventRecord(c.ev_stop, s));
         SL_TRY(c.stage_end("msa_pairwise", s));
         c.timed = true;

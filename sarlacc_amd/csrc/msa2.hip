@@ -944,10 +944,10 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     a.col = d_col; a.pos = d_pos; a.row_cnt = d_cnt; a.row_ent = d_ent; a.row_pred = d_pred; a.part = d_part; a.ovf = d_ovf; a.redo = d_redo; a.width = d_width;
 
     // ---- all pairs ----
-    for (const MsaJob& J : B.jobs) *cells += static_cast<double>(J.lr) * (std::abs(J.lc - J.lr) + 2 * bandwidth + 1);
+    for (const MsaJob& J : B.jobs) *cells += static_cast<double>(J.lr) * msa_pair_band(bandwidth, J.lr, J.lc);
     SL_TRY(c.stage_begin("msa_pairwise", s));
     SL_TRY(msa_pairwise_launch(B.jobs, d_jobs, d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, 1, nullptr, nullptr,
-                               d_map, d_stats, nullptr, s));
+                               d_map, d_stats, s));
     SL_TRY(c.stage_end("msa_pairwise", s));
     if (overlap) SL_TRY((*overlap)());
     // ---- guide trees, leaves ----

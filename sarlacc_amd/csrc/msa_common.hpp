@@ -34,14 +34,28 @@ struct MsaArgs {
                             // the bound is what guarantees that every wave leaves the walk)
 };
 
+// Band cap of the MSA specification (both versions; oracle/msa.c orc_msa_pairwise): a pair is aligned inside
+// at most MSA_MAXBAND diagonals.  Where |lc - lr| + 2 bandwidth + 1 exceeds that, the bandwidth of that pair
+// shrinks to the largest that fits; where even |lc - lr| + 1 does not fit, the pair gets the diagonal
+// alignment (position p opposite position p, the tail of the longer sequence unaligned) without any DP.
+// Returns the pair's bandwidth, or -1 for the diagonal alignment.
+constexpr int MSA_MAXBAND = 1024;
+__host__ __device__ __forceinline__ int msa_pair_bandwidth(int bandwidth, int lr, int lc) {
+    const long long dl = lc > lr ? lc - lr : lr - lc;
+    if (dl + 2LL * bandwidth + 1 <= MSA_MAXBAND) return bandwidth;
+    return MSA_MAXBAND - 1 - dl >= 0 ? static_cast<int>((MSA_MAXBAND - 1 - dl) / 2) : -1;
+}
+// diagonals the pair's DP covers (1 for the diagonal alignment)
+__host__ __device__ __forceinline__ int msa_pair_band(int bandwidth, int lr, int lc) {
+    const int bw = msa_pair_bandwidth(bandwidth, lr, lc);
+    return bw < 0 ? 1 : (lc > lr ? lc - lr : lr - lc) + 2 * bw + 1;
+}
+
 // Launches the pairwise kernels for `jobs` (host copy, for sizing and band classes; d_jobs the same on
-// the device) on stream s.  out_mode 0: ins/aln (spec v1), 1: maps + stats (spec v2).  Jobs whose band
-// exceeds 1024 diagonals are skipped and their indices appended to `too_wide` (the caller degrades
-// those groups instead of failing the batch).
+// the device) on stream s.  out_mode 0: ins/aln (spec v1), 1: maps + stats (spec v2).
 int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, const uint8_t* d_seq,
                         double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
-                        int out_mode, uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats,
-                        std::vector<int>* too_wide, hipStream_t s);
+                        int out_mode, uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats, hipStream_t s);
 
 __device__ __forceinline__ uint8_t dna5_code(uint8_t c) {
     switch (c) {

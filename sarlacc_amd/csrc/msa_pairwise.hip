@@ -158,6 +158,33 @@ __device__ __forceinline__ void msa_walk(const MsaArgs& A, const MsaJob& J, int 
     }
 }
 
+// The diagonal alignment of a pair whose length difference alone exceeds the band cap (msa_pair_bandwidth() < 0).
+template <int OUT, bool RDREV>
+__device__ __forceinline__ void msa_diagonal_pair(const MsaArgs& A, const MsaJob& J, int jobidx, const uint8_t* s_rd, const uint8_t* s_ct) {
+    const int lane = threadIdx.x;
+    const int lr = J.lr, lc = J.lc, k = min(lr, lc);
+    if (OUT == 0) {
+        uint16_t* ins = A.ins + J.out_off;
+        uint8_t* aln = A.aln + J.out_off;
+        for (int p = lane; p <= lc; p += 64) {
+            ins[p] = (p == lc && lr > lc) ? static_cast<uint16_t>(lr - lc) : static_cast<uint16_t>(0);
+            if (p < lc) aln[p] = p < k ? 1 : 0;
+        }
+    } else {
+        uint16_t* mapA = A.map + J.out_off;
+        uint16_t* mapB = A.map + J.out2_off;
+        for (int p = lane; p < lc; p += 64) mapA[p] = p < k ? static_cast<uint16_t>(p) : static_cast<uint16_t>(0xFFFF);
+        for (int p = lane; p < lr; p += 64) mapB[p] = p < k ? static_cast<uint16_t>(p) : static_cast<uint16_t>(0xFFFF);
+        int nequal = 0;
+        for (int p0 = 0; p0 < k; p0 += 64) {
+            const int p = p0 + lane;
+            const bool eq = p < k && s_rd[4 + (RDREV ? lr - 1 - p : p)] == s_ct[4 + p];
+            nequal += __popcll(__ballot(eq));
+        }
+        if (lane == 0) A.stats[jobidx] = make_int2(nequal, k);
+    }
+}
+
 // stages the Dna5 codes (<< SHIFT) of centre and read into LDS (4 bytes of padding on either side)
 // pad_c / pad_r (0 or 1) shift the two arrays by one byte (the packed kernel makes its read addresses even).
 template <bool RDREV, int SHIFT>
@@ -210,12 +237,17 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_ad(const MsaArgs A) {
         const int jobidx = A.order ? A.order[jobn] : jobn;
         const MsaJob J = A.jobs[jobidx];
         const int lr = J.lr, lc = J.lc;
-        const int dlo = min(0, lc - lr) - A.bw;
-        const int dhi = max(0, lc - lr) + A.bw;
+        const int bw = msa_pair_bandwidth(A.bw, lr, lc);
+        const int dlo = min(0, lc - lr) - bw;
+        const int dhi = max(0, lc - lr) + bw;
         const int B = dhi - dlo + 1;
         uint8_t* s_ct = s_ct0;
         uint8_t* s_rd;
         stage_codes<false, 0>(A, J, s_ct, s_rd);
+        if (bw < 0) {   // uniform over the wave
+            msa_diagonal_pair<OUT, false>(A, J, jobidx, s_rd, s_ct);
+            continue;
+        }
 
         int Hc[C], Ec[C], Fc[C];
         bool kvalid[C];
@@ -458,14 +490,19 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
         const int jobidx = A.order ? A.order[jobn] : jobn;
         const MsaJob J = A.jobs[jobidx];
         const int lr = J.lr, lc = J.lc;
-        const int dlo = min(0, lc - lr) - A.bw;
-        const int dhi = max(0, lc - lr) + A.bw;
+        const int bw = msa_pair_bandwidth(A.bw, lr, lc);
+        const int dlo = min(0, lc - lr) - bw;
+        const int dhi = max(0, lc - lr) + bw;
         const int B = dhi - dlo + 1;
         // code arrays placed so that every lane's code-word address is even (see lds_load_words):
         //   centre words start at s_ct + 3 + 2 w + dlo + (C/2) lane, read words at s_rd + 3 + lr - 2 w + (C/2) lane
         uint8_t* s_ct = s_ct0;
         uint8_t* s_rd;
         stage_codes<true, 4>(A, J, s_ct, s_rd, (dlo + 1) & 1, (lr + 1) & 1);
+        if (bw < 0) {   // uniform over the wave
+            msa_diagonal_pair<OUT, true>(A, J, jobidx, s_rd, s_ct);
+            continue;
+        }
 
         unsigned Hev[M], Hod[M], Eev[M], Eod[M], Fev[M], Fod[M];
         unsigned gouEv[M], geuEv[M], gouOd[M], geuOd[M];   // vertical costs; PK_INF sinks the candidate at the band edge
@@ -729,8 +766,7 @@ static int launch_class(bool packed, int C, const MsaArgs& a, int grid, size_t l
 
 int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, const uint8_t* d_seq, double match,
                         double mismatch, double gap_extension, double gap_opening, int bandwidth, int out_mode,
-                        uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats, std::vector<int>* too_wide,
-                        hipStream_t s) {
+                        uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats, hipStream_t s) {
     if (jobs.empty()) return 0;
     Context& c = ctx();
     // jobs by band class: 4, 8 or 16 diagonals per lane (bands up to 256 / 512 / 1024); one launch per
@@ -738,16 +774,12 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
     std::vector<int> order[3];
     int cls_lr[3] = {0, 0, 0}, cls_lc[3] = {0, 0, 0}, cls_band[3] = {1, 1, 1};
     for (size_t q = 0; q < jobs.size(); ++q) {
-        const long long band = std::llabs(static_cast<long long>(jobs[q].lc) - jobs[q].lr) + 2LL * bandwidth + 1;
-        if (band > 1024) {
-            if (too_wide) { too_wide->push_back(static_cast<int>(q)); continue; }
-            return fail("sarlacc_amd: alignment band of %lld diagonals exceeds 1024 (length difference + 2*bandwidth + 1)", band);
-        }
+        const int band = msa_pair_band(bandwidth, jobs[q].lr, jobs[q].lc);   // capped at MSA_MAXBAND by the spec
         const int cls = band <= 256 ? 0 : (band <= 512 ? 1 : 2);
         order[cls].push_back(static_cast<int>(q));
         cls_lr[cls] = std::max(cls_lr[cls], jobs[q].lr);
         cls_lc[cls] = std::max(cls_lc[cls], jobs[q].lc);
-        cls_band[cls] = std::max(cls_band[cls], static_cast<int>(band));
+        cls_band[cls] = std::max(cls_band[cls], band);
     }
     MsaArgs a{};
     a.seq = d_seq; a.jobs = d_jobs;

@@ -186,3 +186,29 @@ def test_msa_spec2_better_on_hard_data(oracle):
         cons, _ = calls.create_consensus_basic_loop(aln, 0.6, 1)
         err[spec] = sum(lev2(c, t) / 2 for c, t in zip(cons, truths))
     assert err[2] < err[1], err
+
+
+def test_msa_band_cap_degrades_the_pair_not_the_batch(oracle, spec):
+    """The band cap of the spec (1024 diagonals per pair, oracle/msa.c orc_msa_pairwise): a bandwidth that
+    does not fit shrinks for that pair; reads differing by 1024 bases or more get the diagonal alignment.
+    The other groups of the call are aligned as usual and every row still spells its read."""
+    from sarlacc_amd import calls
+    from sarlacc_amd.mock import NUC, mutate
+    rng = np.random.default_rng(77)
+    t1 = NUC[rng.integers(0, 4, 700)]
+    t2 = NUC[rng.integers(0, 4, 3000)]
+    reads = [mutate(t1, rng, 0.05, 0.01).tobytes().decode() for _ in range(4)]          # ordinary group
+    reads += [mutate(t2, rng, 0.03, 0.01).tobytes().decode() for _ in range(3)]         # holds a length outlier:
+    reads.append(mutate(t2[:1700], rng, 0.03, 0.01).tobytes().decode())                #   1300 bases shorter
+    reads += [mutate(t1, rng, 0.05, 0.01).tobytes().decode()[:n] for n in (700, 400, 650)]   # 300 shorter: bw shrinks at 600
+    groups = [[1, 2, 3, 4], [5, 6, 7, 8], [9, 10, 11]]
+    for bw in (100, 600, 5000):
+        want = oracle.quick_msa(groups, reads, 0, -1, -5, -1, bw, spec=spec)
+        got = calls.quick_msa(groups, reads, 0, -1, -5, -1, bw)
+        assert got == want, bw
+        for rows, g in zip(got, groups):
+            assert len({len(r) for r in rows}) == 1
+            assert [r.replace("-", "") for r in rows] == [reads[i - 1] for i in g]
+    # the ordinary group does not depend on what else is in the call
+    alone = calls.quick_msa([groups[0]], reads, 0, -1, -5, -1, 100)
+    assert alone[0] == calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)[0]

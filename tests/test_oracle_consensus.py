@@ -153,3 +153,20 @@ def test_msa_contract(oracle):
     # Rd example of the reference (man/multiReadAlign.Rd:72-77): one-base deletion
     out = oracle.quick_msa([[1, 2]], ["ACACTGGTTCAGGT", "ACACGGTTCAGGT"], 0, -1, -5, -1, 100)[0]
     assert out[0] == "ACACTGGTTCAGGT" and out[1].replace("-", "") == "ACACGGTTCAGGT" and len(out[1]) == 14
+
+
+def test_msa_band_cap_rule(oracle):
+    """orc_msa_pairwise's band cap: |lc - lr| >= 1024 -> diagonal alignment; otherwise the bandwidth shrinks
+    to what fits into 1024 diagonals, so an enormous `bandwidth` equals the largest one that fits."""
+    rng = np.random.default_rng(3)
+    a = "".join(rng.choice(list("ACGT"), 1500))
+    b = a[:300]
+    for spec in (1, 2):
+        rows = oracle.quick_msa([[1, 2]], [a, b], 0, -1, -5, -1, 100, spec=spec)[0]
+        assert rows[0] == a and rows[1] == b + "-" * 1200          # position p opposite position p
+        rows = oracle.quick_msa([[1, 2]], [b, a], 0, -1, -5, -1, 100, spec=spec)[0]
+        assert rows[1] == a and rows[0] == b + "-" * 1200
+    c = a[:200] + a[260:900]                                        # 60-base deletion, 900 vs 840 bases
+    big = oracle.quick_msa([[1, 2]], [a[:900], c], 0, -1, -5, -1, 10 ** 6, spec=1)[0]
+    fit = oracle.quick_msa([[1, 2]], [a[:900], c], 0, -1, -5, -1, (1023 - 60) // 2, spec=1)[0]
+    assert big == fit and big[1].replace("-", "") == c
