@@ -53,6 +53,12 @@ struct ConsArgs {
     int fix_cap;
     long long* fix_pos;        // output byte index
     double* fix_val;           // 4 per entry: sorted scores (quality) or {max,total,0,0} (basic)
+    int* fix_grp;              // k_consensus_qf: group of the entry (entries of groups handed to the generic kernel are void)
+    // k_consensus_qf (fast path) and its hand-over to k_consensus_q4
+    const double* strip;       // [(navail + 1)][QF_STRIP][QF_SLOTS]: per quality the strip (w w w r w w w), replicated; last row zeros
+    int* gflag;                // per group: 1 = the fast kernel met something it does not handle; the generic kernel redoes the group
+    int only_flagged;          // k_consensus_q4: skip groups whose flag is 0
+    long long aln_bytes, qual_bytes;   // sizes of the two buffers (the fast kernel reads whole dwords)
 };
 
 __device__ __forceinline__ double dev_log1pexp(double x) {
@@ -286,6 +292,7 @@ __global__ void __launch_bounds__(256, 4) k_consensus_q4(const ConsArgs A) {
     const int zero_entry = 5 * A.navail;
 
     for (long long g = static_cast<long long>(blockIdx.x) * 4 + wave; g < A.ngroups; g += static_cast<long long>(gridDim.x) * 4) {
+        if (A.only_flagged && !A.gflag[g]) continue;
         const long long row0 = A.grp_rows[g];
         const int nrows = static_cast<int>(A.grp_rows[g + 1] - row0);
         if (nrows == 0) {
@@ -454,6 +461,255 @@ __global__ void __launch_bounds__(256, 4) k_consensus_q4(const ConsArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_consensus_qf: the quality vote on clean data, built around the instruction count per cell.
+//
+// Same sums in the same order as k_consensus_q4 (4 columns per lane, rows in order).  What is different:
+//  * everything that can be done on the four characters of a lane at once is done on the dword: gap
+//    detection, non-gap count, the position of every character in the quality string (byte-wise prefix
+//    by one multiplication), the expansion of the lane's quality bytes to the slots of its characters
+//    (one v_perm), range and alphabet checks;
+//  * the wave prefix of the non-gap counts is one DPP scan for three rows (10-bit fields);
+//  * the four addends of a cell come from LDS with ONE address: per quality value the table holds the
+//    strip (w w w r w w w) of log(e/3) and log1p(-e); a cell of base code c reads strip[3 - c + b] for
+//    base b = 0..3, i.e. four ds_read_b64 at immediate offsets from (row of q) + (3 - c) -- no select.
+//    Base codes are (char >> 1) & 3: A 0, C 1, T 2, G 3.  Every double is replicated for 16 lane slots.
+//    Gaps read the all-zero row (adding +0.0 leaves the sums bit-identical).
+// It handles alignments of A, C, G, T and '-' with qualities inside the encoding, at most 64 rows stored
+// back to back; anything else (N or other characters, a quality outside the table, quality strings
+// shorter or longer than their rows, the last bytes of a buffer) sets the group's flag and the group is
+// redone by k_consensus_q4 -- detection costs a few SWAR operations per dword and is exact.
+constexpr int QF_SLOTS = 16;
+constexpr int QF_STRIP = 7;
+constexpr int QF_ROWB = QF_STRIP * QF_SLOTS * 8;   // 896 bytes per quality value
+constexpr int QF_RB = 6;                           // rows per batch: two scans of three packed counts
+constexpr int QF_THREADS = 1024;
+
+__device__ __forceinline__ unsigned qf_scan(unsigned x) {   // inclusive prefix sum over the wavefront
+    x += static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x111, 0xf, 0xf, false));   // row_shr:1
+    x += static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x112, 0xf, 0xf, false));   // row_shr:2
+    x += static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x114, 0xf, 0xf, false));   // row_shr:4
+    x += static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x118, 0xf, 0xf, false));   // row_shr:8
+    x += static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x142, 0xa, 0xf, false));   // row_bcast:15
+    x += static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x143, 0xc, 0xf, false));   // row_bcast:31
+    return x;
+}
+
+__global__ void __launch_bounds__(QF_THREADS) k_consensus_qf(const ConsArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(A.strip);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        const int n16 = (A.navail + 1) * (QF_ROWB / 16);
+        for (int x = threadIdx.x; x < n16; x += QF_THREADS) dst[x] = src[x];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned char* const lanebase = smem + (lane & 15) * 8;
+    const unsigned DASH4 = 0x2d2d2d2du;
+    const unsigned QOFF4 = static_cast<unsigned>(A.qoffset) * 0x01010101u;
+    const unsigned QZERO4 = static_cast<unsigned>(A.qoffset + A.navail) * 0x01010101u;   // the quality "character" of the zero row
+    const unsigned KHI = static_cast<unsigned>(0x80 - A.navail) * 0x01010101u;           // q + KHI has bit 7 set iff q >= navail
+    const unsigned LUT = 0x47544341u;                                                    // code -> character: A C T G
+
+    for (long long g = static_cast<long long>(blockIdx.x) * (QF_THREADS / 64) + wave; g < A.ngroups;
+         g += static_cast<long long>(gridDim.x) * (QF_THREADS / 64)) {
+        const long long row0 = A.grp_rows[g];
+        const int nrows = static_cast<int>(A.grp_rows[g + 1] - row0);
+        if (nrows == 0) {
+            if (lane == 0) { A.cons_len[g] = 0; A.gflag[g] = 0; }
+            continue;
+        }
+        const long long abase = A.aln_off[row0];
+        const long long W = A.aln_off[row0 + 1] - abase;
+        // row descriptors: lane r holds row r
+        long long qo = 0;
+        int qlen = 0;
+        bool rowbad = false;
+        if (lane < nrows && nrows <= 64) {
+            const long long q = A.row_read ? A.row_read[row0 + lane] - 1 : row0 + lane;
+            qo = A.qual_off[q];
+            qlen = static_cast<int>(A.qual_off[q + 1] - qo);
+            rowbad = A.aln_off[row0 + lane] != abase + static_cast<long long>(lane) * W || qo + qlen + 4 > A.qual_bytes;
+        }
+        if (nrows > 64 || W >= (1ll << 30) || abase + static_cast<long long>(nrows) * W + 4 > A.aln_bytes || __ballot(rowbad)) {
+            if (lane == 0) A.gflag[g] = 1;
+            continue;
+        }
+        const int qo_lo = static_cast<int>(qo), qo_hi = static_cast<int>(qo >> 32);
+        int vpos = 0;
+        unsigned bad = 0;
+        const double thresh = static_cast<double>(nrows) * A.mincov;
+        const long long obase = A.out_off[g];
+        int outpos = 0;
+
+        unsigned vn[QF_RB];
+#pragma unroll
+        for (int b = 0; b < QF_RB; ++b) {
+            unsigned w = DASH4;
+            if (b < nrows && 4 * lane < static_cast<int>(W)) w = *reinterpret_cast<const cons_u32_unaligned*>(A.aln + abase + static_cast<long long>(b) * W + 4 * lane);
+            vn[b] = w;
+        }
+        for (long long c0 = 0; c0 < W; c0 += 256) {
+            const int col = static_cast<int>(c0) + 4 * lane;
+            const int remain = static_cast<int>(W) - col;          // characters of the row at and after `col`
+            const unsigned keepmask = remain >= 4 ? 0xffffffffu : (remain <= 0 ? 0u : ((1u << (8 * remain)) - 1u));
+            double acc[4][4];
+            unsigned inc4 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0;
+
+            for (int r0 = 0; r0 < nrows; r0 += QF_RB) {
+                unsigned v[QF_RB], ng[QF_RB], qw[QF_RB];
+#pragma unroll
+                for (int b = 0; b < QF_RB; ++b) v[b] = (vn[b] & keepmask) | (DASH4 & ~keepmask);   // requested one batch ahead
+                unsigned pk[2] = {0u, 0u};
+#pragma unroll
+                for (int b = 0; b < QF_RB; ++b) {
+                    const unsigned x = v[b] ^ DASH4;
+                    const unsigned t = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x;
+                    ng[b] = t & 0x80808080u;                        // bit 7 of every non-gap byte
+                    pk[b / 3] |= static_cast<unsigned>(__builtin_popcount(ng[b])) << (10 * (b % 3));
+                }
+                const unsigned sc0 = qf_scan(pk[0]), sc1 = qf_scan(pk[1]);
+                const unsigned tot0 = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(sc0), 63));
+                const unsigned tot1 = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(sc1), 63));
+#pragma unroll
+                for (int b = 0; b < QF_RB; ++b) {
+                    const int r = r0 + b;
+                    const int rr = r < 63 ? r : 63;
+                    const unsigned incl = ((b < 3 ? sc0 : sc1) >> (10 * (b % 3))) & 0x3ffu;
+                    const unsigned total = ((b < 3 ? tot0 : tot1) >> (10 * (b % 3))) & 0x3ffu;
+                    const int n = __builtin_popcount(ng[b]);
+                    const int carry = __builtin_amdgcn_readlane(vpos, rr);
+                    const int ql = __builtin_amdgcn_readlane(qlen, rr);
+                    const int pos = carry + static_cast<int>(incl) - n;
+                    if (r < nrows && lane == rr) vpos = carry + static_cast<int>(total);
+                    bad |= (r < nrows && pos + n > ql) ? 0x80u : 0u;
+                    unsigned w = QZERO4;
+                    if (r < nrows && n > 0) {
+                        const long long qb = (static_cast<long long>(__builtin_amdgcn_readlane(qo_hi, rr)) << 32) |
+                                             static_cast<unsigned>(__builtin_amdgcn_readlane(qo_lo, rr));
+                        w = *reinterpret_cast<const cons_u32_unaligned*>(A.qual + qb + (pos < ql ? pos : ql));
+                    }
+                    qw[b] = w;
+                }
+                {   // characters of the next batch (next rows of this step, or the first rows of the next step)
+                    const bool wrap = r0 + QF_RB >= nrows;
+                    const int nr0 = wrap ? 0 : r0 + QF_RB;
+                    const int ncol = wrap ? col + 256 : col;
+#pragma unroll
+                    for (int b = 0; b < QF_RB; ++b) {
+                        const int r = nr0 + b;
+                        unsigned w = DASH4;
+                        if (r < nrows && ncol < static_cast<int>(W)) w = *reinterpret_cast<const cons_u32_unaligned*>(A.aln + abase + static_cast<long long>(r) * W + ncol);
+                        vn[b] = w;
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < QF_RB; ++b) {
+                    if (r0 + b >= nrows) break;
+                    const unsigned one = ng[b] >> 7;                                     // 1 per non-gap byte
+                    const unsigned ff = (ng[b] << 1) - one;                              // 0xff per non-gap byte
+                    const unsigned presel = (one << 8) + (one << 16) + (one << 24);      // byte k: non-gap bytes below k
+                    const unsigned sel = (presel & ff) | (0x04040404u & ~ff);
+                    const unsigned qe = __builtin_amdgcn_perm(QZERO4, qw[b], sel);       // quality of every character, zero row for gaps
+                    const unsigned qi = qe - QOFF4;
+                    bad |= (qi | (qi + KHI)) & ng[b];
+                    const unsigned selw = (v[b] >> 1) & 0x03030303u;                     // base codes
+                    bad |= (__builtin_amdgcn_perm(LUT, LUT, selw) ^ v[b]) & ff;          // characters other than A, C, G, T
+                    inc4 += one;
+                    const unsigned tst = 0x03030303u - selw;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned off = __umul24((qi >> (8 * k)) & 0xffu, QF_ROWB) + (((tst >> (8 * k)) & 0xffu) << 7);
+                        const unsigned char* cell = lanebase + off;
+                        acc[k][0] += *reinterpret_cast<const double*>(cell);
+                        acc[k][1] += *reinterpret_cast<const double*>(cell + 128);
+                        acc[k][2] += *reinterpret_cast<const double*>(cell + 256);
+                        acc[k][3] += *reinterpret_cast<const double*>(cell + 384);
+                    }
+                }
+            }
+
+            // ---- per-column result (accumulators are in code order A, C, T, G) ----
+            int nkept = 0;
+            int below_kept = 0;
+            bool keepk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int inck = static_cast<int>((inc4 >> (8 * k)) & 0xffu);
+                keepk[k] = (k < remain) && !(inck < thresh);
+                const unsigned long long m = __ballot(keepk[k]);
+                below_kept += __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), 0));
+                nkept += __popcll(m);
+            }
+            int o = outpos + below_kept;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!keepk[k]) continue;
+                const double sA = acc[k][0], sC = acc[k][1], sG = acc[k][3], sT = acc[k][2];
+                // first maximum in the order A, C, G, T (std::max_element)
+                const double mx = fmax(fmax(sA, sC), fmax(sG, sT));
+                const int best = sA == mx ? 0 : (sC == mx ? 1 : (sG == mx ? 2 : 3));
+                // Estimate of the Phred value in fp32: with u = score - max, S = sum of exp(u) over the three other
+                // bases, the log error is log(S / (1 + S)) and the Phred value 10 log10(2) (log2(1 + S) - log2(S)).
+                // Mathematically the value of the reference's log1pexp chain; the fp32 error (< 1e-4 in the Phred
+                // value) only matters next to a rounding boundary, where the exact chain is evaluated instead.
+                const float NEG = -1.0e30f;
+                const float uA = best == 0 ? NEG : static_cast<float>(sA - mx), uC = best == 1 ? NEG : static_cast<float>(sC - mx);
+                const float uG = best == 2 ? NEG : static_cast<float>(sG - mx), uT = best == 3 ? NEG : static_cast<float>(sT - mx);
+                const float L2E = 1.44269504088896341f;
+                const float S = (__builtin_amdgcn_exp2f(uA * L2E) + __builtin_amdgcn_exp2f(uC * L2E)) +
+                                (__builtin_amdgcn_exp2f(uG * L2E) + __builtin_amdgcn_exp2f(uT * L2E));
+                float xf = 3.01029995663981195f * (__builtin_amdgcn_logf(1.0f + S) - __builtin_amdgcn_logf(S));   // v_log_f32 = log2
+                float fr = xf - floorf(xf);
+                int qv;
+                bool near = false;
+                double a = 0, b = 0, c = 0, d = 0;
+                if (xf < 93.4f && fabsf(fr - 0.5f) < 4e-4f) {     // too close for the estimate: the reference's chain in fp64
+                    double t;
+                    a = sA; b = sC; c = sG; d = sT;
+                    if (a > b) { t = a; a = b; b = t; }
+                    if (c > d) { t = c; c = d; d = t; }
+                    if (a > c) { t = a; a = c; c = t; }
+                    if (b > d) { t = b; b = d; d = t; }
+                    if (b > c) { t = b; b = c; c = t; }
+                    const double le = exact_log_error(a, b, c, d);
+                    const double x = -10 * le / A.ln10;
+                    const double frac = x - floor(x);
+                    near = x < 93.4 && fabs(frac - 0.5) < 1e-9;
+                    double q = round(x);
+                    if (q > 93.0) q = 93.0;
+                    qv = static_cast<int>(q);
+                } else {
+                    xf = fminf(xf, 93.0f);                          // also takes +inf (S underflowed to 0)
+                    qv = static_cast<int>(floorf(xf + 0.5f));
+                }
+                A.cons[obase + o] = "ACGT"[best];
+                A.phred[obase + o] = static_cast<uint8_t>(qv + 33);
+                if (near) {
+                    const int slot = atomicAdd(A.fix_count, 1);
+                    if (slot < A.fix_cap) {
+                        A.fix_pos[slot] = obase + o;
+                        A.fix_grp[slot] = static_cast<int>(g);
+                        A.fix_val[4 * slot + 0] = a; A.fix_val[4 * slot + 1] = b;
+                        A.fix_val[4 * slot + 2] = c; A.fix_val[4 * slot + 3] = d;
+                    }
+                }
+                ++o;
+            }
+            outpos += nkept;
+        }
+        // every quality string consumed exactly, nothing unusual seen: the group is done
+        const bool dirty = __ballot(bad != 0u || (lane < nrows && vpos != qlen)) != 0ull;
+        if (lane == 0) {
+            A.gflag[g] = dirty ? 1 : 0;
+            if (!dirty) A.cons_len[g] = outpos;
+        }
+    }
+}
+
 // kept columns of every alignment -> contiguous output (one block per alignment)
 __global__ void k_consensus_compact(const uint8_t* cons, const uint8_t* phred, const double* lerr, const int64_t* out_off,
                                     const int32_t* len, const long long* dst_off, long long ngroups, uint8_t* dcons,
@@ -516,6 +772,15 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         SL_TRY(upload("cons.vec", vec.data(), vec.size(), &d_vec, s));
         a.vec = d_vec;
         a.qoffset = static_cast<int>(enc_names[0]); a.navail = enc_n;
+        // k_consensus_qf: per quality the strip (w w w r w w w), every double replicated for QF_SLOTS lanes; zero row last
+        std::vector<double> strip(static_cast<size_t>(enc_n + 1) * QF_STRIP * QF_SLOTS, 0.0);
+        for (int k = 0; k < enc_n; ++k)
+            for (int i = 0; i < QF_STRIP; ++i)
+                for (int sl = 0; sl < QF_SLOTS; ++sl)
+                    strip[(static_cast<size_t>(k) * QF_STRIP + i) * QF_SLOTS + sl] = (i == 3) ? right[k] : wrong[k];
+        double* d_strip;
+        SL_TRY(upload("cons.strip", strip.data(), strip.size(), &d_strip, s));
+        a.strip = d_strip;
     }
     a.ngroups = ng_eval;
     a.mincov = min_cov; a.pseudo = pseudo; a.ln10 = std::log(10);
@@ -538,6 +803,11 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
     SL_HIP(hipMemsetAsync(d_fixn, 0, sizeof(int), s));
     a.cons = d_cons; a.phred = d_phred; a.lerr = d_lerr; a.cons_len = d_len; a.row_status = d_status;
     a.first_bad_char = d_badchar; a.fix_count = d_fixn; a.fix_cap = fix_cap; a.fix_pos = d_fixpos; a.fix_val = d_fixval;
+    int* d_fixgrp; int* d_gflag;
+    SL_TRY(scratch("cons.fixgrp", fix_cap, &d_fixgrp));
+    SL_TRY(scratch("cons.gflag", static_cast<size_t>(std::max<int64_t>(ngroups, 1)), &d_gflag));
+    SL_HIP(hipMemsetAsync(d_fixgrp, 0xff, sizeof(int) * fix_cap, s));
+    a.fix_grp = d_fixgrp; a.gflag = d_gflag; a.only_flagged = 0;
 
     if (ng_eval > 0) {
         const size_t lds = (quality ? 2 * sizeof(double) * enc_n : 0) + (2 * sizeof(long long) + 3 * sizeof(int)) * static_cast<size_t>(max_rows) + 16;
@@ -551,6 +821,18 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         c.stage_reset("consensus");
         SL_TRY(c.stage_begin("consensus", s));
         if (q4) {
+            // clean groups on the fast kernel (one 1024-thread workgroup per CU around a ~85 KB strip table in LDS);
+            // whatever it flags is redone by the generic kernel
+            const size_t ldsf = static_cast<size_t>(enc_n + 1) * QF_ROWB;
+            const bool qf = a.aln_bytes > 0 && a.qual_bytes > 0 && enc_n <= 127 && a.qoffset + enc_n <= 255 && ldsf <= 150 * 1024 &&
+                            !std::getenv("SARLACC_CONSENSUS_GENERIC");
+            if (qf) {
+                SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_consensus_qf), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsf)));
+                const int gridf = static_cast<int>(std::min<int64_t>((ng_eval + QF_THREADS / 64 - 1) / (QF_THREADS / 64), c.num_cu));
+                hipLaunchKernelGGL(k_consensus_qf, dim3(gridf), dim3(QF_THREADS), ldsf, s, a);
+                SL_HIP(hipGetLastError());
+                a.only_flagged = 1;
+            }
             const int grid4 = static_cast<int>(std::min<int64_t>((ng_eval + 3) / 4, static_cast<int64_t>(c.num_cu) * 64));
             hipLaunchKernelGGL(k_consensus_q4, dim3(grid4), dim3(256), lds4, s, a);
         } else {
@@ -623,7 +905,15 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         std::vector<double> fv(static_cast<size_t>(fixn) * 4);
         SL_HIP(hipMemcpy(fp.data(), d_fixpos, sizeof(long long) * fp.size(), hipMemcpyDeviceToHost));
         SL_HIP(hipMemcpy(fv.data(), d_fixval, sizeof(double) * fv.size(), hipMemcpyDeviceToHost));
+        // entries the fast kernel made for a group it later handed over are void (the generic kernel made its own)
+        std::vector<int> fg(static_cast<size_t>(fixn)), gflag;
+        SL_HIP(hipMemcpy(fg.data(), d_fixgrp, sizeof(int) * fg.size(), hipMemcpyDeviceToHost));
+        if (a.only_flagged) {
+            gflag.resize(static_cast<size_t>(ng_eval));
+            SL_HIP(hipMemcpy(gflag.data(), d_gflag, sizeof(int) * gflag.size(), hipMemcpyDeviceToHost));
+        }
         for (int k = 0; k < fixn; ++k) {
+            if (fg[k] >= 0 && !gflag.empty() && gflag[static_cast<size_t>(fg[k])]) continue;
             double le;
             if (quality) {
                 double denom = fv[4 * k];
@@ -695,6 +985,7 @@ static int run_consensus(bool quality, const char* aln, const int64_t* aln_off, 
     SL_TRY(upload("cons.grows", grp_rows, static_cast<size_t>(ngroups) + 1, &d_grows, s));
     SL_TRY(upload("cons.ooff", out_off.data(), out_off.size(), &d_ooff, s));
     a.aln = d_aln; a.aln_off = d_aoff; a.grp_rows = d_grows; a.out_off = d_ooff; a.max_rows = max_rows;
+    a.aln_bytes = total;
     if (quality) {
         const int64_t qrows = qgrp_rows[ng_eval];
         const int64_t qbase = qual_off[0];
@@ -704,7 +995,7 @@ static int run_consensus(bool quality, const char* aln, const int64_t* aln_off, 
         uint8_t* d_q; int64_t* d_qoff;
         SL_TRY(upload("cons.qual", reinterpret_cast<const uint8_t*>(qual) + qbase, static_cast<size_t>(qtotal), &d_q, s));
         SL_TRY(upload("cons.qoff", qrel.data(), qrel.size(), &d_qoff, s));
-        a.qual = d_q; a.qual_off = d_qoff;
+        a.qual = d_q; a.qual_off = d_qoff; a.qual_bytes = qtotal;
     }
     return consensus_core(quality, a, ngroups, ng_eval, rows_eval, total, out_off, aln + base, struct_err_kind, min_cov, pseudo,
                           enc_errors, enc_names, enc_n, cons, phred, cons_off, lerr, s);
@@ -792,7 +1083,8 @@ static int msa_consensus_impl(const int64_t* grp_off, const int32_t* grp, int64_
     SL_TRY(upload("cons.grows", grows.data(), grows.size(), &d_grows, s));
     SL_TRY(upload("cons.ooff", out_off.data(), out_off.size(), &d_ooff, s));
     a.aln = res.d_out; a.aln_off = d_aoff; a.grp_rows = d_grows; a.out_off = d_ooff; a.max_rows = max_rows;
-    if (quality) { a.qual = d_q; a.qual_off = d_qoff; a.row_read = res.d_members; }
+    a.aln_bytes = total;
+    if (quality) { a.qual = d_q; a.qual_off = d_qoff; a.row_read = res.d_members; a.qual_bytes = qrel[static_cast<size_t>(nseq)]; }
     return consensus_core(quality, a, ngroups, ngroups, nrows, total, out_off, nullptr, 0, min_cov, pseudo_count, enc_errors,
                           enc_names, enc_n, cons, phred, cons_off, nullptr, s);
 }

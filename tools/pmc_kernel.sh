@@ -1,0 +1,26 @@
+# SQ / LDS counters of the kernels whose name contains <substr>, for an arbitrary python command (two passes).
+#   tools/pmc_kernel.sh <tag> <kernel substr> <script> [args]
+TAG=$1; SUB=$2; shift; shift
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp
+rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/p1 -o pmc -- python3 $GRAFT_REPO_ROOT/$@ > $OUT/p1.log 2>&1
+echo "pass 1 done"
+rocprofv3 --output-format csv --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE -d $OUT/p2 -o pmc -- python3 $GRAFT_REPO_ROOT/$@ > $OUT/p2.log 2>&1
+echo "pass 2 done"
+cd $GRAFT_REPO_ROOT
+python3 - <<PY
+import csv, glob
+for p in ("p1", "p2"):
+    tot, calls = {}, {}
+    for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % p, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "$SUB" in r["Kernel_Name"]:
+                key = (r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])
+                tot[key] = tot.get(key, 0) + float(r["Counter_Value"])
+                calls[key] = calls.get(key, 0) + 1
+    for k in sorted(tot):
+        print("%-42s %-24s %14.5g  (%d launches)" % (k[0], k[1], tot[k], calls[k]))
+PY
+find $OUT -name "*counter_collection.csv" -size +20M -delete
