@@ -74,6 +74,7 @@ struct M2Args {
     int ngroups;
     int ma, mm;
     unsigned long long* clk;       // SARLACC_MSA2_CLOCKS: cycles of the chain kernel's phases, first wave of the last launch
+    unsigned long long* xdbg;      // SARLACC_MSA2_EXACTDBG: per group (cycles, rows << 32 | entries) of k_m2_chain_exact
     const uint16_t* map;
     const int2* stats;
     double* dist;
@@ -373,16 +374,19 @@ __device__ __forceinline__ unsigned long long m2_rowmax16(unsigned long long v) 
 // Node value = (f << 32) | ~id, so that the maximum prefers the larger f and then the earlier match
 // (id = row * M2_CAP + index in the row + 1; 0 = no match).  All matches of a row are looked up before any of
 // them is entered.
-// P[l] = best node value (f << 32 | ~id) over the matches entered so far with column <= l: a non-decreasing
-// step function of l.  It is stored explicitly up to `top`, the largest column entered so far (beyond it the
-// value is P[top]), so a match with column j reads P[j - 1] -- one access, no tree -- and entering it raises P on
-// the columns from j upwards for as long as they are smaller (a short run: the chain advances with the columns).
-// The 16 lanes of a group serve the 16 entries of one row.  P is a circular window of M2_PWIN columns in LDS:
-// the matches of same-molecule reads stay within a few columns of `top`.  When a match lies M2_PWIN - 1 or more
-// columns below the largest column seen up to and including its row (unrelated reads in the cluster), the
-// window cannot answer: the group's round is flagged (redo) and done by k_m2_chain_exact, which keeps the
-// prefix maxima of ALL columns in a Fenwick tree.
-constexpr int M2_PWIN = 64;
+// Prefix maxima over the second child's columns are kept for the M2_PWIN = 512 columns behind the front in a
+// three-level structure with POINT updates: L0 one value per column, L1 per block of 8 columns, L2 per superblock
+// of 64; everything older than the 8 superblocks ending at the front's is folded into one scalar.  A match with
+// column j reads the columns of its block below j, the blocks of its superblock below its block and the
+// superblocks of the window below its own -- at most 21 values, one round of LDS reads for the sixteen entries
+// of a row -- and entering it is three maxima.  (A step function raised over the columns from j upwards, which
+// this replaces, degenerates when the front runs ahead of the heavy matches: clusters of two molecules.)  The 16
+// lanes of a group serve the 16 entries of one row.  When a match lies in a superblock that has left the window
+// (more than 448-511 columns behind the largest column seen up to and including its row), the window cannot answer:
+// the group's round is flagged (redo) and done by k_m2_chain_exact, which keeps the prefix maxima of ALL columns
+// in a Fenwick tree.
+constexpr int M2_PWIN = 512;
+constexpr int M2_L1 = M2_PWIN, M2_L2 = M2_PWIN + M2_PWIN / 8, M2_PSIZE = M2_PWIN + M2_PWIN / 8 + M2_PWIN / 64;
 
 __device__ __forceinline__ int m2_qmax_i32(int v) {   // maximum over the 16 lanes of a DPP row, in every lane
     v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));
@@ -393,8 +397,7 @@ __device__ __forceinline__ int m2_qmax_i32(int v) {   // maximum over the 16 lan
 }
 
 __global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nactive) {
-    constexpr bool GLOBALP = false;
-    __shared__ unsigned long long s_buf[4][M2_PWIN > 256 ? M2_PWIN : 256];   // P window, later the traceback stage
+    __shared__ unsigned long long s_buf[4][M2_PSIZE > 256 ? M2_PSIZE : 256];   // the three levels, later the traceback stage
     const int lane = threadIdx.x, qd = lane >> 4, t = lane & 15;
     const int g = blockIdx.x * 4 + qd;
     bool act = g < nactive;
@@ -410,9 +413,9 @@ __global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nact
     }
     (void)nB;
     unsigned long long* const P = &s_buf[qd][0];
-    auto pidx = [&](int l) -> int { return GLOBALP ? l : (l & (M2_PWIN - 1)); };
-    auto pload = [&](int l) -> unsigned long long { return P[pidx(l)]; };
-    auto pstore = [&](int l, unsigned long long v) { P[pidx(l)] = v; };
+    for (int x = t; x < M2_PSIZE; x += 16) P[x] = 0;
+    unsigned long long pbelow = 0;   // best over the superblocks that left the window
+    int sbT = 0;                     // superblock of the front: the window holds superblocks sbT - 7 .. sbT
     unsigned long long* const ent = A.row_ent + G.row_base * static_cast<long long>(M2_CAP);
     unsigned* const prd = A.row_pred + G.row_base * static_cast<long long>(M2_CAP);
     for (int i = t; i < nA; i += 16) A.part[G.row_base + i] = -1;
@@ -445,35 +448,58 @@ __global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nact
             const bool mk0 = act && i < nA && t < cb[r];
             const unsigned long long e = eb[r];
             const int j = static_cast<int>(e >> 32);
-            // query: best over the columns < j, state before the row
-            unsigned long long v = 0;
-            // T = largest column up to and including this row; a match at or below T - W + 1 is beyond the window
-            const int oldtop = top;
+            // the window follows the largest column seen up to and including this row: superblocks leaving it are
+            // folded into pbelow and their slots cleared
             const int newtop = m2_qmax_i32(mk0 ? j : -1);
             const int T = max(top, newtop);
-            if (mk0 && j <= T - M2_PWIN + 1) bad = true;
-            const bool mk = mk0 && !bad;
-            if (mk && j > 0) {
-                const int l = j - 1;   // (> T - W >= top - W: inside the window)
-                v = l > top ? ptop : pload(l);
+            top = T;
+            if ((T >> 6) > sbT) {
+                const int adv = min((T >> 6) - sbT, 8);
+                for (int q = 1; q <= adv; ++q) {
+                    const int slot = ((T >> 6) - adv + q) & 7;
+                    const unsigned long long old = P[M2_L2 + slot];
+                    pbelow = old > pbelow ? old : pbelow;
+                    if (t == 0) P[M2_L2 + slot] = 0;
+                    if (t < 8) P[M2_L1 + slot * 8 + t] = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) P[slot * 64 + u * 16 + t] = 0;
+                }
+                sbT = T >> 6;
             }
+            if (mk0 && (j >> 6) < sbT - 7) bad = true;
+            const bool mk = mk0 && !bad;
+            // query: best over the columns < j, state before the row (unconditional reads, masked afterwards)
+            unsigned long long v = pbelow;
+            {
+                const int jb = j >> 3, js = j >> 6;
+                unsigned long long rd[21];
+#pragma unroll
+                for (int d = 1; d <= 7; ++d) {
+                    rd[d - 1] = P[(j - d) & (M2_PWIN - 1)];
+                    rd[6 + d] = P[M2_L1 + ((jb - d) & 63)];
+                    rd[13 + d] = P[M2_L2 + ((js - d) & 7)];
+                }
+#pragma unroll
+                for (int d = 1; d <= 7; ++d) {
+                    const unsigned long long c0 = (j - d) >= (j & ~7) ? rd[d - 1] : 0ull;
+                    const unsigned long long c1 = (jb - d) >= (js << 3) ? rd[6 + d] : 0ull;
+                    const unsigned long long c2 = (js - d) >= max(sbT - 7, 0) ? rd[13 + d] : 0ull;
+                    const unsigned long long m01 = c0 > c1 ? c0 : c1;
+                    const unsigned long long m = m01 > c2 ? m01 : c2;
+                    v = m > v ? m : v;
+                }
+            }
+            if (!mk) v = 0;
             const unsigned f = static_cast<unsigned>(e) + static_cast<unsigned>(v >> 32);
             const unsigned pred = v ? ~static_cast<unsigned>(v) : 0u;
             const unsigned id = static_cast<unsigned>(i) * M2_CAP + static_cast<unsigned>(t) + 1u;
             const unsigned long long nv = mk ? ((static_cast<unsigned long long>(f) << 32) | static_cast<unsigned>(~id)) : 0ull;
             if (mk) prd[static_cast<long long>(i) * M2_CAP + t] = pred;
-            // the explicit part of P grows to the row's largest column (filled with the old plateau value)
-            if (newtop > top) {
-                for (int l = max(top + 1, GLOBALP ? 0 : newtop - M2_PWIN + 1) + t; l <= newtop; l += 16) pstore(l, ptop);
-                top = newtop;
-            }
-            // enter the matches: raise P from column j upwards while it is smaller (a column beyond the old top was
-            // just filled with the old plateau, which every new value exceeds: no need to read it)
+            // enter the matches (all queries of the row were issued before: LDS operations of a wave execute in order)
             if (mk) {
-                for (int l = j; l <= top; ++l) {
-                    if (l <= oldtop && pload(l) >= nv) break;
-                    atomicMax(&P[pidx(l)], nv);
-                }
+                atomicMax(&P[j & (M2_PWIN - 1)], nv);
+                atomicMax(&P[M2_L1 + ((j >> 3) & 63)], nv);
+                atomicMax(&P[M2_L2 + ((j >> 6) & 7)], nv);
             }
             // P[top] is the best over everything entered so far
             const unsigned long long rowbest = m2_rowmax16(nv);
@@ -542,6 +568,8 @@ __global__ void __launch_bounds__(64) k_m2_chain_exact(M2Args A, int round, unsi
     const int2 jn = A.joins[fm + round];
     const int nA = A.ncols[2 * fm + jn.x], nB = A.ncols[2 * fm + jn.y];
     const int lane = threadIdx.x;
+    const unsigned long long xclk0 = __builtin_amdgcn_s_memtime();
+    unsigned long long xent = 0;
     unsigned long long* const s_stage = reinterpret_cast<unsigned long long*>(smem);   // [64 rows][M2_CAP]
     unsigned long long* const s_nv = s_stage + 64 * M2_CAP;                              // [M2_CAP]
     int* const s_j = reinterpret_cast<int*>(s_nv + M2_CAP);                             // [M2_CAP]
@@ -577,6 +605,7 @@ __global__ void __launch_bounds__(64) k_m2_chain_exact(M2Args A, int round, unsi
         for (int r = 0; r < rows; ++r) {
             const int c = min(__builtin_amdgcn_readfirstlane(s_cnt[r]), M2_CAP);
             if (c == 0) continue;
+            xent += static_cast<unsigned>(c);
             const int i = i0 + r;
             for (int k0 = 0; k0 < c; k0 += 4) {          // queries
                 const int k = k0 + sub;
@@ -647,6 +676,7 @@ __global__ void __launch_bounds__(64) k_m2_chain_exact(M2Args A, int round, unsi
         }
     }
     if (lane == 0) A.redo[g] = 0;
+    if (A.xdbg && lane == 0) { A.xdbg[2 * g] = __builtin_amdgcn_s_memtime() - xclk0; A.xdbg[2 * g + 1] = (static_cast<unsigned long long>(nA) << 32) | xent; }
 }
 
 // ---- wave helpers for the renumbering (performance is irrelevant here) ----
@@ -940,6 +970,7 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     unsigned long long* d_clk = nullptr;
     if (std::getenv("SARLACC_MSA2_CLOCKS")) { SL_TRY(scratch((pf + ".clk").c_str(), 8, &d_clk)); SL_HIP(hipMemsetAsync(d_clk, 0, 64, s)); }
     a.clk = d_clk;
+    if (std::getenv("SARLACC_MSA2_EXACTDBG")) { SL_TRY(scratch((pf + ".xdbg").c_str(), 2 * ng, &a.xdbg)); SL_HIP(hipMemsetAsync(a.xdbg, 0, sizeof(unsigned long long) * 2 * ng, s)); }
     a.map = d_map; a.stats = d_stats; a.dist = d_dist; a.joins = d_joins; a.nodemask = d_mask; a.ncols = d_ncols;
     a.col = d_col; a.pos = d_pos; a.row_cnt = d_cnt; a.row_ent = d_ent; a.row_pred = d_pred; a.part = d_part; a.ovf = d_ovf; a.redo = d_redo; a.width = d_width;
 
@@ -978,6 +1009,16 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
         // rounds the window could not answer (unrelated reads in the cluster): exact chain search
         if (exact_gbit) hipLaunchKernelGGL(k_m2_chain_exact<true>, dim3(static_cast<unsigned>(nactive)), dim3(64), exact_lds, s, a, round, d_gbit);
         else hipLaunchKernelGGL(k_m2_chain_exact<false>, dim3(static_cast<unsigned>(nactive)), dim3(64), exact_lds, s, a, round, d_gbit);
+        if (a.xdbg) {
+            SL_HIP(hipStreamSynchronize(s));
+            std::vector<unsigned long long> hx(2 * ng);
+            SL_HIP(hipMemcpy(hx.data(), a.xdbg, sizeof(unsigned long long) * hx.size(), hipMemcpyDeviceToHost));
+            SL_HIP(hipMemsetAsync(a.xdbg, 0, sizeof(unsigned long long) * hx.size(), s));
+            unsigned long long mx = 0, sum = 0, mxinfo = 0; int cntf = 0, mxg = -1;
+            for (size_t q = 0; q < ng; ++q) if (hx[2 * q]) { ++cntf; sum += hx[2 * q]; if (hx[2 * q] > mx) { mx = hx[2 * q]; mxinfo = hx[2 * q + 1]; mxg = static_cast<int>(q); } }
+            fprintf(stderr, "exact round %d: active %d flagged %d  cycles max %llu (group %d n=%d rows %llu entries %llu) sum %llu\n", round, nactive, cntf, mx,
+                    mxg, mxg >= 0 ? B.groups[mxg].n : 0, mxinfo >> 32, mxinfo & 0xffffffffull, sum);
+        }
         hipLaunchKernelGGL(k_m2_merge, dim3(static_cast<unsigned>(nactive)), dim3(256), 0, s, a, round, d_nca, d_ncb, d_pb);
         SL_HIP(hipGetLastError());
         if (std::getenv("SARLACC_MSA2_DEBUG")) {   // first group of the batch, for comparison with ORC_MSA2_DEBUG of the oracle

@@ -1,0 +1,32 @@
+"""umi_group -> msa_consensus on device-generated molecules (bench.py's pipeline pass), stage and kernel-group times.
+    python tools/perf_pipeline_resident.py [molecules] [spec] [reps]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import sarlacc_amd
+from sarlacc_amd import calls, devsynth, pipeline
+from sarlacc_amd.strset import StringSet
+
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+spec = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+dev = torch.device("cuda:0")
+mol = devsynth.make_molecule_reads(G, 10, 2000, seed=2000, device=dev)
+off = mol["off"].cpu().numpy()
+umis = StringSet(mol["umi"].cpu().numpy(), mol["umi_off"].cpu().numpy())
+enc = sarlacc_amd.phred_encoding()
+calls.set_msa_spec(spec)
+for rep in range(reps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = pipeline.run_resident(umis, mol["seq"], mol["qual"], off, enc, threshold=1)
+    dt = time.perf_counter() - t0
+    sizes = np.diff(r["goff"])
+    print("rep %d spec %d: %.3f s  (%.1f M reads/min)  kernel ms %s  groups %d (max size %d, >10 reads: %d)  v1 fallback %d" % (
+        rep, spec, dt, (off.size - 1) / dt * 60 / 1e6, {k: round(v, 1) for k, v in r["kernel_ms"].items()}, sizes.size,
+        sizes.max(), int((sizes > 10).sum()), int(r["counts"]["msa_v1_fallback"])), flush=True)
