@@ -188,7 +188,7 @@ __global__ void k_m2_init(M2Args A, const int* member_group, int nmembers) {
 // agree on 1-3 columns).  Loads are issued in independent batches: the positions r_c of every third sequence
 // first (LDS), then up to M2_BATCH (c, b) pairs at a time -- the dependent chain map -> map -> col of one
 // candidate is three memory latencies long, so the pairs of a batch are looked up side by side.
-constexpr int M2_BATCH = 16;
+constexpr int M2_BATCH = 4;
 
 template <bool UNITW>
 __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
