@@ -374,17 +374,18 @@ __device__ __forceinline__ unsigned long long m2_rowmax16(unsigned long long v) 
 // Node value = (f << 32) | ~id, so that the maximum prefers the larger f and then the earlier match
 // (id = row * M2_CAP + index in the row + 1; 0 = no match).  All matches of a row are looked up before any of
 // them is entered.
-// Prefix maxima over the second child's columns are kept for the M2_PWIN = 512 columns behind the front in a
-// three-level structure with POINT updates: L0 one value per column, L1 per block of 8 columns, L2 per superblock
-// of 64; everything older than the 8 superblocks ending at the front's is folded into one scalar.  A match with
-// column j reads the columns of its block below j, the blocks of its superblock below its block and the
-// superblocks of the window below its own -- at most 21 values, one round of LDS reads for the sixteen entries
-// of a row -- and entering it is three maxima.  (A step function raised over the columns from j upwards, which
-// this replaces, degenerates when the front runs ahead of the heavy matches: clusters of two molecules.)  The 16
-// lanes of a group serve the 16 entries of one row.  When a match lies in a superblock that has left the window
-// (more than 448-511 columns behind the largest column seen up to and including its row), the window cannot answer:
-// the group's round is flagged (redo) and done by k_m2_chain_exact, which keeps the prefix maxima of ALL columns
-// in a Fenwick tree.
+// Prefix maxima over the second child's columns are kept for the M2_PWIN = 512 columns behind the front in three
+// levels of PREFIX arrays: L0[c] = best over the columns of c's block of 8 up to c, L1[b] = best over the blocks of
+// b's superblock (64 columns) up to b, L2[s] = best over everything up to superblock s (a new superblock starts
+// with its predecessor's value); what lies behind the 8 superblocks ending at the front's is one scalar.  A match
+// with column j reads THREE values -- L0[j - 1], L1[block - 1], L2[superblock - 1], where they exist -- and
+// entering it raises the at most 8 + 8 + 8 entries from its column, block and superblock to the end of their
+// block, superblock and the front (LDS maxima without return).  (A step function over single columns raised from
+// j up to the front, which this replaces, degenerates when the front runs ahead of the heavy matches: clusters of
+// two molecules.)  The 16 lanes of a group serve the 16 entries of one row.  When a match lies in a superblock that
+// has left the window (448-511 columns behind the largest column seen up to and including its row), the window
+// cannot answer: the group's round is flagged (redo) and done by k_m2_chain_exact, which keeps the prefix maxima
+// of ALL columns in a Fenwick tree.
 constexpr int M2_PWIN = 512;
 constexpr int M2_L1 = M2_PWIN, M2_L2 = M2_PWIN + M2_PWIN / 8, M2_PSIZE = M2_PWIN + M2_PWIN / 8 + M2_PWIN / 64;
 
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nact
     unsigned* const prd = A.row_pred + G.row_base * static_cast<long long>(M2_CAP);
     for (int i = t; i < nA; i += 16) A.part[G.row_base + i] = -1;
     int top = -1;
-    unsigned long long ptop = 0;
+    unsigned long long lbest = 0;    // best node entered by this lane (the chain's last match is the overall maximum)
     bool bad = false;
     const int nAmax = max(max(__shfl(nA, 0), __shfl(nA, 16)), max(__shfl(nA, 32), __shfl(nA, 48)));
     // rows in blocks of 16: lane t holds entry t and the count of each of the block's rows (the counts are
@@ -448,47 +449,38 @@ __global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nact
             const bool mk0 = act && i < nA && t < cb[r];
             const unsigned long long e = eb[r];
             const int j = static_cast<int>(e >> 32);
-            // the window follows the largest column seen up to and including this row: superblocks leaving it are
-            // folded into pbelow and their slots cleared
+            // the window follows the largest column seen up to and including this row
             const int newtop = m2_qmax_i32(mk0 ? j : -1);
             const int T = max(top, newtop);
             top = T;
             if ((T >> 6) > sbT) {
+                // new superblocks start with the prefix of everything before them; the slots they take over held the
+                // superblocks 8 further back, whose prefix becomes the scalar for "behind the window"
+                const unsigned long long carried = P[M2_L2 + (sbT & 7)];
                 const int adv = min((T >> 6) - sbT, 8);
                 for (int q = 1; q <= adv; ++q) {
                     const int slot = ((T >> 6) - adv + q) & 7;
-                    const unsigned long long old = P[M2_L2 + slot];
-                    pbelow = old > pbelow ? old : pbelow;
-                    if (t == 0) P[M2_L2 + slot] = 0;
+                    pbelow = P[M2_L2 + slot];
+                    if (t == 0) P[M2_L2 + slot] = carried;
                     if (t < 8) P[M2_L1 + slot * 8 + t] = 0;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) P[slot * 64 + u * 16 + t] = 0;
                 }
+                if ((T >> 6) - sbT >= 8) pbelow = carried;
                 sbT = T >> 6;
             }
             if (mk0 && (j >> 6) < sbT - 7) bad = true;
             const bool mk = mk0 && !bad;
-            // query: best over the columns < j, state before the row (unconditional reads, masked afterwards)
-            unsigned long long v = pbelow;
-            {
-                const int jb = j >> 3, js = j >> 6;
-                unsigned long long rd[21];
-#pragma unroll
-                for (int d = 1; d <= 7; ++d) {
-                    rd[d - 1] = P[(j - d) & (M2_PWIN - 1)];
-                    rd[6 + d] = P[M2_L1 + ((jb - d) & 63)];
-                    rd[13 + d] = P[M2_L2 + ((js - d) & 7)];
-                }
-#pragma unroll
-                for (int d = 1; d <= 7; ++d) {
-                    const unsigned long long c0 = (j - d) >= (j & ~7) ? rd[d - 1] : 0ull;
-                    const unsigned long long c1 = (jb - d) >= (js << 3) ? rd[6 + d] : 0ull;
-                    const unsigned long long c2 = (js - d) >= max(sbT - 7, 0) ? rd[13 + d] : 0ull;
-                    const unsigned long long m01 = c0 > c1 ? c0 : c1;
-                    const unsigned long long m = m01 > c2 ? m01 : c2;
-                    v = m > v ? m : v;
-                }
-            }
+            // query: best over the columns < j, state before the row (unconditional reads, selected afterwards)
+            const int jb = j >> 3, js = j >> 6;
+            const unsigned long long r0 = P[(j - 1) & (M2_PWIN - 1)];
+            const unsigned long long r1 = P[M2_L1 + ((jb - 1) & 63)];
+            const unsigned long long r2 = P[M2_L2 + ((js - 1) & 7)];
+            const unsigned long long q0 = (j & 7) ? r0 : 0ull;
+            const unsigned long long q1 = (jb & 7) ? r1 : 0ull;
+            const unsigned long long q2 = (js >= 1 && js - 1 >= sbT - 7) ? r2 : pbelow;
+            const unsigned long long q01 = q0 > q1 ? q0 : q1;
+            unsigned long long v = q01 > q2 ? q01 : q2;
             if (!mk) v = 0;
             const unsigned f = static_cast<unsigned>(e) + static_cast<unsigned>(v >> 32);
             const unsigned pred = v ? ~static_cast<unsigned>(v) : 0u;
@@ -496,20 +488,26 @@ __global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nact
             const unsigned long long nv = mk ? ((static_cast<unsigned long long>(f) << 32) | static_cast<unsigned>(~id)) : 0ull;
             if (mk) prd[static_cast<long long>(i) * M2_CAP + t] = pred;
             // enter the matches (all queries of the row were issued before: LDS operations of a wave execute in order)
+            // One predicated block, no inner branches: positions past the end of the block are clamped onto its last
+            // entry (entered more than once, harmless for a maximum).  Only lanes with a match take part -- maxima on one
+            // LDS address serialise, and the stale entries of the other lanes would all name the same few slots.
             if (mk) {
-                atomicMax(&P[j & (M2_PWIN - 1)], nv);
-                atomicMax(&P[M2_L1 + ((j >> 3) & 63)], nv);
-                atomicMax(&P[M2_L2 + ((j >> 6) & 7)], nv);
+                const int c0 = (j & ~7) & (M2_PWIN - 1), b0 = (jb & ~7) & 63;
+                const int cj = j & 7, cb8 = jb & 7;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    atomicMax(&P[c0 + min(cj + d, 7)], nv);
+                    atomicMax(&P[M2_L1 + b0 + min(cb8 + d, 7)], nv);
+                }
+                for (int sb = js; sb <= sbT; ++sb) atomicMax(&P[M2_L2 + (sb & 7)], nv);
             }
-            // P[top] is the best over everything entered so far
-            const unsigned long long rowbest = m2_rowmax16(nv);
-            ptop = rowbest > ptop ? rowbest : ptop;
+            lbest = nv > lbest ? nv : lbest;
         }
         bad = m2_qmax_i32(bad ? 1 : 0) != 0;   // (a failed group keeps going on garbage until here; its round is redone)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { eb[r] = en[r]; cb[r] = cn[r]; }
     }
-    unsigned long long best = ptop;
+    unsigned long long best = m2_rowmax16(lbest);
     if (act && bad && t == 0) A.redo[g] = 1;
     if (bad) { nA = 0; best = 0; }
     if (!act) { nA = 0; best = 0; }
