@@ -117,9 +117,10 @@ def case_umi(rng):
 def case_consensus(rng):
     ngroups = int(rng.integers(1, 12))
     alns, quals = [], []
+    p_n = float(rng.choice([0.0, 0.0, 0.03]))          # without N the groups take the fast kernel (k_consensus_qf)
     for _ in range(ngroups):
-        nrows = int(rng.integers(0, 30))
-        W = int(rng.integers(0, 400))
+        nrows = int(rng.integers(0, int(rng.choice([30, 30, 80]))))   # beyond 64 rows: the generic kernel
+        W = int(rng.integers(0, int(rng.choice([400, 400, 1500]))))
         truth = rng.choice(list("ACGT"), W) if W else np.array([], dtype="<U1")
         rows, qs = [], []
         for _ in range(nrows):
@@ -127,7 +128,9 @@ def case_consensus(rng):
             if W:
                 sub = rng.random(W) < 0.1
                 r[sub] = rng.choice(list("ACGT"), int(sub.sum()))
-                r[rng.random(W) < 0.03] = "N"
+                r[rng.random(W) < p_n] = "N"
+                if rng.random() < 0.02:
+                    r[int(rng.integers(0, W))] = "acgtRY"[int(rng.integers(0, 6))]
                 r[rng.random(W) < rng.choice([0.05, 0.4])] = "-"
             row = "".join(r)
             rows.append(row)
@@ -161,11 +164,19 @@ def case_msa(rng):
         groups.append(idx)
     if not reads:
         reads = ["ACGT"]
+    if rng.random() < 0.15 and groups and groups[0]:     # a length outlier and a huge bandwidth: the band cap of the spec
+        k = groups[0][0] - 1
+        reads[k] = reads[k] + mutate(NUC[rng.integers(0, 4, int(rng.choice([300, 1100, 1500])))], rng, 0.0, 0.0).tobytes().decode()
     params = [(0, -1, -5, -1), (0, -1, -1, -5), (1, -2, -2, -2), (2, -3, -1, -4), (0, -1, -1, -1)][int(rng.integers(0, 5))]
-    bw = int(rng.choice([0, 3, 20, 100, 180]))
-    g, o, err = both(lambda: calls.quick_msa(groups, reads, *params, bw), lambda: O.quick_msa(groups, reads, *params, bw))
+    bw = int(rng.choice([0, 3, 20, 100, 180, 600, 5000]))
+    spec = int(rng.choice([1, 2, 2]))
+    calls.set_msa_spec(spec)
+    try:
+        g, o, err = both(lambda: calls.quick_msa(groups, reads, *params, bw), lambda: O.quick_msa(groups, reads, *params, bw, spec=spec))
+    finally:
+        calls.set_msa_spec(0)
     if not err:
-        assert g == o, "msa rows"
+        assert g == o, "msa rows (spec %d)" % spec
 
 
 def case_mask(rng):
@@ -284,6 +295,16 @@ def case_fastq(rng):
     dev = DeviceReads.from_fastq(text.encode())
     s_, q_ = dev.download()
     assert len(dev) == n and s_.to_strings() == seqs and q_.to_strings() == quals and dev.names == names, "fastq"
+    # the same file streamed in chunks of `number` records through blocks that end anywhere
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".fastq") as fh:
+        fh.write(text.encode()); fh.flush()
+        number, block = int(rng.integers(1, 40)), int(rng.choice([37, 512, 4096, 1 << 20]))
+        cs, cq, cn, sizes = [], [], [], []
+        for chunk in DeviceReads.stream_fastq(fh.name, number, block_bytes=block):
+            a, b = chunk.download()
+            cs += a.to_strings(); cq += b.to_strings(); cn += list(chunk.names); sizes.append(len(chunk))
+        assert cs == seqs and cq == quals and cn == names and all(x == number for x in sizes[:-1]) and (not sizes or 0 < sizes[-1] <= number), "fastq chunks"
 
 
 CASES = [case_align, case_align, case_umi, case_consensus, case_msa, case_mask, case_unmask, case_fused, case_fastq]
