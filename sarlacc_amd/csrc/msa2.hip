@@ -1000,7 +1000,7 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
         int nactive = 0;
         while (nactive < static_cast<int>(ng) && B.groups[nactive].n - 1 > round) ++nactive;
         if (nactive == 0) break;
-        const dim3 ggrid(std::min(16u, m2_blocks(B.max_wcap, 64)), static_cast<unsigned>(nactive));
+        const dim3 ggrid(std::min(128u, m2_blocks(B.max_wcap, 64)), static_cast<unsigned>(nactive));
         if (unitw) hipLaunchKernelGGL(k_m2_gather<true>, ggrid, dim3(64), 0, s, a, round);
         else hipLaunchKernelGGL(k_m2_gather<false>, ggrid, dim3(64), 0, s, a, round);
         hipLaunchKernelGGL(k_m2_chain_q, dim3(m2_blocks(nactive, 4)), dim3(64), 0, s, a, round, nactive);
