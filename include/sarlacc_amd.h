@@ -169,6 +169,28 @@ int sarlacc_dev_scramble(const uint8_t* d_seq, const uint8_t* d_qual, const int6
 int sarlacc_unmask_alignment(const char* aln, const int64_t* aln_off, int64_t naln,
                              const char* orig, const int64_t* orig_off, int64_t norig, char* out);
 
+/* ---- alignment profiling: variable-length results, two-call protocol -- *count / *nins always
+ * receive the full number of entries; the arrays are filled only when their capacity suffices. ---- */
+
+/* replaces .Call find_homopolymers  (src/homopolymer.cpp:87-134): runs of two or more equal bases of every (possibly
+ * gapped) sequence: idx (0-based sequence), pos (1-based start in the ungapped sequence), size, base. */
+int sarlacc_find_homopolymers(const char* seq, const int64_t* off, int64_t n, int32_t* idx, int32_t* pos, int32_t* size,
+                              char* base, int64_t cap, int64_t* count);
+
+/* replaces .Call match_homopolymers  (src/homopolymer.cpp:141-209): per alignment and homopolymer of the reference string
+ * the longest run of the same base in the read string that overlaps it: idx (0-based alignment), pos (as above), rlen. */
+int sarlacc_match_homopolymers(const char* ref, const int64_t* ref_off, int64_t nref, const char* read, const int64_t* read_off,
+                               int64_t nread, int32_t* idx, int32_t* pos, int32_t* rlen, int64_t cap, int64_t* count);
+
+/* replaces .Call find_errors  (src/find_errors.cpp:9-121): per base of the (first alignment's) reference the number of
+ * alignments whose read shows A, C, G, T or a deletion there, and one (position of the next reference base, 0-based;
+ * length) entry per insertion.  *standard_len = bases of the reference; with cap_bases below it (or the count arrays
+ * NULL) nothing else is computed. */
+int sarlacc_find_errors(const char* ref, const int64_t* ref_off, int64_t nref, const char* read, const int64_t* read_off,
+                        int64_t nread, int64_t* standard_len, char* bases, int32_t* to_a, int32_t* to_c, int32_t* to_g,
+                        int32_t* to_t, int32_t* deletions, int64_t cap_bases, int32_t* ins_pos, int32_t* ins_len,
+                        int64_t cap_ins, int64_t* nins);
+
 /* FASTQ text already in device memory -> resident read batch.  Replaces the
  * host-side ShortRead::FastqStreamer + .FASTQ2QSDS conversion (R/adaptorAlign.R:26-37,:104-110;
  * R/realizeReads.R:15-26).  4-line records, LF or CRLF, trailing blank lines ignored; sequences

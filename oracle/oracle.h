@@ -83,6 +83,18 @@ int orc_mask_bad_bases(const char* seq, const int64_t* seq_off,
 int orc_unmask_alignment(const char* aln, const int64_t* aln_off, int64_t naln, const char* orig,
                          const int64_t* orig_off, int64_t norig, char* out);
 
+/* ---- alignment profiling (reference src/homopolymer.cpp, src/find_errors.cpp) ----
+ * Variable-length outputs: two-call protocol, *count is always the full number of entries. */
+int orc_find_homopolymers(const char* seq, const int64_t* off, int64_t n, int32_t* idx, int32_t* pos, int32_t* size,
+                          char* base, int64_t cap, int64_t* count);
+int orc_match_homopolymers(const char* ref, const int64_t* ref_off, int64_t nref, const char* read, const int64_t* read_off,
+                           int64_t nread, int32_t* idx, int32_t* pos, int32_t* rlen, int64_t cap, int64_t* count);
+/* returns 2 when cap_bases is smaller than *standard_len (nothing else filled) */
+int orc_find_errors(const char* ref, const int64_t* ref_off, int64_t nref, const char* read, const int64_t* read_off,
+                    int64_t nread, int64_t* standard_len, char* bases, int32_t* to_a, int32_t* to_c, int32_t* to_g,
+                    int32_t* to_t, int32_t* deletions, int64_t cap_bases, int32_t* ins_pos, int32_t* ins_len, int64_t cap_ins,
+                    int64_t* nins);
+
 /* per-read shuffle of the scrambled-control callers (our generator, see align.c) */
 int orc_scramble(const char* seq, const char* qual, const int64_t* off, int64_t n, uint64_t seed,
                  char* oseq, char* oqual);

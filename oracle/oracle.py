@@ -350,3 +350,61 @@ def quick_msa(groupings, sequences, match, mismatch, gap_extension, gap_opening,
         W = width.value
         out.append([buf[r * W:(r + 1) * W].tobytes().decode() for r in range(m)])
     return out
+
+
+# ---- alignment profiling (src/homopolymer.cpp, src/find_errors.cpp) ----
+def find_homopolymers(seqs):
+    """-> [index (0-based), position (1-based), size, base] as the reference's .Call returns them."""
+    sb, so = pack(seqs)
+    n = len(so) - 1
+    cnt = C.c_int64(0)
+    cap = 16
+    while True:
+        idx, pos, size = (np.zeros(cap, np.int32) for _ in range(3))
+        base = np.zeros(cap, np.uint8)
+        _check(lib().orc_find_homopolymers(_p(sb), _p(so), C.c_int64(n), _p(idx), _p(pos), _p(size), _p(base), C.c_int64(cap), C.byref(cnt)))
+        if cnt.value <= cap:
+            break
+        cap = cnt.value
+    k = cnt.value
+    return [idx[:k], pos[:k], size[:k], [chr(c) for c in base[:k]]]
+
+
+def match_homopolymers(refs, reads):
+    rb, ro = pack(refs)
+    qb, qo = pack(reads)
+    cnt = C.c_int64(0)
+    cap = 16
+    while True:
+        idx, pos, rlen = (np.zeros(cap, np.int32) for _ in range(3))
+        _check(lib().orc_match_homopolymers(_p(rb), _p(ro), C.c_int64(len(ro) - 1), _p(qb), _p(qo), C.c_int64(len(qo) - 1),
+                                            _p(idx), _p(pos), _p(rlen), C.c_int64(cap), C.byref(cnt)))
+        if cnt.value <= cap:
+            break
+        cap = cnt.value
+    k = cnt.value
+    return [idx[:k], pos[:k], rlen[:k]]
+
+
+def find_errors(refs, reads):
+    """-> [bases, to A, to C, to G, to T, deletions, insertion positions (0-based), insertion lengths]"""
+    rb, ro = pack(refs)
+    qb, qo = pack(reads)
+    cap_b = int(ro[1] - ro[0]) if len(ro) > 1 else 0
+    cap_i = 16
+    sl, ni = C.c_int64(0), C.c_int64(0)
+    while True:
+        bases = np.zeros(max(cap_b, 1), np.uint8)
+        cols = [np.zeros(max(cap_b, 1), np.int32) for _ in range(5)]
+        ip, il = np.zeros(cap_i, np.int32), np.zeros(cap_i, np.int32)
+        rc = lib().orc_find_errors(_p(rb), _p(ro), C.c_int64(len(ro) - 1), _p(qb), _p(qo), C.c_int64(len(qo) - 1), C.byref(sl), _p(bases),
+                                   *[_p(c) for c in cols], C.c_int64(cap_b), _p(ip), _p(il), C.c_int64(cap_i), C.byref(ni))
+        if rc == 2:
+            cap_b = sl.value
+            continue
+        _check(rc)
+        if ni.value <= cap_i:
+            break
+        cap_i = ni.value
+    n = sl.value
+    return ["".join(chr(c) for c in bases[:n])] + [c[:n] for c in cols] + [ip[:ni.value], il[:ni.value]]

@@ -498,3 +498,62 @@ def umi_group_from_pairs(umi, limit, pairs, flat=False):
     if flat:
         return co[:ncl.value + 1], cl[:int(co[ncl.value])]
     return lists_from_csr(co, cl, ncl.value)
+
+
+# ---------------------------------------------------------------------------
+# alignment profiling (SURVEY 8 f4)
+def find_homopolymers(sequences):
+    """.Call find_homopolymers (src/homopolymer.cpp:87-134): [index (0-based), position (1-based, ungapped),
+    size, base] of every run of two or more equal bases."""
+    s = StringSet.from_strings(sequences)
+    n = len(s)
+    cnt = C.c_int64(0)
+    cap = max(64, s.total // 8)
+    while True:
+        idx, pos, size = (np.zeros(cap, np.int32) for _ in range(3))
+        base = np.zeros(cap, np.uint8)
+        check(_lib.lib().sarlacc_find_homopolymers(ptr(s.chars), ptr(s.off), C.c_int64(n), ptr(idx), ptr(pos), ptr(size), ptr(base),
+                                                   C.c_int64(cap), C.byref(cnt)))
+        if cnt.value <= cap:
+            break
+        cap = cnt.value
+    k = cnt.value
+    return [idx[:k], pos[:k], size[:k], [chr(c) for c in base[:k]]]
+
+
+def match_homopolymers(ref_align, read_align):
+    """.Call match_homopolymers (src/homopolymer.cpp:141-209): [alignment (0-based), position of the reference
+    homopolymer, longest overlapping run of the same base in the read]."""
+    r, q = StringSet.from_strings(ref_align), StringSet.from_strings(read_align)
+    cnt = C.c_int64(0)
+    cap = max(64, r.total // 8)
+    while True:
+        idx, pos, rlen = (np.zeros(cap, np.int32) for _ in range(3))
+        check(_lib.lib().sarlacc_match_homopolymers(ptr(r.chars), ptr(r.off), C.c_int64(len(r)), ptr(q.chars), ptr(q.off), C.c_int64(len(q)),
+                                                    ptr(idx), ptr(pos), ptr(rlen), C.c_int64(cap), C.byref(cnt)))
+        if cnt.value <= cap:
+            break
+        cap = cnt.value
+    k = cnt.value
+    return [idx[:k], pos[:k], rlen[:k]]
+
+
+def find_errors(ref_align, read_align):
+    """.Call find_errors (src/find_errors.cpp:9-121): [bases, to A, to C, to G, to T, deletions, insertion
+    positions (0-based, position of the next reference base), insertion lengths]."""
+    r, q = StringSet.from_strings(ref_align), StringSet.from_strings(read_align)
+    cap_b = int(r.off[1] - r.off[0]) if len(r) else 0
+    cap_i = max(64, r.total // 16)
+    sl, ni = C.c_int64(0), C.c_int64(0)
+    while True:
+        bases = np.zeros(max(cap_b, 1), np.uint8)
+        cols = [np.zeros(max(cap_b, 1), np.int32) for _ in range(5)]
+        ip, il = np.zeros(cap_i, np.int32), np.zeros(cap_i, np.int32)
+        check(_lib.lib().sarlacc_find_errors(ptr(r.chars), ptr(r.off), C.c_int64(len(r)), ptr(q.chars), ptr(q.off), C.c_int64(len(q)),
+                                             C.byref(sl), ptr(bases), *[ptr(c) for c in cols], C.c_int64(cap_b), ptr(ip), ptr(il),
+                                             C.c_int64(cap_i), C.byref(ni)))
+        if ni.value <= cap_i:
+            break
+        cap_i = ni.value
+    n = sl.value
+    return ["".join(chr(c) for c in bases[:n])] + [c[:n] for c in cols] + [ip[:ni.value], il[:ni.value]]

@@ -570,3 +570,52 @@ def extractSubseq(aligned, reads, subseq1=None, subseq2=None):
             raise RuntimeError("score mismatch from 'aligned' for adaptor %s" % key[-1])
         out[key] = res["subseq"]
     return out
+
+
+# ---------------------------------------------------------------------------
+# alignment profiling (R/homopolymerFinder.R, R/homopolymerMatcher.R, R/errorFinder.R).  Pairwise alignments are given
+# as the two gapped string sets the R code takes out of a PairwiseAlignmentsSingleSubject object:
+# alignedSubject (reference) and alignedPattern (reads); ranges are (start, end) pairs, 1-based inclusive.
+def homopolymerFinder(seq):
+    """homopolymerFinder (R/homopolymerFinder.R:6-22): per sequence the list of (start, end, base)."""
+    s = StringSet.from_strings(seq)
+    idx, pos, size, base = calls.find_homopolymers(s)
+    out = [[] for _ in range(len(s))]
+    for i, p, w, b in zip(idx.tolist(), pos.tolist(), size.tolist(), base):
+        out[i].append((p, p + w - 1, b))
+    return out
+
+
+def homopolymerMatcher(ref_aligned, read_aligned):
+    """homopolymerMatcher (R/homopolymerMatcher.R:9-36): the homopolymers of the (single) reference and, for each,
+    the sorted observed lengths over the alignments."""
+    ref, reads = StringSet.from_strings(ref_aligned), StringSet.from_strings(read_aligned)
+    if len(ref) == 0 or len({x.replace("-", "") for x in ref.to_strings()}) != 1:
+        raise ValueError("alignments should be global and involve a single subject")
+    _, positions, obs = calls.match_homopolymers(ref, reads)
+    runs = homopolymerFinder(ref.slice(0, 1))[0]
+    start_of = {r[0]: k for k, r in enumerate(runs)}
+    by_pos = [[] for _ in runs]
+    for p, l in zip(positions.tolist(), obs.tolist()):
+        by_pos[start_of[p]].append(l)
+    return [{"start": a, "end": b, "base": c, "observed": sorted(v)} for (a, b, c), v in zip(runs, by_pos)]
+
+
+def errorFinder(ref_aligned, read_aligned):
+    """errorFinder (R/errorFinder.R:9-49): per reference position (plus one past the end) the counts of A, C, G, T and
+    deletions and the sorted insertion lengths (0 for alignments without one there); and the 4 x 4 transition matrix."""
+    ref, reads = StringSet.from_strings(ref_aligned), StringSet.from_strings(read_aligned)
+    if len(ref) == 0 or len({x.replace("-", "") for x in ref.to_strings()}) != 1:
+        raise ValueError("alignments should be global and involve a single subject")
+    bases, a, c, g, t, d, ipos, ilen = calls.find_errors(ref, reads)
+    n = len(bases)
+    ins = [[] for _ in range(n + 1)]
+    for p, l in zip(ipos.tolist(), ilen.tolist()):
+        ins[p].append(l)
+    full = {"base": list(bases) + [None], "A": a.tolist() + [None], "C": c.tolist() + [None], "G": g.tolist() + [None],
+            "T": t.tolist() + [None], "deletion": d.tolist() + [None],
+            "insertion": [sorted([0] * (len(ref) - len(v)) + v) for v in ins]}
+    cols = {"A": a, "C": c, "G": g, "T": t}
+    barr = np.frombuffer(bases.encode(), dtype=np.uint8) if n else np.zeros(0, np.uint8)
+    transition = np.array([[int(cols[y][barr == ord(x)].sum()) for y in "ACGT"] for x in "ACGT"], dtype=np.int64)
+    return {"full": full, "transition": transition}

@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GLUE = os.path.join(ROOT, "r-glue", "src")
 
-# routine -> number of SEXP arguments (init.cpp:9-35); the three profiling helpers stay in the reference's C++
+# routine -> number of SEXP arguments (init.cpp:9-35): all 18 registered routines
 ROUTINES = {
     "adaptor_align": 8, "adaptor_align_score_only": 6, "barcode_align": 6, "general_align": 7,
     "mask_bad_bases": 4, "unmask_alignment": 2,
@@ -18,6 +18,7 @@ ROUTINES = {
     "create_consensus_quality": 4, "create_consensus_quality_loop": 4,
     "umi_group": 5, "fast_levdist_test": 3, "cluster_umis_test": 1, "compute_lev_masked": 1,
     "quick_msa": 7,
+    "find_homopolymers": 1, "match_homopolymers": 2, "find_errors": 2,
 }
 
 
@@ -93,7 +94,8 @@ def test_every_abi_call_matches_the_header():
     expect = {"sarlacc_adaptor_align", "sarlacc_adaptor_align_score_only", "sarlacc_barcode_align", "sarlacc_general_align",
               "sarlacc_mask_bad_bases", "sarlacc_unmask_alignment", "sarlacc_umi_group", "sarlacc_fast_levdist_test",
               "sarlacc_cluster_umis_test", "sarlacc_compute_lev_masked", "sarlacc_quick_msa",
-              "sarlacc_create_consensus_basic_loop", "sarlacc_create_consensus_quality_loop", "sarlacc_last_error"}
+              "sarlacc_create_consensus_basic_loop", "sarlacc_create_consensus_quality_loop", "sarlacc_last_error",
+              "sarlacc_find_homopolymers", "sarlacc_match_homopolymers", "sarlacc_find_errors"}
     assert expect <= used
 
 
