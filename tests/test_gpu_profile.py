@@ -98,8 +98,9 @@ def test_find_errors(oracle):
     # errors in the order the reference's loop meets them
     for rf, rd, msg in ((["ACGT"], ["ACG"], "equal length"), (["ACGT", "ACGTA"], ["ACGT", "ACGTA"], "same for all alignments"),
                         (["ACGT", "ACGT"], ["ACGT", "ACNT"], "unknown character 'N'"), (["ACGT"], [], "should match up"),
-                        (["ACGT", "ACGTAA", "AC"], ["ACGT", "ACGTNA", "A"], "unknown character 'N'"),
-                        (["ACGT", "AC", "ACGTAA"], ["ACGT", "A", "ACGTNA"], "equal length")):
+                        (["ACGT", "ACGT", "AC"], ["ACGT", "ANGT", "A"], "unknown character 'N'"),
+                        (["ACGT", "AC", "ACGT"], ["ACGT", "A", "ANGT"], "equal length"),
+                        (["ACGT", "ACGTAA"], ["ACGT", "ACGTNA"], "same for all alignments")):
         with pytest.raises(SarlaccError, match=msg):
             calls.find_errors(rf, rd)
         with pytest.raises(oracle.OracleError, match=msg):

@@ -307,7 +307,43 @@ def case_fastq(rng):
         assert cs == seqs and cq == quals and cn == names and all(x == number for x in sizes[:-1]) and (not sizes or 0 < sizes[-1] <= number), "fastq chunks"
 
 
-CASES = [case_align, case_align, case_umi, case_consensus, case_msa, case_mask, case_unmask, case_fused, case_fastq]
+def case_profile(rng):
+    """find_homopolymers / match_homopolymers / find_errors on random gapped pairwise alignments (occasionally
+    malformed: unequal lengths, a stray character, a reference that changes)."""
+    n = int(rng.integers(0, 40))
+    L = int(rng.choice([0, 1, 8, 60, 400]))
+    ref = rng.choice(list("AACGTT"), L) if L else np.array([], dtype="<U1")
+    refs, reads = [], []
+    for _ in range(n):
+        a, b = [], []
+        for c in ref:
+            u = rng.random()
+            if u < 0.05:
+                a.append(c); b.append("-")
+            elif u < 0.1:
+                k = int(rng.integers(1, 4)); a += ["-"] * k; b += list(rng.choice(list("ACGT"), k)); a.append(c); b.append(c)
+            else:
+                a.append(c); b.append(c if rng.random() > 0.1 else "ACGT"[int(rng.integers(0, 4))])
+        refs.append("".join(a)); reads.append("".join(b))
+    if n and rng.random() < 0.1:
+        k = int(rng.integers(0, n))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            reads[k] = reads[k] + "A"
+        elif kind == 1 and reads[k]:
+            reads[k] = "N" + reads[k][1:]
+        else:
+            refs[k] = refs[k] + "ACGT"; reads[k] = reads[k] + "ACGT"
+    same = lambda g, o: all((x if isinstance(x, (list, str)) else np.asarray(x).tolist()) == (y if isinstance(y, (list, str)) else np.asarray(y).tolist()) for x, y in zip(g, o))
+    g, o, err = both(lambda: calls.find_homopolymers(refs + reads), lambda: O.find_homopolymers(refs + reads))
+    assert err or same(g, o), "find_homopolymers"
+    g, o, err = both(lambda: calls.match_homopolymers(refs, reads), lambda: O.match_homopolymers(refs, reads))
+    assert err or same(g, o), "match_homopolymers"
+    g, o, err = both(lambda: calls.find_errors(refs, reads), lambda: O.find_errors(refs, reads))
+    assert err or same(g, o), "find_errors"
+
+
+CASES = [case_align, case_align, case_umi, case_consensus, case_msa, case_mask, case_unmask, case_fused, case_fastq, case_profile]
 
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
