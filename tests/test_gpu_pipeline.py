@@ -158,3 +158,37 @@ def test_two_rank_pipeline_driver_matches_single_rank():
     assert chk["clusters_identical"]
     assert out["consensus_reads"] == chk["consensus_reads"] and out["consensus_bases"] == chk["consensus_bases"]
     assert abs(out["score_checksum"] - chk["score_checksum"]) < 1e-6 * max(1.0, abs(chk["score_checksum"]))
+
+
+def test_bench_two_ranks_prints_the_contract_line():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process; here both ranks
+    share the one GPU and the collective runs over gloo): one JSON line from rank 0 with the whole-job value, the
+    pipeline pass with its label all-gather, and every rank seen."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SARLACC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--reads", "20000", "--read-len", "500", "--molecules", "1500", "--copies", "6", "--no-cpu", "--no-host-pointer"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [x for x in res.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["reads_per_gpu"] == 20000 and "workload" in out["config"]
+    p = out["pipeline"]
+    assert p["reads"] == 2 * 1500 * 6 and p["n_ranks_seen"] == 2
+    assert p["all_gather"]["backend"] == "gloo" and p["all_gather"]["bytes_received_total"] == 2 * 2 * 4 * 1500 * 6
+    assert p["consensus_reads"] > 0 and p["reads_per_min"] > 0 and set(p["rooflines"]) == {"k_msa_pairwise_pk", "k_consensus_qf"}
