@@ -190,6 +190,12 @@ __global__ void k_m2_init(M2Args A, const int* member_group, int nmembers) {
 // candidate is three memory latencies long, so the pairs of a batch are looked up side by side.
 constexpr int M2_BATCH = 4;
 
+__device__ __forceinline__ long long m2_uniform64(long long v) {   // a wave-uniform 64-bit value into scalar registers
+    const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+    const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32)));
+    return static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
 template <bool UNITW>
 __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
     __shared__ uint16_t s_r[M2_MAXN][64];   // position of the lane's base in every other member (0xFFFF: gap)
@@ -283,30 +289,46 @@ __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
             unsigned qq[M2_BATCH];
             int jj[M2_BATCH], ww[M2_BATCH], bq[M2_BATCH];
             bool ok[M2_BATCH];
+            // phase 1: the M2_BATCH map lookups are requested back to back -- nothing between them uses a loaded value,
+            // so the compiler does not wait for one before it issues the next (uses in the same loop body would)
+            unsigned rr[M2_BATCH], mm[M2_BATCH], rix[M2_BATCH];
+            int cuq[M2_BATCH], flg[M2_BATCH];   // flg: bit 0 candidate exists, bit 1 direct edge (c = b), bit 2 counted (direct or b != c)
 #pragma unroll
             for (int u = 0; u < M2_BATCH; ++u) {
                 const bool in = f0 + u < total;
-                const int b = s_b[bi];
+                // the candidate's members are the same for every lane: their descriptors are moved to scalar registers
+                // so that the address arithmetic runs on the scalar unit (values read from LDS arrive in VGPRs)
+                const int b = __builtin_amdgcn_readfirstlane(s_b[bi]);
                 const int cu = ci == 0 ? b : ((ci - 1) + ((ci - 1) >= a ? 1 : 0));
                 const unsigned r = s_r[cu][lane];
                 const int bslot = cu == b ? 0 : (b < cu ? b : b - 1);
-                const unsigned ridx = min(r != M2_NONE ? r : 0u, static_cast<unsigned>(max(s_len[cu] - 1, 0)));
-                const unsigned m = A.map[s_mapbase[cu] + static_cast<long long>(bslot) * s_len[cu] + ridx];
-                qq[u] = cu == b ? r : m;
-                ok[u] = in && (ci == 0 || b != cu) && r != M2_NONE && qq[u] != M2_NONE;
-                bq[u] = b;
-                ww[u] = 1;
-                if (!UNITW) {
-                    const int xc = dna5_code(A.seq[s_seqoff[cu] + ridx]);
-                    ww[u] = (xc << 16) | ((cu == b ? 1 : 0) << 15) | m2_w0(xa, xc, A.ma, A.mm);   // (finished below)
-                }
-                if (in) { if (++bi == nbm) { bi = 0; ++ci; } }
+                const int lencu = __builtin_amdgcn_readfirstlane(s_len[cu]);
+                const long long mbase = m2_uniform64(s_mapbase[cu]) + static_cast<long long>(bslot) * lencu;
+                const unsigned ridx = min(r != M2_NONE ? r : 0u, static_cast<unsigned>(max(lencu - 1, 0)));
+                mm[u] = A.map[mbase + ridx];
+                rr[u] = r; rix[u] = ridx; cuq[u] = cu; bq[u] = b;
+                flg[u] = (in ? 1 : 0) | (cu == b ? 2 : 0) | ((ci == 0 || b != cu) ? 4 : 0);
+                bi = in ? bi + 1 : bi;
+                const bool wrap = bi == nbm;
+                bi = wrap ? 0 : bi;
+                ci = wrap ? ci + 1 : ci;
             }
 #pragma unroll
             for (int u = 0; u < M2_BATCH; ++u) {
-                const int b = bq[u];
-                const unsigned qidx = min(ok[u] ? qq[u] : 0u, static_cast<unsigned>(max(s_len[b] - 1, 0)));
-                jj[u] = A.col[s_colbase[b] + qidx];
+                qq[u] = (flg[u] & 2) ? rr[u] : mm[u];
+                ok[u] = (flg[u] & 1) && (flg[u] & 4) && rr[u] != M2_NONE && qq[u] != M2_NONE;
+                ww[u] = 1;
+                if (!UNITW) {
+                    const int xc = dna5_code(A.seq[s_seqoff[cuq[u]] + rix[u]]);
+                    ww[u] = (xc << 16) | (((flg[u] & 2) ? 1 : 0) << 15) | m2_w0(xa, xc, A.ma, A.mm);   // (finished below)
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < M2_BATCH; ++u) {
+                const int b = __builtin_amdgcn_readfirstlane(bq[u]);
+                const int lenb = __builtin_amdgcn_readfirstlane(s_len[b]);
+                const unsigned qidx = min(ok[u] ? qq[u] : 0u, static_cast<unsigned>(max(lenb - 1, 0)));
+                jj[u] = A.col[m2_uniform64(s_colbase[b]) + qidx];
                 if (!UNITW) {
                     const int xc = ww[u] >> 16, wac = ww[u] & 0x7fff;
                     const bool direct = (ww[u] >> 15) & 1;
