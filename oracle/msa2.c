@@ -226,7 +226,6 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
         prof[a].ncols = LEN(&L, a);
         for (int64_t p = 0; p < LEN(&L, a); ++p) col[L.off[a] + p] = p;
     }
-    int incoherent = 0;
     for (int64_t k = 0; k + 1 < n && !rc; ++k) {
         prof_t* A = &prof[joins[2 * k]];
         prof_t* B = &prof[joins[2 * k + 1]];
@@ -377,12 +376,6 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
             for (int64_t q = 0; q < LEN(&L, b); ++q) col[L.off[b] + q] = ncB[col[L.off[b] + q]];
         }
         free(posA); free(mi); free(mj); free(mw); free(f); free(pred); free(bestAt); free(pa); free(ncA); free(ncB);
-    }
-    if (!rc && incoherent) {
-        for (int64_t x = 0; x < 2 * n - 1; ++x) free(prof[x].mem);
-        free(prof); free(col); free(joins);
-        lib_free(&L);
-        return orc_msa_group(seq, off, n, ma, mm, go, ge, bw, out, cap, width);
     }
     if (!rc) {
         const int64_t Wd = prof[2 * n - 2].ncols;
