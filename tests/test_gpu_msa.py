@@ -212,3 +212,39 @@ def test_msa_band_cap_degrades_the_pair_not_the_batch(oracle, spec):
     # the ordinary group does not depend on what else is in the call
     alone = calls.quick_msa([groups[0]], reads, 0, -1, -5, -1, 100)
     assert alone[0] == calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)[0]
+
+
+@pytest.mark.parametrize("seed,nmol,per,length", [(41, 2, 9, 500), (42, 3, 8, 400), (43, 2, 15, 900), (44, 4, 7, 250)])
+def test_msa_spec2_umi_collisions(oracle, seed, nmol, per, length):
+    """Clusters of several unrelated molecules (UMI collisions: a quarter of the clusters at 10^5 molecules): their
+    library is mostly noise, matches scatter far behind the front of the chain (the windowed chain kernel hands such
+    rounds to the exact one) and profiles outgrow the first-pass capacity (second pass with exact capacity) -- rows
+    must still be those of the CPU statement, in one call with ordinary clusters around them."""
+    from sarlacc_amd import calls
+    from sarlacc_amd.mock import NUC, mutate
+    calls.set_msa_spec(2)
+    try:
+        rng = np.random.default_rng(seed)
+        reads, groups = [], []
+        for _ in range(3):
+            truths = [NUC[rng.integers(0, 4, int(length * rng.uniform(0.8, 1.2)))] for _ in range(nmol)]
+            idx = []
+            order = rng.permutation(nmol * per)
+            for o in order:
+                reads.append(mutate(truths[o % nmol], rng, 0.05, 0.01).tobytes().decode())
+                idx.append(len(reads))
+            groups.append(idx[:32])
+            plain = NUC[rng.integers(0, 4, length)]
+            idx2 = []
+            for _ in range(6):
+                reads.append(mutate(plain, rng, 0.05, 0.01).tobytes().decode())
+                idx2.append(len(reads))
+            groups.append(idx2)
+        want = oracle.quick_msa(groups, reads, 0, -1, -5, -1, 100, spec=2)
+        got = calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)
+        for g, (a, b) in enumerate(zip(got, want)):
+            assert a == b, "group %d differs" % g
+        for rows, g in zip(got, groups):
+            assert [r.replace("-", "") for r in rows] == [reads[i - 1] for i in g]
+    finally:
+        calls.set_msa_spec(0)

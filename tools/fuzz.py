@@ -164,6 +164,9 @@ def case_msa(rng):
         groups.append(idx)
     if not reads:
         reads = ["ACGT"]
+    if rng.random() < 0.2 and len(groups) >= 2 and groups[0] and groups[1]:   # a UMI collision: two molecules in one cluster
+        groups[0] = groups[0] + groups[1]
+        groups[1] = []
     if rng.random() < 0.15 and groups and groups[0]:     # a length outlier and a huge bandwidth: the band cap of the spec
         k = groups[0][0] - 1
         reads[k] = reads[k] + mutate(NUC[rng.integers(0, 4, int(rng.choice([300, 1100, 1500])))], rng, 0.0, 0.0).tobytes().decode()
