@@ -84,11 +84,24 @@ int scratch(const char* name, size_t count, T** dev) {
 }
 
 // ---- MSA stage with the rows left on the device (msa.hip) ---------------------
+// Rows as vote codes (fused MSA + quality consensus): the row writers know the read position of every cell, so they
+// can emit, instead of the character, the 16-bit code the vote kernel needs -- the index of the (quality, base)
+// entry in its LDS table, bit 15 for a gap (consensus.hip: k_consensus_code).  The qualities must be laid out like
+// the reads (same relative offsets).
+struct CodeSpec {
+    bool want = false;
+    const uint8_t* const* qual = nullptr;   // *qual: the qualities in HBM, valid once `ready` has fired
+    hipEvent_t ready = nullptr;             // null: already there
+    int qoffset = 0, navail = 0;
+    int* d_bad = nullptr;                   // device: smallest flat row with a quality below the encoding (INT_MAX: none)
+};
 struct MsaResult {
     std::vector<int32_t> width;     // per group (caller sizes it: ngroups)
     std::vector<int64_t> out_off;   // per group start of its rows in d_out (caller sizes it: ngroups + 1)
     uint8_t* d_out = nullptr;       // gapped rows, group after group, equal width inside a group
     int32_t* d_members = nullptr;   // flattened 1-based read ids, one per row
+    CodeSpec code;                  // in: code rows wanted instead of characters
+    uint16_t* d_codes = nullptr;    // out: the rows as codes (offsets as for d_out, in cells)
 };
 // d_seq_resident (optional): the concatenated reads already in HBM (byte 0 = seq_off[0]); `seq` is then
 // not read and nothing is uploaded but the offsets.

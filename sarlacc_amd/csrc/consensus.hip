@@ -18,7 +18,7 @@
 //
 // This is the one streaming, HBM-bound stage of the path: 2 B in per alignment
 // cell (gapped base + quality), 2 B out per kept column.
-#include "common.hpp"
+#include "msa_common.hpp"
 
 #include "../../include/sarlacc_amd.h"
 
@@ -59,6 +59,10 @@ struct ConsArgs {
     int* gflag;                // per group: 1 = the fast kernel met something it does not handle; the generic kernel redoes the group
     int only_flagged;          // k_consensus_q4: skip groups whose flag is 0
     long long aln_bytes, qual_bytes;   // sizes of the two buffers (the fast kernel reads whole dwords)
+    // k_consensus_code: the rows as 16-bit vote codes written by the MSA stage (CodeSpec, common.hpp)
+    const uint16_t* codes;     // same offsets as aln, in cells
+    const double* strip8;      // [(navail + 1)][CODE_STRIP][QF_SLOTS]: (w w w r w w w w) per quality, zero row last
+    int* code_bad;             // smallest row with a quality below the encoding (INT_MAX: none)
 };
 
 __device__ __forceinline__ double dev_log1pexp(double x) {
@@ -710,6 +714,155 @@ __global__ void __launch_bounds__(QF_THREADS) k_consensus_qf(const ConsArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_consensus_code: the quality vote on rows the MSA stage wrote as 16-bit vote codes (fused multiReadAlign +
+// consensusReadSeq).  A code is the index of the cell's (quality, base) entry in the LDS table -- the row writers
+// know the read position of every cell, so the quality lookup, the gap / N / alphabet handling and the clamping
+// are theirs -- with bit 15 set for a gap.  What is left per cell: one address (code * 128 + the lane's slot), four
+// 8-byte LDS reads at immediate offsets, four additions in row order; per row and lane one 8-byte load of four
+// codes, independent of everything else, so the next batch of rows is always in flight.  Same sums in the same
+// order as the other kernels.
+constexpr int QC_RB = 5;
+constexpr int QC_ROWB = CODE_STRIP * QF_SLOTS * 8;   // 1024 bytes per quality value
+typedef unsigned long long __attribute__((aligned(1))) cons_u64_unaligned;
+
+__global__ void __launch_bounds__(QF_THREADS) k_consensus_code(const ConsArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(A.strip8);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        const int n16 = (A.navail + 1) * (QC_ROWB / 16);
+        for (int x = threadIdx.x; x < n16; x += QF_THREADS) dst[x] = src[x];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned char* const lanebase = smem + (lane & 15) * 8;
+    const unsigned gap1 = CODE_GAPBIT | code_zero_index(A.navail);
+    const unsigned long long GAP4 = gap1 * 0x0001000100010001ull;
+
+    for (long long g = static_cast<long long>(blockIdx.x) * (QF_THREADS / 64) + wave; g < A.ngroups;
+         g += static_cast<long long>(gridDim.x) * (QF_THREADS / 64)) {
+        const long long row0 = A.grp_rows[g];
+        const int nrows = static_cast<int>(A.grp_rows[g + 1] - row0);
+        if (nrows == 0) {
+            if (lane == 0) A.cons_len[g] = 0;
+            continue;
+        }
+        const long long cbase = A.aln_off[row0];
+        const long long W = A.aln_off[row0 + 1] - cbase;
+        const double thresh = static_cast<double>(nrows) * A.mincov;
+        const long long obase = A.out_off[g];
+        int outpos = 0;
+        const uint16_t* const rows = A.codes + cbase;
+
+        for (long long c0 = 0; c0 < W; c0 += 256) {
+            const int col = static_cast<int>(c0) + 4 * lane;
+            const int remain = static_cast<int>(W) - col;          // cells of the row at and after `col`
+            const unsigned long long keep = remain >= 4 ? ~0ull : (remain <= 0 ? 0ull : ((1ull << (16 * remain)) - 1ull));
+            double acc[4][4];
+            unsigned gaps01 = 0, gaps23 = 0;                        // packed 16-bit gap counts of the lane's four columns
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0;
+            // Loads are unconditional -- rows past the last one re-read it, lanes past the row end read its start, both
+            // masked afterwards -- so that the compiler can count them and wait only for the batch it is about to use.
+            const int lcol = remain > 0 ? col : 0;
+            unsigned long long wn[QC_RB];
+#pragma unroll
+            for (int b = 0; b < QC_RB; ++b) wn[b] = *reinterpret_cast<const cons_u64_unaligned*>(rows + static_cast<long long>(min(b, nrows - 1)) * W + lcol);
+            for (int r0 = 0; r0 < nrows; r0 += QC_RB) {
+                unsigned long long w[QC_RB];
+#pragma unroll
+                for (int b = 0; b < QC_RB; ++b) w[b] = (wn[b] & keep) | (GAP4 & ~keep);
+#pragma unroll
+                for (int b = 0; b < QC_RB; ++b)                 // the next batch (nothing depends on the data)
+                    wn[b] = *reinterpret_cast<const cons_u64_unaligned*>(rows + static_cast<long long>(min(r0 + QC_RB + b, nrows - 1)) * W + lcol);
+#pragma unroll
+                for (int b = 0; b < QC_RB; ++b) {
+                    if (r0 + b >= nrows) break;
+                    const unsigned lo = static_cast<unsigned>(w[b]), hi = static_cast<unsigned>(w[b] >> 32);
+                    gaps01 += (lo >> 15) & 0x00010001u;
+                    gaps23 += (hi >> 15) & 0x00010001u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned h = ((k < 2 ? lo : hi) >> (16 * (k & 1))) & 0x7fffu;
+                        // four single 8-byte reads (2 LDS cycles each); merged into two ds_read2_b64 they take 8 cycles each
+                        // (MI355X_MICROARCH.md, LDS table) -- volatile keeps the compiler from pairing them
+                        typedef const volatile double __attribute__((address_space(3))) lds_cvd;
+                        lds_cvd* cell = reinterpret_cast<lds_cvd*>(reinterpret_cast<uintptr_t>(lanebase + (h << 7)) & 0xffffffffu);
+                        const double t0 = cell[0], t1 = cell[16], t2 = cell[32], t3 = cell[48];
+                        acc[k][0] += t0; acc[k][1] += t1; acc[k][2] += t2; acc[k][3] += t3;
+                    }
+                }
+            }
+
+            // ---- per-column result (accumulators are in code order A, C, T, G) ----
+            int nkept = 0;
+            int below_kept = 0;
+            bool keepk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int inck = nrows - static_cast<int>(((k < 2 ? gaps01 : gaps23) >> (16 * (k & 1))) & 0xffffu);
+                keepk[k] = (k < remain) && !(inck < thresh);
+                const unsigned long long m = __ballot(keepk[k]);
+                below_kept += __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), 0));
+                nkept += __popcll(m);
+            }
+            int o = outpos + below_kept;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!keepk[k]) continue;
+                const double sA = acc[k][0], sC = acc[k][1], sG = acc[k][3], sT = acc[k][2];
+                const double mx = fmax(fmax(sA, sC), fmax(sG, sT));
+                const int best = sA == mx ? 0 : (sC == mx ? 1 : (sG == mx ? 2 : 3));
+                // fp32 estimate of the Phred value, the reference's chain in fp64 next to a rounding boundary (see k_consensus_qf)
+                const float NEG = -1.0e30f;
+                const float uA = best == 0 ? NEG : static_cast<float>(sA - mx), uC = best == 1 ? NEG : static_cast<float>(sC - mx);
+                const float uG = best == 2 ? NEG : static_cast<float>(sG - mx), uT = best == 3 ? NEG : static_cast<float>(sT - mx);
+                const float L2E = 1.44269504088896341f;
+                const float S = (__builtin_amdgcn_exp2f(uA * L2E) + __builtin_amdgcn_exp2f(uC * L2E)) +
+                                (__builtin_amdgcn_exp2f(uG * L2E) + __builtin_amdgcn_exp2f(uT * L2E));
+                float xf = 3.01029995663981195f * (__builtin_amdgcn_logf(1.0f + S) - __builtin_amdgcn_logf(S));
+                const float fr = xf - floorf(xf);
+                int qv;
+                bool near = false;
+                double a = 0, b = 0, c = 0, d = 0;
+                if (xf < 93.4f && fabsf(fr - 0.5f) < 4e-4f) {
+                    double t;
+                    a = sA; b = sC; c = sG; d = sT;
+                    if (a > b) { t = a; a = b; b = t; }
+                    if (c > d) { t = c; c = d; d = t; }
+                    if (a > c) { t = a; a = c; c = t; }
+                    if (b > d) { t = b; b = d; d = t; }
+                    if (b > c) { t = b; b = c; c = t; }
+                    const double le = exact_log_error(a, b, c, d);
+                    const double x = -10 * le / A.ln10;
+                    const double frac = x - floor(x);
+                    near = x < 93.4 && fabs(frac - 0.5) < 1e-9;
+                    double q = round(x);
+                    if (q > 93.0) q = 93.0;
+                    qv = static_cast<int>(q);
+                } else {
+                    xf = fminf(xf, 93.0f);
+                    qv = static_cast<int>(floorf(xf + 0.5f));
+                }
+                A.cons[obase + o] = "ACGT"[best];
+                A.phred[obase + o] = static_cast<uint8_t>(qv + 33);
+                if (near) {
+                    const int slot = atomicAdd(A.fix_count, 1);
+                    if (slot < A.fix_cap) {
+                        A.fix_pos[slot] = obase + o;
+                        A.fix_val[4 * slot + 0] = a; A.fix_val[4 * slot + 1] = b;
+                        A.fix_val[4 * slot + 2] = c; A.fix_val[4 * slot + 3] = d;
+                    }
+                }
+                ++o;
+            }
+            outpos += nkept;
+        }
+        if (lane == 0) A.cons_len[g] = outpos;
+    }
+}
+
 // kept columns of every alignment -> contiguous output (one block per alignment)
 __global__ void k_consensus_compact(const uint8_t* cons, const uint8_t* phred, const double* lerr, const int64_t* out_off,
                                     const int32_t* len, const long long* dst_off, long long ngroups, uint8_t* dcons,
@@ -781,6 +934,16 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         double* d_strip;
         SL_TRY(upload("cons.strip", strip.data(), strip.size(), &d_strip, s));
         a.strip = d_strip;
+        if (a.codes) {   // k_consensus_code: (w w w r w w w w) per quality, zero row last
+            std::vector<double> strip8(static_cast<size_t>(enc_n + 1) * CODE_STRIP * QF_SLOTS, 0.0);
+            for (int k = 0; k < enc_n; ++k)
+                for (int i = 0; i < CODE_STRIP; ++i)
+                    for (int sl = 0; sl < QF_SLOTS; ++sl)
+                        strip8[(static_cast<size_t>(k) * CODE_STRIP + i) * QF_SLOTS + sl] = (i == 3) ? right[k] : wrong[k];
+            double* d_strip8;
+            SL_TRY(upload("cons.strip8", strip8.data(), strip8.size(), &d_strip8, s));
+            a.strip8 = d_strip8;
+        }
     }
     a.ngroups = ng_eval;
     a.mincov = min_cov; a.pseudo = pseudo; a.ln10 = std::log(10);
@@ -820,7 +983,13 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         c.counts["consensus_cells"] = static_cast<double>(total);
         c.stage_reset("consensus");
         SL_TRY(c.stage_begin("consensus", s));
-        if (q4) {
+        if (a.codes) {
+            // rows written as vote codes by the MSA stage: nothing to decode
+            const size_t ldsc = static_cast<size_t>(enc_n + 1) * QC_ROWB;
+            SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_consensus_code), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsc)));
+            const int gridc = static_cast<int>(std::min<int64_t>((ng_eval + QF_THREADS / 64 - 1) / (QF_THREADS / 64), c.num_cu));
+            hipLaunchKernelGGL(k_consensus_code, dim3(gridc), dim3(QF_THREADS), ldsc, s, a);
+        } else if (q4) {
             // clean groups on the fast kernel (one 1024-thread workgroup per CU around a ~85 KB strip table in LDS);
             // whatever it flags is redone by the generic kernel
             const size_t ldsf = static_cast<size_t>(enc_n + 1) * QF_ROWB;
@@ -868,6 +1037,11 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         char msg[96];
         snprintf(msg, sizeof msg, "unknown character '%c' in alignment string", bc);
         return fail("%s", msg);
+    }
+    if (a.codes && a.code_bad) {
+        int bad_row = 0x7fffffff;
+        SL_HIP(hipMemcpy(&bad_row, a.code_bad, sizeof bad_row, hipMemcpyDeviceToHost));
+        if (bad_row != 0x7fffffff) return fail("quality cannot be lower than smallest encoded value");
     }
     if (quality)
         for (int64_t r = 0; r < rows_eval; ++r) {
@@ -1033,7 +1207,25 @@ static int msa_consensus_impl(const int64_t* grp_off, const int32_t* grp, int64_
     // alignments run (qualities stay in read order; every row finds its string through the member list)
     uint8_t* d_q = nullptr; int64_t* d_qoff = nullptr;
     hipStream_t copy_stream = nullptr;
+    hipEvent_t q_ready = nullptr;
     std::vector<int64_t> qrel;
+    // Rows as vote codes (k_consensus_code) when the quality strings are laid out like the reads -- every read as long as
+    // its quality string, which is also what the reference demands -- and the table fits LDS; otherwise characters.
+    bool codes = quality && static_cast<size_t>(enc_n + 1) * QC_ROWB <= 150 * 1024 && static_cast<int>(enc_names[0]) + enc_n <= 255 &&
+                 !std::getenv("SARLACC_CONSENSUS_CHARS");
+    for (int64_t r = 0; codes && r < nseq; ++r)
+        if (qual_off[r + 1] - qual_off[r] != seq_off[r + 1] - seq_off[r]) codes = false;
+    const uint8_t* d_q_const = nullptr;
+    if (codes) {
+        SL_TRY(ensure_device());
+        int* d_bad;
+        SL_TRY(scratch("cons.codebad", 1, &d_bad));
+        const int none = 0x7fffffff;
+        SL_HIP(hipMemcpy(d_bad, &none, sizeof none, hipMemcpyHostToDevice));
+        SL_HIP(hipEventCreateWithFlags(&q_ready, hipEventDisableTiming));
+        res.code.want = true; res.code.qual = &d_q_const; res.code.ready = q_ready;
+        res.code.qoffset = static_cast<int>(enc_names[0]); res.code.navail = enc_n; res.code.d_bad = d_bad;
+    }
     const std::function<int()> upload_quals = [&]() -> int {
         if (!quality) return 0;
         const int64_t qbase = qual_off[0];
@@ -1043,8 +1235,11 @@ static int msa_consensus_impl(const int64_t* grp_off, const int32_t* grp, int64_
         if (d_qual_res) d_q = const_cast<uint8_t*>(d_qual_res);
         else SL_TRY(upload("cons.qual", reinterpret_cast<const uint8_t*>(qual) + qbase, static_cast<size_t>(qrel[nseq]), &d_q, copy_stream));
         SL_TRY(upload("cons.qoff", qrel.data(), qrel.size(), &d_qoff, copy_stream));
+        d_q_const = d_q;
+        if (q_ready) SL_HIP(hipEventRecord(q_ready, copy_stream));
         return 0;
     };
+    struct EventGuard { hipEvent_t* e; ~EventGuard() { if (*e) (void)hipEventDestroy(*e); } } q_ready_guard{&q_ready};
     const int msa_rc = msa_run(grp_off, grp, ngroups, seq, seq_off, nseq, match, mismatch, gap_extension, gap_opening, bandwidth, true,
                                -1, &res, &upload_quals, d_seq_res);
     if (copy_stream) {
@@ -1084,6 +1279,7 @@ static int msa_consensus_impl(const int64_t* grp_off, const int32_t* grp, int64_
     SL_TRY(upload("cons.ooff", out_off.data(), out_off.size(), &d_ooff, s));
     a.aln = res.d_out; a.aln_off = d_aoff; a.grp_rows = d_grows; a.out_off = d_ooff; a.max_rows = max_rows;
     a.aln_bytes = total;
+    if (codes) { a.codes = res.d_codes; a.code_bad = res.code.d_bad; }
     if (quality) { a.qual = d_q; a.qual_off = d_qoff; a.row_read = res.d_members; a.qual_bytes = qrel[static_cast<size_t>(nseq)]; }
     return consensus_core(quality, a, ngroups, ngroups, nrows, total, out_off, nullptr, 0, min_cov, pseudo_count, enc_errors,
                           enc_names, enc_n, cons, phred, cons_off, nullptr, s);

@@ -52,6 +52,11 @@ struct MergeArgs {
     int32_t* width;            // per group
     const long long* out_off;  // per group start in out
     uint8_t* out;
+    // rows as vote codes instead of characters (CodeSpec, common.hpp): out16 != nullptr
+    uint16_t* out16;
+    const uint8_t* qual;       // laid out like seq
+    int qoffset, navail;
+    int* bad;
 };
 
 // job index of read position r (inside its group), -1 for the centre
@@ -99,9 +104,18 @@ __global__ void k_msa_write(MergeArgs A, const long long* row_group, const int* 
     const long long id = A.members[G.read0 + r] - 1;
     const uint8_t* src = A.seq + A.seq_off[id];
     const int W = A.width[g];
-    uint8_t* dst = A.out + A.out_off[g] + static_cast<long long>(r) * W;
+    const bool codes = A.out16 != nullptr;
+    uint8_t* dst = codes ? nullptr : A.out + A.out_off[g] + static_cast<long long>(r) * W;
+    uint16_t* dst16 = codes ? A.out16 + A.out_off[g] + static_cast<long long>(r) * W : nullptr;
+    const uint8_t* ql = codes ? A.qual + A.seq_off[id] : nullptr;
+    const uint16_t gapcode = static_cast<uint16_t>(CODE_GAPBIT | code_zero_index(A.navail));
+    bool badq = false;
+    // cell `c` of the row holds read position `rp` (character ch), or a gap
+#define MSA_PUT(c, ch, rp) { if (codes) dst16[c] = vote_code(ch, ql[rp], A.qoffset, A.navail, badq); else dst[c] = ch; }
+#define MSA_GAP(c) { if (codes) dst16[c] = gapcode; else dst[c] = '-'; }
     if (G.nreads == 1) {  // verbatim (src/quick_msa.cpp:46-50)
-        for (int p = threadIdx.x; p < W; p += blockDim.x) dst[p] = src[p];
+        for (int p = threadIdx.x; p < W; p += blockDim.x) MSA_PUT(p, src[p], p)
+        if (badq) atomicMin(A.bad, static_cast<int>(row));
         return;
     }
     const long long jb = job_of(G, r);
@@ -134,13 +148,18 @@ __global__ void k_msa_write(MergeArgs A, const long long* row_group, const int* 
     for (int p = p0; p < p1; ++p) {
         const int k = ins ? ins[p] : 0;
         const int m = mi[p];
-        for (int x = 0; x < k; ++x) dst[col++] = "ACGTN"[dna5_code(src[rp++])];
-        for (int x = k; x < m; ++x) dst[col++] = '-';
+        for (int x = 0; x < k; ++x) { MSA_PUT(col, "ACGTN"[dna5_code(src[rp])], rp) ++col; ++rp; }
+        for (int x = k; x < m; ++x) { MSA_GAP(col) ++col; }
         if (p < lc) {
             const bool matched = aln ? aln[p] != 0 : true;
-            dst[col++] = matched ? "ACGTN"[dna5_code(src[rp++])] : '-';
+            if (matched) { MSA_PUT(col, "ACGTN"[dna5_code(src[rp])], rp) ++rp; }
+            else MSA_GAP(col)
+            ++col;
         }
     }
+    if (badq) atomicMin(A.bad, static_cast<int>(row));
+#undef MSA_PUT
+#undef MSA_GAP
 }
 
 // ---------------------------------------------------------------------------
@@ -283,8 +302,20 @@ int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const 
     SL_TRY(upload("msa.ooff", ooff.data(), ooff.size(), &d_ooff, s));
     SL_TRY(upload("msa.rg", row_group.data(), row_group.size(), &d_rg, s));
     SL_TRY(upload("msa.rp", row_pos.data(), row_pos.size(), &d_rp, s));
-    SL_TRY(scratch("msa.out", static_cast<size_t>(ooff[ngroups]), &d_out));
-    m.out_off = d_ooff; m.out = d_out;
+    m.out_off = d_ooff;
+    if (res->code.want) {
+        // rows as vote codes: the qualities may still be on their way (upload hook on a stream of its own)
+        uint16_t* d_out16;
+        SL_TRY(scratch("msa.out16", static_cast<size_t>(ooff[ngroups]) + 4, &d_out16));   // (+4: the vote kernel reads four codes at a time)
+        if (res->code.ready) SL_HIP(hipStreamWaitEvent(s, res->code.ready, 0));
+        m.out = nullptr; m.out16 = d_out16; m.qual = *res->code.qual; m.qoffset = res->code.qoffset; m.navail = res->code.navail;
+        m.bad = res->code.d_bad;
+        res->d_codes = d_out16;
+        d_out = nullptr;
+    } else {
+        SL_TRY(scratch("msa.out", static_cast<size_t>(ooff[ngroups]), &d_out));
+        m.out = d_out; m.out16 = nullptr;
+    }
     const long long nrows = static_cast<long long>(row_group.size());
     hipLaunchKernelGGL(k_msa_write, dim3(static_cast<unsigned>(nrows)), dim3(256), 0, s, m, d_rg, d_rp, nrows);
     SL_HIP(hipGetLastError());

@@ -91,6 +91,11 @@ struct M2Args {
     int* redo;                     // per group: this round's chain has to be done by k_m2_chain_exact
     int32_t* width;                // per group: columns of the final profile
     uint8_t* out;                  // gapped rows
+    // rows as vote codes instead of characters (CodeSpec, common.hpp): out16 != nullptr
+    uint16_t* out16;
+    const uint8_t* qual;           // laid out like seq
+    int qoffset, navail;
+    int* bad;
 };
 
 __device__ __forceinline__ int m2_w0(int x, int y, int ma, int mm) {
@@ -835,8 +840,25 @@ __global__ void k_m2_write(M2Args A, const int* member_group, int nmembers, cons
     const M2Member Me = A.members[m];
     const int a = m - G.first_member;
     const int W = A.width[g];
-    uint8_t* dst = A.out + out_off[g] + static_cast<long long>(a) * W;
     const uint8_t* src = A.seq + Me.seq_off;
+    if (A.out16) {   // vote codes: the cell's quality is the read position's
+        uint16_t* dst16 = A.out16 + out_off[g] + static_cast<long long>(a) * W;
+        const uint8_t* ql = A.qual + Me.seq_off;
+        const uint16_t gapcode = static_cast<uint16_t>(CODE_GAPBIT | code_zero_index(A.navail));
+        bool badq = false;
+        if (G.n == 1) {
+            for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < W; c += gridDim.x * blockDim.x) dst16[c] = vote_code(src[c], ql[c], A.qoffset, A.navail, badq);
+        } else {
+            const uint16_t* row = A.pos + G.pos_base + static_cast<long long>(a) * G.wcap;
+            for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < W; c += gridDim.x * blockDim.x) {
+                const unsigned p = row[c];
+                dst16[c] = p == M2_NONE ? gapcode : vote_code("ACGTN"[dna5_code(src[p])], ql[p], A.qoffset, A.navail, badq);
+            }
+        }
+        if (badq) atomicMin(A.bad, m);
+        return;
+    }
+    uint8_t* dst = A.out + out_off[g] + static_cast<long long>(a) * W;
     if (G.n == 1) {   // verbatim (src/quick_msa.cpp:46-50)
         for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < W; c += gridDim.x * blockDim.x) dst[c] = src[c];
         return;
@@ -1089,11 +1111,17 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
 }
 
 // rows of the batch's groups (except those flagged in `skip`) at out + off[group of the caller's list]
-static int m2_write_batch(M2Batch& B, const std::string& pf, const std::vector<long long>& off_of_batch_group, uint8_t* d_out, hipStream_t s) {
+static int m2_write_batch(M2Batch& B, const std::string& pf, const std::vector<long long>& off_of_batch_group, void* d_out,
+                          const CodeSpec& code, hipStream_t s) {
     if (B.members.empty()) return 0;
     long long* d_off;
     SL_TRY(upload((pf + ".ooff").c_str(), off_of_batch_group.data(), off_of_batch_group.size(), &d_off, s));
-    B.a.out = d_out;
+    if (code.want) {
+        B.a.out = nullptr; B.a.out16 = static_cast<uint16_t*>(d_out);
+        B.a.qual = *code.qual; B.a.qoffset = code.qoffset; B.a.navail = code.navail; B.a.bad = code.d_bad;
+    } else {
+        B.a.out = static_cast<uint8_t*>(d_out); B.a.out16 = nullptr;
+    }
     int maxw = 1;
     for (int32_t w : B.width) maxw = std::max(maxw, static_cast<int>(w));
     hipLaunchKernelGGL(k_m2_write, dim3(std::max(1u, m2_blocks(maxw, 256)), static_cast<unsigned>(B.members.size())), dim3(256), 0, s, B.a,
@@ -1107,8 +1135,10 @@ static int m2_write_batch(M2Batch& B, const std::string& pf, const std::vector<l
 static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vector<int64_t>& ids, const uint8_t* d_seq,
                      const std::vector<int64_t>& rel, double match, double mismatch, double gap_extension, double gap_opening,
                      int bandwidth, std::vector<int32_t>& width, std::vector<long long>& off, uint8_t** d_rows,
-                     const std::function<int()>* overlap, hipStream_t s) {
+                     const std::function<int()>* overlap, const CodeSpec& code, hipStream_t s) {
     Context& c = ctx();
+    const size_t cs = code.want ? 2 : 1;   // bytes per cell of the row buffer (offsets and widths stay in cells)
+    bool waited = false;
     width.assign(ids.size(), 0);
     off.assign(ids.size() + 1, 0);
     *d_rows = nullptr;
@@ -1180,10 +1210,11 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
                 boff[q] = need;
                 need += static_cast<long long>(bw[q]) * B.groups[q].n;
             }
-            SL_TRY(rows_reserve(static_cast<size_t>(used), static_cast<size_t>(need) + 1));
+            SL_TRY(rows_reserve(static_cast<size_t>(used) * cs, (static_cast<size_t>(need) + 1) * cs));
             SL_HIP(hipMemcpyAsync(B.a.width, bw.data(), sizeof(int32_t) * bw.size(), hipMemcpyHostToDevice, s));
             B.width = bw;
-            SL_TRY(m2_write_batch(B, "m2", boff, static_cast<uint8_t*>(rows_ws.ptr), s));
+            if (code.want && code.ready && !waited) { SL_HIP(hipStreamWaitEvent(s, code.ready, 0)); waited = true; }   // qualities in HBM
+            SL_TRY(m2_write_batch(B, "m2", boff, rows_ws.ptr, code, s));
             SL_HIP(hipStreamSynchronize(s));   // the batch's host vectors and workspaces are reused by the next one
             used = need;
             q0 = q1;
@@ -1257,7 +1288,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     std::vector<int32_t> w2;
     std::vector<long long> o2;
     uint8_t* d_rows2 = nullptr;
-    SL_TRY(msa2_core(grp_off, grp, v2, d_seq, rel, match, mismatch, gap_extension, gap_opening, bandwidth, w2, o2, &d_rows2, overlap, s));
+    SL_TRY(msa2_core(grp_off, grp, v2, d_seq, rel, match, mismatch, gap_extension, gap_opening, bandwidth, w2, o2, &d_rows2, overlap, res->code, s));
     c.counts["msa_v1_fallback"] = static_cast<double>(v1.size());
     // spec v1 part on a compacted group list: more than M2_MAXN reads, reads too long, or dropped by the guard
     MsaResult r1;
@@ -1271,6 +1302,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         }
         r1.width.assign(v1.size(), 0);
         r1.out_off.assign(v1.size() + 1, 0);
+        r1.code = res->code;
         SL_TRY(msa1_run(g1off.data(), g1.data(), static_cast<int64_t>(v1.size()), seq, seq_off, nseq, match, mismatch, gap_extension,
                         gap_opening, bandwidth, true, -1, &r1, nullptr, d_seq, true));
     }
@@ -1291,8 +1323,12 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         }
     }
     if (want_rows && out_cap >= 0 && out_cap < out_off[ngroups]) return fail("sarlacc_amd: MSA output buffer too small (%lld needed)", static_cast<long long>(out_off[ngroups]));
+    // (offsets and sizes so far are in cells; a cell is one character, or one 16-bit vote code)
+    const long long cs = res->code.want ? 2 : 1;
     uint8_t* d_final;
-    SL_TRY(scratch("msa.final", static_cast<size_t>(out_off[ngroups]) + 1, &d_final));
+    SL_TRY(scratch(res->code.want ? "msa.final16" : "msa.final", static_cast<size_t>(out_off[ngroups] * cs) + 8, &d_final));
+    if (cs > 1)
+        for (int64_t g = 0; g < ngroups; ++g) { src_off[g] *= cs; dst_off[g] *= cs; nbytes[g] *= cs; }
     // two launches, one per source buffer (groups of the other kind copy nothing)
     for (int pass = 0; pass < 2; ++pass) {
         std::vector<long long> nb(nbytes);
@@ -1303,11 +1339,13 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         SL_TRY(upload(pass == 0 ? "msa.cp.do1" : "msa.cp.do2", dst_off.data(), dst_off.size(), &d_do, s));
         SL_TRY(upload(pass == 0 ? "msa.cp.nb1" : "msa.cp.nb2", nb.data(), nb.size(), &d_nb, s));
         if (pass == 0 && v1.empty()) continue;
-        hipLaunchKernelGGL(k_rows_copy, dim3(static_cast<unsigned>(ngroups)), dim3(256), 0, s, pass == 0 ? r1.d_out : d_rows2, d_so, d_final, d_do, d_nb);
+        const uint8_t* src1 = res->code.want ? reinterpret_cast<const uint8_t*>(r1.d_codes) : r1.d_out;
+        hipLaunchKernelGGL(k_rows_copy, dim3(static_cast<unsigned>(ngroups)), dim3(256), 0, s, pass == 0 ? src1 : d_rows2, d_so, d_final, d_do, d_nb);
         SL_HIP(hipGetLastError());
     }
     SL_HIP(hipStreamSynchronize(s));
-    res->d_out = d_final;
+    if (res->code.want) res->d_codes = reinterpret_cast<uint16_t*>(d_final);
+    else res->d_out = d_final;
     return 0;
 }
 

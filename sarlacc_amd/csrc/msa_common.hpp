@@ -67,4 +67,27 @@ __device__ __forceinline__ uint8_t dna5_code(uint8_t c) {
     return 4;
 }
 
+// ---- vote codes (CodeSpec, common.hpp).  Table entry = quality index * 8 + slot: the vote kernel reads the four
+// consecutive entries from the code's index; per quality the strip is (w w w r w w w w), bases in the order
+// A, C, T, G read from slot 3 - base, any other character from slot 4 (wrong for all four); the row after the last
+// quality is all zeros (N: counted as a base, adds nothing; gap: the same with bit 15 set). ----
+constexpr int CODE_STRIP = 8;
+constexpr unsigned CODE_GAPBIT = 0x8000u;
+__host__ __device__ __forceinline__ unsigned code_zero_index(int navail) { return static_cast<unsigned>(navail) * CODE_STRIP; }
+// ch: the row's character (upper case for aligned rows; verbatim for single-read groups); q: its quality character
+__device__ __forceinline__ uint16_t vote_code(uint8_t ch, uint8_t q, int qoffset, int navail, bool& bad) {
+    if (ch == 'N') return static_cast<uint16_t>(code_zero_index(navail));
+    int qi = static_cast<int>(static_cast<signed char>(q)) - qoffset;
+    if (qi < 0) { bad = true; qi = 0; }
+    if (qi >= navail) qi = navail - 1;
+    int slot = 4;                       // a character other than A, C, G, T, N
+    switch (ch) {
+        case 'A': slot = 3; break;      // base order of the vote kernel: A 0, C 1, T 2, G 3
+        case 'C': slot = 2; break;
+        case 'T': slot = 1; break;
+        case 'G': slot = 0; break;
+    }
+    return static_cast<uint16_t>(qi * CODE_STRIP + slot);
+}
+
 }  // namespace sarlacc

@@ -1,5 +1,6 @@
-"""Consensus vote at BASELINE C4 shape on resident reads: the fast kernel (k_consensus_qf, clean groups) against
-the generic one (k_consensus_q4, SARLACC_CONSENSUS_GENERIC=1) -- same strings required, kernel ms from HIP events.
+"""Consensus vote at BASELINE C4 shape on resident reads: the three kernels of the quality vote -- generic characters
+(k_consensus_q4), fast characters (k_consensus_qf), vote codes written by the MSA stage (k_consensus_code, the default of
+the fused calls) -- same strings required, kernel ms from HIP events; "merge" = the MSA stage's row writer and merge.
 Groups are the molecules themselves (known, in read order), MSA under spec v1 so the run is short.
     python tools/perf_consensus.py [molecules] [copies] [read_len]"""
 import os
@@ -30,24 +31,28 @@ def main():
     enc = sarlacc_amd.phred_encoding()
     calls.set_msa_spec(1)
     res = {}
-    for mode in ("generic", "fast", "generic", "fast"):
+    # generic: characters, k_consensus_q4; fast: characters, k_consensus_qf (+ q4 on flagged groups);
+    # codes: the MSA stage writes 16-bit vote codes, k_consensus_code (what the fused calls do by default)
+    for mode in ("generic", "fast", "codes", "generic", "fast", "codes"):
+        os.environ.pop("SARLACC_CONSENSUS_GENERIC", None)
+        os.environ.pop("SARLACC_CONSENSUS_CHARS", None)
+        if mode != "codes":
+            os.environ["SARLACC_CONSENSUS_CHARS"] = "1"
         if mode == "generic":
             os.environ["SARLACC_CONSENSUS_GENERIC"] = "1"
-        else:
-            os.environ.pop("SARLACC_CONSENSUS_GENERIC", None)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         cons, phred = device.dev_msa_consensus(goff, gflat, mol["seq"], mol["qual"], off, 0, -1, -5, -1, 100, 0.6, encoding=enc)
         dt = time.perf_counter() - t0
         ms = _lib.stage_ms("consensus")
         cells = _lib.stage_count("consensus_cells")
-        print("%-8s consensus %.3f ms  %.0f cells  %.1f GB/s algorithmic (2 B/cell)  call %.2f s" % (
-            mode, ms, cells, 2 * cells / ms / 1e6, dt), flush=True)
+        print("%-8s consensus %.3f ms  %.0f cells  %.1f GB/s algorithmic (2 B/cell)  merge %.2f ms  call %.2f s" % (
+            mode, ms, cells, 2 * cells / ms / 1e6, _lib.stage_ms("msa_merge"), dt), flush=True)
         if not nocheck:
             res[mode] = (cons.to_strings(), phred.to_strings())
     if nocheck:
         return
-    same = res["generic"] == res["fast"]
+    same = res["generic"] == res["fast"] == res["codes"]
     print("identical strings:", same, "groups", len(res["fast"][0]))
     if not same:
         a, b = res["generic"], res["fast"]

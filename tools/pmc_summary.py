@@ -16,10 +16,10 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCES = {"k_align": ["align.hip"], "k_msa_pairwise": ["msa_pairwise.hip", "msa_common.hpp"], "k_consensus_qf": ["consensus.hip"]}
+SOURCES = {"k_align": ["align.hip"], "k_msa_pairwise": ["msa_pairwise.hip", "msa_common.hpp"], "k_consensus_code": ["consensus.hip", "msa_common.hpp"]}
 # share of fp64 instructions (4 issue cycles per wave64 instruction on a SIMD-32; everything else
 # 2) in the kernel's VALU stream, from the disassembly of its main loop
-FP64_SHARE = {"k_align": 0.75, "k_msa_pairwise": 0.0, "k_consensus_qf": 0.12}
+FP64_SHARE = {"k_align": 0.75, "k_msa_pairwise": 0.0, "k_consensus_code": 0.18}
 
 
 def source_sha(names):
