@@ -726,6 +726,45 @@ constexpr int QC_RB = 5;
 constexpr int QC_ROWB = CODE_STRIP * QF_SLOTS * 8;   // 1024 bytes per quality value
 typedef unsigned long long __attribute__((aligned(1))) cons_u64_unaligned;
 
+// The rows of one 256-column step: per row and lane one 8-byte load of four codes, requested one batch of rows
+// ahead; per cell one address, four 8-byte LDS reads, four additions.  Loads are unconditional -- rows past the last
+// one re-read it, lanes past the row end read its start, both masked afterwards -- so that the compiler can count them
+// and wait only for the batch it is about to use.  MASK: the step contains the row end (cells beyond it become gaps).
+template <bool MASK>
+__device__ __forceinline__ void qc_rows(const uint16_t* rows, long long W, int nrows, int col, int remain, const unsigned char* lanebase,
+                                        unsigned long long GAP4, double (&acc)[4][4], unsigned& gaps01, unsigned& gaps23) {
+    const unsigned long long keep = !MASK || remain >= 4 ? ~0ull : (remain <= 0 ? 0ull : ((1ull << (16 * remain)) - 1ull));
+    const int lcol = (!MASK || remain > 0) ? col : 0;
+    unsigned long long wn[QC_RB];
+#pragma unroll
+    for (int b = 0; b < QC_RB; ++b) wn[b] = *reinterpret_cast<const cons_u64_unaligned*>(rows + static_cast<long long>(min(b, nrows - 1)) * W + lcol);
+    for (int r0 = 0; r0 < nrows; r0 += QC_RB) {
+        unsigned long long w[QC_RB];
+#pragma unroll
+        for (int b = 0; b < QC_RB; ++b) w[b] = MASK ? ((wn[b] & keep) | (GAP4 & ~keep)) : wn[b];
+#pragma unroll
+        for (int b = 0; b < QC_RB; ++b)                 // the next batch (nothing depends on the data)
+            wn[b] = *reinterpret_cast<const cons_u64_unaligned*>(rows + static_cast<long long>(min(r0 + QC_RB + b, nrows - 1)) * W + lcol);
+#pragma unroll
+        for (int b = 0; b < QC_RB; ++b) {
+            if (r0 + b >= nrows) break;
+            const unsigned lo = static_cast<unsigned>(w[b]), hi = static_cast<unsigned>(w[b] >> 32);
+            gaps01 += (lo >> 15) & 0x00010001u;
+            gaps23 += (hi >> 15) & 0x00010001u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned h = ((k < 2 ? lo : hi) >> (16 * (k & 1))) & 0x7fffu;
+                // four single 8-byte reads (2 LDS cycles each); merged into two ds_read2_b64 they take 8 cycles each
+                // (MI355X_MICROARCH.md, LDS table) -- volatile keeps the compiler from pairing them
+                typedef const volatile double __attribute__((address_space(3))) lds_cvd;
+                lds_cvd* cell = reinterpret_cast<lds_cvd*>(reinterpret_cast<uintptr_t>(lanebase + (h << 7)) & 0xffffffffu);
+                const double t0 = cell[0], t1 = cell[16], t2 = cell[32], t3 = cell[48];
+                acc[k][0] += t0; acc[k][1] += t1; acc[k][2] += t2; acc[k][3] += t3;
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(QF_THREADS) k_consensus_code(const ConsArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     {
@@ -758,42 +797,13 @@ __global__ void __launch_bounds__(QF_THREADS) k_consensus_code(const ConsArgs A)
         for (long long c0 = 0; c0 < W; c0 += 256) {
             const int col = static_cast<int>(c0) + 4 * lane;
             const int remain = static_cast<int>(W) - col;          // cells of the row at and after `col`
-            const unsigned long long keep = remain >= 4 ? ~0ull : (remain <= 0 ? 0ull : ((1ull << (16 * remain)) - 1ull));
             double acc[4][4];
             unsigned gaps01 = 0, gaps23 = 0;                        // packed 16-bit gap counts of the lane's four columns
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0;
-            // Loads are unconditional -- rows past the last one re-read it, lanes past the row end read its start, both
-            // masked afterwards -- so that the compiler can count them and wait only for the batch it is about to use.
-            const int lcol = remain > 0 ? col : 0;
-            unsigned long long wn[QC_RB];
-#pragma unroll
-            for (int b = 0; b < QC_RB; ++b) wn[b] = *reinterpret_cast<const cons_u64_unaligned*>(rows + static_cast<long long>(min(b, nrows - 1)) * W + lcol);
-            for (int r0 = 0; r0 < nrows; r0 += QC_RB) {
-                unsigned long long w[QC_RB];
-#pragma unroll
-                for (int b = 0; b < QC_RB; ++b) w[b] = (wn[b] & keep) | (GAP4 & ~keep);
-#pragma unroll
-                for (int b = 0; b < QC_RB; ++b)                 // the next batch (nothing depends on the data)
-                    wn[b] = *reinterpret_cast<const cons_u64_unaligned*>(rows + static_cast<long long>(min(r0 + QC_RB + b, nrows - 1)) * W + lcol);
-#pragma unroll
-                for (int b = 0; b < QC_RB; ++b) {
-                    if (r0 + b >= nrows) break;
-                    const unsigned lo = static_cast<unsigned>(w[b]), hi = static_cast<unsigned>(w[b] >> 32);
-                    gaps01 += (lo >> 15) & 0x00010001u;
-                    gaps23 += (hi >> 15) & 0x00010001u;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const unsigned h = ((k < 2 ? lo : hi) >> (16 * (k & 1))) & 0x7fffu;
-                        // four single 8-byte reads (2 LDS cycles each); merged into two ds_read2_b64 they take 8 cycles each
-                        // (MI355X_MICROARCH.md, LDS table) -- volatile keeps the compiler from pairing them
-                        typedef const volatile double __attribute__((address_space(3))) lds_cvd;
-                        lds_cvd* cell = reinterpret_cast<lds_cvd*>(reinterpret_cast<uintptr_t>(lanebase + (h << 7)) & 0xffffffffu);
-                        const double t0 = cell[0], t1 = cell[16], t2 = cell[32], t3 = cell[48];
-                        acc[k][0] += t0; acc[k][1] += t1; acc[k][2] += t2; acc[k][3] += t3;
-                    }
-                }
-            }
+            // the rows of this step: a variant without the row-end mask for the steps that lie wholly inside the row
+            if (c0 + 256 <= W) qc_rows<false>(rows, W, nrows, col, remain, lanebase, GAP4, acc, gaps01, gaps23);
+            else qc_rows<true>(rows, W, nrows, col, remain, lanebase, GAP4, acc, gaps01, gaps23);
 
             // ---- per-column result (accumulators are in code order A, C, T, G) ----
             int nkept = 0;
