@@ -248,3 +248,39 @@ def test_msa_spec2_umi_collisions(oracle, seed, nmol, per, length):
             assert [r.replace("-", "") for r in rows] == [reads[i - 1] for i in g]
     finally:
         calls.set_msa_spec(0)
+
+
+def test_fused_vote_codes_equal_character_rows(spec, monkeypatch):
+    """The fused call's two routes -- rows written as 16-bit vote codes (default) and character rows
+    (SARLACC_CONSENSUS_CHARS=1) -- give the same strings, with N in the reads, other characters in single-read groups
+    (returned verbatim by the MSA), qualities beyond the encoding (clamped) and below it (the reference's error);
+    quality strings whose lengths differ from their reads take the character route and its errors."""
+    import sarlacc_amd
+    from sarlacc_amd import SarlaccError, calls
+    from sarlacc_amd.encoding import Encoding
+    from sarlacc_amd.strset import csr_from_lists
+    rng = np.random.default_rng(91)
+    reads, groups, _ = sim_groups(rng, 25, 7, 300)
+    reads = ["".join("N" if rng.random() < 0.03 else c for c in r) for r in reads]
+    for g in groups:
+        if len(g) == 1:
+            r = list(reads[g[0] - 1]); r[len(r) // 2] = "y"; r[0] = "a"; reads[g[0] - 1] = "".join(r)
+    reads.append("ACGTRYacgtn"); groups.append([len(reads)])
+    quals = ["".join(chr(int(c)) for c in rng.integers(35, 100, len(r))) for r in reads]
+    goff, gvals = csr_from_lists(groups)
+    q = np.arange(40, dtype=np.float64)                       # an encoding that stops at Q39: higher characters are clamped
+    enc = Encoding(np.power(10.0, -q / 10.0), bytes(range(33, 73)))
+    res = {}
+    for route in ("codes", "chars"):
+        if route == "chars":
+            monkeypatch.setenv("SARLACC_CONSENSUS_CHARS", "1")
+        res[route] = calls.msa_consensus_flat(goff, gvals, reads, 0, -1, -5, -1, 100, 0.6, quals=quals, encoding=enc)
+        bad = list(quals); bad[3] = " " + bad[3][1:]
+        with pytest.raises(SarlaccError, match="quality cannot be lower than smallest encoded value"):
+            calls.msa_consensus_flat(goff, gvals, reads, 0, -1, -5, -1, 100, 0.6, quals=bad, encoding=enc)
+        short = list(quals); short[groups[0][0] - 1] = short[groups[0][0] - 1][:-1]
+        with pytest.raises(SarlaccError, match="quality vector is shorter than the alignment sequence"):
+            calls.msa_consensus_flat(goff, gvals, reads, 0, -1, -5, -1, 100, 0.6, quals=short, encoding=enc)
+    assert res["codes"][0].to_strings() == res["chars"][0].to_strings()
+    assert res["codes"][1].to_strings() == res["chars"][1].to_strings()
+    assert sarlacc_amd.stage_ms("consensus") > 0
