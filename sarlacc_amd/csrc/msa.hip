@@ -94,7 +94,39 @@ __global__ void k_msa_width(MergeArgs A) {
     if (threadIdx.x == 0) A.width[g] = static_cast<int32_t>(G.lc + s_sum);
 }
 
-// One block per (group, read): columns come from prefix sums over the centre positions.
+__device__ __forceinline__ int wave_scan(int x) {   // inclusive prefix sum over the wavefront (DPP)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31
+    return x;
+}
+
+constexpr int WRITE_THREADS = 256;
+// Character tables of the row writer: 0 aligned rows as characters (upper-cased bases, N for the rest),
+// 1 aligned rows as vote slots, 2 verbatim rows as vote slots, 3 verbatim rows as characters (identity).
+struct WriteMap {
+    uint8_t t[4][256];
+    constexpr WriteMap() : t{} {
+        for (int c = 0; c < 256; ++c) {
+            const int u = (c >= 'a' && c <= 'z') ? c - 32 : c;
+            const bool base = u == 'A' || u == 'C' || u == 'G' || u == 'T';
+            const int up = base ? u : 'N';
+            t[0][c] = static_cast<uint8_t>(up);
+            t[1][c] = static_cast<uint8_t>(up == 'A' ? 3 : up == 'C' ? 2 : up == 'T' ? 1 : up == 'G' ? 0 : 5);
+            t[2][c] = static_cast<uint8_t>(c == 'N' ? 5 : c == 'A' ? 3 : c == 'C' ? 2 : c == 'T' ? 1 : c == 'G' ? 0 : 4);
+            t[3][c] = static_cast<uint8_t>(c);
+        }
+    }
+};
+__device__ const WriteMap k_write_map{};
+
+// One block per (group, read): columns come from prefix sums over the centre positions.  CODES: the cells are
+// 16-bit vote codes (msa_common.hpp) instead of characters.  The per-character work (upper-casing, N for anything
+// that is not a base, the vote slot) goes through a 256-entry LDS table built once per block.
+template <bool CODES>
 __global__ void k_msa_write(MergeArgs A, const long long* row_group, const int* row_pos, long long nrows) {
     const long long row = blockIdx.x;
     if (row >= nrows) return;
@@ -104,62 +136,85 @@ __global__ void k_msa_write(MergeArgs A, const long long* row_group, const int* 
     const long long id = A.members[G.read0 + r] - 1;
     const uint8_t* src = A.seq + A.seq_off[id];
     const int W = A.width[g];
-    const bool codes = A.out16 != nullptr;
-    uint8_t* dst = codes ? nullptr : A.out + A.out_off[g] + static_cast<long long>(r) * W;
-    uint16_t* dst16 = codes ? A.out16 + A.out_off[g] + static_cast<long long>(r) * W : nullptr;
-    const uint8_t* ql = codes ? A.qual + A.seq_off[id] : nullptr;
-    const uint16_t gapcode = static_cast<uint16_t>(CODE_GAPBIT | code_zero_index(A.navail));
+    uint8_t* dst = CODES ? nullptr : A.out + A.out_off[g] + static_cast<long long>(r) * W;
+    uint16_t* dst16 = CODES ? A.out16 + A.out_off[g] + static_cast<long long>(r) * W : nullptr;
+    const uint8_t* ql = CODES ? A.qual + A.seq_off[id] : nullptr;
+    const unsigned zero = code_zero_index(A.navail);
+    const uint16_t gapcode = static_cast<uint16_t>(CODE_GAPBIT | zero);
+    const bool verbatim = G.nreads == 1;   // src/quick_msa.cpp:46-50
+    // s_map[c]: characters -> the row's character; codes -> the vote slot, 5 = N (the all-zero table row)
+    __shared__ uint8_t s_map[256];
+    s_map[threadIdx.x] = k_write_map.t[CODES ? (verbatim ? 2 : 1) : (verbatim ? 3 : 0)][threadIdx.x];
+    __syncthreads();
     bool badq = false;
-    // cell `c` of the row holds read position `rp` (character ch), or a gap
-#define MSA_PUT(c, ch, rp) { if (codes) dst16[c] = vote_code(ch, ql[rp], A.qoffset, A.navail, badq); else dst[c] = ch; }
-#define MSA_GAP(c) { if (codes) dst16[c] = gapcode; else dst[c] = '-'; }
-    if (G.nreads == 1) {  // verbatim (src/quick_msa.cpp:46-50)
-        for (int p = threadIdx.x; p < W; p += blockDim.x) MSA_PUT(p, src[p], p)
+    // cell `c` of the row holds read position `rp`, or a gap
+    auto put = [&](unsigned c, unsigned rp) {   // unsigned: 32-bit offsets from the scalar row bases
+        const unsigned v = s_map[src[rp]];
+        if (CODES) {
+            int qi = static_cast<int>(static_cast<signed char>(ql[rp])) - A.qoffset;
+            badq |= qi < 0 && v != 5;
+            qi = min(max(qi, 0), A.navail - 1);
+            dst16[c] = static_cast<uint16_t>(v == 5 ? zero : static_cast<unsigned>(qi) * CODE_STRIP + v);
+        } else {
+            dst[c] = static_cast<uint8_t>(v);
+        }
+    };
+    auto gap = [&](unsigned c) {
+        if (CODES) dst16[c] = gapcode;
+        else dst[c] = '-';
+    };
+    if (verbatim) {
+        for (int p = threadIdx.x; p < W; p += blockDim.x) put(p, p);
         if (badq) atomicMin(A.bad, static_cast<int>(row));
         return;
     }
     const long long jb = job_of(G, r);
-    const uint16_t* ins = jb >= 0 ? A.ins + A.jobs[jb].out_off : nullptr;
-    const uint8_t* aln = jb >= 0 ? A.aln + A.jobs[jb].out_off : nullptr;
+    const bool other = jb >= 0;            // not the centre itself: has an alignment to the centre
     const uint16_t* mi = A.maxins + A.mi_off[g];
-    // serial chunked prefix: each thread owns a contiguous slice of centre positions
+    const uint16_t* ins = other ? A.ins + A.jobs[jb].out_off : mi;   // (centre: loaded and ignored)
+    const uint8_t* aln = other ? A.aln + A.jobs[jb].out_off : reinterpret_cast<const uint8_t*>(mi);
+    // Tiles of WRITE_THREADS centre positions, one per thread: a block-wide exclusive scan of (columns taken,
+    // read bases taken) gives every position its first cell, so neighbouring threads write neighbouring cells.
     const int lc = G.lc;
-    const int per = (lc + 1 + blockDim.x - 1) / blockDim.x;
-    const int p0 = min(static_cast<int>(threadIdx.x) * per, lc + 1), p1 = min(p0 + per, lc + 1);
-    __shared__ long long s_col[1024], s_rp[1024];
-    long long ccol = 0, crp = 0;
-    for (int p = p0; p < p1; ++p) {
-        ccol += mi[p] + (p < lc ? 1 : 0);
-        crp += (ins ? ins[p] : 0) + ((p < lc) ? (aln ? aln[p] : 1) : 0);
-    }
-    s_col[threadIdx.x] = ccol;
-    s_rp[threadIdx.x] = crp;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long a = 0, b = 0;
-        for (unsigned t = 0; t < blockDim.x; ++t) {
-            const long long x = s_col[t], y = s_rp[t];
-            s_col[t] = a; s_rp[t] = b;
-            a += x; b += y;
+    const int wv = threadIdx.x >> 6;
+    constexpr int NWV = WRITE_THREADS / 64;
+    __shared__ int s_wc[2][NWV], s_wr[2][NWV];
+    int base_col = 0, base_rp = 0, flip = 0;
+    // clamped addresses: the loads stay unconditional, and the next tile's are issued before this tile's barrier
+    int kraw, mraw, araw;
+    auto fetch = [&](int p) {
+        const unsigned pc = static_cast<unsigned>(min(p, lc));
+        kraw = ins[pc]; mraw = mi[pc]; araw = aln[pc];   // aln has lc + 1 entries too (the last is unused)
+    };
+    fetch(threadIdx.x);
+    for (int tb = 0; tb <= lc; tb += WRITE_THREADS, flip ^= 1) {
+        const int p = tb + static_cast<int>(threadIdx.x);
+        const bool live = p <= lc, cell = p < lc;
+        const int kcur = kraw, mcur = mraw, acur = araw;
+        fetch(p + WRITE_THREADS);
+        const int k = live && other ? kcur : 0;
+        const int m = live ? mcur : 0;
+        const bool matched = cell && (other ? acur != 0 : true);
+        const int vcol = m + (cell ? 1 : 0), vrp = k + (matched ? 1 : 0);
+        int icol = wave_scan(vcol), irp = wave_scan(vrp);
+        asm volatile("" : "+v"(icol), "+v"(irp));   // keeps the scans as fused DPP adds (no re-derivation from their steps)
+        if ((threadIdx.x & 63) == 63) { s_wc[flip][wv] = icol; s_wr[flip][wv] = irp; }
+        __syncthreads();   // alternating buffers: one barrier per tile
+        int col = base_col + icol - vcol, rp = base_rp + irp - vrp;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) {
+            const int a = s_wc[flip][w], b = s_wr[flip][w];
+            if (w < wv) { col += a; rp += b; }
+            base_col += a; base_rp += b;
         }
-    }
-    __syncthreads();
-    long long col = s_col[threadIdx.x], rp = s_rp[threadIdx.x];
-    for (int p = p0; p < p1; ++p) {
-        const int k = ins ? ins[p] : 0;
-        const int m = mi[p];
-        for (int x = 0; x < k; ++x) { MSA_PUT(col, "ACGTN"[dna5_code(src[rp])], rp) ++col; ++rp; }
-        for (int x = k; x < m; ++x) { MSA_GAP(col) ++col; }
-        if (p < lc) {
-            const bool matched = aln ? aln[p] != 0 : true;
-            if (matched) { MSA_PUT(col, "ACGTN"[dna5_code(src[rp])], rp) ++rp; }
-            else MSA_GAP(col)
-            ++col;
+        if (m) {   // rare: insertion columns before this centre position
+            for (int x = 0; x < k; ++x) { put(col, rp); ++col; ++rp; }
+            for (int x = k; x < m; ++x) { gap(col); ++col; }
         }
+        if (matched) put(col, rp);
+        else if (cell) gap(col);
     }
     if (badq) atomicMin(A.bad, static_cast<int>(row));
-#undef MSA_PUT
-#undef MSA_GAP
 }
 
 // ---------------------------------------------------------------------------
@@ -317,7 +372,8 @@ int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const 
         m.out = d_out; m.out16 = nullptr;
     }
     const long long nrows = static_cast<long long>(row_group.size());
-    hipLaunchKernelGGL(k_msa_write, dim3(static_cast<unsigned>(nrows)), dim3(256), 0, s, m, d_rg, d_rp, nrows);
+    if (m.out16) hipLaunchKernelGGL(k_msa_write<true>, dim3(static_cast<unsigned>(nrows)), dim3(WRITE_THREADS), 0, s, m, d_rg, d_rp, nrows);
+    else hipLaunchKernelGGL(k_msa_write<false>, dim3(static_cast<unsigned>(nrows)), dim3(WRITE_THREADS), 0, s, m, d_rg, d_rp, nrows);
     SL_HIP(hipGetLastError());
     SL_TRY(c.stage_end("msa_merge", s));
     res->d_out = d_out;
