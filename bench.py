@@ -134,15 +134,15 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     backend = os.environ.get("SARLACC_DIST_BACKEND", "nccl")  # gloo only to exercise this path on one GPU
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world)
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a HIP device")
     dev_index = local_rank % ndev
-    torch.cuda.set_device(dev_index)
+    torch.cuda.set_device(dev_index)   # before the process group: RCCL binds its communicator to the current device
     device = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     red_device = device if backend == "nccl" else torch.device("cpu")
     D = dist if world > 1 else None
 

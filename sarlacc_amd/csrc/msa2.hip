@@ -381,6 +381,206 @@ __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
     if (A.clk && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { A.clk[4] = __builtin_amdgcn_s_memtime() - gclk0; A.clk[5] = gcand; A.clk[6] = static_cast<unsigned long long>(nA); A.clk[7] = static_cast<unsigned long long>(n); }
 }
 
+// ---- unit weights (the default scores): the candidates of a round as a table of scalar descriptors ----
+// Entry e = pass * |B| + bi of a group's table: pass 0 the direct edges (c = b), pass 1 + c the triplets through
+// member c, each for the second child's members b ascending -- the canonical candidate order of k_m2_gather, with the
+// block of c == a left in: the lane's position "in a itself" is a gap by construction, so those entries add nothing.
+//   M2Cand { map of (c -> b), columns of b, len(c) - 1, len(b) - 1, LDS row of c }
+// A direct edge reads the identity map (position in b = the staged position itself); an entry that does not count
+// (c == b in a triplet pass) and the M2_UBATCH - 1 padding entries behind the table point at an LDS row that holds only
+// gaps.  The gather therefore has no flags and no special cases: every entry is
+//   r = row[c][lane];  q = map[min(r, len(c) - 1)];  j = col[min(q, len(b) - 1)];  valid = r, q are not gaps
+// and, read with wave-uniform indices, the descriptors arrive by scalar loads -- no descriptor arithmetic on the
+// vector unit, nothing moved through LDS and v_readfirstlane.
+constexpr int M2_UBATCH = 4;   // candidates looked up side by side by k_m2_gather_unit
+typedef const __attribute__((address_space(1))) uint16_t m2_gu16;
+typedef const __attribute__((address_space(1))) int m2_gi32;
+struct __attribute__((aligned(32))) M2Cand {
+    const uint16_t* map;
+    const int* col;
+    int lenc_m1, lenb_m1;
+    int row_off;    // byte offset of the LDS row (M2_MAXN: the all-gaps row)
+    int pad;
+};
+static_assert(sizeof(M2Cand) == 32, "M2Cand is read as one 8-dword scalar load");
+
+__global__ void k_m2_identity(uint16_t* ident) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < 65536) ident[x] = static_cast<uint16_t>(x);
+}
+
+__global__ void __launch_bounds__(64) k_m2_candidates(M2Args A, int round, M2Cand* tab, const long long* tab_off, const uint16_t* ident) {
+    __shared__ int s_b[M2_MAXN];
+    const int g = blockIdx.x;
+    const M2Group G = A.groups[g];
+    if (round >= G.n - 1 || A.ovf[g] != 0) return;
+    const int n = G.n, fm = G.first_member;
+    const int2 jn = A.joins[fm + round];
+    const unsigned maskB = A.nodemask[2 * fm + jn.y];
+    const int lane = threadIdx.x;
+    if (lane < M2_MAXN && ((maskB >> lane) & 1u)) s_b[__popc(maskB & ((1u << lane) - 1u))] = lane;
+    const int nbm = __popc(maskB);
+    __syncthreads();
+    M2Cand* const T = tab + tab_off[g];
+    const int E = nbm * (n + 1);
+    for (int e = lane; e < E + M2_UBATCH - 1; e += 64) {
+        M2Cand C;
+        C.pad = 0;
+        if (e >= E) {   // padding: the batch that holds the last entries reads up to M2_UBATCH - 1 more
+            C.map = ident; C.col = A.col + A.members[fm].col_base; C.lenc_m1 = 0; C.lenb_m1 = 0; C.row_off = M2_MAXN * 128;
+        } else {
+            const int pass = e / nbm, b = s_b[e % nbm];
+            const int cu = pass == 0 ? b : pass - 1;
+            const M2Member Mc = A.members[fm + cu], Mb = A.members[fm + b];
+            C.col = A.col + Mb.col_base;
+            C.lenb_m1 = max(Mb.len - 1, 0);
+            if (pass == 0) { C.map = ident; C.lenc_m1 = 65534; C.row_off = b * 128; }
+            else {
+                const int bslot = cu == b ? 0 : (b < cu ? b : b - 1);
+                C.map = A.map + Mc.map_base + static_cast<long long>(bslot) * Mc.len;
+                C.lenc_m1 = max(Mc.len - 1, 0);
+                C.row_off = (cu == b ? M2_MAXN : cu) * 128;
+            }
+        }
+        T[e] = C;
+    }
+}
+
+// Unit weights: a list entry is one register, (column << 16) | weight (a column is < 65535, a weight at most
+// |A| |B| (n + 1) <= 8448); 0xFFFF0000 is an empty slot, an invalid candidate carries a column no entry can hold.
+// The columns of a list are distinct, so at most one entry matches.  Three tiers, each behind a wave-wide test:
+// entries 0-3; entries 4-7 and the append into 0-7 (some lane of the wave meets a new column at most steps, so
+// this tier has to be short); entries 8-15.
+constexpr unsigned M2_EMPTY = 0xFFFF0000u;
+#define M2_MATCH1(K0, K1)                                                                              \
+    _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                           \
+        const bool m_ = (pe[k_] >> 16) == j_;                                                          \
+        pe[k_] += m_ ? 1u : 0u;                                                                        \
+        hit_ = hit_ || m_;                                                                             \
+    }
+#define M2_APPEND1(K0, K1)                                                                             \
+    {                                                                                                  \
+        const bool app_ = !hit_ && cnt < (K1);                                                         \
+        _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) pe[k_] = (app_ && cnt == k_) ? ((j_ << 16) | 1u) : pe[k_]; \
+        cnt += app_ ? 1 : 0;                                                                           \
+        hit_ = hit_ || app_;                                                                           \
+    }
+#define M2_ADD1(J, VALID)                                                                              \
+    {                                                                                                  \
+        const bool v_ = (VALID);                                                                       \
+        const unsigned j_ = v_ ? static_cast<unsigned>(J) : 0x1FFFFu;                                  \
+        bool hit_ = !v_;                                                                               \
+        M2_MATCH1(0, 4)                                                                                \
+        if (__ballot(!hit_)) {                                                                         \
+            M2_MATCH1(4, 8)                                                                            \
+            M2_APPEND1(0, 8)                                                                           \
+            if (__ballot(!hit_)) {                                                                     \
+                M2_MATCH1(8, M2_CAP)                                                                   \
+                /* a new column; beyond M2_CAP distinct columns it is ignored (spec v2, step 5) */     \
+                M2_APPEND1(8, M2_CAP)                                                                  \
+            }                                                                                          \
+        }                                                                                              \
+    }
+
+__global__ void __launch_bounds__(64) k_m2_gather_unit(M2Args A, int round, const M2Cand* __restrict__ tab, const long long* __restrict__ tab_off) {
+    __shared__ uint16_t s_r[M2_MAXN + 1][64];   // position of the lane's base in every other member (0xFFFF: gap); last row: gaps
+    const int g = blockIdx.y;
+    const M2Group G = A.groups[g];
+    if (round >= G.n - 1 || A.ovf[g] != 0) return;
+    const int n = G.n, fm = G.first_member;
+    const int2 jn = A.joins[fm + round];
+    const unsigned maskA = A.nodemask[2 * fm + jn.x], maskB = A.nodemask[2 * fm + jn.y];
+    const int nA = A.ncols[2 * fm + jn.x];
+    const int E = __popc(maskB) * (n + 1);
+    const M2Cand* const T = tab + tab_off[g];
+    const int lane = threadIdx.x;
+    s_r[M2_MAXN][lane] = static_cast<uint16_t>(M2_NONE);   // (every lane reads its own column of s_r only)
+    const unsigned char* const s_rlane = reinterpret_cast<const unsigned char*>(&s_r[0][lane]);
+    for (int i0 = blockIdx.x * 64; i0 < nA; i0 += gridDim.x * 64) {
+        const int i = i0 + lane;
+        unsigned pe[M2_CAP];
+#pragma unroll
+        for (int k = 0; k < M2_CAP; ++k) pe[k] = M2_EMPTY;
+        int cnt = 0;
+        const bool row = i < nA;
+        for (int a = 0; a < n; ++a) {
+            if (!((maskA >> a) & 1u)) continue;
+            const unsigned p = row ? A.pos[G.pos_base + static_cast<long long>(a) * G.wcap + i] : M2_NONE;
+            const bool havep = p != M2_NONE;
+            if (!__ballot(havep)) continue;
+            const M2Member Ma = A.members[fm + a];
+            {   // positions in every other member: unconditional loads (clamped), selected afterwards
+                const unsigned pidx = havep ? p : 0u;
+                for (int c0 = 0; c0 < n; c0 += 8) {
+                    uint16_t rv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = min(c0 + u, n - 1);
+                        const int slot = c == a ? 0 : (c < a ? c : c - 1);
+                        rv[u] = A.map[Ma.map_base + static_cast<long long>(slot) * Ma.len + pidx];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (c0 + u < n) s_r[c0 + u][lane] = (c0 + u != a && havep) ? rv[u] : static_cast<uint16_t>(M2_NONE);
+                }
+            }
+            for (int f0 = 0; f0 < E; f0 += M2_UBATCH) {
+                unsigned rr[M2_UBATCH], qq[M2_UBATCH];
+                int jj[M2_UBATCH];
+                // the map lookups of the batch, then the column lookups, each requested back to back
+#pragma unroll
+                for (int u = 0; u < M2_UBATCH; ++u) {
+                    const M2Cand& C = T[f0 + u];
+                    rr[u] = *reinterpret_cast<const uint16_t*>(s_rlane + C.row_off);
+                    // (the pointers are global memory: said explicitly, a pointer read from memory would be dereferenced
+                    // by flat loads, which wait on the LDS counter as well)
+                    qq[u] = ((m2_gu16*)C.map)[min(rr[u], static_cast<unsigned>(C.lenc_m1))];   // (a gap clamps to a valid index)
+                }
+#pragma unroll
+                for (int u = 0; u < M2_UBATCH; ++u)
+                    jj[u] = ((m2_gi32*)T[f0 + u].col)[min(qq[u], static_cast<unsigned>(T[f0 + u].lenb_m1))];
+#pragma unroll
+                for (int u = 0; u < M2_UBATCH; ++u) M2_ADD1(jj[u], rr[u] != M2_NONE && qq[u] != M2_NONE)
+            }
+        }
+        if (row) {
+            // noise filter and ordering by column: as in k_m2_gather
+            int ej[M2_CAP], ew[M2_CAP];
+#pragma unroll
+            for (int k = 0; k < M2_CAP; ++k) { ej[k] = k < cnt ? static_cast<int>(pe[k] >> 16) : -1; ew[k] = k < cnt ? static_cast<int>(pe[k] & 0xffffu) : 0; }
+            int wmax = 0;
+#pragma unroll
+            for (int k = 0; k < M2_CAP; ++k) wmax = max(wmax, ew[k]);
+            {
+                int kept = 0;
+#pragma unroll
+                for (int k = 0; k < M2_CAP; ++k) {
+                    const bool keep = k < cnt && 2 * ew[k] >= wmax;
+                    if (!keep) ej[k] = 0x7fffffff;
+                    kept += keep ? 1 : 0;
+                }
+                cnt = kept;
+            }
+            unsigned long long* const mine = A.row_ent + (G.row_base + i) * static_cast<long long>(G.cap);
+#pragma unroll
+            for (int k = 0; k < M2_CAP; ++k) {
+                if (ej[k] != 0x7fffffff && ej[k] >= 0) {
+                    int rank = 0;
+#pragma unroll
+                    for (int q = 0; q < M2_CAP; ++q)
+                        if (ej[q] >= 0 && ej[q] < ej[k]) ++rank;
+                    mine[rank] = (static_cast<unsigned long long>(static_cast<unsigned>(ej[k])) << 32) | static_cast<unsigned>(ew[k]);
+                }
+            }
+            A.row_cnt[G.row_base + i] = static_cast<uint16_t>(cnt);
+        }
+    }
+}
+#undef M2_ADD1
+#undef M2_MATCH1
+#undef M2_APPEND1
+#undef M2_ADD
+
 // maximum of a 64-bit value over the 16 lanes of a DPP row
 __device__ __forceinline__ unsigned long long m2_rowmax16(unsigned long long v) {
     // maximum over the 16 lanes of a DPP row, delivered to every lane of the row (row_ror 8, 4, 2, 1)
@@ -1032,6 +1232,17 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     // The groups of a batch are ordered by size (m2_plan), so the groups that still have a join to do in round r
     // are a prefix of the batch.
     const bool unitw = a.ma <= 1 && a.mm <= 1;
+    // unit weights: per-round candidate descriptors (k_m2_candidates), < n^2 entries of two int4 per group
+    const bool old_gather = std::getenv("SARLACC_MSA2_OLDGATHER") != nullptr;
+    M2Cand* d_tab = nullptr; long long* d_toff = nullptr; uint16_t* d_ident = nullptr;
+    if (unitw && !old_gather) {
+        std::vector<long long> toff(ng + 1, 0);
+        for (size_t q = 0; q < ng; ++q) toff[q + 1] = toff[q] + static_cast<long long>(B.groups[q].n) * B.groups[q].n + M2_UBATCH;   // (n - 1)(n + 1) entries + padding
+        SL_TRY(upload((pf + ".toff").c_str(), toff.data(), toff.size(), &d_toff, s));
+        SL_TRY(scratch((pf + ".tab").c_str(), static_cast<size_t>(toff[ng]) + 1, &d_tab));
+        SL_TRY(scratch("msa2.ident", 65536, &d_ident));
+        hipLaunchKernelGGL(k_m2_identity, dim3(256), dim3(256), 0, s, d_ident);
+    }
     // exact chain kernel: Fenwick tree in LDS while it fits 64 KB, in HBM for wider profiles
     const size_t exact_base = sizeof(unsigned long long) * (64 * M2_CAP + M2_CAP) + sizeof(int) * (M2_CAP + 64);
     const bool exact_gbit = exact_base + sizeof(unsigned long long) * (static_cast<size_t>(B.max_wcap) + 2) > 64 * 1024;
@@ -1045,7 +1256,10 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
         while (nactive < static_cast<int>(ng) && B.groups[nactive].n - 1 > round) ++nactive;
         if (nactive == 0) break;
         const dim3 ggrid(std::min(128u, m2_blocks(B.max_wcap, 64)), static_cast<unsigned>(nactive));
-        if (unitw) hipLaunchKernelGGL(k_m2_gather<true>, ggrid, dim3(64), 0, s, a, round);
+        if (unitw && !old_gather) {
+            hipLaunchKernelGGL(k_m2_candidates, dim3(static_cast<unsigned>(nactive)), dim3(64), 0, s, a, round, d_tab, d_toff, d_ident);
+            hipLaunchKernelGGL(k_m2_gather_unit, ggrid, dim3(64), 0, s, a, round, d_tab, d_toff);
+        } else if (unitw) hipLaunchKernelGGL(k_m2_gather<true>, ggrid, dim3(64), 0, s, a, round);
         else hipLaunchKernelGGL(k_m2_gather<false>, ggrid, dim3(64), 0, s, a, round);
         hipLaunchKernelGGL(k_m2_chain_q, dim3(m2_blocks(nactive, 4)), dim3(64), 0, s, a, round, nactive);
         // rounds the window could not answer (unrelated reads in the cluster): exact chain search
