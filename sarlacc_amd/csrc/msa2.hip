@@ -18,7 +18,8 @@
 // Kernels, per merge round k (every group performs its k-th join in the same launches):
 //   k_m2_gather  lane = column i of the first child; walks the library (map -> map -> col) for every
 //                member pair and third sequence, sums the weights per partner column in a private list
-//                (LDS), writes the list sorted by column;
+//                (registers), writes the list sorted by column; with unit weights (the default scores)
+//                k_m2_candidates + k_m2_gather_unit: the round's (c, b) pairs as a table of scalar descriptors;
 //   k_m2_chain   one wavefront per group: heaviest chain over the lists in row order with a Fenwick tree
 //                of prefix maxima in LDS (16 lanes read / update the <= 16 nodes of one match in one
 //                instruction), then the traceback through the stored predecessors;
