@@ -214,6 +214,35 @@ def test_msa_band_cap_degrades_the_pair_not_the_batch(oracle, spec):
     assert alone[0] == calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)[0]
 
 
+def test_msa_spec2_gather_kernels_agree(monkeypatch):
+    """Unit weights take the table-driven gather (k_m2_candidates + k_m2_gather_unit); SARLACC_MSA2_OLDGATHER=1 sends the
+    same call through the general kernel.  Rows must be identical, on ordinary clusters, on clusters of two molecules and
+    on groups of very different sizes in one batch (candidate tables of n^2 entries each)."""
+    from sarlacc_amd import calls
+    from sarlacc_amd.mock import NUC, mutate
+    rng = np.random.default_rng(77)
+    reads, groups = [], []
+    for n, length, nmol in [(2, 300, 1), (3, 150, 1), (10, 700, 1), (16, 400, 2), (32, 200, 3), (7, 0, 1), (9, 1100, 1)]:
+        truths = [NUC[rng.integers(0, 4, length)] for _ in range(nmol)]
+        idx = []
+        for k in range(n):
+            reads.append(mutate(truths[k % nmol], rng, 0.05, 0.02).tobytes().decode())
+            idx.append(len(reads))
+        groups.append(idx)
+    calls.set_msa_spec(2)
+    try:
+        for params in [(0, -1, -5, -1, 100), (1, -2, -2, -2, 20)]:
+            new = calls.quick_msa(groups, reads, *params)
+            monkeypatch.setenv("SARLACC_MSA2_OLDGATHER", "1")
+            old = calls.quick_msa(groups, reads, *params)
+            monkeypatch.delenv("SARLACC_MSA2_OLDGATHER")
+            assert new == old
+            for rows, g in zip(new, groups):
+                assert [r.replace("-", "") for r in rows] == [reads[i - 1] for i in g]
+    finally:
+        calls.set_msa_spec(0)
+
+
 @pytest.mark.parametrize("seed,nmol,per,length", [(41, 2, 9, 500), (42, 3, 8, 400), (43, 2, 15, 900), (44, 4, 7, 250)])
 def test_msa_spec2_umi_collisions(oracle, seed, nmol, per, length):
     """Clusters of several unrelated molecules (UMI collisions: a quarter of the clusters at 10^5 molecules): their
