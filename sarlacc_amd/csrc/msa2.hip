@@ -618,10 +618,12 @@ constexpr int M2_PWIN = 512;
 constexpr int M2_L1 = M2_PWIN, M2_L2 = M2_PWIN + M2_PWIN / 8, M2_PSIZE = M2_PWIN + M2_PWIN / 8 + M2_PWIN / 64;
 
 __device__ __forceinline__ int m2_qmax_i32(int v) {   // maximum over the 16 lanes of a DPP row, in every lane
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false));
+    // one v_max_i32_dpp per rotation (every lane of a rotation has a source, so there is no `old` operand to keep; written
+    // as asm because the compiler emits a move + a DPP move + a maximum for the builtin).  s_nop 1: a DPP operand read
+    // needs two wait states after the VALU write of that register.
+#define M2_QSTEP(ROR) asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %1 row_ror:" #ROR " row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(v));
+    M2_QSTEP(8) M2_QSTEP(4) M2_QSTEP(2) M2_QSTEP(1)
+#undef M2_QSTEP
     return v;
 }
 
