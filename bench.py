@@ -63,7 +63,7 @@ def pmc_record(kernel, sources):
     collected from inside this process).  Returned only while the kernel's source files still hash to
     what was profiled, so stale counters never sit next to fresh timings."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s*.json" % kernel)),
-                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+                   key=lambda f: (["_final_" in os.path.basename(f)], [int(x) for x in re.findall(r"\d+", os.path.basename(f))]))
     for f in reversed(files):
         with open(f) as fh:
             d = json.load(fh)
