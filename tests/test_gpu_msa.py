@@ -119,6 +119,43 @@ def test_fused_msa_consensus_equals_two_calls(quality):
     assert len(got[0]) == len(groups) and got[0][5] == ""
 
 
+@pytest.mark.parametrize("spec", [1, 2])
+def test_fused_long_rows_with_many_insertions(spec):
+    """Rows of many writer tiles (12-kb reads) with insertion-rich alignments (5 % indels: columns that exist in one
+    read only, runs of them after homopolymers) and lower-case / non-base characters in the reads: the fused call on
+    vote codes against the two-call route on character rows, both MSA specs."""
+    import sarlacc_amd
+    from sarlacc_amd import calls
+    from sarlacc_amd.mock import NUC, mutate
+    from sarlacc_amd.strset import StringSet, csr_from_lists
+    rng = np.random.default_rng(90 + spec)
+    reads, groups = [], []
+    for n, length in [(5, 12000), (3, 7000), (2, 300), (1, 500)]:
+        truth = NUC[rng.integers(0, 4, length)]
+        idx = []
+        for _ in range(n):
+            r = bytearray(mutate(truth, rng, 0.03, 0.05).tobytes())
+            for pos in rng.integers(0, len(r), 6):
+                r[pos] = ord("acgtnRY"[int(rng.integers(0, 7))])
+            reads.append(r.decode())
+            idx.append(len(reads))
+        groups.append(idx)
+    quals = ["".join(chr(int(c)) for c in rng.integers(35, 100, len(r))) for r in reads]
+    goff, gvals = csr_from_lists(groups)
+    enc = sarlacc_amd.phred_encoding()
+    calls.set_msa_spec(spec)
+    try:
+        rows, grp_rows, _ = calls.quick_msa_flat(goff, gvals, reads, 0, -1, -5, -1, 100)
+        qsub = StringSet.from_strings(quals).subset(gvals[:int(goff[-1])].astype(np.int64) - 1)
+        want = calls.create_consensus_flat(rows, grp_rows, 0.6, quals=qsub, encoding=enc)
+        got = calls.msa_consensus_flat(goff, gvals, reads, 0, -1, -5, -1, 100, 0.6, quals=quals, encoding=enc)
+    finally:
+        calls.set_msa_spec(0)
+    assert got[0].to_strings() == want[0].to_strings()
+    assert got[1].to_strings() == want[1].to_strings()
+    assert len(got[0][0]) > 10000
+
+
 def test_msa_long_reads(oracle):
     """40-kb reads: read and centre codes take more than the default 64 KB of dynamic LDS."""
     from sarlacc_amd import calls
