@@ -69,6 +69,7 @@ struct M2Group {
 };
 
 struct M2Args {
+    int g0;                        // first group of this launch (the round kernels run on sub-ranges of a batch, one per stream)
     const uint8_t* seq;
     const M2Group* groups;
     const M2Member* members;
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
     __shared__ long long s_mapbase[M2_MAXN], s_colbase[M2_MAXN], s_seqoff[M2_MAXN];   // the members' descriptors
     __shared__ int s_len[M2_MAXN];
     __shared__ int s_b[M2_MAXN];   // the second child's members, ascending
-    const int g = blockIdx.y;
+    const int g = A.g0 + blockIdx.y;
     const M2Group G = A.groups[g];
     if (round >= G.n - 1 || A.ovf[g] != 0) return;
     const int n = G.n, fm = G.first_member;
@@ -412,7 +413,7 @@ __global__ void k_m2_identity(uint16_t* ident) {
 
 __global__ void __launch_bounds__(64) k_m2_candidates(M2Args A, int round, M2Cand* tab, const long long* tab_off, const uint16_t* ident) {
     __shared__ int s_b[M2_MAXN];
-    const int g = blockIdx.x;
+    const int g = A.g0 + blockIdx.x;
     const M2Group G = A.groups[g];
     if (round >= G.n - 1 || A.ovf[g] != 0) return;
     const int n = G.n, fm = G.first_member;
@@ -485,7 +486,7 @@ constexpr unsigned M2_EMPTY = 0xFFFF0000u;
 
 __global__ void __launch_bounds__(64) k_m2_gather_unit(M2Args A, int round, const M2Cand* __restrict__ tab, const long long* __restrict__ tab_off) {
     __shared__ uint16_t s_r[M2_MAXN + 1][64];   // position of the lane's base in every other member (0xFFFF: gap); last row: gaps
-    const int g = blockIdx.y;
+    const int g = A.g0 + blockIdx.y;
     const M2Group G = A.groups[g];
     if (round >= G.n - 1 || A.ovf[g] != 0) return;
     const int n = G.n, fm = G.first_member;
@@ -630,7 +631,7 @@ __device__ __forceinline__ int m2_qmax_i32(int v) {   // maximum over the 16 lan
 __global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nactive) {
     __shared__ unsigned long long s_buf[4][M2_PSIZE > 256 ? M2_PSIZE : 256];   // the three levels, later the traceback stage
     const int lane = threadIdx.x, qd = lane >> 4, t = lane & 15;
-    const int g = blockIdx.x * 4 + qd;
+    const int g = A.g0 + blockIdx.x * 4 + qd;
     bool act = g < nactive;
     M2Group G{};
     if (act) G = A.groups[g];
@@ -789,7 +790,7 @@ __global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nact
 template <bool GBIT>
 __global__ void __launch_bounds__(64) k_m2_chain_exact(M2Args A, int round, unsigned long long* gbit) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int g = blockIdx.x;
+    const int g = A.g0 + blockIdx.x;
     if (!A.redo[g]) return;
     const M2Group G = A.groups[g];
     const int fm = G.first_member;
@@ -930,7 +931,7 @@ __device__ __forceinline__ int m2_suffix_min_incl(int v) {          // inclusive
 
 // ---- new column numbers, col / pos of every member: one workgroup of 256 threads per group ----
 __global__ void __launch_bounds__(256) k_m2_merge(M2Args A, int round, int* ncA, int* ncB, int* partB) {
-    const int g = blockIdx.x;
+    const int g = A.g0 + blockIdx.x;
     const M2Group G = A.groups[g];
     if (round >= G.n - 1 || A.ovf[g] != 0) return;
     const int n = G.n, fm = G.first_member;
@@ -1166,6 +1167,24 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
     return 0;
 }
 
+// streams of the round loop (created once per process, non-blocking: the caller's stream may be the legacy default one)
+struct M2Streams {
+    std::vector<hipStream_t> st;
+    std::vector<hipEvent_t> join;
+    hipEvent_t fork = nullptr;
+    int ensure(int n) {
+        if (!fork) SL_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        while (static_cast<int>(st.size()) < n) {
+            hipStream_t x; hipEvent_t e;
+            SL_HIP(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+            SL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            st.push_back(x); join.push_back(e);
+        }
+        return 0;
+    }
+};
+static M2Streams& m2_streams() { static M2Streams m; return m; }
+
 static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq, double match, double mismatch, double gap_extension,
                         double gap_opening, int bandwidth, bool exact, const std::function<int()>* overlap, double* cells, hipStream_t s) {
     Context& c = ctx();
@@ -1254,20 +1273,51 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     if (exact_gbit) SL_TRY(scratch((pf + ".gbit").c_str(), static_cast<size_t>(row_n) + ng + 1, &d_gbit));
     else if (exact_lds > 48 * 1024)
         SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_m2_chain_exact<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(exact_lds)));
+    // The groups of a batch are cut into NS contiguous ranges, each with a stream of its own: the chain kernels are
+    // serial per group (few, long wavefronts), the gather is wide, so a range's chain runs under another range's
+    // gather.  A group stays in its range for all rounds (its kernels stay in order on one stream).
+    int NS = 2;   // (measured at C4: 1 stream 1.04 s, 2 streams 0.90 s, 3 and 4 streams 1.11-1.12 s -- beyond the hardware queues a process gets)
+    if (const char* e = std::getenv("SARLACC_MSA2_STREAMS")) NS = std::min(8, std::max(1, std::atoi(e)));
+    if (a.xdbg || std::getenv("SARLACC_MSA2_DEBUG") || a.clk) NS = 1;
+    if (ng < 64) NS = 1;
+    const bool stagger = !std::getenv("SARLACC_MSA2_NOSTAGGER");
+    M2Streams& MS = m2_streams();
+    if (NS > 1) SL_TRY(MS.ensure(NS));
+    std::vector<int> cut(static_cast<size_t>(NS) + 1, 0);
+    for (int k = 0; k <= NS; ++k) cut[k] = static_cast<int>((static_cast<long long>(ng) * k / NS) / 4 * 4);
+    cut[NS] = static_cast<int>(ng);
+    if (NS > 1) {
+        SL_HIP(hipEventRecord(MS.fork, s));
+        for (int k = 0; k < NS; ++k) SL_HIP(hipStreamWaitEvent(MS.st[k], MS.fork, 0));
+    }
     for (int round = 0; round + 1 < B.max_n; ++round) {
         int nactive = 0;
         while (nactive < static_cast<int>(ng) && B.groups[nactive].n - 1 > round) ++nactive;
         if (nactive == 0) break;
-        const dim3 ggrid(std::min(128u, m2_blocks(B.max_wcap, 64)), static_cast<unsigned>(nactive));
-        if (unitw && !old_gather) {
-            hipLaunchKernelGGL(k_m2_candidates, dim3(static_cast<unsigned>(nactive)), dim3(64), 0, s, a, round, d_tab, d_toff, d_ident);
-            hipLaunchKernelGGL(k_m2_gather_unit, ggrid, dim3(64), 0, s, a, round, d_tab, d_toff);
-        } else if (unitw) hipLaunchKernelGGL(k_m2_gather<true>, ggrid, dim3(64), 0, s, a, round);
-        else hipLaunchKernelGGL(k_m2_gather<false>, ggrid, dim3(64), 0, s, a, round);
-        hipLaunchKernelGGL(k_m2_chain_q, dim3(m2_blocks(nactive, 4)), dim3(64), 0, s, a, round, nactive);
-        // rounds the window could not answer (unrelated reads in the cluster): exact chain search
-        if (exact_gbit) hipLaunchKernelGGL(k_m2_chain_exact<true>, dim3(static_cast<unsigned>(nactive)), dim3(64), exact_lds, s, a, round, d_gbit);
-        else hipLaunchKernelGGL(k_m2_chain_exact<false>, dim3(static_cast<unsigned>(nactive)), dim3(64), exact_lds, s, a, round, d_gbit);
+        for (int k = 0; k < NS; ++k) {
+            const int lo = cut[k], hi = std::min(cut[k + 1], nactive);
+            if (lo >= hi) continue;
+            const unsigned cnt = static_cast<unsigned>(hi - lo);
+            hipStream_t sk = NS > 1 ? MS.st[k] : s;
+            M2Args ak = a;
+            ak.g0 = lo;
+            const dim3 ggrid(std::min(128u, m2_blocks(B.max_wcap, 64)), cnt);
+            // first round: a range starts when the one before it has finished its gather, so that from then on the
+            // ranges are out of phase (their kernels have the same lengths: started together they would stay together)
+            if (NS > 1 && round == 0 && k > 0 && stagger) SL_HIP(hipStreamWaitEvent(sk, MS.join[k - 1], 0));
+            if (unitw && !old_gather) {
+                hipLaunchKernelGGL(k_m2_candidates, dim3(cnt), dim3(64), 0, sk, ak, round, d_tab, d_toff, d_ident);
+                hipLaunchKernelGGL(k_m2_gather_unit, ggrid, dim3(64), 0, sk, ak, round, d_tab, d_toff);
+            } else if (unitw) hipLaunchKernelGGL(k_m2_gather<true>, ggrid, dim3(64), 0, sk, ak, round);
+            else hipLaunchKernelGGL(k_m2_gather<false>, ggrid, dim3(64), 0, sk, ak, round);
+            if (NS > 1 && round == 0 && stagger) SL_HIP(hipEventRecord(MS.join[k], sk));
+            hipLaunchKernelGGL(k_m2_chain_q, dim3(m2_blocks(cnt, 4)), dim3(64), 0, sk, ak, round, hi);
+            // rounds the window could not answer (unrelated reads in the cluster): exact chain search
+            if (exact_gbit) hipLaunchKernelGGL(k_m2_chain_exact<true>, dim3(cnt), dim3(64), exact_lds, sk, ak, round, d_gbit);
+            else hipLaunchKernelGGL(k_m2_chain_exact<false>, dim3(cnt), dim3(64), exact_lds, sk, ak, round, d_gbit);
+            if (NS > 1) hipLaunchKernelGGL(k_m2_merge, dim3(cnt), dim3(256), 0, sk, ak, round, d_nca, d_ncb, d_pb);
+        }
+        SL_HIP(hipGetLastError());
         if (a.xdbg) {
             SL_HIP(hipStreamSynchronize(s));
             std::vector<unsigned long long> hx(2 * ng);
@@ -1278,7 +1328,7 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
             fprintf(stderr, "exact round %d: active %d flagged %d  cycles max %llu (group %d n=%d rows %llu entries %llu) sum %llu\n", round, nactive, cntf, mx,
                     mxg, mxg >= 0 ? B.groups[mxg].n : 0, mxinfo >> 32, mxinfo & 0xffffffffull, sum);
         }
-        hipLaunchKernelGGL(k_m2_merge, dim3(static_cast<unsigned>(nactive)), dim3(256), 0, s, a, round, d_nca, d_ncb, d_pb);
+        if (NS == 1) hipLaunchKernelGGL(k_m2_merge, dim3(static_cast<unsigned>(nactive)), dim3(256), 0, s, a, round, d_nca, d_ncb, d_pb);
         SL_HIP(hipGetLastError());
         if (std::getenv("SARLACC_MSA2_DEBUG")) {   // first group of the batch, for comparison with ORC_MSA2_DEBUG of the oracle
             SL_HIP(hipStreamSynchronize(s));
@@ -1303,6 +1353,11 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
             }
         }
     }
+    if (NS > 1)
+        for (int k = 0; k < NS; ++k) {
+            SL_HIP(hipEventRecord(MS.join[k], MS.st[k]));
+            SL_HIP(hipStreamWaitEvent(s, MS.join[k], 0));
+        }
     if (d_clk) {
         unsigned long long hc[8];
         SL_HIP(hipMemcpy(hc, d_clk, sizeof hc, hipMemcpyDeviceToHost));
