@@ -1172,7 +1172,15 @@ struct M2Streams {
     std::vector<hipStream_t> st;
     std::vector<hipEvent_t> join;
     hipEvent_t fork = nullptr;
+    int device = -1;
     int ensure(int n) {
+        if (device != ctx().device) {   // (streams and events belong to the device that was current when they were made)
+            for (hipStream_t x : st) (void)hipStreamDestroy(x);
+            for (hipEvent_t e : join) (void)hipEventDestroy(e);
+            if (fork) (void)hipEventDestroy(fork);
+            st.clear(); join.clear(); fork = nullptr;
+            device = ctx().device;
+        }
         if (!fork) SL_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
         while (static_cast<int>(st.size()) < n) {
             hipStream_t x; hipEvent_t e;
