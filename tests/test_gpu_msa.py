@@ -251,6 +251,37 @@ def test_msa_band_cap_degrades_the_pair_not_the_batch(oracle, spec):
     assert alone[0] == calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)[0]
 
 
+@pytest.mark.parametrize("ngroups", [64, 70, 131])
+def test_msa_spec2_two_round_streams(oracle, ngroups, monkeypatch):
+    """From 64 groups on, the merge rounds of spec v2 run on two streams over two contiguous ranges of the batch (cut at a
+    multiple of 4 groups; groups sorted by size, so the later rounds leave the second range empty): rows identical to
+    the CPU statement and to the single-stream run."""
+    from sarlacc_amd import calls
+    from sarlacc_amd.mock import NUC, mutate
+    rng = np.random.default_rng(500 + ngroups)
+    reads, groups = [], []
+    for g in range(ngroups):
+        n = int(rng.choice([2, 3, 4, 5, 9]))
+        truth = NUC[rng.integers(0, 4, int(rng.integers(40, 160)))]
+        idx = []
+        for _ in range(n):
+            reads.append(mutate(truth, rng, 0.05, 0.02).tobytes().decode())
+            idx.append(len(reads))
+        groups.append(idx)
+    calls.set_msa_spec(2)
+    try:
+        got = calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)
+        monkeypatch.setenv("SARLACC_MSA2_STREAMS", "1")
+        one = calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)
+        monkeypatch.delenv("SARLACC_MSA2_STREAMS")
+    finally:
+        calls.set_msa_spec(0)
+    assert got == one
+    want = oracle.quick_msa(groups, reads, 0, -1, -5, -1, 100, spec=2)
+    for g, (a, b) in enumerate(zip(got, want)):
+        assert a == b, "group %d differs" % g
+
+
 def test_msa_spec2_gather_kernels_agree(monkeypatch):
     """Unit weights take the table-driven gather (k_m2_candidates + k_m2_gather_unit); SARLACC_MSA2_OLDGATHER=1 sends the
     same call through the general kernel.  Rows must be identical, on ordinary clusters, on clusters of two molecules and
