@@ -1285,9 +1285,10 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     // serial per group (few, long wavefronts), the gather is wide, so a range's chain runs under another range's
     // gather.  A group stays in its range for all rounds (its kernels stay in order on one stream).
     int NS = 2;   // (measured at C4: 1 stream 1.04 s, 2 streams 0.90 s, 3 and 4 streams 1.11-1.12 s -- beyond the hardware queues a process gets)
-    if (const char* e = std::getenv("SARLACC_MSA2_STREAMS")) NS = std::min(8, std::max(1, std::atoi(e)));
+    size_t min_groups = 64;   // below that a batch is not worth two queues
+    if (const char* e = std::getenv("SARLACC_MSA2_STREAMS")) { NS = std::min(8, std::max(1, std::atoi(e))); min_groups = 8; }   // (testing: small batches too)
     if (a.xdbg || std::getenv("SARLACC_MSA2_DEBUG") || a.clk) NS = 1;
-    if (ng < 64) NS = 1;
+    if (ng < min_groups) NS = 1;
     const bool stagger = !std::getenv("SARLACC_MSA2_NOSTAGGER");
     M2Streams& MS = m2_streams();
     if (NS > 1) SL_TRY(MS.ensure(NS));

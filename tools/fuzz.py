@@ -151,8 +151,9 @@ def case_consensus(rng):
 def case_msa(rng):
     from sarlacc_amd.mock import NUC, mutate
     reads, groups = [], []
-    for _ in range(int(rng.integers(1, 6))):
-        L = int(rng.choice([0, 5, 60, 300, 900]))
+    many = rng.random() < 0.15   # many small groups: batches wide enough for the two round streams of spec v2
+    for _ in range(int(rng.integers(8, 48)) if many else int(rng.integers(1, 6))):
+        L = int(rng.choice([0, 5, 40, 90])) if many else int(rng.choice([0, 5, 60, 300, 900]))
         truth = NUC[rng.integers(0, 4, L)]
         idx = []
         for _ in range(int(rng.integers(0, 9))):
