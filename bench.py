@@ -16,7 +16,9 @@ kernels.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--read-len L]
 
-For N > 1 launch with torch.distributed.run (one rank per GPU).  Reads shard across ranks
+For N > 1: one rank per GPU under torch.distributed.run -- either started by the caller (RANK / WORLD_SIZE in
+the environment) or, when `python bench.py --gpus N` is run bare, by bench.py itself as a child process; --gpus
+larger than the visible device count is an error, never a silent one-GPU run.  Reads shard across ranks
 (weak scaling: --reads and --molecules are per GPU); the DP has no data-path collective,
 the pipeline all-gathers the UMI cluster labels over RCCL (configs[4] in miniature).
 Rank 0 prints one JSON line.
@@ -123,20 +125,38 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true")
     ap.add_argument("--no-host-pointer", action="store_true", help="skip the PCIe-inclusive host-pointer figures")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    backend = os.environ.get("SARLACC_DIST_BACKEND", "nccl")  # gloo only to exercise this path on one GPU
-    ndev = torch.cuda.device_count()
+    share = os.environ.get("SARLACC_BENCH_SHARE_GPU") == "1"   # rehearsal: several ranks on one card (never a measurement)
+    ndev = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
     if ndev < 1:
         raise SystemExit("bench.py needs a HIP device")
+    if args.gpus > ndev and not share:
+        raise SystemExit("--gpus %d, but only %d HIP device(s) are visible" % (args.gpus, ndev))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started without a launcher: start the ranks ourselves -- as a fresh CHILD process, before anything in this
+        # process has touched the GPU (never re-exec a process that has) -- relay its output and exit with its code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("SARLACC_DIST_BACKEND", "nccl")  # gloo only to exercise this path on one GPU
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)   # before the process group: RCCL binds its communicator to the current device
     device = torch.device("cuda", dev_index)
@@ -308,6 +328,7 @@ def main():
                 "stage_s": dict(zip(names, mx[3:3 + len(names)])), "kernel_ms": kms,
                 "all_gather": {"seconds": mx[2], "bytes_received_total": int(sm[4]), "backend": backend if world > 1 else None},
                 "n_ranks_seen": n_seen,
+                "clusters_all_ranks": last["clusters_all_ranks"],
                 "workload": "%d molecules x %d reads x %d bp per GPU generated in HBM, %d-bp UMIs: umi_group(threshold %d, one "
                             "pre-group per GPU) -> label all-gather -> msa_consensus (quick_msa bandwidth 100 + quality "
                             "consensus, rows stay in HBM); reads and qualities resident, UMIs / group lists / consensus "

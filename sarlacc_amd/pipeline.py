@@ -30,12 +30,14 @@ def labels_from_clusters(coff, cmem, n):
 def clusters_from_labels(label, pos):
     """Inverse of labels_from_clusters for one pre-group: CSR (coff, cmem) in cluster order."""
     have = np.flatnonzero(label >= 0)
-    order = have[np.lexsort((pos[have], label[have]))]
-    k = int(label[have].max()) + 1 if have.size else 0
-    sizes = np.bincount(label[have], minlength=k)
+    lab = label[have].astype(np.int64)
+    k = int(lab.max()) + 1 if have.size else 0
+    sizes = np.bincount(lab, minlength=k)
     coff = np.zeros(k + 1, np.int64)
     np.cumsum(sizes, out=coff[1:])
-    return coff, (order + 1).astype(np.int32)
+    cmem = np.zeros(have.size, np.int32)
+    cmem[coff[lab] + pos[have]] = (have + 1).astype(np.int32)   # (label, position) names the slot: a scatter, no sort
+    return coff, cmem
 
 
 def all_gather_labels(label, pos, dist, device_t=None):
@@ -73,10 +75,18 @@ def run_resident(umis, d_seq, d_qual, off_host, encoding, threshold=1, bandwidth
     umi_ms = _lib.stage_ms("umi_pairs")
     gathered = None
     gather_s, gather_bytes = 0.0, 0
+    clusters_all_ranks = int(coff.size - 1)
     label, pos = labels_from_clusters(coff, cmem, n)
     if dist is not None and dist.get_world_size() > 1:
         labs, poss, gather_s, gather_bytes = all_gather_labels(label, pos, dist, gather_device)
         gathered = (labs, poss)
+        # the exchange's result is what the rest of the pass runs on: this rank's clusters are rebuilt from its
+        # row of the gathered labels (and must be the ones it sent), the other rows give the global assignment
+        coff_g, cmem_g = clusters_from_labels(labs[dist.get_rank()], poss[dist.get_rank()])
+        if not (np.array_equal(coff_g, coff) and np.array_equal(cmem_g, cmem)):
+            raise RuntimeError("all-gathered cluster labels do not rebuild this rank's clusters")
+        coff, cmem = coff_g, cmem_g
+        clusters_all_ranks = int((labs.max(axis=1) + 1).sum())
     t2 = time.perf_counter()
     goff, gflat = calls.csr_select(coff, cmem, np.diff(coff) >= min_cluster)
     t3 = time.perf_counter()
@@ -87,7 +97,7 @@ def run_resident(umis, d_seq, d_qual, off_host, encoding, threshold=1, bandwidth
         "cons": cons, "phred": phred, "coff": coff, "cmem": cmem, "goff": goff, "gflat": gflat, "gathered": gathered,
         "stage_s": {"umi_group": t1 - t0, "label_exchange": t2 - t1, "host_glue": t3 - t2, "msa_consensus": t4 - t3,
                     "total": t4 - t0},
-        "all_gather_s": gather_s, "all_gather_bytes": gather_bytes,
+        "all_gather_s": gather_s, "all_gather_bytes": gather_bytes, "clusters_all_ranks": clusters_all_ranks,
         "kernel_ms": {"umi_pairs": umi_ms, "msa_pairwise": _lib.stage_ms("msa_pairwise"),
                       "msa_merge": _lib.stage_ms("msa_merge"), "consensus": _lib.stage_ms("consensus")},
         "counts": {"msa_pairs": _lib.stage_count("msa_pairs"), "msa_cells": _lib.stage_count("msa_cells"),

@@ -174,7 +174,7 @@ def test_bench_two_ranks_prints_the_contract_line():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, SARLACC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, SARLACC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", SARLACC_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--reads", "20000", "--read-len", "500", "--molecules", "1500", "--copies", "6", "--no-cpu", "--no-host-pointer"]
@@ -192,3 +192,78 @@ def test_bench_two_ranks_prints_the_contract_line():
     assert p["reads"] == 2 * 1500 * 6 and p["n_ranks_seen"] == 2
     assert p["all_gather"]["backend"] == "gloo" and p["all_gather"]["bytes_received_total"] == 2 * 2 * 4 * 1500 * 6
     assert p["consensus_reads"] > 0 and p["reads_per_min"] > 0 and set(p["rooflines"]) == {"k_msa_pairwise_pk", "k_consensus_code"}
+    assert p["clusters_all_ranks"] >= p["consensus_reads"]
+
+
+def test_bench_starts_its_own_ranks_and_refuses_missing_gpus():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts torch.distributed.run itself as a
+    child process (two ranks sharing this GPU over gloo here) and relays the one JSON line with n_gpus = 2;
+    without the sharing switch the same command on a one-GPU box exits non-zero instead of printing n_gpus: 1."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        base.pop(k, None)
+    args = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", "8000",
+            "--read-len", "400", "--molecules", "600", "--copies", "6", "--no-cpu", "--no-host-pointer"]
+    env = dict(base, SARLACC_DIST_BACKEND="gloo", SARLACC_BENCH_SHARE_GPU="1")
+    res = subprocess.run(args, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [x for x in res.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["pipeline"]["n_ranks_seen"] == 2
+    if torch.cuda.device_count() < 2:
+        res = subprocess.run(args, env=base, capture_output=True, text=True, timeout=300)
+        assert res.returncode != 0 and not [x for x in res.stdout.splitlines() if x.startswith("{")]
+        assert "HIP device" in res.stderr
+
+
+def test_rccl_label_all_gather_world_size_one():
+    """The RCCL code path itself (backend "nccl" IS RCCL on ROCm), which the two-rank tests cannot take on a one-GPU
+    box: a process group of one rank, the pipeline's all-gather of cluster labels on device tensors, and the
+    gathered row rebuilding the clusters that were sent.  In a child process: a communicator is process-wide state."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = """
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from sarlacc_amd import pipeline
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+rng = np.random.default_rng(5)
+n = 50000
+sizes = rng.integers(1, 12, size=n)
+sizes = sizes[np.cumsum(sizes) <= n]
+coff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+cmem = (rng.permutation(n)[:coff[-1]] + 1).astype(np.int32)
+label, pos = pipeline.labels_from_clusters(coff, cmem, n)
+labs, poss, secs, nbytes = pipeline.all_gather_labels(label, pos, dist, torch.device("cuda", 0))
+assert labs.shape == (1, n) and nbytes == 0 and secs >= 0
+c2, m2 = pipeline.clusters_from_labels(labs[0], poss[0])
+assert np.array_equal(c2, coff) and np.array_equal(m2, cmem)
+t = torch.arange(8, device="cuda", dtype=torch.float64)
+dist.all_reduce(t)
+torch.cuda.synchronize()
+assert t.cpu().tolist() == list(range(8))
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok")
+""" % (root, port)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "rccl ok" in res.stdout, res.stderr[-2000:]
