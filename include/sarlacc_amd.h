@@ -262,6 +262,12 @@ int sarlacc_umi_group_from_pairs(const char* umi, const int64_t* off, int64_t n,
  * larger groups and for reads beyond 21 823 bases).  0 restores the default (or SARLACC_MSA_SPEC). */
 int sarlacc_set_msa_spec(int spec);
 
+/* A/B switches of the tests and the perf tools (every default, 0, is the product path): "msa_spec",
+ * "msa2_general_rows", "msa2_chain_hbm", "align_pensel", "align_chunks", "align_k", "align_waves_per_cu",
+ * "consensus_chars", "consensus_generic", "msa_int32".  The environment (SARLACC_<NAME>) is read once, when the
+ * first option is asked for; afterwards only this call changes a value.  Nothing in the reference corresponds. */
+int sarlacc_set_option(const char* name, int value);
+
 /* replaces .Call quick_msa  (src/quick_msa.cpp:15-80); argument order as there
  * (the R caller passes -gapOpening as gap_extension and -gapExtension as
  * gap_opening, R/multiReadAlign.R:47).  Groups: CSR of 1-based read ids.

@@ -50,6 +50,22 @@ int orc_fail(const char* msg);
 
 #define MSA2_ROWCAP 16
 
+/* The two own rules of step 5 can be switched off, and their effect counted, to bound what they change
+ * (tests/test_oracle_msa2_rules.py, tools/msa2_rules.py).  Process-wide; the defaults are the spec. */
+static int g_nocap = 0, g_nofilter = 0;
+enum { ST_JOINS, ST_ROWS, ST_ROWS_WITH_CAND, ST_ROWS_CAPPED, ST_CAND_IGNORED, ST_ENT_BEFORE_FILTER, ST_ENT_FILTERED,
+       ST_ROWS_FILTERED, ST_ENT_KEPT, ST_TRIPLES, ST_TRIPLES_2Q, ST_TRIPLES_3Q, ST_TRIPLES_GAPDIRECT, ST_CANDIDATES,
+       ST_ROWS_MULTI, ST_MAX_ROW_ENTRIES, ST_N };
+static int64_t g_stats[ST_N];
+#define STAT_ADD(k, v) __atomic_fetch_add(&g_stats[k], (int64_t)(v), __ATOMIC_RELAXED)
+
+void orc_msa2_set_rules(int nocap, int nofilter) { g_nocap = nocap; g_nofilter = nofilter; }
+int orc_msa2_stats(int64_t* out, int64_t cap, int reset) {
+    for (int k = 0; k < ST_N && k < cap; ++k) out[k] = __atomic_load_n(&g_stats[k], __ATOMIC_RELAXED);
+    if (reset) for (int k = 0; k < ST_N; ++k) __atomic_store_n(&g_stats[k], 0, __ATOMIC_RELAXED);
+    return ST_N;
+}
+
 static char dna5(char c) {
     switch (c) {
         case 'A': case 'C': case 'G': case 'T': return c;
@@ -248,11 +264,16 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
         for (int64_t v = 0; v < B->nmem; ++v) inB |= 1u << B->mem[v];
         int64_t* idxA = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);   /* member slot of sequence a in posA */
         for (int64_t u = 0; u < A->nmem; ++u) idxA[A->mem[u]] = u;
+        /* a row's list: MSA2_ROWCAP entries by the spec; every candidate column when the cap is switched off */
+        const int64_t rowcap = g_nocap ? A->nmem * B->nmem * (n + 1) + 1 : MSA2_ROWCAP;
+        int64_t* lj = (int64_t*)malloc(sizeof(int64_t) * (size_t)rowcap);
+        int64_t* lw = (int64_t*)malloc(sizeof(int64_t) * (size_t)rowcap);
+        STAT_ADD(ST_JOINS, 1);
+        STAT_ADD(ST_ROWS, nA);
         for (int64_t i = 0; i < nA; ++i) {
-            int64_t lj[MSA2_ROWCAP], lw[MSA2_ROWCAP];
-            int cnt = 0;
-#define ADD(J, Wt) do { int k_; for (k_ = 0; k_ < cnt; ++k_) if (lj[k_] == (J)) { lw[k_] += (Wt); break; } \
-                        if (k_ == cnt && cnt < MSA2_ROWCAP) { lj[cnt] = (J); lw[cnt] = (Wt); ++cnt; } } while (0)
+            int64_t cnt = 0, ignored = 0, ncand = 0;
+#define ADD(J, Wt) do { int64_t k_; ++ncand; for (k_ = 0; k_ < cnt; ++k_) if (lj[k_] == (J)) { lw[k_] += (Wt); break; } \
+                        if (k_ == cnt) { if (cnt < rowcap) { lj[cnt] = (J); lw[cnt] = (Wt); ++cnt; } else ++ignored; } } while (0)
             for (int64_t a = 0; a < n; ++a) {
                 if (!((inA >> a) & 1u)) continue;
                 const int64_t p = posA[idxA[a] * nA + i];
@@ -261,6 +282,21 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
                 for (int64_t b = 0; b < n; ++b) {          /* direct edges */
                     if (!((inB >> b) & 1u)) continue;
                     const int64_t q = L.map[a * n + b][p];
+                    {   /* statistics only: how many different positions of b do the direct edge and the triplets name */
+                        int64_t q1 = q, q2 = -1, third = 0;
+                        for (int64_t c = 0; c < n; ++c) {
+                            if (c == a || c == b) continue;
+                            const int64_t r = L.map[a * n + c][p];
+                            if (r < 0) continue;
+                            const int64_t qc = L.map[c * n + b][r];
+                            if (qc < 0 || qc == q1 || qc == q2) continue;
+                            if (q1 < 0) q1 = qc; else if (q2 < 0) q2 = qc; else third = 1;
+                        }
+                        STAT_ADD(ST_TRIPLES, 1);
+                        if (q2 >= 0) STAT_ADD(ST_TRIPLES_2Q, 1);
+                        if (third) STAT_ADD(ST_TRIPLES_3Q, 1);
+                        if (q < 0 && q1 >= 0) STAT_ADD(ST_TRIPLES_GAPDIRECT, 1);
+                    }
                     if (q < 0) continue;
                     ADD(col[L.off[b] + q], w0(xa, SEQ(&L, b)[q], ma, mm));
                 }
@@ -279,23 +315,34 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
                 }
             }
 #undef ADD
+            STAT_ADD(ST_CANDIDATES, ncand);
+            if (cnt) STAT_ADD(ST_ROWS_WITH_CAND, 1);
+            if (ignored) { STAT_ADD(ST_ROWS_CAPPED, 1); STAT_ADD(ST_CAND_IGNORED, ignored); }
+            STAT_ADD(ST_ENT_BEFORE_FILTER, cnt);
             /* noise filter */
-            {
+            if (!g_nofilter) {
                 int64_t wmax = 0;
-                int kept = 0;
-                for (int x = 0; x < cnt; ++x) if (lw[x] > wmax) wmax = lw[x];
-                for (int x = 0; x < cnt; ++x)
+                int64_t kept = 0;
+                for (int64_t x = 0; x < cnt; ++x) if (lw[x] > wmax) wmax = lw[x];
+                for (int64_t x = 0; x < cnt; ++x)
                     if (2 * lw[x] >= wmax) { lj[kept] = lj[x]; lw[kept] = lw[x]; ++kept; }
+                if (kept < cnt) { STAT_ADD(ST_ROWS_FILTERED, 1); STAT_ADD(ST_ENT_FILTERED, cnt - kept); }
                 cnt = kept;
             }
+            STAT_ADD(ST_ENT_KEPT, cnt);
+            if (cnt > 1) STAT_ADD(ST_ROWS_MULTI, 1);
+            {
+                int64_t cur = __atomic_load_n(&g_stats[ST_MAX_ROW_ENTRIES], __ATOMIC_RELAXED);
+                while (cnt > cur && !__atomic_compare_exchange_n(&g_stats[ST_MAX_ROW_ENTRIES], &cur, cnt, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+            }
             /* by column */
-            for (int x = 1; x < cnt; ++x) {
+            for (int64_t x = 1; x < cnt; ++x) {
                 const int64_t tj = lj[x], tw = lw[x];
-                int y = x - 1;
+                int64_t y = x - 1;
                 while (y >= 0 && lj[y] > tj) { lj[y + 1] = lj[y]; lw[y + 1] = lw[y]; --y; }
                 lj[y + 1] = tj; lw[y + 1] = tw;
             }
-            for (int x = 0; x < cnt; ++x) {
+            for (int64_t x = 0; x < cnt; ++x) {
                 if (nm == mcap) {
                     mcap *= 2;
                     mi = (int64_t*)realloc(mi, sizeof(int64_t) * (size_t)mcap);
@@ -306,7 +353,7 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
                 ++nm;
             }
         }
-        free(idxA);
+        free(idxA); free(lj); free(lw);
         /* heaviest chain: f(m) = w(m) + best f over matches with smaller row and smaller column;
          * "best" = larger f, then smaller match index.  bestAt[j] = best match ending in column j among the
          * processed rows; a row's matches all look at the state before the row. */

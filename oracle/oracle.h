@@ -164,6 +164,12 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t nreads,
                    char* out, int64_t cap, int64_t* width);
 /* Inspection hooks for the tests: the guide tree (joins[2*k], joins[2*k+1] = node ids merged by join k;
  * leaves 0..n-1, join k creates node n+k) and the pairwise distances (n*n doubles). */
+/* spec v2's own rules (row cap, noise filter) switched off for A/B runs, and counters of how often they act:
+ * joins, rows, rows with candidates, rows capped, candidates ignored by the cap, entries before the filter,
+ * entries filtered, rows filtered, entries kept, (a,p,b) triples, triples naming >= 2 / >= 3 positions of b,
+ * triples whose direct edge is a gap, candidates, rows with > 1 entry, most entries in a row. */
+void orc_msa2_set_rules(int nocap, int nofilter);
+int orc_msa2_stats(int64_t* out, int64_t cap, int reset);
 int orc_msa2_tree(const char* seq, const int64_t* off, int64_t nreads,
                   int match, int mismatch, int gapopen, int gapext, int bandwidth,
                   int32_t* joins, double* dist);

@@ -326,6 +326,25 @@ def msa2_tree(reads, match, mismatch, gap_extension, gap_opening, bandwidth):
     return joins[:max(n - 1, 0)], dist
 
 
+MSA2_STAT_NAMES = ("joins", "rows", "rows_with_candidates", "rows_capped", "candidates_ignored_by_cap",
+                   "entries_before_filter", "entries_filtered", "rows_filtered", "entries_kept", "triples",
+                   "triples_2_positions", "triples_3_positions", "triples_gap_direct", "candidates",
+                   "rows_multi_entry", "max_row_entries")
+
+
+def msa2_set_rules(nocap=False, nofilter=False):
+    """Switch spec v2's own rules (row cap of 16 partner columns, half-the-heaviest noise filter) off / on."""
+    lib().orc_msa2_set_rules.restype = None
+    lib().orc_msa2_set_rules(int(bool(nocap)), int(bool(nofilter)))
+
+
+def msa2_stats(reset=True):
+    """Counters of spec v2's library walk since the last reset (names: MSA2_STAT_NAMES)."""
+    buf = np.zeros(len(MSA2_STAT_NAMES), np.int64)
+    lib().orc_msa2_stats(_p(buf), C.c_int64(buf.size), int(bool(reset)))
+    return dict(zip(MSA2_STAT_NAMES, buf.tolist()))
+
+
 def quick_msa(groupings, sequences, match, mismatch, gap_extension, gap_opening, bandwidth, spec=2, tcoffee_max=32):
     """Same argument order as the reference .Call (src/quick_msa.cpp:15): note that
     the R caller passes (-gapOpening, -gapExtension) into (gap_extension, gap_opening)

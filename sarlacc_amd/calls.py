@@ -322,6 +322,11 @@ def set_msa_spec(spec):
     check(_lib.lib().sarlacc_set_msa_spec(int(spec)))
 
 
+def set_option(name, value):
+    """sarlacc_set_option: the A/B switches of the tests and perf tools (include/sarlacc_amd.h lists them); 0 = product path."""
+    check(_lib.lib().sarlacc_set_option(str(name).encode(), int(value)))
+
+
 def quick_msa(groupings, sequences, match, mismatch, gapExtension, gapOpening, bandwidth):
     """.Call quick_msa (src/quick_msa.cpp:15-80), same argument order (the R caller passes
     -gapOpening as gapExtension and -gapExtension as gapOpening, R/multiReadAlign.R:47).

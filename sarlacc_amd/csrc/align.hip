@@ -970,8 +970,7 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     }
 
     Shape sh = pick_shape(R);
-    if (const char* ek = std::getenv("SARLACC_ALIGN_K")) {  // tuning override
-        const int K = std::atoi(ek);
+    if (const int K = option(OPT_ALIGN_K)) {  // tuning override
         const int W = (R + K - 1) / K;
         if ((K == 1 || K == 2 || K == 4 || K == 8 || K == 16) && W <= 64) {
             const int Wp = W <= 16 ? 16 : W;
@@ -985,9 +984,9 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     size_t per_wave_elems = kernel_mode ? ((static_cast<size_t>(max_len) + sh.W + 16) / tb_steps + 2) * 64 : 0;
     // gapopen >= 0 (GO >= GE): no penalty selects on the device, see k_align
     bool pensel = !(GO >= GE);
-    if (const char* ep = std::getenv("SARLACC_ALIGN_PENSEL")) pensel = pensel || std::atoi(ep) != 0;  // testing: force the general path
+    pensel = pensel || option(OPT_ALIGN_PENSEL) != 0;  // testing: force the general path
     // adaptor_align without penalty selects: snapshots + windowed recompute instead of the code stream
-    if (kernel_mode == 1 && local && !pensel && !std::getenv("SARLACC_ALIGN_STREAM")) {
+    if (kernel_mode == 1 && local && !pensel) {
         kernel_mode = 3;
         const size_t nsnap = (static_cast<size_t>(max_len) + sh.W + 16) / SNAP_P + 2;
         per_wave_elems = static_cast<size_t>(snap_win(R, sh.W) / tb_steps) * 64 +
@@ -998,7 +997,7 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     // exactly resident grid with a static stride (1.74 -> 2.07 TCUPS at 1M x 2kb; flat from 128 to
     // 384 waves per CU).  The per-wave scratch tiles scale with the grid and are capped below.
     int waves_per_cu = 128;
-    if (const char* ew = std::getenv("SARLACC_ALIGN_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(ew));
+    if (option(OPT_ALIGN_WAVES_PER_CU) > 0) waves_per_cu = option(OPT_ALIGN_WAVES_PER_CU);
     // workgroups of NWAVES wavefronts; every wavefront owns a traceback tile
     long long grid = std::min<long long>((nitems + NWAVES - 1) / NWAVES,
                                          (static_cast<long long>(c.num_cu) * waves_per_cu + NWAVES - 1) / NWAVES);
@@ -1136,7 +1135,7 @@ static int host_align(const char* seq, const int64_t* seq_off, const char* qual,
     int64_t nchunks = 1;
     if (kernel_mode != 2 && R > 0) {
         if (total_bytes >= (static_cast<int64_t>(512) << 20)) nchunks = std::min<int64_t>(8, total_bytes / (static_cast<int64_t>(256) << 20));
-        if (const char* ec = std::getenv("SARLACC_ALIGN_CHUNKS")) nchunks = std::max(1, std::atoi(ec));   // testing
+        if (option(OPT_ALIGN_CHUNKS) > 0) nchunks = option(OPT_ALIGN_CHUNKS);   // testing
         nchunks = std::max<int64_t>(1, std::min<int64_t>(nchunks, n));
     }
     HostBatch hb;

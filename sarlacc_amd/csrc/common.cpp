@@ -1,6 +1,8 @@
 // common.cpp -- error reporting, device context and workspace cache.
 #include "common.hpp"
 
+#include <cstdlib>
+
 #include "../../include/sarlacc_amd.h"
 
 namespace sarlacc {
@@ -18,6 +20,29 @@ int fail(const char* fmt, ...) {
     va_end(ap);
     last_error() = buf;
     return 1;
+}
+
+static const char* const kOptNames[OPT_N] = {"msa_spec", "msa2_general_rows", "msa2_chain_hbm", "align_pensel", "align_chunks",
+                                             "align_k", "align_waves_per_cu", "consensus_chars", "consensus_generic", "msa_int32"};
+static int* option_values() {
+    static int values[OPT_N];
+    static const bool parsed = [] {
+        for (int k = 0; k < OPT_N; ++k) {
+            std::string env = "SARLACC_";
+            for (const char* p = kOptNames[k]; *p; ++p) env += static_cast<char>(*p >= 'a' && *p <= 'z' ? *p - 32 : *p);
+            const char* e = std::getenv(env.c_str());
+            values[k] = e ? std::atoi(e) : 0;
+        }
+        return true;
+    }();
+    (void)parsed;
+    return values;
+}
+int option(Opt o) { return option_values()[o]; }
+int set_option(const char* name, int value) {
+    for (int k = 0; k < OPT_N; ++k)
+        if (name && std::strcmp(name, kOptNames[k]) == 0) { option_values()[k] = value; return 0; }
+    return fail("sarlacc_amd: unknown option '%s'", name ? name : "(null)");
 }
 
 Context& ctx() {
@@ -117,6 +142,8 @@ extern "C" {
 const char* sarlacc_last_error(void) { return sarlacc::last_error().c_str(); }
 
 int sarlacc_version(void) { return 100; }
+
+int sarlacc_set_option(const char* name, int value) { return sarlacc::set_option(name, value); }
 
 int sarlacc_device_count(void) {
     int count = 0;

@@ -33,6 +33,26 @@ int fail(const char* fmt, ...);
         if (rc__) return rc__;    \
     } while (0)
 
+// ---- options --------------------------------------------------------------
+// The A/B switches the tests and the perf tools use; every default (0) is the product path.  Read ONCE from
+// the environment (SARLACC_<NAME IN CAPITALS>) the first time any option is asked for, afterwards only changed
+// through sarlacc_set_option -- no kernel launch path evaluates the environment.
+enum Opt {
+    OPT_MSA_SPEC,             // 1: centre-star, 2: consistency-based progressive (0 = default = 2)
+    OPT_MSA2_GENERAL_ROWS,    // spec v2: the library walk by the any-weights code also for unit weights
+    OPT_MSA2_CHAIN_HBM,       // spec v2: the chain's prefix maxima in HBM from the start (the fallback of the LDS ring)
+    OPT_ALIGN_PENSEL,         // quality DP: the instantiation with explicit penalty selects also for gapopen >= 0
+    OPT_ALIGN_CHUNKS,         // host-pointer DP: number of upload chunks
+    OPT_ALIGN_K,              // quality DP: reference columns per lane (perf sweeps)
+    OPT_ALIGN_WAVES_PER_CU,   // quality DP: grid size (perf sweeps)
+    OPT_CONSENSUS_CHARS,      // fused MSA + consensus on character rows instead of vote codes
+    OPT_CONSENSUS_GENERIC,    // quality vote on character rows: the generic kernel only
+    OPT_MSA_INT32,            // pairwise MSA alignments by the 32-bit kernel
+    OPT_N
+};
+int option(Opt o);
+int set_option(const char* name, int value);
+
 // ---- device context -------------------------------------------------------
 // One per host thread (a .Call runs on R's main thread; BiocParallel workers are
 // separate processes, /root/reference/R/adaptorAlign.R:126-134).

@@ -988,7 +988,7 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
         const int grid = static_cast<int>(std::min<int64_t>(ng_eval, static_cast<int64_t>(c.num_cu) * 32));
         // quality vote without the per-column log errors: 4 columns per lane, 4 alignments per workgroup
         const size_t lds4 = sizeof(double) * 4 * (5 * static_cast<size_t>(enc_n) + 1) + 4 * (2 * sizeof(long long) + 3 * sizeof(int)) * static_cast<size_t>(max_rows) + 16;
-        const bool q4 = quality && !lerr && lds4 <= 48 * 1024 && !std::getenv("SARLACC_CONSENSUS_NARROW");
+        const bool q4 = quality && !lerr && lds4 <= 48 * 1024;
         SL_HIP(hipEventRecord(c.ev_start, s));
         c.counts["consensus_cells"] = static_cast<double>(total);
         c.stage_reset("consensus");
@@ -1004,7 +1004,7 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
             // whatever it flags is redone by the generic kernel
             const size_t ldsf = static_cast<size_t>(enc_n + 1) * QF_ROWB;
             const bool qf = a.aln_bytes > 0 && a.qual_bytes > 0 && enc_n <= 127 && a.qoffset + enc_n <= 255 && ldsf <= 150 * 1024 &&
-                            !std::getenv("SARLACC_CONSENSUS_GENERIC");
+                            !option(OPT_CONSENSUS_GENERIC);
             if (qf) {
                 SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_consensus_qf), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsf)));
                 const int gridf = static_cast<int>(std::min<int64_t>((ng_eval + QF_THREADS / 64 - 1) / (QF_THREADS / 64), c.num_cu));
@@ -1222,7 +1222,7 @@ static int msa_consensus_impl(const int64_t* grp_off, const int32_t* grp, int64_
     // Rows as vote codes (k_consensus_code) when the quality strings are laid out like the reads -- every read as long as
     // its quality string, which is also what the reference demands -- and the table fits LDS; otherwise characters.
     bool codes = quality && static_cast<size_t>(enc_n + 1) * QC_ROWB <= 150 * 1024 && static_cast<int>(enc_names[0]) + enc_n <= 255 &&
-                 !std::getenv("SARLACC_CONSENSUS_CHARS");
+                 !option(OPT_CONSENSUS_CHARS);
     for (int64_t r = 0; codes && r < nseq; ++r)
         if (qual_off[r + 1] - qual_off[r] != seq_off[r + 1] - seq_off[r]) codes = false;
     const uint8_t* d_q_const = nullptr;

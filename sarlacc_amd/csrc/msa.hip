@@ -237,9 +237,6 @@ int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const 
         const int32_t v = grp[grp_off[0] + i];
         if (v < 1 || v > nseq) return fail("sarlacc_amd: group index %d outside 1..%lld", v, static_cast<long long>(nseq));
     }
-    const bool timing = std::getenv("SARLACC_TIMING") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double tm0 = now();
     // ---- host-side job list: centre = lower median by (length, position) ----
     std::vector<MsaGroup> groups(static_cast<size_t>(ngroups));
     std::vector<MsaJob> jobs;
@@ -290,7 +287,6 @@ int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const 
     SL_TRY(ensure_device());
     hipStream_t s = nullptr;
     Context& c = ctx();
-    const double tm1 = now();
     const int64_t total = nseq ? seq_off[nseq] - seq_off[0] : 0;
     std::vector<int64_t> rel(static_cast<size_t>(nseq) + 1);
     for (int64_t i = 0; i <= nseq; ++i) rel[i] = (nseq ? seq_off[i] : 0) - (nseq ? seq_off[0] : 0);
@@ -325,9 +321,7 @@ int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const 
         SL_TRY(c.stage_end("msa_pairwise", s));
         c.timed = true;
     }
-    const double tm2 = now();
     if (overlap) SL_TRY((*overlap)());
-    const double tm3 = now();
     MergeArgs m{};
     m.seq = d_seq; m.seq_off = d_soff; m.members = d_mem; m.groups = d_groups; m.jobs = d_jobs; m.ngroups = ngroups;
     m.ins = d_ins; m.aln = d_aln; m.maxins = d_maxins; m.mi_off = d_mioff; m.width = d_width;
@@ -377,11 +371,6 @@ int msa1_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const 
     SL_HIP(hipGetLastError());
     SL_TRY(c.stage_end("msa_merge", s));
     res->d_out = d_out;
-    if (timing) {
-        SL_HIP(hipStreamSynchronize(s));
-        fprintf(stderr, "msa_run: job list %.3f s | uploads + launches %.3f s | overlap hook %.3f s | kernels + row write %.3f s\n",
-                tm1 - tm0, tm2 - tm1, tm3 - tm2, now() - tm3);
-    }
     return 0;
 }
 

@@ -14,20 +14,24 @@
 //                 msa_pairwise.hip (OUT 1);
 //   col   int32   column of every base in the profile that currently holds its read;
 //   pos   uint16  per group n x wcap: position of read a at column c of its profile (0xFFFF = gap);
-//   rows  per profile column of the first child of a merge: up to `cap` (partner column, weight) entries.
-// Kernels, per merge round k (every group performs its k-th join in the same launches):
-//   k_m2_gather  lane = column i of the first child; walks the library (map -> map -> col) for every
-//                member pair and third sequence, sums the weights per partner column in a private list
-//                (registers), writes the list sorted by column; with unit weights (the default scores)
-//                k_m2_candidates + k_m2_gather_unit: the round's (c, b) pairs as a table of scalar descriptors;
-//   k_m2_chain   one wavefront per group: heaviest chain over the lists in row order with a Fenwick tree
-//                of prefix maxima in LDS (16 lanes read / update the <= 16 nodes of one match in one
-//                instruction), then the traceback through the stored predecessors;
-//   k_m2_merge   one workgroup per group: new column numbers (first child's unmatched columns before the
-//                second child's between two matched pairs), col / pos of every member updated.
+//   tab   M2Cand  per group and join: the (third read, second-child member) candidates of the library walk as
+//                 32-byte scalar descriptors (k_m2_tables, once per batch).
+// Groups are independent (src/quick_msa.cpp:39); only the joins INSIDE a group are ordered.  So after the pairwise
+// alignments and the guide trees ONE launch does all the merging: k_m2_group, one wavefront per group, groups
+// pulled from an atomic counter in order of decreasing size, and for every join of its group the wavefront runs
+//   rows      lane = column i of the first child; walks the library (map -> map -> col) for every member pair
+//             and third read, sums the weights per partner column in a private list (registers), applies the
+//             row cap and the noise filter of spec v2 step 5 and appends the row's entries, by column, to a
+//             compact match list (row, column, weight) in the wavefront's scratch;
+//   chain     heaviest chain over the match list, 64 matches per step: prefix maxima over the second child's
+//             columns in an LDS ring behind the front, dependencies inside the block resolved in registers,
+//             predecessors stored per match; then the walk back through the predecessors;
+//   renumber  new column numbers (first child's unmatched columns before the second child's between two
+//             matched pairs), col / pos of every member updated.
+// Nothing is exchanged between wavefronts, so there is no waiting and no launch per join (round 2 launched five
+// kernels per join for all groups of a batch and spent most of the stage with a few long wavefronts on the chip).
 // A row keeps the first M2_CAP distinct partner columns (spec v2, step 5); groups whose profiles outgrow the
 // fast capacity are redone with profiles as wide as the sum of the read lengths.
-#include <chrono>
 #include <cstdlib>
 #include <cstring>
 
@@ -42,7 +46,7 @@
 namespace sarlacc {
 
 constexpr int M2_MAXN = 32;          // group sizes aligned by spec v2 (member sets are 32-bit masks)
-constexpr int M2_CAP = 16;           // partner columns per row on the fast path (private lists in LDS)
+constexpr int M2_CAP = 16;           // partner columns per row (spec v2, step 5)
 constexpr unsigned M2_NONE = 0xFFFFu;
 // profile capacity of the first pass: same-molecule reads grow a profile by 10-20 %, one or two unrelated reads in
 // the cluster by their length each
@@ -56,45 +60,49 @@ struct M2Member {         // one read of a group
     int pad;
 };
 struct M2Group {
-    int first_member;     // member a of the group is members[first_member + a]; joins at first_member + k,
-                          // tree nodes (leaves 0..n-1, join k creates n + k) at 2 * first_member + node
+    int first_member;     // member a of the group is members[first_member + a]; joins at first_member + k
     int n;
     int wcap;             // capacity of a profile in columns
-    int cap;              // entries per row list
-    long long row_base;   // into the per-column arrays (lists, partners, renumbering): wcap entries
+    int pad;
     long long pos_base;   // into d_pos: n * wcap
     long long first_job;  // pairwise job of (a, b), a < b: first_job + a n - a (a + 1) / 2 + b - a - 1
     long long dist_base;  // into the tree kernel's scratch: n * n + n doubles
-    long long out_off;    // the group's rows in the row buffer
+    long long tab_base;   // into the candidate tables (unit weights)
 };
 
+// counters of one call (sarlacc_stage_count): how often spec v2's own rules act, and the chain's fallback
+enum { M2C_ROWS, M2C_ROWS_CAPPED, M2C_ENT_FILTERED, M2C_ROWS_FILTERED, M2C_ENT_KEPT, M2C_JOINS, M2C_JOINS_HBMQ, M2C_N };
+
 struct M2Args {
-    int g0;                        // first group of this launch (the round kernels run on sub-ranges of a batch, one per stream)
     const uint8_t* seq;
     const M2Group* groups;
     const M2Member* members;
     int ngroups;
     int ma, mm;
-    unsigned long long* clk;       // SARLACC_MSA2_CLOCKS: cycles of the chain kernel's phases, first wave of the last launch
-    unsigned long long* xdbg;      // SARLACC_MSA2_EXACTDBG: per group (cycles, rows << 32 | entries) of k_m2_chain_exact
     const uint16_t* map;
     const int2* stats;
     double* dist;
     int2* joins;
-    uint32_t* nodemask;
-    int* ncols;
+    int* join_tab;                 // per join (first_member + k): start of its candidates inside the group's table
     int* col;
     uint16_t* pos;
-    uint16_t* row_cnt;             // entries in a row's list
-    unsigned long long* row_ent;   // (partner column << 32) | weight
-    unsigned* row_pred;            // id of the predecessor of every entry on its best chain (0: none)
-    int* part;                     // partner column of column i of the first child, -1 if unmatched
-    int* ovf;                      // per group: a capacity was exceeded
-    int* redo;                     // per group: this round's chain has to be done by k_m2_chain_exact
+    int* ovf;                      // per group: a profile outgrew its capacity
     int32_t* width;                // per group: columns of the final profile
+    // ---- k_m2_group: work counter, counters, per-wavefront scratch (w_rows columns each) ----
+    int* next;
+    unsigned long long* counters;
+    unsigned long long* w_ent;     // match list: (row << 48) | (column << 32) | weight; M2_CAP entries per column
+    unsigned* w_pred;              // per match: 1 + index of its predecessor on its best chain (0: none)
+    int* w_part;                   // partner column of column i of the first child, -1 if unmatched
+    int* w_nca;                    // new numbers of the first child's columns
+    int* w_ncb;                    // ... of the second child's
+    int* w_pb;                     // partner row of column j of the second child
+    unsigned long long* w_q;       // prefix maxima over all columns (the chain's fallback when the LDS ring cannot answer)
+    long long w_rows;
+    int chain_hbm;                 // testing: the prefix maxima in HBM from the start (what the LDS ring falls back to)
+    // ---- row writer ----
     uint8_t* out;                  // gapped rows
-    // rows as vote codes instead of characters (CodeSpec, common.hpp): out16 != nullptr
-    uint16_t* out16;
+    uint16_t* out16;               // rows as vote codes instead of characters (CodeSpec, common.hpp): out16 != nullptr
     const uint8_t* qual;           // laid out like seq
     int qoffset, navail;
     int* bad;
@@ -112,10 +120,7 @@ __global__ void k_m2_tree(M2Args A) {
     const M2Group G = A.groups[g];
     const int n = G.n;
     const int fm = G.first_member;
-    for (int a = 0; a < n; ++a) {
-        A.nodemask[2 * fm + a] = 1u << a;
-        A.ncols[2 * fm + a] = A.members[fm + a].len;
-    }
+    A.width[g] = n == 1 ? A.members[fm].len : 0;   // (groups of two and more: written by k_m2_group)
     if (n < 2) return;
     double* D = A.dist + G.dist_base;
     double* R = D + static_cast<long long>(n) * n;
@@ -188,213 +193,19 @@ __global__ void k_m2_init(M2Args A, const int* member_group, int nmembers) {
     }
 }
 
-// ---- match lists of one merge round ----
-// lane = column i of the first child.  The row's list (first M2_CAP distinct partner columns in the canonical
-// enumeration order of spec v2, step 5: a ascending; direct edges b ascending; then c ascending, b ascending)
-// lives in registers; a candidate is compared with the first entries before anything else (same-molecule reads
-// agree on 1-3 columns).  Loads are issued in independent batches: the positions r_c of every third sequence
-// first (LDS), then up to M2_BATCH (c, b) pairs at a time -- the dependent chain map -> map -> col of one
-// candidate is three memory latencies long, so the pairs of a batch are looked up side by side.
-constexpr int M2_BATCH = 4;
-
-__device__ __forceinline__ long long m2_uniform64(long long v) {   // a wave-uniform 64-bit value into scalar registers
-    const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
-    const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32)));
-    return static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
-}
-
-template <bool UNITW>
-__global__ void __launch_bounds__(64) k_m2_gather(M2Args A, int round) {
-    __shared__ uint16_t s_r[M2_MAXN][64];   // position of the lane's base in every other member (0xFFFF: gap)
-    __shared__ long long s_mapbase[M2_MAXN], s_colbase[M2_MAXN], s_seqoff[M2_MAXN];   // the members' descriptors
-    __shared__ int s_len[M2_MAXN];
-    __shared__ int s_b[M2_MAXN];   // the second child's members, ascending
-    const int g = A.g0 + blockIdx.y;
-    const M2Group G = A.groups[g];
-    if (round >= G.n - 1 || A.ovf[g] != 0) return;
-    const int n = G.n, fm = G.first_member;
-    const int2 jn = A.joins[fm + round];
-    const unsigned maskA = A.nodemask[2 * fm + jn.x], maskB = A.nodemask[2 * fm + jn.y];
-    const int nA = A.ncols[2 * fm + jn.x];
-    const int lane = threadIdx.x;
-    if (lane < M2_MAXN) {
-        const M2Member Me = A.members[fm + min(lane, n - 1)];
-        s_mapbase[lane] = Me.map_base; s_colbase[lane] = Me.col_base; s_seqoff[lane] = Me.seq_off; s_len[lane] = lane < n ? Me.len : 0;
-        if ((maskB >> lane) & 1u) s_b[__popc(maskB & ((1u << lane) - 1u))] = lane;
-    }
-    const int nbm = __popc(maskB);
-    __syncthreads();
-    const unsigned long long gclk0 = __builtin_amdgcn_s_memtime();
-    unsigned long long gcand = 0;
-    for (int i0 = blockIdx.x * 64; i0 < nA; i0 += gridDim.x * 64) {
-    const int i = i0 + lane;
-    int ej[M2_CAP], ew[M2_CAP];
-#pragma unroll
-    for (int k = 0; k < M2_CAP; ++k) { ej[k] = -1; ew[k] = 0; }
-    int cnt = 0;
-    // add(j, w): selects only, every index a compile-time constant -- the lists must stay in registers (a lambda
-    // capturing the arrays, or an index the compiler cannot resolve, sends them to scratch memory, whose loads
-    // then wait behind every lookup in flight)
-#define M2_ADD(J, W, VALID)                                                                            \
-    {                                                                                                  \
-        const int j_ = (J), w_ = (W);                                                                  \
-        bool hit_ = !(VALID);                                                                          \
-        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                                             \
-            const bool m_ = !hit_ && ej[k_] == j_;                                                     \
-            ew[k_] += m_ ? w_ : 0;                                                                     \
-            hit_ = hit_ || m_;                                                                         \
-        }                                                                                              \
-        if (__ballot(!hit_)) {                                                                         \
-            _Pragma("unroll") for (int k_ = 3; k_ < M2_CAP; ++k_) {                                    \
-                const bool m_ = !hit_ && ej[k_] == j_;                                                 \
-                ew[k_] += m_ ? w_ : 0;                                                                 \
-                hit_ = hit_ || m_;                                                                     \
-            }                                                                                          \
-            /* a new column; beyond M2_CAP distinct columns it is ignored (spec v2, step 5) */         \
-            const bool app_ = !hit_ && cnt < M2_CAP;                                                   \
-            _Pragma("unroll") for (int k_ = 0; k_ < M2_CAP; ++k_) {                                    \
-                const bool s_ = app_ && k_ == cnt;                                                     \
-                ej[k_] = s_ ? j_ : ej[k_];                                                             \
-                ew[k_] = s_ ? w_ : ew[k_];                                                             \
-            }                                                                                          \
-            cnt += app_ ? 1 : 0;                                                                       \
-        }                                                                                              \
-    }
-    const bool row = i < nA;
-    for (int a = 0; a < n; ++a) {
-        if (!((maskA >> a) & 1u)) continue;
-        const unsigned p = row ? A.pos[G.pos_base + static_cast<long long>(a) * G.wcap + i] : M2_NONE;
-        const bool havep = p != M2_NONE;
-        if (!__ballot(havep)) continue;
-        const M2Member Ma = A.members[fm + a];
-        const int xa = (UNITW || !havep) ? 0 : dna5_code(A.seq[Ma.seq_off + p]);
-        // positions in every other member: unconditional loads (clamped), selected afterwards -- see below
-        {
-            const unsigned pidx = havep ? p : 0u;
-            for (int c0 = 0; c0 < n; c0 += 8) {
-                uint16_t rv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = min(c0 + u, n - 1);
-                    const int slot = c == a ? 0 : (c < a ? c : c - 1);
-                    rv[u] = A.map[Ma.map_base + static_cast<long long>(slot) * Ma.len + pidx];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (c0 + u < n) s_r[c0 + u][lane] = (c0 + u != a && havep) ? rv[u] : static_cast<uint16_t>(M2_NONE);
-            }
-        }
-        // canonical order of the candidates: the direct edges (c = b) for b in B ascending, then for c ascending the
-        // triplets (c, b), b in B ascending, b != c -- a flat list of nbm + (n - 1) nbm entries, looked up M2_BATCH at a
-        // time side by side (the second child is often a single read: batching over its members alone would leave
-        // one candidate per memory latency).
-        const int total = nbm * n;   // direct pass (ci = 0) + the n - 1 third sequences
-        int ci = 0, bi = 0;          // position in the flat list: pass ci (0 = direct; ci >= 1: c = ci - 1, skipping a), member bi
-        for (int f0 = 0; f0 < total; f0 += M2_BATCH) {
-            // every load of the batch is unconditional (indices clamped to valid ones, results selected afterwards):
-            // a branch around a load makes the compiler wait for it before it issues the next one
-            unsigned qq[M2_BATCH];
-            int jj[M2_BATCH], ww[M2_BATCH], bq[M2_BATCH];
-            bool ok[M2_BATCH];
-            // phase 1: the M2_BATCH map lookups are requested back to back -- nothing between them uses a loaded value,
-            // so the compiler does not wait for one before it issues the next (uses in the same loop body would)
-            unsigned rr[M2_BATCH], mm[M2_BATCH], rix[M2_BATCH];
-            int cuq[M2_BATCH], flg[M2_BATCH];   // flg: bit 0 candidate exists, bit 1 direct edge (c = b), bit 2 counted (direct or b != c)
-#pragma unroll
-            for (int u = 0; u < M2_BATCH; ++u) {
-                const bool in = f0 + u < total;
-                // the candidate's members are the same for every lane: their descriptors are moved to scalar registers
-                // so that the address arithmetic runs on the scalar unit (values read from LDS arrive in VGPRs)
-                const int b = __builtin_amdgcn_readfirstlane(s_b[bi]);
-                const int cu = ci == 0 ? b : ((ci - 1) + ((ci - 1) >= a ? 1 : 0));
-                const unsigned r = s_r[cu][lane];
-                const int bslot = cu == b ? 0 : (b < cu ? b : b - 1);
-                const int lencu = __builtin_amdgcn_readfirstlane(s_len[cu]);
-                const long long mbase = m2_uniform64(s_mapbase[cu]) + static_cast<long long>(bslot) * lencu;
-                const unsigned ridx = min(r != M2_NONE ? r : 0u, static_cast<unsigned>(max(lencu - 1, 0)));
-                mm[u] = A.map[mbase + ridx];
-                rr[u] = r; rix[u] = ridx; cuq[u] = cu; bq[u] = b;
-                flg[u] = (in ? 1 : 0) | (cu == b ? 2 : 0) | ((ci == 0 || b != cu) ? 4 : 0);
-                bi = in ? bi + 1 : bi;
-                const bool wrap = bi == nbm;
-                bi = wrap ? 0 : bi;
-                ci = wrap ? ci + 1 : ci;
-            }
-#pragma unroll
-            for (int u = 0; u < M2_BATCH; ++u) {
-                qq[u] = (flg[u] & 2) ? rr[u] : mm[u];
-                ok[u] = (flg[u] & 1) && (flg[u] & 4) && rr[u] != M2_NONE && qq[u] != M2_NONE;
-                ww[u] = 1;
-                if (!UNITW) {
-                    const int xc = dna5_code(A.seq[s_seqoff[cuq[u]] + rix[u]]);
-                    ww[u] = (xc << 16) | (((flg[u] & 2) ? 1 : 0) << 15) | m2_w0(xa, xc, A.ma, A.mm);   // (finished below)
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < M2_BATCH; ++u) {
-                const int b = __builtin_amdgcn_readfirstlane(bq[u]);
-                const int lenb = __builtin_amdgcn_readfirstlane(s_len[b]);
-                const unsigned qidx = min(ok[u] ? qq[u] : 0u, static_cast<unsigned>(max(lenb - 1, 0)));
-                jj[u] = A.col[m2_uniform64(s_colbase[b]) + qidx];
-                if (!UNITW) {
-                    const int xc = ww[u] >> 16, wac = ww[u] & 0x7fff;
-                    const bool direct = (ww[u] >> 15) & 1;
-                    const int wcb = m2_w0(xc, dna5_code(A.seq[s_seqoff[b] + qidx]), A.ma, A.mm);
-                    ww[u] = direct ? wac : (wac < wcb ? wac : wcb);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < M2_BATCH; ++u)
-                if (f0 + u < total) M2_ADD(jj[u], ww[u], ok[u])
-        }
-        gcand += total;
-    }
-    if (row) {
-        // noise filter (spec v2, step 5): entries lighter than half the row's heaviest are dropped -- the partner
-        // columns reached only through reads unrelated to the rest of the cluster
-        int wmax = 0;
-#pragma unroll
-        for (int k = 0; k < M2_CAP; ++k) wmax = max(wmax, ew[k]);
-        {
-            int kept = 0;
-#pragma unroll
-            for (int k = 0; k < M2_CAP; ++k) {
-                const bool keep = k < cnt && 2 * ew[k] >= wmax;
-                if (!keep) ej[k] = 0x7fffffff;   // sorts behind every kept column
-                kept += keep ? 1 : 0;
-            }
-            cnt = kept;
-        }
-        // by column: rank of every entry among the valid ones (the columns of a list are distinct)
-        unsigned long long* const mine = A.row_ent + (G.row_base + i) * static_cast<long long>(G.cap);
-#pragma unroll
-        for (int k = 0; k < M2_CAP; ++k) {
-            if (ej[k] != 0x7fffffff && ej[k] >= 0) {
-                int rank = 0;
-#pragma unroll
-                for (int q = 0; q < M2_CAP; ++q)
-                    if (ej[q] >= 0 && ej[q] < ej[k]) ++rank;
-                mine[rank] = (static_cast<unsigned long long>(static_cast<unsigned>(ej[k])) << 32) | static_cast<unsigned>(ew[k]);
-            }
-        }
-        A.row_cnt[G.row_base + i] = static_cast<uint16_t>(cnt);
-    }
-    }
-    if (A.clk && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { A.clk[4] = __builtin_amdgcn_s_memtime() - gclk0; A.clk[5] = gcand; A.clk[6] = static_cast<unsigned long long>(nA); A.clk[7] = static_cast<unsigned long long>(n); }
-}
-
-// ---- unit weights (the default scores): the candidates of a round as a table of scalar descriptors ----
-// Entry e = pass * |B| + bi of a group's table: pass 0 the direct edges (c = b), pass 1 + c the triplets through
-// member c, each for the second child's members b ascending -- the canonical candidate order of k_m2_gather, with the
-// block of c == a left in: the lane's position "in a itself" is a gap by construction, so those entries add nothing.
+// ---- unit weights (the default scores): the candidates of every join as tables of scalar descriptors ----
+// Entry e = pass * |B| + bi of a join's table: pass 0 the direct edges (c = b), pass 1 + c the triplets through
+// member c, each for the second child's members b ascending -- the canonical candidate order of spec v2 step 5, with
+// the block of c == a left in: the lane's position "in a itself" is a gap by construction, so those entries add nothing.
 //   M2Cand { map of (c -> b), columns of b, len(c) - 1, len(b) - 1, LDS row of c }
 // A direct edge reads the identity map (position in b = the staged position itself); an entry that does not count
 // (c == b in a triplet pass) and the M2_UBATCH - 1 padding entries behind the table point at an LDS row that holds only
-// gaps.  The gather therefore has no flags and no special cases: every entry is
+// gaps.  The walk therefore has no flags and no special cases: every entry is
 //   r = row[c][lane];  q = map[min(r, len(c) - 1)];  j = col[min(q, len(b) - 1)];  valid = r, q are not gaps
-// and, read with wave-uniform indices, the descriptors arrive by scalar loads -- no descriptor arithmetic on the
-// vector unit, nothing moved through LDS and v_readfirstlane.
-constexpr int M2_UBATCH = 4;   // candidates looked up side by side by k_m2_gather_unit
+// and, read with wave-uniform indices from memory no kernel writes while it is read, the descriptors arrive by scalar
+// loads -- no descriptor arithmetic on the vector unit.  The tables depend only on the tree, so they are written
+// once per batch, for all joins, before the merging starts.
+constexpr int M2_UBATCH = 4;   // candidates looked up side by side
 typedef const __attribute__((address_space(1))) uint16_t m2_gu16;
 typedef const __attribute__((address_space(1))) int m2_gi32;
 struct __attribute__((aligned(32))) M2Cand {
@@ -405,50 +216,166 @@ struct __attribute__((aligned(32))) M2Cand {
     int pad;
 };
 static_assert(sizeof(M2Cand) == 32, "M2Cand is read as one 8-dword scalar load");
+// worst case over all trees: every pair of reads is joined once, sum over the joins of |B| <= n (n - 1) / 2
+static inline long long m2_tab_entries(int n) { return static_cast<long long>(n) * (n - 1) / 2 * (n + 1) + static_cast<long long>(std::max(0, n - 1)) * (M2_UBATCH - 1) + 1; }
 
 __global__ void k_m2_identity(uint16_t* ident) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x < 65536) ident[x] = static_cast<uint16_t>(x);
 }
 
-__global__ void __launch_bounds__(64) k_m2_candidates(M2Args A, int round, M2Cand* tab, const long long* tab_off, const uint16_t* ident) {
+__global__ void __launch_bounds__(64) k_m2_tables(M2Args A, M2Cand* tab, const uint16_t* ident) {
     __shared__ int s_b[M2_MAXN];
-    const int g = A.g0 + blockIdx.x;
+    __shared__ unsigned s_mask[2 * M2_MAXN];
+    const int g = blockIdx.x;
     const M2Group G = A.groups[g];
-    if (round >= G.n - 1 || A.ovf[g] != 0) return;
     const int n = G.n, fm = G.first_member;
-    const int2 jn = A.joins[fm + round];
-    const unsigned maskB = A.nodemask[2 * fm + jn.y];
+    if (n < 2) return;
     const int lane = threadIdx.x;
-    if (lane < M2_MAXN && ((maskB >> lane) & 1u)) s_b[__popc(maskB & ((1u << lane) - 1u))] = lane;
-    const int nbm = __popc(maskB);
+    if (lane < n) s_mask[lane] = 1u << lane;
     __syncthreads();
-    M2Cand* const T = tab + tab_off[g];
-    const int E = nbm * (n + 1);
-    for (int e = lane; e < E + M2_UBATCH - 1; e += 64) {
-        M2Cand C;
-        C.pad = 0;
-        if (e >= E) {   // padding: the batch that holds the last entries reads up to M2_UBATCH - 1 more
-            C.map = ident; C.col = A.col + A.members[fm].col_base; C.lenc_m1 = 0; C.lenb_m1 = 0; C.row_off = M2_MAXN * 128;
-        } else {
-            const int pass = e / nbm, b = s_b[e % nbm];
-            const int cu = pass == 0 ? b : pass - 1;
-            const M2Member Mc = A.members[fm + cu], Mb = A.members[fm + b];
-            C.col = A.col + Mb.col_base;
-            C.lenb_m1 = max(Mb.len - 1, 0);
-            if (pass == 0) { C.map = ident; C.lenc_m1 = 65534; C.row_off = b * 128; }
-            else {
-                const int bslot = cu == b ? 0 : (b < cu ? b : b - 1);
-                C.map = A.map + Mc.map_base + static_cast<long long>(bslot) * Mc.len;
-                C.lenc_m1 = max(Mc.len - 1, 0);
-                C.row_off = (cu == b ? M2_MAXN : cu) * 128;
+    int off = 0;
+    for (int k = 0; k + 1 < n; ++k) {
+        const int2 jn = A.joins[fm + k];
+        const unsigned maskA = s_mask[jn.x], maskB = s_mask[jn.y];
+        if (lane < M2_MAXN && ((maskB >> lane) & 1u)) s_b[__popc(maskB & ((1u << lane) - 1u))] = lane;
+        const int nbm = __popc(maskB);
+        __syncthreads();
+        if (lane == 0) { s_mask[n + k] = maskA | maskB; A.join_tab[fm + k] = off; }
+        M2Cand* const T = tab + G.tab_base + off;
+        const int E = nbm * (n + 1);
+        for (int e = lane; e < E + M2_UBATCH - 1; e += 64) {
+            M2Cand C;
+            C.pad = 0;
+            if (e >= E) {   // padding: the batch that holds the last entries reads up to M2_UBATCH - 1 more
+                C.map = ident; C.col = A.col + A.members[fm].col_base; C.lenc_m1 = 0; C.lenb_m1 = 0; C.row_off = M2_MAXN * 128;
+            } else {
+                const int pass = e / nbm, b = s_b[e % nbm];
+                const int cu = pass == 0 ? b : pass - 1;
+                const M2Member Mc = A.members[fm + cu], Mb = A.members[fm + b];
+                C.col = A.col + Mb.col_base;
+                C.lenb_m1 = max(Mb.len - 1, 0);
+                if (pass == 0) { C.map = ident; C.lenc_m1 = 65534; C.row_off = b * 128; }
+                else {
+                    const int bslot = cu == b ? 0 : (b < cu ? b : b - 1);
+                    C.map = A.map + Mc.map_base + static_cast<long long>(bslot) * Mc.len;
+                    C.lenc_m1 = max(Mc.len - 1, 0);
+                    C.row_off = (cu == b ? M2_MAXN : cu) * 128;
+                }
             }
+            T[e] = C;
         }
-        T[e] = C;
+        off += E + M2_UBATCH - 1;
+        __syncthreads();
     }
 }
 
-// Unit weights: a list entry is one register, (column << 16) | weight (a column is < 65535, a weight at most
+// =============================================================================================
+// k_m2_group: all joins of one group on one wavefront
+
+typedef unsigned long long m2_u64;
+
+__device__ __forceinline__ int m2_rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ m2_u64 m2_readlane64(m2_u64 v, int l) {
+    const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), l));
+    const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), l));
+    return (static_cast<m2_u64>(hi) << 32) | lo;
+}
+// wave-wide inclusive prefix sum / maximum / minimum of an int (ds_bpermute; used once per block of rows)
+__device__ __forceinline__ int m2_incl_sum(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ int m2_wave_max(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ int m2_wave_min(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ int m2_excl_max(int v, int identity, int lane) {   // exclusive prefix maximum over the lanes
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(x, d);
+        if (lane >= d) x = max(x, o);
+    }
+    const int e = __shfl_up(x, 1);
+    return lane == 0 ? identity : e;
+}
+__device__ __forceinline__ int m2_suffix_min_incl(int v, int lane) {          // inclusive suffix minimum over the lanes
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_down(x, d);
+        if (lane + d < 64) x = min(x, o);
+    }
+    return x;
+}
+// inclusive prefix maximum of a 64-bit value over the wavefront: DPP row shifts inside the rows of 16, then the last
+// lane of row 0 / 2 broadcast into row 1 / 3 and lane 31 into rows 2 and 3 (lanes without a source read 0, the identity)
+__device__ __forceinline__ m2_u64 m2_scan_max64(m2_u64 v) {
+#define M2_SCAN_STEP(CTRL, ROWMASK)                                                                                              \
+    {                                                                                                                            \
+        const unsigned lo = static_cast<unsigned>(v), hi = static_cast<unsigned>(v >> 32);                                       \
+        const unsigned olo = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(lo), CTRL, ROWMASK, 0xf, false)); \
+        const unsigned ohi = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(hi), CTRL, ROWMASK, 0xf, false)); \
+        const m2_u64 o = (static_cast<m2_u64>(ohi) << 32) | olo;                                                                 \
+        v = o > v ? o : v;                                                                                                       \
+    }
+    M2_SCAN_STEP(0x111, 0xf) M2_SCAN_STEP(0x112, 0xf) M2_SCAN_STEP(0x114, 0xf) M2_SCAN_STEP(0x118, 0xf)
+    M2_SCAN_STEP(0x142, 0xa) M2_SCAN_STEP(0x143, 0xc)
+#undef M2_SCAN_STEP
+    return v;
+}
+
+struct M2Join {       // wave-uniform description of one join
+    int n, fm;
+    unsigned maskA, maskB;
+    int nA, nB;
+};
+
+// A row's list -> filter, order by column, append to the match list.  ej[k] < 0: empty slot.
+// (macro: the lists must stay in registers, every index a compile-time constant)
+#define M2_FINISH_ROW()                                                                                                  \
+    {                                                                                                                    \
+        int wmax = 0;                                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < M2_CAP; ++k) wmax = max(wmax, ew[k]);                                      \
+        int kept = 0;                                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < M2_CAP; ++k) {                                                             \
+            /* noise filter (spec v2, step 5): entries lighter than half the row's heaviest are dropped */              \
+            const bool keep = k < cnt && 2 * ew[k] >= wmax;                                                              \
+            if (!keep) ej[k] = -1;                                                                                       \
+            kept += keep ? 1 : 0;                                                                                        \
+        }                                                                                                                \
+        if (!row) kept = 0;                                                                                              \
+        st_filtered += row ? static_cast<unsigned>(cnt - kept) : 0u;                                                     \
+        st_rowsf += (row && kept < cnt) ? 1u : 0u;                                                                       \
+        const int incl = m2_incl_sum(kept, lane);                                                                        \
+        m2_u64* const mine = ent + ne + (incl - kept);                                                                   \
+        if (row) {                                                                                                       \
+            _Pragma("unroll") for (int k = 0; k < M2_CAP; ++k) {                                                         \
+                if (ej[k] >= 0) {   /* by column: rank of the entry among the kept ones (columns are distinct) */       \
+                    int rank = 0;                                                                                        \
+                    _Pragma("unroll") for (int q = 0; q < M2_CAP; ++q) rank += (ej[q] >= 0 && ej[q] < ej[k]) ? 1 : 0;    \
+                    mine[rank] = (static_cast<m2_u64>(static_cast<unsigned>(i)) << 48) |                                 \
+                                 (static_cast<m2_u64>(static_cast<unsigned>(ej[k])) << 32) | static_cast<unsigned>(ew[k]); \
+                }                                                                                                        \
+            }                                                                                                            \
+            part[i] = -1;                                                                                                \
+        }                                                                                                                \
+        ne += __builtin_amdgcn_readlane(incl, 63);                                                                       \
+    }
+
+// ---- rows of one join, unit weights ----
+// A list entry is one register, (column << 16) | weight (a column is < 65535, a weight at most
 // |A| |B| (n + 1) <= 8448); 0xFFFF0000 is an empty slot, an invalid candidate carries a column no entry can hold.
 // The columns of a list are distinct, so at most one entry matches.  Three tiers, each behind a wave-wide test:
 // entries 0-3; entries 4-7 and the append into 0-7 (some lane of the wave meets a new column at most steps, so
@@ -480,33 +407,31 @@ constexpr unsigned M2_EMPTY = 0xFFFF0000u;
                 M2_MATCH1(8, M2_CAP)                                                                   \
                 /* a new column; beyond M2_CAP distinct columns it is ignored (spec v2, step 5) */     \
                 M2_APPEND1(8, M2_CAP)                                                                  \
+                capped = capped || !hit_;                                                              \
             }                                                                                          \
         }                                                                                              \
     }
 
-__global__ void __launch_bounds__(64) k_m2_gather_unit(M2Args A, int round, const M2Cand* __restrict__ tab, const long long* __restrict__ tab_off) {
-    __shared__ uint16_t s_r[M2_MAXN + 1][64];   // position of the lane's base in every other member (0xFFFF: gap); last row: gaps
-    const int g = A.g0 + blockIdx.y;
-    const M2Group G = A.groups[g];
-    if (round >= G.n - 1 || A.ovf[g] != 0) return;
-    const int n = G.n, fm = G.first_member;
-    const int2 jn = A.joins[fm + round];
-    const unsigned maskA = A.nodemask[2 * fm + jn.x], maskB = A.nodemask[2 * fm + jn.y];
-    const int nA = A.ncols[2 * fm + jn.x];
-    const int E = __popc(maskB) * (n + 1);
-    const M2Cand* const T = tab + tab_off[g];
+__device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, const M2Join& J, const M2Cand* __restrict__ T,
+                                            unsigned char* smem, m2_u64* ent, int* part, unsigned& st_capped, unsigned& st_filtered,
+                                            unsigned& st_rowsf) {
+    uint16_t (*s_r)[64] = reinterpret_cast<uint16_t (*)[64]>(smem);   // [M2_MAXN + 1][64]: position of the lane's base in every other member; last row: gaps
     const int lane = threadIdx.x;
+    const int n = J.n, fm = J.fm, nA = J.nA;
+    const int E = __popc(J.maskB) * (n + 1);
     s_r[M2_MAXN][lane] = static_cast<uint16_t>(M2_NONE);   // (every lane reads its own column of s_r only)
     const unsigned char* const s_rlane = reinterpret_cast<const unsigned char*>(&s_r[0][lane]);
-    for (int i0 = blockIdx.x * 64; i0 < nA; i0 += gridDim.x * 64) {
+    int ne = 0;
+    for (int i0 = 0; i0 < nA; i0 += 64) {
         const int i = i0 + lane;
         unsigned pe[M2_CAP];
 #pragma unroll
         for (int k = 0; k < M2_CAP; ++k) pe[k] = M2_EMPTY;
         int cnt = 0;
+        bool capped = false;
         const bool row = i < nA;
         for (int a = 0; a < n; ++a) {
-            if (!((maskA >> a) & 1u)) continue;
+            if (!((J.maskA >> a) & 1u)) continue;
             const unsigned p = row ? A.pos[G.pos_base + static_cast<long long>(a) * G.wcap + i] : M2_NONE;
             const bool havep = p != M2_NONE;
             if (!__ballot(havep)) continue;
@@ -545,494 +470,444 @@ __global__ void __launch_bounds__(64) k_m2_gather_unit(M2Args A, int round, cons
                 for (int u = 0; u < M2_UBATCH; ++u) M2_ADD1(jj[u], rr[u] != M2_NONE && qq[u] != M2_NONE)
             }
         }
-        if (row) {
-            // noise filter and ordering by column: as in k_m2_gather
-            int ej[M2_CAP], ew[M2_CAP];
+        st_capped += (row && capped) ? 1u : 0u;
+        int ej[M2_CAP], ew[M2_CAP];
 #pragma unroll
-            for (int k = 0; k < M2_CAP; ++k) { ej[k] = k < cnt ? static_cast<int>(pe[k] >> 16) : -1; ew[k] = k < cnt ? static_cast<int>(pe[k] & 0xffffu) : 0; }
-            int wmax = 0;
-#pragma unroll
-            for (int k = 0; k < M2_CAP; ++k) wmax = max(wmax, ew[k]);
-            {
-                int kept = 0;
-#pragma unroll
-                for (int k = 0; k < M2_CAP; ++k) {
-                    const bool keep = k < cnt && 2 * ew[k] >= wmax;
-                    if (!keep) ej[k] = 0x7fffffff;
-                    kept += keep ? 1 : 0;
-                }
-                cnt = kept;
-            }
-            unsigned long long* const mine = A.row_ent + (G.row_base + i) * static_cast<long long>(G.cap);
-#pragma unroll
-            for (int k = 0; k < M2_CAP; ++k) {
-                if (ej[k] != 0x7fffffff && ej[k] >= 0) {
-                    int rank = 0;
-#pragma unroll
-                    for (int q = 0; q < M2_CAP; ++q)
-                        if (ej[q] >= 0 && ej[q] < ej[k]) ++rank;
-                    mine[rank] = (static_cast<unsigned long long>(static_cast<unsigned>(ej[k])) << 32) | static_cast<unsigned>(ew[k]);
-                }
-            }
-            A.row_cnt[G.row_base + i] = static_cast<uint16_t>(cnt);
-        }
+        for (int k = 0; k < M2_CAP; ++k) { ej[k] = k < cnt ? static_cast<int>(pe[k] >> 16) : -1; ew[k] = k < cnt ? static_cast<int>(pe[k] & 0xffffu) : 0; }
+        M2_FINISH_ROW()
     }
+    return ne;
 }
 #undef M2_ADD1
 #undef M2_MATCH1
 #undef M2_APPEND1
-#undef M2_ADD
 
-// maximum of a 64-bit value over the 16 lanes of a DPP row
-__device__ __forceinline__ unsigned long long m2_rowmax16(unsigned long long v) {
-    // maximum over the 16 lanes of a DPP row, delivered to every lane of the row (row_ror 8, 4, 2, 1)
-#define M2_STEP(CTRL)                                                                                                         \
-    {                                                                                                                         \
-        const unsigned lo = static_cast<unsigned>(v), hi = static_cast<unsigned>(v >> 32);                                    \
-        const unsigned olo = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(lo), CTRL, 0xf, 0xf, false)); \
-        const unsigned ohi = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(hi), CTRL, 0xf, 0xf, false)); \
-        const unsigned long long o = (static_cast<unsigned long long>(ohi) << 32) | olo;                                      \
-        v = o > v ? o : v;                                                                                                    \
-    }
-    M2_STEP(0x128) M2_STEP(0x124) M2_STEP(0x122) M2_STEP(0x121)
-#undef M2_STEP
-    return v;
+// ---- rows of one join, any weights ----
+// The row's list (first M2_CAP distinct partner columns in the canonical enumeration order of spec v2, step 5:
+// a ascending; direct edges b ascending; then c ascending, b ascending) lives in registers; a candidate is
+// compared with the first entries before anything else (same-molecule reads agree on 1-3 columns).  Loads are
+// issued in independent batches: the positions r_c of every third sequence first (LDS), then up to M2_BATCH (c, b)
+// pairs at a time -- the dependent chain map -> map -> col of one candidate is three memory latencies long.
+constexpr int M2_BATCH = 4;
+
+__device__ __forceinline__ long long m2_uniform64(long long v) {   // a wave-uniform 64-bit value into scalar registers
+    const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+    const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32)));
+    return static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
 
-// ---- heaviest chain of one merge round: four groups per wavefront, 16 lanes each ----
-// Node value = (f << 32) | ~id, so that the maximum prefers the larger f and then the earlier match
-// (id = row * M2_CAP + index in the row + 1; 0 = no match).  All matches of a row are looked up before any of
-// them is entered.
-// Prefix maxima over the second child's columns are kept for the M2_PWIN = 512 columns behind the front in three
-// levels of PREFIX arrays: L0[c] = best over the columns of c's block of 8 up to c, L1[b] = best over the blocks of
-// b's superblock (64 columns) up to b, L2[s] = best over everything up to superblock s (a new superblock starts
-// with its predecessor's value); what lies behind the 8 superblocks ending at the front's is one scalar.  A match
-// with column j reads THREE values -- L0[j - 1], L1[block - 1], L2[superblock - 1], where they exist -- and
-// entering it raises the at most 8 + 8 + 8 entries from its column, block and superblock to the end of their
-// block, superblock and the front (LDS maxima without return).  (A step function over single columns raised from
-// j up to the front, which this replaces, degenerates when the front runs ahead of the heavy matches: clusters of
-// two molecules.)  The 16 lanes of a group serve the 16 entries of one row.  When a match lies in a superblock that
-// has left the window (448-511 columns behind the largest column seen up to and including its row), the window
-// cannot answer: the group's round is flagged (redo) and done by k_m2_chain_exact, which keeps the prefix maxima
-// of ALL columns in a Fenwick tree.
-constexpr int M2_PWIN = 512;
-constexpr int M2_L1 = M2_PWIN, M2_L2 = M2_PWIN + M2_PWIN / 8, M2_PSIZE = M2_PWIN + M2_PWIN / 8 + M2_PWIN / 64;
+#define M2_ADD(J, W, VALID)                                                                            \
+    {                                                                                                  \
+        const int j_ = (J), w_ = (W);                                                                  \
+        bool hit_ = !(VALID);                                                                          \
+        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                                             \
+            const bool m_ = !hit_ && ej[k_] == j_;                                                     \
+            ew[k_] += m_ ? w_ : 0;                                                                     \
+            hit_ = hit_ || m_;                                                                         \
+        }                                                                                              \
+        if (__ballot(!hit_)) {                                                                         \
+            _Pragma("unroll") for (int k_ = 3; k_ < M2_CAP; ++k_) {                                    \
+                const bool m_ = !hit_ && ej[k_] == j_;                                                 \
+                ew[k_] += m_ ? w_ : 0;                                                                 \
+                hit_ = hit_ || m_;                                                                     \
+            }                                                                                          \
+            /* a new column; beyond M2_CAP distinct columns it is ignored (spec v2, step 5) */         \
+            const bool app_ = !hit_ && cnt < M2_CAP;                                                   \
+            capped = capped || (!hit_ && !app_);                                                       \
+            _Pragma("unroll") for (int k_ = 0; k_ < M2_CAP; ++k_) {                                    \
+                const bool s_ = app_ && k_ == cnt;                                                     \
+                ej[k_] = s_ ? j_ : ej[k_];                                                             \
+                ew[k_] = s_ ? w_ : ew[k_];                                                             \
+            }                                                                                          \
+            cnt += app_ ? 1 : 0;                                                                       \
+        }                                                                                              \
+    }
 
-__device__ __forceinline__ int m2_qmax_i32(int v) {   // maximum over the 16 lanes of a DPP row, in every lane
-    // one v_max_i32_dpp per rotation (every lane of a rotation has a source, so there is no `old` operand to keep; written
-    // as asm because the compiler emits a move + a DPP move + a maximum for the builtin).  s_nop 1: a DPP operand read
-    // needs two wait states after the VALU write of that register.
-#define M2_QSTEP(ROR) asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %1 row_ror:" #ROR " row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(v));
-    M2_QSTEP(8) M2_QSTEP(4) M2_QSTEP(2) M2_QSTEP(1)
-#undef M2_QSTEP
-    return v;
-}
-
-__global__ void __launch_bounds__(64) k_m2_chain_q(M2Args A, int round, int nactive) {
-    __shared__ unsigned long long s_buf[4][M2_PSIZE > 256 ? M2_PSIZE : 256];   // the three levels, later the traceback stage
-    const int lane = threadIdx.x, qd = lane >> 4, t = lane & 15;
-    const int g = A.g0 + blockIdx.x * 4 + qd;
-    bool act = g < nactive;
-    M2Group G{};
-    if (act) G = A.groups[g];
-    if (act && round >= G.n - 1) act = false;
-    if (act && A.ovf[g] != 0) act = false;   // dropped (coherence guard, or a profile outgrew its capacity)
-    int nA = 0, nB = 0;
-    if (act) {
-        const int2 jn = A.joins[G.first_member + round];
-        nA = A.ncols[2 * G.first_member + jn.x];
-        nB = A.ncols[2 * G.first_member + jn.y];
-    }
-    (void)nB;
-    unsigned long long* const P = &s_buf[qd][0];
-    for (int x = t; x < M2_PSIZE; x += 16) P[x] = 0;
-    unsigned long long pbelow = 0;   // best over the superblocks that left the window
-    int sbT = 0;                     // superblock of the front: the window holds superblocks sbT - 7 .. sbT
-    unsigned long long* const ent = A.row_ent + G.row_base * static_cast<long long>(M2_CAP);
-    unsigned* const prd = A.row_pred + G.row_base * static_cast<long long>(M2_CAP);
-    for (int i = t; i < nA; i += 16) A.part[G.row_base + i] = -1;
-    int top = -1;
-    unsigned long long lbest = 0;    // best node entered by this lane (the chain's last match is the overall maximum)
-    bool bad = false;
-    const int nAmax = max(max(__shfl(nA, 0), __shfl(nA, 16)), max(__shfl(nA, 32), __shfl(nA, 48)));
-    // rows in blocks of 16: lane t holds entry t and the count of each of the block's rows (the counts are
-    // broadcast loads: all 16 lanes of a group read the same address)
-    unsigned long long eb[16];
-    int cb[16];
-    auto load_block = [&](int ib, unsigned long long (&e)[16], int (&c)[16]) {
-        // unconditional loads (a row index clamped into the group's rows): a select around each load would make
-        // the compiler wait for every one of them in turn
-        const int last = max(nA - 1, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) e[r] = ent[static_cast<long long>(min(ib + r, last)) * M2_CAP + t];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = static_cast<int>(A.row_cnt[G.row_base + min(ib + r, last)]);
-    };
-    load_block(0, eb, cb);
-    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
-    for (int ib = 0; ib < nAmax; ib += 16) {
-        unsigned long long en[16];
-        int cn[16];
-        load_block(ib + 16, en, cn);   // next block in flight while this one is processed
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = ib + r;
-            const bool mk0 = act && i < nA && t < cb[r];
-            const unsigned long long e = eb[r];
-            const int j = static_cast<int>(e >> 32);
-            // the window follows the largest column seen up to and including this row
-            const int newtop = m2_qmax_i32(mk0 ? j : -1);
-            const int T = max(top, newtop);
-            top = T;
-            if ((T >> 6) > sbT) {
-                // new superblocks start with the prefix of everything before them; the slots they take over held the
-                // superblocks 8 further back, whose prefix becomes the scalar for "behind the window"
-                const unsigned long long carried = P[M2_L2 + (sbT & 7)];
-                const int adv = min((T >> 6) - sbT, 8);
-                for (int q = 1; q <= adv; ++q) {
-                    const int slot = ((T >> 6) - adv + q) & 7;
-                    pbelow = P[M2_L2 + slot];
-                    if (t == 0) P[M2_L2 + slot] = carried;
-                    if (t < 8) P[M2_L1 + slot * 8 + t] = 0;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) P[slot * 64 + u * 16 + t] = 0;
-                }
-                if ((T >> 6) - sbT >= 8) pbelow = carried;
-                sbT = T >> 6;
-            }
-            if (mk0 && (j >> 6) < sbT - 7) bad = true;
-            const bool mk = mk0 && !bad;
-            // query: best over the columns < j, state before the row (unconditional reads, selected afterwards)
-            const int jb = j >> 3, js = j >> 6;
-            const unsigned long long r0 = P[(j - 1) & (M2_PWIN - 1)];
-            const unsigned long long r1 = P[M2_L1 + ((jb - 1) & 63)];
-            const unsigned long long r2 = P[M2_L2 + ((js - 1) & 7)];
-            const unsigned long long q0 = (j & 7) ? r0 : 0ull;
-            const unsigned long long q1 = (jb & 7) ? r1 : 0ull;
-            const unsigned long long q2 = (js >= 1 && js - 1 >= sbT - 7) ? r2 : pbelow;
-            const unsigned long long q01 = q0 > q1 ? q0 : q1;
-            unsigned long long v = q01 > q2 ? q01 : q2;
-            if (!mk) v = 0;
-            const unsigned f = static_cast<unsigned>(e) + static_cast<unsigned>(v >> 32);
-            const unsigned pred = v ? ~static_cast<unsigned>(v) : 0u;
-            const unsigned id = static_cast<unsigned>(i) * M2_CAP + static_cast<unsigned>(t) + 1u;
-            const unsigned long long nv = mk ? ((static_cast<unsigned long long>(f) << 32) | static_cast<unsigned>(~id)) : 0ull;
-            if (mk) prd[static_cast<long long>(i) * M2_CAP + t] = pred;
-            // enter the matches (all queries of the row were issued before: LDS operations of a wave execute in order)
-            // One predicated block, no inner branches: positions past the end of the block are clamped onto its last
-            // entry (entered more than once, harmless for a maximum).  Only lanes with a match take part -- maxima on one
-            // LDS address serialise, and the stale entries of the other lanes would all name the same few slots.
-            if (mk) {
-                const int c0 = (j & ~7) & (M2_PWIN - 1), b0 = (jb & ~7) & 63;
-                const int cj = j & 7, cb8 = jb & 7;
-#pragma unroll
-                for (int d = 0; d < 8; ++d) {
-                    atomicMax(&P[c0 + min(cj + d, 7)], nv);
-                    atomicMax(&P[M2_L1 + b0 + min(cb8 + d, 7)], nv);
-                }
-                for (int sb = js; sb <= sbT; ++sb) atomicMax(&P[M2_L2 + (sb & 7)], nv);
-            }
-            lbest = nv > lbest ? nv : lbest;
-        }
-        bad = m2_qmax_i32(bad ? 1 : 0) != 0;   // (a failed group keeps going on garbage until here; its round is redone)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { eb[r] = en[r]; cb[r] = cn[r]; }
-    }
-    unsigned long long best = m2_rowmax16(lbest);
-    if (act && bad && t == 0) A.redo[g] = 1;
-    if (bad) { nA = 0; best = 0; }
-    if (!act) { nA = 0; best = 0; }
-    // traceback through the stored predecessors, 16 rows staged at a time (the P window is free now)
-    __threadfence();
-    unsigned long long* const stage = &s_buf[qd][0];   // [16 rows][16 entries]
-    const unsigned long long clk1 = __builtin_amdgcn_s_memtime();
-    unsigned id = best ? ~static_cast<unsigned>(best) : 0u;
-    int steps = 2 * nA + 64;
-    while (__builtin_amdgcn_ballot_w64(id != 0 && steps > 0)) {
-        const bool go = id != 0 && steps > 0;
-        const int itop = go ? static_cast<int>((id - 1u) / M2_CAP) : 0;
-        const int i0 = max(0, itop - 15);
-        {
-            // all loads first, then the LDS writes (interleaved, every load would wait for the write before it)
-            unsigned long long ev[16];
-            unsigned pv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {   // (rows above itop are never followed: clamped, not masked)
-                ev[r] = ent[static_cast<long long>(min(i0 + r, itop)) * M2_CAP + t];
-                pv[r] = prd[static_cast<long long>(min(i0 + r, itop)) * M2_CAP + t];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) stage[r * 16 + t] = (ev[r] & 0xffffffff00000000ull) | pv[r];
-        }
-        --steps;
-        while (__builtin_amdgcn_ballot_w64(go && id != 0 && steps > 0 && static_cast<int>((id - 1u) / M2_CAP) >= i0)) {
-            const bool in = go && id != 0 && steps > 0 && static_cast<int>((id - 1u) / M2_CAP) >= i0;
-            if (in) {
-                const int i = static_cast<int>((id - 1u) / M2_CAP), k = static_cast<int>((id - 1u) % M2_CAP);
-                const unsigned long long e = stage[(i - i0) * 16 + k];
-                if (t == 0) A.part[G.row_base + i] = static_cast<int>(e >> 32);
-                id = static_cast<unsigned>(e);
-                --steps;
-            }
-        }
-    }
-    if (A.clk && blockIdx.x == 0 && lane == 0) {
-        const unsigned long long clk2 = __builtin_amdgcn_s_memtime();
-        A.clk[0] = clk1 - clk0; A.clk[1] = clk2 - clk1; A.clk[2] = static_cast<unsigned long long>(nAmax);
-    }
-}
-
-// ---- heaviest chain, exact for any pattern of matches: one wavefront per flagged group ----
-// Fenwick tree over the second child's columns: a match with column j reads the prefix maximum of nodes j,
-// j - lowbit(j), .. (columns < j) and afterwards raises nodes j + 1, (j + 1) + lowbit, ..; sub-groups of 16 lanes
-// serve one match each, one node per lane.  All matches of a row are looked up before any of them is entered.
-// GBIT: the tree lives in HBM (wcap + 1 nodes per group at row_base + g) -- profiles too wide for LDS.
-template <bool GBIT>
-__global__ void __launch_bounds__(64) k_m2_chain_exact(M2Args A, int round, unsigned long long* gbit) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int g = A.g0 + blockIdx.x;
-    if (!A.redo[g]) return;
-    const M2Group G = A.groups[g];
-    const int fm = G.first_member;
-    const int2 jn = A.joins[fm + round];
-    const int nA = A.ncols[2 * fm + jn.x], nB = A.ncols[2 * fm + jn.y];
+__device__ __forceinline__ int m2_rows_general(const M2Args& A, const M2Group& G, const M2Join& J, unsigned char* smem, m2_u64* ent,
+                                               int* part, unsigned& st_capped, unsigned& st_filtered, unsigned& st_rowsf) {
+    uint16_t (*s_r)[64] = reinterpret_cast<uint16_t (*)[64]>(smem);                                  // [M2_MAXN][64]
+    long long* const s_mapbase = reinterpret_cast<long long*>(smem + (M2_MAXN + 1) * 128);            // the members' descriptors
+    long long* const s_colbase = s_mapbase + M2_MAXN;
+    long long* const s_seqoff = s_colbase + M2_MAXN;
+    int* const s_len = reinterpret_cast<int*>(s_seqoff + M2_MAXN);
+    int* const s_b = s_len + M2_MAXN;                                                                 // the second child's members, ascending
     const int lane = threadIdx.x;
-    const unsigned long long xclk0 = __builtin_amdgcn_s_memtime();
-    unsigned long long xent = 0;
-    unsigned long long* const s_stage = reinterpret_cast<unsigned long long*>(smem);   // [64 rows][M2_CAP]
-    unsigned long long* const s_nv = s_stage + 64 * M2_CAP;                              // [M2_CAP]
-    int* const s_j = reinterpret_cast<int*>(s_nv + M2_CAP);                             // [M2_CAP]
-    int* const s_cnt = s_j + M2_CAP;                                                    // [64]
-    unsigned long long* const bit = GBIT ? gbit + G.row_base + g : reinterpret_cast<unsigned long long*>(s_cnt + 64);   // [nB + 1]
-    for (int x = lane; x <= nB; x += 64) bit[x] = 0;
-    if (GBIT) __threadfence();
-    for (int i = lane; i < nA; i += 64) A.part[G.row_base + i] = -1;
-    const unsigned long long* const ent = A.row_ent + G.row_base * static_cast<long long>(M2_CAP);
-    unsigned* const prd = A.row_pred + G.row_base * static_cast<long long>(M2_CAP);
-    const int sub = lane >> 4, t = lane & 15;
-    const unsigned nBu = static_cast<unsigned>(nB);
-    const int last = max(nA - 1, 0);
-    unsigned long long best = 0;
-    auto bit_load = [&](unsigned x) -> unsigned long long {
-        if (GBIT) return __hip_atomic_load(&bit[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the atomics act in L2)
-        return bit[x];
-    };
-    for (int i0 = 0; i0 < nA; i0 += 64) {
-        __syncthreads();
-        {   // 64 rows: lane = row; unconditional loads (clamped row index)
-            const int rowi = min(i0 + lane, last);
-            unsigned long long ev[M2_CAP];
-#pragma unroll
-            for (int k = 0; k < M2_CAP; ++k) ev[k] = ent[static_cast<long long>(rowi) * M2_CAP + k];
-            const int c = static_cast<int>(A.row_cnt[G.row_base + rowi]);
-#pragma unroll
-            for (int k = 0; k < M2_CAP; ++k) s_stage[lane * M2_CAP + k] = ev[k];
-            s_cnt[lane] = (i0 + lane < nA) ? c : 0;
-        }
-        __syncthreads();
-        const int rows = min(64, nA - i0);
-        for (int r = 0; r < rows; ++r) {
-            const int c = min(__builtin_amdgcn_readfirstlane(s_cnt[r]), M2_CAP);
-            if (c == 0) continue;
-            xent += static_cast<unsigned>(c);
-            const int i = i0 + r;
-            for (int k0 = 0; k0 < c; k0 += 4) {          // queries
-                const int k = k0 + sub;
-                const bool act = k < c;
-                const unsigned long long e = act ? s_stage[r * M2_CAP + k] : 0ull;
-                const int j = static_cast<int>(e >> 32);
-                unsigned x = act ? static_cast<unsigned>(j) : 0u;
-#pragma unroll
-                for (int q = 0; q < 15; ++q) x = (q < t) ? (x & (x - 1u)) : x;
-                unsigned long long v = x ? bit_load(x) : 0ull;
-                v = m2_rowmax16(v);
-                const unsigned f = static_cast<unsigned>(e) + static_cast<unsigned>(v >> 32);
-                const unsigned pred = v ? ~static_cast<unsigned>(v) : 0u;
-                const unsigned id = static_cast<unsigned>(i) * M2_CAP + static_cast<unsigned>(k) + 1u;
-                const unsigned long long nv = (static_cast<unsigned long long>(f) << 32) | static_cast<unsigned>(~id);
-                if (act) {
-                    best = nv > best ? nv : best;
-                    if (t == 0) { prd[static_cast<long long>(i) * M2_CAP + k] = pred; s_j[k] = j; s_nv[k] = nv; }
-                }
-            }
-            __syncthreads();
-            for (int k0 = 0; k0 < c; k0 += 4) {          // updates
-                const int k = k0 + sub;
-                if (k < c) {
-                    const unsigned long long nv = s_nv[k];
-                    unsigned y = static_cast<unsigned>(s_j[k]) + 1u;
-#pragma unroll
-                    for (int q = 0; q < 15; ++q) y = (q < t && y <= nBu) ? y + (y & (0u - y)) : y;
-                    if (y <= nBu) atomicMax(&bit[y], nv);
-                }
-            }
-            __syncthreads();
-        }
+    const int n = J.n, fm = J.fm, nA = J.nA;
+    const unsigned maskB = J.maskB;
+    if (lane < M2_MAXN) {
+        const M2Member Me = A.members[fm + min(lane, n - 1)];
+        s_mapbase[lane] = Me.map_base; s_colbase[lane] = Me.col_base; s_seqoff[lane] = Me.seq_off; s_len[lane] = lane < n ? Me.len : 0;
+        if ((maskB >> lane) & 1u) s_b[__popc(maskB & ((1u << lane) - 1u))] = lane;
     }
-    {   // the chain's last match: maximum over the four sub-groups
-        const unsigned long long o1 = (static_cast<unsigned long long>(static_cast<unsigned>(__shfl_xor(static_cast<int>(best >> 32), 16))) << 32) |
-                                      static_cast<unsigned>(__shfl_xor(static_cast<int>(best), 16));
-        best = o1 > best ? o1 : best;
-        const unsigned long long o2 = (static_cast<unsigned long long>(static_cast<unsigned>(__shfl_xor(static_cast<int>(best >> 32), 32))) << 32) |
-                                      static_cast<unsigned>(__shfl_xor(static_cast<int>(best), 32));
-        best = o2 > best ? o2 : best;
-    }
-    // traceback through the stored predecessors, 64 rows staged at a time
-    __threadfence();
-    unsigned id = best ? ~static_cast<unsigned>(best) : 0u;
-    id = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(id)));
-    int steps = 2 * nA + 64;   // a chain has at most one match per row; staging a block also counts one step
-    while (id && --steps >= 0) {
-        const int itop = static_cast<int>((id - 1u) / M2_CAP);
-        const int i0 = max(0, itop - 63);
-        __syncthreads();
-        {
-            const int rowi = min(i0 + lane, itop);
-            unsigned long long ev[M2_CAP];
-            unsigned pv[M2_CAP];
-#pragma unroll
-            for (int k = 0; k < M2_CAP; ++k) { ev[k] = ent[static_cast<long long>(rowi) * M2_CAP + k]; pv[k] = prd[static_cast<long long>(rowi) * M2_CAP + k]; }
-#pragma unroll
-            for (int k = 0; k < M2_CAP; ++k) s_stage[lane * M2_CAP + k] = (ev[k] & 0xffffffff00000000ull) | pv[k];
-        }
-        __syncthreads();
-        while (id && --steps >= 0) {
-            const int i = static_cast<int>((id - 1u) / M2_CAP), k = static_cast<int>((id - 1u) % M2_CAP);
-            if (i < i0) break;
-            const unsigned long long e = s_stage[(i - i0) * M2_CAP + k];
-            if (lane == 0) A.part[G.row_base + i] = static_cast<int>(e >> 32);
-            id = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned>(e))));
-        }
-    }
-    if (lane == 0) A.redo[g] = 0;
-    if (A.xdbg && lane == 0) { A.xdbg[2 * g] = __builtin_amdgcn_s_memtime() - xclk0; A.xdbg[2 * g + 1] = (static_cast<unsigned long long>(nA) << 32) | xent; }
-}
-
-// ---- wave helpers for the renumbering (performance is irrelevant here) ----
-__device__ __forceinline__ int m2_excl_max(int v, int identity) {   // exclusive prefix maximum over the lanes
-    int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(x, d);
-        if (static_cast<int>(threadIdx.x & 63) >= d) x = max(x, o);
-    }
-    const int e = __shfl_up(x, 1);
-    return (threadIdx.x & 63) == 0 ? identity : e;
-}
-__device__ __forceinline__ int m2_suffix_min_incl(int v) {          // inclusive suffix minimum over the lanes
-    int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_down(x, d);
-        if (static_cast<int>(threadIdx.x & 63) + d < 64) x = min(x, o);
-    }
-    return x;
-}
-
-// ---- new column numbers, col / pos of every member: one workgroup of 256 threads per group ----
-__global__ void __launch_bounds__(256) k_m2_merge(M2Args A, int round, int* ncA, int* ncB, int* partB) {
-    const int g = A.g0 + blockIdx.x;
-    const M2Group G = A.groups[g];
-    if (round >= G.n - 1 || A.ovf[g] != 0) return;
-    const int n = G.n, fm = G.first_member;
-    const int2 jn = A.joins[fm + round];
-    const unsigned maskA = A.nodemask[2 * fm + jn.x], maskB = A.nodemask[2 * fm + jn.y];
-    const int nA = A.ncols[2 * fm + jn.x], nB = A.ncols[2 * fm + jn.y];
-    const int* part = A.part + G.row_base;
-    int* const nca = ncA + G.row_base;
-    int* const ncb = ncB + G.row_base;
-    int* const pb = partB + G.row_base;
-    __shared__ int s_newW;
-    const int lane = threadIdx.x & 63;
-    // partner rows of the second child's columns
-    for (int j = threadIdx.x; j < nB; j += blockDim.x) pb[j] = -1;
+    const int nbm = __popc(maskB);
     __syncthreads();
-    for (int i = threadIdx.x; i < nA; i += blockDim.x) {
+    int ne = 0;
+    for (int i0 = 0; i0 < nA; i0 += 64) {
+        const int i = i0 + lane;
+        int ej[M2_CAP], ew[M2_CAP];
+#pragma unroll
+        for (int k = 0; k < M2_CAP; ++k) { ej[k] = -1; ew[k] = 0; }
+        int cnt = 0;
+        bool capped = false;
+        const bool row = i < nA;
+        for (int a = 0; a < n; ++a) {
+            if (!((J.maskA >> a) & 1u)) continue;
+            const unsigned p = row ? A.pos[G.pos_base + static_cast<long long>(a) * G.wcap + i] : M2_NONE;
+            const bool havep = p != M2_NONE;
+            if (!__ballot(havep)) continue;
+            const M2Member Ma = A.members[fm + a];
+            const int xa = !havep ? 0 : dna5_code(A.seq[Ma.seq_off + p]);
+            {
+                const unsigned pidx = havep ? p : 0u;
+                for (int c0 = 0; c0 < n; c0 += 8) {
+                    uint16_t rv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = min(c0 + u, n - 1);
+                        const int slot = c == a ? 0 : (c < a ? c : c - 1);
+                        rv[u] = A.map[Ma.map_base + static_cast<long long>(slot) * Ma.len + pidx];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (c0 + u < n) s_r[c0 + u][lane] = (c0 + u != a && havep) ? rv[u] : static_cast<uint16_t>(M2_NONE);
+                }
+            }
+            // canonical order of the candidates: the direct edges (c = b) for b in B ascending, then for c ascending the
+            // triplets (c, b), b in B ascending, b != c -- a flat list of nbm + (n - 1) nbm entries
+            const int total = nbm * n;   // direct pass (ci = 0) + the n - 1 third sequences
+            int ci = 0, bi = 0;          // position in the flat list: pass ci (0 = direct; ci >= 1: c = ci - 1, skipping a), member bi
+            for (int f0 = 0; f0 < total; f0 += M2_BATCH) {
+                unsigned qq[M2_BATCH];
+                int jj[M2_BATCH], ww[M2_BATCH], bq[M2_BATCH];
+                bool ok[M2_BATCH];
+                unsigned rr[M2_BATCH], mm[M2_BATCH], rix[M2_BATCH];
+                int cuq[M2_BATCH], flg[M2_BATCH];   // flg: bit 0 candidate exists, bit 1 direct edge (c = b), bit 2 counted (direct or b != c)
+#pragma unroll
+                for (int u = 0; u < M2_BATCH; ++u) {
+                    const bool in = f0 + u < total;
+                    const int b = __builtin_amdgcn_readfirstlane(s_b[bi]);
+                    const int cu = ci == 0 ? b : ((ci - 1) + ((ci - 1) >= a ? 1 : 0));
+                    const unsigned r = s_r[cu][lane];
+                    const int bslot = cu == b ? 0 : (b < cu ? b : b - 1);
+                    const int lencu = __builtin_amdgcn_readfirstlane(s_len[cu]);
+                    const long long mbase = m2_uniform64(s_mapbase[cu]) + static_cast<long long>(bslot) * lencu;
+                    const unsigned ridx = min(r != M2_NONE ? r : 0u, static_cast<unsigned>(max(lencu - 1, 0)));
+                    mm[u] = A.map[mbase + ridx];
+                    rr[u] = r; rix[u] = ridx; cuq[u] = cu; bq[u] = b;
+                    flg[u] = (in ? 1 : 0) | (cu == b ? 2 : 0) | ((ci == 0 || b != cu) ? 4 : 0);
+                    bi = in ? bi + 1 : bi;
+                    const bool wrap = bi == nbm;
+                    bi = wrap ? 0 : bi;
+                    ci = wrap ? ci + 1 : ci;
+                }
+#pragma unroll
+                for (int u = 0; u < M2_BATCH; ++u) {
+                    qq[u] = (flg[u] & 2) ? rr[u] : mm[u];
+                    ok[u] = (flg[u] & 1) && (flg[u] & 4) && rr[u] != M2_NONE && qq[u] != M2_NONE;
+                    const int xc = dna5_code(A.seq[s_seqoff[cuq[u]] + rix[u]]);
+                    ww[u] = (xc << 16) | (((flg[u] & 2) ? 1 : 0) << 15) | m2_w0(xa, xc, A.ma, A.mm);   // (finished below)
+                }
+#pragma unroll
+                for (int u = 0; u < M2_BATCH; ++u) {
+                    const int b = __builtin_amdgcn_readfirstlane(bq[u]);
+                    const int lenb = __builtin_amdgcn_readfirstlane(s_len[b]);
+                    const unsigned qidx = min(ok[u] ? qq[u] : 0u, static_cast<unsigned>(max(lenb - 1, 0)));
+                    jj[u] = A.col[m2_uniform64(s_colbase[b]) + qidx];
+                    const int xc = ww[u] >> 16, wac = ww[u] & 0x7fff;
+                    const bool direct = (ww[u] >> 15) & 1;
+                    const int wcb = m2_w0(xc, dna5_code(A.seq[s_seqoff[b] + qidx]), A.ma, A.mm);
+                    ww[u] = direct ? wac : (wac < wcb ? wac : wcb);
+                }
+#pragma unroll
+                for (int u = 0; u < M2_BATCH; ++u)
+                    if (f0 + u < total) M2_ADD(jj[u], ww[u], ok[u])
+            }
+        }
+        st_capped += (row && capped) ? 1u : 0u;
+        M2_FINISH_ROW()
+    }
+    return ne;
+}
+#undef M2_ADD
+#undef M2_FINISH_ROW
+
+// ---- heaviest chain of one join over the match list, 64 matches per step ----
+// f(m) = w(m) + the best f over the matches with a smaller row AND a smaller column, "best" = larger f, then the
+// earlier match (oracle/msa2.c): a node is (f << 32) | ~id with id = 1 + the match's index in the list (row-major,
+// columns ascending inside a row), so an unsigned maximum picks it.  All matches of a row see the state before the row.
+//   Q[c] = best node among the matches entered so far with column <= c, kept for the columns up to the front F (the
+// largest column entered; everything beyond it equals Q[F], one scalar).  A block of up to 64 matches that ends on a
+// row boundary is (1) looked up in Q -- the matches of earlier blocks; (2) resolved against each other in registers:
+// lanes are in list order, so when lane s broadcasts its finished node every lane with a larger row and a larger column
+// takes the maximum, and lane s + 1 is finished in turn; (3) entered: Q is extended to the new front, the block's nodes
+// are written with LDS maxima and the prefix maximum is re-established from the block's smallest column to the front
+// by a DPP scan per 64 columns.  With RING the columns live in an LDS ring of M2_QW entries behind the front; a block
+// that reaches further back (unrelated reads in the cluster) makes the function return false and the join's chain is
+// redone with Q over all columns in HBM (RING = false; atomics and L2-coherent loads, rare).
+constexpr int M2_QW = 512;
+
+template <bool RING>
+__device__ __forceinline__ bool m2_chain_forward(const m2_u64* ent, int ne, unsigned* pred, m2_u64* Q, m2_u64& tail, int& err) {
+    const int lane = threadIdx.x;
+    int F = -1;
+    m2_u64 QF = 0;
+    auto q_load = [&](int c) -> m2_u64 {
+        if (RING) return Q[c & (M2_QW - 1)];
+        return __hip_atomic_load(&Q[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto q_store = [&](int c, m2_u64 v) {
+        if (RING) Q[c & (M2_QW - 1)] = v;
+        else __hip_atomic_store(&Q[c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    int m0 = 0;
+    while (m0 < ne) {
+        const int m = m0 + lane;
+        const bool in = m < ne;
+        const m2_u64 e = ent[min(m, ne - 1)];
+        // a block ends on a row boundary: the matches of the row that continues into the next block wait for it
+        const int inext = m0 + 64 < ne ? static_cast<int>(ent[m0 + 64] >> 48) : -1;
+        const int i = static_cast<int>(e >> 48), j = static_cast<int>((e >> 32) & 0xffffu);
+        const unsigned w = static_cast<unsigned>(e);
+        const bool act = in && i != inext;
+        const int nb = __popcll(__ballot(act));   // (the waiting matches are the last lanes: the list is in row order)
+        if (nb == 0) { err = 1; return true; }   // cannot happen: a row holds at most M2_CAP < 64 matches
+        const int jmax = m2_wave_max(act ? j : -1), jmin = m2_wave_min(act ? j : 0x7fffffff);
+        const int newF = max(F, jmax);
+        if (RING && newF - jmin >= M2_QW - 2) return false;
+        // (1) state before the block
+        m2_u64 best = 0;
+        if (act && j > 0) best = (j - 1 > F) ? QF : q_load(j - 1);
+        // (2) the block's own matches, in list order
+        const unsigned ij = (static_cast<unsigned>(i) << 16) | static_cast<unsigned>(j);
+        for (int s = 0; s < nb; ++s) {
+            const unsigned bh = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(best >> 32), s));
+            const unsigned ws = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(w), s));
+            const unsigned ijs = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(ij), s));
+            const m2_u64 nvs = (static_cast<m2_u64>(bh + ws) << 32) | static_cast<unsigned>(~static_cast<unsigned>(m0 + s + 1));
+            const bool dom = act && i > static_cast<int>(ijs >> 16) && j > static_cast<int>(ijs & 0xffffu);
+            best = (dom && nvs > best) ? nvs : best;
+        }
+        const unsigned id = static_cast<unsigned>(m) + 1u;
+        const m2_u64 nv = act ? ((static_cast<m2_u64>(w + static_cast<unsigned>(best >> 32)) << 32) | static_cast<unsigned>(~id)) : 0ull;
+        if (act) pred[m] = best ? ~static_cast<unsigned>(best) : 0u;
+        // (3) enter the block
+        for (int c0 = RING ? max(F + 1, newF - M2_QW + 1) : F + 1; c0 <= newF; c0 += 64)
+            if (c0 + lane <= newF) q_store(c0 + lane, QF);
+        if (!RING) __threadfence();
+        __syncthreads();
+        if (act) {
+            if (RING) atomicMax(&Q[j & (M2_QW - 1)], nv);
+            else atomicMax(&Q[j], nv);
+        }
+        if (!RING) __threadfence();
+        __syncthreads();
+        m2_u64 carry = jmin > 0 ? q_load(jmin - 1) : 0ull;
+        for (int c0 = jmin; c0 <= newF; c0 += 64) {
+            const int c = c0 + lane;
+            m2_u64 x = c <= newF ? q_load(c) : 0ull;
+            x = m2_scan_max64(x);
+            x = x > carry ? x : carry;
+            if (c <= newF) q_store(c, x);
+            carry = m2_readlane64(x, 63);
+        }
+        if (!RING) __threadfence();
+        __syncthreads();
+        QF = carry;
+        F = newF;
+        m0 += nb;
+    }
+    tail = QF;
+    return true;
+}
+
+// walk back through the predecessors: part[row] = column for the matches of the chain
+__device__ __forceinline__ void m2_chain_walk(const m2_u64* ent, int ne, const unsigned* pred, m2_u64 tail, int* part, int& err) {
+    const int lane = threadIdx.x;
+    unsigned cur = tail ? ~static_cast<unsigned>(tail) : 0u;
+    cur = static_cast<unsigned>(m2_rfl(static_cast<int>(cur)));
+    int steps = ne + 2;   // a predecessor has a smaller index: the walk visits every match at most once
+    while (cur != 0u && steps > 0) {
+        const int mb = static_cast<int>(cur - 1u) & ~63;
+        const int m = mb + lane;
+        const m2_u64 e = ent[min(m, ne - 1)];
+        const unsigned p = pred[min(m, ne - 1)];
+        unsigned long long visited = 0;
+        do {
+            const int l = static_cast<int>(cur - 1u) - mb;
+            visited |= 1ull << l;
+            cur = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(p), l));
+            --steps;
+        } while (cur != 0u && static_cast<int>(cur - 1u) >= mb && steps > 0);
+        if ((visited >> lane) & 1ull) part[static_cast<int>(e >> 48)] = static_cast<int>((e >> 32) & 0xffffu);
+    }
+    if (cur != 0u) err = 2;
+}
+
+// ---- new column numbers, col / pos of every member (one wavefront) ----
+// returns the width of the joined profile, or -1 when it exceeds the capacity
+__device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, const M2Join& J, const int* part, int* nca, int* ncb, int* pb) {
+    const int lane = threadIdx.x;
+    const int n = J.n, fm = J.fm, nA = J.nA, nB = J.nB;
+    // partner rows of the second child's columns
+    for (int j = lane; j < nB; j += 64) pb[j] = -1;
+    __threadfence_block();
+    __syncthreads();
+    for (int i = lane; i < nA; i += 64) {
         const int pj = part[i];
         if (pj >= 0) pb[pj] = i;
     }
     __threadfence_block();
     __syncthreads();
-    if (threadIdx.x < 64) {
-        // first child: column i -> i + (columns of the second child up to the previous matched partner) - matches before
-        int jprev = -1, t0 = 0;
-        for (int i0 = 0; i0 < nA; i0 += 64) {
-            const int i = i0 + lane;
-            const int pj = i < nA ? part[i] : -1;
-            const unsigned long long ball = __ballot(pj >= 0);
-            const int before = __popcll(ball & ((1ull << lane) - 1ull));
-            const int pm = max(m2_excl_max(pj, -1), jprev);
-            const int t = t0 + before;
-            if (i < nA) nca[i] = pj >= 0 ? i + pj - t : i + (pm + 1) - t;
-            t0 += __popcll(ball);
-            int mx = pj;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
-            jprev = max(jprev, mx);
-        }
-        const int nm = t0;
-        // second child: column j -> (row of the next matched pair, or nA) + j - matches before; descending for "next"
-        int inext = nA;
-        for (int j0 = ((nB - 1) / 64) * 64; j0 >= 0 && nB > 0; j0 -= 64) {
-            const int j = j0 + lane;
-            const int pi = j < nB ? pb[j] : -1;
-            int nx = m2_suffix_min_incl(pi >= 0 ? pi : 0x7fffffff);
-            nx = min(nx, inext);
-            if (j < nB) ncb[j] = nx;          // provisional: the row of the next matched pair at or after j
-            int mn = pi >= 0 ? pi : 0x7fffffff;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) mn = min(mn, __shfl_xor(mn, d));
-            inext = min(inext, mn);
-        }
-        int tb = 0;
-        for (int j0 = 0; j0 < nB; j0 += 64) {
-            const int j = j0 + lane;
-            const int pi = j < nB ? pb[j] : -1;
-            const unsigned long long ball = __ballot(pi >= 0);
-            const int before = tb + __popcll(ball & ((1ull << lane) - 1ull));
-            if (j < nB) ncb[j] = ncb[j] + j - before;   // matched: next = its own row
-            tb += __popcll(ball);
-        }
-        if (lane == 0) s_newW = nA + nB - nm;
+    // first child: column i -> i + (columns of the second child up to the previous matched partner) - matches before
+    int jprev = -1, t0 = 0;
+    for (int i0 = 0; i0 < nA; i0 += 64) {
+        const int i = i0 + lane;
+        const int pj = i < nA ? part[i] : -1;
+        const unsigned long long ball = __ballot(pj >= 0);
+        const int before = __popcll(ball & ((1ull << lane) - 1ull));
+        const int pm = max(m2_excl_max(pj, -1, lane), jprev);
+        const int t = t0 + before;
+        if (i < nA) nca[i] = pj >= 0 ? i + pj - t : i + (pm + 1) - t;
+        t0 += __popcll(ball);
+        jprev = max(jprev, m2_wave_max(pj));
+    }
+    const int nm = t0;
+    // second child: column j -> (row of the next matched pair, or nA) + j - matches before; descending for "next"
+    int inext = nA;
+    for (int j0 = ((nB - 1) / 64) * 64; j0 >= 0 && nB > 0; j0 -= 64) {
+        const int j = j0 + lane;
+        const int pi = j < nB ? pb[j] : -1;
+        int nx = m2_suffix_min_incl(pi >= 0 ? pi : 0x7fffffff, lane);
+        nx = min(nx, inext);
+        if (j < nB) ncb[j] = nx;          // provisional: the row of the next matched pair at or after j
+        inext = min(inext, m2_wave_min(pi >= 0 ? pi : 0x7fffffff));
     }
     __threadfence_block();
     __syncthreads();
-    const int newW = s_newW;
-    if (newW > G.wcap) {
-        if (threadIdx.x == 0) { A.ovf[g] = 1; A.nodemask[2 * fm + n + round] = maskA | maskB; A.ncols[2 * fm + n + round] = G.wcap; }
-        return;
+    int tb = 0;
+    for (int j0 = 0; j0 < nB; j0 += 64) {
+        const int j = j0 + lane;
+        const int pi = j < nB ? pb[j] : -1;
+        const unsigned long long ball = __ballot(pi >= 0);
+        const int before = tb + __popcll(ball & ((1ull << lane) - 1ull));
+        if (j < nB) ncb[j] = ncb[j] + j - before;   // matched: next = its own row
+        tb += __popcll(ball);
     }
+    __threadfence_block();
+    __syncthreads();
+    const int newW = nA + nB - nm;
+    if (newW > G.wcap) return -1;
     // clear the members' rows of pos, then scatter the new columns
+    const unsigned both = J.maskA | J.maskB;
     for (int a = 0; a < n; ++a) {
-        if (!(((maskA | maskB) >> a) & 1u)) continue;
+        if (!((both >> a) & 1u)) continue;
         uint16_t* row = A.pos + G.pos_base + static_cast<long long>(a) * G.wcap;
-        for (int c = threadIdx.x; c < newW; c += blockDim.x) row[c] = static_cast<uint16_t>(M2_NONE);
+        for (int c = lane; c < newW; c += 64) row[c] = static_cast<uint16_t>(M2_NONE);
     }
     __threadfence_block();
     __syncthreads();
     for (int a = 0; a < n; ++a) {
-        const bool inA = (maskA >> a) & 1u, inB = (maskB >> a) & 1u;
-        if (!inA && !inB) continue;
+        const bool inA = (J.maskA >> a) & 1u;
+        if (!((both >> a) & 1u)) continue;
         const M2Member Me = A.members[fm + a];
         const int* nc = inA ? nca : ncb;
         uint16_t* row = A.pos + G.pos_base + static_cast<long long>(a) * G.wcap;
-        for (int p = threadIdx.x; p < Me.len; p += blockDim.x) {
+        for (int p = lane; p < Me.len; p += 64) {
             const int c = nc[A.col[Me.col_base + p]];
             A.col[Me.col_base + p] = c;
             row[c] = static_cast<uint16_t>(p);
         }
     }
-    if (threadIdx.x == 0) { A.nodemask[2 * fm + n + round] = maskA | maskB; A.ncols[2 * fm + n + round] = newW; }
+    __threadfence_block();
+    __syncthreads();
+    return newW;
 }
 
-__global__ void k_m2_width(M2Args A) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= A.ngroups) return;
-    const M2Group G = A.groups[g];
-    int w = 0;
-    if (G.n == 1) w = A.members[G.first_member].len;
-    else if (G.n >= 2) w = A.ncols[2 * G.first_member + 2 * G.n - 2];
-    A.width[g] = w;
+constexpr int M2_LDS_BYTES = (M2_MAXN + 1) * 128 + M2_MAXN * 3 * 8 + M2_MAXN * 2 * 4;   // rows' staging (5248) >= the chain's ring (4096)
+static_assert(M2_LDS_BYTES >= M2_QW * 8, "the chain's ring shares the LDS of the rows' staging");
+
+template <bool UNITW>
+__global__ void __launch_bounds__(64) k_m2_group(M2Args A, const M2Cand* __restrict__ tab) {
+    __shared__ __align__(16) unsigned char smem[M2_LDS_BYTES];
+    const int lane = threadIdx.x;
+    const long long wb = static_cast<long long>(blockIdx.x) * A.w_rows;
+    m2_u64* const ent = A.w_ent + wb * M2_CAP;
+    unsigned* const pred = A.w_pred + wb * M2_CAP;
+    int* const part = A.w_part + wb;
+    int* const nca = A.w_nca + wb;
+    int* const ncb = A.w_ncb + wb;
+    int* const pb = A.w_pb + wb;
+    m2_u64* const qg = A.w_q + wb;
+    unsigned st_capped = 0, st_filtered = 0, st_rowsf = 0;
+    unsigned long long st_rows = 0, st_kept = 0, st_joins = 0, st_hbmq = 0;
+    for (;;) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(A.next, 1);
+        g = m2_rfl(g);
+        if (g >= A.ngroups) break;
+        const M2Group G = A.groups[g];
+        const int n = G.n, fm = G.first_member;
+        if (n < 2) continue;
+        // the nodes of the guide tree live in the lanes: lane k = node k (leaves 0 .. n - 1, join k creates n + k)
+        unsigned nmask = lane < n ? (1u << lane) : 0u;
+        int ncols = lane < n ? A.members[fm + lane].len : 0;
+        int err = 0, width = 0;
+        bool over = false;
+        for (int round = 0; round + 1 < n; ++round) {
+            const int2 jn = A.joins[fm + round];
+            const int jx = m2_rfl(jn.x), jy = m2_rfl(jn.y);
+            M2Join J;
+            J.n = n; J.fm = fm;
+            J.maskA = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(nmask), jx));
+            J.maskB = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(nmask), jy));
+            J.nA = __builtin_amdgcn_readlane(ncols, jx);
+            J.nB = __builtin_amdgcn_readlane(ncols, jy);
+            __syncthreads();
+            int ne;
+            if (UNITW) ne = m2_rows_unit(A, G, J, tab + G.tab_base + m2_rfl(A.join_tab[fm + round]), smem, ent, part, st_capped, st_filtered, st_rowsf);
+            else ne = m2_rows_general(A, G, J, smem, ent, part, st_capped, st_filtered, st_rowsf);
+            st_rows += static_cast<unsigned>(J.nA);
+            st_kept += static_cast<unsigned>(ne);
+            ++st_joins;
+            __threadfence_block();
+            __syncthreads();
+            if (ne > 0) {
+                m2_u64 tail = 0;
+                m2_u64* const ring = reinterpret_cast<m2_u64*>(smem);
+                if (A.chain_hbm || !m2_chain_forward<true>(ent, ne, pred, ring, tail, err)) {
+                    ++st_hbmq;
+                    __syncthreads();
+                    m2_chain_forward<false>(ent, ne, pred, qg, tail, err);
+                }
+                __threadfence_block();
+                __syncthreads();
+                m2_chain_walk(ent, ne, pred, tail, part, err);
+                __threadfence_block();
+                __syncthreads();
+            }
+            const int newW = m2_renumber(A, G, J, part, nca, ncb, pb);
+            if (newW < 0 || err) { over = true; break; }
+            if (lane == n + round) { nmask = J.maskA | J.maskB; ncols = newW; }
+            width = newW;
+        }
+        if (lane == 0) {
+            if (over) A.ovf[g] = err ? 2 : 1;
+            else A.width[g] = width;
+        }
+    }
+    // the wavefront's counters
+    st_capped = static_cast<unsigned>(m2_incl_sum(static_cast<int>(st_capped), lane));
+    st_filtered = static_cast<unsigned>(m2_incl_sum(static_cast<int>(st_filtered), lane));
+    st_rowsf = static_cast<unsigned>(m2_incl_sum(static_cast<int>(st_rowsf), lane));
+    if (lane == 63) {
+        atomicAdd(&A.counters[M2C_ROWS_CAPPED], static_cast<unsigned long long>(st_capped));
+        atomicAdd(&A.counters[M2C_ENT_FILTERED], static_cast<unsigned long long>(st_filtered));
+        atomicAdd(&A.counters[M2C_ROWS_FILTERED], static_cast<unsigned long long>(st_rowsf));
+        atomicAdd(&A.counters[M2C_ROWS], st_rows);
+        atomicAdd(&A.counters[M2C_ENT_KEPT], st_kept);
+        atomicAdd(&A.counters[M2C_JOINS], st_joins);
+        atomicAdd(&A.counters[M2C_JOINS_HBMQ], st_hbmq);
+    }
 }
 
 // one block per (member, chunk of columns): the gapped row of a member
@@ -1044,6 +919,7 @@ __global__ void k_m2_write(M2Args A, const int* member_group, int nmembers, cons
     const M2Member Me = A.members[m];
     const int a = m - G.first_member;
     const int W = A.width[g];
+    if (W <= 0 && G.n != 1) return;   // (a group sent to the next pass)
     const uint8_t* src = A.seq + Me.seq_off;
     if (A.out16) {   // vote codes: the cell's quality is the read position's
         uint16_t* dst16 = A.out16 + out_off[g] + static_cast<long long>(a) * W;
@@ -1074,23 +950,18 @@ __global__ void k_m2_write(M2Args A, const int* member_group, int nmembers, cons
     }
 }
 
+
 // =============================================================================================
 // host side
 
-static int g_msa_spec = 0;   // 0: not set (SARLACC_MSA_SPEC or 2)
-
-static int msa_spec() {
-    if (g_msa_spec) return g_msa_spec;
-    if (const char* e = std::getenv("SARLACC_MSA_SPEC")) return std::atoi(e) == 1 ? 1 : 2;
-    return 2;
-}
+static int msa_spec() { return option(OPT_MSA_SPEC) == 1 ? 1 : 2; }
 
 static inline unsigned m2_blocks(long long n, int bs) { return static_cast<unsigned>((n + bs - 1) / bs); }
 
 // One batch of groups (`ids`: indices into the caller's group list) through the v2 kernels.
-// exact = false: fast capacities (lists of M2_CAP entries in LDS, profiles of 2 maxlen + 64 columns); groups
-// that outgrow them come back in `redo`.  exact = true: worst-case capacities, nothing can overflow.
-// Leaves the batch's state (pos, members ...) in the "m2*" workspaces with prefix `pf` for the row writer.
+// exact_w = false: fast profile capacity (3 maxlen + 64 columns); groups that outgrow it come back flagged.
+// exact_w = true: profiles as wide as the sum of the read lengths, nothing can overflow.
+// Leaves the batch's state (pos, members ...) in the "m2*" workspaces for the row writer.
 struct M2Batch {
     std::vector<int64_t> ids;      // caller's group indices, by decreasing group size
     std::vector<size_t> slot;      // position of each in the caller's order (msa2_core)
@@ -1103,10 +974,11 @@ struct M2Batch {
     M2Args a{};                   // device pointers
     int* d_member_group = nullptr;
     int max_len = 0, max_wcap = 0, max_n = 0;
+    long long tab_n = 0;
 };
 
 static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const int64_t* rel, bool exact_w) {
-    long long map_pos = 0, col_pos = 0, row_pos = 0, pos_pos = 0, dist_pos = 0;
+    long long map_pos = 0, col_pos = 0, pos_pos = 0, dist_pos = 0, tab_pos = 0;
     B.groups.clear(); B.members.clear(); B.member_group.clear(); B.jobs.clear();
     B.max_len = 0; B.max_wcap = 0; B.max_n = 0;
     for (size_t q = 0; q < B.ids.size(); ++q) {
@@ -1124,18 +996,17 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
             mx = std::max(mx, len);
         }
         const long long fast_w = M2_FASTW(mx);
-        // (65535 columns is the ceiling of spec v2: positions and the 16-level Fenwick tree; only reachable when the
-        // sum of the read lengths exceeds it AND the alignment really is that wide)
+        // (65535 columns is the ceiling of spec v2: positions and columns are 16-bit; only reachable when the sum of
+        // the read lengths exceeds it AND the alignment really is that wide)
         G.wcap = static_cast<int>(std::min<long long>(65535, std::min<long long>(sum, exact_w ? sum : fast_w)));
         if (G.wcap < 1) G.wcap = 1;
-        G.cap = M2_CAP;
-        G.row_base = row_pos;
         G.pos_base = pos_pos;
         G.first_job = static_cast<long long>(B.jobs.size());
         G.dist_base = dist_pos;
-        row_pos += G.wcap;
+        G.tab_base = tab_pos;
         pos_pos += static_cast<long long>(n) * G.wcap;
         dist_pos += static_cast<long long>(n) * n + n;
+        tab_pos += m2_tab_entries(n);
         for (int a = 0; a < n; ++a) {
             M2Member Me{};
             Me.seq_off = rel[mem[a] - 1];
@@ -1164,47 +1035,20 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
         B.max_n = std::max(B.max_n, n);
         B.groups.push_back(G);
     }
+    B.tab_n = tab_pos;
     return 0;
 }
 
-// streams of the round loop (created once per process, non-blocking: the caller's stream may be the legacy default one)
-struct M2Streams {
-    std::vector<hipStream_t> st;
-    std::vector<hipEvent_t> join;
-    hipEvent_t fork = nullptr;
-    int device = -1;
-    int ensure(int n) {
-        if (device != ctx().device) {   // (streams and events belong to the device that was current when they were made)
-            for (hipStream_t x : st) (void)hipStreamDestroy(x);
-            for (hipEvent_t e : join) (void)hipEventDestroy(e);
-            if (fork) (void)hipEventDestroy(fork);
-            st.clear(); join.clear(); fork = nullptr;
-            device = ctx().device;
-        }
-        if (!fork) SL_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-        while (static_cast<int>(st.size()) < n) {
-            hipStream_t x; hipEvent_t e;
-            SL_HIP(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
-            SL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            st.push_back(x); join.push_back(e);
-        }
-        return 0;
-    }
-};
-static M2Streams& m2_streams() { static M2Streams m; return m; }
-
 static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq, double match, double mismatch, double gap_extension,
-                        double gap_opening, int bandwidth, bool exact, const std::function<int()>* overlap, double* cells, hipStream_t s) {
+                        double gap_opening, int bandwidth, const std::function<int()>* overlap, double* cells, double* counters,
+                        hipStream_t s) {
     Context& c = ctx();
     const size_t ng = B.groups.size(), nm = B.members.size();
     if (ng == 0) return 0;
-    long long map_n = 0, col_n = 0, row_n = 0, pos_n = 0, dist_n = 0, ent_n = 0;
+    long long map_n = 0, col_n = 0, pos_n = 0, dist_n = 0;
     for (const M2Member& Me : B.members) col_n += Me.len;
-    for (const M2Group& G : B.groups) {
-        row_n += G.wcap; pos_n += static_cast<long long>(G.n) * G.wcap; dist_n += static_cast<long long>(G.n) * G.n + G.n;
-    }
+    for (const M2Group& G : B.groups) { pos_n += static_cast<long long>(G.n) * G.wcap; dist_n += static_cast<long long>(G.n) * G.n + G.n; }
     if (!B.members.empty()) { const M2Member& L = B.members.back(); const M2Group& G = B.groups[B.member_group.back()]; map_n = L.map_base + static_cast<long long>(std::max(0, G.n - 1)) * L.len; }
-    ent_n = row_n * static_cast<long long>(M2_CAP);
     M2Args& a = B.a;
     a = M2Args{};
     M2Group* d_groups; M2Member* d_members; MsaJob* d_jobs; int* d_mg;
@@ -1213,38 +1057,21 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     SL_TRY(upload((pf + ".mg").c_str(), B.member_group.data(), nm, &d_mg, s));
     SL_TRY(upload((pf + ".jobs").c_str(), B.jobs.data(), B.jobs.size(), &d_jobs, s));
     B.d_member_group = d_mg;
-    uint16_t* d_map; int2* d_stats; double* d_dist; int2* d_joins; uint32_t* d_mask; int* d_ncols; int* d_col; uint16_t* d_pos;
-    uint16_t* d_cnt; unsigned long long* d_ent; int* d_part; int* d_nca; int* d_ncb; int* d_pb; int* d_ovf; int32_t* d_width;
+    uint16_t* d_map; int2* d_stats; double* d_dist; int2* d_joins; int* d_jtab; int* d_col; uint16_t* d_pos; int* d_ovf; int32_t* d_width;
     SL_TRY(scratch((pf + ".map").c_str(), static_cast<size_t>(map_n) + 1, &d_map));
     SL_TRY(scratch((pf + ".stats").c_str(), B.jobs.size() + 1, &d_stats));
     SL_TRY(scratch((pf + ".dist").c_str(), static_cast<size_t>(dist_n) + 1, &d_dist));
     SL_TRY(scratch((pf + ".joins").c_str(), nm + 1, &d_joins));
-    SL_TRY(scratch((pf + ".mask").c_str(), 2 * nm + 2, &d_mask));
-    SL_TRY(scratch((pf + ".ncols").c_str(), 2 * nm + 2, &d_ncols));
+    SL_TRY(scratch((pf + ".jtab").c_str(), nm + 1, &d_jtab));
     SL_TRY(scratch((pf + ".col").c_str(), static_cast<size_t>(col_n) + 1, &d_col));
     SL_TRY(scratch((pf + ".pos").c_str(), static_cast<size_t>(pos_n) + 1, &d_pos));
-    SL_TRY(scratch((pf + ".cnt").c_str(), static_cast<size_t>(row_n) + 1, &d_cnt));
-    SL_TRY(scratch((pf + ".ent").c_str(), static_cast<size_t>(ent_n) + 1, &d_ent));
-    unsigned* d_pred;
-    SL_TRY(scratch((pf + ".pred").c_str(), static_cast<size_t>(ent_n) + 1, &d_pred));
-    SL_TRY(scratch((pf + ".part").c_str(), static_cast<size_t>(row_n) + 1, &d_part));
-    SL_TRY(scratch((pf + ".nca").c_str(), static_cast<size_t>(row_n) + 1, &d_nca));
-    SL_TRY(scratch((pf + ".ncb").c_str(), static_cast<size_t>(row_n) + 1, &d_ncb));
-    SL_TRY(scratch((pf + ".pb").c_str(), static_cast<size_t>(row_n) + 1, &d_pb));
     SL_TRY(scratch((pf + ".ovf").c_str(), ng, &d_ovf));
-    int* d_redo;
-    SL_TRY(scratch((pf + ".redo").c_str(), ng, &d_redo));
-    SL_HIP(hipMemsetAsync(d_redo, 0, sizeof(int) * ng, s));
     SL_TRY(scratch((pf + ".width").c_str(), ng, &d_width));
     SL_HIP(hipMemsetAsync(d_ovf, 0, sizeof(int) * ng, s));
     a.seq = d_seq; a.groups = d_groups; a.members = d_members; a.ngroups = static_cast<int>(ng);
     a.ma = static_cast<int>(match); a.mm = static_cast<int>(mismatch);
-    unsigned long long* d_clk = nullptr;
-    if (std::getenv("SARLACC_MSA2_CLOCKS")) { SL_TRY(scratch((pf + ".clk").c_str(), 8, &d_clk)); SL_HIP(hipMemsetAsync(d_clk, 0, 64, s)); }
-    a.clk = d_clk;
-    if (std::getenv("SARLACC_MSA2_EXACTDBG")) { SL_TRY(scratch((pf + ".xdbg").c_str(), 2 * ng, &a.xdbg)); SL_HIP(hipMemsetAsync(a.xdbg, 0, sizeof(unsigned long long) * 2 * ng, s)); }
-    a.map = d_map; a.stats = d_stats; a.dist = d_dist; a.joins = d_joins; a.nodemask = d_mask; a.ncols = d_ncols;
-    a.col = d_col; a.pos = d_pos; a.row_cnt = d_cnt; a.row_ent = d_ent; a.row_pred = d_pred; a.part = d_part; a.ovf = d_ovf; a.redo = d_redo; a.width = d_width;
+    a.map = d_map; a.stats = d_stats; a.dist = d_dist; a.joins = d_joins; a.join_tab = d_jtab;
+    a.col = d_col; a.pos = d_pos; a.ovf = d_ovf; a.width = d_width;
 
     // ---- all pairs ----
     for (const MsaJob& J : B.jobs) *cells += static_cast<double>(J.lr) * msa_pair_band(bandwidth, J.lr, J.lc);
@@ -1253,134 +1080,64 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
                                d_map, d_stats, s));
     SL_TRY(c.stage_end("msa_pairwise", s));
     if (overlap) SL_TRY((*overlap)());
-    // ---- guide trees, leaves ----
+    // ---- guide trees, leaves, candidate tables ----
     SL_TRY(c.stage_begin("msa_merge", s));
     hipLaunchKernelGGL(k_m2_tree, dim3(m2_blocks(static_cast<long long>(ng), 64)), dim3(64), 0, s, a);
     if (nm) hipLaunchKernelGGL(k_m2_init, dim3(std::max(1u, m2_blocks(B.max_len, 256)), static_cast<unsigned>(nm)), dim3(256), 0, s, a, d_mg, static_cast<int>(nm));
     SL_HIP(hipGetLastError());
-    // ---- progressive merging, one round per join ----
-    // The groups of a batch are ordered by size (m2_plan), so the groups that still have a join to do in round r
-    // are a prefix of the batch.
-    const bool unitw = a.ma <= 1 && a.mm <= 1;
-    // unit weights: per-round candidate descriptors (k_m2_candidates), < n^2 entries of two int4 per group
-    const bool old_gather = std::getenv("SARLACC_MSA2_OLDGATHER") != nullptr;
-    M2Cand* d_tab = nullptr; long long* d_toff = nullptr; uint16_t* d_ident = nullptr;
-    if (unitw && !old_gather) {
-        std::vector<long long> toff(ng + 1, 0);
-        for (size_t q = 0; q < ng; ++q) toff[q + 1] = toff[q] + static_cast<long long>(B.groups[q].n) * B.groups[q].n + M2_UBATCH;   // (n - 1)(n + 1) entries + padding
-        SL_TRY(upload((pf + ".toff").c_str(), toff.data(), toff.size(), &d_toff, s));
-        SL_TRY(scratch((pf + ".tab").c_str(), static_cast<size_t>(toff[ng]) + 1, &d_tab));
+    const bool unitw = a.ma <= 1 && a.mm <= 1 && !option(OPT_MSA2_GENERAL_ROWS);
+    M2Cand* d_tab = nullptr;
+    if (unitw) {
+        uint16_t* d_ident;
+        SL_TRY(scratch((pf + ".tab").c_str(), static_cast<size_t>(B.tab_n) + 1, &d_tab));
         SL_TRY(scratch("msa2.ident", 65536, &d_ident));
         hipLaunchKernelGGL(k_m2_identity, dim3(256), dim3(256), 0, s, d_ident);
-    }
-    // exact chain kernel: Fenwick tree in LDS while it fits 64 KB, in HBM for wider profiles
-    const size_t exact_base = sizeof(unsigned long long) * (64 * M2_CAP + M2_CAP) + sizeof(int) * (M2_CAP + 64);
-    const bool exact_gbit = exact_base + sizeof(unsigned long long) * (static_cast<size_t>(B.max_wcap) + 2) > 64 * 1024;
-    const size_t exact_lds = exact_gbit ? exact_base : exact_base + sizeof(unsigned long long) * (static_cast<size_t>(B.max_wcap) + 2);
-    unsigned long long* d_gbit = nullptr;
-    if (exact_gbit) SL_TRY(scratch((pf + ".gbit").c_str(), static_cast<size_t>(row_n) + ng + 1, &d_gbit));
-    else if (exact_lds > 48 * 1024)
-        SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_m2_chain_exact<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(exact_lds)));
-    // The groups of a batch are cut into NS contiguous ranges, each with a stream of its own: the chain kernels are
-    // serial per group (few, long wavefronts), the gather is wide, so a range's chain runs under another range's
-    // gather.  A group stays in its range for all rounds (its kernels stay in order on one stream).
-    int NS = 2;   // (measured at C4: 1 stream 1.04 s, 2 streams 0.90 s, 3 and 4 streams 1.11-1.12 s -- beyond the hardware queues a process gets)
-    size_t min_groups = 64;   // below that a batch is not worth two queues
-    if (const char* e = std::getenv("SARLACC_MSA2_STREAMS")) { NS = std::min(8, std::max(1, std::atoi(e))); min_groups = 8; }   // (testing: small batches too)
-    if (a.xdbg || std::getenv("SARLACC_MSA2_DEBUG") || a.clk) NS = 1;
-    if (ng < min_groups) NS = 1;
-    const bool stagger = !std::getenv("SARLACC_MSA2_NOSTAGGER");
-    M2Streams& MS = m2_streams();
-    if (NS > 1) SL_TRY(MS.ensure(NS));
-    std::vector<int> cut(static_cast<size_t>(NS) + 1, 0);
-    for (int k = 0; k <= NS; ++k) cut[k] = static_cast<int>((static_cast<long long>(ng) * k / NS) / 4 * 4);
-    cut[NS] = static_cast<int>(ng);
-    if (NS > 1) {
-        SL_HIP(hipEventRecord(MS.fork, s));
-        for (int k = 0; k < NS; ++k) SL_HIP(hipStreamWaitEvent(MS.st[k], MS.fork, 0));
-    }
-    for (int round = 0; round + 1 < B.max_n; ++round) {
-        int nactive = 0;
-        while (nactive < static_cast<int>(ng) && B.groups[nactive].n - 1 > round) ++nactive;
-        if (nactive == 0) break;
-        for (int k = 0; k < NS; ++k) {
-            const int lo = cut[k], hi = std::min(cut[k + 1], nactive);
-            if (lo >= hi) continue;
-            const unsigned cnt = static_cast<unsigned>(hi - lo);
-            hipStream_t sk = NS > 1 ? MS.st[k] : s;
-            M2Args ak = a;
-            ak.g0 = lo;
-            const dim3 ggrid(std::min(128u, m2_blocks(B.max_wcap, 64)), cnt);
-            // first round: a range starts when the one before it has finished its gather, so that from then on the
-            // ranges are out of phase (their kernels have the same lengths: started together they would stay together)
-            if (NS > 1 && round == 0 && k > 0 && stagger) SL_HIP(hipStreamWaitEvent(sk, MS.join[k - 1], 0));
-            if (unitw && !old_gather) {
-                hipLaunchKernelGGL(k_m2_candidates, dim3(cnt), dim3(64), 0, sk, ak, round, d_tab, d_toff, d_ident);
-                hipLaunchKernelGGL(k_m2_gather_unit, ggrid, dim3(64), 0, sk, ak, round, d_tab, d_toff);
-            } else if (unitw) hipLaunchKernelGGL(k_m2_gather<true>, ggrid, dim3(64), 0, sk, ak, round);
-            else hipLaunchKernelGGL(k_m2_gather<false>, ggrid, dim3(64), 0, sk, ak, round);
-            if (NS > 1 && round == 0 && stagger) SL_HIP(hipEventRecord(MS.join[k], sk));
-            hipLaunchKernelGGL(k_m2_chain_q, dim3(m2_blocks(cnt, 4)), dim3(64), 0, sk, ak, round, hi);
-            // rounds the window could not answer (unrelated reads in the cluster): exact chain search
-            if (exact_gbit) hipLaunchKernelGGL(k_m2_chain_exact<true>, dim3(cnt), dim3(64), exact_lds, sk, ak, round, d_gbit);
-            else hipLaunchKernelGGL(k_m2_chain_exact<false>, dim3(cnt), dim3(64), exact_lds, sk, ak, round, d_gbit);
-            if (NS > 1) hipLaunchKernelGGL(k_m2_merge, dim3(cnt), dim3(256), 0, sk, ak, round, d_nca, d_ncb, d_pb);
-        }
+        hipLaunchKernelGGL(k_m2_tables, dim3(static_cast<unsigned>(ng)), dim3(64), 0, s, a, d_tab, d_ident);
         SL_HIP(hipGetLastError());
-        if (a.xdbg) {
-            SL_HIP(hipStreamSynchronize(s));
-            std::vector<unsigned long long> hx(2 * ng);
-            SL_HIP(hipMemcpy(hx.data(), a.xdbg, sizeof(unsigned long long) * hx.size(), hipMemcpyDeviceToHost));
-            SL_HIP(hipMemsetAsync(a.xdbg, 0, sizeof(unsigned long long) * hx.size(), s));
-            unsigned long long mx = 0, sum = 0, mxinfo = 0; int cntf = 0, mxg = -1;
-            for (size_t q = 0; q < ng; ++q) if (hx[2 * q]) { ++cntf; sum += hx[2 * q]; if (hx[2 * q] > mx) { mx = hx[2 * q]; mxinfo = hx[2 * q + 1]; mxg = static_cast<int>(q); } }
-            fprintf(stderr, "exact round %d: active %d flagged %d  cycles max %llu (group %d n=%d rows %llu entries %llu) sum %llu\n", round, nactive, cntf, mx,
-                    mxg, mxg >= 0 ? B.groups[mxg].n : 0, mxinfo >> 32, mxinfo & 0xffffffffull, sum);
-        }
-        if (NS == 1) hipLaunchKernelGGL(k_m2_merge, dim3(static_cast<unsigned>(nactive)), dim3(256), 0, s, a, round, d_nca, d_ncb, d_pb);
+    }
+    // ---- progressive merging: one launch, one wavefront per group (groups in order of decreasing size) ----
+    size_t nmulti = 0;
+    while (nmulti < ng && B.groups[nmulti].n >= 2) ++nmulti;
+    if (nmulti) {
+        int per_cu = 0;
+        if (unitw) SL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_m2_group<true>, 64, 0));
+        else SL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_m2_group<false>, 64, 0));
+        per_cu = std::max(1, std::min(per_cu, 32));
+        const long long w_rows = (static_cast<long long>(B.max_wcap) + 64 + 63) / 64 * 64;
+        const long long per_wave = w_rows * (M2_CAP * 12 + 4 * 4 + 8);
+        long long waves = std::min<long long>(static_cast<long long>(per_cu) * std::max(1, c.num_cu), static_cast<long long>(nmulti));
+        waves = std::max<long long>(1, std::min(waves, (24LL << 30) / per_wave));   // (scratch of the resident wavefronts: at most 24 GB)
+        int* d_next; unsigned long long* d_cnt;
+        SL_TRY(scratch((pf + ".w_ent").c_str(), static_cast<size_t>(waves * w_rows * M2_CAP), &a.w_ent));
+        SL_TRY(scratch((pf + ".w_pred").c_str(), static_cast<size_t>(waves * w_rows * M2_CAP), &a.w_pred));
+        SL_TRY(scratch((pf + ".w_part").c_str(), static_cast<size_t>(waves * w_rows), &a.w_part));
+        SL_TRY(scratch((pf + ".w_nca").c_str(), static_cast<size_t>(waves * w_rows), &a.w_nca));
+        SL_TRY(scratch((pf + ".w_ncb").c_str(), static_cast<size_t>(waves * w_rows), &a.w_ncb));
+        SL_TRY(scratch((pf + ".w_pb").c_str(), static_cast<size_t>(waves * w_rows), &a.w_pb));
+        SL_TRY(scratch((pf + ".w_q").c_str(), static_cast<size_t>(waves * w_rows), &a.w_q));
+        SL_TRY(scratch((pf + ".next").c_str(), 1, &d_next));
+        SL_TRY(scratch((pf + ".cnt").c_str(), M2C_N, &d_cnt));
+        SL_HIP(hipMemsetAsync(d_next, 0, sizeof(int), s));
+        SL_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * M2C_N, s));
+        a.w_rows = w_rows; a.next = d_next; a.counters = d_cnt;
+        a.chain_hbm = option(OPT_MSA2_CHAIN_HBM) ? 1 : 0;
+        M2Args am = a;
+        am.ngroups = static_cast<int>(nmulti);   // (the groups of one read need no merging: they are the tail of the batch)
+        if (unitw) hipLaunchKernelGGL(k_m2_group<true>, dim3(static_cast<unsigned>(waves)), dim3(64), 0, s, am, d_tab);
+        else hipLaunchKernelGGL(k_m2_group<false>, dim3(static_cast<unsigned>(waves)), dim3(64), 0, s, am, d_tab);
         SL_HIP(hipGetLastError());
-        if (std::getenv("SARLACC_MSA2_DEBUG")) {   // first group of the batch, for comparison with ORC_MSA2_DEBUG of the oracle
-            SL_HIP(hipStreamSynchronize(s));
-            const M2Group& G = B.groups[0];
-            if (round < G.n - 1) {
-                std::vector<int2> hj(G.n);
-                std::vector<int> hn(2 * G.n), hp(G.wcap);
-                std::vector<uint16_t> hc(G.wcap);
-                std::vector<unsigned long long> he(static_cast<size_t>(G.wcap) * G.cap);
-                SL_HIP(hipMemcpy(hj.data(), d_joins + G.first_member, sizeof(int2) * G.n, hipMemcpyDeviceToHost));
-                SL_HIP(hipMemcpy(hn.data(), d_ncols + 2 * G.first_member, sizeof(int) * 2 * G.n, hipMemcpyDeviceToHost));
-                SL_HIP(hipMemcpy(hp.data(), d_part + G.row_base, sizeof(int) * G.wcap, hipMemcpyDeviceToHost));
-                SL_HIP(hipMemcpy(hc.data(), d_cnt + G.row_base, sizeof(uint16_t) * G.wcap, hipMemcpyDeviceToHost));
-                SL_HIP(hipMemcpy(he.data(), d_ent + G.row_base * G.cap, sizeof(unsigned long long) * he.size(), hipMemcpyDeviceToHost));
-                const int nA = hn[hj[round].x];
-                fprintf(stderr, "GPU round %d: join %d %d nA %d nB %d -> %d\n", round, hj[round].x, hj[round].y, nA, hn[hj[round].y], hn[G.n + round]);
-                for (int i = 0; i < nA; ++i) {
-                    fprintf(stderr, "  row %d part %d :", i, hp[i]);
-                    for (int k = 0; k < hc[i]; ++k) fprintf(stderr, " (%d w %u)", static_cast<int>(he[static_cast<size_t>(i) * G.cap + k] >> 32), static_cast<unsigned>(he[static_cast<size_t>(i) * G.cap + k]));
-                    fprintf(stderr, "\n");
-                }
-            }
-        }
     }
-    if (NS > 1)
-        for (int k = 0; k < NS; ++k) {
-            SL_HIP(hipEventRecord(MS.join[k], MS.st[k]));
-            SL_HIP(hipStreamWaitEvent(s, MS.join[k], 0));
-        }
-    if (d_clk) {
-        unsigned long long hc[8];
-        SL_HIP(hipMemcpy(hc, d_clk, sizeof hc, hipMemcpyDeviceToHost));
-        fprintf(stderr, "gather kernel, block (0,0) of the last launch: %llu cycles, %llu candidate steps (x64 lanes), %llu rows in the profile, n = %llu\n", hc[4], hc[5], hc[6], hc[7]);
-        fprintf(stderr, "chain kernel, first wave of the last LDS launch: forward %llu cycles, traceback %llu cycles, %llu rows\n", hc[0], hc[1], hc[2]);
-    }
-    hipLaunchKernelGGL(k_m2_width, dim3(m2_blocks(static_cast<long long>(ng), 256)), dim3(256), 0, s, a);
-    SL_HIP(hipGetLastError());
     SL_TRY(c.stage_end("msa_merge", s));
     B.width.resize(ng);
     B.ovf.resize(ng);
+    unsigned long long hc[M2C_N] = {};
     SL_HIP(hipMemcpyAsync(B.width.data(), d_width, sizeof(int32_t) * ng, hipMemcpyDeviceToHost, s));
     SL_HIP(hipMemcpyAsync(B.ovf.data(), d_ovf, sizeof(int) * ng, hipMemcpyDeviceToHost, s));
+    if (nmulti) SL_HIP(hipMemcpyAsync(hc, a.counters, sizeof hc, hipMemcpyDeviceToHost, s));
     SL_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < M2C_N; ++k) counters[k] += static_cast<double>(hc[k]);
+    for (size_t q = 0; q < ng; ++q)
+        if (B.ovf[q] > 1) return fail("sarlacc_amd: internal error: the chain search of an MSA join did not finish");
     int stuck = 0;
     if (!B.jobs.empty()) {
         int* d_stuck;
@@ -1391,7 +1148,7 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     return 0;
 }
 
-// rows of the batch's groups (except those flagged in `skip`) at out + off[group of the caller's list]
+// rows of the batch's groups (except those sent to the next pass, whose width is 0) at out + off[group of the caller's list]
 static int m2_write_batch(M2Batch& B, const std::string& pf, const std::vector<long long>& off_of_batch_group, void* d_out,
                           const CodeSpec& code, hipStream_t s) {
     if (B.members.empty()) return 0;
@@ -1439,8 +1196,17 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         rows_ws.cap = want;
         return 0;
     };
-    const long long map_budget = 6LL << 30, ent_budget = 8LL << 30, job_budget = 3000000;
+    // Batches: what a batch holds per group is the library (both maps of every pair: 4 (n - 1) bytes per base), the
+    // positions / columns of its profiles and, with unit weights, its candidate tables.  Sized for an HBM of 288 GB
+    // (C4, 10^5 groups x 10 reads x 2 kb, is one batch of about 60 GB), bounded by a share of what is free now.
+    size_t free_b = 0, total_b = 0;
+    SL_HIP(hipMemGetInfo(&free_b, &total_b));
+    long long reusable = 0;   // the workspaces of an earlier call are grown in place, not added
+    for (const char* nm : {"m2.map", "m2.pos", "m2.col", "m2.tab"}) { auto it = c.ws.find(nm); if (it != c.ws.end()) reusable += static_cast<long long>(it->second.cap); }
+    const long long mem_budget = std::max<long long>(1LL << 30, std::min<long long>(96LL << 30, (static_cast<long long>(free_b) + reusable) / 2));
+    const long long job_budget = 12000000;
     double cells = 0, pairs = 0;
+    double counters[M2C_N] = {};
     bool first = true;
     long long used = 0;
     // Pass 0: every group with the fast profile capacity.  Pass 1: the groups whose profiles outgrew it (several
@@ -1449,7 +1215,8 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
     std::iota(todo.begin(), todo.end(), size_t(0));
     for (int pass = 0; pass < 2 && !todo.empty(); ++pass) {
         const bool exact_w = pass == 1;
-        // processing order: by decreasing group size, so that a batch holds groups with about the same number of joins
+        // processing order: by decreasing group size -- the wavefronts of k_m2_group take the groups in this order, the
+        // longest first
         std::stable_sort(todo.begin(), todo.end(), [&](size_t x, size_t y) {
             return grp_off[ids[x] + 1] - grp_off[ids[x]] > grp_off[ids[y] + 1] - grp_off[ids[y]];
         });
@@ -1457,23 +1224,23 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         size_t q0 = 0;
         while (q0 < todo.size()) {
             M2Batch B;
-            long long map_b = 0, ent_b = 0, jobs_b = 0;
+            long long mem_b = 0, jobs_b = 0;
             size_t q1 = q0;
             while (q1 < todo.size()) {
                 const int64_t g = ids[todo[q1]];
                 const long long n = grp_off[g + 1] - grp_off[g];
                 long long sum = 0, mx = 0;
                 for (long long a = 0; a < n; ++a) { const long long len = rel[grp[grp_off[g] + a]] - rel[grp[grp_off[g] + a] - 1]; sum += len; mx = std::max(mx, len); }
-                const long long wc = exact_w ? sum : std::min(sum, M2_FASTW(mx));
-                const long long mb = 2 * (n - 1) * sum, eb = wc * M2_CAP * 12, jb = n * (n - 1) / 2;
-                if (q1 > q0 && (map_b + mb > map_budget || ent_b + eb > ent_budget || jobs_b + jb > job_budget)) break;
-                map_b += mb; ent_b += eb; jobs_b += jb;
+                const long long wc = exact_w ? sum : std::min(sum, static_cast<long long>(M2_FASTW(mx)));
+                const long long mb = 2 * (n - 1) * sum + 2 * n * wc + 4 * sum + 32 * m2_tab_entries(static_cast<int>(n)), jb = n * (n - 1) / 2;
+                if (q1 > q0 && (mem_b + mb > mem_budget || jobs_b + jb > job_budget)) break;
+                mem_b += mb; jobs_b += jb;
                 B.ids.push_back(g);
-                B.slot.push_back(todo[q1]);   // (already by decreasing size: the groups with a join left in round r are a prefix)
+                B.slot.push_back(todo[q1]);
                 ++q1;
             }
             SL_TRY(m2_plan(B, grp_off, grp, rel.data(), exact_w));
-            SL_TRY(m2_run_batch(B, "m2", d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, false, first ? overlap : nullptr, &cells, s));
+            SL_TRY(m2_run_batch(B, "m2", d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, first ? overlap : nullptr, &cells, counters, s));
             first = false;
             pairs += static_cast<double>(B.jobs.size());
             long long need = used;
@@ -1502,8 +1269,16 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         }
         todo.swap(again);
     }
-    c.counts["msa_pairs"] = (c.counts.count("msa_pairs") ? c.counts["msa_pairs"] : 0.0) + pairs;
-    c.counts["msa_cells"] = (c.counts.count("msa_cells") ? c.counts["msa_cells"] : 0.0) + cells;
+    auto add = [&](const char* name, double v) { c.counts[name] = (c.counts.count(name) ? c.counts[name] : 0.0) + v; };
+    add("msa_pairs", pairs);
+    add("msa_cells", cells);
+    add("msa2_rows", counters[M2C_ROWS]);
+    add("msa2_rows_capped", counters[M2C_ROWS_CAPPED]);
+    add("msa2_entries_filtered", counters[M2C_ENT_FILTERED]);
+    add("msa2_rows_filtered", counters[M2C_ROWS_FILTERED]);
+    add("msa2_entries_kept", counters[M2C_ENT_KEPT]);
+    add("msa2_joins", counters[M2C_JOINS]);
+    add("msa2_joins_chain_in_hbm", counters[M2C_JOINS_HBMQ]);
     if (!rows_ws.ptr) SL_TRY(rows_reserve(0, 16));
     *d_rows = static_cast<uint8_t*>(rows_ws.ptr);
     return 0;
@@ -1553,8 +1328,9 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     hipStream_t s = nullptr;
     c.stage_reset("msa_pairwise");
     c.stage_reset("msa_merge");
-    c.counts["msa_pairs"] = 0;
-    c.counts["msa_cells"] = 0;
+    for (const char* nm : {"msa_pairs", "msa_cells", "msa2_rows", "msa2_rows_capped", "msa2_entries_filtered", "msa2_rows_filtered",
+                           "msa2_entries_kept", "msa2_joins", "msa2_joins_chain_in_hbm"})
+        c.counts[nm] = 0;
     if (v2.empty())
         return msa1_run(grp_off, grp, ngroups, seq, seq_off, nseq, match, mismatch, gap_extension, gap_opening, bandwidth, want_rows,
                         out_cap, res, overlap, d_seq_resident);
@@ -1636,6 +1412,5 @@ using namespace sarlacc;
 
 extern "C" int sarlacc_set_msa_spec(int spec) {
     if (spec != 0 && spec != 1 && spec != 2) return fail("sarlacc_amd: MSA spec must be 1 (centre-star) or 2 (consistency-based progressive), 0 = default");
-    sarlacc::g_msa_spec = spec;
-    return 0;
+    return sarlacc::set_option("msa_spec", spec);
 }

@@ -29,7 +29,6 @@ struct MsaArgs {
     int2* stats;            // OUT 1: per job (aligned pairs with equal bases, aligned pairs)
     void* tb;               // per-wave traceback tile
     unsigned long long tb_per_wave;  // in tile words
-    int dbg;                // timing experiments only (SARLACC_MSA_DBG): 1 no walk, 2 no guarded rows, 4 no code stores
     int* stuck;             // set when a traceback exceeds its step bound (cannot happen with consistent codes;
                             // the bound is what guarantees that every wave leaves the walk)
 };

@@ -48,11 +48,7 @@ template <int CTRL>
 __device__ __forceinline__ int dpp_int(int old, int v) {
     return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false);
 }
-#ifdef MSA_EXP_ROWDPP   // timing experiment: row shifts instead of wave shifts (wrong results)
-constexpr int DPP_WAVE_SHL1 = 0x101, DPP_WAVE_SHR1 = 0x111;
-#else
 constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;
-#endif
 
 __device__ __forceinline__ int wave_max(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(MSA_NEG, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
@@ -530,13 +526,8 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
         // ---- one step (one parity) on the packed state ----
         auto step_pk = [&](auto par_tag, const unsigned (&pen)[M], int inject) {
             constexpr int par = decltype(par_tag)::value;
-#ifdef MSA_EXP_NODPP   // timing experiment (wrong results)
-            if (par == 0) { xlH = static_cast<int>(Hod[M - 1]) + 1; xlF = static_cast<int>(Fod[M - 1]) + 1; }
-            else { xrH = static_cast<int>(Hev[0]) + 1; xrE = static_cast<int>(Eev[0]) + 1; }
-#else
             if (par == 0) { xlH = dpp_int<DPP_WAVE_SHR1>(xlH, static_cast<int>(Hod[M - 1])); xlF = dpp_int<DPP_WAVE_SHR1>(xlF, static_cast<int>(Fod[M - 1])); }
             else { xrH = dpp_int<DPP_WAVE_SHL1>(xrH, static_cast<int>(Hev[0])); xrE = dpp_int<DPP_WAVE_SHL1>(xrE, static_cast<int>(Eev[0])); }
-#endif
             unsigned nH[M], nE[M], nF[M];
 #pragma unroll
             for (int m = 0; m < M; ++m) {
@@ -560,12 +551,8 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
                 const unsigned d = same + pen[m];
                 const unsigned mn = pk_min(e, f);
                 const unsigned hv = pk_min(d, mn);
-#ifdef MSA_EXP_NOFLAGS   // timing experiment (wrong results)
-                acc[m] ^= hv;
-#else
                 // code = 8 [f != fop] + 4 [e != eop] + 2 [mn != e] + [hv != d], shifted into the accumulator
                 acc[m] = pk_mad<16>(acc[m], pk_mad<4>(pk_mad<2>(pk_ne(f, fop), pk_ne(e, eop)), pk_mad<2>(pk_ne(mn, e), pk_ne(hv, d))));
-#endif
                 nH[m] = hv; nE[m] = e; nF[m] = f;
             }
             // first row of the job only: the step that computes cell (0, 0) sets H(0, 0) = 0 in its lane
@@ -660,10 +647,8 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
             lds_issue_words<NW>(cp, cn);
             subblock_pk(std::integral_constant<int, 0>{}, rw, cw, inj0, inj1);
             subblock_pk(std::integral_constant<int, 1>{}, rw, cw, inj2, inj3);
-            if (!(A.dbg & 4)) {
 #pragma unroll
-                for (int m = 0; m < M; ++m) tile[static_cast<size_t>(w * M + m) * 64 + lane] = acc[m];
-            }
+            for (int m = 0; m < M; ++m) tile[static_cast<size_t>(w * M + m) * 64 + lane] = acc[m];
         };
         LdsHalves ra[NW], ca[NW], rb[NW], cb[NW];   // code words in flight, double buffered
         {
@@ -700,7 +685,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
             rin = h >> 1;
             shift = 16 * (h & 1) + 4 * (3 - (t & 3));
         };
-        if (!(A.dbg & 1)) msa_walk<OUT, true, true, 4, M, uint32_t>(A, J, jobidx, dlo, tile, nwr, s_tb, s_rd, s_ct, locate);
+        msa_walk<OUT, true, true, 4, M, uint32_t>(A, J, jobidx, dlo, tile, nwr, s_tb, s_rd, s_ct, locate);
         __syncthreads();
     }
 }
@@ -791,9 +776,8 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
     SL_TRY(scratch("msa.stuck", 1, &d_stuck));
     SL_HIP(hipMemsetAsync(d_stuck, 0, sizeof(int), s));
     a.stuck = d_stuck;
-    if (const char* dbg = std::getenv("SARLACC_MSA_DBG")) a.dbg = std::atoi(dbg);
     int mmc = 0, goc = 0, gec = 0;
-    const bool domain_ok = cost_domain(ma, mm, go, ge, &mmc, &goc, &gec) && !std::getenv("SARLACC_MSA_INT32");
+    const bool domain_ok = cost_domain(ma, mm, go, ge, &mmc, &goc, &gec) && !option(OPT_MSA_INT32);
     for (int cls = 0; cls < 3; ++cls) {
         if (order[cls].empty()) continue;
         const int C = 4 << cls;
@@ -807,7 +791,6 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
         const size_t spw = C == 4 ? 2 : 1;
         const size_t per_wave = packed ? ((steps + 3) / 4 + 1) * (C / 4) * 64 : (steps / (2 * spw) + 2) * 64;
         size_t lds = MSA_WIN * 64 * word + static_cast<size_t>(cls_lc[cls]) + static_cast<size_t>(cls_lr[cls]) + 48;
-        if (const char* pad = std::getenv("SARLACC_MSA_LDSPAD")) lds += static_cast<size_t>(std::atoi(pad));   // occupancy experiments
         if (lds > 160 * 1024) return fail("sarlacc_amd: reads of %d bases do not fit the MSA kernel's LDS staging", std::max(cls_lr[cls], cls_lc[cls]));
         // many more single-wave workgroups than fit at once (a wave then aligns only a few pairs and the
         // hardware balances the load); their traceback tiles are the price, capped at 24 GB of HBM

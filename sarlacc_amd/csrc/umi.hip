@@ -1039,7 +1039,7 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
     const TileInfo* d_subinfo = nullptr;
     unsigned int nlisted = 0;
     const long long ntp = static_cast<long long>(tile_hi - tile_lo) * nt;
-    if (S.words == 1 && limit >= 0 && limit <= 5 && nt >= 16 && ntp <= (1ll << 31) && !std::getenv("SARLACC_UMI_ALLTILES")) {
+    if (S.words == 1 && limit >= 0 && limit <= 5 && nt >= 16 && ntp <= (1ll << 31)) {
         TileInfo* d_info; uint32_t* d_l; unsigned int* d_lc;
         SL_TRY(scratch((p + ".tinfo").c_str(), static_cast<size_t>(nt), &d_info));
         // the list is bounded by the upper triangle of the launch

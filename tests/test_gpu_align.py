@@ -146,11 +146,15 @@ def test_gap_penalty_variants(oracle, oenc, enc, R, go, ge):
 
 
 @pytest.mark.parametrize("R", [3, 16, 30, 31, 64, 100, 300])
-def test_forced_penalty_select_kernel(oracle, oenc, enc, R, monkeypatch):
+def test_forced_penalty_select_kernel(oracle, oenc, enc, R):
     """Both kernel variants must agree with the oracle for ordinary penalties."""
-    monkeypatch.setenv("SARLACC_ALIGN_PENSEL", "1")
-    _penalty_batch(oracle, oenc, enc, R, 5, 1, seed=8000 + R)
-    _penalty_batch(oracle, oenc, enc, R, 2.5, 0.75, seed=8100 + R)
+    from sarlacc_amd import calls
+    calls.set_option("align_pensel", 1)
+    try:
+        _penalty_batch(oracle, oenc, enc, R, 5, 1, seed=8000 + R)
+        _penalty_batch(oracle, oenc, enc, R, 2.5, 0.75, seed=8100 + R)
+    finally:
+        calls.set_option("align_pensel", 0)
 
 
 def test_c2_shape_sample(oracle, oenc, enc):
@@ -325,18 +329,25 @@ def test_unmask_alignment(oracle):
         calls.unmask_alignment(["AAAA", "NNNN", "AA-A"], ["AAAA", "GG", "A"])
 
 
-@pytest.mark.parametrize("chunks", [2, 3, 7])
-def test_chunked_host_calls_match_single_launch(oracle, oenc, enc, monkeypatch, chunks):
+@pytest.fixture
+def chunked(request):
+    from sarlacc_amd import calls
+    calls.set_option("align_chunks", request.param)
+    yield request.param
+    calls.set_option("align_chunks", 0)
+
+
+@pytest.mark.parametrize("chunked", [2, 3, 7], indirect=True)
+def test_chunked_host_calls_match_single_launch(oracle, oenc, enc, chunked):
     """Large host-pointer calls are sent to the device in chunks whose upload overlaps the
-    previous chunk's kernel (SARLACC_ALIGN_CHUNKS forces it on a small batch): same scores,
+    previous chunk's kernel (option align_chunks forces it on a small batch): same scores,
     positions, sections and the same first error as the single launch and the oracle."""
     from sarlacc_amd import calls
     from sarlacc_amd._lib import SarlaccError
     from sarlacc_amd.mock import random_reads
-    reads, quals = random_reads(101, 0, 300, seed=40 + chunks)
+    reads, quals = random_reads(101, 0, 300, seed=40 + chunked)
     adaptor = "ACGATCAGC" + "N" * 12 + "GTCAGTCAG"
     want = oracle.adaptor_align(reads, quals, oenc, 5, 1, adaptor, [9, 0], [21, 30])
-    monkeypatch.setenv("SARLACC_ALIGN_CHUNKS", str(chunks))
     got = calls.adaptor_align(reads, quals, enc, 5, 1, adaptor, [9, 0], [21, 30])
     assert np.array_equal(got[0].view(np.int64), want[0].view(np.int64))
     assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])

@@ -251,17 +251,17 @@ def test_msa_band_cap_degrades_the_pair_not_the_batch(oracle, spec):
     assert alone[0] == calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)[0]
 
 
-@pytest.mark.parametrize("ngroups", [64, 70, 131])
-def test_msa_spec2_two_round_streams(oracle, ngroups, monkeypatch):
-    """From 64 groups on, the merge rounds of spec v2 run on two streams over two contiguous ranges of the batch (cut at a
-    multiple of 4 groups; groups sorted by size, so the later rounds leave the second range empty): rows identical to
-    the CPU statement and to the single-stream run."""
+@pytest.mark.parametrize("ngroups", [64, 70, 131, 700])
+def test_msa_spec2_many_groups_one_launch(oracle, ngroups):
+    """All merging of spec v2 is one launch: one wavefront per group, groups handed out by an atomic counter in order of
+    decreasing size -- more groups than the test's other cases, of mixed sizes, so that wavefronts take several groups
+    each and finish them at different joins: rows identical to the CPU statement."""
     from sarlacc_amd import calls
     from sarlacc_amd.mock import NUC, mutate
     rng = np.random.default_rng(500 + ngroups)
     reads, groups = [], []
     for g in range(ngroups):
-        n = int(rng.choice([2, 3, 4, 5, 9]))
+        n = int(rng.choice([1, 2, 3, 4, 5, 9]))
         truth = NUC[rng.integers(0, 4, int(rng.integers(40, 160)))]
         idx = []
         for _ in range(n):
@@ -271,21 +271,19 @@ def test_msa_spec2_two_round_streams(oracle, ngroups, monkeypatch):
     calls.set_msa_spec(2)
     try:
         got = calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)
-        monkeypatch.setenv("SARLACC_MSA2_STREAMS", "1")
-        one = calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)
-        monkeypatch.delenv("SARLACC_MSA2_STREAMS")
     finally:
         calls.set_msa_spec(0)
-    assert got == one
     want = oracle.quick_msa(groups, reads, 0, -1, -5, -1, 100, spec=2)
     for g, (a, b) in enumerate(zip(got, want)):
         assert a == b, "group %d differs" % g
 
 
-def test_msa_spec2_gather_kernels_agree(monkeypatch):
-    """Unit weights take the table-driven gather (k_m2_candidates + k_m2_gather_unit); SARLACC_MSA2_OLDGATHER=1 sends the
-    same call through the general kernel.  Rows must be identical, on ordinary clusters, on clusters of two molecules and
-    on groups of very different sizes in one batch (candidate tables of n^2 entries each)."""
+def test_msa_spec2_code_paths_agree(oracle):
+    """Unit weights take the table-driven library walk (scalar candidate descriptors) and keep the chain's prefix maxima
+    in an LDS ring; the options msa2_general_rows / msa2_chain_hbm send the same call through the any-weights walk and
+    through the chain's fallback (prefix maxima over all columns in HBM).  Rows must be identical, and those of the CPU
+    statement, on ordinary clusters, on clusters of two and three molecules and on groups of very different sizes in one
+    batch."""
     from sarlacc_amd import calls
     from sarlacc_amd.mock import NUC, mutate
     rng = np.random.default_rng(77)
@@ -301,10 +299,14 @@ def test_msa_spec2_gather_kernels_agree(monkeypatch):
     try:
         for params in [(0, -1, -5, -1, 100), (1, -2, -2, -2, 20)]:
             new = calls.quick_msa(groups, reads, *params)
-            monkeypatch.setenv("SARLACC_MSA2_OLDGATHER", "1")
-            old = calls.quick_msa(groups, reads, *params)
-            monkeypatch.delenv("SARLACC_MSA2_OLDGATHER")
-            assert new == old
+            assert new == oracle.quick_msa(groups, reads, *params, spec=2)
+            for opt in ("msa2_general_rows", "msa2_chain_hbm"):
+                calls.set_option(opt, 1)
+                try:
+                    other = calls.quick_msa(groups, reads, *params)
+                finally:
+                    calls.set_option(opt, 0)
+                assert new == other, opt
             for rows, g in zip(new, groups):
                 assert [r.replace("-", "") for r in rows] == [reads[i - 1] for i in g]
     finally:
@@ -347,9 +349,9 @@ def test_msa_spec2_umi_collisions(oracle, seed, nmol, per, length):
         calls.set_msa_spec(0)
 
 
-def test_fused_vote_codes_equal_character_rows(spec, monkeypatch):
+def test_fused_vote_codes_equal_character_rows(spec):
     """The fused call's two routes -- rows written as 16-bit vote codes (default) and character rows
-    (SARLACC_CONSENSUS_CHARS=1) -- give the same strings, with N in the reads, other characters in single-read groups
+    (option consensus_chars) -- give the same strings, with N in the reads, other characters in single-read groups
     (returned verbatim by the MSA), qualities beyond the encoding (clamped) and below it (the reference's error);
     quality strings whose lengths differ from their reads take the character route and its errors."""
     import sarlacc_amd
@@ -369,8 +371,7 @@ def test_fused_vote_codes_equal_character_rows(spec, monkeypatch):
     enc = Encoding(np.power(10.0, -q / 10.0), bytes(range(33, 73)))
     res = {}
     for route in ("codes", "chars"):
-        if route == "chars":
-            monkeypatch.setenv("SARLACC_CONSENSUS_CHARS", "1")
+        calls.set_option("consensus_chars", 1 if route == "chars" else 0)
         res[route] = calls.msa_consensus_flat(goff, gvals, reads, 0, -1, -5, -1, 100, 0.6, quals=quals, encoding=enc)
         bad = list(quals); bad[3] = " " + bad[3][1:]
         with pytest.raises(SarlaccError, match="quality cannot be lower than smallest encoded value"):
@@ -378,6 +379,7 @@ def test_fused_vote_codes_equal_character_rows(spec, monkeypatch):
         short = list(quals); short[groups[0][0] - 1] = short[groups[0][0] - 1][:-1]
         with pytest.raises(SarlaccError, match="quality vector is shorter than the alignment sequence"):
             calls.msa_consensus_flat(goff, gvals, reads, 0, -1, -5, -1, 100, 0.6, quals=short, encoding=enc)
+    calls.set_option("consensus_chars", 0)
     assert res["codes"][0].to_strings() == res["chars"][0].to_strings()
     assert res["codes"][1].to_strings() == res["chars"][1].to_strings()
     assert sarlacc_amd.stage_ms("consensus") > 0

@@ -1,11 +1,10 @@
 """Tuning probe for the DP kernel: times sarlacc_dev_align on a resident batch for
-score-only vs traceback and a few launch shapes (env overrides SARLACC_ALIGN_K,
-SARLACC_ALIGN_WAVES_PER_CU)."""
+score-only vs traceback and a few launch shapes (options align_k, align_waves_per_cu)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import sarlacc_amd
-from sarlacc_amd import device as sdev, devsynth
+from sarlacc_amd import calls, device as sdev, devsynth
 import bench
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
@@ -31,8 +30,8 @@ def run(trace, reps=3):
 
 for K in (os.environ.get("KS", "1,2,4").split(",")):
     for w in (os.environ.get("WS", "4,8,12,16").split(",")):
-        os.environ["SARLACC_ALIGN_K"] = K
-        os.environ["SARLACC_ALIGN_WAVES_PER_CU"] = w
+        calls.set_option("align_k", int(K))
+        calls.set_option("align_waves_per_cu", int(w))
         for trace in (False, True):
             t = run(trace)
             print("K=%s waves/CU=%s trace=%d  %.2f ms  %.1f GCUPS" % (K, w, trace, t, cells / t / 1e6), flush=True)

@@ -34,12 +34,8 @@ def main():
     # generic: characters, k_consensus_q4; fast: characters, k_consensus_qf (+ q4 on flagged groups);
     # codes: the MSA stage writes 16-bit vote codes, k_consensus_code (what the fused calls do by default)
     for mode in ("generic", "fast", "codes", "generic", "fast", "codes"):
-        os.environ.pop("SARLACC_CONSENSUS_GENERIC", None)
-        os.environ.pop("SARLACC_CONSENSUS_CHARS", None)
-        if mode != "codes":
-            os.environ["SARLACC_CONSENSUS_CHARS"] = "1"
-        if mode == "generic":
-            os.environ["SARLACC_CONSENSUS_GENERIC"] = "1"
+        calls.set_option("consensus_chars", 0 if mode == "codes" else 1)
+        calls.set_option("consensus_generic", 1 if mode == "generic" else 0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         cons, phred = device.dev_msa_consensus(goff, gflat, mol["seq"], mol["qual"], off, 0, -1, -5, -1, 100, 0.6, encoding=enc)

@@ -1,7 +1,7 @@
 """A/B timing of the pairwise MSA kernel on the C4 job shape (G groups x 10 reads x L bp), several
-variants in one process (SARLACC_MSA_DBG / SARLACC_MSA_INT32 are read at every call):
+variants in one process (packed 16-bit kernel, and option msa_int32 = the 32-bit kernel):
     python tools/perf_msa.py [G] [L]"""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import sarlacc_amd
@@ -18,18 +18,11 @@ def main():
     goff = np.arange(0, n + 1, 10, dtype=np.int64)
     gflat = np.arange(1, n + 1, dtype=np.int32)
     enc = sarlacc_amd.phred_encoding()
-    variants = [("packed", {}), ("int32", {"SARLACC_MSA_INT32": "1"}), ("packed no-walk", {"SARLACC_MSA_DBG": "1"}),
-                ("packed no-guard", {"SARLACC_MSA_DBG": "2"}), ("packed no-store", {"SARLACC_MSA_DBG": "4"}),
-                ("packed no-walk no-guard no-store", {"SARLACC_MSA_DBG": "7"})]
+    variants = [("packed", 0), ("int32", 1)]
     for rep in range(3):
-        for name, env in variants:
-            for k in ("SARLACC_MSA_INT32", "SARLACC_MSA_DBG"):
-                os.environ.pop(k, None)
-            os.environ.update(env)
-            try:
-                calls.msa_consensus_flat(goff, gflat, reads, 0, -1, -5, -1, 100, 0.6, quals=quals, encoding=enc)
-            except Exception as e:  # debug variants produce garbage alignments
-                pass
+        for name, int32 in variants:
+            calls.set_option("msa_int32", int32)
+            calls.msa_consensus_flat(goff, gflat, reads, 0, -1, -5, -1, 100, 0.6, quals=quals, encoding=enc)
             if rep:
                 print("rep %d %-36s pairwise %.2f ms (%d pairs, %.3g cells)" % (rep, name, _lib.stage_ms("msa_pairwise"),
                       _lib.stage_count("msa_pairs"), _lib.stage_count("msa_cells")), flush=True)
