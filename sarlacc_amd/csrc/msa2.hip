@@ -71,7 +71,9 @@ struct M2Group {
 };
 
 // counters of one call (sarlacc_stage_count): how often spec v2's own rules act, and the chain's fallback
-enum { M2C_ROWS, M2C_ROWS_CAPPED, M2C_ENT_FILTERED, M2C_ROWS_FILTERED, M2C_ENT_KEPT, M2C_JOINS, M2C_JOINS_HBMQ, M2C_N };
+enum { M2C_ROWS, M2C_ROWS_CAPPED, M2C_ENT_FILTERED, M2C_ROWS_FILTERED, M2C_ENT_KEPT, M2C_JOINS, M2C_JOINS_HBMQ,
+       // where the wavefronts' time goes (s_memtime cycles summed over the wavefronts) and when they leave (s_memrealtime, 100 MHz)
+       M2C_CYC_ROWS, M2C_CYC_CHAIN, M2C_CYC_WALK, M2C_CYC_RENUMBER, M2C_T_START, M2C_T_FIRST_EXIT, M2C_T_LAST_EXIT, M2C_N };
 
 struct M2Args {
     const uint8_t* seq;
@@ -276,48 +278,39 @@ __global__ void __launch_bounds__(64) k_m2_tables(M2Args A, M2Cand* tab, const u
 typedef unsigned long long m2_u64;
 
 __device__ __forceinline__ int m2_rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// The lane index, recomputed where a phase starts: `volatile`, so nothing derived from it (lane addresses, lane masks)
+// is computed once at the top of the kernel and kept in registers through every other phase.
+__device__ __forceinline__ int m2_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 __device__ __forceinline__ m2_u64 m2_readlane64(m2_u64 v, int l) {
     const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), l));
     const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), l));
     return (static_cast<m2_u64>(hi) << 32) | lo;
 }
-// wave-wide inclusive prefix sum / maximum / minimum of an int (ds_bpermute; used once per block of rows)
-__device__ __forceinline__ int m2_incl_sum(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d);
-        if (lane >= d) v += o;
+// Wave-wide scans of an int by DPP: row shifts inside the rows of 16 lanes, then the last lane of row 0 / 2 broadcast
+// into row 1 / 3 and lane 31 into rows 2 and 3; lanes without a source read the identity.  (Not __shfl: its
+// ds_bpermute needs a lane-address register per step, and the compiler keeps those alive through the whole kernel.)
+template <int OP>   // 0: sum, 1: maximum, 2: minimum
+__device__ __forceinline__ int m2_scan_i32(int v, const int identity) {
+#define M2_ISTEP(CTRL, ROWMASK)                                                                      \
+    {                                                                                                \
+        const int o = __builtin_amdgcn_update_dpp(identity, v, CTRL, ROWMASK, 0xf, false);           \
+        v = OP == 0 ? v + o : (OP == 1 ? max(v, o) : min(v, o));                                     \
     }
+    M2_ISTEP(0x111, 0xf) M2_ISTEP(0x112, 0xf) M2_ISTEP(0x114, 0xf) M2_ISTEP(0x118, 0xf)
+    M2_ISTEP(0x142, 0xa) M2_ISTEP(0x143, 0xc)
+#undef M2_ISTEP
     return v;
 }
-__device__ __forceinline__ int m2_wave_max(int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
-    return v;
-}
-__device__ __forceinline__ int m2_wave_min(int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
-    return v;
-}
-__device__ __forceinline__ int m2_excl_max(int v, int identity, int lane) {   // exclusive prefix maximum over the lanes
-    int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(x, d);
-        if (lane >= d) x = max(x, o);
-    }
-    const int e = __shfl_up(x, 1);
-    return lane == 0 ? identity : e;
-}
-__device__ __forceinline__ int m2_suffix_min_incl(int v, int lane) {          // inclusive suffix minimum over the lanes
-    int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_down(x, d);
-        if (lane + d < 64) x = min(x, o);
-    }
-    return x;
+__device__ __forceinline__ int m2_incl_sum(int v) { return m2_scan_i32<0>(v, 0); }
+__device__ __forceinline__ int m2_wave_max(int v) { return __builtin_amdgcn_readlane(m2_scan_i32<1>(v, static_cast<int>(0x80000000)), 63); }
+__device__ __forceinline__ int m2_wave_min(int v) { return __builtin_amdgcn_readlane(m2_scan_i32<2>(v, 0x7fffffff), 63); }
+__device__ __forceinline__ int m2_excl_max(int v, const int identity) {   // exclusive prefix maximum over the lanes
+    const int x = m2_scan_i32<1>(v, static_cast<int>(0x80000000));
+    return max(__builtin_amdgcn_update_dpp(identity, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false), identity);
 }
 // inclusive prefix maximum of a 64-bit value over the wavefront: DPP row shifts inside the rows of 16, then the last
 // lane of row 0 / 2 broadcast into row 1 / 3 and lane 31 into rows 2 and 3 (lanes without a source read 0, the identity)
@@ -358,7 +351,7 @@ struct M2Join {       // wave-uniform description of one join
         if (!row) kept = 0;                                                                                              \
         st_filtered += row ? static_cast<unsigned>(cnt - kept) : 0u;                                                     \
         st_rowsf += (row && kept < cnt) ? 1u : 0u;                                                                       \
-        const int incl = m2_incl_sum(kept, lane);                                                                        \
+        const int incl = m2_incl_sum(kept);                                                                        \
         m2_u64* const mine = ent + ne + (incl - kept);                                                                   \
         if (row) {                                                                                                       \
             _Pragma("unroll") for (int k = 0; k < M2_CAP; ++k) {                                                         \
@@ -416,7 +409,7 @@ __device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, c
                                             unsigned char* smem, m2_u64* ent, int* part, unsigned& st_capped, unsigned& st_filtered,
                                             unsigned& st_rowsf) {
     uint16_t (*s_r)[64] = reinterpret_cast<uint16_t (*)[64]>(smem);   // [M2_MAXN + 1][64]: position of the lane's base in every other member; last row: gaps
-    const int lane = threadIdx.x;
+    const int lane = m2_lane();
     const int n = J.n, fm = J.fm, nA = J.nA;
     const int E = __popc(J.maskB) * (n + 1);
     s_r[M2_MAXN][lane] = static_cast<uint16_t>(M2_NONE);   // (every lane reads its own column of s_r only)
@@ -471,10 +464,38 @@ __device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, c
             }
         }
         st_capped += (row && capped) ? 1u : 0u;
-        int ej[M2_CAP], ew[M2_CAP];
+        {   // filter, order by column, append -- on the packed entries: (column << 16) | weight orders by column
+            unsigned wmax = 0;
 #pragma unroll
-        for (int k = 0; k < M2_CAP; ++k) { ej[k] = k < cnt ? static_cast<int>(pe[k] >> 16) : -1; ew[k] = k < cnt ? static_cast<int>(pe[k] & 0xffffu) : 0; }
-        M2_FINISH_ROW()
+            for (int k = 0; k < M2_CAP; ++k) wmax = max(wmax, k < cnt ? (pe[k] & 0xffffu) : 0u);
+            int kept = 0;
+#pragma unroll
+            for (int k = 0; k < M2_CAP; ++k) {
+                // noise filter (spec v2, step 5): entries lighter than half the row's heaviest are dropped
+                const bool keep = k < cnt && 2u * (pe[k] & 0xffffu) >= wmax;
+                pe[k] = keep ? pe[k] : 0xFFFFFFFFu;   // (sorts behind every kept entry)
+                kept += keep ? 1 : 0;
+            }
+            if (!row) kept = 0;
+            st_filtered += row ? static_cast<unsigned>(cnt - kept) : 0u;
+            st_rowsf += (row && kept < cnt) ? 1u : 0u;
+            const int incl = m2_incl_sum(kept);
+            m2_u64* const mine = ent + ne + (incl - kept);
+            if (row) {
+                const m2_u64 rowbits = static_cast<m2_u64>(static_cast<unsigned>(i)) << 48;
+#pragma unroll
+                for (int k = 0; k < M2_CAP; ++k) {
+                    if (pe[k] != 0xFFFFFFFFu) {   // rank of the entry among the kept ones (columns are distinct)
+                        int rank = 0;
+#pragma unroll
+                        for (int q = 0; q < M2_CAP; ++q) rank += pe[q] < pe[k] ? 1 : 0;
+                        mine[rank] = rowbits | (static_cast<m2_u64>(pe[k] >> 16) << 32) | (pe[k] & 0xffffu);
+                    }
+                }
+                part[i] = -1;
+            }
+            ne += __builtin_amdgcn_readlane(incl, 63);
+        }
     }
     return ne;
 }
@@ -531,7 +552,7 @@ __device__ __forceinline__ int m2_rows_general(const M2Args& A, const M2Group& G
     long long* const s_seqoff = s_colbase + M2_MAXN;
     int* const s_len = reinterpret_cast<int*>(s_seqoff + M2_MAXN);
     int* const s_b = s_len + M2_MAXN;                                                                 // the second child's members, ascending
-    const int lane = threadIdx.x;
+    const int lane = m2_lane();
     const int n = J.n, fm = J.fm, nA = J.nA;
     const unsigned maskB = J.maskB;
     if (lane < M2_MAXN) {
@@ -648,7 +669,7 @@ constexpr int M2_QW = 512;
 
 template <bool RING>
 __device__ __forceinline__ bool m2_chain_forward(const m2_u64* ent, int ne, unsigned* pred, m2_u64* Q, m2_u64& tail, int& err) {
-    const int lane = threadIdx.x;
+    const int lane = m2_lane();
     int F = -1;
     m2_u64 QF = 0;
     auto q_load = [&](int c) -> m2_u64 {
@@ -722,7 +743,7 @@ __device__ __forceinline__ bool m2_chain_forward(const m2_u64* ent, int ne, unsi
 
 // walk back through the predecessors: part[row] = column for the matches of the chain
 __device__ __forceinline__ void m2_chain_walk(const m2_u64* ent, int ne, const unsigned* pred, m2_u64 tail, int* part, int& err) {
-    const int lane = threadIdx.x;
+    const int lane = m2_lane();
     unsigned cur = tail ? ~static_cast<unsigned>(tail) : 0u;
     cur = static_cast<unsigned>(m2_rfl(static_cast<int>(cur)));
     int steps = ne + 2;   // a predecessor has a smaller index: the walk visits every match at most once
@@ -746,7 +767,7 @@ __device__ __forceinline__ void m2_chain_walk(const m2_u64* ent, int ne, const u
 // ---- new column numbers, col / pos of every member (one wavefront) ----
 // returns the width of the joined profile, or -1 when it exceeds the capacity
 __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, const M2Join& J, const int* part, int* nca, int* ncb, int* pb) {
-    const int lane = threadIdx.x;
+    const int lane = m2_lane();
     const int n = J.n, fm = J.fm, nA = J.nA, nB = J.nB;
     // partner rows of the second child's columns
     for (int j = lane; j < nB; j += 64) pb[j] = -1;
@@ -765,7 +786,7 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
         const int pj = i < nA ? part[i] : -1;
         const unsigned long long ball = __ballot(pj >= 0);
         const int before = __popcll(ball & ((1ull << lane) - 1ull));
-        const int pm = max(m2_excl_max(pj, -1, lane), jprev);
+        const int pm = max(m2_excl_max(pj, -1), jprev);
         const int t = t0 + before;
         if (i < nA) nca[i] = pj >= 0 ? i + pj - t : i + (pm + 1) - t;
         t0 += __popcll(ball);
@@ -775,12 +796,11 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
     // second child: column j -> (row of the next matched pair, or nA) + j - matches before; descending for "next"
     int inext = nA;
     for (int j0 = ((nB - 1) / 64) * 64; j0 >= 0 && nB > 0; j0 -= 64) {
-        const int j = j0 + lane;
+        const int j = j0 + 63 - lane;     // (descending over the lanes: "at or after j" is a prefix)
         const int pi = j < nB ? pb[j] : -1;
-        int nx = m2_suffix_min_incl(pi >= 0 ? pi : 0x7fffffff, lane);
-        nx = min(nx, inext);
-        if (j < nB) ncb[j] = nx;          // provisional: the row of the next matched pair at or after j
-        inext = min(inext, m2_wave_min(pi >= 0 ? pi : 0x7fffffff));
+        const int sc = m2_scan_i32<2>(pi >= 0 ? pi : 0x7fffffff, 0x7fffffff);
+        if (j < nB) ncb[j] = min(sc, inext);          // provisional: the row of the next matched pair at or after j
+        inext = min(inext, __builtin_amdgcn_readlane(sc, 63));
     }
     __threadfence_block();
     __syncthreads();
@@ -823,12 +843,14 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
     return newW;
 }
 
-constexpr int M2_LDS_BYTES = (M2_MAXN + 1) * 128 + M2_MAXN * 3 * 8 + M2_MAXN * 2 * 4;   // rows' staging (5248) >= the chain's ring (4096)
-static_assert(M2_LDS_BYTES >= M2_QW * 8, "the chain's ring shares the LDS of the rows' staging");
+// LDS of a wavefront: the rows' staging, reused by the chain's ring (4096 B).  4224 B with unit weights (the any-weights
+// walk keeps the members' descriptors there too): 32 single-wave workgroups per CU fit beside each other.
+constexpr int M2_LDS_UNIT = (M2_MAXN + 1) * 128, M2_LDS_GENERAL = M2_LDS_UNIT + M2_MAXN * 3 * 8 + M2_MAXN * 2 * 4;
+static_assert(M2_LDS_UNIT >= M2_QW * 8, "the chain's ring shares the LDS of the rows' staging");
 
 template <bool UNITW>
 __global__ void __launch_bounds__(64) k_m2_group(M2Args A, const M2Cand* __restrict__ tab) {
-    __shared__ __align__(16) unsigned char smem[M2_LDS_BYTES];
+    __shared__ __align__(16) unsigned char smem[UNITW ? M2_LDS_UNIT : M2_LDS_GENERAL];
     const int lane = threadIdx.x;
     const long long wb = static_cast<long long>(blockIdx.x) * A.w_rows;
     m2_u64* const ent = A.w_ent + wb * M2_CAP;
@@ -840,6 +862,8 @@ __global__ void __launch_bounds__(64) k_m2_group(M2Args A, const M2Cand* __restr
     m2_u64* const qg = A.w_q + wb;
     unsigned st_capped = 0, st_filtered = 0, st_rowsf = 0;
     unsigned long long st_rows = 0, st_kept = 0, st_joins = 0, st_hbmq = 0;
+    unsigned long long cy_rows = 0, cy_chain = 0, cy_walk = 0, cy_renum = 0;
+    if (lane == 0) atomicMin(&A.counters[M2C_T_START], __builtin_amdgcn_s_memrealtime());
     for (;;) {
         int g = 0;
         if (lane == 0) g = atomicAdd(A.next, 1);
@@ -863,6 +887,7 @@ __global__ void __launch_bounds__(64) k_m2_group(M2Args A, const M2Cand* __restr
             J.nA = __builtin_amdgcn_readlane(ncols, jx);
             J.nB = __builtin_amdgcn_readlane(ncols, jy);
             __syncthreads();
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             int ne;
             if (UNITW) ne = m2_rows_unit(A, G, J, tab + G.tab_base + m2_rfl(A.join_tab[fm + round]), smem, ent, part, st_capped, st_filtered, st_rowsf);
             else ne = m2_rows_general(A, G, J, smem, ent, part, st_capped, st_filtered, st_rowsf);
@@ -871,6 +896,8 @@ __global__ void __launch_bounds__(64) k_m2_group(M2Args A, const M2Cand* __restr
             ++st_joins;
             __threadfence_block();
             __syncthreads();
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            unsigned long long t2 = t1;
             if (ne > 0) {
                 m2_u64 tail = 0;
                 m2_u64* const ring = reinterpret_cast<m2_u64*>(smem);
@@ -881,11 +908,15 @@ __global__ void __launch_bounds__(64) k_m2_group(M2Args A, const M2Cand* __restr
                 }
                 __threadfence_block();
                 __syncthreads();
+                t2 = __builtin_amdgcn_s_memtime();
                 m2_chain_walk(ent, ne, pred, tail, part, err);
                 __threadfence_block();
                 __syncthreads();
             }
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
             const int newW = m2_renumber(A, G, J, part, nca, ncb, pb);
+            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+            cy_rows += t1 - t0; cy_chain += t2 - t1; cy_walk += t3 - t2; cy_renum += t4 - t3;
             if (newW < 0 || err) { over = true; break; }
             if (lane == n + round) { nmask = J.maskA | J.maskB; ncols = newW; }
             width = newW;
@@ -896,9 +927,9 @@ __global__ void __launch_bounds__(64) k_m2_group(M2Args A, const M2Cand* __restr
         }
     }
     // the wavefront's counters
-    st_capped = static_cast<unsigned>(m2_incl_sum(static_cast<int>(st_capped), lane));
-    st_filtered = static_cast<unsigned>(m2_incl_sum(static_cast<int>(st_filtered), lane));
-    st_rowsf = static_cast<unsigned>(m2_incl_sum(static_cast<int>(st_rowsf), lane));
+    st_capped = static_cast<unsigned>(m2_incl_sum(static_cast<int>(st_capped)));
+    st_filtered = static_cast<unsigned>(m2_incl_sum(static_cast<int>(st_filtered)));
+    st_rowsf = static_cast<unsigned>(m2_incl_sum(static_cast<int>(st_rowsf)));
     if (lane == 63) {
         atomicAdd(&A.counters[M2C_ROWS_CAPPED], static_cast<unsigned long long>(st_capped));
         atomicAdd(&A.counters[M2C_ENT_FILTERED], static_cast<unsigned long long>(st_filtered));
@@ -907,6 +938,13 @@ __global__ void __launch_bounds__(64) k_m2_group(M2Args A, const M2Cand* __restr
         atomicAdd(&A.counters[M2C_ENT_KEPT], st_kept);
         atomicAdd(&A.counters[M2C_JOINS], st_joins);
         atomicAdd(&A.counters[M2C_JOINS_HBMQ], st_hbmq);
+        atomicAdd(&A.counters[M2C_CYC_ROWS], cy_rows);
+        atomicAdd(&A.counters[M2C_CYC_CHAIN], cy_chain);
+        atomicAdd(&A.counters[M2C_CYC_WALK], cy_walk);
+        atomicAdd(&A.counters[M2C_CYC_RENUMBER], cy_renum);
+        const unsigned long long tx = __builtin_amdgcn_s_memrealtime();
+        atomicMin(&A.counters[M2C_T_FIRST_EXIT], tx);
+        atomicMax(&A.counters[M2C_T_LAST_EXIT], tx);
     }
 }
 
@@ -1118,7 +1156,12 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
         SL_TRY(scratch((pf + ".next").c_str(), 1, &d_next));
         SL_TRY(scratch((pf + ".cnt").c_str(), M2C_N, &d_cnt));
         SL_HIP(hipMemsetAsync(d_next, 0, sizeof(int), s));
-        SL_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * M2C_N, s));
+        {
+            unsigned long long init[M2C_N] = {};
+            init[M2C_T_START] = init[M2C_T_FIRST_EXIT] = ~0ull;
+            SL_HIP(hipMemcpyAsync(d_cnt, init, sizeof init, hipMemcpyHostToDevice, s));
+            SL_HIP(hipStreamSynchronize(s));   // (init is on this frame's stack)
+        }
         a.w_rows = w_rows; a.next = d_next; a.counters = d_cnt;
         a.chain_hbm = option(OPT_MSA2_CHAIN_HBM) ? 1 : 0;
         M2Args am = a;
@@ -1135,7 +1178,13 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     SL_HIP(hipMemcpyAsync(B.ovf.data(), d_ovf, sizeof(int) * ng, hipMemcpyDeviceToHost, s));
     if (nmulti) SL_HIP(hipMemcpyAsync(hc, a.counters, sizeof hc, hipMemcpyDeviceToHost, s));
     SL_HIP(hipStreamSynchronize(s));
-    for (int k = 0; k < M2C_N; ++k) counters[k] += static_cast<double>(hc[k]);
+    if (nmulti) {
+        for (int k = 0; k < M2C_T_START; ++k) counters[k] += static_cast<double>(hc[k]);
+        // seconds from the first wavefront's start to the first / the last wavefront's exit (100 MHz counter)
+        counters[M2C_T_FIRST_EXIT] += static_cast<double>(hc[M2C_T_FIRST_EXIT] - hc[M2C_T_START]) * 1e-8;
+        counters[M2C_T_LAST_EXIT] += static_cast<double>(hc[M2C_T_LAST_EXIT] - hc[M2C_T_START]) * 1e-8;
+        counters[M2C_T_START] += static_cast<double>(hc[M2C_JOINS] ? 1 : 0);   // (launches)
+    }
     for (size_t q = 0; q < ng; ++q)
         if (B.ovf[q] > 1) return fail("sarlacc_amd: internal error: the chain search of an MSA join did not finish");
     int stuck = 0;
@@ -1279,6 +1328,13 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
     add("msa2_entries_kept", counters[M2C_ENT_KEPT]);
     add("msa2_joins", counters[M2C_JOINS]);
     add("msa2_joins_chain_in_hbm", counters[M2C_JOINS_HBMQ]);
+    add("msa2_cycles_rows", counters[M2C_CYC_ROWS]);
+    add("msa2_cycles_chain", counters[M2C_CYC_CHAIN]);
+    add("msa2_cycles_walk", counters[M2C_CYC_WALK]);
+    add("msa2_cycles_renumber", counters[M2C_CYC_RENUMBER]);
+    add("msa2_launches", counters[M2C_T_START]);
+    add("msa2_first_exit_s", counters[M2C_T_FIRST_EXIT]);
+    add("msa2_last_exit_s", counters[M2C_T_LAST_EXIT]);
     if (!rows_ws.ptr) SL_TRY(rows_reserve(0, 16));
     *d_rows = static_cast<uint8_t*>(rows_ws.ptr);
     return 0;
@@ -1329,7 +1385,8 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     c.stage_reset("msa_pairwise");
     c.stage_reset("msa_merge");
     for (const char* nm : {"msa_pairs", "msa_cells", "msa2_rows", "msa2_rows_capped", "msa2_entries_filtered", "msa2_rows_filtered",
-                           "msa2_entries_kept", "msa2_joins", "msa2_joins_chain_in_hbm"})
+                           "msa2_entries_kept", "msa2_joins", "msa2_joins_chain_in_hbm", "msa2_cycles_rows", "msa2_cycles_chain",
+                           "msa2_cycles_walk", "msa2_cycles_renumber", "msa2_launches", "msa2_first_exit_s", "msa2_last_exit_s"})
         c.counts[nm] = 0;
     if (v2.empty())
         return msa1_run(grp_off, grp, ngroups, seq, seq_off, nseq, match, mismatch, gap_extension, gap_opening, bandwidth, want_rows,

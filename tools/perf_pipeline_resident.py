@@ -31,3 +31,6 @@ for rep in range(reps):
         rep, spec, dt, (off.size - 1) / dt * 60 / 1e6, {k: round(v, 1) for k, v in r["kernel_ms"].items()}, sizes.size,
         sizes.max(), int((sizes > 10).sum()), int(r["counts"]["msa_v1_fallback"])), flush=True)
     print("      stage s %s" % {k: round(v, 4) for k, v in r["stage_s"].items()}, flush=True)
+    from sarlacc_amd import _lib
+    print("      msa2 %s" % {k: _lib.stage_count("msa2_" + k) for k in ("rows", "rows_capped", "entries_filtered", "rows_filtered", "entries_kept",
+          "joins", "joins_chain_in_hbm", "cycles_rows", "cycles_chain", "cycles_walk", "cycles_renumber", "launches", "first_exit_s", "last_exit_s")}, flush=True)

@@ -1,4 +1,4 @@
-# SQ / LDS counters of the kernels whose name contains <substr>, for an arbitrary python command (two passes).
+# SQ / LDS / cache counters of the kernels whose name contains <substr>, for an arbitrary python command (three passes).
 #   tools/pmc_kernel.sh <tag> <kernel substr> <script> [args]
 TAG=$1; SUB=$2; shift; shift
 export TMPDIR=/tmp
@@ -9,10 +9,12 @@ rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_
 echo "pass 1 done"
 rocprofv3 --output-format csv --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE -d $OUT/p2 -o pmc -- python3 $GRAFT_REPO_ROOT/$@ > $OUT/p2.log 2>&1
 echo "pass 2 done"
+rocprofv3 --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE -d $OUT/p3 -o pmc -- python3 $GRAFT_REPO_ROOT/$@ > $OUT/p3.log 2>&1
+echo "pass 3 done"
 cd $GRAFT_REPO_ROOT
 python3 - <<PY
 import csv, glob
-for p in ("p1", "p2"):
+for p in ("p1", "p2", "p3"):
     tot, calls = {}, {}
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % p, recursive=True):
         for r in csv.DictReader(open(f)):
