@@ -41,6 +41,7 @@ enum Opt {
     OPT_MSA_SPEC,             // 1: centre-star, 2: consistency-based progressive (0 = default = 2)
     OPT_MSA2_GENERAL_ROWS,    // spec v2: the library walk by the any-weights code also for unit weights
     OPT_MSA2_CHAIN_HBM,       // spec v2: the chain's prefix maxima in HBM from the start (the fallback of the LDS ring)
+    OPT_MSA2_WAVES_PER_CU,    // spec v2: resident wavefronts of the merge kernel per CU (perf sweeps)
     OPT_ALIGN_PENSEL,         // quality DP: the instantiation with explicit penalty selects also for gapopen >= 0
     OPT_ALIGN_CHUNKS,         // host-pointer DP: number of upload chunks
     OPT_ALIGN_K,              // quality DP: reference columns per lane (perf sweeps)

@@ -15,7 +15,7 @@
 //   col   int32   column of every base in the profile that currently holds its read;
 //   pos   uint16  per group n x wcap: position of read a at column c of its profile (0xFFFF = gap);
 //   tab   M2Cand  per group and join: the (third read, second-child member) candidates of the library walk as
-//                 32-byte scalar descriptors (k_m2_tables, once per batch).
+//                 16-byte descriptors (k_m2_tables, once per batch), staged into LDS by the wavefront that walks them.
 // Groups are independent (src/quick_msa.cpp:39); only the joins INSIDE a group are ordered.  So after the pairwise
 // alignments and the guide trees ONE launch does all the merging: k_m2_group, one wavefront per group, groups
 // pulled from an atomic counter in order of decreasing size, and for every join of its group the wavefront runs
@@ -68,6 +68,7 @@ struct M2Group {
     long long first_job;  // pairwise job of (a, b), a < b: first_job + a n - a (a + 1) / 2 + b - a - 1
     long long dist_base;  // into the tree kernel's scratch: n * n + n doubles
     long long tab_base;   // into the candidate tables (unit weights)
+    long long map0, col0; // map_base / col_base of the group's first member: the candidates address both relative to them
 };
 
 // counters of one call (sarlacc_stage_count): how often spec v2's own rules act, and the chain's fallback
@@ -195,38 +196,40 @@ __global__ void k_m2_init(M2Args A, const int* member_group, int nmembers) {
     }
 }
 
-// ---- unit weights (the default scores): the candidates of every join as tables of scalar descriptors ----
-// Entry e = pass * |B| + bi of a join's table: pass 0 the direct edges (c = b), pass 1 + c the triplets through
-// member c, each for the second child's members b ascending -- the canonical candidate order of spec v2 step 5, with
-// the block of c == a left in: the lane's position "in a itself" is a gap by construction, so those entries add nothing.
-//   M2Cand { map of (c -> b), columns of b, len(c) - 1, len(b) - 1, LDS row of c }
-// A direct edge reads the identity map (position in b = the staged position itself); an entry that does not count
-// (c == b in a triplet pass) and the M2_UBATCH - 1 padding entries behind the table point at an LDS row that holds only
-// gaps.  The walk therefore has no flags and no special cases: every entry is
-//   r = row[c][lane];  q = map[min(r, len(c) - 1)];  j = col[min(q, len(b) - 1)];  valid = r, q are not gaps
-// and, read with wave-uniform indices from memory no kernel writes while it is read, the descriptors arrive by scalar
-// loads -- no descriptor arithmetic on the vector unit.  The tables depend only on the tree, so they are written
-// once per batch, for all joins, before the merging starts.
+// ---- unit weights (the default scores): the candidates of every join as tables of descriptors ----
+// A join's table: first the direct edges (c = b), then for c = 0 .. n - 1 the triplets through member c, each for the
+// second child's members b ascending -- the canonical candidate order of spec v2 step 5, with the block of c == a left in
+// (the lane's position "in a itself" is a gap by construction, so those entries add nothing).  Both sections are padded to
+// whole batches of M2_UBATCH entries.
+//   M2Cand { byte offset of the map (c -> b), byte offset of the columns of b, len(c) - 1 | (len(b) - 1) << 16,
+//            byte offset of the LDS row of c | direct << 31 }
+// -- offsets relative to the group's first map / column array, so that every lookup is `scalar base + 32-bit lane
+// offset`.  A direct edge carries the flag instead of a map (the position in b is the staged position itself); an entry
+// that does not count (c == b in a triplet pass, padding) names the LDS row that holds only gaps.  The walk therefore
+// has no special cases: every entry is
+//   r = row[c][lane];  q = direct ? r : map[min(r, len(c) - 1)];  j = col[min(q, len(b) - 1)];  valid = r, q are not gaps.
+// The tables depend only on the tree, so k_m2_tables writes them once per batch, for all joins, before the merging
+// starts; the wavefront that merges a group stages the table of the current join into its LDS (all of it when it fits
+// beside the staged rows, otherwise chunk by chunk) and reads the descriptors from there with wave-uniform addresses.
+// (Round 2 read 32-byte descriptors by scalar loads: with one wavefront per group the scalar cache of a CU would have
+// to hold 32 different tables; a quarter of those loads missed it and every miss parks the wavefront.)
 constexpr int M2_UBATCH = 4;   // candidates looked up side by side
+constexpr int M2_LDS_UNIT = 5120;   // LDS of a wavefront of k_m2_group (unit weights): 32 of them per CU
 typedef const __attribute__((address_space(1))) uint16_t m2_gu16;
 typedef const __attribute__((address_space(1))) int m2_gi32;
-struct __attribute__((aligned(32))) M2Cand {
-    const uint16_t* map;
-    const int* col;
-    int lenc_m1, lenb_m1;
-    int row_off;    // byte offset of the LDS row (M2_MAXN: the all-gaps row)
-    int pad;
+struct __attribute__((aligned(16))) M2Cand {
+    unsigned map_boff;   // bytes from the group's first map
+    unsigned col_boff;   // bytes from the group's first column array
+    unsigned lens;       // len(c) - 1 | (len(b) - 1) << 16
+    unsigned row;        // LDS byte offset of the row of c (row n: gaps) | 0x80000000 for a direct edge
 };
-static_assert(sizeof(M2Cand) == 32, "M2Cand is read as one 8-dword scalar load");
-// worst case over all trees: every pair of reads is joined once, sum over the joins of |B| <= n (n - 1) / 2
-static inline long long m2_tab_entries(int n) { return static_cast<long long>(n) * (n - 1) / 2 * (n + 1) + static_cast<long long>(std::max(0, n - 1)) * (M2_UBATCH - 1) + 1; }
+static_assert(sizeof(M2Cand) == 16, "M2Cand is one 128-bit LDS read");
+constexpr unsigned M2_DIRECT = 0x80000000u;
+__host__ __device__ __forceinline__ int m2_round_batch(int x) { return (x + M2_UBATCH - 1) / M2_UBATCH * M2_UBATCH; }
+// worst case over all trees: every pair of reads is joined once, so the sum over the joins of |B| is at most n (n - 1) / 2
+static inline long long m2_tab_entries(int n) { return static_cast<long long>(n) * (n - 1) / 2 * (n + 1) + 2LL * std::max(0, n - 1) * (M2_UBATCH - 1) + 1; }
 
-__global__ void k_m2_identity(uint16_t* ident) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x < 65536) ident[x] = static_cast<uint16_t>(x);
-}
-
-__global__ void __launch_bounds__(64) k_m2_tables(M2Args A, M2Cand* tab, const uint16_t* ident) {
+__global__ void __launch_bounds__(64) k_m2_tables(M2Args A, M2Cand* tab) {
     __shared__ int s_b[M2_MAXN];
     __shared__ unsigned s_mask[2 * M2_MAXN];
     const int g = blockIdx.x;
@@ -245,29 +248,29 @@ __global__ void __launch_bounds__(64) k_m2_tables(M2Args A, M2Cand* tab, const u
         __syncthreads();
         if (lane == 0) { s_mask[n + k] = maskA | maskB; A.join_tab[fm + k] = off; }
         M2Cand* const T = tab + G.tab_base + off;
-        const int E = nbm * (n + 1);
-        for (int e = lane; e < E + M2_UBATCH - 1; e += 64) {
+        const int Ed = m2_round_batch(nbm), Et = m2_round_batch(nbm * n);
+        for (int e = lane; e < Ed + Et; e += 64) {
             M2Cand C;
-            C.pad = 0;
-            if (e >= E) {   // padding: the batch that holds the last entries reads up to M2_UBATCH - 1 more
-                C.map = ident; C.col = A.col + A.members[fm].col_base; C.lenc_m1 = 0; C.lenb_m1 = 0; C.row_off = M2_MAXN * 128;
-            } else {
-                const int pass = e / nbm, b = s_b[e % nbm];
-                const int cu = pass == 0 ? b : pass - 1;
+            C.map_boff = 0; C.col_boff = 0; C.lens = 0; C.row = static_cast<unsigned>(n) * 128u;   // padding: the gaps row
+            const bool direct = e < Ed;
+            const int x = direct ? e : e - Ed;
+            if (x < (direct ? nbm : nbm * n)) {
+                const int b = s_b[x % nbm];
+                const int cu = direct ? b : x / nbm;
                 const M2Member Mc = A.members[fm + cu], Mb = A.members[fm + b];
-                C.col = A.col + Mb.col_base;
-                C.lenb_m1 = max(Mb.len - 1, 0);
-                if (pass == 0) { C.map = ident; C.lenc_m1 = 65534; C.row_off = b * 128; }
+                C.col_boff = static_cast<unsigned>((Mb.col_base - G.col0) * 4);
+                const unsigned lenb = static_cast<unsigned>(max(Mb.len - 1, 0));
+                if (direct) { C.lens = lenb << 16; C.row = (static_cast<unsigned>(b) * 128u) | M2_DIRECT; }
                 else {
                     const int bslot = cu == b ? 0 : (b < cu ? b : b - 1);
-                    C.map = A.map + Mc.map_base + static_cast<long long>(bslot) * Mc.len;
-                    C.lenc_m1 = max(Mc.len - 1, 0);
-                    C.row_off = (cu == b ? M2_MAXN : cu) * 128;
+                    C.map_boff = static_cast<unsigned>((Mc.map_base - G.map0 + static_cast<long long>(bslot) * Mc.len) * 2);
+                    C.lens = static_cast<unsigned>(max(Mc.len - 1, 0)) | (lenb << 16);
+                    C.row = static_cast<unsigned>(cu == b ? n : cu) * 128u;
                 }
             }
             T[e] = C;
         }
-        off += E + M2_UBATCH - 1;
+        off += Ed + Et;
         __syncthreads();
     }
 }
@@ -405,15 +408,28 @@ constexpr unsigned M2_EMPTY = 0xFFFF0000u;
         }                                                                                              \
     }
 
-__device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, const M2Join& J, const M2Cand* __restrict__ T,
+__device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, const M2Join& J, const M2Cand* T,
                                             unsigned char* smem, m2_u64* ent, int* part, unsigned& st_capped, unsigned& st_filtered,
                                             unsigned& st_rowsf) {
-    uint16_t (*s_r)[64] = reinterpret_cast<uint16_t (*)[64]>(smem);   // [M2_MAXN + 1][64]: position of the lane's base in every other member; last row: gaps
+    // LDS: rows 0 .. n - 1 of 64 positions each (position of the lane's base in member c), row n: gaps; behind them the
+    // join's candidates
     const int lane = m2_lane();
     const int n = J.n, fm = J.fm, nA = J.nA;
-    const int E = __popc(J.maskB) * (n + 1);
-    s_r[M2_MAXN][lane] = static_cast<uint16_t>(M2_NONE);   // (every lane reads its own column of s_r only)
-    const unsigned char* const s_rlane = reinterpret_cast<const unsigned char*>(&s_r[0][lane]);
+    const int nbm = __popc(J.maskB);
+    const int E = m2_round_batch(nbm) + m2_round_batch(nbm * n);
+    uint16_t* const s_rl = reinterpret_cast<uint16_t*>(smem) + lane;     // (every lane reads its own column of the rows only)
+    const unsigned char* const s_rlane = reinterpret_cast<const unsigned char*>(s_rl);
+    M2Cand* const s_tab = reinterpret_cast<M2Cand*>(smem + (n + 1) * 128);
+    const int cap = ((M2_LDS_UNIT - (n + 1) * 128) / 16) & ~(M2_UBATCH - 1);
+    const bool resident = E <= cap;
+    s_rl[n * 64] = static_cast<uint16_t>(M2_NONE);
+    auto stage = [&](int c0, int cnt) {
+        for (int e = lane; e < cnt; e += 64) s_tab[e] = T[c0 + e];
+        __syncthreads();
+    };
+    if (resident) stage(0, E);
+    const char* const mapb = reinterpret_cast<const char*>(A.map + G.map0);
+    const char* const colb = reinterpret_cast<const char*>(A.col + G.col0);
     int ne = 0;
     for (int i0 = 0; i0 < nA; i0 += 64) {
         const int i = i0 + lane;
@@ -441,26 +457,31 @@ __device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, c
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
-                        if (c0 + u < n) s_r[c0 + u][lane] = (c0 + u != a && havep) ? rv[u] : static_cast<uint16_t>(M2_NONE);
+                        if (c0 + u < n) s_rl[(c0 + u) * 64] = (c0 + u != a && havep) ? rv[u] : static_cast<uint16_t>(M2_NONE);
                 }
             }
-            for (int f0 = 0; f0 < E; f0 += M2_UBATCH) {
-                unsigned rr[M2_UBATCH], qq[M2_UBATCH];
-                int jj[M2_UBATCH];
-                // the map lookups of the batch, then the column lookups, each requested back to back
+            for (int c0 = 0; c0 < E; c0 += cap) {
+                const int ce = min(cap, E - c0);
+                if (!resident) { __syncthreads(); stage(c0, ce); }
+                for (int f0 = 0; f0 < ce; f0 += M2_UBATCH) {
+                    unsigned rr[M2_UBATCH], qq[M2_UBATCH], cb[M2_UBATCH], ln[M2_UBATCH], dr[M2_UBATCH];
+                    int jj[M2_UBATCH];
+                    // the map lookups of the batch, then the column lookups, each requested back to back
 #pragma unroll
-                for (int u = 0; u < M2_UBATCH; ++u) {
-                    const M2Cand& C = T[f0 + u];
-                    rr[u] = *reinterpret_cast<const uint16_t*>(s_rlane + C.row_off);
-                    // (the pointers are global memory: said explicitly, a pointer read from memory would be dereferenced
-                    // by flat loads, which wait on the LDS counter as well)
-                    qq[u] = ((m2_gu16*)C.map)[min(rr[u], static_cast<unsigned>(C.lenc_m1))];   // (a gap clamps to a valid index)
+                    for (int u = 0; u < M2_UBATCH; ++u) {
+                        const M2Cand C = s_tab[f0 + u];   // (wave-uniform address: one broadcast read)
+                        rr[u] = *reinterpret_cast<const uint16_t*>(s_rlane + (C.row & 0xffffu));
+                        cb[u] = C.col_boff; ln[u] = C.lens >> 16; dr[u] = C.row;
+                        qq[u] = *((m2_gu16*)(mapb + (C.map_boff + (min(rr[u], C.lens & 0xffffu) << 1))));   // (a gap clamps to a valid index)
+                    }
+#pragma unroll
+                    for (int u = 0; u < M2_UBATCH; ++u) {
+                        qq[u] = (dr[u] & M2_DIRECT) ? rr[u] : qq[u];
+                        jj[u] = *((m2_gi32*)(colb + (cb[u] + (min(qq[u], ln[u]) << 2))));
+                    }
+#pragma unroll
+                    for (int u = 0; u < M2_UBATCH; ++u) M2_ADD1(jj[u], rr[u] != M2_NONE && qq[u] != M2_NONE)
                 }
-#pragma unroll
-                for (int u = 0; u < M2_UBATCH; ++u)
-                    jj[u] = ((m2_gi32*)T[f0 + u].col)[min(qq[u], static_cast<unsigned>(T[f0 + u].lenb_m1))];
-#pragma unroll
-                for (int u = 0; u < M2_UBATCH; ++u) M2_ADD1(jj[u], rr[u] != M2_NONE && qq[u] != M2_NONE)
             }
         }
         st_capped += (row && capped) ? 1u : 0u;
@@ -843,13 +864,13 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
     return newW;
 }
 
-// LDS of a wavefront: the rows' staging, reused by the chain's ring (4096 B).  4224 B with unit weights (the any-weights
-// walk keeps the members' descriptors there too): 32 single-wave workgroups per CU fit beside each other.
-constexpr int M2_LDS_UNIT = (M2_MAXN + 1) * 128, M2_LDS_GENERAL = M2_LDS_UNIT + M2_MAXN * 3 * 8 + M2_MAXN * 2 * 4;
-static_assert(M2_LDS_UNIT >= M2_QW * 8, "the chain's ring shares the LDS of the rows' staging");
+// LDS of a wavefront: the rows' staging (+ the join's candidates with unit weights, the members' descriptors in the
+// any-weights walk), reused by the chain's ring (4096 B).  5 KB: 32 single-wave workgroups per CU fit beside each other.
+constexpr int M2_LDS_GENERAL = (M2_MAXN + 1) * 128 + M2_MAXN * 3 * 8 + M2_MAXN * 2 * 4;
+static_assert(M2_LDS_UNIT >= M2_QW * 8 && M2_LDS_UNIT >= (M2_MAXN + 1) * 128 + 16 * M2_UBATCH, "the chain's ring and the rows' staging share the LDS");
 
 template <bool UNITW>
-__global__ void __launch_bounds__(64) k_m2_group(M2Args A, const M2Cand* __restrict__ tab) {
+__global__ void __launch_bounds__(64) k_m2_group(M2Args A, const M2Cand* tab) {
     __shared__ __align__(16) unsigned char smem[UNITW ? M2_LDS_UNIT : M2_LDS_GENERAL];
     const int lane = threadIdx.x;
     const long long wb = static_cast<long long>(blockIdx.x) * A.w_rows;
@@ -1042,6 +1063,8 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
         G.first_job = static_cast<long long>(B.jobs.size());
         G.dist_base = dist_pos;
         G.tab_base = tab_pos;
+        G.map0 = map_pos;
+        G.col0 = col_pos;
         pos_pos += static_cast<long long>(n) * G.wcap;
         dist_pos += static_cast<long long>(n) * n + n;
         tab_pos += m2_tab_entries(n);
@@ -1126,11 +1149,8 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     const bool unitw = a.ma <= 1 && a.mm <= 1 && !option(OPT_MSA2_GENERAL_ROWS);
     M2Cand* d_tab = nullptr;
     if (unitw) {
-        uint16_t* d_ident;
         SL_TRY(scratch((pf + ".tab").c_str(), static_cast<size_t>(B.tab_n) + 1, &d_tab));
-        SL_TRY(scratch("msa2.ident", 65536, &d_ident));
-        hipLaunchKernelGGL(k_m2_identity, dim3(256), dim3(256), 0, s, d_ident);
-        hipLaunchKernelGGL(k_m2_tables, dim3(static_cast<unsigned>(ng)), dim3(64), 0, s, a, d_tab, d_ident);
+        hipLaunchKernelGGL(k_m2_tables, dim3(static_cast<unsigned>(ng)), dim3(64), 0, s, a, d_tab);
         SL_HIP(hipGetLastError());
     }
     // ---- progressive merging: one launch, one wavefront per group (groups in order of decreasing size) ----
@@ -1141,6 +1161,7 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
         if (unitw) SL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_m2_group<true>, 64, 0));
         else SL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_m2_group<false>, 64, 0));
         per_cu = std::max(1, std::min(per_cu, 32));
+        if (option(OPT_MSA2_WAVES_PER_CU) > 0) per_cu = std::min(per_cu, option(OPT_MSA2_WAVES_PER_CU));
         const long long w_rows = (static_cast<long long>(B.max_wcap) + 64 + 63) / 64 * 64;
         const long long per_wave = w_rows * (M2_CAP * 12 + 4 * 4 + 8);
         long long waves = std::min<long long>(static_cast<long long>(per_cu) * std::max(1, c.num_cu), static_cast<long long>(nmulti));
@@ -1281,7 +1302,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
                 long long sum = 0, mx = 0;
                 for (long long a = 0; a < n; ++a) { const long long len = rel[grp[grp_off[g] + a]] - rel[grp[grp_off[g] + a] - 1]; sum += len; mx = std::max(mx, len); }
                 const long long wc = exact_w ? sum : std::min(sum, static_cast<long long>(M2_FASTW(mx)));
-                const long long mb = 2 * (n - 1) * sum + 2 * n * wc + 4 * sum + 32 * m2_tab_entries(static_cast<int>(n)), jb = n * (n - 1) / 2;
+                const long long mb = 2 * (n - 1) * sum + 2 * n * wc + 4 * sum + 16 * m2_tab_entries(static_cast<int>(n)), jb = n * (n - 1) / 2;
                 if (q1 > q0 && (mem_b + mb > mem_budget || jobs_b + jb > job_budget)) break;
                 mem_b += mb; jobs_b += jb;
                 B.ids.push_back(g);

@@ -15,12 +15,28 @@ from sarlacc_amd.strset import StringSet
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 spec = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+pure = len(sys.argv) > 4 and sys.argv[4] == "pure"   # groups = the molecules themselves (no UMI clustering, no mixed clusters)
 dev = torch.device("cuda:0")
 mol = devsynth.make_molecule_reads(G, 10, 2000, seed=2000, device=dev)
 off = mol["off"].cpu().numpy()
 umis = StringSet(mol["umi"].cpu().numpy(), mol["umi_off"].cpu().numpy())
 enc = sarlacc_amd.phred_encoding()
 calls.set_msa_spec(spec)
+if pure:
+    from sarlacc_amd import _lib, device
+    n = off.size - 1
+    goff = np.arange(0, n + 1, 10, dtype=np.int64)
+    gflat = np.arange(1, n + 1, dtype=np.int32)
+    for rep in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cons, phred = device.dev_msa_consensus(goff, gflat, mol["seq"], mol["qual"], off, 0, -1, -5, -1, 100, 0.6, encoding=enc)
+        dt = time.perf_counter() - t0
+        print("pure rep %d spec %d: %.3f s  pairwise %.1f ms  merge %.1f ms  consensus %.1f ms" % (
+            rep, spec, dt, _lib.stage_ms("msa_pairwise"), _lib.stage_ms("msa_merge"), _lib.stage_ms("consensus")), flush=True)
+        print("      msa2 %s" % {k: _lib.stage_count("msa2_" + k) for k in ("rows", "rows_capped", "entries_filtered", "entries_kept", "joins",
+              "joins_chain_in_hbm", "cycles_rows", "cycles_chain", "cycles_walk", "cycles_renumber", "first_exit_s", "last_exit_s")}, flush=True)
+    sys.exit(0)
 for rep in range(reps):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -31,6 +47,9 @@ for rep in range(reps):
         rep, spec, dt, (off.size - 1) / dt * 60 / 1e6, {k: round(v, 1) for k, v in r["kernel_ms"].items()}, sizes.size,
         sizes.max(), int((sizes > 10).sum()), int(r["counts"]["msa_v1_fallback"])), flush=True)
     print("      stage s %s" % {k: round(v, 4) for k, v in r["stage_s"].items()}, flush=True)
+    if rep == 0:
+        h = np.bincount(sizes)
+        print("      group sizes: %s" % {int(k): int(v) for k, v in enumerate(h) if v}, flush=True)
     from sarlacc_amd import _lib
     print("      msa2 %s" % {k: _lib.stage_count("msa2_" + k) for k in ("rows", "rows_capped", "entries_filtered", "rows_filtered", "entries_kept",
           "joins", "joins_chain_in_hbm", "cycles_rows", "cycles_chain", "cycles_walk", "cycles_renumber", "launches", "first_exit_s", "last_exit_s")}, flush=True)
