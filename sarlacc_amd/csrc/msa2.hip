@@ -46,6 +46,10 @@
 namespace sarlacc {
 
 constexpr int M2_MAXN = 32;          // group sizes aligned by spec v2 (member sets are 32-bit masks)
+#ifndef M2_WAVES_EU
+#define M2_WAVES_EU 8   // wavefronts per SIMD the merge kernel is compiled for (its registers are capped accordingly)
+#endif
+constexpr int M2_NB = 12, M2_NC = 20; // groups of up to M2_NB reads: one wavefront; up to M2_NC: 4; larger: 8 (k_m2_group)
 constexpr int M2_CAP = 16;           // partner columns per row (spec v2, step 5)
 constexpr unsigned M2_NONE = 0xFFFFu;
 // profile capacity of the first pass: same-molecule reads grow a profile by 10-20 %, one or two unrelated reads in
@@ -74,7 +78,9 @@ struct M2Group {
 // counters of one call (sarlacc_stage_count): how often spec v2's own rules act, and the chain's fallback
 enum { M2C_ROWS, M2C_ROWS_CAPPED, M2C_ENT_FILTERED, M2C_ROWS_FILTERED, M2C_ENT_KEPT, M2C_JOINS, M2C_JOINS_HBMQ,
        // where the wavefronts' time goes (s_memtime cycles summed over the wavefronts) and when they leave (s_memrealtime, 100 MHz)
-       M2C_CYC_ROWS, M2C_CYC_CHAIN, M2C_CYC_WALK, M2C_CYC_RENUMBER, M2C_T_START, M2C_T_FIRST_EXIT, M2C_T_LAST_EXIT, M2C_N };
+       M2C_CYC_ROWS, M2C_CYC_CHAIN, M2C_CYC_WALK, M2C_CYC_RENUMBER, M2C_T_START, M2C_T_FIRST_EXIT, M2C_T_LAST_EXIT,
+       M2C_T_EXIT1, M2C_T_EXIT4, M2C_T_EXIT8,   // last exit of the instantiation with 1 / 4 / 8 wavefronts per group
+       M2C_N };
 
 struct M2Args {
     const uint8_t* seq;
@@ -91,7 +97,8 @@ struct M2Args {
     uint16_t* pos;
     int* ovf;                      // per group: a profile outgrew its capacity
     int32_t* width;                // per group: columns of the final profile
-    // ---- k_m2_group: work counter, counters, per-wavefront scratch (w_rows columns each) ----
+    // ---- k_m2_group: the launch's range of groups [g0, g1), work counter, counters, per-workgroup scratch (w_rows columns each) ----
+    int g0, g1;
     int* next;
     unsigned long long* counters;
     unsigned long long* w_ent;     // match list: (row << 48) | (column << 32) | weight; M2_CAP entries per column
@@ -214,7 +221,7 @@ __global__ void k_m2_init(M2Args A, const int* member_group, int nmembers) {
 // (Round 2 read 32-byte descriptors by scalar loads: with one wavefront per group the scalar cache of a CU would have
 // to hold 32 different tables; a quarter of those loads missed it and every miss parks the wavefront.)
 constexpr int M2_UBATCH = 4;   // candidates looked up side by side
-constexpr int M2_LDS_UNIT = 5120;   // LDS of a wavefront of k_m2_group (unit weights): 32 of them per CU
+constexpr int M2_LDS_UNIT = 5056;   // LDS of a wavefront of k_m2_group (unit weights): 32 of them per CU
 typedef const __attribute__((address_space(1))) uint16_t m2_gu16;
 typedef const __attribute__((address_space(1))) int m2_gi32;
 struct __attribute__((aligned(16))) M2Cand {
@@ -408,30 +415,26 @@ constexpr unsigned M2_EMPTY = 0xFFFF0000u;
         }                                                                                              \
     }
 
-__device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, const M2Join& J, const M2Cand* T,
-                                            unsigned char* smem, m2_u64* ent, int* part, unsigned& st_capped, unsigned& st_filtered,
-                                            unsigned& st_rowsf) {
-    // LDS: rows 0 .. n - 1 of 64 positions each (position of the lane's base in member c), row n: gaps; behind them the
-    // join's candidates
+__device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, const M2Join& J, const M2Cand* T, int i_lo, int i_hi,
+                                            unsigned char* s_rows, M2Cand* s_tab, int cap, bool resident, m2_u64* ent, int* part,
+                                            unsigned& st_capped, unsigned& st_filtered, unsigned& st_rowsf) {
+    // s_rows (LDS, this wavefront's): rows 0 .. n - 1 of 64 positions each (position of the lane's base in member c), row n:
+    // gaps.  s_tab (LDS): the join's candidates -- all of them (`resident`, staged by the caller) or room for `cap` at a time.
     const int lane = m2_lane();
     const int n = J.n, fm = J.fm, nA = J.nA;
     const int nbm = __popc(J.maskB);
     const int E = m2_round_batch(nbm) + m2_round_batch(nbm * n);
-    uint16_t* const s_rl = reinterpret_cast<uint16_t*>(smem) + lane;     // (every lane reads its own column of the rows only)
+    uint16_t* const s_rl = reinterpret_cast<uint16_t*>(s_rows) + lane;     // (every lane reads its own column of the rows only)
     const unsigned char* const s_rlane = reinterpret_cast<const unsigned char*>(s_rl);
-    M2Cand* const s_tab = reinterpret_cast<M2Cand*>(smem + (n + 1) * 128);
-    const int cap = ((M2_LDS_UNIT - (n + 1) * 128) / 16) & ~(M2_UBATCH - 1);
-    const bool resident = E <= cap;
     s_rl[n * 64] = static_cast<uint16_t>(M2_NONE);
-    auto stage = [&](int c0, int cnt) {
+    auto stage = [&](int c0, int cnt) {   // (single-wavefront workgroups only)
         for (int e = lane; e < cnt; e += 64) s_tab[e] = T[c0 + e];
         __syncthreads();
     };
-    if (resident) stage(0, E);
     const char* const mapb = reinterpret_cast<const char*>(A.map + G.map0);
     const char* const colb = reinterpret_cast<const char*>(A.col + G.col0);
     int ne = 0;
-    for (int i0 = 0; i0 < nA; i0 += 64) {
+    for (int i0 = i_lo; i0 < i_hi; i0 += 64) {
         const int i = i0 + lane;
         unsigned pe[M2_CAP];
 #pragma unroll
@@ -565,8 +568,8 @@ __device__ __forceinline__ long long m2_uniform64(long long v) {   // a wave-uni
         }                                                                                              \
     }
 
-__device__ __forceinline__ int m2_rows_general(const M2Args& A, const M2Group& G, const M2Join& J, unsigned char* smem, m2_u64* ent,
-                                               int* part, unsigned& st_capped, unsigned& st_filtered, unsigned& st_rowsf) {
+__device__ __forceinline__ int m2_rows_general(const M2Args& A, const M2Group& G, const M2Join& J, int i_lo, int i_hi, unsigned char* smem,
+                                               m2_u64* ent, int* part, unsigned& st_capped, unsigned& st_filtered, unsigned& st_rowsf) {
     uint16_t (*s_r)[64] = reinterpret_cast<uint16_t (*)[64]>(smem);                                  // [M2_MAXN][64]
     long long* const s_mapbase = reinterpret_cast<long long*>(smem + (M2_MAXN + 1) * 128);            // the members' descriptors
     long long* const s_colbase = s_mapbase + M2_MAXN;
@@ -584,7 +587,7 @@ __device__ __forceinline__ int m2_rows_general(const M2Args& A, const M2Group& G
     const int nbm = __popc(maskB);
     __syncthreads();
     int ne = 0;
-    for (int i0 = 0; i0 < nA; i0 += 64) {
+    for (int i0 = i_lo; i0 < i_hi; i0 += 64) {
         const int i = i0 + lane;
         int ej[M2_CAP], ew[M2_CAP];
 #pragma unroll
@@ -688,8 +691,26 @@ __device__ __forceinline__ int m2_rows_general(const M2Args& A, const M2Group& G
 // redone with Q over all columns in HBM (RING = false; atomics and L2-coherent loads, rare).
 constexpr int M2_QW = 512;
 
+// The match list of a join comes in segments: wavefront w of the workgroup wrote the rows of its range at
+// ent + w * stride, cnt[w] matches; pfx[w] = matches before segment w (the index of a match counts through the segments).
+struct M2Segs {
+    int nseg;
+    long long stride;
+    const int* cnt;   // LDS
+    const int* pfx;   // LDS, nseg + 1 entries
+};
+
+// (single wavefront: LDS operations of a wavefront execute in order, so no barrier is needed between them -- only the
+// compiler must keep the order; the HBM variant waits for its stores and atomics)
 template <bool RING>
-__device__ __forceinline__ bool m2_chain_forward(const m2_u64* ent, int ne, unsigned* pred, m2_u64* Q, m2_u64& tail, int& err) {
+__device__ __forceinline__ void m2_chain_order() {
+    if (!RING) __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool RING>
+__device__ __forceinline__ bool m2_chain_forward(const m2_u64* ent, const M2Segs& S, unsigned* pred, m2_u64* Q, m2_u64& tail, int& err) {
     const int lane = m2_lane();
     int F = -1;
     m2_u64 QF = 0;
@@ -701,149 +722,163 @@ __device__ __forceinline__ bool m2_chain_forward(const m2_u64* ent, int ne, unsi
         if (RING) Q[c & (M2_QW - 1)] = v;
         else __hip_atomic_store(&Q[c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    int m0 = 0;
-    while (m0 < ne) {
-        const int m = m0 + lane;
-        const bool in = m < ne;
-        const m2_u64 e = ent[min(m, ne - 1)];
-        // a block ends on a row boundary: the matches of the row that continues into the next block wait for it
-        const int inext = m0 + 64 < ne ? static_cast<int>(ent[m0 + 64] >> 48) : -1;
-        const int i = static_cast<int>(e >> 48), j = static_cast<int>((e >> 32) & 0xffffu);
-        const unsigned w = static_cast<unsigned>(e);
-        const bool act = in && i != inext;
-        const int nb = __popcll(__ballot(act));   // (the waiting matches are the last lanes: the list is in row order)
-        if (nb == 0) { err = 1; return true; }   // cannot happen: a row holds at most M2_CAP < 64 matches
-        const int jmax = m2_wave_max(act ? j : -1), jmin = m2_wave_min(act ? j : 0x7fffffff);
-        const int newF = max(F, jmax);
-        if (RING && newF - jmin >= M2_QW - 2) return false;
-        // (1) state before the block
-        m2_u64 best = 0;
-        if (act && j > 0) best = (j - 1 > F) ? QF : q_load(j - 1);
-        // (2) the block's own matches, in list order
-        const unsigned ij = (static_cast<unsigned>(i) << 16) | static_cast<unsigned>(j);
-        for (int s = 0; s < nb; ++s) {
-            const unsigned bh = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(best >> 32), s));
-            const unsigned ws = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(w), s));
-            const unsigned ijs = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(ij), s));
-            const m2_u64 nvs = (static_cast<m2_u64>(bh + ws) << 32) | static_cast<unsigned>(~static_cast<unsigned>(m0 + s + 1));
-            const bool dom = act && i > static_cast<int>(ijs >> 16) && j > static_cast<int>(ijs & 0xffffu);
-            best = (dom && nvs > best) ? nvs : best;
+    for (int sg = 0; sg < S.nseg; ++sg) {
+        const m2_u64* const es = ent + sg * S.stride;
+        const int ne = m2_rfl(S.cnt[sg]);
+        const int base = m2_rfl(S.pfx[sg]);
+        int m0 = 0;
+        while (m0 < ne) {
+            const int m = m0 + lane;
+            const bool in = m < ne;
+            const m2_u64 e = es[min(m, ne - 1)];
+            // a block ends on a row boundary: the matches of the row that continues into the next block wait for it
+            // (a segment ends on one: segments are ranges of rows)
+            const int inext = m0 + 64 < ne ? static_cast<int>(es[m0 + 64] >> 48) : -1;
+            const int i = static_cast<int>(e >> 48), j = static_cast<int>((e >> 32) & 0xffffu);
+            const unsigned w = static_cast<unsigned>(e);
+            const bool act = in && i != inext;
+            const int nb = __popcll(__ballot(act));   // (the waiting matches are the last lanes: the list is in row order)
+            if (nb == 0) { err = 1; return true; }   // cannot happen: a row holds at most M2_CAP < 64 matches
+            const int jmax = m2_wave_max(act ? j : -1), jmin = m2_wave_min(act ? j : 0x7fffffff);
+            const int newF = max(F, jmax);
+            if (RING && newF - jmin >= M2_QW - 2) return false;
+            // (1) state before the block
+            m2_u64 best = 0;
+            if (act && j > 0) best = (j - 1 > F) ? QF : q_load(j - 1);
+            // (2) the block's own matches, in list order
+            const unsigned ij = (static_cast<unsigned>(i) << 16) | static_cast<unsigned>(j);
+            for (int s = 0; s < nb; ++s) {
+                const unsigned bh = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(best >> 32), s));
+                const unsigned ws = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(w), s));
+                const unsigned ijs = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(ij), s));
+                const m2_u64 nvs = (static_cast<m2_u64>(bh + ws) << 32) | static_cast<unsigned>(~static_cast<unsigned>(base + m0 + s + 1));
+                const bool dom = act && i > static_cast<int>(ijs >> 16) && j > static_cast<int>(ijs & 0xffffu);
+                best = (dom && nvs > best) ? nvs : best;
+            }
+            const unsigned id = static_cast<unsigned>(base + m) + 1u;
+            const m2_u64 nv = act ? ((static_cast<m2_u64>(w + static_cast<unsigned>(best >> 32)) << 32) | static_cast<unsigned>(~id)) : 0ull;
+            if (act) pred[base + m] = best ? ~static_cast<unsigned>(best) : 0u;
+            // (3) enter the block
+            for (int c0 = RING ? max(F + 1, newF - M2_QW + 1) : F + 1; c0 <= newF; c0 += 64)
+                if (c0 + lane <= newF) q_store(c0 + lane, QF);
+            m2_chain_order<RING>();
+            if (act) {
+                if (RING) atomicMax(&Q[j & (M2_QW - 1)], nv);
+                else atomicMax(&Q[j], nv);
+            }
+            m2_chain_order<RING>();
+            m2_u64 carry = jmin > 0 ? q_load(jmin - 1) : 0ull;
+            for (int c0 = jmin; c0 <= newF; c0 += 64) {
+                const int c = c0 + lane;
+                m2_u64 x = c <= newF ? q_load(c) : 0ull;
+                x = m2_scan_max64(x);
+                x = x > carry ? x : carry;
+                if (c <= newF) q_store(c, x);
+                carry = m2_readlane64(x, 63);
+            }
+            m2_chain_order<RING>();
+            QF = carry;
+            F = newF;
+            m0 += nb;
         }
-        const unsigned id = static_cast<unsigned>(m) + 1u;
-        const m2_u64 nv = act ? ((static_cast<m2_u64>(w + static_cast<unsigned>(best >> 32)) << 32) | static_cast<unsigned>(~id)) : 0ull;
-        if (act) pred[m] = best ? ~static_cast<unsigned>(best) : 0u;
-        // (3) enter the block
-        for (int c0 = RING ? max(F + 1, newF - M2_QW + 1) : F + 1; c0 <= newF; c0 += 64)
-            if (c0 + lane <= newF) q_store(c0 + lane, QF);
-        if (!RING) __threadfence();
-        __syncthreads();
-        if (act) {
-            if (RING) atomicMax(&Q[j & (M2_QW - 1)], nv);
-            else atomicMax(&Q[j], nv);
-        }
-        if (!RING) __threadfence();
-        __syncthreads();
-        m2_u64 carry = jmin > 0 ? q_load(jmin - 1) : 0ull;
-        for (int c0 = jmin; c0 <= newF; c0 += 64) {
-            const int c = c0 + lane;
-            m2_u64 x = c <= newF ? q_load(c) : 0ull;
-            x = m2_scan_max64(x);
-            x = x > carry ? x : carry;
-            if (c <= newF) q_store(c, x);
-            carry = m2_readlane64(x, 63);
-        }
-        if (!RING) __threadfence();
-        __syncthreads();
-        QF = carry;
-        F = newF;
-        m0 += nb;
     }
     tail = QF;
     return true;
 }
 
 // walk back through the predecessors: part[row] = column for the matches of the chain
-__device__ __forceinline__ void m2_chain_walk(const m2_u64* ent, int ne, const unsigned* pred, m2_u64 tail, int* part, int& err) {
+__device__ __forceinline__ void m2_chain_walk(const m2_u64* ent, const M2Segs& S, const unsigned* pred, m2_u64 tail, int* part, int& err) {
     const int lane = m2_lane();
     unsigned cur = tail ? ~static_cast<unsigned>(tail) : 0u;
     cur = static_cast<unsigned>(m2_rfl(static_cast<int>(cur)));
-    int steps = ne + 2;   // a predecessor has a smaller index: the walk visits every match at most once
+    int sg = S.nseg - 1;
+    int steps = m2_rfl(S.pfx[S.nseg]) + 2;   // a predecessor has a smaller index: the walk visits every match at most once
     while (cur != 0u && steps > 0) {
-        const int mb = static_cast<int>(cur - 1u) & ~63;
-        const int m = mb + lane;
-        const m2_u64 e = ent[min(m, ne - 1)];
-        const unsigned p = pred[min(m, ne - 1)];
+        while (sg > 0 && static_cast<int>(cur - 1u) < m2_rfl(S.pfx[sg])) --sg;
+        const int base = m2_rfl(S.pfx[sg]), ne = m2_rfl(S.cnt[sg]);
+        const int mb = (static_cast<int>(cur - 1u) - base) & ~63;   // block of 64 matches inside the segment
+        const int m = min(mb + lane, ne - 1);
+        const m2_u64 e = ent[sg * S.stride + m];
+        const unsigned p = pred[base + m];
         unsigned long long visited = 0;
         do {
-            const int l = static_cast<int>(cur - 1u) - mb;
+            const int l = static_cast<int>(cur - 1u) - base - mb;
             visited |= 1ull << l;
             cur = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(p), l));
             --steps;
-        } while (cur != 0u && static_cast<int>(cur - 1u) >= mb && steps > 0);
+        } while (cur != 0u && static_cast<int>(cur - 1u) >= base + mb && steps > 0);
         if ((visited >> lane) & 1ull) part[static_cast<int>(e >> 48)] = static_cast<int>((e >> 32) & 0xffffu);
     }
     if (cur != 0u) err = 2;
 }
 
-// ---- new column numbers, col / pos of every member (one wavefront) ----
+// ---- new column numbers, col / pos of every member: the scans on the first wavefront, the rest on all NW ----
 // returns the width of the joined profile, or -1 when it exceeds the capacity
-__device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, const M2Join& J, const int* part, int* nca, int* ncb, int* pb) {
+template <int NW>
+__device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, const M2Join& J, const int* part, int* nca, int* ncb, int* pb,
+                                           int* s_newW) {
     const int lane = m2_lane();
+    const int wave = m2_rfl(static_cast<int>(threadIdx.x >> 6));
+    const int tid = wave * 64 + lane;
+    constexpr int NT = 64 * NW;
     const int n = J.n, fm = J.fm, nA = J.nA, nB = J.nB;
     // partner rows of the second child's columns
-    for (int j = lane; j < nB; j += 64) pb[j] = -1;
+    for (int j = tid; j < nB; j += NT) pb[j] = -1;
     __threadfence_block();
     __syncthreads();
-    for (int i = lane; i < nA; i += 64) {
+    for (int i = tid; i < nA; i += NT) {
         const int pj = part[i];
         if (pj >= 0) pb[pj] = i;
     }
     __threadfence_block();
     __syncthreads();
-    // first child: column i -> i + (columns of the second child up to the previous matched partner) - matches before
-    int jprev = -1, t0 = 0;
-    for (int i0 = 0; i0 < nA; i0 += 64) {
-        const int i = i0 + lane;
-        const int pj = i < nA ? part[i] : -1;
-        const unsigned long long ball = __ballot(pj >= 0);
-        const int before = __popcll(ball & ((1ull << lane) - 1ull));
-        const int pm = max(m2_excl_max(pj, -1), jprev);
-        const int t = t0 + before;
-        if (i < nA) nca[i] = pj >= 0 ? i + pj - t : i + (pm + 1) - t;
-        t0 += __popcll(ball);
-        jprev = max(jprev, m2_wave_max(pj));
-    }
-    const int nm = t0;
-    // second child: column j -> (row of the next matched pair, or nA) + j - matches before; descending for "next"
-    int inext = nA;
-    for (int j0 = ((nB - 1) / 64) * 64; j0 >= 0 && nB > 0; j0 -= 64) {
-        const int j = j0 + 63 - lane;     // (descending over the lanes: "at or after j" is a prefix)
-        const int pi = j < nB ? pb[j] : -1;
-        const int sc = m2_scan_i32<2>(pi >= 0 ? pi : 0x7fffffff, 0x7fffffff);
-        if (j < nB) ncb[j] = min(sc, inext);          // provisional: the row of the next matched pair at or after j
-        inext = min(inext, __builtin_amdgcn_readlane(sc, 63));
+    if (wave == 0) {
+        // first child: column i -> i + (columns of the second child up to the previous matched partner) - matches before
+        int jprev = -1, t0 = 0;
+        for (int i0 = 0; i0 < nA; i0 += 64) {
+            const int i = i0 + lane;
+            const int pj = i < nA ? part[i] : -1;
+            const unsigned long long ball = __ballot(pj >= 0);
+            const int before = __popcll(ball & ((1ull << lane) - 1ull));
+            const int pm = max(m2_excl_max(pj, -1), jprev);
+            const int t = t0 + before;
+            if (i < nA) nca[i] = pj >= 0 ? i + pj - t : i + (pm + 1) - t;
+            t0 += __popcll(ball);
+            jprev = max(jprev, m2_wave_max(pj));
+        }
+        const int nm = t0;
+        // second child: column j -> (row of the next matched pair, or nA) + j - matches before; descending for "next"
+        int inext = nA;
+        for (int j0 = ((nB - 1) / 64) * 64; j0 >= 0 && nB > 0; j0 -= 64) {
+            const int j = j0 + 63 - lane;     // (descending over the lanes: "at or after j" is a prefix)
+            const int pi = j < nB ? pb[j] : -1;
+            const int sc = m2_scan_i32<2>(pi >= 0 ? pi : 0x7fffffff, 0x7fffffff);
+            if (j < nB) ncb[j] = min(sc, inext);          // provisional: the row of the next matched pair at or after j
+            inext = min(inext, __builtin_amdgcn_readlane(sc, 63));
+        }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        int tb = 0;
+        for (int j0 = 0; j0 < nB; j0 += 64) {
+            const int j = j0 + lane;
+            const int pi = j < nB ? pb[j] : -1;
+            const unsigned long long ball = __ballot(pi >= 0);
+            const int before = tb + __popcll(ball & ((1ull << lane) - 1ull));
+            if (j < nB) ncb[j] = ncb[j] + j - before;   // matched: next = its own row
+            tb += __popcll(ball);
+        }
+        if (lane == 0) *s_newW = nA + nB - nm;
     }
     __threadfence_block();
     __syncthreads();
-    int tb = 0;
-    for (int j0 = 0; j0 < nB; j0 += 64) {
-        const int j = j0 + lane;
-        const int pi = j < nB ? pb[j] : -1;
-        const unsigned long long ball = __ballot(pi >= 0);
-        const int before = tb + __popcll(ball & ((1ull << lane) - 1ull));
-        if (j < nB) ncb[j] = ncb[j] + j - before;   // matched: next = its own row
-        tb += __popcll(ball);
-    }
-    __threadfence_block();
-    __syncthreads();
-    const int newW = nA + nB - nm;
+    const int newW = m2_rfl(*s_newW);
     if (newW > G.wcap) return -1;
     // clear the members' rows of pos, then scatter the new columns
     const unsigned both = J.maskA | J.maskB;
     for (int a = 0; a < n; ++a) {
         if (!((both >> a) & 1u)) continue;
         uint16_t* row = A.pos + G.pos_base + static_cast<long long>(a) * G.wcap;
-        for (int c = lane; c < newW; c += 64) row[c] = static_cast<uint16_t>(M2_NONE);
+        for (int c = tid; c < newW; c += NT) row[c] = static_cast<uint16_t>(M2_NONE);
     }
     __threadfence_block();
     __syncthreads();
@@ -853,7 +888,7 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
         const M2Member Me = A.members[fm + a];
         const int* nc = inA ? nca : ncb;
         uint16_t* row = A.pos + G.pos_base + static_cast<long long>(a) * G.wcap;
-        for (int p = lane; p < Me.len; p += 64) {
+        for (int p = tid; p < Me.len; p += NT) {
             const int c = nc[A.col[Me.col_base + p]];
             A.col[Me.col_base + p] = c;
             row[c] = static_cast<uint16_t>(p);
@@ -864,15 +899,24 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
     return newW;
 }
 
-// LDS of a wavefront: the rows' staging (+ the join's candidates with unit weights, the members' descriptors in the
-// any-weights walk), reused by the chain's ring (4096 B).  5 KB: 32 single-wave workgroups per CU fit beside each other.
-constexpr int M2_LDS_GENERAL = (M2_MAXN + 1) * 128 + M2_MAXN * 3 * 8 + M2_MAXN * 2 * 4;
+// LDS of a workgroup: per wavefront the rows' staging ((n + 1) rows of 128 B), behind them the join's candidates; the
+// chain's ring (4096 B, first wavefront) reuses the front.  One wavefront per group: 5 KB, 32 workgroups per CU, larger
+// tables go through in chunks.  NW wavefronts per group (groups of up to NMAX reads): the whole table of any join fits.
+constexpr int m2_lds_bytes(bool unitw, int nw, int nmax) {
+    return !unitw ? (M2_MAXN + 1) * 128 + M2_MAXN * 3 * 8 + M2_MAXN * 2 * 4
+                  : (nw == 1 ? M2_LDS_UNIT : nw * (nmax + 1) * 128 + ((nmax - 1 + M2_UBATCH) + ((nmax - 1) * nmax + M2_UBATCH)) * 16);
+}
 static_assert(M2_LDS_UNIT >= M2_QW * 8 && M2_LDS_UNIT >= (M2_MAXN + 1) * 128 + 16 * M2_UBATCH, "the chain's ring and the rows' staging share the LDS");
 
-template <bool UNITW>
-__global__ void __launch_bounds__(64) k_m2_group(M2Args A, const M2Cand* tab) {
-    __shared__ __align__(16) unsigned char smem[UNITW ? M2_LDS_UNIT : M2_LDS_GENERAL];
-    const int lane = threadIdx.x;
+// One workgroup of NW wavefronts per group (groups of up to NMAX reads; NW = 1 takes any).  The rows of a join are
+// cut into NW ranges, one per wavefront; the chain runs on the first wavefront; the renumbering's copies on all.
+template <bool UNITW, int NW, int NMAX>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? M2_WAVES_EU : 4, 8))) k_m2_group(M2Args A, const M2Cand* tab) {
+    __shared__ __align__(16) unsigned char smem[m2_lds_bytes(UNITW, NW, NMAX)];
+    __shared__ int s_cnt[NW], s_pfx[NW + 1], s_ctl[4];
+    static_assert(UNITW || NW == 1, "the any-weights walk runs on one wavefront");
+    const int lane = threadIdx.x & 63;
+    const int wave = m2_rfl(static_cast<int>(threadIdx.x >> 6));
     const long long wb = static_cast<long long>(blockIdx.x) * A.w_rows;
     m2_u64* const ent = A.w_ent + wb * M2_CAP;
     unsigned* const pred = A.w_pred + wb * M2_CAP;
@@ -884,21 +928,22 @@ __global__ void __launch_bounds__(64) k_m2_group(M2Args A, const M2Cand* tab) {
     unsigned st_capped = 0, st_filtered = 0, st_rowsf = 0;
     unsigned long long st_rows = 0, st_kept = 0, st_joins = 0, st_hbmq = 0;
     unsigned long long cy_rows = 0, cy_chain = 0, cy_walk = 0, cy_renum = 0;
-    if (lane == 0) atomicMin(&A.counters[M2C_T_START], __builtin_amdgcn_s_memrealtime());
+    if (threadIdx.x == 0) atomicMin(&A.counters[M2C_T_START], __builtin_amdgcn_s_memrealtime());
     for (;;) {
-        int g = 0;
-        if (lane == 0) g = atomicAdd(A.next, 1);
-        g = m2_rfl(g);
-        if (g >= A.ngroups) break;
+        __syncthreads();
+        if (threadIdx.x == 0) s_ctl[0] = A.g0 + atomicAdd(A.next, 1);
+        __syncthreads();
+        const int g = m2_rfl(s_ctl[0]);
+        if (g >= A.g1) break;
         const M2Group G = A.groups[g];
         const int n = G.n, fm = G.first_member;
         if (n < 2) continue;
-        // the nodes of the guide tree live in the lanes: lane k = node k (leaves 0 .. n - 1, join k creates n + k)
+        // the nodes of the guide tree live in the lanes (of every wavefront): lane k = node k (leaves 0 .. n - 1, join k creates n + k)
         unsigned nmask = lane < n ? (1u << lane) : 0u;
         int ncols = lane < n ? A.members[fm + lane].len : 0;
         int err = 0, width = 0;
-        bool over = false;
-        for (int round = 0; round + 1 < n; ++round) {
+        bool over = n > NMAX;   // (the host sends a group to an instantiation that holds it)
+        for (int round = 0; round + 1 < n && !over; ++round) {
             const int2 jn = A.joins[fm + round];
             const int jx = m2_rfl(jn.x), jy = m2_rfl(jn.y);
             M2Join J;
@@ -909,45 +954,77 @@ __global__ void __launch_bounds__(64) k_m2_group(M2Args A, const M2Cand* tab) {
             J.nB = __builtin_amdgcn_readlane(ncols, jy);
             __syncthreads();
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            // ---- rows: wavefront w takes the blocks of 64 rows [w bpw, (w + 1) bpw) and writes its matches at ent + w stride ----
+            const int bpw = ((J.nA + 63) / 64 + NW - 1) / NW;
+            const long long stride = static_cast<long long>(bpw) * 64 * M2_CAP;
+            const int i_lo = min(wave * bpw * 64, J.nA), i_hi = min((wave + 1) * bpw * 64, J.nA);
             int ne;
-            if (UNITW) ne = m2_rows_unit(A, G, J, tab + G.tab_base + m2_rfl(A.join_tab[fm + round]), smem, ent, part, st_capped, st_filtered, st_rowsf);
-            else ne = m2_rows_general(A, G, J, smem, ent, part, st_capped, st_filtered, st_rowsf);
-            st_rows += static_cast<unsigned>(J.nA);
-            st_kept += static_cast<unsigned>(ne);
-            ++st_joins;
+            if (UNITW) {
+                const M2Cand* const T = tab + G.tab_base + m2_rfl(A.join_tab[fm + round]);
+                const int rows_b = (n + 1) * 128;
+                M2Cand* const s_tab = reinterpret_cast<M2Cand*>(smem + NW * rows_b);
+                const int cap = ((m2_lds_bytes(UNITW, NW, NMAX) - NW * rows_b) / 16) & ~(M2_UBATCH - 1);
+                const int nbm = __popc(J.maskB);
+                const int E = m2_round_batch(nbm) + m2_round_batch(nbm * n);
+                const bool resident = E <= cap;
+                if (resident) {
+                    for (int e = threadIdx.x; e < E; e += 64 * NW) s_tab[e] = T[e];
+                    __syncthreads();
+                } else if (NW > 1) { err = 3; }   // (cannot happen: the LDS of a multi-wavefront instantiation holds any table of its groups)
+                ne = err ? 0 : m2_rows_unit(A, G, J, T, i_lo, i_hi, smem + wave * rows_b, s_tab, cap, resident, ent + wave * stride, part, st_capped,
+                                            st_filtered, st_rowsf);
+            } else {
+                ne = m2_rows_general(A, G, J, i_lo, i_hi, smem, ent, part, st_capped, st_filtered, st_rowsf);
+            }
+            if (lane == 0) s_cnt[wave] = ne;
             __threadfence_block();
             __syncthreads();
+            if (threadIdx.x == 0) {
+                int acc = 0;
+                for (int w = 0; w < NW; ++w) { s_pfx[w] = acc; acc += s_cnt[w]; }
+                s_pfx[NW] = acc;
+            }
+            __syncthreads();
+            const int ne_all = m2_rfl(s_pfx[NW]);
             const unsigned long long t1 = __builtin_amdgcn_s_memtime();
             unsigned long long t2 = t1;
-            if (ne > 0) {
-                m2_u64 tail = 0;
-                m2_u64* const ring = reinterpret_cast<m2_u64*>(smem);
-                if (A.chain_hbm || !m2_chain_forward<true>(ent, ne, pred, ring, tail, err)) {
-                    ++st_hbmq;
-                    __syncthreads();
-                    m2_chain_forward<false>(ent, ne, pred, qg, tail, err);
+            if (wave == 0) {
+                st_rows += static_cast<unsigned>(J.nA);
+                st_kept += static_cast<unsigned>(ne_all);
+                ++st_joins;
+                if (ne_all > 0) {
+                    M2Segs S;
+                    S.nseg = NW; S.stride = stride; S.cnt = s_cnt; S.pfx = s_pfx;
+                    m2_u64 tail = 0;
+                    m2_u64* const ring = reinterpret_cast<m2_u64*>(smem);
+                    if (A.chain_hbm || !m2_chain_forward<true>(ent, S, pred, ring, tail, err)) {
+                        ++st_hbmq;
+                        m2_chain_order<false>();
+                        m2_chain_forward<false>(ent, S, pred, qg, tail, err);
+                    }
+                    m2_chain_order<false>();
+                    t2 = __builtin_amdgcn_s_memtime();
+                    m2_chain_walk(ent, S, pred, tail, part, err);
                 }
-                __threadfence_block();
-                __syncthreads();
-                t2 = __builtin_amdgcn_s_memtime();
-                m2_chain_walk(ent, ne, pred, tail, part, err);
-                __threadfence_block();
-                __syncthreads();
+                if (lane == 0) s_ctl[1] = err;
             }
+            __threadfence_block();
+            __syncthreads();
+            err = m2_rfl(s_ctl[1]) | err;
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-            const int newW = m2_renumber(A, G, J, part, nca, ncb, pb);
+            const int newW = m2_renumber<NW>(A, G, J, part, nca, ncb, pb, &s_ctl[2]);
             const unsigned long long t4 = __builtin_amdgcn_s_memtime();
-            cy_rows += t1 - t0; cy_chain += t2 - t1; cy_walk += t3 - t2; cy_renum += t4 - t3;
+            if (wave == 0) { cy_rows += t1 - t0; cy_chain += t2 - t1; cy_walk += t3 - t2; cy_renum += t4 - t3; }
             if (newW < 0 || err) { over = true; break; }
             if (lane == n + round) { nmask = J.maskA | J.maskB; ncols = newW; }
             width = newW;
         }
-        if (lane == 0) {
-            if (over) A.ovf[g] = err ? 2 : 1;
+        if (threadIdx.x == 0) {
+            if (over) A.ovf[g] = err || n > NMAX ? 2 : 1;
             else A.width[g] = width;
         }
     }
-    // the wavefront's counters
+    // the wavefronts' counters
     st_capped = static_cast<unsigned>(m2_incl_sum(static_cast<int>(st_capped)));
     st_filtered = static_cast<unsigned>(m2_incl_sum(static_cast<int>(st_filtered)));
     st_rowsf = static_cast<unsigned>(m2_incl_sum(static_cast<int>(st_rowsf)));
@@ -955,17 +1032,20 @@ __global__ void __launch_bounds__(64) k_m2_group(M2Args A, const M2Cand* tab) {
         atomicAdd(&A.counters[M2C_ROWS_CAPPED], static_cast<unsigned long long>(st_capped));
         atomicAdd(&A.counters[M2C_ENT_FILTERED], static_cast<unsigned long long>(st_filtered));
         atomicAdd(&A.counters[M2C_ROWS_FILTERED], static_cast<unsigned long long>(st_rowsf));
-        atomicAdd(&A.counters[M2C_ROWS], st_rows);
-        atomicAdd(&A.counters[M2C_ENT_KEPT], st_kept);
-        atomicAdd(&A.counters[M2C_JOINS], st_joins);
-        atomicAdd(&A.counters[M2C_JOINS_HBMQ], st_hbmq);
-        atomicAdd(&A.counters[M2C_CYC_ROWS], cy_rows);
-        atomicAdd(&A.counters[M2C_CYC_CHAIN], cy_chain);
-        atomicAdd(&A.counters[M2C_CYC_WALK], cy_walk);
-        atomicAdd(&A.counters[M2C_CYC_RENUMBER], cy_renum);
-        const unsigned long long tx = __builtin_amdgcn_s_memrealtime();
-        atomicMin(&A.counters[M2C_T_FIRST_EXIT], tx);
-        atomicMax(&A.counters[M2C_T_LAST_EXIT], tx);
+        if (wave == 0) {
+            atomicAdd(&A.counters[M2C_ROWS], st_rows);
+            atomicAdd(&A.counters[M2C_ENT_KEPT], st_kept);
+            atomicAdd(&A.counters[M2C_JOINS], st_joins);
+            atomicAdd(&A.counters[M2C_JOINS_HBMQ], st_hbmq);
+            atomicAdd(&A.counters[M2C_CYC_ROWS], cy_rows);
+            atomicAdd(&A.counters[M2C_CYC_CHAIN], cy_chain);
+            atomicAdd(&A.counters[M2C_CYC_WALK], cy_walk);
+            atomicAdd(&A.counters[M2C_CYC_RENUMBER], cy_renum);
+            const unsigned long long tx = __builtin_amdgcn_s_memrealtime();
+            atomicMin(&A.counters[M2C_T_FIRST_EXIT], tx);
+            atomicMax(&A.counters[M2C_T_LAST_EXIT], tx);
+            atomicMax(&A.counters[NW == 1 ? M2C_T_EXIT1 : (NW == 4 ? M2C_T_EXIT4 : M2C_T_EXIT8)], tx);
+        }
     }
 }
 
@@ -1100,6 +1180,33 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
     return 0;
 }
 
+// streams of the side-by-side instantiations of k_m2_group (created once per process and device, non-blocking: the
+// caller's stream may be the legacy default one)
+struct M2Streams {
+    std::vector<hipStream_t> st;
+    std::vector<hipEvent_t> join;
+    hipEvent_t fork = nullptr;
+    int device = -1;
+    int ensure(int n) {
+        if (device != ctx().device) {   // (streams and events belong to the device that was current when they were made)
+            for (hipStream_t x : st) (void)hipStreamDestroy(x);
+            for (hipEvent_t e : join) (void)hipEventDestroy(e);
+            if (fork) (void)hipEventDestroy(fork);
+            st.clear(); join.clear(); fork = nullptr;
+            device = ctx().device;
+        }
+        if (!fork) SL_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        while (static_cast<int>(st.size()) < n) {
+            hipStream_t x; hipEvent_t e;
+            SL_HIP(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+            SL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            st.push_back(x); join.push_back(e);
+        }
+        return 0;
+    }
+};
+static M2Streams& m2_streams() { static M2Streams m; return m; }
+
 static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq, double match, double mismatch, double gap_extension,
                         double gap_opening, int bandwidth, const std::function<int()>* overlap, double* cells, double* counters,
                         hipStream_t s) {
@@ -1153,43 +1260,73 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
         hipLaunchKernelGGL(k_m2_tables, dim3(static_cast<unsigned>(ng)), dim3(64), 0, s, a, d_tab);
         SL_HIP(hipGetLastError());
     }
-    // ---- progressive merging: one launch, one wavefront per group (groups in order of decreasing size) ----
+    // ---- progressive merging: every join of every group in ONE round of launches ----
+    // Groups are ordered by decreasing size.  A group is merged by one workgroup: one wavefront for the bulk (up to
+    // M2_NB reads), 4 wavefronts up to M2_NC reads, 8 beyond -- the cost of a group grows with the cube of its size, and
+    // the longest group sets the length of the launch.  The three instantiations run side by side on streams of their own.
     size_t nmulti = 0;
     while (nmulti < ng && B.groups[nmulti].n >= 2) ++nmulti;
     if (nmulti) {
-        int per_cu = 0;
-        if (unitw) SL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_m2_group<true>, 64, 0));
-        else SL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_m2_group<false>, 64, 0));
-        per_cu = std::max(1, std::min(per_cu, 32));
-        if (option(OPT_MSA2_WAVES_PER_CU) > 0) per_cu = std::min(per_cu, option(OPT_MSA2_WAVES_PER_CU));
-        const long long w_rows = (static_cast<long long>(B.max_wcap) + 64 + 63) / 64 * 64;
-        const long long per_wave = w_rows * (M2_CAP * 12 + 4 * 4 + 8);
-        long long waves = std::min<long long>(static_cast<long long>(per_cu) * std::max(1, c.num_cu), static_cast<long long>(nmulti));
-        waves = std::max<long long>(1, std::min(waves, (24LL << 30) / per_wave));   // (scratch of the resident wavefronts: at most 24 GB)
-        int* d_next; unsigned long long* d_cnt;
-        SL_TRY(scratch((pf + ".w_ent").c_str(), static_cast<size_t>(waves * w_rows * M2_CAP), &a.w_ent));
-        SL_TRY(scratch((pf + ".w_pred").c_str(), static_cast<size_t>(waves * w_rows * M2_CAP), &a.w_pred));
-        SL_TRY(scratch((pf + ".w_part").c_str(), static_cast<size_t>(waves * w_rows), &a.w_part));
-        SL_TRY(scratch((pf + ".w_nca").c_str(), static_cast<size_t>(waves * w_rows), &a.w_nca));
-        SL_TRY(scratch((pf + ".w_ncb").c_str(), static_cast<size_t>(waves * w_rows), &a.w_ncb));
-        SL_TRY(scratch((pf + ".w_pb").c_str(), static_cast<size_t>(waves * w_rows), &a.w_pb));
-        SL_TRY(scratch((pf + ".w_q").c_str(), static_cast<size_t>(waves * w_rows), &a.w_q));
-        SL_TRY(scratch((pf + ".next").c_str(), 1, &d_next));
+        size_t iC = 0, iB = 0;
+        if (unitw) {
+            while (iC < nmulti && B.groups[iC].n > M2_NC) ++iC;
+            iB = iC;
+            while (iB < nmulti && B.groups[iB].n > M2_NB) ++iB;
+        }
+        unsigned long long* d_cnt;
+        int* d_next;
+        SL_TRY(scratch((pf + ".next").c_str(), 4, &d_next));
         SL_TRY(scratch((pf + ".cnt").c_str(), M2C_N, &d_cnt));
-        SL_HIP(hipMemsetAsync(d_next, 0, sizeof(int), s));
+        SL_HIP(hipMemsetAsync(d_next, 0, 4 * sizeof(int), s));
         {
             unsigned long long init[M2C_N] = {};
             init[M2C_T_START] = init[M2C_T_FIRST_EXIT] = ~0ull;
             SL_HIP(hipMemcpyAsync(d_cnt, init, sizeof init, hipMemcpyHostToDevice, s));
             SL_HIP(hipStreamSynchronize(s));   // (init is on this frame's stack)
         }
-        a.w_rows = w_rows; a.next = d_next; a.counters = d_cnt;
+        a.counters = d_cnt;
         a.chain_hbm = option(OPT_MSA2_CHAIN_HBM) ? 1 : 0;
-        M2Args am = a;
-        am.ngroups = static_cast<int>(nmulti);   // (the groups of one read need no merging: they are the tail of the batch)
-        if (unitw) hipLaunchKernelGGL(k_m2_group<true>, dim3(static_cast<unsigned>(waves)), dim3(64), 0, s, am, d_tab);
-        else hipLaunchKernelGGL(k_m2_group<false>, dim3(static_cast<unsigned>(waves)), dim3(64), 0, s, am, d_tab);
-        SL_HIP(hipGetLastError());
+        const long long w_rows = (static_cast<long long>(B.max_wcap) + 63) / 64 * 64 + 64 * 9;   // (+ the slack of 8 row ranges)
+        const long long per_wg = w_rows * (M2_CAP * 12 + 4 * 4 + 8);
+        a.w_rows = w_rows;
+        M2Streams& MS = m2_streams();
+        SL_TRY(MS.ensure(2));
+        SL_HIP(hipEventRecord(MS.fork, s));
+        struct Cls { size_t lo, hi; int nw; const char* tag; };
+        const Cls cls[3] = {{0, iC, 8, ".c"}, {iC, iB, 4, ".b"}, {iB, nmulti, 1, ".a"}};
+        for (int k = 0; k < 3; ++k) {
+            if (cls[k].lo >= cls[k].hi) continue;
+            hipStream_t sk = k < 2 ? MS.st[k] : s;
+            if (k < 2) SL_HIP(hipStreamWaitEvent(sk, MS.fork, 0));
+            const void* fn = !unitw ? reinterpret_cast<const void*>(&k_m2_group<false, 1, M2_MAXN>)
+                             : k == 0 ? reinterpret_cast<const void*>(&k_m2_group<true, 8, M2_MAXN>)
+                             : k == 1 ? reinterpret_cast<const void*>(&k_m2_group<true, 4, M2_NC>)
+                                      : reinterpret_cast<const void*>(&k_m2_group<true, 1, M2_MAXN>);
+            int per_cu = 0;
+            SL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * cls[k].nw, 0));
+            per_cu = std::max(1, std::min(per_cu, 32 / cls[k].nw));
+            if (option(OPT_MSA2_WAVES_PER_CU) > 0) per_cu = std::max(1, std::min(per_cu, option(OPT_MSA2_WAVES_PER_CU) / cls[k].nw));
+            long long wgs = std::min<long long>(static_cast<long long>(per_cu) * std::max(1, c.num_cu), static_cast<long long>(cls[k].hi - cls[k].lo));
+            wgs = std::max<long long>(1, std::min(wgs, (16LL << 30) / per_wg));   // (scratch of the resident workgroups: at most 16 GB per instantiation)
+            M2Args am = a;
+            const std::string q = pf + cls[k].tag;
+            SL_TRY(scratch((q + ".w_ent").c_str(), static_cast<size_t>(wgs * w_rows * M2_CAP), &am.w_ent));
+            SL_TRY(scratch((q + ".w_pred").c_str(), static_cast<size_t>(wgs * w_rows * M2_CAP), &am.w_pred));
+            SL_TRY(scratch((q + ".w_part").c_str(), static_cast<size_t>(wgs * w_rows), &am.w_part));
+            SL_TRY(scratch((q + ".w_nca").c_str(), static_cast<size_t>(wgs * w_rows), &am.w_nca));
+            SL_TRY(scratch((q + ".w_ncb").c_str(), static_cast<size_t>(wgs * w_rows), &am.w_ncb));
+            SL_TRY(scratch((q + ".w_pb").c_str(), static_cast<size_t>(wgs * w_rows), &am.w_pb));
+            SL_TRY(scratch((q + ".w_q").c_str(), static_cast<size_t>(wgs * w_rows), &am.w_q));
+            am.g0 = static_cast<int>(cls[k].lo); am.g1 = static_cast<int>(cls[k].hi);
+            am.next = d_next + k;
+            const dim3 grid(static_cast<unsigned>(wgs)), block(64 * cls[k].nw);
+            if (!unitw) hipLaunchKernelGGL((k_m2_group<false, 1, M2_MAXN>), grid, block, 0, sk, am, d_tab);
+            else if (k == 0) hipLaunchKernelGGL((k_m2_group<true, 8, M2_MAXN>), grid, block, 0, sk, am, d_tab);
+            else if (k == 1) hipLaunchKernelGGL((k_m2_group<true, 4, M2_NC>), grid, block, 0, sk, am, d_tab);
+            else hipLaunchKernelGGL((k_m2_group<true, 1, M2_MAXN>), grid, block, 0, sk, am, d_tab);
+            SL_HIP(hipGetLastError());
+            if (k < 2) { SL_HIP(hipEventRecord(MS.join[k], sk)); SL_HIP(hipStreamWaitEvent(s, MS.join[k], 0)); }
+        }
     }
     SL_TRY(c.stage_end("msa_merge", s));
     B.width.resize(ng);
@@ -1204,6 +1341,8 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
         // seconds from the first wavefront's start to the first / the last wavefront's exit (100 MHz counter)
         counters[M2C_T_FIRST_EXIT] += static_cast<double>(hc[M2C_T_FIRST_EXIT] - hc[M2C_T_START]) * 1e-8;
         counters[M2C_T_LAST_EXIT] += static_cast<double>(hc[M2C_T_LAST_EXIT] - hc[M2C_T_START]) * 1e-8;
+        for (int k = M2C_T_EXIT1; k <= M2C_T_EXIT8; ++k)
+            if (hc[k]) counters[k] += static_cast<double>(hc[k] - hc[M2C_T_START]) * 1e-8;
         counters[M2C_T_START] += static_cast<double>(hc[M2C_JOINS] ? 1 : 0);   // (launches)
     }
     for (size_t q = 0; q < ng; ++q)
@@ -1356,6 +1495,9 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
     add("msa2_launches", counters[M2C_T_START]);
     add("msa2_first_exit_s", counters[M2C_T_FIRST_EXIT]);
     add("msa2_last_exit_s", counters[M2C_T_LAST_EXIT]);
+    add("msa2_exit_s_1wave", counters[M2C_T_EXIT1]);
+    add("msa2_exit_s_4waves", counters[M2C_T_EXIT4]);
+    add("msa2_exit_s_8waves", counters[M2C_T_EXIT8]);
     if (!rows_ws.ptr) SL_TRY(rows_reserve(0, 16));
     *d_rows = static_cast<uint8_t*>(rows_ws.ptr);
     return 0;
@@ -1407,7 +1549,8 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     c.stage_reset("msa_merge");
     for (const char* nm : {"msa_pairs", "msa_cells", "msa2_rows", "msa2_rows_capped", "msa2_entries_filtered", "msa2_rows_filtered",
                            "msa2_entries_kept", "msa2_joins", "msa2_joins_chain_in_hbm", "msa2_cycles_rows", "msa2_cycles_chain",
-                           "msa2_cycles_walk", "msa2_cycles_renumber", "msa2_launches", "msa2_first_exit_s", "msa2_last_exit_s"})
+                           "msa2_cycles_walk", "msa2_cycles_renumber", "msa2_launches", "msa2_first_exit_s", "msa2_last_exit_s",
+                           "msa2_exit_s_1wave", "msa2_exit_s_4waves", "msa2_exit_s_8waves"})
         c.counts[nm] = 0;
     if (v2.empty())
         return msa1_run(grp_off, grp, ngroups, seq, seq_off, nseq, match, mismatch, gap_extension, gap_opening, bandwidth, want_rows,
