@@ -1268,7 +1268,7 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     while (nmulti < ng && B.groups[nmulti].n >= 2) ++nmulti;
     if (nmulti) {
         size_t iC = 0, iB = 0;
-        if (unitw) {
+        if (unitw && !option(OPT_MSA2_SINGLE_WAVE)) {
             while (iC < nmulti && B.groups[iC].n > M2_NC) ++iC;
             iB = iC;
             while (iB < nmulti && B.groups[iB].n > M2_NB) ++iB;

@@ -1,6 +1,6 @@
 """Randomised differential fuzzing of every C-ABI entry point against the CPU oracle.
-Usage: python tools/fuzz.py [seconds] [seed].  Prints the first mismatch (with a reproducer seed)
-or a summary of the cases run."""
+Usage: python tools/fuzz.py [seconds] [seed] [case name, e.g. case_msa].  Prints the first mismatch (with a
+reproducer seed) or a summary of the cases run."""
 import os, sys, time, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -151,7 +151,7 @@ def case_consensus(rng):
 def case_msa(rng):
     from sarlacc_amd.mock import NUC, mutate
     reads, groups = [], []
-    many = rng.random() < 0.15   # many small groups: batches wide enough for the two round streams of spec v2
+    many = rng.random() < 0.15   # many small groups: workgroups of the merge kernel take several groups each
     for _ in range(int(rng.integers(8, 48)) if many else int(rng.integers(1, 6))):
         L = int(rng.choice([0, 5, 40, 90])) if many else int(rng.choice([0, 5, 60, 300, 900]))
         truth = NUC[rng.integers(0, 4, L)]
@@ -168,17 +168,30 @@ def case_msa(rng):
     if rng.random() < 0.2 and len(groups) >= 2 and groups[0] and groups[1]:   # a UMI collision: two molecules in one cluster
         groups[0] = groups[0] + groups[1]
         groups[1] = []
+    if rng.random() < 0.25:   # a large cluster of one to four molecules: 13-32 reads, the 4- and 8-wavefront workgroups of spec v2
+        L = int(rng.choice([30, 80, 200]))
+        truths = [NUC[rng.integers(0, 4, int(L * rng.uniform(0.7, 1.3)))] for _ in range(int(rng.integers(1, 5)))]
+        idx = []
+        for k in range(int(rng.integers(13, 33))):
+            reads.append(mutate(truths[int(rng.integers(0, len(truths)))], rng, 0.06, 0.02).tobytes().decode())
+            idx.append(len(reads))
+        groups.insert(int(rng.integers(0, len(groups) + 1)), idx)
     if rng.random() < 0.15 and groups and groups[0]:     # a length outlier and a huge bandwidth: the band cap of the spec
         k = groups[0][0] - 1
         reads[k] = reads[k] + mutate(NUC[rng.integers(0, 4, int(rng.choice([300, 1100, 1500])))], rng, 0.0, 0.0).tobytes().decode()
     params = [(0, -1, -5, -1), (0, -1, -1, -5), (1, -2, -2, -2), (2, -3, -1, -4), (0, -1, -1, -1)][int(rng.integers(0, 5))]
     bw = int(rng.choice([0, 3, 20, 100, 180, 600, 5000]))
-    spec = int(rng.choice([1, 2, 2]))
+    spec = int(rng.choice([1, 2, 2, 2]))
+    opts = [o for o in ("msa2_general_rows", "msa2_chain_hbm", "msa2_single_wave") if rng.random() < 0.15]   # the other code paths of spec v2
     calls.set_msa_spec(spec)
+    for o_ in opts:
+        calls.set_option(o_, 1)
     try:
         g, o, err = both(lambda: calls.quick_msa(groups, reads, *params, bw), lambda: O.quick_msa(groups, reads, *params, bw, spec=spec))
     finally:
         calls.set_msa_spec(0)
+        for o_ in opts:
+            calls.set_option(o_, 0)
     if not err:
         assert g == o, "msa rows (spec %d)" % spec
 
@@ -360,6 +373,8 @@ CASES = [case_align, case_align, case_umi, case_consensus, case_msa, case_mask, 
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if len(sys.argv) > 3:
+        CASES = [globals()[sys.argv[3]]]
     t0 = last_note = time.time()
     counts = {}
     k = 0
