@@ -110,6 +110,54 @@ def cpu_baseline(seq_strings, qual_strings, cores):
             "note": "the reference's C++ needs Rcpp/Biostrings headers absent from the image, hence a port"}
 
 
+def cpu_baseline_pipeline(umi_strings, threshold, groups, read_strings, qual_strings, cores):
+    """The oracle beside the pipeline half: umi_group on the first 2*10^4 and 10^5 UMIs of the batch as one
+    pre-group (one thread: the reference's loop over one pre-group is serial, src/umi_group.cpp:35, and its clustering
+    is O(#clusters x n), so the 10^6 figure is an explicit extrapolation), quick_msa under the default spec and
+    create_consensus_quality_loop on a sample of the batch's clusters (all cores over groups = the analogue of
+    R/multiReadAlign.R:29-31, and one core)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.build()
+    enc = O.phred_encoding()
+    out = {"kind": "port", "cores": cores}
+    um = {}
+    for n in (20000, 100000):
+        if n > len(umi_strings):
+            continue
+        t0 = time.perf_counter()
+        O.umi_group(umi_strings[:n], threshold, None, threshold, [list(range(1, n + 1))])
+        um[str(n)] = time.perf_counter() - t0
+    if um:
+        out["umi_group_seconds"] = um
+        out["umi_group_note"] = "one pre-group, 1 thread; super-linear in n (greedy clustering scans all live nodes per cluster)"
+        if "20000" in um and "100000" in um and um["20000"] > 0:
+            import math
+            expo = math.log(um["100000"] / um["20000"]) / math.log(5.0)
+            out["umi_group_extrapolated_1M_seconds"] = um["100000"] * 10.0 ** expo
+            out["umi_group_scaling_exponent"] = expo
+
+    def run(gs):
+        aln = O.quick_msa(gs, read_strings, 0, -1, -5, -1, 100)
+        q = [[qual_strings[i - 1] for i in g] for g in gs]
+        O.create_consensus_quality_loop(aln, 0.6, q, enc)
+        return sum(len(g) for g in gs)
+
+    t0 = time.perf_counter()
+    n1 = run(groups[:max(1, len(groups) // max(cores, 1))])
+    dt1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        nall = sum(ex.map(lambda g: run([g]), groups))
+    dt = time.perf_counter() - t0
+    out["msa_consensus"] = {"value": nall / dt * 60.0, "unit": "reads/min", "cores": cores,
+                            "sample": "%d clusters (%d reads) of the same batch, quick_msa spec v2 + quality consensus, %d threads over "
+                                      "clusters (%.1f s)" % (len(groups), nall, cores, dt),
+                            "single_core": {"value": n1 / dt1 * 60.0, "unit": "reads/min", "cores": 1,
+                                            "sample": "%d reads (%.1f s)" % (n1, dt1)}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -267,6 +315,46 @@ def main():
         out["host_pointer"] = {"gcups": cells / best / 1e9, "seconds": best,
                                "note": "sarlacc_adaptor_align on host buffers: chunked upload overlapped with the kernels, results downloaded"}
         del hs, hq
+    # generic level (SURVEY section 8d ii): adaptorAlign on the resident reads -- front / back windows of `tolerance` = 250 bases
+    # (R/adaptorAlign.R:86-95), four alignments per read with traceback and sections (:186-189), strand choice
+    if rank == 0 and not args.no_host_pointer:
+        from sarlacc_amd import generics
+        from sarlacc_amd.resident import DevBuffer, DeviceReads
+        h_off = off.cpu().numpy()
+        dev_reads = DeviceReads(DevBuffer.borrow(seq.data_ptr(), total_bases), DevBuffer.borrow(qual.data_ptr(), total_bases),
+                                DevBuffer.borrow(off.data_ptr(), 8 * (n + 1)), h_off, enc)
+        sub1, sub2 = generics._setup_subseqs(ADAPTOR1), generics._setup_subseqs(ADAPTOR2)
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dfront, dback = dev_reads.front_and_back(250)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hfront, hback = dfront.download()[0], dback.download()[0]
+            t2 = time.perf_counter()
+            kms, parts = 0.0, []
+            for ad, d, h, sb in ((ADAPTOR1, dfront, hfront, sub1), (ADAPTOR2, dback, hback, sub2), (ADAPTOR1, dback, hback, sub1),
+                                 (ADAPTOR2, dfront, hfront, sub2)):
+                parts.append(generics._align_and_extract_resident(ad, d, h, GAP_OPEN, GAP_EXT, sb["starts"], sb["ends"]))
+                kms += sarlacc_amd.last_kernel_ms()
+            t3 = time.perf_counter()
+            rev, _ = generics._resolve_strand(parts[0]["score"], parts[1]["score"], parts[2]["score"], parts[3]["score"])
+            generics._swap_rows(parts[0], parts[2], rev)
+            generics._swap_rows(parts[1], parts[3], rev)
+            t4 = time.perf_counter()
+            wcells = 2 * int(dfront.total) * (len(ADAPTOR1) + len(ADAPTOR2))
+            cur = {"seconds": t4 - t0, "gcups": wcells / (t4 - t0) / 1e9, "kernel_gcups": wcells / (kms * 1e-3) / 1e9,
+                   "reads_per_s": n / (t4 - t0), "reversed": int(rev.sum()),
+                   "breakdown_s": {"windows_on_device": t1 - t0, "windows_to_host_for_subsequences": t2 - t1,
+                                   "four_alignments_calls": t3 - t2, "four_alignments_kernels": kms * 1e-3,
+                                   "strand_choice_host": t4 - t3}}
+            best = cur if best is None or cur["seconds"] < best["seconds"] else best
+            del dfront, dback, hfront, hback, parts
+        best["note"] = ("adaptorAlign on the resident batch: tolerance 250, adaptor1 x front, adaptor2 x back, adaptor1 x back, adaptor2 x front "
+                        "(30- and 22-base adaptors), traceback + sections, strand resolution; cells = window bases x adaptor length")
+        out["generic_level"] = best
+        del dev_reads
     cpu_sample = None
     if rank == 0 and not args.no_cpu:
         # the GPU box gives a one-GPU job a share of 16 host cores (more threads than that only contend)
@@ -349,6 +437,13 @@ def main():
                                        "traffic": pc["traffic"], "traffic_source": pc["traffic_source"], "pmc": pc.get("derived")},
                 },
             }
+            out["pipeline"]["msa2_rules"] = {
+                "rows": cnt["msa2_rows"], "rows_capped": cnt["msa2_rows_capped"], "rows_filtered": cnt["msa2_rows_filtered"],
+                "entries_filtered": cnt["msa2_entries_filtered"], "entries_kept": cnt["msa2_entries_kept"], "joins": cnt["msa2_joins"],
+                "joins_chain_in_hbm": cnt["msa2_joins_chain_in_hbm"],
+                "note": "how often spec v2's own rules act in this pass: rows (profile columns of a first child) that met a 17th "
+                        "partner column, library entries dropped as lighter than half their row's heaviest; joins whose chain "
+                        "left the LDS ring (DESIGN.md section 5)"}
             out["pipeline"]["spec_v1"] = {"reads_per_min": sm[0] / v1[0] * 60.0, "seconds": v1[0],
                                           "kernel_ms": {"msa_pairwise": v1[1], "msa_merge": v1[2]},
                                           "msa_pairs": r1["counts"]["msa_pairs"],
@@ -367,6 +462,41 @@ def main():
                                                    "identical_to_resident": bool(same),
                                                    "note": "same stages through the host-pointer C ABI (reads + qualities cross PCIe), rank 0 only"}
                 del hs, hq
+        # BASELINE configs[3] as it is worded: 100k groups x 10 reads x 2 kb -- the molecules themselves as groups (no UMI
+        # clustering in front, so no clusters of several molecules)
+        goff_p = np.arange(0, nr + 1, args.copies, dtype=np.int64)
+        gflat_p = np.arange(1, nr + 1, dtype=np.int32)
+        c4 = None
+        for _ in range(2):
+            fence()
+            t0 = time.perf_counter()
+            cons_p, _ = sdev.dev_msa_consensus(goff_p, gflat_p, mol["seq"], mol["qual"], off_host, 0, -1, -5, -1, 100, 0.6, encoding=enc)
+            fence()
+            dt = time.perf_counter() - t0
+            c4 = {"seconds": dt, "kernel_ms": {k: sarlacc_amd.stage_ms(k) for k in ("msa_pairwise", "msa_merge", "consensus")},
+                  "consensus_reads": len(cons_p), "rows_capped": sarlacc_amd.stage_count("msa2_rows_capped"),
+                  "entries_filtered": sarlacc_amd.stage_count("msa2_entries_filtered"), "rows": sarlacc_amd.stage_count("msa2_rows")}
+        c4v = reduce([c4["seconds"]] + [c4["kernel_ms"][k] for k in ("msa_pairwise", "msa_merge", "consensus")], dist.ReduceOp.MAX)
+        if rank == 0:
+            out["pipeline"]["c4_pure_groups"] = {
+                "reads_per_min": sm[0] / c4v[0] * 60.0, "seconds": c4v[0],
+                "kernel_ms": dict(zip(("msa_pairwise", "msa_merge", "consensus"), c4v[1:])),
+                "groups": int(goff_p.size - 1), "msa2_rows": c4["rows"], "msa2_rows_capped": c4["rows_capped"],
+                "msa2_entries_filtered": c4["entries_filtered"],
+                "workload": "multiReadAlign + consensusReadSeq on %d groups x %d reads x %d bp per GPU (the molecules as groups)" % (
+                    args.molecules, args.copies, args.read_len)}
+        if rank == 0 and not args.no_cpu:
+            cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
+            h_seq, h_qual = mol["seq"].cpu().numpy(), mol["qual"].cpu().numpy()
+            sizes = np.diff(last["goff"])
+            pick = np.linspace(0, sizes.size - 1, num=min(2 * cores, sizes.size)).astype(np.int64)
+            ids = sorted({int(i) for k in pick for i in last["gflat"][last["goff"][k]:last["goff"][k + 1]]})
+            renum = {r: j + 1 for j, r in enumerate(ids)}
+            rs = [h_seq[off_host[r - 1]:off_host[r]].tobytes().decode() for r in ids]
+            qs = [h_qual[off_host[r - 1]:off_host[r]].tobytes().decode() for r in ids]
+            groups_s = [[renum[int(i)] for i in last["gflat"][last["goff"][k]:last["goff"][k + 1]]] for k in pick]
+            out["pipeline"]["cpu_baseline"] = cpu_baseline_pipeline(umis.to_strings()[:100000], args.threshold, groups_s, rs, qs, cores)
+            del h_seq, h_qual
         del mol
         torch.cuda.empty_cache()
 

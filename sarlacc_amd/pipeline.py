@@ -101,5 +101,7 @@ def run_resident(umis, d_seq, d_qual, off_host, encoding, threshold=1, bandwidth
         "kernel_ms": {"umi_pairs": umi_ms, "msa_pairwise": _lib.stage_ms("msa_pairwise"),
                       "msa_merge": _lib.stage_ms("msa_merge"), "consensus": _lib.stage_ms("consensus")},
         "counts": {"msa_pairs": _lib.stage_count("msa_pairs"), "msa_cells": _lib.stage_count("msa_cells"),
-                   "consensus_cells": _lib.stage_count("consensus_cells"), "msa_v1_fallback": _lib.stage_count("msa_v1_fallback")},
+                   "consensus_cells": _lib.stage_count("consensus_cells"), "msa_v1_fallback": _lib.stage_count("msa_v1_fallback"),
+                   **{k: _lib.stage_count(k) for k in ("msa2_rows", "msa2_rows_capped", "msa2_rows_filtered", "msa2_entries_filtered",
+                                                       "msa2_entries_kept", "msa2_joins", "msa2_joins_chain_in_hbm")}},
     }

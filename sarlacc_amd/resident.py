@@ -19,6 +19,15 @@ class DevBuffer:
         check(_lib.lib().sarlacc_dev_malloc(C.byref(self.ptr), C.c_int64(self.nbytes)))
 
     @classmethod
+    def borrow(cls, address, nbytes):
+        """A view of device memory somebody else owns (e.g. a torch tensor's data_ptr()): never freed here."""
+        b = object.__new__(cls)
+        b.nbytes = int(nbytes)
+        b.ptr = C.c_void_p(int(address))
+        b.owned = False
+        return b
+
+    @classmethod
     def from_numpy(cls, a):
         a = np.ascontiguousarray(a)
         b = cls(a.nbytes)
@@ -32,7 +41,7 @@ class DevBuffer:
 
     def __del__(self):
         try:
-            if self.ptr:
+            if self.ptr and getattr(self, "owned", True):
                 _lib.lib().sarlacc_dev_free(self.ptr)
                 self.ptr = C.c_void_p()
         except Exception:
