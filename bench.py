@@ -74,8 +74,9 @@ def pmc_record(kernel, sources):
         fe, wr = d.get("FETCH_SIZE_KB_per_launch") or [], d.get("WRITE_SIZE_KB_per_launch") or []
         if not fe or not wr:
             continue
-        return {"traffic": (sum(fe) / len(fe) + sum(wr) / len(wr)) * 1024.0, "traffic_source": os.path.relpath(f, ROOT),
-                "workload": d.get("workload"), "derived": d.get("derived")}
+        # gfx950: FETCH_SIZE counts 128-byte requests as 64 bytes (MI355X_MICROARCH.md, HBM) -- reads are doubled
+        return {"traffic": d.get("traffic_bytes_per_launch", (2.0 * sum(fe) / len(fe) + sum(wr) / len(wr)) * 1024.0),
+                "traffic_source": os.path.relpath(f, ROOT), "workload": d.get("workload"), "derived": d.get("derived")}
     return {"traffic": None, "traffic_source": None}
 
 
@@ -295,6 +296,7 @@ def main():
                          "unit": "T lane-op/s (fp64)", "frac": ops / VALU64_PEAK_TLOPS,
                          "algorithmic_ops_per_cell": ALIGN_OPS_PER_CELL,
                          "traffic": pmc["traffic"], "traffic_source": pmc["traffic_source"], "pmc": pmc.get("derived"),
+                         "traffic_ratio": pmc["traffic"] / alg_bytes if pmc["traffic"] else None,
                          "hbm": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": hbm / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes},
                          "note": "fp64 DP recurrence: vector-issue bound; compulsory traffic is 0.042 B/cell, so the HBM "
@@ -407,6 +409,9 @@ def main():
             msa_ops = cnt["msa_cells"] * MSA_OPS_PER_CELL / (kms["msa_pairwise"] * 1e-3) / 1e12
             cons_bytes = 2.0 * cnt["consensus_cells"] + 2.0 * cons_cols
             cons_gbs = cons_bytes / (kms["consensus"] * 1e-3) / 1e9
+            # algorithmic bytes of the pairwise stage under spec v2: the clustered reads in (1 B per base) and both position maps of
+            # every pair out (2 B per base of either read)
+            msa_alg_bytes = float(args.read_len) * (float(last["gflat"].size) + 4.0 * cnt["msa_pairs"])
             pm = pmc_record("k_msa_pairwise", ["msa_pairwise.hip", "msa_common.hpp"])
             pc = pmc_record("k_consensus_code", ["consensus.hip", "msa_common.hpp"])
             n_seen = dist.get_world_size() if world > 1 else 1
@@ -431,10 +436,13 @@ def main():
                                           "issue_peak_measured": 1024 * 64 / 4.2 * 2.4e9 / 1e12,
                                           "issue_peak_note": "tools/ubench_valu.hip on MI355X: packed 16-bit / VOP3 / DPP instructions issue in ~4.2 cycles per "
                                                              "wave64 (profiles/r02_ubench_valu_issue_v1.txt); the kernel holds two cells per instruction",
-                                          "traffic": pm["traffic"], "traffic_source": pm["traffic_source"], "pmc": pm.get("derived")},
+                                          "traffic": pm["traffic"], "traffic_source": pm["traffic_source"], "pmc": pm.get("derived"),
+                                          "algorithmic_bytes": msa_alg_bytes,
+                                          "traffic_ratio": pm["traffic"] / msa_alg_bytes if pm["traffic"] else None},
                     "k_consensus_code": {"bound": "hbm", "achieved": cons_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": cons_gbs / HBM_PEAK_GBS, "algorithmic_bytes": cons_bytes,
-                                       "traffic": pc["traffic"], "traffic_source": pc["traffic_source"], "pmc": pc.get("derived")},
+                                       "traffic": pc["traffic"], "traffic_source": pc["traffic_source"], "pmc": pc.get("derived"),
+                                       "traffic_ratio": pc["traffic"] / cons_bytes if pc["traffic"] else None},
                 },
             }
             out["pipeline"]["msa2_rules"] = {

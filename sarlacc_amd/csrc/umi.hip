@@ -25,6 +25,8 @@
 
 #include "common.hpp"
 
+#include <chrono>
+
 #include <rocprim/rocprim.hpp>
 
 #include "../../include/sarlacc_amd.h"
@@ -1260,6 +1262,7 @@ static int cluster_dev(const DevAdj& adj, int n, const int32_t* d_members, const
         hipLaunchKernelGGL(k_cl_decrement, g, b, 0, s, S, round);
         SL_HIP(hipGetLastError());
         if (round > 4 * n + 16) return fail("sarlacc_amd: clustering did not converge");
+        ctx().counts["umi_cluster_rounds"] = round + 1;
     }
 
     // ---- output order: solos by index, then picks by key descending ----
@@ -1473,9 +1476,18 @@ int sarlacc_umi_group(const char* umi1, const int64_t* off1, const char* umi2, c
         SL_TRY(upload("g.gid", gid.data(), static_cast<size_t>(N), &d_gid, s));
         SL_TRY(upload("g.single", single.data(), static_cast<size_t>(N), &d_single, s));
         DevAdj adj;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = now();
         SL_TRY(group_adjacency(d_c1, d_o1, d_c2, d_o2, d_grp, d_gid, d_single, static_cast<int>(ngroups), N, thresh1, thresh2, &adj, s));
+        SL_HIP(hipStreamSynchronize(s));
+        const double t1 = now();
         ClusterResult res;
         SL_TRY(cluster_dev(adj, N, d_grp, d_gid, static_cast<int>(ngroups), false, &res, s));
+        const double t2 = now();
+        // where a call's time goes (sarlacc_stage_count): seconds of the neighbour search incl. sorts / of the clustering
+        ctx().counts["umi_adjacency_s"] = t1 - t0;
+        ctx().counts["umi_cluster_s"] = t2 - t1;
+        ctx().counts["umi_links"] = static_cast<double>(adj.nnz);
         std::vector<long long> co(static_cast<size_t>(res.nclu) + 1);
         SL_HIP(hipMemcpy(co.data(), res.d_coff, sizeof(long long) * co.size(), hipMemcpyDeviceToHost));
         if (res.total) SL_HIP(hipMemcpy(clu, res.d_out, sizeof(int32_t) * static_cast<size_t>(res.total), hipMemcpyDeviceToHost));

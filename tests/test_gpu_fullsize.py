@@ -126,6 +126,46 @@ def test_c4_msa_and_consensus_ten_thousand_groups(enc, oracle):
     assert np.mean(errs) < 0.002 and np.max(errs) < 0.01
 
 
+def test_c4_full_size_sampled_against_oracle(enc, oenc, oracle):
+    """BASELINE config 4 at its stated size -- 100 000 groups x 10 reads x 2 kb, generated in HBM -- through the fused
+    multiReadAlign + consensusReadSeq call on resident reads (MSA spec v2, quality vote): the consensus and Phred strings of
+    320 groups spread over the batch must be the oracle's, character for character; all groups come back, every
+    consensus within a few bases of 2 kb."""
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    from sarlacc_amd import device, devsynth
+    G, K, L = 100_000, 10, 2000
+    dev = torch.device("cuda:0")
+    mol = devsynth.make_molecule_reads(G, K, L, seed=4242, device=dev)
+    off = mol["off"].cpu().numpy()
+    n = off.size - 1
+    goff = np.arange(0, n + 1, K, dtype=np.int64)
+    gflat = np.arange(1, n + 1, dtype=np.int32)
+    cons, phred = device.dev_msa_consensus(goff, gflat, mol["seq"], mol["qual"], off, 0, -1, -5, -1, 100, 0.6, encoding=enc)
+    assert len(cons) == G and np.array_equal(cons.widths(), phred.widths())
+    assert np.abs(cons.widths() - L).max() < 60
+    pick = np.linspace(0, G - 1, 320).astype(np.int64)
+    h_seq, h_qual = mol["seq"], mol["qual"]
+
+    def host(t, g):
+        lo, hi = int(off[g * K]), int(off[(g + 1) * K])
+        b = t[lo:hi].cpu().numpy().tobytes()
+        return [b[int(off[g * K + r]) - lo:int(off[g * K + r + 1]) - lo].decode() for r in range(K)]
+
+    data = [(host(h_seq, int(g)), host(h_qual, int(g))) for g in pick]
+
+    def want(rq):
+        reads, quals = rq
+        aln = oracle.quick_msa([list(range(1, K + 1))], reads, 0, -1, -5, -1, 100)
+        return oracle.create_consensus_quality_loop(aln, 0.6, [quals], oenc)
+
+    with ThreadPoolExecutor(16) as ex:
+        wants = list(ex.map(want, data))
+    for g, w in zip(pick, wants):
+        assert cons[int(g)] == w[0][0], "consensus of group %d differs from the oracle's" % g
+        assert phred[int(g)] == w[1][0], "Phred string of group %d differs from the oracle's" % g
+
+
 def test_c1_full_pipeline_identical_to_oracle(monkeypatch):
     """BASELINE config 1 at its stated size: mockReads 100 molecules x 10 reads x 1 kb through
     adaptorAlign -> umiGroup -> multiReadAlign -> consensusReadSeq; the HIP path and the CPU oracle

@@ -16,10 +16,11 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCES = {"k_align": ["align.hip"], "k_msa_pairwise": ["msa_pairwise.hip", "msa_common.hpp"], "k_consensus_code": ["consensus.hip", "msa_common.hpp"]}
+SOURCES = {"k_align": ["align.hip"], "k_msa_pairwise": ["msa_pairwise.hip", "msa_common.hpp"], "k_consensus_code": ["consensus.hip", "msa_common.hpp"],
+           "k_m2_group": ["msa2.hip", "msa_common.hpp"]}
 # share of fp64 instructions (4 issue cycles per wave64 instruction on a SIMD-32; everything else
 # 2) in the kernel's VALU stream, from the disassembly of its main loop
-FP64_SHARE = {"k_align": 0.75, "k_msa_pairwise": 0.0, "k_consensus_code": 0.18}
+FP64_SHARE = {"k_align": 0.75, "k_msa_pairwise": 0.0, "k_consensus_code": 0.18, "k_m2_group": 0.0}
 
 
 def source_sha(names):
@@ -78,6 +79,12 @@ def main():
     key = name.split("(")[0] if res["kernel_stats"] else kernel
     res["FETCH_SIZE_KB_per_launch"] = per_launch(counter_rows(os.path.join(out_dir, "pmc_fetch")), key, "FETCH_SIZE")
     res["WRITE_SIZE_KB_per_launch"] = per_launch(counter_rows(os.path.join(out_dir, "pmc_write")), key, "WRITE_SIZE")
+    # HBM bytes per launch after the gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 128-byte
+    # requests as 64 bytes, so reads are doubled; WRITE_SIZE is taken as reported
+    fe, wr = res["FETCH_SIZE_KB_per_launch"], res["WRITE_SIZE_KB_per_launch"]
+    if fe and wr:
+        res["traffic_bytes_per_launch"] = (2.0 * sum(fe) / len(fe) + sum(wr) / len(wr)) * 1024.0
+        res["traffic_correction"] = "2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports half the bytes read)"
     sq = {}
     for sub, names in (("pmc_sq", ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
                                    "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")),
@@ -108,8 +115,8 @@ def main():
         if "SQ_LDS_IDX_ACTIVE" in sq and sq.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
             d["lds_bank_conflict_frac"] = sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / sq["SQ_LDS_IDX_ACTIVE"]
         res["derived"] = d
-    res["note"] = ("FETCH_SIZE on gfx950 reports half the bytes of wide (16 B/lane) coalesced reads "
-                   "(MI355X_MICROARCH.md, HBM); narrower accesses are uncalibrated, value taken at face")
+    res["note"] = ("FETCH_SIZE on gfx950 reports half the bytes of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM): "
+                   "traffic_bytes_per_launch doubles it; the guide calls narrower accesses uncalibrated")
     print(json.dumps(res, indent=1))
 
 
