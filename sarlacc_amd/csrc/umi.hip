@@ -230,6 +230,7 @@ struct PairArgs {
     int tile_lo;                    // first row tile of this launch (row tiles shard across GPUs)
     const uint32_t* tile_list;      // optional: the (row tile << 16 | column tile) pairs to search, one per block
     const TileInfo* sub_info;       // optional: common prefixes of the 64-element blocks (4 per tile)
+    unsigned list_stride;           // block b searches tile_list[b * list_stride] (1; larger: a sample of the list)
 };
 
 // ---------------------------------------------------------------------------
@@ -342,7 +343,7 @@ __device__ __forceinline__ bool shd_reject(unsigned long long ca, int la, unsign
 template <int K>
 __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
     int bi = blockIdx.x + A.tile_lo, bj = blockIdx.y;
-    if (A.tile_list) { const uint32_t e = A.tile_list[blockIdx.x]; bi = static_cast<int>(e >> 16); bj = static_cast<int>(e & 0xffffu); }
+    if (A.tile_list) { const uint32_t e = A.tile_list[static_cast<size_t>(blockIdx.x) * A.list_stride]; bi = static_cast<int>(e >> 16); bj = static_cast<int>(e & 0xffffu); }
     if (bj < bi) return;
     // column tile (c*) and row tile (r*) both live in LDS: survivors of the cheap filters are
     // queued per wave and evaluated 64 at a time, so the exact DP always runs on full waves
@@ -805,6 +806,71 @@ __global__ void k_cl_pick(ClusterState S, int round) {
     S.pickkey[v] = k;
 }
 
+// The same three passes with one wavefront per node, for dense neighbourhoods (threshold 3 on 12-base UMIs: hundreds
+// of neighbours per node, thousands for some -- one thread per node would walk them alone): the lanes stride over the
+// node's list, so the list is read coalesced and the neighbours' words are gathered 64 at a time.
+__device__ __forceinline__ unsigned long long cl_wave_max64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned lo = static_cast<unsigned>(__shfl_xor(static_cast<int>(v), d));
+        const unsigned hi = static_cast<unsigned>(__shfl_xor(static_cast<int>(v >> 32), d));
+        const unsigned long long o = (static_cast<unsigned long long>(hi) << 32) | lo;
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_cl_m1_w(ClusterState S) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (v >= S.n) return;
+    unsigned long long m = 0;
+    if (S.state[v] == 0)
+        for (long long p = S.off[v] + lane; p < S.off[v + 1]; p += 64) m = max(m, S.key[S.nbr[p]]);
+    m = cl_wave_max64(m);
+    if (lane == 0) S.m1[v] = m;
+}
+
+__global__ void __launch_bounds__(256) k_cl_pick_w(ClusterState S, int round) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (v >= S.n) return;
+    const unsigned long long k = S.key[v];
+    if (k == 0) return;
+    const long long a = S.off[v], b = S.off[v + 1];
+    unsigned long long m2 = k;
+    for (long long p = a + lane; p < b; p += 64) {
+        const int w = S.nbr[p];
+        if (S.state[w] == 0) m2 = max(m2, S.m1[w]);
+    }
+    m2 = cl_wave_max64(m2);
+    if (m2 != k) return;
+    // cluster = still-unused neighbours in list order (src/cluster_umis.cpp:78-91)
+    int c = 0;
+    for (long long p0 = a; p0 < b; p0 += 64) {
+        const long long p = p0 + lane;
+        const int w = p < b ? S.nbr[p] : -1;
+        const bool live = w >= 0 && S.state[w] == 0;
+        const unsigned long long ball = __ballot(live);
+        if (live) {
+            S.memb[a + c + __popcll(ball & ((1ull << lane) - 1ull))] = w;
+            S.mark[w] = round;
+        }
+        c += __popcll(ball);
+    }
+    if (lane == 0) { S.csize[v] = c; S.seed[v] = 1; S.pickkey[v] = k; }
+}
+
+__global__ void __launch_bounds__(256) k_cl_decrement_w(ClusterState S, int round) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (v >= S.n || S.mark[v] != round) return;
+    for (long long p = S.off[v] + lane; p < S.off[v + 1]; p += 64) {
+        const int x = S.nbr[p];
+        if (S.state[x] == 0) atomicSub(&S.remaining[x], 1);
+    }
+}
+
 // state flips happen in a separate pass so that k_cl_pick sees a consistent snapshot
 __global__ void k_cl_commit(ClusterState S, int round) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1069,12 +1135,34 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
         SL_HIP(hipStreamSynchronize(s));
         d_list = d_l;
     }
+    // Capacity of the pair buffer: 32 per element covers thresholds 1 and 2; dense neighbourhoods (threshold 3 on 12-base
+    // UMIs: hundreds of neighbours each) would overflow it and cost a second full search, so the density is first
+    // estimated from a sample of the listed tile pairs (k_tile_pairs appends them in no particular order).
+    if (d_list && nlisted >= 2048 && limit >= 0) {
+        const unsigned stride = 32, ns = nlisted / stride;   // every 32nd listed tile pair
+        SL_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
+        PairArgs a{S.U, S.gid, n, lim2, d_edges, d_count, cap, tile_lo, d_list, d_subinfo, stride};
+        const int K = std::min(limit, UMI_MAXLEN);
+        if (K <= 0) launch_pairs<0>(a, tile_hi, ns, s);
+        else if (K == 1) launch_pairs<1>(a, tile_hi, ns, s);
+        else if (K == 2) launch_pairs<2>(a, tile_hi, ns, s);
+        else if (K == 3) launch_pairs<3>(a, tile_hi, ns, s);
+        else if (K == 4) launch_pairs<4>(a, tile_hi, ns, s);
+        else launch_pairs<5>(a, tile_hi, ns, s);
+        SL_HIP(hipGetLastError());
+        unsigned long long ms = 0;
+        SL_HIP(hipMemcpyAsync(&ms, d_count, sizeof ms, hipMemcpyDeviceToHost, s));
+        SL_HIP(hipStreamSynchronize(s));
+        const double est = static_cast<double>(ms) * static_cast<double>(nlisted) / static_cast<double>(ns);
+        cap = std::max<unsigned long long>(cap, static_cast<unsigned long long>(est * 1.25) + (1u << 20));
+        ctx().counts["umi_pairs_estimated"] = est;
+    }
     for (int attempt = 0; attempt < 2 && limit >= 0; ++attempt) {
         void* pe;
         SL_TRY(c.buffer((p + ".edges").c_str(), cap * sizeof(unsigned long long), &pe));
         d_edges = static_cast<unsigned long long*>(pe);
         SL_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
-        PairArgs a{S.U, S.gid, n, lim2, d_edges, d_count, cap, tile_lo, d_list, d_subinfo};
+        PairArgs a{S.U, S.gid, n, lim2, d_edges, d_count, cap, tile_lo, d_list, d_subinfo, 1u};
         SL_HIP(hipEventRecord(c.ev_start, s));
         c.stage_reset("umi_pairs");
         SL_TRY(c.stage_begin("umi_pairs", s));
@@ -1107,6 +1195,7 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
         c.timed = true;
         SL_HIP(hipMemcpyAsync(&m, d_count, sizeof m, hipMemcpyDeviceToHost, s));
         SL_HIP(hipStreamSynchronize(s));
+        ctx().counts["umi_pair_attempts"] = attempt + 1;
         if (m <= cap) break;
         cap = m;  // the kernel kept counting: second attempt has the exact size
     }
@@ -1147,7 +1236,9 @@ static int neighbour_keys(const std::string& p, const SortedUmis& S, int limit, 
     if (limit < 0) limit = -1;  // nothing can match a negative limit
     unsigned long long* d_edges;
     unsigned long long m;
+    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     SL_TRY(pair_edges(p, S, limit, 0, -1, &d_edges, &m, s));
+    ctx().counts["umi_pair_search_s"] = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
     return keys_from_edges(p, S, limit, d_single, d_edges, m, out, s);
 }
 
@@ -1175,8 +1266,14 @@ static int group_adjacency(const uint8_t* d_c1, const int64_t* d_o1, const uint8
                            int limit1, int limit2, DevAdj* adj, hipStream_t s) {
     SortedUmis S1;
     DirectedKeys K1;
+    auto now = [&] { (void)hipStreamSynchronize(s); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     SL_TRY(encode_and_rank("u1", d_c1, d_o1, d_members, d_gid, ngroups, n, &S1, s, d_single));
+    const double t1 = now();
     SL_TRY(neighbour_keys("u1", S1, limit1, d_single, &K1, s));
+    const double t2 = now();
+    ctx().counts["umi_encode_sort_s"] = t1 - t0;
+    ctx().counts["umi_search_and_key_sort_s"] = t2 - t1;
     if (!d_c2) return adjacency_from_keys("adj", K1.keys, K1.nk, S1.perm, n, adj, s);
 
     // membership set of UMI1 links keyed by original column id
@@ -1236,7 +1333,9 @@ static int cluster_dev(const DevAdj& adj, int n, const int32_t* d_members, const
     const int big = std::numeric_limits<int>::max();
     const int init[3] = {big, big, big};
     SL_HIP(hipMemcpyAsync(S.err, init, sizeof init, hipMemcpyHostToDevice, s));
-    const dim3 g(nblk(n, 256)), b(256);
+    const dim3 g(nblk(n, 256)), b(256), gw(nblk(n, 4));
+    // one wavefront per node from 24 links per node on average (one thread per node below that)
+    const bool dense = adj.nnz >= 24LL * n;
     hipLaunchKernelGGL(k_cl_init, g, b, 0, s, S, check_sym ? 1 : 0);
     int herr[3];
     SL_HIP(hipMemcpyAsync(herr, S.err, sizeof herr, hipMemcpyDeviceToHost, s));
@@ -1256,10 +1355,17 @@ static int cluster_dev(const DevAdj& adj, int n, const int32_t* d_members, const
         SL_HIP(hipMemcpyAsync(&live, S.live, sizeof live, hipMemcpyDeviceToHost, s));
         SL_HIP(hipStreamSynchronize(s));
         if (live == 0) break;
-        hipLaunchKernelGGL(k_cl_m1, g, b, 0, s, S);
-        hipLaunchKernelGGL(k_cl_pick, g, b, 0, s, S, round);
-        hipLaunchKernelGGL(k_cl_commit, g, b, 0, s, S, round);
-        hipLaunchKernelGGL(k_cl_decrement, g, b, 0, s, S, round);
+        if (dense) {
+            hipLaunchKernelGGL(k_cl_m1_w, gw, b, 0, s, S);
+            hipLaunchKernelGGL(k_cl_pick_w, gw, b, 0, s, S, round);
+            hipLaunchKernelGGL(k_cl_commit, g, b, 0, s, S, round);
+            hipLaunchKernelGGL(k_cl_decrement_w, gw, b, 0, s, S, round);
+        } else {
+            hipLaunchKernelGGL(k_cl_m1, g, b, 0, s, S);
+            hipLaunchKernelGGL(k_cl_pick, g, b, 0, s, S, round);
+            hipLaunchKernelGGL(k_cl_commit, g, b, 0, s, S, round);
+            hipLaunchKernelGGL(k_cl_decrement, g, b, 0, s, S, round);
+        }
         SL_HIP(hipGetLastError());
         if (round > 4 * n + 16) return fail("sarlacc_amd: clustering did not converge");
         ctx().counts["umi_cluster_rounds"] = round + 1;

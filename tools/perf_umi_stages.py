@@ -17,6 +17,7 @@ for thr in thrs:
         t0 = time.perf_counter()
         coff, cmem = calls.umi_group_flat(ss, thr, None, thr, goff, gflat)
         dt = time.perf_counter() - t0
-        print("thr=%d n=%d flat call %.3f s | pair kernel %.1f ms | adjacency %.3f s (links %.3g) | clustering %.3f s in %d rounds | clusters %d" % (
+        print("thr=%d n=%d flat call %.3f s | pair kernel %.1f ms | adjacency %.3f s (links %.3g) | clustering %.3f s in %d rounds | clusters %d | encode+sort %.3f s, search+key sort %.3f s (pair search %.3f s in %d attempt(s))" % (
             thr, len(ss), dt, _lib.stage_ms("umi_pairs"), _lib.stage_count("umi_adjacency_s"), _lib.stage_count("umi_links"),
-            _lib.stage_count("umi_cluster_s"), int(_lib.stage_count("umi_cluster_rounds")), coff.size - 1), flush=True)
+            _lib.stage_count("umi_cluster_s"), int(_lib.stage_count("umi_cluster_rounds")), coff.size - 1, _lib.stage_count("umi_encode_sort_s"),
+            _lib.stage_count("umi_search_and_key_sort_s"), _lib.stage_count("umi_pair_search_s"), int(_lib.stage_count("umi_pair_attempts"))), flush=True)
