@@ -32,6 +32,7 @@
 // kernels per join for all groups of a batch and spent most of the stage with a few long wavefronts on the chip).
 // A row keeps the first M2_CAP distinct partner columns (spec v2, step 5); groups whose profiles outgrow the
 // fast capacity are redone with profiles as wide as the sum of the read lengths.
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 
@@ -41,6 +42,7 @@
 
 #include <algorithm>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 namespace sarlacc {
@@ -1096,6 +1098,13 @@ __global__ void k_m2_write(M2Args A, const int* member_group, int nmembers, cons
 static int msa_spec() { return option(OPT_MSA_SPEC) == 1 ? 1 : 2; }
 
 static inline unsigned m2_blocks(long long n, int bs) { return static_cast<unsigned>((n + bs - 1) / bs); }
+static inline double m2_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// host seconds of the MSA stage outside its kernels, by part (sarlacc_stage_count "msa_host_<part>_s")
+static void m2_host_time(const char* part, double t0) {
+    std::map<std::string, double>& cn = ctx().counts;
+    const std::string k = std::string("msa_host_") + part + "_s";
+    cn[k] = (cn.count(k) ? cn[k] : 0.0) + (m2_now() - t0);
+}
 
 // One batch of groups (`ids`: indices into the caller's group list) through the v2 kernels.
 // exact_w = false: fast profile capacity (3 maxlen + 64 columns); groups that outgrow it come back flagged.
@@ -1114,18 +1123,22 @@ struct M2Batch {
     int* d_member_group = nullptr;
     int max_len = 0, max_wcap = 0, max_n = 0;
     long long tab_n = 0;
+    MsaJobSummary jsum;           // band classes and cell count of `jobs`
 };
 
-static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const int64_t* rel, bool exact_w) {
-    long long map_pos = 0, col_pos = 0, pos_pos = 0, dist_pos = 0, tab_pos = 0;
-    B.groups.clear(); B.members.clear(); B.member_group.clear(); B.jobs.clear();
+// Host tables of a batch: groups, members, the pairwise jobs (4.4 million at C4).  The offsets come from one serial pass
+// over the groups; members and jobs are then filled by a few threads over disjoint ranges of groups.
+static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const int64_t* rel, bool exact_w, int bandwidth) {
+    const size_t ngr = B.ids.size();
+    B.groups.assign(ngr, M2Group{});
     B.max_len = 0; B.max_wcap = 0; B.max_n = 0;
-    for (size_t q = 0; q < B.ids.size(); ++q) {
+    long long map_pos = 0, col_pos = 0, pos_pos = 0, dist_pos = 0, tab_pos = 0, mem_pos = 0, job_pos = 0;
+    for (size_t q = 0; q < ngr; ++q) {
         const int64_t g = B.ids[q];
         const int32_t* mem = grp + grp_off[g];
         const int n = static_cast<int>(grp_off[g + 1] - grp_off[g]);
-        M2Group G{};
-        G.first_member = static_cast<int>(B.members.size());
+        M2Group& G = B.groups[q];
+        G.first_member = static_cast<int>(mem_pos);
         G.n = n;
         long long sum = 0;
         int mx = 0;
@@ -1140,7 +1153,7 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
         G.wcap = static_cast<int>(std::min<long long>(65535, std::min<long long>(sum, exact_w ? sum : fast_w)));
         if (G.wcap < 1) G.wcap = 1;
         G.pos_base = pos_pos;
-        G.first_job = static_cast<long long>(B.jobs.size());
+        G.first_job = job_pos;
         G.dist_base = dist_pos;
         G.tab_base = tab_pos;
         G.map0 = map_pos;
@@ -1148,35 +1161,67 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
         pos_pos += static_cast<long long>(n) * G.wcap;
         dist_pos += static_cast<long long>(n) * n + n;
         tab_pos += m2_tab_entries(n);
-        for (int a = 0; a < n; ++a) {
-            M2Member Me{};
-            Me.seq_off = rel[mem[a] - 1];
-            Me.len = static_cast<int>(rel[mem[a]] - rel[mem[a] - 1]);
-            Me.map_base = map_pos;
-            Me.col_base = col_pos;
-            map_pos += static_cast<long long>(std::max(0, n - 1)) * Me.len;
-            col_pos += Me.len;
-            B.members.push_back(Me);
-            B.member_group.push_back(static_cast<int>(q));
-        }
-        if (n >= 2)
-            for (int a = 0; a < n; ++a)
-                for (int b = a + 1; b < n; ++b) {
-                    const M2Member& Ma = B.members[G.first_member + a];
-                    const M2Member& Mb = B.members[G.first_member + b];
-                    MsaJob J{};
-                    J.read_off = Mb.seq_off; J.ctr_off = Ma.seq_off;   // rows = b, columns = a
-                    J.lr = Mb.len; J.lc = Ma.len;
-                    J.out_off = Ma.map_base + static_cast<long long>(b - 1) * Ma.len;    // b among the others of a
-                    J.out2_off = Mb.map_base + static_cast<long long>(a) * Mb.len;       // a among the others of b
-                    B.jobs.push_back(J);
-                }
+        map_pos += static_cast<long long>(std::max(0, n - 1)) * sum;
+        col_pos += sum;
+        mem_pos += n;
+        job_pos += static_cast<long long>(n) * (n - 1) / 2;
         B.max_len = std::max(B.max_len, mx);
         B.max_wcap = std::max(B.max_wcap, G.wcap);
         B.max_n = std::max(B.max_n, n);
-        B.groups.push_back(G);
     }
     B.tab_n = tab_pos;
+    B.members.assign(static_cast<size_t>(mem_pos), M2Member{});
+    B.member_group.assign(static_cast<size_t>(mem_pos), 0);
+    B.jobs.assign(static_cast<size_t>(job_pos), MsaJob{});
+    auto fill = [&](size_t q0, size_t q1, MsaJobSummary* sum) {
+        for (size_t q = q0; q < q1; ++q) {
+            const M2Group& G = B.groups[q];
+            const int32_t* mem = grp + grp_off[B.ids[q]];
+            const int n = G.n;
+            M2Member* const M = B.members.data() + G.first_member;
+            long long mp = G.map0, cp = G.col0;
+            for (int a = 0; a < n; ++a) {
+                M2Member& Me = M[a];
+                Me.seq_off = rel[mem[a] - 1];
+                Me.len = static_cast<int>(rel[mem[a]] - rel[mem[a] - 1]);
+                Me.map_base = mp;
+                Me.col_base = cp;
+                mp += static_cast<long long>(std::max(0, n - 1)) * Me.len;
+                cp += Me.len;
+                B.member_group[static_cast<size_t>(G.first_member) + a] = static_cast<int>(q);
+            }
+            MsaJob* J = B.jobs.data() + G.first_job;
+            for (int a = 0; a < n; ++a)
+                for (int b = a + 1; b < n; ++b, ++J) {
+                    const M2Member& Ma = M[a];
+                    const M2Member& Mb = M[b];
+                    J->read_off = Mb.seq_off; J->ctr_off = Ma.seq_off;   // rows = b, columns = a
+                    J->lr = Mb.len; J->lc = Ma.len;
+                    J->out_off = Ma.map_base + static_cast<long long>(b - 1) * Ma.len;    // b among the others of a
+                    J->out2_off = Mb.map_base + static_cast<long long>(a) * Mb.len;       // a among the others of b
+                    sum->add(bandwidth, J->lr, J->lc);
+                }
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nthreads = job_pos < 200000 ? 1 : std::max<size_t>(1, std::min<size_t>(hw ? hw : 1, 8));
+    B.jsum = MsaJobSummary{};
+    if (nthreads == 1) fill(0, ngr, &B.jsum);
+    else {
+        // ranges of groups with about the same number of jobs each
+        std::vector<std::thread> pool;
+        std::vector<MsaJobSummary> part(nthreads);
+        size_t q0 = 0;
+        for (size_t t = 0; t < nthreads; ++t) {
+            const long long want = job_pos * static_cast<long long>(t + 1) / static_cast<long long>(nthreads);
+            size_t q1 = q0;
+            while (q1 < ngr && (t + 1 == nthreads || B.groups[q1].first_job + static_cast<long long>(B.groups[q1].n) * (B.groups[q1].n - 1) / 2 <= want)) ++q1;
+            pool.emplace_back(fill, q0, q1, &part[t]);
+            q0 = q1;
+        }
+        for (std::thread& th : pool) th.join();
+        for (const MsaJobSummary& ps : part) B.jsum.merge(ps);
+    }
     return 0;
 }
 
@@ -1220,6 +1265,7 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     M2Args& a = B.a;
     a = M2Args{};
     M2Group* d_groups; M2Member* d_members; MsaJob* d_jobs; int* d_mg;
+    double th = m2_now();
     SL_TRY(upload((pf + ".groups").c_str(), B.groups.data(), ng, &d_groups, s));
     SL_TRY(upload((pf + ".members").c_str(), B.members.data(), nm, &d_members, s));
     SL_TRY(upload((pf + ".mg").c_str(), B.member_group.data(), nm, &d_mg, s));
@@ -1241,12 +1287,15 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     a.map = d_map; a.stats = d_stats; a.dist = d_dist; a.joins = d_joins; a.join_tab = d_jtab;
     a.col = d_col; a.pos = d_pos; a.ovf = d_ovf; a.width = d_width;
 
+    m2_host_time("upload_alloc", th);
     // ---- all pairs ----
-    for (const MsaJob& J : B.jobs) *cells += static_cast<double>(J.lr) * msa_pair_band(bandwidth, J.lr, J.lc);
+    th = m2_now();
+    *cells += B.jsum.cells;
     SL_TRY(c.stage_begin("msa_pairwise", s));
     SL_TRY(msa_pairwise_launch(B.jobs, d_jobs, d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, 1, nullptr, nullptr,
-                               d_map, d_stats, s));
+                               d_map, d_stats, s, &B.jsum));
     SL_TRY(c.stage_end("msa_pairwise", s));
+    m2_host_time("pairwise_launch", th);
     if (overlap) SL_TRY((*overlap)());
     // ---- guide trees, leaves, candidate tables ----
     SL_TRY(c.stage_begin("msa_merge", s));
@@ -1448,10 +1497,13 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
                 B.slot.push_back(todo[q1]);
                 ++q1;
             }
-            SL_TRY(m2_plan(B, grp_off, grp, rel.data(), exact_w));
+            double th = m2_now();
+            SL_TRY(m2_plan(B, grp_off, grp, rel.data(), exact_w, bandwidth));
+            m2_host_time("plan", th);
             SL_TRY(m2_run_batch(B, "m2", d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, first ? overlap : nullptr, &cells, counters, s));
             first = false;
             pairs += static_cast<double>(B.jobs.size());
+            th = m2_now();
             long long need = used;
             std::vector<long long> boff(B.groups.size(), 0);
             std::vector<int32_t> bw = B.width;
@@ -1473,6 +1525,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             if (code.want && code.ready && !waited) { SL_HIP(hipStreamWaitEvent(s, code.ready, 0)); waited = true; }   // qualities in HBM
             SL_TRY(m2_write_batch(B, "m2", boff, rows_ws.ptr, code, s));
             SL_HIP(hipStreamSynchronize(s));   // the batch's host vectors and workspaces are reused by the next one
+            m2_host_time("rows", th);
             used = need;
             q0 = q1;
         }
@@ -1547,6 +1600,10 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     hipStream_t s = nullptr;
     c.stage_reset("msa_pairwise");
     c.stage_reset("msa_merge");
+    for (const char* nm : {"msa_host_plan_s", "msa_host_upload_alloc_s", "msa_host_pairwise_launch_s", "msa_host_rows_s", "msa_host_select_s",
+                           "msa_host_total_s"})
+        c.counts[nm] = 0;
+    const double t_run = m2_now();
     for (const char* nm : {"msa_pairs", "msa_cells", "msa2_rows", "msa2_rows_capped", "msa2_entries_filtered", "msa2_rows_filtered",
                            "msa2_entries_kept", "msa2_joins", "msa2_joins_chain_in_hbm", "msa2_cycles_rows", "msa2_cycles_chain",
                            "msa2_cycles_walk", "msa2_cycles_renumber", "msa2_launches", "msa2_first_exit_s", "msa2_last_exit_s",
@@ -1624,6 +1681,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     SL_HIP(hipStreamSynchronize(s));
     if (res->code.want) res->d_codes = reinterpret_cast<uint16_t*>(d_final);
     else res->d_out = d_final;
+    m2_host_time("total", t_run);
     return 0;
 }
 

@@ -50,11 +50,38 @@ __host__ __device__ __forceinline__ int msa_pair_band(int bandwidth, int lr, int
     return bw < 0 ? 1 : (lc > lr ? lc - lr : lr - lc) + 2 * bw + 1;
 }
 
+// What the launcher needs to know about a job list (band classes: up to 256 / 512 / 1024 diagonals); a caller that builds
+// the list with several threads fills it on the way (msa2.hip), otherwise the launcher walks the list itself.
+struct MsaJobSummary {
+    size_t n[3] = {0, 0, 0};
+    int lr[3] = {0, 0, 0}, lc[3] = {0, 0, 0}, band[3] = {1, 1, 1};
+    double cells = 0;   // rows x diagonals over all jobs
+    void add(int bandwidth, int jlr, int jlc) {
+        const int b = msa_pair_band(bandwidth, jlr, jlc);   // capped at MSA_MAXBAND by the spec
+        const int cls = b <= 256 ? 0 : (b <= 512 ? 1 : 2);
+        ++n[cls];
+        lr[cls] = jlr > lr[cls] ? jlr : lr[cls];
+        lc[cls] = jlc > lc[cls] ? jlc : lc[cls];
+        band[cls] = b > band[cls] ? b : band[cls];
+        cells += static_cast<double>(jlr) * b;
+    }
+    void merge(const MsaJobSummary& o) {
+        for (int k = 0; k < 3; ++k) {
+            n[k] += o.n[k];
+            lr[k] = o.lr[k] > lr[k] ? o.lr[k] : lr[k];
+            lc[k] = o.lc[k] > lc[k] ? o.lc[k] : lc[k];
+            band[k] = o.band[k] > band[k] ? o.band[k] : band[k];
+        }
+        cells += o.cells;
+    }
+};
+
 // Launches the pairwise kernels for `jobs` (host copy, for sizing and band classes; d_jobs the same on
 // the device) on stream s.  out_mode 0: ins/aln (spec v1), 1: maps + stats (spec v2).
 int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, const uint8_t* d_seq,
                         double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
-                        int out_mode, uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats, hipStream_t s);
+                        int out_mode, uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats, hipStream_t s,
+                        const MsaJobSummary* summary = nullptr);
 
 __device__ __forceinline__ uint8_t dna5_code(uint8_t c) {
     switch (c) {

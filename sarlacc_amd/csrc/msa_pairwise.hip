@@ -751,20 +751,27 @@ static int launch_class(bool packed, int C, const MsaArgs& a, int grid, size_t l
 
 int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, const uint8_t* d_seq, double match,
                         double mismatch, double gap_extension, double gap_opening, int bandwidth, int out_mode,
-                        uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats, hipStream_t s) {
+                        uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats, hipStream_t s, const MsaJobSummary* summary) {
     if (jobs.empty()) return 0;
     Context& c = ctx();
     // jobs by band class: 4, 8 or 16 diagonals per lane (bands up to 256 / 512 / 1024); one launch per
     // class, so the common narrow bands are not dragged to the widest job's shape
     std::vector<int> order[3];
-    int cls_lr[3] = {0, 0, 0}, cls_lc[3] = {0, 0, 0}, cls_band[3] = {1, 1, 1};
-    for (size_t q = 0; q < jobs.size(); ++q) {
-        const int band = msa_pair_band(bandwidth, jobs[q].lr, jobs[q].lc);   // capped at MSA_MAXBAND by the spec
-        const int cls = band <= 256 ? 0 : (band <= 512 ? 1 : 2);
-        order[cls].push_back(static_cast<int>(q));
-        cls_lr[cls] = std::max(cls_lr[cls], jobs[q].lr);
-        cls_lc[cls] = std::max(cls_lc[cls], jobs[q].lc);
-        cls_band[cls] = std::max(cls_band[cls], band);
+    MsaJobSummary own;
+    if (!summary) {
+        for (size_t q = 0; q < jobs.size(); ++q) own.add(bandwidth, jobs[q].lr, jobs[q].lc);
+        summary = &own;
+    }
+    const size_t* cls_n = summary->n;
+    const int *cls_lr = summary->lr, *cls_lc = summary->lc, *cls_band = summary->band;
+    // the usual case -- every pair in one class -- needs no index list: the launch takes the jobs as they are
+    const bool one_class = cls_n[0] == jobs.size() || cls_n[1] == jobs.size() || cls_n[2] == jobs.size();
+    if (!one_class) {
+        for (int k = 0; k < 3; ++k) order[k].reserve(cls_n[k]);
+        for (size_t q = 0; q < jobs.size(); ++q) {
+            const int band = msa_pair_band(bandwidth, jobs[q].lr, jobs[q].lc);
+            order[band <= 256 ? 0 : (band <= 512 ? 1 : 2)].push_back(static_cast<int>(q));
+        }
     }
     MsaArgs a{};
     a.seq = d_seq; a.jobs = d_jobs;
@@ -779,7 +786,7 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
     int mmc = 0, goc = 0, gec = 0;
     const bool domain_ok = cost_domain(ma, mm, go, ge, &mmc, &goc, &gec) && !option(OPT_MSA_INT32);
     for (int cls = 0; cls < 3; ++cls) {
-        if (order[cls].empty()) continue;
+        if (cls_n[cls] == 0) continue;
         const int C = 4 << cls;
         const bool packed = domain_ok && pk_range_ok(mmc, goc, gec, cls_band[cls]);
         if (packed) { a.ma = 0; a.mm = mmc; a.go = goc; a.ge = gec; }
@@ -794,15 +801,15 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
         if (lds > 160 * 1024) return fail("sarlacc_amd: reads of %d bases do not fit the MSA kernel's LDS staging", std::max(cls_lr[cls], cls_lc[cls]));
         // many more single-wave workgroups than fit at once (a wave then aligns only a few pairs and the
         // hardware balances the load); their traceback tiles are the price, capped at 24 GB of HBM
-        long long grid = std::min<long long>(static_cast<long long>(order[cls].size()), static_cast<long long>(c.num_cu) * 128);
+        long long grid = std::min<long long>(static_cast<long long>(cls_n[cls]), static_cast<long long>(c.num_cu) * 128);
         const size_t budget = static_cast<size_t>(24) << 30;
         grid = std::min<long long>(grid, std::max<long long>(1, static_cast<long long>(budget / (per_wave * word))));
-        void* d_tb; int* d_order;
+        void* d_tb; int* d_order = nullptr;
         const char* tb_name[3] = {"msa.tb0", "msa.tb1", "msa.tb2"};
         const char* ord_name[3] = {"msa.ord0", "msa.ord1", "msa.ord2"};
         SL_TRY(c.buffer(tb_name[cls], static_cast<size_t>(grid) * per_wave * word, &d_tb));
-        SL_TRY(upload(ord_name[cls], order[cls].data(), order[cls].size(), &d_order, s));
-        a.order = d_order; a.njobs = static_cast<int>(order[cls].size());
+        if (!one_class) SL_TRY(upload(ord_name[cls], order[cls].data(), order[cls].size(), &d_order, s));
+        a.order = d_order; a.njobs = static_cast<int>(cls_n[cls]);
         a.tb = d_tb; a.tb_per_wave = per_wave;
         if (out_mode == 0) SL_TRY(launch_class<0>(packed, C, a, static_cast<int>(grid), lds, s));
         else SL_TRY(launch_class<1>(packed, C, a, static_cast<int>(grid), lds, s));

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 import sarlacc_amd
-from sarlacc_amd import calls, devsynth, pipeline
+from sarlacc_amd import _lib, calls, devsynth, pipeline
 from sarlacc_amd.strset import StringSet
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
@@ -47,6 +47,7 @@ for rep in range(reps):
         rep, spec, dt, (off.size - 1) / dt * 60 / 1e6, {k: round(v, 1) for k, v in r["kernel_ms"].items()}, sizes.size,
         sizes.max(), int((sizes > 10).sum()), int(r["counts"]["msa_v1_fallback"])), flush=True)
     print("      stage s %s" % {k: round(v, 4) for k, v in r["stage_s"].items()}, flush=True)
+    print("      msa host s %s" % {k: round(_lib.stage_count("msa_host_%s_s" % k), 4) for k in ("plan", "upload_alloc", "pairwise_launch", "rows", "total")}, flush=True)
     if rep == 0:
         h = np.bincount(sizes)
         print("      group sizes: %s" % {int(k): int(v) for k, v in enumerate(h) if v}, flush=True)

@@ -27,7 +27,7 @@ rocprofv3 --output-format csv --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_
     -d "$OUT/pmc_sq2" -o pmc -- $BENCH > "$OUT/pmc_sq2.log" 2>&1 || echo "sq2 pass failed (counter names?)"
 echo "sq2 done"
 cd - > /dev/null
-for K in k_align k_msa_pairwise k_consensus_code; do
+for K in k_align k_msa_pairwise k_consensus_code k_m2_group; do
     python3 tools/pmc_summary.py "$OUT" $K > "$OUT/pmc_$K.json"
 done
 cat "$OUT"/pmc_k_*.json
