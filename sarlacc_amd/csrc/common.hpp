@@ -43,6 +43,7 @@ enum Opt {
     OPT_MSA2_CHAIN_HBM,       // spec v2: the chain's prefix maxima in HBM from the start (the fallback of the LDS ring)
     OPT_MSA2_WAVES_PER_CU,    // spec v2: resident wavefronts of the merge kernel per CU (perf sweeps)
     OPT_MSA2_SINGLE_WAVE,     // spec v2: one wavefront per group whatever its size (A/B of the 4- and 8-wavefront workgroups)
+    OPT_MSA2_BATCHES,         // spec v2: number of pipelined batches of a call (default: as few as memory allows)
     OPT_ALIGN_PENSEL,         // quality DP: the instantiation with explicit penalty selects also for gapopen >= 0
     OPT_ALIGN_CHUNKS,         // host-pointer DP: number of upload chunks
     OPT_ALIGN_K,              // quality DP: reference columns per lane (perf sweeps)

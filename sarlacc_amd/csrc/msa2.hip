@@ -1124,6 +1124,7 @@ struct M2Batch {
     int max_len = 0, max_wcap = 0, max_n = 0;
     long long tab_n = 0;
     MsaJobSummary jsum;           // band classes and cell count of `jobs`
+    hipEvent_t pair_done = nullptr;   // the all-pairs alignments of the batch have finished (m2_prepare -> m2_merge)
 };
 
 // Host tables of a batch: groups, members, the pairwise jobs (4.4 million at C4).  The offsets come from one serial pass
@@ -1231,16 +1232,20 @@ struct M2Streams {
     std::vector<hipStream_t> st;
     std::vector<hipEvent_t> join;
     hipEvent_t fork = nullptr;
+    hipEvent_t pair[2] = {nullptr, nullptr};   // "alignments of the batch in workspace set k are done"
     int device = -1;
     int ensure(int n) {
         if (device != ctx().device) {   // (streams and events belong to the device that was current when they were made)
             for (hipStream_t x : st) (void)hipStreamDestroy(x);
             for (hipEvent_t e : join) (void)hipEventDestroy(e);
             if (fork) (void)hipEventDestroy(fork);
+            for (int k = 0; k < 2; ++k) { if (pair[k]) (void)hipEventDestroy(pair[k]); pair[k] = nullptr; }
             st.clear(); join.clear(); fork = nullptr;
             device = ctx().device;
         }
         if (!fork) SL_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k)
+            if (!pair[k]) SL_HIP(hipEventCreateWithFlags(&pair[k], hipEventDisableTiming));
         while (static_cast<int>(st.size()) < n) {
             hipStream_t x; hipEvent_t e;
             SL_HIP(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
@@ -1252,9 +1257,11 @@ struct M2Streams {
 };
 static M2Streams& m2_streams() { static M2Streams m; return m; }
 
-static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq, double match, double mismatch, double gap_extension,
-                        double gap_opening, int bandwidth, const std::function<int()>* overlap, double* cells, double* counters,
-                        hipStream_t s) {
+// First half of a batch: tables to the device, workspaces, the all-pairs alignments -- on stream `sp`, which runs ahead of
+// the merging: while the wavefronts of k_m2_group wait for memory (most of their time) the alignments of the NEXT batch
+// keep the vector units busy.  `B.pair_done` fires when the batch's library is complete.
+static int m2_prepare(M2Batch& B, const std::string& pf, const uint8_t* d_seq, double match, double mismatch, double gap_extension,
+                      double gap_opening, int bandwidth, double* cells, bool first_of_call, hipStream_t s) {
     Context& c = ctx();
     const size_t ng = B.groups.size(), nm = B.members.size();
     if (ng == 0) return 0;
@@ -1293,10 +1300,24 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     *cells += B.jsum.cells;
     SL_TRY(c.stage_begin("msa_pairwise", s));
     SL_TRY(msa_pairwise_launch(B.jobs, d_jobs, d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, 1, nullptr, nullptr,
-                               d_map, d_stats, s, &B.jsum));
+                               d_map, d_stats, s, &B.jsum, first_of_call));
     SL_TRY(c.stage_end("msa_pairwise", s));
     m2_host_time("pairwise_launch", th);
-    if (overlap) SL_TRY((*overlap)());
+    SL_HIP(hipEventRecord(B.pair_done, s));
+    return 0;
+}
+
+// Second half: guide trees, candidate tables, all the merging, widths back to the host -- on stream `s` (and the streams of
+// the side-by-side instantiations) once the batch's alignments are done.
+static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStream_t s) {
+    Context& c = ctx();
+    const size_t ng = B.groups.size(), nm = B.members.size();
+    if (ng == 0) return 0;
+    M2Args& a = B.a;
+    int* const d_mg = B.d_member_group;
+    int32_t* const d_width = a.width;
+    int* const d_ovf = a.ovf;
+    SL_HIP(hipStreamWaitEvent(s, B.pair_done, 0));
     // ---- guide trees, leaves, candidate tables ----
     SL_TRY(c.stage_begin("msa_merge", s));
     hipLaunchKernelGGL(k_m2_tree, dim3(m2_blocks(static_cast<long long>(ng), 64)), dim3(64), 0, s, a);
@@ -1358,7 +1379,7 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
             long long wgs = std::min<long long>(static_cast<long long>(per_cu) * std::max(1, c.num_cu), static_cast<long long>(cls[k].hi - cls[k].lo));
             wgs = std::max<long long>(1, std::min(wgs, (16LL << 30) / per_wg));   // (scratch of the resident workgroups: at most 16 GB per instantiation)
             M2Args am = a;
-            const std::string q = pf + cls[k].tag;
+            const std::string q = std::string("m2w") + cls[k].tag;   // (shared by the batches: their merging runs one after the other)
             SL_TRY(scratch((q + ".w_ent").c_str(), static_cast<size_t>(wgs * w_rows * M2_CAP), &am.w_ent));
             SL_TRY(scratch((q + ".w_pred").c_str(), static_cast<size_t>(wgs * w_rows * M2_CAP), &am.w_pred));
             SL_TRY(scratch((q + ".w_part").c_str(), static_cast<size_t>(wgs * w_rows), &am.w_part));
@@ -1396,13 +1417,6 @@ static int m2_run_batch(M2Batch& B, const std::string& pf, const uint8_t* d_seq,
     }
     for (size_t q = 0; q < ng; ++q)
         if (B.ovf[q] > 1) return fail("sarlacc_amd: internal error: the chain search of an MSA join did not finish");
-    int stuck = 0;
-    if (!B.jobs.empty()) {
-        int* d_stuck;
-        SL_TRY(scratch("msa.stuck", 1, &d_stuck));
-        SL_HIP(hipMemcpy(&stuck, d_stuck, sizeof stuck, hipMemcpyDeviceToHost));
-        if (stuck) return fail("sarlacc_amd: internal error: an MSA traceback exceeded its step bound");
-    }
     return 0;
 }
 
@@ -1454,56 +1468,83 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         rows_ws.cap = want;
         return 0;
     };
-    // Batches: what a batch holds per group is the library (both maps of every pair: 4 (n - 1) bytes per base), the
-    // positions / columns of its profiles and, with unit weights, its candidate tables.  Sized for an HBM of 288 GB
-    // (C4, 10^5 groups x 10 reads x 2 kb, is one batch of about 60 GB), bounded by a share of what is free now.
+    // Batches.  What a batch holds per group is the library (both maps of every pair: 4 (n - 1) bytes per base), the positions /
+    // columns of its profiles and, with unit weights, its candidate tables -- about 60 GB for C4 (10^5 groups x 10 reads
+    // x 2 kb), sized for an HBM of 288 GB and bounded by a share of what is free now.  A large call is cut into a few
+    // batches that are PIPELINED: the all-pairs alignments of batch k + 1 (vector-unit bound) run on a stream of their
+    // own under the merging of batch k (memory-latency bound); two sets of workspaces alternate.
     size_t free_b = 0, total_b = 0;
     SL_HIP(hipMemGetInfo(&free_b, &total_b));
     long long reusable = 0;   // the workspaces of an earlier call are grown in place, not added
-    for (const char* nm : {"m2.map", "m2.pos", "m2.col", "m2.tab"}) { auto it = c.ws.find(nm); if (it != c.ws.end()) reusable += static_cast<long long>(it->second.cap); }
+    for (const char* pfx : {"m2a", "m2b"})
+        for (const char* nm : {".map", ".pos", ".col", ".tab"}) { auto it = c.ws.find(std::string(pfx) + nm); if (it != c.ws.end()) reusable += static_cast<long long>(it->second.cap); }
     const long long mem_budget = std::max<long long>(1LL << 30, std::min<long long>(96LL << 30, (static_cast<long long>(free_b) + reusable) / 2));
     const long long job_budget = 12000000;
     double cells = 0, pairs = 0;
     double counters[M2C_N] = {};
-    bool first = true;
     long long used = 0;
+    M2Streams& MS = m2_streams();
+    SL_TRY(MS.ensure(3));
+    hipStream_t sp = MS.st[2];
+    SL_HIP(hipEventRecord(MS.fork, s));          // whatever the caller queued on `s` (the reads) comes first
+    SL_HIP(hipStreamWaitEvent(sp, MS.fork, 0));
+    bool first = true;
     // Pass 0: every group with the fast profile capacity.  Pass 1: the groups whose profiles outgrew it (several
     // unrelated reads in one cluster), with profiles as wide as the sum of the read lengths.
     std::vector<size_t> todo(ids.size());
     std::iota(todo.begin(), todo.end(), size_t(0));
     for (int pass = 0; pass < 2 && !todo.empty(); ++pass) {
         const bool exact_w = pass == 1;
-        // processing order: by decreasing group size -- the wavefronts of k_m2_group take the groups in this order, the
+        // processing order: by decreasing group size -- the workgroups of k_m2_group take the groups in this order, the
         // longest first
         std::stable_sort(todo.begin(), todo.end(), [&](size_t x, size_t y) {
             return grp_off[ids[x] + 1] - grp_off[ids[x]] > grp_off[ids[y] + 1] - grp_off[ids[y]];
         });
         std::vector<size_t> again;
-        size_t q0 = 0;
-        while (q0 < todo.size()) {
-            M2Batch B;
-            long long mem_b = 0, jobs_b = 0;
-            size_t q1 = q0;
-            while (q1 < todo.size()) {
-                const int64_t g = ids[todo[q1]];
-                const long long n = grp_off[g + 1] - grp_off[g];
-                long long sum = 0, mx = 0;
-                for (long long a = 0; a < n; ++a) { const long long len = rel[grp[grp_off[g] + a]] - rel[grp[grp_off[g] + a] - 1]; sum += len; mx = std::max(mx, len); }
-                const long long wc = exact_w ? sum : std::min(sum, static_cast<long long>(M2_FASTW(mx)));
-                const long long mb = 2 * (n - 1) * sum + 2 * n * wc + 4 * sum + 16 * m2_tab_entries(static_cast<int>(n)), jb = n * (n - 1) / 2;
-                if (q1 > q0 && (mem_b + mb > mem_budget || jobs_b + jb > job_budget)) break;
-                mem_b += mb; jobs_b += jb;
-                B.ids.push_back(g);
-                B.slot.push_back(todo[q1]);
-                ++q1;
-            }
+        long long mem_all = 0, jobs_all = 0;
+        for (size_t q : todo) {
+            const int64_t g = ids[q];
+            const long long n = grp_off[g + 1] - grp_off[g];
+            long long sum = 0, mx = 0;
+            for (long long a = 0; a < n; ++a) { const long long len = rel[grp[grp_off[g] + a]] - rel[grp[grp_off[g] + a] - 1]; sum += len; mx = std::max(mx, len); }
+            const long long wc = exact_w ? sum : std::min(sum, static_cast<long long>(M2_FASTW(mx)));
+            mem_all += 2 * (n - 1) * sum + 2 * n * wc + 4 * sum + 16 * m2_tab_entries(static_cast<int>(n));
+            jobs_all += n * (n - 1) / 2;
+        }
+        // batches: as many as memory and the job list demand, a few more for the overlap once there is enough work; every
+        // batch gets every nb-th group of the sorted list, so all of them hold the same mix of sizes
+        // (one batch when everything fits -- then the stage timers do not overlap either; from two on the two workspace
+        // sets share the budget.  Measured at C4 with two pipelined batches: pure groups 5 % faster end to end, clusters
+        // of several molecules unchanged -- the alignments saturate the vector units by themselves.)
+        long long nb = std::max<long long>(1, std::max((mem_all + mem_budget - 1) / mem_budget, (jobs_all + job_budget - 1) / job_budget));
+        const long long want = option(OPT_MSA2_BATCHES) > 0 ? option(OPT_MSA2_BATCHES) : 1;
+        if (std::max(nb, want) > 1) nb = std::max<long long>(want, std::max((2 * mem_all + mem_budget - 1) / mem_budget, (jobs_all + job_budget - 1) / job_budget));
+        nb = std::min<long long>(nb, static_cast<long long>(todo.size()));
+        std::vector<M2Batch> batches(static_cast<size_t>(nb));
+        for (size_t q = 0; q < todo.size(); ++q) {
+            M2Batch& B = batches[q % static_cast<size_t>(nb)];
+            B.ids.push_back(ids[todo[q]]);
+            B.slot.push_back(todo[q]);
+        }
+        const char* const pfs[2] = {"m2a", "m2b"};
+        auto prepare = [&](size_t k) -> int {
+            M2Batch& B = batches[k];
             double th = m2_now();
             SL_TRY(m2_plan(B, grp_off, grp, rel.data(), exact_w, bandwidth));
             m2_host_time("plan", th);
-            SL_TRY(m2_run_batch(B, "m2", d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, first ? overlap : nullptr, &cells, counters, s));
-            first = false;
+            B.pair_done = MS.pair[k & 1];
+            SL_TRY(m2_prepare(B, pfs[k & 1], d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, &cells, first, sp));
             pairs += static_cast<double>(B.jobs.size());
-            th = m2_now();
+            if (first && overlap) SL_TRY((*overlap)());
+            first = false;
+            return 0;
+        };
+        SL_TRY(prepare(0));
+        for (size_t k = 0; k < batches.size(); ++k) {
+            M2Batch& B = batches[k];
+            if (k + 1 < batches.size()) SL_TRY(prepare(k + 1));   // (its workspaces: those of batch k - 1, finished and read back)
+            SL_TRY(m2_merge(B, pfs[k & 1], counters, s));
+            double th = m2_now();
             long long need = used;
             std::vector<long long> boff(B.groups.size(), 0);
             std::vector<int32_t> bw = B.width;
@@ -1523,13 +1564,22 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             SL_HIP(hipMemcpyAsync(B.a.width, bw.data(), sizeof(int32_t) * bw.size(), hipMemcpyHostToDevice, s));
             B.width = bw;
             if (code.want && code.ready && !waited) { SL_HIP(hipStreamWaitEvent(s, code.ready, 0)); waited = true; }   // qualities in HBM
-            SL_TRY(m2_write_batch(B, "m2", boff, rows_ws.ptr, code, s));
-            SL_HIP(hipStreamSynchronize(s));   // the batch's host vectors and workspaces are reused by the next one
+            SL_TRY(m2_write_batch(B, pfs[k & 1], boff, rows_ws.ptr, code, s));
+            SL_HIP(hipStreamSynchronize(s));   // the batch's host vectors and workspaces are reused by the batch after the next
             m2_host_time("rows", th);
             used = need;
-            q0 = q1;
+            // (the host tables of the batch are not needed any more)
+            std::vector<MsaJob>().swap(B.jobs);
         }
         todo.swap(again);
+    }
+    SL_HIP(hipStreamSynchronize(sp));
+    if (pairs > 0) {
+        int* d_stuck;
+        int stuck = 0;
+        SL_TRY(scratch("msa.stuck", 1, &d_stuck));
+        SL_HIP(hipMemcpy(&stuck, d_stuck, sizeof stuck, hipMemcpyDeviceToHost));
+        if (stuck) return fail("sarlacc_amd: internal error: an MSA traceback exceeded its step bound");
     }
     auto add = [&](const char* name, double v) { c.counts[name] = (c.counts.count(name) ? c.counts[name] : 0.0) + v; };
     add("msa_pairs", pairs);

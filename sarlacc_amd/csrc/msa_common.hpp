@@ -81,7 +81,9 @@ struct MsaJobSummary {
 int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, const uint8_t* d_seq,
                         double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
                         int out_mode, uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats, hipStream_t s,
-                        const MsaJobSummary* summary = nullptr);
+                        const MsaJobSummary* summary = nullptr, bool reset_stuck = true);
+// (reset_stuck = false: the "traceback exceeded its step bound" flag of earlier launches of the same call is kept, the
+// caller reads it once at the end -- pipelined batches, msa2.hip)
 
 __device__ __forceinline__ uint8_t dna5_code(uint8_t c) {
     switch (c) {

@@ -751,7 +751,7 @@ static int launch_class(bool packed, int C, const MsaArgs& a, int grid, size_t l
 
 int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, const uint8_t* d_seq, double match,
                         double mismatch, double gap_extension, double gap_opening, int bandwidth, int out_mode,
-                        uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats, hipStream_t s, const MsaJobSummary* summary) {
+                        uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats, hipStream_t s, const MsaJobSummary* summary, bool reset_stuck) {
     if (jobs.empty()) return 0;
     Context& c = ctx();
     // jobs by band class: 4, 8 or 16 diagonals per lane (bands up to 256 / 512 / 1024); one launch per
@@ -781,7 +781,7 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
     a.bw = bandwidth; a.ins = d_ins; a.aln = d_aln; a.map = d_map; a.stats = d_stats;
     int* d_stuck;
     SL_TRY(scratch("msa.stuck", 1, &d_stuck));
-    SL_HIP(hipMemsetAsync(d_stuck, 0, sizeof(int), s));
+    if (reset_stuck) SL_HIP(hipMemsetAsync(d_stuck, 0, sizeof(int), s));
     a.stuck = d_stuck;
     int mmc = 0, goc = 0, gec = 0;
     const bool domain_ok = cost_domain(ma, mm, go, ge, &mmc, &goc, &gec) && !option(OPT_MSA_INT32);
