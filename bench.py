@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--molecules", type=int, default=100_000, help="molecules per GPU (pipeline workload, x --copies reads)")
     ap.add_argument("--copies", type=int, default=10)
     ap.add_argument("--threshold", type=int, default=1, help="umiGroup threshold of the pipeline workload")
-    ap.add_argument("--cpu-sample", type=int, default=3000, help="reads per host core in the CPU baseline")
+    ap.add_argument("--cpu-sample", type=int, default=12000, help="reads per host core in the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
     ap.add_argument("--no-host-pointer", action="store_true", help="skip the PCIe-inclusive host-pointer figures")
@@ -497,7 +497,7 @@ def main():
             cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
             h_seq, h_qual = mol["seq"].cpu().numpy(), mol["qual"].cpu().numpy()
             sizes = np.diff(last["goff"])
-            pick = np.linspace(0, sizes.size - 1, num=min(2 * cores, sizes.size)).astype(np.int64)
+            pick = np.linspace(0, sizes.size - 1, num=min(12 * cores, sizes.size)).astype(np.int64)
             ids = sorted({int(i) for k in pick for i in last["gflat"][last["goff"][k]:last["goff"][k + 1]]})
             renum = {r: j + 1 for j, r in enumerate(ids)}
             rs = [h_seq[off_host[r - 1]:off_host[r]].tobytes().decode() for r in ids]

@@ -83,8 +83,12 @@ def main():
     # requests as 64 bytes, so reads are doubled; WRITE_SIZE is taken as reported
     fe, wr = res["FETCH_SIZE_KB_per_launch"], res["WRITE_SIZE_KB_per_launch"]
     if fe and wr:
-        res["traffic_bytes_per_launch"] = (2.0 * sum(fe) / len(fe) + sum(wr) / len(wr)) * 1024.0
-        res["traffic_correction"] = "2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports half the bytes read)"
+        # the full-size launches only (a bench run also launches the kernel on remainders: groups redone with wider profiles ...)
+        big_f = [x for x in fe if x >= 0.5 * max(fe)]
+        big_w = [x for x in wr if x >= 0.5 * max(wr)]
+        res["traffic_bytes_per_launch"] = (2.0 * sum(big_f) / len(big_f) + sum(big_w) / len(big_w)) * 1024.0
+        res["traffic_correction"] = ("2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports half the bytes read), mean over the "
+                                     "launches within a factor 2 of the largest (%d of %d)" % (len(big_f), len(fe)))
     sq = {}
     for sub, names in (("pmc_sq", ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
                                    "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")),
