@@ -425,6 +425,7 @@ __device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, c
     const int lane = m2_lane();
     const int n = J.n, fm = J.fm, nA = J.nA;
     const int nbm = __popc(J.maskB);
+    const bool leafB = nbm == 1;   // (a single member in the second child is a leaf of the guide tree: col = position)
     const int E = m2_round_batch(nbm) + m2_round_batch(nbm * n);
     uint16_t* const s_rl = reinterpret_cast<uint16_t*>(s_rows) + lane;     // (every lane reads its own column of the rows only)
     const unsigned char* const s_rlane = reinterpret_cast<const unsigned char*>(s_rl);
@@ -480,9 +481,13 @@ __device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, c
                         qq[u] = *((m2_gu16*)(mapb + (C.map_boff + (min(rr[u], C.lens & 0xffffu) << 1))));   // (a gap clamps to a valid index)
                     }
 #pragma unroll
-                    for (int u = 0; u < M2_UBATCH; ++u) {
-                        qq[u] = (dr[u] & M2_DIRECT) ? rr[u] : qq[u];
-                        jj[u] = *((m2_gi32*)(colb + (cb[u] + (min(qq[u], ln[u]) << 2))));
+                    for (int u = 0; u < M2_UBATCH; ++u) qq[u] = (dr[u] & M2_DIRECT) ? rr[u] : qq[u];
+                    if (leafB) {   // the second child is one read that has not been merged yet: its columns are its positions
+#pragma unroll
+                        for (int u = 0; u < M2_UBATCH; ++u) jj[u] = static_cast<int>(qq[u]);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < M2_UBATCH; ++u) jj[u] = *((m2_gi32*)(colb + (cb[u] + (min(qq[u], ln[u]) << 2))));
                     }
 #pragma unroll
                     for (int u = 0; u < M2_UBATCH; ++u) M2_ADD1(jj[u], rr[u] != M2_NONE && qq[u] != M2_NONE)
