@@ -264,7 +264,7 @@ int sarlacc_set_msa_spec(int spec);
 
 /* A/B switches of the tests and the perf tools (every default, 0, is the product path): "msa_spec",
  * "msa2_general_rows", "msa2_chain_hbm", "msa2_waves_per_cu", "msa2_single_wave", "msa2_batches", "align_pensel", "align_chunks", "align_k", "align_waves_per_cu",
- * "consensus_chars", "consensus_generic", "msa_int32".  The environment (SARLACC_<NAME>) is read once, when the
+ * "consensus_chars", "consensus_generic", "msa_int32", "msa_affine".  The environment (SARLACC_<NAME>) is read once, when the
  * first option is asked for; afterwards only this call changes a value.  Nothing in the reference corresponds. */
 int sarlacc_set_option(const char* name, int value);
 

@@ -51,6 +51,7 @@ enum Opt {
     OPT_CONSENSUS_CHARS,      // fused MSA + consensus on character rows instead of vote codes
     OPT_CONSENSUS_GENERIC,    // quality vote on character rows: the generic kernel only
     OPT_MSA_INT32,            // pairwise MSA alignments by the 32-bit kernel
+    OPT_MSA_AFFINE,           // pairwise MSA alignments by the full affine recurrence also where open <= extend makes it linear
     OPT_N
 };
 int option(Opt o);

@@ -470,7 +470,13 @@ __device__ __forceinline__ int wave_min(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-template <int C, int OUT>
+// LIN: the first gap character costs no more than a further one (open' <= extend' in the cost domain -- what the
+// reference's DEFAULT call gives: R/multiReadAlign.R:47 hands (-gapOpening, -gapExtension) = (-5, -1) to parameters that
+// src/quick_msa.cpp:26-31 reads as (extend, open), so the aligner sees open -1, extend -5).  H <= E and H <= F in every
+// cell, so  H(up) + open <= E(up) + extend  always: E = H(up) + open, F = H(left) + open, the "opened" flags are constant
+// (ties prefer open by the spec), and the recurrence needs neither the E / F registers and their two lane exchanges per
+// step nor half of the traceback flags -- the same cells, codes and walk with 17 instead of 29 instructions per step.
+template <int C, int OUT, bool LIN>
 __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
     constexpr int H2 = C / 2, M = C / 4;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -526,33 +532,36 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
         // ---- one step (one parity) on the packed state ----
         auto step_pk = [&](auto par_tag, const unsigned (&pen)[M], int inject) {
             constexpr int par = decltype(par_tag)::value;
-            if (par == 0) { xlH = dpp_int<DPP_WAVE_SHR1>(xlH, static_cast<int>(Hod[M - 1])); xlF = dpp_int<DPP_WAVE_SHR1>(xlF, static_cast<int>(Fod[M - 1])); }
-            else { xrH = dpp_int<DPP_WAVE_SHL1>(xrH, static_cast<int>(Hev[0])); xrE = dpp_int<DPP_WAVE_SHL1>(xrE, static_cast<int>(Eev[0])); }
+            if (par == 0) { xlH = dpp_int<DPP_WAVE_SHR1>(xlH, static_cast<int>(Hod[M - 1])); if (!LIN) xlF = dpp_int<DPP_WAVE_SHR1>(xlF, static_cast<int>(Fod[M - 1])); }
+            else { xrH = dpp_int<DPP_WAVE_SHL1>(xrH, static_cast<int>(Hev[0])); if (!LIN) xrE = dpp_int<DPP_WAVE_SHL1>(xrE, static_cast<int>(Eev[0])); }
             unsigned nH[M], nE[M], nF[M];
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                unsigned upH, upE, lfH, lfF, same;
+                unsigned upH, upE = 0, lfH, lfF = 0, same;
                 if (par == 0) {
-                    upH = Hod[m]; upE = Eod[m];
+                    upH = Hod[m];
                     lfH = pk_shift_in(Hod[m], m > 0 ? Hod[m > 0 ? m - 1 : 0] : static_cast<unsigned>(xlH));
-                    lfF = pk_shift_in(Fod[m], m > 0 ? Fod[m > 0 ? m - 1 : 0] : static_cast<unsigned>(xlF));
+                    if (!LIN) { upE = Eod[m]; lfF = pk_shift_in(Fod[m], m > 0 ? Fod[m > 0 ? m - 1 : 0] : static_cast<unsigned>(xlF)); }
                     same = Hev[m];
                 } else {
-                    lfH = Hev[m]; lfF = Fev[m];
+                    lfH = Hev[m];
                     upH = pk_shift_in(m + 1 < M ? Hev[m + 1 < M ? m + 1 : 0] : static_cast<unsigned>(xrH), Hev[m]);
-                    upE = pk_shift_in(m + 1 < M ? Eev[m + 1 < M ? m + 1 : 0] : static_cast<unsigned>(xrE), Eev[m]);
+                    if (!LIN) { lfF = Fev[m]; upE = pk_shift_in(m + 1 < M ? Eev[m + 1 < M ? m + 1 : 0] : static_cast<unsigned>(xrE), Eev[m]); }
                     same = Hod[m];
                 }
                 const unsigned eop = upH + (par == 0 ? gouEv[m] : gouOd[m]);
-                const unsigned eex = upE + (par == 0 ? geuEv[m] : geuOd[m]);
-                const unsigned e = pk_min(eop, eex);
-                const unsigned fop = lfH + GO, fex = lfF + GE;
-                const unsigned f = pk_min(fop, fex);
+                const unsigned fop = lfH + GO;
+                unsigned e = eop, f = fop;
+                if (!LIN) {
+                    e = pk_min(eop, upE + (par == 0 ? geuEv[m] : geuOd[m]));
+                    f = pk_min(fop, lfF + GE);
+                }
                 const unsigned d = same + pen[m];
                 const unsigned mn = pk_min(e, f);
                 const unsigned hv = pk_min(d, mn);
-                // code = 8 [f != fop] + 4 [e != eop] + 2 [mn != e] + [hv != d], shifted into the accumulator
-                acc[m] = pk_mad<16>(acc[m], pk_mad<4>(pk_mad<2>(pk_ne(f, fop), pk_ne(e, eop)), pk_mad<2>(pk_ne(mn, e), pk_ne(hv, d))));
+                // code = 8 [f != fop] + 4 [e != eop] + 2 [mn != e] + [hv != d], shifted into the accumulator (LIN: e is eop, f is fop)
+                if (LIN) acc[m] = pk_mad<16>(acc[m], pk_mad<2>(pk_ne(mn, e), pk_ne(hv, d)));
+                else acc[m] = pk_mad<16>(acc[m], pk_mad<4>(pk_mad<2>(pk_ne(f, fop), pk_ne(e, eop)), pk_mad<2>(pk_ne(mn, e), pk_ne(hv, d))));
                 nH[m] = hv; nE[m] = e; nF[m] = f;
             }
             // first row of the job only: the step that computes cell (0, 0) sets H(0, 0) = 0 in its lane
@@ -566,8 +575,8 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
             }
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                if (par == 0) { Hev[m] = nH[m]; Eev[m] = nE[m]; Fev[m] = nF[m]; }
-                else { Hod[m] = nH[m]; Eod[m] = nE[m]; Fod[m] = nF[m]; }
+                if (par == 0) { Hev[m] = nH[m]; if (!LIN) { Eev[m] = nE[m]; Fev[m] = nF[m]; } }
+                else { Hod[m] = nH[m]; if (!LIN) { Eod[m] = nE[m]; Fod[m] = nF[m]; } }
             }
         };
 
@@ -632,8 +641,8 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const unsigned de = delta & vmEv[m], dd = delta & vmOd[m];
-                Hev[m] -= de; Eev[m] -= de; Fev[m] -= de;
-                Hod[m] -= dd; Eod[m] -= dd; Fod[m] -= dd;
+                Hev[m] -= de; Hod[m] -= dd;
+                if (!LIN) { Eev[m] -= de; Fev[m] -= de; Eod[m] -= dd; Fod[m] -= dd; }
             }
         };
         // one word row on the code halves (rh, ch) issued one row earlier; those of row w + 1 are issued into (rn, cn)
@@ -727,14 +736,19 @@ static int launch_ad(const MsaArgs& a, int grid, size_t lds, hipStream_t s) {
     return 0;
 }
 
-template <int C, int OUT>
-static int launch_pk(const MsaArgs& a, int grid, size_t lds, hipStream_t s) {
+template <int C, int OUT, bool LIN>
+static int launch_pk2(const MsaArgs& a, int grid, size_t lds, hipStream_t s) {
     if (lds > 48 * 1024)
-        SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msa_pairwise_pk<C, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msa_pairwise_pk<C, OUT, LIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(lds)));
-    hipLaunchKernelGGL((k_msa_pairwise_pk<C, OUT>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((k_msa_pairwise_pk<C, OUT, LIN>), dim3(grid), dim3(64), lds, s, a);
     SL_HIP(hipGetLastError());
     return 0;
+}
+template <int C, int OUT>
+static int launch_pk(const MsaArgs& a, int grid, size_t lds, hipStream_t s) {
+    // (costs as the kernel sees them: a.go = first gap character, a.ge = every further one)
+    return a.go <= a.ge && !option(OPT_MSA_AFFINE) ? launch_pk2<C, OUT, true>(a, grid, lds, s) : launch_pk2<C, OUT, false>(a, grid, lds, s);
 }
 
 template <int OUT>

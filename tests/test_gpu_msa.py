@@ -156,6 +156,25 @@ def test_fused_long_rows_with_many_insertions(spec):
     assert len(got[0][0]) > 10000
 
 
+@pytest.mark.parametrize("params", [(0, -1, -5, -1, 100), (1, -2, -2, -2, 20), (0, -1, -1, -1, 100), (2, -3, -7, -2, 60)])
+def test_pairwise_linear_gap_kernel_equals_affine(oracle, spec, params):
+    """Where the first gap character costs no more than a further one -- the reference's default call: the aligner sees open
+    -1, extend -5 (R/multiReadAlign.R:47, src/quick_msa.cpp:26-31) -- extension is never strictly better than re-opening, and
+    the packed pairwise kernel runs without E / F states (k_msa_pairwise_pk<.., LIN>).  Option msa_affine sends the same
+    call through the full affine recurrence: identical rows, and the CPU statement's."""
+    from sarlacc_amd import calls
+    rng = np.random.default_rng(97)
+    reads, groups, _ = sim_groups(rng, 10, 7, 350, sub=0.08, indel=0.03)
+    lin = calls.quick_msa(groups, reads, *params)
+    calls.set_option("msa_affine", 1)
+    try:
+        aff = calls.quick_msa(groups, reads, *params)
+    finally:
+        calls.set_option("msa_affine", 0)
+    assert lin == aff
+    assert lin == oracle.quick_msa(groups, reads, *params, spec=spec)
+
+
 def test_msa_long_reads(oracle):
     """40-kb reads: read and centre codes take more than the default 64 KB of dynamic LDS."""
     from sarlacc_amd import calls
