@@ -46,9 +46,11 @@ VALU32_PEAK_TLOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 78.6 T lane-ops/s, 32-bit
 VALU64_PEAK_TLOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # 39.3 T lane-ops/s, fp64
 # algorithmic work per DP cell: quality DP = 10 fp64 add/sub/max/compare
 # (Appendix A of SURVEY.md: H, LJ, V, UJ updates, M, three compares); integer Gotoh of the MSA
-# pairwise stage = 5 add + 4 max + 2 for the match score = 11 int32 ops (traceback bits excluded)
+# pairwise stage = 5 add + 4 max + 2 for the match score = 11 int32 ops (traceback bits excluded); with the reference's
+# default scores the first gap character costs no more than a further one, the recurrence is the linear-gap one and
+# the kernel runs it as such: 3 add + 2 min + 2 for the match score = 7
 ALIGN_OPS_PER_CELL = 10
-MSA_OPS_PER_CELL = 11
+MSA_OPS_PER_CELL = 7
 
 
 def source_sha(names):
@@ -385,12 +387,13 @@ def main():
         # the same pass with the centre-star alignment (spec v1, round 1's algorithm) for comparison, on every rank
         calls.set_msa_spec(1)
         try:
-            fence()
-            t0 = time.perf_counter()
-            r1 = pipeline.run_resident(umis, mol["seq"], mol["qual"], off_host, enc, threshold=args.threshold, dist=D,
-                                       gather_device=gather_device)
-            fence()
-            dt1 = time.perf_counter() - t0
+            for _ in range(2):   # (the first pass sizes spec v1's own workspaces)
+                fence()
+                t0 = time.perf_counter()
+                r1 = pipeline.run_resident(umis, mol["seq"], mol["qual"], off_host, enc, threshold=args.threshold, dist=D,
+                                           gather_device=gather_device)
+                fence()
+                dt1 = time.perf_counter() - t0
         finally:
             calls.set_msa_spec(0)
         v1 = reduce([dt1, r1["kernel_ms"]["msa_pairwise"], r1["kernel_ms"]["msa_merge"]], dist.ReduceOp.MAX)
@@ -432,6 +435,7 @@ def main():
                 "rooflines": {
                     "k_msa_pairwise_pk": {"bound": "valu", "achieved": msa_ops, "peak": VALU32_PEAK_TLOPS, "unit": "T lane-op/s (int32)",
                                           "frac": msa_ops / VALU32_PEAK_TLOPS, "algorithmic_ops_per_cell": MSA_OPS_PER_CELL,
+                                          "recurrence": "linear gaps (open -1 <= extend -5 as the aligner sees the default call): k_msa_pairwise_pk<4, 1, LIN>",
                                           "tcups": cnt["msa_cells"] / (kms["msa_pairwise"] * 1e-3) / 1e12,
                                           "issue_peak_measured": 1024 * 64 / 4.2 * 2.4e9 / 1e12,
                                           "issue_peak_note": "tools/ubench_valu.hip on MI355X: packed 16-bit / VOP3 / DPP instructions issue in ~4.2 cycles per "
