@@ -153,6 +153,13 @@ int sarlacc_dev_download(void* h, const void* d, int64_t bytes);
  * min(tol,width) bases with reversed qualities.  d_woff: offsets of the windows (n+1). */
 int sarlacc_dev_windows(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
                         const int64_t* d_woff, int which, uint8_t* d_oseq, uint8_t* d_oqual, void* stream);
+/* Sub-sequences of resident reads, straight to host strings (XVector::subseq in .align_and_extract, R/adaptorAlign.R:160-174):
+ * output r = width[r] bases from the 1-based position start[r] of read r of batch A -- or of batch B where from_b[r] != 0
+ * (from_b may be NULL; adaptorAlign's strand choice takes, per read, the alignment on the front or on the back window).
+ * start / width / from_b are host arrays; out_off (n + 1) and out_chars (out_cap bytes) are filled on the host. */
+int sarlacc_dev_subseq(const uint8_t* d_seq_a, const int64_t* d_off_a, const uint8_t* d_seq_b, const int64_t* d_off_b,
+                       const uint8_t* from_b, const int32_t* start, const int32_t* width, int64_t n, char* out_chars,
+                       int64_t out_cap, int64_t* out_off, void* stream);
 /* realizeReads on resident reads (R/realizeReads.R:28-43): output r = read d_idx[r] (0-based),
  * reverse-complemented when d_rev[r] != 0 (qualities reversed), cut to the oriented positions
  * d_tstart[r] .. d_tstart[r] + width - 1 (1-based), widths given by the output offsets d_ooff. */

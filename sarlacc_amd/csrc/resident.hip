@@ -65,6 +65,23 @@ __global__ void k_realize(const uint8_t* seq, const uint8_t* qual, const int64_t
     }
 }
 
+// Sub-sequences of resident reads (XVector::subseq as .align_and_extract uses it, R/adaptorAlign.R:160-174): output r = `width[r]`
+// bases from the 1-based position `start[r]` of read r of batch A, or of batch B where from_b[r] != 0 (the strand choice of
+// adaptorAlign picks, per read, the alignment on the front or on the back window).  One thread per read: the pieces are a
+// dozen bases long.  bad: smallest r whose range leaves its read.
+__global__ void k_subseq(const uint8_t* seq_a, const int64_t* off_a, const uint8_t* seq_b, const int64_t* off_b, const uint8_t* from_b,
+                         const int32_t* start, const int64_t* ooff, long long n, uint8_t* out, int* bad) {
+    const long long r = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+    if (r >= n) return;
+    const bool b = from_b && from_b[r];
+    const uint8_t* seq = b ? seq_b : seq_a;
+    const int64_t* off = b ? off_b : off_a;
+    const long long s = off[r], L = off[r + 1] - s, o0 = ooff[r], w = ooff[r + 1] - o0, q0 = static_cast<long long>(start[r]) - 1;
+    if (w <= 0) return;
+    if (q0 < 0 || q0 + w > L) { atomicMin(bad, static_cast<int>(r)); return; }
+    for (long long p = 0; p < w; ++p) out[o0 + p] = seq[s + q0 + p];
+}
+
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long& x) {
     x += 0x9E3779B97F4A7C15ull;
     unsigned long long z = x;
@@ -143,6 +160,36 @@ int sarlacc_dev_windows(const uint8_t* d_seq, const uint8_t* d_qual, const int64
     hipLaunchKernelGGL(k_windows, dim3(static_cast<unsigned>(n)), dim3(64), 0, static_cast<hipStream_t>(stream), d_seq,
                        d_qual, d_off, static_cast<long long>(n), d_woff, which, d_oseq, d_oqual);
     SL_HIP(hipGetLastError());
+    return 0;
+}
+
+int sarlacc_dev_subseq(const uint8_t* d_seq_a, const int64_t* d_off_a, const uint8_t* d_seq_b, const int64_t* d_off_b,
+                       const uint8_t* from_b, const int32_t* start, const int32_t* width, int64_t n, char* out_chars,
+                       int64_t out_cap, int64_t* out_off, void* stream) {
+    if (n < 0) return fail("sarlacc_amd: negative number of reads");
+    out_off[0] = 0;
+    for (int64_t r = 0; r < n; ++r) out_off[r + 1] = out_off[r] + (width[r] > 0 ? width[r] : 0);
+    if (n == 0 || out_off[n] == 0) return 0;
+    if (out_off[n] > out_cap) return fail("sarlacc_amd: sub-sequence buffer too small (%lld needed)", static_cast<long long>(out_off[n]));
+    if (from_b && (!d_seq_b || !d_off_b)) return fail("sarlacc_amd: a second batch is selected but not given");
+    SL_TRY(ensure_device());
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint8_t* d_sel = nullptr; int32_t* d_start; int64_t* d_ooff; uint8_t* d_out; int* d_bad;
+    if (from_b) SL_TRY(upload("subseq.sel", from_b, static_cast<size_t>(n), &d_sel, s));
+    SL_TRY(upload("subseq.start", start, static_cast<size_t>(n), &d_start, s));
+    SL_TRY(upload("subseq.ooff", out_off, static_cast<size_t>(n) + 1, &d_ooff, s));
+    SL_TRY(scratch("subseq.out", static_cast<size_t>(out_off[n]), &d_out));
+    SL_TRY(scratch("subseq.bad", 1, &d_bad));
+    const int big = 0x7fffffff;
+    SL_HIP(hipMemcpyAsync(d_bad, &big, sizeof big, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_subseq, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, d_seq_a, d_off_a, d_seq_b, d_off_b, d_sel, d_start,
+                       d_ooff, static_cast<long long>(n), d_out, d_bad);
+    SL_HIP(hipGetLastError());
+    int bad = big;
+    SL_HIP(hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipMemcpyAsync(out_chars, d_out, static_cast<size_t>(out_off[n]), hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    if (bad != big) return fail("sarlacc_amd: sub-sequence of read %d lies outside the read", bad + 1);
     return 0;
 }
 

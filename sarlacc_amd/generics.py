@@ -181,13 +181,27 @@ def _adaptor_align_chunk(adaptor1, adaptor2, sub1, sub2, args, tolerance, reads=
     """One yield of the streamer: the four alignments of .align_AA_internal (R/adaptorAlign.R:180-207) and
     the strand choice, on a host batch (`reads`) or a resident one (`dev`)."""
     if dev is not None:
+        # resident batch: the four alignments run on the device windows; the strand is chosen from the four score vectors, and
+        # only then are the sub-sequences cut -- on the device, from the window of the chosen strand, a dozen bases per read
+        # across PCIe instead of the windows themselves
         dfront, dback = dev.front_and_back(tolerance)
-        hfront, hback = dfront.download()[0], dback.download()[0]   # only the windows, for the sub-sequences
-        cur_starts = _align_and_extract_resident(adaptor1, dfront, hfront, *args, sub1["starts"], sub1["ends"])
-        cur_ends = _align_and_extract_resident(adaptor2, dback, hback, *args, sub2["starts"], sub2["ends"])
-        rc_starts = _align_and_extract_resident(adaptor1, dback, hback, *args, sub1["starts"], sub1["ends"])
-        rc_ends = _align_and_extract_resident(adaptor2, dfront, hfront, *args, sub2["starts"], sub2["ends"])
-        width = np.diff(dev.off_host).astype(np.int32)
+        runs = {}
+        for key, (ad, d, sb) in {"cs": (adaptor1, dfront, sub1), "ce": (adaptor2, dback, sub2), "rs": (adaptor1, dback, sub1),
+                                 "re": (adaptor2, dfront, sub2)}.items():
+            runs[key] = d.align_map(ad, args[0], args[1], np.asarray(sb["starts"], dtype=np.int32) - 1, sb["ends"])
+        rev, _ = _resolve_strand(runs["cs"][0], runs["ce"][0], runs["rs"][0], runs["re"][0])
+
+        def chosen(cur, rc, d_cur, d_rc):
+            res = {"score": np.where(rev, rc[0], cur[0]), "start": np.where(rev, rc[1], cur[1]), "end": np.where(rev, rc[2], cur[2]),
+                   "subseq": {}}
+            for i in range(len(cur[3])):
+                st, wd = np.where(rev, rc[3][i], cur[3][i]), np.where(rev, rc[4][i], cur[4][i])
+                res["subseq"]["Sub%d" % (i + 1)] = StrList(d_cur.subseq(st, wd, other=d_rc, from_other=rev))   # decoded on demand
+            return res
+
+        cur_starts = chosen(runs["cs"], runs["rs"], dfront, dback)
+        cur_ends = chosen(runs["ce"], runs["re"], dback, dfront)
+        return cur_starts, cur_ends, rev, np.diff(dev.off_host).astype(np.int32)
     else:
         front, back = _get_front_and_back(reads, tolerance)
         cur_starts = _align_and_extract(adaptor1, front, *args, sub1["starts"], sub1["ends"])

@@ -160,6 +160,21 @@ class DeviceReads:
             out.append(d)
         return out[0], out[1]
 
+    def subseq(self, start, width, other=None, from_other=None):
+        """XVector::subseq on the resident batch, straight to a host StringSet: element r = `width[r]` bases from the 1-based
+        position `start[r]` of read r -- of `other`'s read r where `from_other[r]` (sarlacc_dev_subseq)."""
+        n = len(self)
+        st = np.ascontiguousarray(start, dtype=np.int32)
+        wd = np.ascontiguousarray(np.maximum(np.asarray(width, dtype=np.int64), 0), dtype=np.int32)
+        off = np.zeros(n + 1, np.int64)
+        total = int(wd.sum(dtype=np.int64))
+        chars = np.zeros(max(total, 1), np.uint8)
+        sel = None if from_other is None else np.ascontiguousarray(from_other, dtype=np.uint8)
+        check(_lib.lib().sarlacc_dev_subseq(self.seq.ptr, self.off.ptr, other.seq.ptr if other is not None else None,
+                                            other.off.ptr if other is not None else None, ptr(sel) if sel is not None else None,
+                                            ptr(st), ptr(wd), C.c_int64(n), ptr(chars), C.c_int64(chars.size), ptr(off), None))
+        return StringSet(chars, off)
+
     def realize(self, idx, reversed_, trim_start=None, trim_end=None):
         """Reads `idx` (0-based) of this batch, reverse-complemented where `reversed_`, cut to the
         1-based inclusive [trim_start, trim_end] of the oriented read (whole read when None):
