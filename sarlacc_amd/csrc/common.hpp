@@ -52,6 +52,8 @@ enum Opt {
     OPT_CONSENSUS_GENERIC,    // quality vote on character rows: the generic kernel only
     OPT_MSA_INT32,            // pairwise MSA alignments by the 32-bit kernel
     OPT_MSA_AFFINE,           // pairwise MSA alignments by the full affine recurrence also where open <= extend makes it linear
+    OPT_UMI_FULL_ROUNDS,      // greedy clustering of dense graphs: every round walks every live list (A/B of the candidate-set rounds)
+    OPT_UMI_TILE_SEARCH,      // neighbour search at thresholds 2 and 3 by the all-tile-pairs kernel (A/B of the split-key search)
     OPT_N
 };
 int option(Opt o);

@@ -871,6 +871,93 @@ __global__ void __launch_bounds__(256) k_cl_decrement_w(ClusterState S, int roun
     }
 }
 
+// Dense graphs (threshold 3 on 12-base UMIs: the 2-hop ball of a node covers a large share of the graph) yield only a
+// few picks per round, all of them among the nodes with the largest keys, while the two passes above walk every live
+// list.  A round can instead be decided on a candidate set C = {live v : remaining[v] >= t}: C is closed upwards in key
+// order, so a candidate is a 2-hop maximum of the whole graph exactly when no other CANDIDATE with a larger key lies
+// within two hops -- hop1[w] = max key over candidates adjacent to w (lists are symmetric), and v is picked iff the
+// maximum of hop1 over its live neighbours is its own key.  Picks outside C are left for a later round (every pick is
+// valid on its own), so the clusters are those of the full rounds; the work per round is |C| lists instead of all.
+struct ClusterTop {
+    int* maxrem;                // largest remaining of a live node, this round
+    int* cand;                  // candidate list
+    int* counts;                // [0] candidates, [1] picks, [2] 1 when the list was cut off at `cap`
+    unsigned long long* hop1;
+    int cap;
+};
+
+__global__ void k_cl_keys_top(ClusterState S, ClusterTop T) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    int rem = 0;
+    if (v < S.n && S.state[v] == 0 && S.remaining[v] > 0) rem = S.remaining[v];
+    if (v < S.n) S.key[v] = rem ? ((static_cast<unsigned long long>(rem) << 32) | static_cast<unsigned>(v)) : 0ull;
+    const unsigned long long live = __ballot(rem > 0);
+    int m = rem;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0 && live) { atomicAdd(S.live, __popcll(live)); atomicMax(T.maxrem, m); }
+}
+
+__global__ void k_cl_collect(ClusterState S, ClusterTop T, int delta) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = max(1, *T.maxrem - delta);
+    const bool in = v < S.n && static_cast<int>(S.key[v] >> 32) >= t;
+    const unsigned long long ball = __ballot(in);
+    if (!ball) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&T.counts[0], __popcll(ball));
+    base = __shfl(base, 0);
+    if (in) {
+        const int slot = base + __popcll(ball & ((1ull << lane) - 1ull));
+        if (slot < T.cap) T.cand[slot] = v; else T.counts[2] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cl_mark_top(ClusterState S, ClusterTop T) {
+    if (T.counts[2]) return;
+    const int nc = T.counts[0], lane = threadIdx.x & 63;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < nc; c += gridDim.x * 4) {
+        const int v = T.cand[c];
+        const unsigned long long k = S.key[v];
+        for (long long p = S.off[v] + lane; p < S.off[v + 1]; p += 64) {
+            const int w = S.nbr[p];
+            if (S.state[w] == 0) atomicMax(&T.hop1[w], k);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cl_pick_top(ClusterState S, ClusterTop T, int round) {
+    if (T.counts[2]) return;
+    const int nc = T.counts[0], lane = threadIdx.x & 63;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < nc; c += gridDim.x * 4) {
+        const int v = T.cand[c];
+        const unsigned long long k = S.key[v];
+        const long long a = S.off[v], b = S.off[v + 1];
+        unsigned long long m2 = k;
+        for (long long p = a + lane; p < b; p += 64) {
+            const int w = S.nbr[p];
+            if (S.state[w] == 0) m2 = max(m2, T.hop1[w]);
+        }
+        m2 = cl_wave_max64(m2);
+        if (m2 != k) continue;
+        // cluster = still-unused neighbours in list order (src/cluster_umis.cpp:78-91)
+        int cnt = 0;
+        for (long long p0 = a; p0 < b; p0 += 64) {
+            const long long p = p0 + lane;
+            const int w = p < b ? S.nbr[p] : -1;
+            const bool live = w >= 0 && S.state[w] == 0;
+            const unsigned long long ball = __ballot(live);
+            if (live) {
+                S.memb[a + cnt + __popcll(ball & ((1ull << lane) - 1ull))] = w;
+                S.mark[w] = round;
+            }
+            cnt += __popcll(ball);
+        }
+        if (lane == 0) { S.csize[v] = cnt; S.seed[v] = 1; S.pickkey[v] = k; atomicAdd(&T.counts[1], 1); }
+    }
+}
+
 // state flips happen in a separate pass so that k_cl_pick sees a consistent snapshot
 __global__ void k_cl_commit(ClusterState S, int round) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1336,6 +1423,9 @@ static int cluster_dev(const DevAdj& adj, int n, const int32_t* d_members, const
     const dim3 g(nblk(n, 256)), b(256), gw(nblk(n, 4));
     // one wavefront per node from 24 links per node on average (one thread per node below that)
     const bool dense = adj.nnz >= 24LL * n;
+    ctx().counts["umi_links"] = static_cast<double>(adj.nnz);
+    ctx().counts["umi_cluster_candidate_rounds"] = 0;
+    ctx().counts["umi_cluster_full_rounds"] = 0;
     hipLaunchKernelGGL(k_cl_init, g, b, 0, s, S, check_sym ? 1 : 0);
     int herr[3];
     SL_HIP(hipMemcpyAsync(herr, S.err, sizeof herr, hipMemcpyDeviceToHost, s));
@@ -1348,14 +1438,54 @@ static int cluster_dev(const DevAdj& adj, int n, const int32_t* d_members, const
     if (herr[2] != big)
         return fail("sarlacc_amd: neighbour lists must be symmetric and contain the read itself (list %d is not)", herr[2] + 1);
 
+    ClusterTop T{};
+    if (dense) {
+        SL_TRY(scratch("cl.maxrem", 1, &T.maxrem));
+        SL_TRY(scratch("cl.counts", 4, &T.counts));
+        SL_TRY(scratch("cl.hop1", nn, &T.hop1));
+        T.cap = std::max(1024, n / 8);
+        SL_TRY(scratch("cl.cand", static_cast<size_t>(T.cap), &T.cand));
+        SL_HIP(hipMemsetAsync(T.counts, 0, 4 * sizeof(int), s));
+    }
+    const bool top_rounds = dense && !option(OPT_UMI_FULL_ROUNDS);
+    int delta = 0;            // candidates: remaining >= (largest remaining) - delta
+    bool was_top = false;     // the previous round ran on a candidate set; its counts are in T.counts
+    long long top_rounds_run = 0, full_rounds_run = 0;
     for (int round = 0;; ++round) {
+        int hc[4] = {0, 0, 0, 0};
+        if (was_top) SL_HIP(hipMemcpyAsync(hc, T.counts, sizeof hc, hipMemcpyDeviceToHost, s));
         SL_HIP(hipMemsetAsync(S.live, 0, sizeof(int), s));
-        hipLaunchKernelGGL(k_cl_keys, g, b, 0, s, S);
+        if (top_rounds) {
+            SL_HIP(hipMemsetAsync(T.maxrem, 0, sizeof(int), s));
+            hipLaunchKernelGGL(k_cl_keys_top, g, b, 0, s, S, T);
+        } else {
+            hipLaunchKernelGGL(k_cl_keys, g, b, 0, s, S);
+        }
         int live = 0;
         SL_HIP(hipMemcpyAsync(&live, S.live, sizeof live, hipMemcpyDeviceToHost, s));
         SL_HIP(hipStreamSynchronize(s));
         if (live == 0) break;
-        if (dense) {
+        bool full = !top_rounds;
+        if (top_rounds && was_top) {
+            // the candidate list of the previous round: cut off -> this round walks every list and the window shrinks;
+            // a productive list (a quarter or more of it picked) may be hiding picks just below it -> widen
+            if (hc[2]) { full = true; delta /= 2; }
+            else if (4ll * hc[1] >= hc[0]) delta = 2 * delta + 1;
+            else if (64ll * hc[1] < hc[0] && hc[0] > 256) delta /= 2;
+        }
+        was_top = false;
+        if (!full) {
+            SL_HIP(hipMemsetAsync(T.counts, 0, 4 * sizeof(int), s));
+            SL_HIP(hipMemsetAsync(T.hop1, 0, sizeof(unsigned long long) * static_cast<size_t>(n), s));
+            hipLaunchKernelGGL(k_cl_collect, g, b, 0, s, S, T, delta);
+            hipLaunchKernelGGL(k_cl_mark_top, dim3(1024), b, 0, s, S, T);
+            hipLaunchKernelGGL(k_cl_pick_top, dim3(1024), b, 0, s, S, T, round);
+            hipLaunchKernelGGL(k_cl_commit, g, b, 0, s, S, round);
+            hipLaunchKernelGGL(k_cl_decrement_w, gw, b, 0, s, S, round);
+            was_top = true;
+            ++top_rounds_run;
+        } else if (dense) {
+            ++full_rounds_run;
             hipLaunchKernelGGL(k_cl_m1_w, gw, b, 0, s, S);
             hipLaunchKernelGGL(k_cl_pick_w, gw, b, 0, s, S, round);
             hipLaunchKernelGGL(k_cl_commit, g, b, 0, s, S, round);
@@ -1369,6 +1499,8 @@ static int cluster_dev(const DevAdj& adj, int n, const int32_t* d_members, const
         SL_HIP(hipGetLastError());
         if (round > 4 * n + 16) return fail("sarlacc_amd: clustering did not converge");
         ctx().counts["umi_cluster_rounds"] = round + 1;
+        ctx().counts["umi_cluster_candidate_rounds"] = static_cast<double>(top_rounds_run);
+        ctx().counts["umi_cluster_full_rounds"] = static_cast<double>(full_rounds_run);
     }
 
     // ---- output order: solos by index, then picks by key descending ----

@@ -93,7 +93,9 @@ def mockup(rng, n, density):
 
 
 @pytest.mark.parametrize("n,density", [(20, 0.05), (20, 0.1), (20, 0.2), (50, 0.2), (50, 0.4), (50, 0.1), (50, 0.0),
-                                       (400, 0.01), (1000, 0.003)])
+                                       (400, 0.01), (1000, 0.003),
+                                       # >= 24 links per node: the rounds run on candidate sets (ClusterTop)
+                                       (300, 0.3), (1000, 0.05), (2500, 0.03)])
 def test_cluster_umis(oracle, n, density):
     from sarlacc_amd import calls
     rng = np.random.default_rng(int(n * 1000 + density * 1000))
@@ -181,6 +183,27 @@ def test_c3_shape_sample(oracle):
         got = calls.umi_group(umis, t, None, t, g)
         same_lists(got, oracle.umi_group(umis, t, None, t, g, fast=True))
         assert sorted(x for c in got for x in c.tolist()) == g[0]
+
+
+def test_dense_neighbourhoods_both_round_schemes(oracle):
+    # short UMIs at threshold 3: hundreds of neighbours per UMI, a few picks per round.  The candidate-set rounds and
+    # the rounds that walk every list give the oracle's clusters, in its order.
+    from sarlacc_amd import _lib, calls
+    rng = np.random.default_rng(4242)
+    umis = ["".join(rng.choice(list("ACGT"), 8)) for _ in range(900)]
+    umis = [u for u in umis for _ in range(int(rng.integers(1, 8)))]
+    umis = [umis[i] for i in rng.permutation(len(umis))]
+    g = [list(range(1, len(umis) + 1))]
+    want = oracle.umi_group(umis, 3, None, 3, g, fast=True)
+    try:
+        for full in (0, 1):
+            calls.set_option("umi_full_rounds", full)
+            same_lists(calls.umi_group(umis, 3, None, 3, g), want)
+            assert _lib.stage_count("umi_links") >= 24 * len(umis)
+            if not full:
+                assert _lib.stage_count("umi_cluster_candidate_rounds") > 0
+    finally:
+        calls.set_option("umi_full_rounds", 0)
 
 
 def test_mask_bad_bases(oracle, oenc, enc):
