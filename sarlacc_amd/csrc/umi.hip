@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <limits>
 #include <string>
+#include <vector>
 
 namespace sarlacc {
 
@@ -231,6 +232,8 @@ struct PairArgs {
     const uint32_t* tile_list;      // optional: the (row tile << 16 | column tile) pairs to search, one per block
     const TileInfo* sub_info;       // optional: common prefixes of the 64-element blocks (4 per tile)
     unsigned list_stride;           // block b searches tile_list[b * list_stride] (1; larger: a sample of the list)
+    int special_lreq;               // >= 0: only pairs with a member that holds an N or is shorter than this (the rest
+                                    // comes from the split-key search); -1: every pair
 };
 
 // ---------------------------------------------------------------------------
@@ -244,16 +247,18 @@ struct PairArgs {
 struct TileInfo {
     unsigned long long pcode;   // common prefix, 2 bits per base from bit 0
     int plen;                   // its length; -1: no information
+    int special;                // some string of the tile holds an N or is shorter than `lreq`
 };
 
 template <int BLK>
-__global__ void __launch_bounds__(BLK) k_tile_info(UmiArrays U, const int* gid, int n, TileInfo* info) {
+__global__ void __launch_bounds__(BLK) k_tile_info(UmiArrays U, const int* gid, int n, int lreq, TileInfo* info) {
     const int t0 = blockIdx.x * BLK, t1 = min(t0 + BLK, n) - 1;
     const int i = t0 + threadIdx.x;
     const uint32_t nm = i < n ? U.nmask[i] : 0u;
     const int anyN = __syncthreads_or(nm != 0u);
+    const int anyShort = __syncthreads_or(i < n && static_cast<int>(U.meta[i] & 0xff) < lreq);
     if (threadIdx.x != 0) return;
-    TileInfo ti{0ull, -1};
+    TileInfo ti{0ull, -1, (anyN || anyShort) ? 1 : 0};
     if (!anyN && (!gid || gid[t0] == gid[t1])) {
         const unsigned long long a = U.code[t0], b = U.code[t1];
         const int la = U.meta[t0] & 0xff, lb = U.meta[t1] & 0xff;
@@ -300,12 +305,13 @@ __device__ __forceinline__ int prefix_dist(unsigned long long x, int m, unsigned
 }
 
 template <int L>
-__global__ void k_tile_pairs(const TileInfo* info, int nt, int tile_lo, int tile_hi, uint32_t* list, unsigned int* count) {
+__global__ void k_tile_pairs(const TileInfo* info, int nt, int tile_lo, int tile_hi, int special_only, uint32_t* list, unsigned int* count) {
     const int bj = blockIdx.x * blockDim.x + threadIdx.x;
     const int bi = blockIdx.y + tile_lo;
     if (bi >= tile_hi || bj >= nt || bj < bi) return;
     bool keep = true;
-    if (bj != bi) {
+    if (special_only && !info[bi].special && !info[bj].special) keep = false;
+    if (keep && bj != bi) {
         const TileInfo R = info[bi], C = info[bj];
         if (R.plen >= 0 && C.plen >= 0) {
             // either orientation may prove that the tiles hold no neighbours
@@ -376,6 +382,7 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
     const int la = ma & 0xff, nNa = (ma >> 8) & 0xff;
     const int gi = (row_on && A.gid) ? A.gid[i] : (row_on ? 0 : -2);
     const int limit = A.lim2 / 2;
+    const bool row_special = A.special_lreq < 0 || na != 0u || la < A.special_lreq;
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t* const q1 = s_q1[wv];   // pairs that passed the length / composition bounds
     uint32_t* const q2 = s_q2[wv];   // ... and the shifted-Hamming bound: exact DP pending
@@ -465,6 +472,7 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
             const int l1 = static_cast<int>(__builtin_amdgcn_sad_u8(compa, ck.z, 0u)) + (nNa > nNb ? nNa - nNb : nNb - nNa);
             const bool anyN = (na | ck.w) != 0u;
             pass = pass && 2 * dl <= A.lim2 && l1 <= (anyN ? 2 * A.lim2 : A.lim2);
+            pass = pass && (row_special || ck.w != 0u || lb < A.special_lreq);
         }
         const unsigned long long mask = __ballot(pass);
         if (mask) {
@@ -613,6 +621,323 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs_long(const PairArgs A) {
                 A.edges[slot] = (static_cast<unsigned long long>(bi * TILE + t) << 32) | static_cast<unsigned>(bj * TILE + jj);
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Split-key neighbour search for thresholds 2 and 3 on large sets.
+//
+// The all-tile-pairs search above looks at every pair: at threshold 3 on 12-base UMIs its length, composition and
+// shifted-Hamming bounds pass most of them on to the exact DP.  The search below enumerates candidates instead.
+// Let lev(a, b) <= k for N-free a, b, and fix h, s with h + s <= |a|.  An optimal alignment sends a[0..h) to a prefix
+// b1 of b and the rest of a to the rest of b; the costs of the two parts sum to <= k.  So with k1 + k2 = k - 1
+//     P(a,b): some prefix of b is within k1 edits of the first h bases of a,  or
+//     S(a,b): some suffix of b is within k2 edits of the last s bases of a
+// (the last s bases of a lie inside the second part, and the part of an alignment that covers them costs no more than
+// the whole).  With k1, k2 <= 1 the strings b that satisfy P(a, .) are those that start with one of the <= 8h + 5
+// one-edit variants of a[0..h) -- a union of contiguous ranges of the set in trie order; S(a, .) the same in the order
+// of the reversed strings.  Rows that share their first h bases share the ranges, so the work items are (row group,
+// 256 candidate columns); a lane holds one column as the pattern of a bit-vector edit distance (Myers 1999 / Hyyro
+// 2003, global variant) and the rows of the group stream through as the text, from scalar registers.
+// Every pair {a, b} is reported once, from its lower-ranked member a: by the prefix scan if P(a, b), else by the
+// suffix scan (which evaluates P(a, b) on the first h + 1 bases to leave those pairs to the prefix scan).  Only a
+// needs h + s <= |a|, so the rows are scanned by length class, each with keys of half its length (at most 8 bases),
+// against columns of any length.
+// Strings with an N (a masked base costs half an edit: the argument above does not hold) or shorter than 8 bases are
+// "special": their pairs come from the tile kernel restricted to pairs with a special member.
+// The result is the same set of pairs as the tile search (tests: both against the oracle and against each other).
+
+struct SkElem {
+    uint32_t plo, phi;   // bit planes of the 2-bit codes, base i at bit i; the scan order's own orientation
+    uint32_t meta;       // len | special << 6 | (first 9 bases of the FORWARD string, 2 bits each) << 8
+    uint32_t rank;       // rank in trie order
+};
+
+struct SkOrder {
+    SkElem* el;                  // [n] in scan order
+    unsigned long long* okey;    // [n] 3 bits per base (A..T = 1..4, N = 5, past the end = 0), first 21 bases, in scan order
+    int* gid;                    // [n] pre-group in scan order (nullptr: one group)
+    int n;
+};
+
+__device__ __forceinline__ uint32_t sk_even_bits(unsigned long long x) {   // bits 0, 2, 4, ... of x -> bits 0, 1, 2, ...
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+    x = (x | (x >> 16)) & 0x00000000ffffffffull;
+    return static_cast<uint32_t>(x);
+}
+
+__device__ __forceinline__ unsigned long long sk_order_key(uint32_t plo, uint32_t phi, uint32_t nmask, int len) {
+    unsigned long long k = 0;
+    const int m = min(len, 21);
+    for (int i = 0; i < m; ++i) {
+        const unsigned long long d = ((nmask >> i) & 1u) ? 5ull : 1ull + ((plo >> i) & 1u) + 2ull * ((phi >> i) & 1u);
+        k |= d << (3 * (20 - i));
+    }
+    return k;
+}
+
+__global__ void __launch_bounds__(256) k_sk_lenhist(UmiArrays U, int n, unsigned int* hist /* [34]: lengths 0..32, [33] strings with an N */) {
+    __shared__ unsigned int s_h[34];
+    if (threadIdx.x < 34) s_h[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        atomicAdd(&s_h[min(static_cast<int>(U.meta[i] & 0xff), 32)], 1u);
+        if (U.nmask[i]) atomicAdd(&s_h[33], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 34 && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+
+// Elements in trie order (REV = false) or, per trie rank, the reversed string with its sort key (REV = true).
+template <bool REV>
+__global__ void k_sk_elems(UmiArrays U, int n, int lreq, SkElem* el, unsigned long long* okey, int* val) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long code = U.code[i];
+    const uint32_t nm = U.nmask[i];
+    const int len = U.meta[i] & 0xff;
+    uint32_t plo = sk_even_bits(code), phi = sk_even_bits(code >> 1), nmo = nm;
+    if (REV && len > 0) { plo = __brev(plo) >> (32 - len); phi = __brev(phi) >> (32 - len); nmo = __brev(nm) >> (32 - len); }
+    const uint32_t special = (nm != 0u || len < lreq) ? 1u : 0u;
+    el[i] = SkElem{plo, phi, static_cast<uint32_t>(len) | (special << 6) | (static_cast<uint32_t>(code & 0x3ffffull) << 8), static_cast<uint32_t>(i)};
+    okey[i] = sk_order_key(plo, phi, nmo, len);
+    if (REV) val[i] = i;
+}
+
+__global__ void k_sk_permute(const SkElem* el, const int* val, const int* gid, int n, SkElem* out, int* gid_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = val[i];
+    out[i] = el[r];
+    if (gid_out) gid_out[i] = gid[r];
+}
+
+// Row groups: maximal runs of the scan order that share pre-group and first h bases.
+__global__ void k_sk_group_flags(SkOrder O, int h, int* flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > O.n) return;
+    if (i == O.n) { flag[i] = 0; return; }
+    bool f = i == 0;
+    if (!f) {
+        const int sh = 3 * (21 - h);
+        f = (O.okey[i] >> sh) != (O.okey[i - 1] >> sh) || (O.gid && O.gid[i] != O.gid[i - 1]);
+    }
+    flag[i] = f ? 1 : 0;
+}
+
+__global__ void k_sk_group_starts(const int* flag, const long long* pos, int n, int* start) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { start[pos[n]] = n; return; }
+    if (flag[i]) start[pos[i]] = i;
+}
+
+constexpr int SK_MAXR = 72;    // ranges per row group: 1 + 3h + h + 4(h + 1) <= 69 for h <= 8
+constexpr int SK_ROWS = 128;   // rows per work item
+constexpr int SK_COLS = 256;   // candidate columns per work item (one per thread)
+
+// first index of the scan order whose (pre-group, key) is >= (g, k) [upper = false] or > (g, k) [upper = true]
+__device__ __forceinline__ int sk_bound(const SkOrder& O, int g, unsigned long long k, bool upper) {
+    int lo = 0, hi = O.n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int gm = O.gid ? O.gid[mid] : 0;
+        const unsigned long long km = O.okey[mid];
+        const bool before = gm != g ? gm < g : (upper ? km <= k : km < k);
+        if (before) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// The candidate columns of every row group: ranges of the scan order that start with a variant (<= k1 edits) of the
+// group's first h bases, merged, as (start, candidates before it); `clip`: columns from the group's own start on
+// (trie order: a pair is reported from its lower-ranked member).
+__global__ void k_sk_ranges(SkOrder O, const int* rg_start, int nrg, int h, int k1, int clip,
+                            int2* ranges, int* nranges, int* ctotal, long long* items) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > nrg) return;
+    if (g == nrg) { items[g] = 0; return; }
+    const int r0 = rg_start[g], r1 = rg_start[g + 1];
+    const unsigned long long key = O.okey[r0];
+    const int grp = O.gid ? O.gid[r0] : 0;
+    int d[10];
+    bool plain = true;   // first h bases present and N-free
+    for (int i = 0; i < h; ++i) { d[i] = static_cast<int>((key >> (3 * (20 - i))) & 7ull); plain = plain && d[i] >= 1 && d[i] <= 4; }
+    int lo[SK_MAXR], hi[SK_MAXR], nr = 0;
+    auto add = [&](const int* v, int m) {
+        unsigned long long k = 0;
+        for (int i = 0; i < m; ++i) k |= static_cast<unsigned long long>(v[i]) << (3 * (20 - i));
+        const unsigned long long fill = (1ull << (3 * (21 - m))) - 1ull;
+        int a = sk_bound(O, grp, k, false);
+        const int b = sk_bound(O, grp, k | fill, true);
+        if (clip) a = max(a, r0);
+        if (a >= b) return;
+        // insert by start
+        int p = nr++;
+        while (p > 0 && lo[p - 1] > a) { lo[p] = lo[p - 1]; hi[p] = hi[p - 1]; --p; }
+        lo[p] = a; hi[p] = b;
+    };
+    if (plain) {
+        int v[10];
+        for (int i = 0; i < h; ++i) v[i] = d[i];
+        add(v, h);
+        if (k1 >= 1) {
+            for (int p = 0; p < h; ++p) {           // substitutions
+                for (int c = 1; c <= 4; ++c) if (c != d[p]) { v[p] = c; add(v, h); }
+                v[p] = d[p];
+            }
+            for (int p = 0; p < h; ++p) {           // one base of the h missing in b
+                if (p > 0 && d[p] == d[p - 1]) continue;   // the same string as deleting p - 1
+                int m = 0;
+                for (int i = 0; i < h; ++i) if (i != p) v[m++] = d[i];
+                add(v, h - 1);
+            }
+            for (int p = 0; p <= h; ++p)            // one more base in b
+                for (int c = 1; c <= 4; ++c) {
+                    if (p < h && c == d[p]) continue;      // the same string as inserting after the run
+                    int m = 0;
+                    for (int i = 0; i < p; ++i) v[m++] = d[i];
+                    v[m++] = c;
+                    for (int i = p; i < h; ++i) v[m++] = d[i];
+                    add(v, h + 1);
+                }
+        }
+    }
+    // merge overlapping ranges
+    int out = 0, total = 0;
+    int2* R = ranges + static_cast<long long>(g) * SK_MAXR;
+    int ca = 0, cb = 0;
+    for (int i = 0; i < nr; ++i) {
+        if (i == 0) { ca = lo[0]; cb = hi[0]; continue; }
+        if (lo[i] <= cb) { cb = max(cb, hi[i]); continue; }
+        R[out++] = make_int2(ca, total); total += cb - ca;
+        ca = lo[i]; cb = hi[i];
+    }
+    if (nr) { R[out++] = make_int2(ca, total); total += cb - ca; }
+    nranges[g] = out;
+    ctotal[g] = total;
+    items[g] = static_cast<long long>((r1 - r0 + SK_ROWS - 1) / SK_ROWS) * ((total + SK_COLS - 1) / SK_COLS);
+}
+
+// P(x, y): some prefix of y (ly bases long) within k1 (0 or 1) edits of the first h bases of x; x, y: 2-bit codes of the
+// first 9 bases (zero beyond the end) -- exactly "y starts with one of the variants k_sk_ranges lists for x".
+__device__ __forceinline__ bool sk_prefix_within(uint32_t x, uint32_t y, int ly, int h, int k1) {
+    auto mism = [](uint32_t u) { return (u | (u >> 1)) & 0x55555555u; };
+    const uint32_t mh = (1u << (2 * h)) - 1u;
+    const uint32_t d0 = mism(x ^ y) & mh;
+    if (ly >= h && __popc(d0) <= k1) return true;
+    if (k1 == 0 || ly < h - 1) return false;
+    const int f = d0 ? (__builtin_ctz(d0) >> 1) : h;             // first mismatch
+    const uint32_t d1 = mism((x >> 2) ^ y) & (mh >> 2);          // x[p + 1] against y[p], p < h - 1
+    const uint32_t d2 = mism(x ^ (y >> 2)) & mh;                 // x[p] against y[p + 1], p < h
+    if ((d1 >> (2 * min(f, h - 1))) == 0u) return true;          // x without its base p is a prefix of y
+    return ly >= h + 1 && (d2 >> (2 * min(f, h))) == 0u;         // x with one base inserted at p is a prefix of y
+}
+
+struct SkScanArgs {
+    const SkElem* el;
+    const int* rg_start;
+    int nrg;
+    const int2* ranges;
+    const int* nranges;
+    const int* ctotal;
+    const long long* item_off;     // [nrg + 1] exclusive
+    unsigned item_stride;          // block b works on item b * item_stride (1; larger: a sample)
+    int limit, h, k1;              // threshold; the prefix split (the suffix scan's check of P)
+    int len_lo, len_hi;            // rows of this launch: lengths len_lo..len_hi (their keys are h and s bases long)
+    uint32_t row_lo, row_hi;       // trie ranks of the rows this launch reports (row tiles shard across GPUs)
+    unsigned long long* edges;
+    unsigned long long* count;
+    unsigned long long cap;
+};
+
+template <bool SUFFIX>
+__global__ void __launch_bounds__(SK_COLS) k_sk_scan(const SkScanArgs A) {
+    __shared__ int2 s_rng[SK_MAXR];
+    __shared__ unsigned long long s_q[SK_COLS / 64][128];
+    __shared__ SkElem s_rows[SK_ROWS];
+    const int t = threadIdx.x, lane = t & 63;
+    const long long item = static_cast<long long>(blockIdx.x) * A.item_stride;
+    int g = 0;
+    {
+        int lo = 0, hi = A.nrg;   // item_off[lo] <= item < item_off[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (A.item_off[mid] <= item) lo = mid; else hi = mid; }
+        g = lo;
+    }
+    const int r0g = A.rg_start[g], r1g = A.rg_start[g + 1];
+    const int C = A.ctotal[g], ncc = (C + SK_COLS - 1) / SK_COLS;
+    const long long local = item - A.item_off[g];
+    const int rc = static_cast<int>(local / ncc), cc = static_cast<int>(local % ncc);
+    const int r0 = r0g + rc * SK_ROWS, r1 = min(r0 + SK_ROWS, r1g);
+    const int nr = A.nranges[g];
+    if (t < nr) s_rng[t] = A.ranges[static_cast<long long>(g) * SK_MAXR + t];
+    if (t < r1 - r0) s_rows[t] = A.el[r0 + t];
+    __syncthreads();
+    const int vc = cc * SK_COLS + t;
+    int col = -1;
+    if (vc < C) {
+        int a = 0, b = nr;
+        while (b - a > 1) { const int m = (a + b) >> 1; if (s_rng[m].y <= vc) a = m; else b = m; }
+        col = s_rng[a].x + (vc - s_rng[a].y);
+    }
+    SkElem e{0u, 0u, 1u | (1u << 6), 0u};
+    if (col >= 0) e = A.el[col];
+    const int lb = e.meta & 63;
+    const bool valid = col >= 0 && !((e.meta >> 6) & 1u);
+    const int sh = 32 - (valid ? lb : 1);
+    const uint32_t pl = e.plo << sh, ph = e.phi << sh, pat = ~0u << sh, low = (2u << sh) - 1u;
+    const uint32_t cfwd = e.meta >> 8;
+    unsigned long long* const q = s_q[t >> 6];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int nq = 0;
+    auto flush = [&](int count) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(A.count, static_cast<unsigned long long>(count));
+        base = (static_cast<unsigned long long>(__shfl(static_cast<int>(base >> 32), 0)) << 32) | static_cast<unsigned>(__shfl(static_cast<int>(base), 0));
+        if (lane < count && base + lane < A.cap) A.edges[base + lane] = q[lane];
+    };
+    for (int r = r0; r < r1; ++r) {
+        const SkElem R = s_rows[r - r0];   // the same address in every lane: one broadcast read
+        const uint32_t rmeta = __builtin_amdgcn_readfirstlane(R.meta);
+        const uint32_t rrank = __builtin_amdgcn_readfirstlane(R.rank);
+        const int la = rmeta & 63;
+        if (((rmeta >> 6) & 1u) || la < A.len_lo || la > A.len_hi) continue;
+        if (rrank < A.row_lo || rrank >= A.row_hi) continue;
+        const uint32_t tlo = __builtin_amdgcn_readfirstlane(R.plo), thi = __builtin_amdgcn_readfirstlane(R.phi);
+        uint32_t Pv = pat, Mv = 0u, HP = 0u, HM = 0u;
+        for (int j = 0; j < la; ++j) {
+            const uint32_t m0 = 0u - ((tlo >> j) & 1u), m1 = 0u - ((thi >> j) & 1u);
+            const uint32_t Eq = ~((pl ^ m0) | (ph ^ m1)) & pat;
+            const uint32_t Xv = Eq | Mv;
+            const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            uint32_t Ph = Mv | ~(Xh | Pv);
+            uint32_t Mh = Pv & Xh;
+            HP = __builtin_amdgcn_alignbit(HP, Ph, 31);
+            HM = __builtin_amdgcn_alignbit(HM, Mh, 31);
+            Ph = (Ph << 1) | low;
+            Mh <<= 1;
+            Pv = Mh | ~(Xv | Ph);
+            Mv = Ph & Xv;
+        }
+        const int d = lb + __popc(HP) - __popc(HM);
+        bool hit = valid && d <= A.limit && e.rank > rrank;   // a pair is reported from its lower-ranked member
+        if (SUFFIX) hit = hit && !sk_prefix_within(rmeta >> 8, cfwd, lb, A.h, A.k1);
+        const unsigned long long ball = __ballot(hit);
+        if (ball) {
+            if (hit) q[nq + __popcll(ball & lt)] = (static_cast<unsigned long long>(rrank) << 32) | e.rank;
+            nq += __popcll(ball);
+            if (nq >= 64) {
+                flush(64);
+                const unsigned long long moved = (64 + lane < nq) ? q[64 + lane] : 0ull;
+                if (64 + lane < nq) q[lane] = moved;
+                nq -= 64;
+            }
+        }
+    }
+    if (nq) flush(nq);
 }
 
 __global__ void k_lev_dense_long(UmiArrays U, int n, double* out) {
@@ -886,7 +1211,8 @@ struct ClusterTop {
     int cap;
 };
 
-__global__ void k_cl_keys_top(ClusterState S, ClusterTop T) {
+__global__ void __launch_bounds__(1024) k_cl_keys_top(ClusterState S, ClusterTop T) {
+    __shared__ int s_live[16], s_max[16];
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     int rem = 0;
     if (v < S.n && S.state[v] == 0 && S.remaining[v] > 0) rem = S.remaining[v];
@@ -895,7 +1221,13 @@ __global__ void k_cl_keys_top(ClusterState S, ClusterTop T) {
     int m = rem;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
-    if ((threadIdx.x & 63) == 0 && live) { atomicAdd(S.live, __popcll(live)); atomicMax(T.maxrem, m); }
+    if ((threadIdx.x & 63) == 0) { s_live[threadIdx.x >> 6] = __popcll(live); s_max[threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int nl = 0, mm = 0;
+        for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) { nl += s_live[w]; mm = max(mm, s_max[w]); }
+        if (nl) { atomicAdd(S.live, nl); atomicMax(T.maxrem, mm); }
+    }
 }
 
 __global__ void k_cl_collect(ClusterState S, ClusterTop T, int delta) {
@@ -1070,6 +1402,7 @@ struct SortedUmis {
     int* gid;      // pre-group per rank (nullptr: a single group)
     int n;
     int words;     // 1: every string has at most 32 bases; UMI_LONG_WORDS otherwise
+    int ngroups;   // pre-groups (1 when gid is nullptr)
 };
 
 // Encode one set of UMIs (optionally the members of a pre-group) and order it like the trie.
@@ -1128,7 +1461,9 @@ static int encode_and_rank(const std::string& p, const uint8_t* d_chars, const i
         SL_TRY(sort_pairs_u64_i32(p.c_str(), klo, k2, idx2, idx, n, 64, s));
     }
     out->gid = nullptr;
+    out->ngroups = 1;
     if (d_gid && ngroups > 1) {  // most significant key: the pre-group
+        out->ngroups = ngroups;
         int* gsorted;
         SL_TRY(scratch((p + ".gid").c_str(), n, &gsorted));
         hipLaunchKernelGGL(k_gather_gid, dim3(nblk(n, 256)), dim3(256), 0, s, d_gid, idx, klo, static_cast<int*>(nullptr), n);
@@ -1144,6 +1479,165 @@ static int encode_and_rank(const std::string& p, const uint8_t* d_chars, const i
     return 0;
 }
 
+static int exclusive_scan_i64(const char* tag, const long long* in, long long* out, size_t n, hipStream_t s) {
+    size_t tmp = 0;
+    SL_HIP(rocprim::exclusive_scan(nullptr, tmp, in, out, 0ll, n, rocprim::plus<long long>(), s));
+    void* d_tmp;
+    SL_TRY(ctx().buffer((std::string(tag) + ".scantmp").c_str(), tmp ? tmp : 16, &d_tmp));
+    SL_HIP(rocprim::exclusive_scan(d_tmp, tmp, in, out, 0ll, n, rocprim::plus<long long>(), s));
+    return 0;
+}
+
+// ---- split-key search: host side ----
+constexpr int SK_MIN_N = 32768;          // below this (or with pre-groups averaging under half of it) the all-tile-pairs search is quick enough
+
+constexpr int SK_MIN_LEN = 8;            // shorter strings are "special" (keys under 4 bases select too much)
+constexpr int SK_MAX_KEY = 8;            // bases per key at most (9 bases of the forward string travel with every element)
+
+struct SkClass { int len_lo, len_hi, h, s; };
+
+struct SkPlan {
+    std::vector<SkClass> classes;   // row lengths present in the set, with the key lengths they scan with
+    int k1 = 0, k2 = 0;             // edits allowed in the prefix / suffix key
+    long long nspecial = 0;
+};
+
+struct SkScan {          // one scan order with row groups for one key length, ready to launch
+    SkOrder O{};
+    int key = 0;
+    int* rg_start = nullptr;
+    int nrg = 0;
+    int2* ranges = nullptr;
+    int *nranges = nullptr, *ctotal = nullptr;
+    long long* item_off = nullptr;
+    long long nitems = 0;
+};
+
+// The lengths present decide the scans: one class per length 8..15 and one for 16 and longer.
+static int sk_plan(const std::string& p, const SortedUmis& S, int limit, SkPlan* plan, hipStream_t s) {
+    unsigned int* d_hist;
+    SL_TRY(scratch((p + ".sk.hist").c_str(), 34, &d_hist));
+    SL_HIP(hipMemsetAsync(d_hist, 0, 34 * sizeof(unsigned int), s));
+    hipLaunchKernelGGL(k_sk_lenhist, dim3(std::min(nblk(S.n, 256), 1024u)), dim3(256), 0, s, S.U, S.n, d_hist);
+    unsigned int hist[34];
+    SL_HIP(hipMemcpyAsync(hist, d_hist, sizeof hist, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    plan->classes.clear();
+    for (int L = SK_MIN_LEN; L <= 2 * SK_MAX_KEY; ++L) {
+        long long rows = hist[L];
+        if (L == 2 * SK_MAX_KEY) for (int M = L + 1; M <= 32; ++M) rows += hist[M];
+        if (!rows) continue;
+        const int h = std::min(L / 2, SK_MAX_KEY);
+        plan->classes.push_back(SkClass{L, L == 2 * SK_MAX_KEY ? 32 : L, h, std::min(L - h, SK_MAX_KEY)});
+    }
+    plan->k1 = 1;
+    plan->k2 = limit - 2;   // limit 2: the suffix key has to match exactly; limit 3: one edit
+    long long shorter = 0;
+    for (int L = 0; L < SK_MIN_LEN; ++L) shorter += hist[L];
+    plan->nspecial = shorter + hist[33];   // an upper bound (short strings with an N count twice)
+    return 0;
+}
+
+static int sk_prepare(const std::string& p, const SkOrder& O, int h, int k1, bool clip, SkScan* out, hipStream_t s) {
+    const int n = O.n;
+    int* d_flag; long long* d_pos;
+    SL_TRY(scratch((p + ".flag").c_str(), static_cast<size_t>(n) + 1, &d_flag));
+    SL_TRY(scratch((p + ".pos").c_str(), static_cast<size_t>(n) + 1, &d_pos));
+    hipLaunchKernelGGL(k_sk_group_flags, dim3(nblk(n + 1, 256)), dim3(256), 0, s, O, h, d_flag);
+    SL_TRY(exclusive_scan_i32(p.c_str(), d_flag, d_pos, static_cast<size_t>(n) + 1, s));
+    long long nrg = 0;
+    SL_HIP(hipMemcpyAsync(&nrg, d_pos + n, sizeof nrg, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    out->O = O;
+    out->key = h;
+    out->nrg = static_cast<int>(nrg);
+    SL_TRY(scratch((p + ".start").c_str(), static_cast<size_t>(nrg) + 1, &out->rg_start));
+    SL_TRY(scratch((p + ".ranges").c_str(), static_cast<size_t>(nrg) * SK_MAXR + 1, &out->ranges));
+    SL_TRY(scratch((p + ".nranges").c_str(), static_cast<size_t>(nrg) + 1, &out->nranges));
+    SL_TRY(scratch((p + ".ctotal").c_str(), static_cast<size_t>(nrg) + 1, &out->ctotal));
+    long long* d_items;
+    SL_TRY(scratch((p + ".items").c_str(), static_cast<size_t>(nrg) + 1, &d_items));
+    SL_TRY(scratch((p + ".itemoff").c_str(), static_cast<size_t>(nrg) + 1, &out->item_off));
+    hipLaunchKernelGGL(k_sk_group_starts, dim3(nblk(n + 1, 256)), dim3(256), 0, s, d_flag, d_pos, n, out->rg_start);
+    hipLaunchKernelGGL(k_sk_ranges, dim3(nblk(nrg + 1, 64)), dim3(64), 0, s, O, out->rg_start, out->nrg, h, k1, clip ? 1 : 0,
+                       out->ranges, out->nranges, out->ctotal, d_items);
+    SL_HIP(hipGetLastError());
+    SL_TRY(exclusive_scan_i64(p.c_str(), d_items, out->item_off, static_cast<size_t>(nrg) + 1, s));
+    SL_HIP(hipMemcpyAsync(&out->nitems, out->item_off + nrg, sizeof(long long), hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+// Both scan orders with their row groups and candidate ranges.
+static int sk_build(const std::string& p, const SortedUmis& S, const SkPlan& plan, std::vector<SkScan>* fwd, std::vector<SkScan>* rev, hipStream_t s) {
+    const int n = S.n;
+    SkOrder X{}, Y{};
+    X.n = Y.n = n;
+    X.gid = S.gid;
+    SL_TRY(scratch((p + ".sk.elx").c_str(), static_cast<size_t>(n), &X.el));
+    SL_TRY(scratch((p + ".sk.keyx").c_str(), static_cast<size_t>(n), &X.okey));
+    hipLaunchKernelGGL(k_sk_elems<false>, dim3(nblk(n, 256)), dim3(256), 0, s, S.U, n, SK_MIN_LEN, X.el, X.okey, static_cast<int*>(nullptr));
+    // reversed strings: sort by key (then by pre-group, stably), carry the trie rank
+    SkElem* d_tmp; unsigned long long *d_rk, *d_rk2; int *d_val, *d_val2;
+    SL_TRY(scratch((p + ".sk.eltmp").c_str(), static_cast<size_t>(n), &d_tmp));
+    SL_TRY(scratch((p + ".sk.rk").c_str(), static_cast<size_t>(n), &d_rk));
+    SL_TRY(scratch((p + ".sk.rk2").c_str(), static_cast<size_t>(n), &d_rk2));
+    SL_TRY(scratch((p + ".sk.val").c_str(), static_cast<size_t>(n), &d_val));
+    SL_TRY(scratch((p + ".sk.val2").c_str(), static_cast<size_t>(n), &d_val2));
+    SL_TRY(scratch((p + ".sk.ely").c_str(), static_cast<size_t>(n), &Y.el));
+    hipLaunchKernelGGL(k_sk_elems<true>, dim3(nblk(n, 256)), dim3(256), 0, s, S.U, n, SK_MIN_LEN, d_tmp, d_rk, d_val);
+    SL_HIP(hipGetLastError());
+    SL_TRY(sort_pairs_u64_i32(p.c_str(), d_rk, d_rk2, d_val, d_val2, static_cast<size_t>(n), 63, s));
+    Y.okey = d_rk2;
+    int* order = d_val2;
+    if (S.gid) {
+        unsigned long long *d_gk, *d_gk2;
+        SL_TRY(scratch((p + ".sk.gk").c_str(), static_cast<size_t>(n), &d_gk));
+        SL_TRY(scratch((p + ".sk.gk2").c_str(), static_cast<size_t>(n), &d_gk2));
+        hipLaunchKernelGGL(k_cl_gidkey, dim3(nblk(n, 256)), dim3(256), 0, s, S.gid, d_val2, static_cast<long long>(n), d_gk);
+        SL_TRY(sort_pairs_u64_i32(p.c_str(), d_gk, d_gk2, d_val2, d_val, static_cast<size_t>(n), ceil_log2(static_cast<unsigned long long>(S.ngroups) + 1), s));
+        order = d_val;
+        // keys in the final order
+        hipLaunchKernelGGL(k_sk_elems<true>, dim3(nblk(n, 256)), dim3(256), 0, s, S.U, n, SK_MIN_LEN, d_tmp, d_rk, d_val2);
+        hipLaunchKernelGGL(k_gather_u64, dim3(nblk(n, 256)), dim3(256), 0, s, d_rk, order, d_rk2, n);
+        SL_TRY(scratch((p + ".sk.gidy").c_str(), static_cast<size_t>(n), &Y.gid));
+    }
+    hipLaunchKernelGGL(k_sk_permute, dim3(nblk(n, 256)), dim3(256), 0, s, d_tmp, order, S.gid, n, Y.el, Y.gid);
+    SL_HIP(hipGetLastError());
+    // row groups and ranges once per key length in use; the prefix scan starts at the row group itself (columns
+    // ranked below the row report the pair themselves)
+    const bool clip = true;
+    fwd->clear(); rev->clear();
+    for (const SkClass& c : plan.classes) {
+        bool have = false;
+        for (const SkScan& q : *fwd) have = have || q.key == c.h;
+        if (!have) { fwd->emplace_back(); SL_TRY(sk_prepare(p + ".skx" + std::to_string(c.h), X, c.h, plan.k1, clip, &fwd->back(), s)); }
+        have = false;
+        for (const SkScan& q : *rev) have = have || q.key == c.s;
+        if (!have) { rev->emplace_back(); SL_TRY(sk_prepare(p + ".sky" + std::to_string(c.s), Y, c.s, plan.k2, false, &rev->back(), s)); }
+    }
+    return 0;
+}
+
+static long long sk_launch(const std::vector<SkScan>& F, const std::vector<SkScan>& R, const SkPlan& plan, int limit, uint32_t row_lo, uint32_t row_hi,
+                           unsigned stride, unsigned long long* edges, unsigned long long* count, unsigned long long cap, hipStream_t s) {
+    long long items = 0;
+    for (const SkClass& c : plan.classes)
+        for (int pass = 0; pass < 2; ++pass) {
+            const SkScan* Q = nullptr;
+            for (const SkScan& q : pass ? R : F) if (q.key == (pass ? c.s : c.h)) Q = &q;
+            if (!Q) continue;
+            const long long blocks = (Q->nitems + stride - 1) / stride;
+            if (blocks <= 0) continue;
+            items += Q->nitems;
+            SkScanArgs a{Q->O.el, Q->rg_start, Q->nrg, Q->ranges, Q->nranges, Q->ctotal, Q->item_off, stride, limit, c.h, plan.k1,
+                         c.len_lo, c.len_hi, row_lo, row_hi, edges, count, cap};
+            if (pass) hipLaunchKernelGGL(k_sk_scan<true>, dim3(static_cast<unsigned>(blocks)), dim3(SK_COLS), 0, s, a);
+            else hipLaunchKernelGGL(k_sk_scan<false>, dim3(static_cast<unsigned>(blocks)), dim3(SK_COLS), 0, s, a);
+        }
+    return items;
+}
+
 template <int K>
 static void launch_pairs(const PairArgs& a, int tile_hi, unsigned ntiles_listed, hipStream_t s) {
     const unsigned nt = nblk(a.n, TILE);
@@ -1156,9 +1650,9 @@ static void launch_pairs(const PairArgs& a, int tile_hi, unsigned ntiles_listed,
 }
 
 template <int L>
-static void launch_tile_pairs(const TileInfo* info, int nt, int tile_lo, int tile_hi, uint32_t* list, unsigned int* count, hipStream_t s) {
+static void launch_tile_pairs(const TileInfo* info, int nt, int tile_lo, int tile_hi, int special_only, uint32_t* list, unsigned int* count, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_pairs<L>, dim3(nblk(nt, 256), static_cast<unsigned>(tile_hi - tile_lo)), dim3(256), 0, s, info, nt,
-                       tile_lo, tile_hi, list, count);
+                       tile_lo, tile_hi, special_only, list, count);
 }
 
 struct DirectedKeys {
@@ -1189,12 +1683,30 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
         SL_TRY(c.buffer((p + ".edges").c_str(), cap * sizeof(unsigned long long), &pe));
         d_edges = static_cast<unsigned long long*>(pe);
     }
+    // Thresholds 2 and 3 on a large set: candidates from the split keys (see k_sk_scan); the tile kernel then only
+    // looks at the pairs with a "special" member, if there are any.
+    SkPlan plan;
+    std::vector<SkScan> fwd, rev;
+    const int min_n = option(OPT_UMI_SPLIT_MIN) > 0 ? option(OPT_UMI_SPLIT_MIN) : SK_MIN_N;
+    bool split = S.words == 1 && (limit == 2 || limit == 3) && n >= min_n && !option(OPT_UMI_TILE_SEARCH) &&
+                 n / std::max(S.ngroups, 1) >= min_n / 2;
+    if (split) {
+        SL_TRY(sk_plan(p, S, limit, &plan, s));
+        split = !plan.classes.empty() && 4 * plan.nspecial <= n;
+    }
+    if (split) SL_TRY(sk_build(p, S, plan, &fwd, &rev, s));
+    const int special_lreq = split ? SK_MIN_LEN : -1;
+    long long split_items = 0;
+    const bool tiles = !split || plan.nspecial > 0;
+    c.counts["umi_split_search"] = split ? 1 : 0;
+    c.counts["umi_split_classes"] = split ? static_cast<double>(plan.classes.size()) : 0;
+    c.counts["umi_split_special"] = split ? static_cast<double>(plan.nspecial) : 0;
     // tile pairs that can hold neighbours (see k_tile_pairs); worth it from a few dozen tiles on
     const uint32_t* d_list = nullptr;
     const TileInfo* d_subinfo = nullptr;
     unsigned int nlisted = 0;
     const long long ntp = static_cast<long long>(tile_hi - tile_lo) * nt;
-    if (S.words == 1 && limit >= 0 && limit <= 5 && nt >= 16 && ntp <= (1ll << 31)) {
+    if (tiles && S.words == 1 && limit >= 0 && limit <= 5 && nt >= 16 && ntp <= (1ll << 31)) {
         TileInfo* d_info; uint32_t* d_l; unsigned int* d_lc;
         SL_TRY(scratch((p + ".tinfo").c_str(), static_cast<size_t>(nt), &d_info));
         // the list is bounded by the upper triangle of the launch
@@ -1202,57 +1714,36 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
         SL_TRY(scratch((p + ".tlist").c_str(), max_list, &d_l));
         SL_TRY(scratch((p + ".tcount").c_str(), 1, &d_lc));
         SL_HIP(hipMemsetAsync(d_lc, 0, sizeof(unsigned int), s));
-        hipLaunchKernelGGL(k_tile_info<TILE>, dim3(static_cast<unsigned>(nt)), dim3(TILE), 0, s, S.U, S.gid, n, d_info);
+        hipLaunchKernelGGL(k_tile_info<TILE>, dim3(static_cast<unsigned>(nt)), dim3(TILE), 0, s, S.U, S.gid, n, std::max(special_lreq, 0), d_info);
         // prefixes of the 64-element blocks for the sub-tile filter inside the pair kernel
         TileInfo* d_sub;
         const unsigned nsub = nblk(n, 64);
         SL_TRY(scratch((p + ".tsub").c_str(), static_cast<size_t>(nsub), &d_sub));
-        hipLaunchKernelGGL(k_tile_info<64>, dim3(nsub), dim3(64), 0, s, S.U, S.gid, n, d_sub);
+        hipLaunchKernelGGL(k_tile_info<64>, dim3(nsub), dim3(64), 0, s, S.U, S.gid, n, 0, d_sub);
         d_subinfo = d_sub;
+        const int so = split ? 1 : 0;
         switch (limit) {
-            case 0: launch_tile_pairs<0>(d_info, nt, tile_lo, tile_hi, d_l, d_lc, s); break;
-            case 1: launch_tile_pairs<1>(d_info, nt, tile_lo, tile_hi, d_l, d_lc, s); break;
-            case 2: launch_tile_pairs<2>(d_info, nt, tile_lo, tile_hi, d_l, d_lc, s); break;
-            case 3: launch_tile_pairs<3>(d_info, nt, tile_lo, tile_hi, d_l, d_lc, s); break;
-            case 4: launch_tile_pairs<4>(d_info, nt, tile_lo, tile_hi, d_l, d_lc, s); break;
-            default: launch_tile_pairs<5>(d_info, nt, tile_lo, tile_hi, d_l, d_lc, s); break;
+            case 0: launch_tile_pairs<0>(d_info, nt, tile_lo, tile_hi, so, d_l, d_lc, s); break;
+            case 1: launch_tile_pairs<1>(d_info, nt, tile_lo, tile_hi, so, d_l, d_lc, s); break;
+            case 2: launch_tile_pairs<2>(d_info, nt, tile_lo, tile_hi, so, d_l, d_lc, s); break;
+            case 3: launch_tile_pairs<3>(d_info, nt, tile_lo, tile_hi, so, d_l, d_lc, s); break;
+            case 4: launch_tile_pairs<4>(d_info, nt, tile_lo, tile_hi, so, d_l, d_lc, s); break;
+            default: launch_tile_pairs<5>(d_info, nt, tile_lo, tile_hi, so, d_l, d_lc, s); break;
         }
         SL_HIP(hipGetLastError());
         SL_HIP(hipMemcpyAsync(&nlisted, d_lc, sizeof nlisted, hipMemcpyDeviceToHost, s));
         SL_HIP(hipStreamSynchronize(s));
         d_list = d_l;
     }
-    // Capacity of the pair buffer: 32 per element covers thresholds 1 and 2; dense neighbourhoods (threshold 3 on 12-base
-    // UMIs: hundreds of neighbours each) would overflow it and cost a second full search, so the density is first
-    // estimated from a sample of the listed tile pairs (k_tile_pairs appends them in no particular order).
-    if (d_list && nlisted >= 2048 && limit >= 0) {
-        const unsigned stride = 32, ns = nlisted / stride;   // every 32nd listed tile pair
-        SL_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
-        PairArgs a{S.U, S.gid, n, lim2, d_edges, d_count, cap, tile_lo, d_list, d_subinfo, stride};
-        const int K = std::min(limit, UMI_MAXLEN);
-        if (K <= 0) launch_pairs<0>(a, tile_hi, ns, s);
-        else if (K == 1) launch_pairs<1>(a, tile_hi, ns, s);
-        else if (K == 2) launch_pairs<2>(a, tile_hi, ns, s);
-        else if (K == 3) launch_pairs<3>(a, tile_hi, ns, s);
-        else if (K == 4) launch_pairs<4>(a, tile_hi, ns, s);
-        else launch_pairs<5>(a, tile_hi, ns, s);
-        SL_HIP(hipGetLastError());
-        unsigned long long ms = 0;
-        SL_HIP(hipMemcpyAsync(&ms, d_count, sizeof ms, hipMemcpyDeviceToHost, s));
-        SL_HIP(hipStreamSynchronize(s));
-        const double est = static_cast<double>(ms) * static_cast<double>(nlisted) / static_cast<double>(ns);
-        cap = std::max<unsigned long long>(cap, static_cast<unsigned long long>(est * 1.25) + (1u << 20));
-        ctx().counts["umi_pairs_estimated"] = est;
-    }
-    for (int attempt = 0; attempt < 2 && limit >= 0; ++attempt) {
-        void* pe;
-        SL_TRY(c.buffer((p + ".edges").c_str(), cap * sizeof(unsigned long long), &pe));
-        d_edges = static_cast<unsigned long long*>(pe);
-        SL_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
-        PairArgs a{S.U, S.gid, n, lim2, d_edges, d_count, cap, tile_lo, d_list, d_subinfo, 1u};
-        SL_HIP(hipEventRecord(c.ev_start, s));
-        c.stage_reset("umi_pairs");
-        SL_TRY(c.stage_begin("umi_pairs", s));
+    const uint32_t row_lo = static_cast<uint32_t>(std::min<long long>(static_cast<long long>(tile_lo) * TILE, n));
+    const uint32_t row_hi = static_cast<uint32_t>(std::min<long long>(static_cast<long long>(tile_hi) * TILE, n));
+    // every search kernel of one pass over the set; `stride` > 1: a sample (every stride-th tile pair / work item)
+    auto launch_all = [&](unsigned stride, unsigned long long capacity) {
+        if (split && row_hi > row_lo) split_items = sk_launch(fwd, rev, plan, limit, row_lo, row_hi, stride, d_edges, d_count, capacity, s);
+        if (!tiles) return;
+        PairArgs a{S.U, S.gid, n, lim2, d_edges, d_count, capacity, tile_lo, d_list, d_subinfo, stride, special_lreq};
+        const unsigned listed = d_list ? nlisted / stride : 0u;
+        if (stride > 1 && !d_list) return;   // a sample needs the list
         const int K = std::min(limit, UMI_MAXLEN);
         if (S.words > 1) {
             if (tile_hi > tile_lo) {
@@ -1267,15 +1758,46 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
                 else hipLaunchKernelGGL(k_umi_pairs_long<-1>, grid, dim3(TILE), 0, s, a);
             }
         }
-        else if (K <= 0) launch_pairs<0>(a, tile_hi, nlisted, s);
-        else if (K == 1) launch_pairs<1>(a, tile_hi, nlisted, s);
-        else if (K == 2) launch_pairs<2>(a, tile_hi, nlisted, s);
-        else if (K == 3) launch_pairs<3>(a, tile_hi, nlisted, s);
-        else if (K == 4) launch_pairs<4>(a, tile_hi, nlisted, s);
-        else if (K == 5) launch_pairs<5>(a, tile_hi, nlisted, s);
-        else if (K <= 8) launch_pairs<8>(a, tile_hi, nlisted, s);
-        else if (K <= 16) launch_pairs<16>(a, tile_hi, nlisted, s);
-        else launch_pairs<UMI_MAXLEN>(a, tile_hi, nlisted, s);
+        else if (K <= 0) launch_pairs<0>(a, tile_hi, listed, s);
+        else if (K == 1) launch_pairs<1>(a, tile_hi, listed, s);
+        else if (K == 2) launch_pairs<2>(a, tile_hi, listed, s);
+        else if (K == 3) launch_pairs<3>(a, tile_hi, listed, s);
+        else if (K == 4) launch_pairs<4>(a, tile_hi, listed, s);
+        else if (K == 5) launch_pairs<5>(a, tile_hi, listed, s);
+        else if (K <= 8) launch_pairs<8>(a, tile_hi, listed, s);
+        else if (K <= 16) launch_pairs<16>(a, tile_hi, listed, s);
+        else launch_pairs<UMI_MAXLEN>(a, tile_hi, listed, s);
+    };
+    // Capacity of the pair buffer: 32 per element covers thresholds 1 and 2; dense neighbourhoods (threshold 3 on 12-base
+    // UMIs: hundreds of neighbours each) would overflow it and cost a second full search, so the density is first
+    // estimated from a sample: every 32nd listed tile pair (k_tile_pairs appends them in no particular order) and
+    // every 32nd work item of the split-key scans.
+    const bool sample_tiles = d_list && nlisted >= 2048;
+    long long all_items = 0;
+    for (const SkScan& q : fwd) all_items += q.nitems;
+    for (const SkScan& q : rev) all_items += q.nitems;
+    const bool sample_items = split && all_items >= 2048;
+    if (limit >= 0 && (sample_tiles || sample_items) && (!tiles || d_list)) {
+        const unsigned stride = 32;
+        SL_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
+        launch_all(stride, cap);
+        SL_HIP(hipGetLastError());
+        unsigned long long ms = 0;
+        SL_HIP(hipMemcpyAsync(&ms, d_count, sizeof ms, hipMemcpyDeviceToHost, s));
+        SL_HIP(hipStreamSynchronize(s));
+        const double est = static_cast<double>(ms) * stride;
+        cap = std::max<unsigned long long>(cap, static_cast<unsigned long long>(est * 1.25) + (1u << 20));
+        ctx().counts["umi_pairs_estimated"] = est;
+    }
+    for (int attempt = 0; attempt < 2 && limit >= 0; ++attempt) {
+        void* pe;
+        SL_TRY(c.buffer((p + ".edges").c_str(), cap * sizeof(unsigned long long), &pe));
+        d_edges = static_cast<unsigned long long*>(pe);
+        SL_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
+        SL_HIP(hipEventRecord(c.ev_start, s));
+        c.stage_reset("umi_pairs");
+        SL_TRY(c.stage_begin("umi_pairs", s));
+        launch_all(1u, cap);
         SL_HIP(hipGetLastError());
         SL_HIP(hipEventRecord(c.ev_stop, s));
         SL_TRY(c.stage_end("umi_pairs", s));
@@ -1284,8 +1806,9 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
         SL_HIP(hipStreamSynchronize(s));
         ctx().counts["umi_pair_attempts"] = attempt + 1;
         if (m <= cap) break;
-        cap = m;  // the kernel kept counting: second attempt has the exact size
+        cap = m;  // the kernels kept counting: second attempt has the exact size
     }
+    c.counts["umi_split_items"] = static_cast<double>(split_items);
     *d_edges_out = d_edges;
     *m_out = m;
     return 0;
@@ -1457,7 +1980,7 @@ static int cluster_dev(const DevAdj& adj, int n, const int32_t* d_members, const
         SL_HIP(hipMemsetAsync(S.live, 0, sizeof(int), s));
         if (top_rounds) {
             SL_HIP(hipMemsetAsync(T.maxrem, 0, sizeof(int), s));
-            hipLaunchKernelGGL(k_cl_keys_top, g, b, 0, s, S, T);
+            hipLaunchKernelGGL(k_cl_keys_top, dim3(nblk(n, 1024)), dim3(1024), 0, s, S, T);
         } else {
             hipLaunchKernelGGL(k_cl_keys, g, b, 0, s, S);
         }

@@ -206,6 +206,85 @@ def test_dense_neighbourhoods_both_round_schemes(oracle):
         calls.set_option("umi_full_rounds", 0)
 
 
+def noisy_umis(rng, molecules, lo, hi, n_rate=0.0, short=0):
+    """Copies of random molecules with substitutions, insertions and deletions; optionally Ns and a few short strings."""
+    out = []
+    for _ in range(molecules):
+        ref = list(rng.choice(list("ACGT"), int(rng.integers(lo, hi + 1))))
+        for _ in range(int(rng.integers(1, 7))):
+            t = list(ref)
+            for _ in range(int(rng.integers(0, 3))):
+                r = rng.random()
+                if r < 0.4:
+                    t[int(rng.integers(0, len(t)))] = str(rng.choice(list("ACGT")))
+                elif r < 0.7 and len(t) > lo:
+                    del t[int(rng.integers(0, len(t)))]
+                elif len(t) < 32:
+                    t.insert(int(rng.integers(0, len(t) + 1)), str(rng.choice(list("ACGT"))))
+            t = [("N" if rng.random() < n_rate else c) for c in t]
+            out.append("".join(t))
+    for _ in range(short):
+        out.append("".join(rng.choice(list("ACGT"), int(rng.integers(1, lo)))))
+    return [out[i] for i in rng.permutation(len(out))]
+
+
+@pytest.mark.parametrize("lo,hi,n_rate,short,split", [(12, 12, 0.0, 0, 1), (8, 11, 0.0, 0, 1), (9, 16, 0.01, 5, 1), (16, 20, 0.0, 3, 1),
+                                                      (10, 10, 0.02, 0, 1), (24, 32, 0.005, 4, 1),
+                                                      (10, 10, 0.06, 0, 0)])   # a quarter of the strings with an N: tile search
+def test_split_key_search_small_sets(oracle, lo, hi, n_rate, short, split):
+    # the candidate search of thresholds 2 and 3 (k_sk_scan), forced onto sets the oracle's trie walks in no time:
+    # the neighbour lists themselves, then the groups with and without pre-groups
+    from sarlacc_amd import SarlaccError, _lib, calls
+    rng = np.random.default_rng(lo * 100 + hi)
+    try:
+        calls.set_option("umi_split_min", 64)
+        for rep in range(3):
+            umis = noisy_umis(rng, 150, lo, hi, n_rate, short)
+            for t in (2, 3):
+                got = calls.fast_levdist_test(umis, t)
+                assert _lib.stage_count("umi_split_search") == split
+                same_lists(got, oracle.fast_levdist_test(umis, t))
+            n = len(umis)
+            pre = rng.integers(0, 2, n)
+            for groups in ([list(range(1, n + 1))], [(np.flatnonzero(pre == g) + 1).tolist() for g in range(2)]):
+                for t in (2, 3):
+                    try:
+                        want = oracle.umi_group(umis, t, None, t, groups, fast=True)
+                    except oracle.OracleError as e:
+                        with pytest.raises(SarlaccError, match=str(e)):
+                            calls.umi_group(umis, t, None, t, groups)
+                        continue
+                    same_lists(calls.umi_group(umis, t, None, t, groups), want)
+    finally:
+        calls.set_option("umi_split_min", 0)
+
+
+@pytest.mark.parametrize("threshold,n", [(2, 60000), (3, 30000)])
+def test_split_key_search_equals_tile_search_and_oracle(oracle, threshold, n):
+    # BASELINE config 3's shape (12-base UMIs, 10 reads per molecule, mockReads errors) from the size on where the split-key
+    # search takes over by itself: the same groups as the all-tile-pairs search and as the oracle
+    from sarlacc_amd import _lib, calls
+    from sarlacc_amd.mock import NUC, mutate
+    rng = np.random.default_rng(31 + threshold)
+    umis = []
+    for _ in range(n // 10):
+        truth = NUC[rng.integers(0, 4, 12)]
+        umis += [mutate(truth, rng).tobytes().decode() for _ in range(10)]
+    g = [list(range(1, len(umis) + 1))]
+    try:
+        calls.set_option("umi_split_min", 20000)   # 32768 by default
+        got = calls.umi_group(umis, threshold, None, threshold, g)
+        assert _lib.stage_count("umi_split_search") == 1
+        calls.set_option("umi_tile_search", 1)
+        tiles = calls.umi_group(umis, threshold, None, threshold, g)
+        assert _lib.stage_count("umi_split_search") == 0
+    finally:
+        calls.set_option("umi_tile_search", 0)
+        calls.set_option("umi_split_min", 0)
+    same_lists(got, tiles)
+    same_lists(got, oracle.umi_group(umis, threshold, None, threshold, g, fast=True))
+
+
 def test_mask_bad_bases(oracle, oenc, enc):
     from sarlacc_amd import SarlaccError, calls
     from sarlacc_amd.mock import random_reads
