@@ -298,27 +298,34 @@ def test_mask_bad_bases(oracle, oenc, enc):
         calls.mask_bad_bases(["ACGT"], ["II I"], enc, 0.1)
 
 
-def test_tile_sharded_pairs_reproduce_umi_group(oracle):
-    """The row-tile shards of the all-pairs search (what each GPU of a node would compute) put
-    together give exactly umi_group's result; shard boundaries balance the triangular work."""
-    from sarlacc_amd import calls
+@pytest.mark.parametrize("split_min", [0, 64])
+def test_tile_sharded_pairs_reproduce_umi_group(oracle, split_min):
+    """The row-tile shards of the pair search (what each GPU of a node would compute) put together give exactly
+    umi_group's result; shard boundaries balance the triangular work.  split_min 64: thresholds 2 and 3 through the
+    split-key search, whose scans report only the rows of the shard."""
+    from sarlacc_amd import _lib, calls
     rng = np.random.default_rng(21)
     umis = []
     for _ in range(300):
         umis += umisim(rng, 8, 12, rate=0.06)
     umis = [umis[i] for i in rng.permutation(len(umis))]
     g = [list(range(1, len(umis) + 1))]
-    for limit in (1, 2):
-        want = calls.umi_group(umis, limit, None, limit, g)
-        same_lists(want, oracle.umi_group(umis, limit, None, limit, g, fast=True))
-        for world in (1, 3, 8):
-            parts = [calls.umi_pairs_shard(umis, limit, r, world) for r in range(world)]
-            allp = np.concatenate(parts)
-            assert len(np.unique(allp)) == allp.size            # no pair is found twice
-            same_lists(calls.umi_group_from_pairs(umis, limit, allp), want)
-            if world == 8:
-                sizes = [p.size for p in parts]
-                assert max(sizes) > 0
+    try:
+        calls.set_option("umi_split_min", split_min)
+        for limit in (1, 2, 3):
+            want = calls.umi_group(umis, limit, None, limit, g)
+            same_lists(want, oracle.umi_group(umis, limit, None, limit, g, fast=True))
+            for world in (1, 3, 8):
+                parts = [calls.umi_pairs_shard(umis, limit, r, world) for r in range(world)]
+                assert _lib.stage_count("umi_split_search") == (1 if split_min and limit >= 2 else 0)
+                allp = np.concatenate(parts)
+                assert len(np.unique(allp)) == allp.size            # no pair is found twice
+                same_lists(calls.umi_group_from_pairs(umis, limit, allp), want)
+                if world == 8:
+                    sizes = [p.size for p in parts]
+                    assert max(sizes) > 0
+    finally:
+        calls.set_option("umi_split_min", 0)
 
 
 def test_umi_group_flat_matches_lists():

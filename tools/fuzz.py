@@ -79,6 +79,13 @@ def case_align(rng):
             assert g[2] == o[2] and g[3] == o[3], "general strings"
 
 
+def umi_switches(rng):
+    """Thresholds 2 and 3 through the split-key search also on small sets (half of the cases), dense graphs clustered
+    by rounds over every list instead of candidate sets (a quarter)."""
+    calls.set_option("umi_split_min", int(rng.choice([0, 16, 200])))
+    calls.set_option("umi_full_rounds", int(rng.random() < 0.25))
+
+
 def case_umi(rng):
     n = int(rng.integers(2, 400))
     length = int(rng.choice([0, 3, 8, 12, 20, 32, 33, 48, 80, 127]))   # beyond 32: the 4-word path (up to 128 bases)
@@ -96,6 +103,7 @@ def case_umi(rng):
             b.insert(int(rng.integers(0, len(b) + 1)), "ACGT"[int(rng.integers(0, 4))])
         umis.append("".join(b))
     limit = int(rng.integers(0, 5))
+    umi_switches(rng)
     ngr = int(rng.choice([1, 1, 3, 20]))
     lab = rng.integers(0, ngr, n)
     groups = [(np.flatnonzero(lab == k) + 1).astype(np.int32) for k in range(ngr)]
@@ -231,6 +239,7 @@ def case_umi_large(rng):
             t = t[:k] + "ACGT"[int(rng.integers(0, 4))] + t[k:]
         umis.append(t)
     limit = int(rng.integers(0, 4))
+    umi_switches(rng)
     ngr = int(rng.choice([1, 1, 2, 5]))
     lab = np.sort(rng.integers(0, ngr, n)) if rng.random() < 0.5 else rng.integers(0, ngr, n)
     groups = [(np.flatnonzero(lab == k) + 1).astype(np.int32) for k in range(ngr)]
