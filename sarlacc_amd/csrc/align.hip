@@ -40,7 +40,9 @@ namespace sarlacc {
 
 constexpr int NGMAX = 4;   // alignments processed side by side in one wavefront
 constexpr int NWAVES = 4;  // wavefronts per workgroup: they share one copy of the cost table in LDS
-constexpr int RING = 128;  // staged read positions per alignment (2 x 64)
+constexpr int RING = 128;        // staged read positions per alignment (2 x 64)
+constexpr int RING_MIRROR = 8;   // the first entries again behind the ring: a block of up to 8 steps reads base + 2u without wrapping
+constexpr int RING_SLOT = 256;   // uint16 entries reserved per alignment (512 B: a ring address is base | offset)
 constexpr int MAX_REF = 1024;
 
 struct AlignArgs {
@@ -148,7 +150,7 @@ struct Int { static constexpr int value = V; };
 // most SNAP_WIN steps with traceback codes; the leader walks the window and, should the path
 // leave it through the top, the next window up is recomputed.  A snapshot is the exact state
 // of the recurrence, so the recomputed cells are the cells of the first pass, bit for bit.
-constexpr int SNAP_P = 128;     // steps between snapshots (multiple of the 64-row staging block)
+constexpr int SNAP_P = 64;      // steps between snapshots (multiple of the 64-row staging block)
 // rows above the row a walk asks for that its window must cover: an alignment of R columns
 // rarely spans more than R + R/4 rows, and a longer one only costs another window
 static inline int snap_head(int R) { return R + R / 4 + 4; }
@@ -182,8 +184,8 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
     // LDS: read rings first (256 B per alignment, so a ring address is base | offset), then the
     // cost table shared by the waves of the workgroup, then the per-wave reference->read maps
     extern __shared__ __align__(256) unsigned char smem[];
-    static_assert(RING * sizeof(uint16_t) == 256, "ring addressing assumes 256 B per alignment");
-    constexpr int RING_BYTES = NWAVES * NGMAX * RING * static_cast<int>(sizeof(uint16_t));
+    static_assert(RING * sizeof(uint16_t) == 256 && RING + RING_MIRROR <= RING_SLOT, "ring addressing assumes 256 B of ring inside a 512 B slot");
+    constexpr int RING_BYTES = NWAVES * NGMAX * RING_SLOT * static_cast<int>(sizeof(uint16_t));
     double* const s_tab = reinterpret_cast<double*>(smem + RING_BYTES);
     // LDS byte address of smem (256-aligned), for hand-built LDS addresses
     const int lds0 = static_cast<int>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)smem));
@@ -201,7 +203,7 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
     const int GOhi = hi32(GO), GOlo = lo32(GO), GEhi = hi32(GE), GElo = lo32(GE);
 
     for (int x = threadIdx.x; x < A.tab_doubles; x += 64 * NWAVES) s_tab[x] = A.tables[x];
-    uint16_t* const s_ring = reinterpret_cast<uint16_t*>(smem) + wave * NGMAX * RING;
+    uint16_t* const s_ring = reinterpret_cast<uint16_t*>(smem) + wave * NGMAX * RING_SLOT;
     int32_t* const s_map = reinterpret_cast<int32_t*>(s_tab + A.tab_doubles) + wave * A.ngroups * (R + 1);
 
     double vgo[K], vge[K], rz[K];
@@ -226,7 +228,7 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
     // MODE 3: the tile holds the codes of one window, the snapshots follow it
     constexpr int NSV = 2 * K + 3;  // doubles per lane in a snapshot
     double* const snap = reinterpret_cast<double*>(scr + static_cast<size_t>(A.snap_win / UNR) * 64);
-    const int ring_g = lds0 + (wave * NGMAX + g) * static_cast<int>(RING * sizeof(uint16_t));  // byte address of this alignment's ring
+    const int ring_g = lds0 + (wave * NGMAX + g) * static_cast<int>(RING_SLOT * sizeof(uint16_t));  // byte address of this alignment's ring
     __syncthreads();
 
     const long long nitems = (A.n + A.ngroups - 1) / A.ngroups;
@@ -256,38 +258,79 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
             if (gg < A.ngroups && item * A.ngroups + gg < A.n) Lmin = min(Lmin, glen[gg]);
         }
 
-        // read staging: fetch 64 positions per alignment one refill ahead of use;
-        // a staged entry is quality | base code << 8 (0-3 = ACGT, 4 = anything else)
-        auto fetch = [&](int gg, int r0) -> uint32_t {
-            const int r = r0 + lane;
-            uint32_t v = 0;
-            if (r < glen[gg]) {
-                const long long idx = gstart[gg] + r;
-                uint32_t code;
+        // Read staging, one refill (64 positions per alignment) ahead of use: lane -> (alignment sg = lane / 16, four
+        // consecutive positions), so one pass of the wave stages all four alignments.  A staged entry is the byte
+        // offset of (base code, quality) inside a block of table rows; base codes 0-3 = ACGT, 4 = anything else.
+        const int sg = lane >> 4, sq = (lane & 15) * 4;
+        const int sgl = sg < A.ngroups ? sg * W : 0;
+        const int slen_any = __shfl(L, sgl);   // every lane takes part: a source lane switched off would read as 0
+        const int slen = sg < A.ngroups ? slen_any : 0;
+        const long long sstart = (static_cast<long long>(__shfl(static_cast<int>(start >> 32), sgl)) << 32) |
+                                 static_cast<unsigned>(__shfl(static_cast<int>(start), sgl));
+        int stoff = 0;   // this lane's alignment: first step of the window being recomputed (toff[sg])
+        struct Pf { uint32_t q, b; };   // four qualities (one per byte); four 2-bit base codes | four exception bits << 8
+        auto fetch4 = [&](int r0) -> Pf {
+            const int r = r0 + sq;
+            const int nv = min(max(slen - r, 0), 4);
+            Pf v{0u, 0u};
+            if (nv == 0) return v;
+            const long long idx = sstart + r;
+            if (nv == 4) {
+                __builtin_memcpy(&v.q, A.qual + idx, 4);   // every byte read lies inside the read (no over-read of caller memory)
                 if (A.nmask) {  // 2-bit packed bases + exception mask (sarlacc_dev_pack_reads)
-                    const uint32_t two = (A.seq[idx >> 2] >> ((idx & 3) * 2)) & 3u;
-                    const uint32_t exc = (A.nmask[idx >> 3] >> (idx & 7)) & 1u;
-                    code = exc ? 4u : two;
+                    const uint32_t two = (A.seq[idx >> 2] | (static_cast<uint32_t>(A.seq[(idx + 3) >> 2]) << 8)) >> ((idx & 3) * 2);
+                    const uint32_t exc = (A.nmask[idx >> 3] | (static_cast<uint32_t>(A.nmask[(idx + 3) >> 3]) << 8)) >> (idx & 7);
+                    v.b = (two & 0xffu) | ((exc & 0xfu) << 8);
                 } else {
-                    const uint32_t b = A.seq[idx];
-                    code = b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u;
+                    uint32_t s4;
+                    __builtin_memcpy(&s4, A.seq + idx, 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t b = (s4 >> (8 * e)) & 0xffu;
+                        const uint32_t x = (b >> 1) & 3u, code = x ^ (x >> 1);         // A C G T -> 0 1 2 3
+                        const uint32_t exc = ((0x54474341u >> (8 * code)) & 0xffu) != b;   // anything else
+                        v.b |= (code << (2 * e)) | (exc << (8 + e));
+                    }
                 }
-                v = A.qual[idx] | (code << 8);
+                return v;
+            }
+            for (int e = 0; e < nv; ++e) {   // the last positions of a read
+                v.q |= static_cast<uint32_t>(A.qual[idx + e]) << (8 * e);
+                uint32_t code, exc;
+                if (A.nmask) {
+                    code = (A.seq[(idx + e) >> 2] >> (((idx + e) & 3) * 2)) & 3u;
+                    exc = (A.nmask[(idx + e) >> 3] >> ((idx + e) & 7)) & 1u;
+                } else {
+                    const uint32_t b = A.seq[idx + e];
+                    code = b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 0u;
+                    exc = !(b == 'A' || b == 'C' || b == 'G' || b == 'T');
+                }
+                v.b |= (code << (2 * e)) | (exc << (8 + e));
             }
             return v;
         };
-        auto stage = [&](int gg, int r0, uint32_t v) {
-            const int r = r0 + lane;
-            int qi = static_cast<int>(static_cast<signed char>(v & 0xff)) - A.qoffset;
-            if (r < glen[gg] && qi < 0) atomicMin(A.badqual, A.read_base + static_cast<int>(item * A.ngroups + gg));
-            qi = qi < 0 ? 0 : (qi >= A.navail ? A.navail - 1 : qi);
-            // byte offset of (base code, quality) inside a block of table rows
-            s_ring[gg * RING + (r & (RING - 1))] = static_cast<uint16_t>((v >> 8) * A.row_bytes + (qi << 3));
+        auto stage4 = [&](int r0, Pf v) {
+            const int r = r0 + sq;
+            uint32_t ent[4];
+            bool bad = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int qi = static_cast<int>(static_cast<signed char>((v.q >> (8 * e)) & 0xffu)) - A.qoffset;
+                bad = bad || (r + e < slen && qi < 0);
+                qi = qi < 0 ? 0 : (qi >= A.navail ? A.navail - 1 : qi);
+                const uint32_t code = ((v.b >> (8 + e)) & 1u) ? 4u : ((v.b >> (2 * e)) & 3u);
+                ent[e] = (r + e < slen) ? code * static_cast<uint32_t>(A.row_bytes) + static_cast<uint32_t>(qi << 3) : 0u;
+            }
+            if (bad) atomicMin(A.badqual, A.read_base + static_cast<int>(item * A.ngroups + sg));
+            const uint2 w = make_uint2(ent[0] | (ent[1] << 16), ent[2] | (ent[3] << 16));
+            uint16_t* const slot = s_ring + sg * RING_SLOT + (r & (RING - 1));   // r is a multiple of 4: 8-byte aligned
+            *reinterpret_cast<uint2*>(slot) = w;
+            if ((r & (RING - 1)) < RING_MIRROR) *reinterpret_cast<uint2*>(slot + RING) = w;
         };
-        uint32_t pf[NGMAX];
+        Pf pf = fetch4(0);
         int toff[NGMAX];  // first step of the window being recomputed (MODE 3), per alignment; 0 in the fill
 #pragma unroll
-        for (int gg = 0; gg < NGMAX; ++gg) { pf[gg] = fetch(gg, 0); toff[gg] = 0; }
+        for (int gg = 0; gg < NGMAX; ++gg) toff[gg] = 0;
 
         // per-column state: score of the previous row, vertical jump score (and, PENSEL only,
         // the penalty the next vertical step pays)
@@ -326,11 +369,10 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
             mask_t m_vnl = GUARD ? 0 : __builtin_amdgcn_ballot_w64(vnl != 0);
             for (int t0 = t_begin; t0 < t_end; t0 += UNR) {
                 if ((t0 & 63) == 0) {
-#pragma unroll
-                    for (int gg = 0; gg < NGMAX; ++gg) {
-                        stage(gg, toff[gg] + t0, pf[gg]);
-                        pf[gg] = fetch(gg, toff[gg] + t0 + 64);
-                    }
+                    int t0s = t0;   // opaque copy: keeps the staging addresses out of the step loop's induction variables
+                    asm volatile("" : "+s"(t0s));
+                    stage4(stoff + t0s, pf);
+                    pf = fetch4(stoff + t0s + 64);
                     if (TR == 2 && (t0 & (SNAP_P - 1)) == 0) {
                         // complete lane state before step t0
                         double* sp = snap + static_cast<size_t>(t0 / SNAP_P) * (NSV * 64) + lane;
@@ -346,6 +388,8 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
                 }
                 Word pk = 0;
                 double v_first = 0.0;   // TR 2: vertical candidate of column R at the block's first step
+                // ring address of the block's first row; the following rows sit behind it (mirror: no wrap inside a block)
+                const uint32_t ring_blk = static_cast<uint32_t>(ring_g | (x2 & 0xff));
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     if (!ROW16) {
@@ -360,7 +404,7 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
                     bool act = true;
                     if (GUARD) act = x2 >= 0 && x2 <= x2max;
                     if (act) {
-                        const int rd = *reinterpret_cast<lds_cu16*>(static_cast<uint32_t>(ring_g | (x2 & 0xff)));
+                        const int rd = *reinterpret_cast<lds_cu16*>(ring_blk + 2u * u);
                         double diag = diag_prev;
                         diag_prev = s_in;
 #pragma unroll
@@ -537,11 +581,9 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
                 diag_prev = sp[(2 * K + 2) * 64];
                 x2 = 2 * (ts - j - 1);
                 x2max = pending ? 2 * L - 2 : -2;
-#pragma unroll
-                for (int gg = 0; gg < NGMAX; ++gg) {
-                    if (toff[gg] >= 64) stage(gg, toff[gg] - 64, fetch(gg, toff[gg] - 64));
-                    pf[gg] = fetch(gg, toff[gg]);
-                }
+                stoff = sg == 0 ? toff[0] : sg == 1 ? toff[1] : sg == 2 ? toff[2] : toff[3];
+                if (stoff >= 64) stage4(stoff - 64, fetch4(stoff - 64));
+                pf = fetch4(stoff);
                 run(Flag<true>{}, Int<3>{}, 0, t_wa);
                 run(Flag<false>{}, Int<3>{}, t_wa, t_wb);
                 run(Flag<true>{}, Int<3>{}, t_wb, nwin);
@@ -1022,7 +1064,7 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     a.snap_head = snap_head(R); a.snap_win = snap_win(R, sh.W);
     a.aln_ref = out.d_aln_ref; a.aln_qry = out.d_aln_qry; a.aln_len = out.d_aln_len; a.edits = out.d_edits;
 
-    const size_t lds = sizeof(uint16_t) * NWAVES * NGMAX * RING + sizeof(double) * rows.size() +
+    const size_t lds = sizeof(uint16_t) * NWAVES * NGMAX * RING_SLOT + sizeof(double) * rows.size() +
                        sizeof(int32_t) * NWAVES * sh.ngroups * (R + 1) + 16;
     if (lds > 64 * 1024) return fail("sarlacc_amd: alignment tables do not fit in LDS");
     SL_HIP(hipEventRecord(c.ev_start, stream));
