@@ -38,7 +38,8 @@
 
 namespace sarlacc {
 
-constexpr int NGMAX = 4;   // alignments processed side by side in one wavefront
+constexpr int NGMAX = 4;   // alignments processed side by side in one wavefront (groups of 16 lanes or more)
+constexpr int NGMAX2 = 8;  // ... with two 8-lane alignments interleaved in every 16-lane DPP row (ROWF 2)
 constexpr int NWAVES = 4;  // wavefronts per workgroup: they share one copy of the cost table in LDS
 constexpr int RING = 128;        // staged read positions per alignment (2 x 64)
 constexpr int RING_MIRROR = 8;   // the first entries again behind the ring: a block of up to 8 steps reads base + 2u without wrapping
@@ -117,18 +118,22 @@ __device__ __forceinline__ double mk64(int hi, int lo) {
     return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
 }
 
-// Shift by one lane towards higher lanes.  ROW16: inside each 16-lane DPP row (row_shr:1); the
-// first lane of every row -- the leader of an alignment when groups are 16 lanes wide -- has no
-// source lane and keeps `keep` (its DP column 0 value: pass the destination itself and the
-// constant set before the loop stays there for free).  Otherwise across the whole wave.
-template <bool ROW16>
+// Hand a value to the lane that owns the next columns of the same alignment.  ROWF 1: alignments are 16 lanes wide
+// and start on DPP row boundaries (row_shr:1); the first lane of every row -- the leader of an alignment -- has no
+// source lane and keeps `keep` (its DP column 0 value: pass the destination itself and the constant set before the
+// loop stays there for free).  ROWF 2: two 8-lane alignments share a DPP row, one in the even and one in the odd
+// lanes, and the hand-over is row_shr:2 -- lanes 0 and 1 of the row are the two leaders and again have no source.
+// Twice the columns per lane at the same width in columns: half the cross-lane moves per cell.  ROWF 0: across
+// the whole wave (wave_shr:1), leaders overwrite what arrives.
+template <int ROWF>
 __device__ __forceinline__ int lane_shr1(int v, int keep) {
-    if (ROW16) return __builtin_amdgcn_update_dpp(keep, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    if (ROWF == 1) return __builtin_amdgcn_update_dpp(keep, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    if (ROWF == 2) return __builtin_amdgcn_update_dpp(keep, v, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
     return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
-template <bool ROW16>
+template <int ROWF>
 __device__ __forceinline__ double lane_shr1(double v, double keep) {
-    return mk64(lane_shr1<ROW16>(hi32(v), hi32(keep)), lane_shr1<ROW16>(lo32(v), lo32(keep)));
+    return mk64(lane_shr1<ROWF>(hi32(v), hi32(keep)), lane_shr1<ROWF>(lo32(v), lo32(keep)));
 }
 
 template <int K>
@@ -161,7 +166,8 @@ static inline int snap_win(int R, int W) { return (SNAP_P + snap_head(R) + W + 7
 // MODE 2: scores + gapped strings + edit distance (general_align).
 // MODE 3: as MODE 1 by snapshots + windowed recompute (LOCAL, !PENSEL only; see SNAP_P).
 // LOCAL: free leading read bases + free vertical gaps in the last column (adaptor mode).
-// ROW16: alignments are 16 lanes wide and start on DPP row boundaries.
+// ROWF: 0 alignments of any width, wave-wide shifts; 1 alignments are 16 lanes wide and start on DPP row
+// boundaries; 2 alignments are 8 lanes wide, two interleaved per DPP row (see lane_shr1).
 // KLAST: index (inside its lane) of reference column R when known at compile time, else -1.
 // PENSEL: select the gap penalty of every step explicitly (only needed when gapopen < 0).
 //
@@ -175,8 +181,13 @@ static inline int snap_win(int R, int W) { return (SNAP_P + snap_head(R) + W + 7
 // subtracts the opening penalty and selects nothing.  Only the "jump continued" flag differs
 // (true instead of false), and the true flag is raw && !(previous cell's move is the same gap
 // kind) -- the traceback applies that from the neighbour's code, which it reads anyway.
-template <int K, int MODE, bool LOCAL, bool ROW16, int KLAST, bool PENSEL>
+template <int K, int MODE, bool LOCAL, int ROWF, int KLAST, bool PENSEL>
 __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const AlignArgs A) {
+    constexpr bool ROW16 = ROWF != 0;                      // leaders keep their column-0 inputs through the DPP fill operand
+    constexpr int NG = ROWF == 2 ? NGMAX2 : NGMAX;         // alignments per wavefront at most
+    // uint16 entries per alignment's ring slot: 512 B slots let a ring address be base | offset; with eight
+    // alignments per wave the slots are packed (ring + mirror) and the address is an add
+    constexpr int SLOT = ROWF == 2 ? RING + RING_MIRROR : RING_SLOT;
     constexpr int UNR = TbSteps<K>::value;
     constexpr int CELLS = UNR * K;
     using Word = typename TbStore<K>::type;
@@ -185,7 +196,8 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
     // cost table shared by the waves of the workgroup, then the per-wave reference->read maps
     extern __shared__ __align__(256) unsigned char smem[];
     static_assert(RING * sizeof(uint16_t) == 256 && RING + RING_MIRROR <= RING_SLOT, "ring addressing assumes 256 B of ring inside a 512 B slot");
-    constexpr int RING_BYTES = NWAVES * NGMAX * RING_SLOT * static_cast<int>(sizeof(uint16_t));
+    constexpr int RING_BYTES = NWAVES * NG * SLOT * static_cast<int>(sizeof(uint16_t));
+    static_assert(RING_BYTES % 8 == 0 && (SLOT * sizeof(uint16_t)) % 8 == 0, "table and 8-byte ring stores stay aligned");
     double* const s_tab = reinterpret_cast<double*>(smem + RING_BYTES);
     // LDS byte address of smem (256-aligned), for hand-built LDS addresses
     const int lds0 = static_cast<int>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)smem));
@@ -193,8 +205,10 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // tell the compiler it is wave-uniform
     const int W = A.W, R = A.R;
-    const int g = lane / W;
-    const int j = lane - g * W;
+    // lane <-> (alignment g of the wave, lane j inside it)
+    auto lane_of = [&](int gg, int jj) -> int { return ROWF == 2 ? ((gg >> 1) << 4) + (jj << 1) + (gg & 1) : gg * W + jj; };
+    const int g = ROWF == 2 ? (((lane >> 4) << 1) | (lane & 1)) : lane / W;
+    const int j = ROWF == 2 ? ((lane & 15) >> 1) : lane - g * W;
     const bool lane_on = g < A.ngroups;
     const bool leader = (j == 0);
     const int c0 = j * K + 1;
@@ -203,7 +217,7 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
     const int GOhi = hi32(GO), GOlo = lo32(GO), GEhi = hi32(GE), GElo = lo32(GE);
 
     for (int x = threadIdx.x; x < A.tab_doubles; x += 64 * NWAVES) s_tab[x] = A.tables[x];
-    uint16_t* const s_ring = reinterpret_cast<uint16_t*>(smem) + wave * NGMAX * RING_SLOT;
+    uint16_t* const s_ring = reinterpret_cast<uint16_t*>(smem) + wave * NG * SLOT;
     int32_t* const s_map = reinterpret_cast<int32_t*>(s_tab + A.tab_doubles) + wave * A.ngroups * (R + 1);
 
     double vgo[K], vge[K], rz[K];
@@ -215,7 +229,8 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
         // compute garbage that nothing reads (their outputs only feed a leader or an idle lane)
         const int cc = c <= R ? c : R;
         colbase[k] = lds0 + RING_BYTES + static_cast<int>(A.colbase[cc]);
-        const bool last = LOCAL && cc == R;
+        // only column R is "last"; with KLAST known it sits at k == KLAST, every other k takes the penalties from SGPRs
+        const bool last = LOCAL && cc == R && (KLAST < 0 || k == KLAST);
         vgo[k] = last ? 0.0 : GO;
         vge[k] = last ? 0.0 : GE;
         rz[k] = A.rowzero[cc];
@@ -228,7 +243,7 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
     // MODE 3: the tile holds the codes of one window, the snapshots follow it
     constexpr int NSV = 2 * K + 3;  // doubles per lane in a snapshot
     double* const snap = reinterpret_cast<double*>(scr + static_cast<size_t>(A.snap_win / UNR) * 64);
-    const int ring_g = lds0 + (wave * NGMAX + g) * static_cast<int>(RING_SLOT * sizeof(uint16_t));  // byte address of this alignment's ring
+    const int ring_g = lds0 + (wave * NG + g) * static_cast<int>(SLOT * sizeof(uint16_t));  // byte address of this alignment's ring
     __syncthreads();
 
     const long long nitems = (A.n + A.ngroups - 1) / A.ngroups;
@@ -241,13 +256,13 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
             start = A.off[read];
             L = static_cast<int>(A.off[read + 1] - start);
         }
-        // wave-uniform description of the (up to NGMAX) reads of this work item, kept in SGPRs
-        long long gstart[NGMAX];
-        int glen[NGMAX];
+        // wave-uniform description of the (up to NG) reads of this work item, kept in SGPRs
+        long long gstart[NG];
+        int glen[NG];
         int Lmax = 0, Lmin = 0x7fffffff;
 #pragma unroll
-        for (int gg = 0; gg < NGMAX; ++gg) {
-            const int src = gg < A.ngroups ? gg * W : 0;
+        for (int gg = 0; gg < NG; ++gg) {
+            const int src = gg < A.ngroups ? lane_of(gg, 0) : 0;
             const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(start), src));
             const int hi = __builtin_amdgcn_readlane(static_cast<int>(start >> 32), src);
             const int len = __builtin_amdgcn_readlane(L, src);
@@ -259,17 +274,24 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
         }
 
         // Read staging, one refill (64 positions per alignment) ahead of use: lane -> (alignment sg = lane / 16, four
-        // consecutive positions), so one pass of the wave stages all four alignments.  A staged entry is the byte
-        // offset of (base code, quality) inside a block of table rows; base codes 0-3 = ACGT, 4 = anything else.
-        const int sg = lane >> 4, sq = (lane & 15) * 4;
-        const int sgl = sg < A.ngroups ? sg * W : 0;
-        const int slen_any = __shfl(L, sgl);   // every lane takes part: a source lane switched off would read as 0
-        const int slen = sg < A.ngroups ? slen_any : 0;
-        const long long sstart = (static_cast<long long>(__shfl(static_cast<int>(start >> 32), sgl)) << 32) |
-                                 static_cast<unsigned>(__shfl(static_cast<int>(start), sgl));
-        int stoff = 0;   // this lane's alignment: first step of the window being recomputed (toff[sg])
+        // consecutive positions), so one pass of the wave stages four alignments (two passes for eight).  A staged entry
+        // is the byte offset of (base code, quality) inside a block of table rows; base codes 0-3 = ACGT, 4 = anything else.
+        constexpr int NPASS = NG / 4;
+        const int sq = (lane & 15) * 4;
+        int sgs[NPASS], slens[NPASS], stoffs[NPASS];   // per pass: the alignment this lane stages, its length, its window start (toff[sg])
+        long long sstarts[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            sgs[ps] = (lane >> 4) + 4 * ps;
+            const int sgl = sgs[ps] < A.ngroups ? lane_of(sgs[ps], 0) : 0;
+            const int slen_any = __shfl(L, sgl);   // every lane takes part: a source lane switched off would read as 0
+            slens[ps] = sgs[ps] < A.ngroups ? slen_any : 0;
+            sstarts[ps] = (static_cast<long long>(__shfl(static_cast<int>(start >> 32), sgl)) << 32) |
+                          static_cast<unsigned>(__shfl(static_cast<int>(start), sgl));
+            stoffs[ps] = 0;
+        }
         struct Pf { uint32_t q, b; };   // four qualities (one per byte); four 2-bit base codes | four exception bits << 8
-        auto fetch4 = [&](int r0) -> Pf {
+        auto fetch4 = [&](int slen, long long sstart, int r0) -> Pf {
             const int r = r0 + sq;
             const int nv = min(max(slen - r, 0), 4);
             Pf v{0u, 0u};
@@ -309,7 +331,7 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
             }
             return v;
         };
-        auto stage4 = [&](int r0, Pf v) {
+        auto stage4 = [&](int sg, int slen, int r0, Pf v) {
             const int r = r0 + sq;
             uint32_t ent[4];
             bool bad = false;
@@ -323,14 +345,16 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
             }
             if (bad) atomicMin(A.badqual, A.read_base + static_cast<int>(item * A.ngroups + sg));
             const uint2 w = make_uint2(ent[0] | (ent[1] << 16), ent[2] | (ent[3] << 16));
-            uint16_t* const slot = s_ring + sg * RING_SLOT + (r & (RING - 1));   // r is a multiple of 4: 8-byte aligned
+            uint16_t* const slot = s_ring + sg * SLOT + (r & (RING - 1));   // r is a multiple of 4: 8-byte aligned
             *reinterpret_cast<uint2*>(slot) = w;
             if ((r & (RING - 1)) < RING_MIRROR) *reinterpret_cast<uint2*>(slot + RING) = w;
         };
-        Pf pf = fetch4(0);
-        int toff[NGMAX];  // first step of the window being recomputed (MODE 3), per alignment; 0 in the fill
+        Pf pf[NPASS];
 #pragma unroll
-        for (int gg = 0; gg < NGMAX; ++gg) toff[gg] = 0;
+        for (int ps = 0; ps < NPASS; ++ps) pf[ps] = fetch4(slens[ps], sstarts[ps], 0);
+        int toff[NG];  // first step of the window being recomputed (MODE 3), per alignment; 0 in the fill
+#pragma unroll
+        for (int gg = 0; gg < NG; ++gg) toff[gg] = 0;
 
         // per-column state: score of the previous row, vertical jump score (and, PENSEL only,
         // the penalty the next vertical step pays)
@@ -371,8 +395,11 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
                 if ((t0 & 63) == 0) {
                     int t0s = t0;   // opaque copy: keeps the staging addresses out of the step loop's induction variables
                     asm volatile("" : "+s"(t0s));
-                    stage4(stoff + t0s, pf);
-                    pf = fetch4(stoff + t0s + 64);
+#pragma unroll
+                    for (int ps = 0; ps < NPASS; ++ps) {
+                        stage4(sgs[ps], slens[ps], stoffs[ps] + t0s, pf[ps]);
+                        pf[ps] = fetch4(slens[ps], sstarts[ps], stoffs[ps] + t0s + 64);
+                    }
                     if (TR == 2 && (t0 & (SNAP_P - 1)) == 0) {
                         // complete lane state before step t0
                         double* sp = snap + static_cast<size_t>(t0 / SNAP_P) * (NSV * 64) + lane;
@@ -389,10 +416,10 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
                 Word pk = 0;
                 double v_first = 0.0;   // TR 2: vertical candidate of column R at the block's first step
                 // ring address of the block's first row; the following rows sit behind it (mirror: no wrap inside a block)
-                const uint32_t ring_blk = static_cast<uint32_t>(ring_g | (x2 & 0xff));
+                const uint32_t ring_blk = static_cast<uint32_t>(ROWF == 2 ? ring_g + (x2 & 0xff) : (ring_g | (x2 & 0xff)));
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    if (!ROW16) {
+                    if (ROWF == 0) {
                         // column 0 of the DP (src/reference_align.cpp:63-78): what a leader lane consumes
                         const int im1 = x2 >> 1;
                         const double col0 = (LOCAL || im1 < 0) ? 0.0 : (-GO - GE * static_cast<double>(im1));
@@ -496,18 +523,18 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
                     if (ROW16 && !LOCAL) {
                         const int i = (x2 >> 1) + 1;  // global mode: column 0 changes with the row
                         const double col0_next = (i < 0) ? 0.0 : (-GO - GE * static_cast<double>(i));
-                        s_in = lane_shr1<ROW16>(left, col0_next);
+                        s_in = lane_shr1<ROWF>(left, col0_next);
                     } else if (ROW16 && !GUARD) {
                         // s_in itself stays live as the next step's diagonal; the register that
                         // held it two steps ago is free and, on leader lanes, holds the same 0.0
-                        s_in = lane_shr1<ROW16>(left, s_two_back);
+                        s_in = lane_shr1<ROWF>(left, s_two_back);
                     } else {
-                        s_in = lane_shr1<ROW16>(left, s_in);
+                        s_in = lane_shr1<ROWF>(left, s_in);
                     }
-                    lj_in = lane_shr1<ROW16>(lj, lj_in);
+                    lj_in = lane_shr1<ROWF>(lj, lj_in);
                     if (PENSEL) {
-                        ph_in = lane_shr1<ROW16>(ph, ph_in);
-                        pl_in = lane_shr1<ROW16>(pl, pl_in);
+                        ph_in = lane_shr1<ROWF>(ph, ph_in);
+                        pl_in = lane_shr1<ROWF>(pl, pl_in);
                     }
                     x2 += 2;
                 }
@@ -538,7 +565,7 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
             int32_t* map = s_map + g * (R + 1);
             const Word* const wtile = scr;
             // walk state of the group's leader: position, and the jump chain being measured
-            int row = (__shfl(land_x2, g * W + jlast) >> 1) + 1, c = R;
+            int row = (__shfl(land_x2, lane_of(g, jlast)) >> 1) + 1, c = R;
             int phase = 0, chain_n = 0, chain_at = 0;
             unsigned cur = 0;
             int want = row;         // lowest row the next window has to hold
@@ -557,8 +584,8 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
                 // pending alignment inside its read (the others compute garbage nobody reads)
                 int nwin = 0, t_wa = 0, t_wb = 0x7fffffff;
 #pragma unroll
-                for (int gg = 0; gg < NGMAX; ++gg) {
-                    const int src = gg < A.ngroups ? gg * W : 0;
+                for (int gg = 0; gg < NG; ++gg) {
+                    const int src = gg < A.ngroups ? lane_of(gg, 0) : 0;
                     toff[gg] = __builtin_amdgcn_readlane(ts, src);
                     const int pend = __builtin_amdgcn_readlane(pending, src);
                     const int need = __builtin_amdgcn_readlane(want + W + 1 - ts, src);
@@ -581,9 +608,13 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
                 diag_prev = sp[(2 * K + 2) * 64];
                 x2 = 2 * (ts - j - 1);
                 x2max = pending ? 2 * L - 2 : -2;
-                stoff = sg == 0 ? toff[0] : sg == 1 ? toff[1] : sg == 2 ? toff[2] : toff[3];
-                if (stoff >= 64) stage4(stoff - 64, fetch4(stoff - 64));
-                pf = fetch4(stoff);
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int q = lane >> 4;   // sgs[ps] = q + 4 * ps
+                    stoffs[ps] = q == 0 ? toff[4 * ps] : q == 1 ? toff[4 * ps + 1] : q == 2 ? toff[4 * ps + 2] : toff[4 * ps + 3];
+                    if (stoffs[ps] >= 64) stage4(sgs[ps], slens[ps], stoffs[ps] - 64, fetch4(slens[ps], sstarts[ps], stoffs[ps] - 64));
+                    pf[ps] = fetch4(slens[ps], sstarts[ps], stoffs[ps]);
+                }
                 run(Flag<true>{}, Int<3>{}, 0, t_wa);
                 run(Flag<false>{}, Int<3>{}, t_wa, t_wb);
                 run(Flag<true>{}, Int<3>{}, t_wb, nwin);
@@ -597,7 +628,7 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
                         const int jj = (cc - 1) / K, kk = (cc - 1) % K;
                         const int tt = rr + jj - ts;
                         if (tt < 0) return false;
-                        const Word w = wtile[static_cast<size_t>(tt / UNR) * 64 + (g * W + jj)];
+                        const Word w = wtile[static_cast<size_t>(tt / UNR) * 64 + lane_of(g, jj)];
                         out = static_cast<unsigned>(w >> (4 * (CELLS - 1 - ((tt % UNR) * K + kk)))) & 15u;
                         return true;
                     };
@@ -609,7 +640,7 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
                                 const int jj = (c - 1) / K, kk = (c - 1) % K;
                                 const int tt = row + jj - ts;
                                 if (tt < 0) break;
-                                const Word w = wtile[static_cast<unsigned>(tt / UNR) * 64u + static_cast<unsigned>(g * W + jj)];
+                                const Word w = wtile[static_cast<unsigned>(tt / UNR) * 64u + static_cast<unsigned>(lane_of(g, jj))];
                                 if (!((w >> (4 * (CELLS - 1 - ((tt % UNR) * K + kk)))) & 2u)) break;
                                 map[c] = row * 2 + 1;
                                 --row; --c;
@@ -672,8 +703,8 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
                         }
                     }
                 }
-                pending = __shfl(pending, g * W);
-                want = __shfl(want, g * W);
+                pending = __shfl(pending, lane_of(g, 0));
+                want = __shfl(want, lane_of(g, 0));
             }
         }
 
@@ -681,14 +712,14 @@ __global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const 
             // make this wave's traceback stores visible to its leader lanes
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const int land = (__shfl(land_prev, g * W + jlast) >> 1) + 1;  // where the walk up column R ends
+            const int land = (__shfl(land_prev, lane_of(g, jlast)) >> 1) + 1;  // where the walk up column R ends
             if (valid && leader) {
                 // raw compare bits of cell (row, c): 1 H>V, 2 M>max(H,V), 4 horizontal jump
                 // continuation beat the step from the left, 8 same for the vertical jump
                 auto nibble = [&](int c, int row) -> unsigned {  // 1 <= c <= R, 1 <= row <= L
                     const int jj = (c - 1) / K, kk = (c - 1) % K;
                     const int tt = row + jj;
-                    const Word w = scr[static_cast<size_t>(tt / UNR) * 64 + (g * W + jj)];
+                    const Word w = scr[static_cast<size_t>(tt / UNR) * 64 + lane_of(g, jj)];
                     return static_cast<unsigned>(w >> (4 * (CELLS - 1 - ((tt % UNR) * K + kk)))) & 15u;
                 };
                 // direction value the reference would have stored at (row, c); a jump continues
@@ -864,28 +895,36 @@ static void build_cost_rows(const std::vector<double>& tab, int n, const uint32_
     colbase[0] = colbase[R ? 1 : 0];
 }
 
-struct Shape { int K, W, ngroups; };
+struct Shape { int K, W, ngroups, rowf; };   // rowf: see k_align's ROWF
 
 // Columns per lane / lanes per alignment / alignments per wave for a reference
 // of R columns: maximise busy lanes, prefer more columns per lane on ties (fewer
 // cross-lane moves per cell).
 static Shape pick_shape(int R) {
-    Shape best{1, 64, 1};
+    Shape best{1, 64, 1, 0};
     double best_u = -1;
     for (int K : {1, 2, 4, 8, 16}) {
         int W = (R + K - 1) / K;
         if (W > 64) continue;
         // groups of up to 16 lanes are padded to one DPP row: NGMAX = 4 of them fill the wave
-        // and the leaders get their column-0 inputs for free (lane_shr1<true>)
+        // and the leaders get their column-0 inputs for free (lane_shr1<1>)
         if (W <= 16) W = 16;
         const int ng = std::min(64 / W, NGMAX);
         const double u = static_cast<double>(ng) * R / (64.0 * K);
-        if (u > best_u + 1e-9 || (u > best_u - 1e-9 && K > best.K && K <= 2)) { best_u = u; best = {K, W, ng}; }
+        if (u > best_u + 1e-9 || (u > best_u - 1e-9 && K > best.K && K <= 2)) { best_u = u; best = {K, W, ng, W == 16 ? 1 : 0}; }
+    }
+    // references of up to 32 columns: eight alignments of 8 lanes, two interleaved per DPP row (lane_shr1<2>) -- the
+    // same share of busy lanes as four alignments of 16 lanes with half the columns per lane, and half the
+    // cross-lane moves per cell
+    for (int K : {2, 4}) {
+        if ((R + K - 1) / K > 8) continue;
+        const double u = static_cast<double>(NGMAX2) * R / (64.0 * K);
+        if (u > best_u - 1e-9) { best_u = u; best = {K, 8, NGMAX2, 2}; break; }
     }
     return best;
 }
 
-template <int K, bool ROW16, int KLAST, bool PENSEL>
+template <int K, int ROW16, int KLAST, bool PENSEL>
 static int launch_mode(int mode, bool local, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
     // adaptor_align is always local, general_align always global; score-only comes in both
     if (mode == 0 && local) hipLaunchKernelGGL((k_align<K, 0, true, ROW16, KLAST, PENSEL>), dim3(grid), dim3(64 * NWAVES), lds, s, a);
@@ -898,25 +937,47 @@ static int launch_mode(int mode, bool local, const AlignArgs& a, int grid, size_
     return 0;
 }
 
-template <int K, bool ROW16, int KLAST>
+template <int K, int ROW16, int KLAST>
 static int launch_pen(bool pensel, int mode, bool local, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
     return pensel ? launch_mode<K, ROW16, KLAST, true>(mode, local, a, grid, lds, s)
                   : launch_mode<K, ROW16, KLAST, false>(mode, local, a, grid, lds, s);
 }
 
-static int launch_k(int K, int W, int R, bool pensel, int mode, bool local, const AlignArgs& a, int grid, size_t lds,
+template <int K, int KLAST>
+static int launch_il(int mode, const AlignArgs& a, int grid, size_t lds, hipStream_t s) {
+    if (mode == 3) hipLaunchKernelGGL((k_align<K, 3, true, 2, KLAST, false>), dim3(grid), dim3(64 * NWAVES), lds, s, a);
+    else hipLaunchKernelGGL((k_align<K, 0, true, 2, KLAST, false>), dim3(grid), dim3(64 * NWAVES), lds, s, a);
+    SL_HIP(hipGetLastError());
+    return 0;
+}
+
+static int launch_k(int K, int rowf, int R, bool pensel, int mode, bool local, const AlignArgs& a, int grid, size_t lds,
                     hipStream_t s) {
-    const bool row16 = (W == 16);
     const int klast = (R - 1) % K;
-    if (K == 1) return row16 ? launch_pen<1, true, 0>(pensel, mode, local, a, grid, lds, s) : launch_pen<1, false, 0>(pensel, mode, local, a, grid, lds, s);
+    if (rowf == 2) {
+        // interleaved alignments: local mode without penalty selects only (adaptor_align by snapshots, score-only)
+        if (!local || pensel || !(mode == 3 || mode == 0)) return fail("sarlacc_amd: interleaved alignments serve local modes 0 and 3 only");
+        const int key = K * 4 + klast;
+        switch (key) {
+            case 2 * 4 + 0: return launch_il<2, 0>(mode, a, grid, lds, s);
+            case 2 * 4 + 1: return launch_il<2, 1>(mode, a, grid, lds, s);
+            case 4 * 4 + 0: return launch_il<4, 0>(mode, a, grid, lds, s);
+            case 4 * 4 + 1: return launch_il<4, 1>(mode, a, grid, lds, s);
+            case 4 * 4 + 2: return launch_il<4, 2>(mode, a, grid, lds, s);
+            case 4 * 4 + 3: return launch_il<4, 3>(mode, a, grid, lds, s);
+        }
+        return fail("sarlacc_amd: unsupported columns-per-lane %d for interleaved alignments", K);
+    }
+    const bool row16 = rowf == 1;
+    if (K == 1) return row16 ? launch_pen<1, 1, 0>(pensel, mode, local, a, grid, lds, s) : launch_pen<1, 0, 0>(pensel, mode, local, a, grid, lds, s);
     if (K == 2) {
-        if (row16) return klast == 0 ? launch_pen<2, true, 0>(pensel, mode, local, a, grid, lds, s) : launch_pen<2, true, 1>(pensel, mode, local, a, grid, lds, s);
-        return klast == 0 ? launch_pen<2, false, 0>(pensel, mode, local, a, grid, lds, s) : launch_pen<2, false, 1>(pensel, mode, local, a, grid, lds, s);
+        if (row16) return klast == 0 ? launch_pen<2, 1, 0>(pensel, mode, local, a, grid, lds, s) : launch_pen<2, 1, 1>(pensel, mode, local, a, grid, lds, s);
+        return klast == 0 ? launch_pen<2, 0, 0>(pensel, mode, local, a, grid, lds, s) : launch_pen<2, 0, 1>(pensel, mode, local, a, grid, lds, s);
     }
     switch (K) {
-        case 4: return row16 ? launch_pen<4, true, -1>(pensel, mode, local, a, grid, lds, s) : launch_pen<4, false, -1>(pensel, mode, local, a, grid, lds, s);
-        case 8: return row16 ? launch_pen<8, true, -1>(pensel, mode, local, a, grid, lds, s) : launch_pen<8, false, -1>(pensel, mode, local, a, grid, lds, s);
-        case 16: return row16 ? launch_pen<16, true, -1>(pensel, mode, local, a, grid, lds, s) : launch_pen<16, false, -1>(pensel, mode, local, a, grid, lds, s);
+        case 4: return row16 ? launch_pen<4, 1, -1>(pensel, mode, local, a, grid, lds, s) : launch_pen<4, 0, -1>(pensel, mode, local, a, grid, lds, s);
+        case 8: return row16 ? launch_pen<8, 1, -1>(pensel, mode, local, a, grid, lds, s) : launch_pen<8, 0, -1>(pensel, mode, local, a, grid, lds, s);
+        case 16: return row16 ? launch_pen<16, 1, -1>(pensel, mode, local, a, grid, lds, s) : launch_pen<16, 0, -1>(pensel, mode, local, a, grid, lds, s);
     }
     return fail("sarlacc_amd: unsupported columns-per-lane %d", K);
 }
@@ -1011,12 +1072,23 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
         SL_TRY(scratch("align.bad", 2, &d_bad));
     }
 
+    // gapopen >= 0 (GO >= GE): no penalty selects on the device, see k_align
+    bool pensel = !(GO >= GE);
+    pensel = pensel || option(OPT_ALIGN_PENSEL) != 0;  // testing: force the general path
     Shape sh = pick_shape(R);
+    // interleaved alignments exist for the local modes without penalty selects (adaptor_align by snapshots, score-only);
+    // align_interleave = -1: the A/B without them
+    const bool il_mode = local && !pensel && (kernel_mode == 0 || kernel_mode == 1);
+    if (sh.rowf == 2 && (!il_mode || option(OPT_ALIGN_INTERLEAVE) < 0)) {
+        const int K = R > 16 ? 2 : 1;
+        sh = {K, 16, NGMAX, 1};
+    }
     if (const int K = option(OPT_ALIGN_K)) {  // tuning override
         const int W = (R + K - 1) / K;
         if ((K == 1 || K == 2 || K == 4 || K == 8 || K == 16) && W <= 64) {
             const int Wp = W <= 16 ? 16 : W;
-            sh = {K, Wp, std::min(64 / Wp, NGMAX)};
+            sh = {K, Wp, std::min(64 / Wp, NGMAX), Wp == 16 ? 1 : 0};
+            if (option(OPT_ALIGN_INTERLEAVE) > 0 && il_mode && W <= 8 && (K == 2 || K == 4)) sh = {K, 8, NGMAX2, 2};
         }
     }
     const long long nitems = (n + sh.ngroups - 1) / sh.ngroups;
@@ -1024,9 +1096,6 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     const int tb_steps = std::max(1, 8 / sh.K);
     const size_t word_bytes = sh.K == 16 ? 8 : 4;
     size_t per_wave_elems = kernel_mode ? ((static_cast<size_t>(max_len) + sh.W + 16) / tb_steps + 2) * 64 : 0;
-    // gapopen >= 0 (GO >= GE): no penalty selects on the device, see k_align
-    bool pensel = !(GO >= GE);
-    pensel = pensel || option(OPT_ALIGN_PENSEL) != 0;  // testing: force the general path
     // adaptor_align without penalty selects: snapshots + windowed recompute instead of the code stream
     if (kernel_mode == 1 && local && !pensel) {
         kernel_mode = 3;
@@ -1064,11 +1133,11 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     a.snap_head = snap_head(R); a.snap_win = snap_win(R, sh.W);
     a.aln_ref = out.d_aln_ref; a.aln_qry = out.d_aln_qry; a.aln_len = out.d_aln_len; a.edits = out.d_edits;
 
-    const size_t lds = sizeof(uint16_t) * NWAVES * NGMAX * RING_SLOT + sizeof(double) * rows.size() +
+    const size_t lds = sizeof(uint16_t) * NWAVES * (sh.rowf == 2 ? NGMAX2 * (RING + RING_MIRROR) : NGMAX * RING_SLOT) + sizeof(double) * rows.size() +
                        sizeof(int32_t) * NWAVES * sh.ngroups * (R + 1) + 16;
     if (lds > 64 * 1024) return fail("sarlacc_amd: alignment tables do not fit in LDS");
     SL_HIP(hipEventRecord(c.ev_start, stream));
-    SL_TRY(launch_k(sh.K, sh.W, R, pensel, kernel_mode, local, a, static_cast<int>(grid), lds, stream));
+    SL_TRY(launch_k(sh.K, sh.rowf, R, pensel, kernel_mode, local, a, static_cast<int>(grid), lds, stream));
     SL_HIP(hipEventRecord(c.ev_stop, stream));
     c.timed = true;
 

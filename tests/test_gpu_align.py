@@ -117,6 +117,27 @@ def test_random_differential(oracle, oenc, enc, R):
     compare_adaptor(oracle, oenc, enc, reads, quals, adaptor, go, ge, ss, se)
 
 
+@pytest.mark.parametrize("R", [3, 16, 17, 30, 32])
+def test_row16_shapes_without_interleaved_alignments(oracle, oenc, enc, R):
+    # references of up to 32 columns run eight 8-lane alignments per wavefront (two interleaved per DPP row); the shapes with
+    # four 16-lane alignments they replaced stay reachable (align_interleave = -1) and give the same bits
+    from sarlacc_amd import calls
+    from sarlacc_amd.mock import random_reads
+    rng = np.random.default_rng(77 + R)
+    adaptor = "".join(rng.choice(list("ACGTN"), R))
+    reads, quals = random_reads(41, 0, 200, seed=R + 5)
+    core = "".join(c if c in "ACGT" else "G" for c in adaptor)
+    for k in (1, 7, 20):
+        reads[k] = reads[k][:30] + core + reads[k][30:]
+        quals[k] = rand_quals([reads[k]], R + k)[0]
+    try:
+        calls.set_option("align_interleave", -1)
+        compare_adaptor(oracle, oenc, enc, reads, quals, adaptor, 5, 1, [0, R // 2], [R // 2 + 1, R])
+    finally:
+        calls.set_option("align_interleave", 0)
+    compare_adaptor(oracle, oenc, enc, reads, quals, adaptor, 5, 1, [0, R // 2], [R // 2 + 1, R])
+
+
 def _penalty_batch(oracle, oenc, enc, R, go, ge, seed):
     from sarlacc_amd import calls
     from sarlacc_amd.mock import random_reads
