@@ -491,6 +491,22 @@ def main():
                                                    "identical_to_resident": bool(same),
                                                    "note": "same stages through the host-pointer C ABI (reads + qualities cross PCIe), rank 0 only"}
                 del hs, hq
+        # BASELINE configs[2] (umiGroup on the batch's UMIs as one pre-group) at umiGroup's own default threshold 3
+        # (R/umiGroup.R:2) and at 2, beside the threshold the pipeline workload uses; second call timed, rank 0's UMIs
+        if rank == 0:
+            from sarlacc_amd import _lib as _L
+            ug = {}
+            for thr in sorted({1, 2, 3, args.threshold}):
+                for _ in range(2):
+                    fence()
+                    t0 = time.perf_counter()
+                    coff_t, _cm = calls.umi_group_flat(umis, thr, None, thr, np.array([0, nr], np.int64), np.arange(1, nr + 1, dtype=np.int32))
+                    dt = time.perf_counter() - t0
+                ug[str(thr)] = {"seconds": dt, "umis_per_s": nr / dt, "clusters": int(coff_t.size - 1), "links": _L.stage_count("umi_links"),
+                                "search_kernels_ms": _L.stage_ms("umi_pairs"), "clustering_s": _L.stage_count("umi_cluster_s"),
+                                "rounds": int(_L.stage_count("umi_cluster_rounds")),
+                                "split_key_search": bool(_L.stage_count("umi_split_search"))}
+            out["pipeline"]["umi_group_thresholds"] = ug
         # BASELINE configs[3] as it is worded: 100k groups x 10 reads x 2 kb -- the molecules themselves as groups (no UMI
         # clustering in front, so no clusters of several molecules)
         goff_p = np.arange(0, nr + 1, args.copies, dtype=np.int64)

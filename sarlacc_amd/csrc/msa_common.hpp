@@ -29,6 +29,8 @@ struct MsaArgs {
     int2* stats;            // OUT 1: per job (aligned pairs with equal bases, aligned pairs)
     void* tb;               // per-wave traceback tile
     unsigned long long tb_per_wave;  // in tile words
+    uint32_t* moves;        // bit-vector kernel: per job, the traceback as a move string (see k_msa_pairwise_bv)
+    unsigned moves_stride;  // words per job
     int* stuck;             // set when a traceback exceeds its step bound (cannot happen with consistent codes;
                             // the bound is what guarantees that every wave leaves the walk)
 };

@@ -700,6 +700,297 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Bit-vector kernel for the unit-cost linear regime (the reference's DEFAULT scores: match 0, mismatch -1 and, after the
+// swapped reading of src/quick_msa.cpp:26-31, every gap character -1): the banded DP is then plain Levenshtein distance
+// inside the band, and one 32-bit operation advances 32 cells (Myers 1999, in Hyyro's 2003 form).
+//   * ONE PAIR PER LANE, 64 pairs per wavefront, no cross-lane traffic.  A lane walks the columns j = 1 .. lc of its
+//     pair with the band's rows i = j - dhi .. j - dlo as a vector of vertical deltas (Pv: +1, Mv: -1) that slides down
+//     one row per column; bit 32 NW - 1 is always the band's bottom row, so the base entering the band and its
+//     vertical delta are inserted at a fixed bit, and the band's top (bit OFF = 32 NW - B) is a per-lane mask.
+//   * Cells outside the band are "infinity" in the specification (oracle/msa.c orc_msa_pairwise).  A cell below the
+//     bottom edge is emulated by vertical delta +1, one above the top edge by horizontal delta +1: either makes the move
+//     from it cost diagonal + 2 >= diagonal + mismatch, so it never wins and never ties its way into the traceback --
+//     the values and decisions inside the band are those of the banded DP (tools model + tests against the oracle).
+//     Rows above row 0 are given D[i][j] = j - i (vertical delta -1, horizontal +1), which the recurrence preserves
+//     and which leaves D[0][j] = j in row 0.
+//   * Traceback: per cell "the diagonal is optimal" (Dg = Eq | ~D0) and "the step from above is" (the new Pv); the walk
+//     takes the diagonal if it can, else up if it can, else left -- the spec's order (d >= e, f; then e >= f).  Two bits
+//     per cell, 2 NW words per column and lane, one contiguous record per column in the lane's own part of the tile:
+//     the walk, per lane as well (~lr + lc dependent steps), then needs one 64-byte line per step and reads its lines
+//     in address order (records interleaved over the lanes made every step two random 64-byte reads from HBM: 0.70 s
+//     for 4.5 M pairs, all of it the walk).
+template <int NW>
+__global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
+    constexpr int BV_LSTRIDE = 2 * NW * 4 + 4;   // dwords per pair in the LDS block (padded: the pairs' pieces spread over the banks)
+    __shared__ __align__(16) uint32_t s_rec[64 * BV_LSTRIDE];
+    const int lane = threadIdx.x;
+    uint4* const tile = static_cast<uint4*>(A.tb) + static_cast<size_t>(blockIdx.x) * (A.tb_per_wave / 4);
+    const int nbatch = (A.njobs + 63) / 64;
+    for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+        const int jobn = batch * 64 + lane;
+        const bool on = jobn < A.njobs;
+        const int jobidx = on ? (A.order ? A.order[jobn] : jobn) : 0;
+        MsaJob J{};
+        if (on) J = A.jobs[jobidx];
+        const int lr = on ? J.lr : 0, lc = on ? J.lc : 0;
+        const int bw = msa_pair_bandwidth(A.bw, lr, lc);
+        uint16_t* const mapA = A.map + J.out_off;
+        uint16_t* const mapB = A.map + J.out2_off;
+        const uint8_t* const rd = A.seq + J.read_off;
+        const uint8_t* const ct = A.seq + J.ctr_off;
+        auto code_of = [](uint32_t b) -> uint32_t {   // dna5_code without branches
+            const uint32_t u = b & 0xdfu, x = (u >> 1) & 3u, c = x ^ (x >> 1);
+            return ((0x54474341u >> (8 * c)) & 0xffu) == u ? c : 4u;
+        };
+        if (on && bw < 0) {   // the diagonal alignment (msa_diagonal_pair), per lane
+            const int k = min(lr, lc);
+            int nequal = 0;
+            for (int p = 0; p < lc; ++p) mapA[p] = p < k ? static_cast<uint16_t>(p) : static_cast<uint16_t>(0xFFFF);
+            for (int p = 0; p < lr; ++p) mapB[p] = p < k ? static_cast<uint16_t>(p) : static_cast<uint16_t>(0xFFFF);
+            for (int p = 0; p < k; ++p) nequal += code_of(rd[p]) == code_of(ct[p]);
+            A.stats[jobidx] = make_int2(nequal, k);
+        }
+        const bool dp = on && bw >= 0;
+#ifdef BV_CLOCKS
+        const long long ck0 = wall_clock64();
+#endif
+        const int dlo = min(0, lc - lr) - bw, dhi = max(0, lc - lr) + bw;
+        const int B = dp ? dhi - dlo + 1 : 1;
+        const int OFF = 32 * NW - B;       // bit of the band's top row
+        const int lcd = dp ? lc : 0;       // columns this lane computes
+        // column 0: rows i <= 0 carry Mv, rows 1 .. -dlo carry Pv; planes hold code 7 (equal to nothing) outside 1 .. lr
+        uint32_t Pv[NW], Mv[NW], R0[NW], R1[NW], R2[NW];
+        uint32_t inb[NW], top[NW];   // bits of the band (>= OFF); the bit of its top row, where the edge's horizontal delta +1 enters
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            Pv[w] = Mv[w] = 0u; R0[w] = R1[w] = R2[w] = ~0u;
+            const int n = OFF - 32 * w;   // bits of this word below the band
+            inb[w] = n <= 0 ? ~0u : (n >= 32 ? 0u : ~((1u << n) - 1u));
+            top[w] = (n >= 0 && n < 32) ? (1u << n) : 0u;
+        }
+        if (dp) {
+            for (int b = 0; b < B; ++b) {
+                const int i = b - dhi, bit = OFF + b;
+                uint32_t c = 7u;
+                if (i >= 1 && i <= lr) c = code_of(rd[i - 1]);
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                    if ((bit >> 5) == w) {
+                        const uint32_t m = 1u << (bit & 31);
+                        if (i <= 0) Mv[w] |= m; else Pv[w] |= m;
+                        if (!(c & 1u)) R0[w] &= ~m;
+                        if (!(c & 2u)) R1[w] &= ~m;
+                        if (!(c & 4u)) R2[w] &= ~m;
+                    }
+            }
+        }
+        // bases of columns 1 .. 4 / 5 .. 8 / 9 .. 12 (see the fetch inside the loop)
+        uint32_t rbuf = 0u, cbuf = 0u, rnext = 0u, cnext = 0u, rnext2 = 0u, cnext2 = 0u;
+        if (dp) {
+            auto grab = [&](int j1, uint32_t& rb, uint32_t& cb) {
+                const int i1 = j1 - dlo;
+                for (int e = 0; e < 4; ++e) {
+                    if (i1 + e >= 1 && i1 + e <= lr) rb |= static_cast<uint32_t>(rd[i1 + e - 1]) << (8 * e);
+                    if (j1 + e <= lc) cb |= static_cast<uint32_t>(ct[j1 + e - 1]) << (8 * e);
+                }
+            };
+            grab(1, rnext, cnext);
+            grab(5, rnext2, cnext2);
+        }
+        int lcw = lcd;   // columns of the longest pair of the wave
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) lcw = max(lcw, __shfl_xor(lcw, d));
+
+#ifdef BV_CLOCKS
+        const long long ck1 = wall_clock64();
+#endif
+        for (int j = 1; j <= lcw; ++j) {
+            const bool act = j <= lcd;
+            // the base entering the band at the bottom (row i = j - dlo) and the column's base, four columns per fetch, fetched
+            // EIGHT columns ahead: a wait for a load also waits for every store issued before it, so the fetch has to be
+            // older than the record stores it would otherwise sit behind
+            const int inew = j - dlo;
+            if ((j & 3) == 1) {
+                rbuf = rnext; cbuf = cnext; rnext = rnext2; cnext = cnext2;
+                rnext2 = cnext2 = 0u;
+                const int j2 = j + 8, i2 = j2 - dlo;
+                if (j2 <= lcd) {
+                    if (i2 + 3 <= lr) __builtin_memcpy(&rnext2, rd + i2 - 1, 4);
+                    else for (int e = 0; e < 4; ++e) if (i2 + e <= lr) rnext2 |= static_cast<uint32_t>(rd[i2 + e - 1]) << (8 * e);
+                    if (j2 + 3 <= lc) __builtin_memcpy(&cnext2, ct + j2 - 1, 4);
+                    else for (int e = 0; e < 4; ++e) if (j2 + e <= lc) cnext2 |= static_cast<uint32_t>(ct[j2 + e - 1]) << (8 * e);
+                }
+            }
+            const int e4 = (j - 1) & 3;
+            uint32_t cn = 7u, cc = 7u;
+            if (act) {
+                if (inew <= lr) cn = code_of((rbuf >> (8 * e4)) & 0xffu);
+                cc = code_of((cbuf >> (8 * e4)) & 0xffu);
+            }
+            const uint32_t m0 = 0u - (cc & 1u), m1 = 0u - ((cc >> 1) & 1u), m2 = 0u - ((cc >> 2) & 1u);
+            // slide down one row; bottom row: vertical delta +1 (its left neighbour lies outside the band)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const bool last = w == NW - 1;
+                Pv[w] = last ? ((Pv[w] >> 1) | 0x80000000u) : __builtin_amdgcn_alignbit(Pv[w + (last ? 0 : 1)], Pv[w], 1);
+                Mv[w] = last ? (Mv[w] >> 1) : __builtin_amdgcn_alignbit(Mv[w + (last ? 0 : 1)], Mv[w], 1);
+                R0[w] = last ? ((R0[w] >> 1) | ((cn & 1u) << 31)) : __builtin_amdgcn_alignbit(R0[w + (last ? 0 : 1)], R0[w], 1);
+                R1[w] = last ? ((R1[w] >> 1) | (((cn >> 1) & 1u) << 31)) : __builtin_amdgcn_alignbit(R1[w + (last ? 0 : 1)], R1[w], 1);
+                R2[w] = last ? ((R2[w] >> 1) | (((cn >> 2) & 1u) << 31)) : __builtin_amdgcn_alignbit(R2[w + (last ? 0 : 1)], R2[w], 1);
+            }
+            uint32_t Dg[NW], Up[NW];
+            uint32_t carry = 0u, ph_in = 0u, mh_in = 0u;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const uint32_t Eq = ~((R0[w] ^ m0) | (R1[w] ^ m1) | (R2[w] ^ m2));
+                const uint32_t band_pv = Pv[w] & inb[w];   // rows that slid out through the top edge no longer count
+                const uint32_t addend = Eq & band_pv;
+                const unsigned long long sum = static_cast<unsigned long long>(addend) + band_pv + carry;
+                carry = static_cast<uint32_t>(sum >> 32);
+                const uint32_t Xh = (static_cast<uint32_t>(sum) ^ band_pv) | Eq;
+                const uint32_t Xv = Eq | Mv[w];
+                const uint32_t Ph = Mv[w] | ~(Xh | band_pv);
+                const uint32_t Mh = band_pv & Xh;
+                Dg[w] = Eq | ~(Xh | Mv[w]);
+                const uint32_t Phs = (Ph << 1) | ph_in | top[w];   // Mh is zero below the band, so Mhs needs nothing at the edge
+                const uint32_t Mhs = (Mh << 1) | mh_in;
+                ph_in = Ph >> 31; mh_in = Mh >> 31;
+                Pv[w] = Mhs | ~(Xv | Phs);
+                Mv[w] = Phs & Xv;
+                Up[w] = Pv[w];
+            }
+            // record of the column into the lane's LDS block: piece 2 w = Dg[w] of the block's four columns, 2 w + 1 = Up[w]
+            {
+                const int c4 = (j - 1) & 3;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    s_rec[lane * BV_LSTRIDE + (2 * w) * 4 + c4] = Dg[w];
+                    s_rec[lane * BV_LSTRIDE + (2 * w + 1) * 4 + c4] = Up[w];
+                }
+            }
+            if ((j & 3) == 0 || j == lcw) {
+                // four columns of all 64 pairs -> one block of the tile, [pair][piece] with 16 bytes per piece: every store
+                // instruction writes 1 KB of consecutive addresses, and a pair's record (2 NW pieces) is contiguous for the walk
+                __syncthreads();
+                const size_t blk = static_cast<size_t>((j - 1) >> 2) * (2 * NW * 64 / 4) * 4;   // uint4 index of the block
+#pragma unroll
+                for (int sidx = 0; sidx < 2 * NW * 64 / 4 / 16; ++sidx) {
+                    const int lin = sidx * 64 + lane;                // 16-byte unit inside the block
+                    const int pl = lin / (2 * NW), piece = lin % (2 * NW);
+                    const uint4 v = *reinterpret_cast<const uint4*>(&s_rec[pl * BV_LSTRIDE + piece * 4]);
+                    tile[blk + lin] = v;
+                }
+                __syncthreads();
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+
+#ifdef BV_CLOCKS
+        const long long ck2 = wall_clock64();
+        int iters = 0;
+#endif
+        // ---- the walk, per lane: decisions only.  The moves go to the pair's move string (2 bits each: 0 diagonal, 1 up,
+        // 2 left; 16 per word, first move in the low bits), k_msa_moves_expand turns them into the position maps -- the walk
+        // then has one store per 16 moves, and no load of it waits behind scattered 2-byte stores (loads and stores share
+        // one counter on this ISA).  A step group fetches the records of FOUR columns at the current word of the band (along a
+        // diagonal the bit stays where it is) and takes up to four diagonal moves and the one move that ends the run: one
+        // memory round trip per ~3 moves instead of one per move. ----
+        {
+            int i = dp ? lr : 0, j = dp ? lc : 0;
+            uint32_t* const mv = A.moves + static_cast<size_t>(jobidx) * A.moves_stride;
+            uint32_t macc = 0u;
+            int nmoves = 0;
+            auto push = [&](uint32_t m) {
+                macc |= m << (2 * (nmoves & 15));
+                ++nmoves;
+                if ((nmoves & 15) == 0) { mv[1 + (nmoves >> 4) - 1] = macc; macc = 0u; }
+            };
+            int budget = lr + lc + 2;
+            while (__ballot(i > 0 || j > 0)) {
+#ifdef BV_CLOCKS
+                ++iters;
+#endif
+                if (!(i > 0 || j > 0)) continue;
+                if (--budget < 0) { atomicExch(A.stuck, 1); i = j = 0; continue; }
+                if (i == 0) { push(2u); --j; continue; }
+                if (j == 0) { push(1u); --i; continue; }
+                const int bit = OFF + i - (j - dhi);
+                if (bit < OFF || bit >= 32 * NW) { atomicExch(A.stuck, 1); i = j = 0; continue; }   // cannot happen: the codes keep the path inside the band
+                const int w = bit >> 5, sh = bit & 31;
+                // the pair's record of the four-column block that holds column j: pieces 2 w (Dg) and 2 w + 1 (Up)
+                const int c4 = (j - 1) & 3;
+                const uint4* const rec = tile + (static_cast<size_t>((j - 1) >> 2) * 64 + lane) * (2 * NW);
+                const uint4 dq = rec[2 * w], uq = rec[2 * w + 1];
+                auto pick = [](const uint4& q, int c) -> uint32_t { return c == 0 ? q.x : (c == 1 ? q.y : (c == 2 ? q.z : q.w)); };
+                bool run = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (run && k <= c4 && i > 0 && j > 0) {
+                        const uint32_t dgw = pick(dq, c4 - k), upw = pick(uq, c4 - k);
+                        if ((dgw >> sh) & 1u) { push(0u); --i; --j; }
+                        else {
+                            if ((upw >> sh) & 1u) { push(1u); --i; } else { push(2u); --j; }
+                            run = false;
+                        }
+                    }
+                }
+            }
+            if (dp) {
+                if (nmoves & 15) mv[1 + (nmoves >> 4)] = macc;
+                mv[0] = static_cast<uint32_t>(nmoves);
+            }
+        }
+#ifdef BV_CLOCKS
+        if (blockIdx.x == 7 && lane == 0 && batch < 7 + 3 * static_cast<int>(gridDim.x))
+            printf("bv batch %d: init %lld fill %lld walk %lld (100 MHz ticks), walk iterations %d, lcw %d B %d\n", batch, ck1 - ck0, ck2 - ck1,
+                   wall_clock64() - ck2, iters, lcw, B);
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
+}
+
+// The move strings of k_msa_pairwise_bv -> position maps and (equal, aligned) counts, one wavefront per pair: 64 moves per
+// step, their positions from prefix counts over the lanes (ballots), so the map entries of a step are written side by side.
+__global__ void __launch_bounds__(256) k_msa_moves_expand(const MsaArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int jobn = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (jobn >= A.njobs) return;
+    const int jobidx = A.order ? A.order[jobn] : jobn;
+    const MsaJob J = A.jobs[jobidx];
+    if (msa_pair_bandwidth(A.bw, J.lr, J.lc) < 0) return;   // the diagonal alignment: written by the pairwise kernel itself
+    uint16_t* const mapA = A.map + J.out_off;
+    uint16_t* const mapB = A.map + J.out2_off;
+    const uint8_t* const rd = A.seq + J.read_off;
+    const uint8_t* const ct = A.seq + J.ctr_off;
+    const uint32_t* const mv = A.moves + static_cast<size_t>(jobidx) * A.moves_stride;
+    const int nmoves = static_cast<int>(mv[0]);
+    int i = J.lr, j = J.lc, nequal = 0, ndiag = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int m0 = 0; m0 < nmoves; m0 += 64) {
+        const int m = m0 + lane;
+        uint32_t t = 3u;   // nothing
+        if (m < nmoves) t = (mv[1 + (m >> 4)] >> (2 * (m & 15))) & 3u;
+        const unsigned long long bi = __ballot(t == 0u || t == 1u), bj = __ballot(t == 0u || t == 2u);
+        const int im = i - __popcll(bi & lt), jm = j - __popcll(bj & lt);   // position before this lane's move
+        bool eq = false;
+        if (t == 0u) {
+            mapA[jm - 1] = static_cast<uint16_t>(im - 1);
+            mapB[im - 1] = static_cast<uint16_t>(jm - 1);
+            eq = dna5_code(rd[im - 1]) == dna5_code(ct[jm - 1]);
+        } else if (t == 1u) mapB[im - 1] = 0xFFFF;
+        else if (t == 2u) mapA[jm - 1] = 0xFFFF;
+        nequal += __popcll(__ballot(eq));
+        ndiag += __popcll(__ballot(t == 0u));
+        i -= __popcll(bi); j -= __popcll(bj);
+    }
+    if (lane == 0) {
+        A.stats[jobidx] = make_int2(nequal, ndiag);
+        if (i != 0 || j != 0) atomicExch(A.stuck, 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 
 // scores -> non-negative costs of the packed kernel; false when they do not fit it
@@ -797,6 +1088,7 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
     SL_TRY(scratch("msa.stuck", 1, &d_stuck));
     if (reset_stuck) SL_HIP(hipMemsetAsync(d_stuck, 0, sizeof(int), s));
     a.stuck = d_stuck;
+    ctx().counts["msa_pairs_bitvector"] = 0;
     int mmc = 0, goc = 0, gec = 0;
     const bool domain_ok = cost_domain(ma, mm, go, ge, &mmc, &goc, &gec) && !option(OPT_MSA_INT32);
     for (int cls = 0; cls < 3; ++cls) {
@@ -807,6 +1099,29 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
         else { a.ma = ma; a.mm = mm; a.go = go; a.ge = ge; }
         // traceback tile of one resident wave, 4 bits per cell: packed kernel C/4 dwords per lane per 4 steps,
         // 32-bit kernel one (C = 16: 64-bit) word per lane per 2 SPW steps
+        // unit-cost linear regime (the default scores), maps + stats, bands of up to 256 diagonals: the bit-vector kernel
+        if (packed && out_mode == 1 && cls == 0 && a.go <= a.ge && a.mm == a.go && a.go > 0 && option(OPT_MSA_BITVECTOR) >= 0) {
+            const int NWb = cls_band[cls] <= 128 ? 4 : 8;
+            const size_t per_wave = (static_cast<size_t>(cls_lc[cls]) + 8) * 2 * NWb * 64;   // 32-bit words: 2 NW per column and pair, in blocks of four columns
+            const long long nbatch = (static_cast<long long>(cls_n[cls]) + 63) / 64;
+            long long grid = std::min<long long>(nbatch, static_cast<long long>(c.num_cu) * 16);
+            const size_t budget = static_cast<size_t>(24) << 30;
+            grid = std::min<long long>(grid, std::max<long long>(1, static_cast<long long>(budget / (per_wave * 4))));
+            void* d_tb; int* d_order = nullptr;
+            SL_TRY(c.buffer("msa.tb0", static_cast<size_t>(grid) * per_wave * 4, &d_tb));
+            if (!one_class) SL_TRY(upload("msa.ord0", order[cls].data(), order[cls].size(), &d_order, s));
+            a.order = d_order; a.njobs = static_cast<int>(cls_n[cls]);
+            a.tb = d_tb; a.tb_per_wave = per_wave;
+            // move strings: one word of length + 2 bits per move, at the job's index
+            a.moves_stride = static_cast<unsigned>((cls_lr[cls] + cls_lc[cls] + 15) / 16 + 2);
+            SL_TRY(scratch("msa.moves", jobs.size() * static_cast<size_t>(a.moves_stride), &a.moves));
+            if (NWb == 4) hipLaunchKernelGGL(k_msa_pairwise_bv<4>, dim3(static_cast<unsigned>(grid)), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL(k_msa_pairwise_bv<8>, dim3(static_cast<unsigned>(grid)), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(k_msa_moves_expand, dim3(static_cast<unsigned>((cls_n[cls] + 3) / 4)), dim3(256), 0, s, a);
+            SL_HIP(hipGetLastError());
+            ctx().counts["msa_pairs_bitvector"] = static_cast<double>(cls_n[cls]);
+            continue;
+        }
         const size_t steps = 2 * static_cast<size_t>(cls_lr[cls]) + cls_band[cls];
         const size_t word = (!packed && C == 16) ? 8 : 4;
         const size_t spw = C == 4 ? 2 : 1;

@@ -259,7 +259,7 @@ def test_split_key_search_small_sets(oracle, lo, hi, n_rate, short, split):
         calls.set_option("umi_split_min", 0)
 
 
-@pytest.mark.parametrize("threshold,n", [(2, 60000), (3, 30000)])
+@pytest.mark.parametrize("threshold,n", [(2, 100000), (3, 40000)])
 def test_split_key_search_equals_tile_search_and_oracle(oracle, threshold, n):
     # BASELINE config 3's shape (12-base UMIs, 10 reads per molecule, mockReads errors) from the size on where the split-key
     # search takes over by itself: the same groups as the all-tile-pairs search and as the oracle
@@ -272,15 +272,13 @@ def test_split_key_search_equals_tile_search_and_oracle(oracle, threshold, n):
         umis += [mutate(truth, rng).tobytes().decode() for _ in range(10)]
     g = [list(range(1, len(umis) + 1))]
     try:
-        calls.set_option("umi_split_min", 20000)   # 32768 by default
-        got = calls.umi_group(umis, threshold, None, threshold, g)
+        got = calls.umi_group(umis, threshold, None, threshold, g)   # the split-key search by itself (>= 32 768 strings)
         assert _lib.stage_count("umi_split_search") == 1
         calls.set_option("umi_tile_search", 1)
         tiles = calls.umi_group(umis, threshold, None, threshold, g)
         assert _lib.stage_count("umi_split_search") == 0
     finally:
         calls.set_option("umi_tile_search", 0)
-        calls.set_option("umi_split_min", 0)
     same_lists(got, tiles)
     same_lists(got, oracle.umi_group(umis, threshold, None, threshold, g, fast=True))
 
