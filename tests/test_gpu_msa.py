@@ -335,7 +335,7 @@ def test_msa_spec2_code_paths_agree(oracle):
         for params in [(0, -1, -5, -1, 100), (1, -2, -2, -2, 20)]:
             new = calls.quick_msa(groups, reads, *params)
             assert new == oracle.quick_msa(groups, reads, *params, spec=2)
-            for opt, val in (("msa2_general_rows", 1), ("msa2_chain_hbm", 1), ("msa2_single_wave", 1), ("msa2_batches", 3)):
+            for opt, val in (("msa2_general_rows", 1), ("msa2_chain_hbm", 1), ("msa2_single_wave", 1), ("msa2_batches", 3), ("msa_bitvector", -1)):
                 calls.set_option(opt, val)
                 try:
                     other = calls.quick_msa(groups, reads, *params)
@@ -344,6 +344,55 @@ def test_msa_spec2_code_paths_agree(oracle):
                 assert new == other, opt
             for rows, g in zip(new, groups):
                 assert [r.replace("-", "") for r in rows] == [reads[i - 1] for i in g]
+    finally:
+        calls.set_msa_spec(0)
+
+
+def test_pairwise_bitvector_kernel_edge_cases(oracle):
+    """The default scores are plain Levenshtein costs inside the band: spec v2's pairwise alignments then run on the
+    bit-vector kernel (one pair per lane, band edges emulated by +1 deltas).  Groups built to press on its corners -- reads
+    of 0, 1 and 2 bases, N and lower-case letters, lengths around the 32-bit word boundaries of the band, pairs whose
+    length difference alone nearly fills the band or exceeds the 1024-diagonal cap (the diagonal alignment), bandwidths 0,
+    1 and 40 (bands of up to 128 diagonals take the four-word variant) -- against the CPU statement and against the packed
+    DP kernel (msa_bitvector = -1)."""
+    from sarlacc_amd import _lib, calls
+    from sarlacc_amd.mock import NUC, mutate
+    rng = np.random.default_rng(2024)
+    def rnd(n):
+        return NUC[rng.integers(0, 4, n)].tobytes().decode()
+    reads, groups = [], []
+    def group(seqs):
+        idx = []
+        for q in seqs:
+            reads.append(q)
+            idx.append(len(reads))
+        groups.append(idx)
+    group(["", "A", "AC", rnd(5)])
+    group(["A", "A"])
+    group(["", ""])
+    base = rnd(300)
+    group([base, base.lower(), base[:150] + "N" + base[151:], base[:100] + "NNNN" + base[104:], base[:-3], "G" + base])
+    for L in (31, 32, 33, 63, 64, 65, 127, 128, 129, 200):
+        t = NUC[rng.integers(0, 4, L)]
+        group([mutate(t, rng, 0.08, 0.04).tobytes().decode() for _ in range(3)])
+    long = rnd(1400)
+    group([long, long[:1250], long[100:], mutate(np.frombuffer(long.encode(), np.uint8), rng, 0.05, 0.02).tobytes().decode()])
+    group([rnd(1300), rnd(120), rnd(700)])          # |lc - lr| beyond the cap: the diagonal alignment
+    group([rnd(400), rnd(520), rnd(610), rnd(455)])   # unrelated reads of different lengths
+    calls.set_msa_spec(2)
+    try:
+        for bw in (100, 40, 1, 0):
+            params = (0, -1, -5, -1, bw)
+            got = calls.quick_msa(groups, reads, *params)
+            assert _lib.stage_count("msa_pairs_bitvector") > 0
+            assert got == oracle.quick_msa(groups, reads, *params, spec=2), bw
+            calls.set_option("msa_bitvector", -1)
+            try:
+                other = calls.quick_msa(groups, reads, *params)
+                assert _lib.stage_count("msa_pairs_bitvector") == 0
+            finally:
+                calls.set_option("msa_bitvector", 0)
+            assert got == other, bw
     finally:
         calls.set_msa_spec(0)
 
