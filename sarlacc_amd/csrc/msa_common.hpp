@@ -58,10 +58,12 @@ struct MsaJobSummary {
     size_t n[3] = {0, 0, 0};
     int lr[3] = {0, 0, 0}, lc[3] = {0, 0, 0}, band[3] = {1, 1, 1};
     double cells = 0;   // rows x diagonals over all jobs
+    double cols[3] = {0, 0, 0};   // centre columns per class
     void add(int bandwidth, int jlr, int jlc) {
         const int b = msa_pair_band(bandwidth, jlr, jlc);   // capped at MSA_MAXBAND by the spec
         const int cls = b <= 256 ? 0 : (b <= 512 ? 1 : 2);
         ++n[cls];
+        cols[cls] += jlc;
         lr[cls] = jlr > lr[cls] ? jlr : lr[cls];
         lc[cls] = jlc > lc[cls] ? jlc : lc[cls];
         band[cls] = b > band[cls] ? b : band[cls];
@@ -73,6 +75,7 @@ struct MsaJobSummary {
             lr[k] = o.lr[k] > lr[k] ? o.lr[k] : lr[k];
             lc[k] = o.lc[k] > lc[k] ? o.lc[k] : lc[k];
             band[k] = o.band[k] > band[k] ? o.band[k] : band[k];
+            cols[k] += o.cols[k];
         }
         cells += o.cells;
     }

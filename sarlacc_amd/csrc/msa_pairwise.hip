@@ -1088,7 +1088,7 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
     SL_TRY(scratch("msa.stuck", 1, &d_stuck));
     if (reset_stuck) SL_HIP(hipMemsetAsync(d_stuck, 0, sizeof(int), s));
     a.stuck = d_stuck;
-    ctx().counts["msa_pairs_bitvector"] = 0;
+    if (reset_stuck) { ctx().counts["msa_pairs_bitvector"] = 0; ctx().counts["msa_bitvector_tile_bytes"] = 0; }
     int mmc = 0, goc = 0, gec = 0;
     const bool domain_ok = cost_domain(ma, mm, go, ge, &mmc, &goc, &gec) && !option(OPT_MSA_INT32);
     for (int cls = 0; cls < 3; ++cls) {
@@ -1119,7 +1119,10 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
             else hipLaunchKernelGGL(k_msa_pairwise_bv<8>, dim3(static_cast<unsigned>(grid)), dim3(64), 0, s, a);
             hipLaunchKernelGGL(k_msa_moves_expand, dim3(static_cast<unsigned>((cls_n[cls] + 3) / 4)), dim3(256), 0, s, a);
             SL_HIP(hipGetLastError());
-            ctx().counts["msa_pairs_bitvector"] = static_cast<double>(cls_n[cls]);
+            ctx().counts["msa_pairs_bitvector"] += static_cast<double>(cls_n[cls]);
+            // traceback records: 2 NW words per centre column and pair, written once
+            ctx().counts["msa_bitvector_tile_bytes"] += summary->cols[cls] * 2 * NWb * 4;
+            ctx().counts["msa_bitvector_words"] = NWb;
             continue;
         }
         const size_t steps = 2 * static_cast<size_t>(cls_lr[cls]) + cls_band[cls];

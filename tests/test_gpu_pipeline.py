@@ -191,7 +191,7 @@ def test_bench_two_ranks_prints_the_contract_line():
     p = out["pipeline"]
     assert p["reads"] == 2 * 1500 * 6 and p["n_ranks_seen"] == 2
     assert p["all_gather"]["backend"] == "gloo" and p["all_gather"]["bytes_received_total"] == 2 * 2 * 4 * 1500 * 6
-    assert p["consensus_reads"] > 0 and p["reads_per_min"] > 0 and set(p["rooflines"]) == {"k_msa_pairwise_pk", "k_consensus_code"}
+    assert p["consensus_reads"] > 0 and p["reads_per_min"] > 0 and set(p["rooflines"]) == {"k_msa_pairwise", "k_consensus_code"}
     assert p["clusters_all_ranks"] >= p["consensus_reads"]
 
 
