@@ -31,6 +31,7 @@ struct MsaArgs {
     unsigned long long tb_per_wave;  // in tile words
     uint32_t* moves;        // bit-vector kernel: per job, the traceback as a move string (see k_msa_pairwise_bv)
     unsigned moves_stride;  // words per job
+    int batch0, batch1;     // bit-vector kernel: the batches (of 64 jobs) this launch works on
     int* stuck;             // set when a traceback exceeds its step bound (cannot happen with consistent codes;
                             // the bound is what guarantees that every wave leaves the walk)
 };

@@ -719,14 +719,17 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
 //     the walk, per lane as well (~lr + lc dependent steps), then needs one 64-byte line per step and reads its lines
 //     in address order (records interleaved over the lanes made every step two random 64-byte reads from HBM: 0.70 s
 //     for 4.5 M pairs, all of it the walk).
-template <int NW>
+//   * PHASE 1 / 2: the two halves as kernels of their own over the batches [batch0, batch1) of a chunk, every batch with its
+//     own tile -- all wavefronts of the first compute (instruction latency hidden by each other instead of sharing the SIMDs
+//     with waiting walks), the second runs at several times the residency (no LDS, few registers), which is what a walk
+//     that waits for memory needs.  PHASE 0: both in one kernel, one tile per resident wavefront (small job lists).
+template <int NW, int PHASE>
 __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
     constexpr int BV_LSTRIDE = 2 * NW * 4 + 4;   // dwords per pair in the LDS block (padded: the pairs' pieces spread over the banks)
-    __shared__ __align__(16) uint32_t s_rec[64 * BV_LSTRIDE];
+    __shared__ __align__(16) uint32_t s_rec[PHASE == 2 ? 4 : 64 * BV_LSTRIDE];
     const int lane = threadIdx.x;
-    uint4* const tile = static_cast<uint4*>(A.tb) + static_cast<size_t>(blockIdx.x) * (A.tb_per_wave / 4);
-    const int nbatch = (A.njobs + 63) / 64;
-    for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    for (int batch = A.batch0 + blockIdx.x; batch < A.batch1; batch += gridDim.x) {
+        uint4* const tile = static_cast<uint4*>(A.tb) + static_cast<size_t>(PHASE == 0 ? blockIdx.x : batch - A.batch0) * (A.tb_per_wave / 4);
         const int jobn = batch * 64 + lane;
         const bool on = jobn < A.njobs;
         const int jobidx = on ? (A.order ? A.order[jobn] : jobn) : 0;
@@ -742,7 +745,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
             const uint32_t u = b & 0xdfu, x = (u >> 1) & 3u, c = x ^ (x >> 1);
             return ((0x54474341u >> (8 * c)) & 0xffu) == u ? c : 4u;
         };
-        if (on && bw < 0) {   // the diagonal alignment (msa_diagonal_pair), per lane
+        if (PHASE != 2 && on && bw < 0) {   // the diagonal alignment (msa_diagonal_pair), per lane
             const int k = min(lr, lc);
             int nequal = 0;
             for (int p = 0; p < lc; ++p) mapA[p] = p < k ? static_cast<uint16_t>(p) : static_cast<uint16_t>(0xFFFF);
@@ -751,13 +754,11 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
             A.stats[jobidx] = make_int2(nequal, k);
         }
         const bool dp = on && bw >= 0;
-#ifdef BV_CLOCKS
-        const long long ck0 = wall_clock64();
-#endif
         const int dlo = min(0, lc - lr) - bw, dhi = max(0, lc - lr) + bw;
         const int B = dp ? dhi - dlo + 1 : 1;
         const int OFF = 32 * NW - B;       // bit of the band's top row
         const int lcd = dp ? lc : 0;       // columns this lane computes
+        if (PHASE != 2) {
         // column 0: rows i <= 0 carry Mv, rows 1 .. -dlo carry Pv; planes hold code 7 (equal to nothing) outside 1 .. lr
         uint32_t Pv[NW], Mv[NW], R0[NW], R1[NW], R2[NW];
         uint32_t inb[NW], top[NW];   // bits of the band (>= OFF); the bit of its top row, where the edge's horizontal delta +1 enters
@@ -801,9 +802,6 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) lcw = max(lcw, __shfl_xor(lcw, d));
 
-#ifdef BV_CLOCKS
-        const long long ck1 = wall_clock64();
-#endif
         for (int j = 1; j <= lcw; ++j) {
             const bool act = j <= lcd;
             // the base entering the band at the bottom (row i = j - dlo) and the column's base, four columns per fetch, fetched
@@ -883,13 +881,13 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
                 __syncthreads();
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        if (PHASE == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        if (PHASE == 1) continue;
 
-#ifdef BV_CLOCKS
-        const long long ck2 = wall_clock64();
-        int iters = 0;
-#endif
         // ---- the walk, per lane: decisions only.  The moves go to the pair's move string (2 bits each: 0 diagonal, 1 up,
         // 2 left; 16 per word, first move in the low bits), k_msa_moves_expand turns them into the position maps -- the walk
         // then has one store per 16 moves, and no load of it waits behind scattered 2-byte stores (loads and stores share
@@ -908,9 +906,6 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
             };
             int budget = lr + lc + 2;
             while (__ballot(i > 0 || j > 0)) {
-#ifdef BV_CLOCKS
-                ++iters;
-#endif
                 if (!(i > 0 || j > 0)) continue;
                 if (--budget < 0) { atomicExch(A.stuck, 1); i = j = 0; continue; }
                 if (i == 0) { push(2u); --j; continue; }
@@ -941,11 +936,6 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
                 mv[0] = static_cast<uint32_t>(nmoves);
             }
         }
-#ifdef BV_CLOCKS
-        if (blockIdx.x == 7 && lane == 0 && batch < 7 + 3 * static_cast<int>(gridDim.x))
-            printf("bv batch %d: init %lld fill %lld walk %lld (100 MHz ticks), walk iterations %d, lcw %d B %d\n", batch, ck1 - ck0, ck2 - ck1,
-                   wall_clock64() - ck2, iters, lcw, B);
-#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     }
 }
@@ -1088,7 +1078,6 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
     SL_TRY(scratch("msa.stuck", 1, &d_stuck));
     if (reset_stuck) SL_HIP(hipMemsetAsync(d_stuck, 0, sizeof(int), s));
     a.stuck = d_stuck;
-    if (reset_stuck) { ctx().counts["msa_pairs_bitvector"] = 0; ctx().counts["msa_bitvector_tile_bytes"] = 0; }
     int mmc = 0, goc = 0, gec = 0;
     const bool domain_ok = cost_domain(ma, mm, go, ge, &mmc, &goc, &gec) && !option(OPT_MSA_INT32);
     for (int cls = 0; cls < 3; ++cls) {
@@ -1099,30 +1088,59 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
         else { a.ma = ma; a.mm = mm; a.go = go; a.ge = ge; }
         // traceback tile of one resident wave, 4 bits per cell: packed kernel C/4 dwords per lane per 4 steps,
         // 32-bit kernel one (C = 16: 64-bit) word per lane per 2 SPW steps
-        // unit-cost linear regime (the default scores), maps + stats, bands of up to 256 diagonals: the bit-vector kernel
+        // unit-cost linear regime (the default scores), maps + stats, bands of up to 256 diagonals: the bit-vector kernels
         if (packed && out_mode == 1 && cls == 0 && a.go <= a.ge && a.mm == a.go && a.go > 0 && option(OPT_MSA_BITVECTOR) >= 0) {
             const int NWb = cls_band[cls] <= 128 ? 4 : 8;
             const size_t per_wave = (static_cast<size_t>(cls_lc[cls]) + 8) * 2 * NWb * 64;   // 32-bit words: 2 NW per column and pair, in blocks of four columns
             const long long nbatch = (static_cast<long long>(cls_n[cls]) + 63) / 64;
-            long long grid = std::min<long long>(nbatch, static_cast<long long>(c.num_cu) * 16);
-            const size_t budget = static_cast<size_t>(24) << 30;
-            grid = std::min<long long>(grid, std::max<long long>(1, static_cast<long long>(budget / (per_wave * 4))));
-            void* d_tb; int* d_order = nullptr;
-            SL_TRY(c.buffer("msa.tb0", static_cast<size_t>(grid) * per_wave * 4, &d_tb));
+            int* d_order = nullptr;
             if (!one_class) SL_TRY(upload("msa.ord0", order[cls].data(), order[cls].size(), &d_order, s));
             a.order = d_order; a.njobs = static_cast<int>(cls_n[cls]);
-            a.tb = d_tb; a.tb_per_wave = per_wave;
+            a.tb_per_wave = per_wave;
             // move strings: one word of length + 2 bits per move, at the job's index
             a.moves_stride = static_cast<unsigned>((cls_lr[cls] + cls_lc[cls] + 15) / 16 + 2);
             SL_TRY(scratch("msa.moves", jobs.size() * static_cast<size_t>(a.moves_stride), &a.moves));
-            if (NWb == 4) hipLaunchKernelGGL(k_msa_pairwise_bv<4>, dim3(static_cast<unsigned>(grid)), dim3(64), 0, s, a);
-            else hipLaunchKernelGGL(k_msa_pairwise_bv<8>, dim3(static_cast<unsigned>(grid)), dim3(64), 0, s, a);
+            // Large lists: fill and walk as kernels of their own over chunks of batches, every batch of a chunk with its own
+            // tile (up to 48 GB of records, a third of the free memory at most); otherwise both phases in one kernel.
+            size_t free_b = 0, total_b = 0;
+            SL_HIP(hipMemGetInfo(&free_b, &total_b));
+            size_t have = 0;
+            { auto it = c.ws.find("msa.tb0"); if (it != c.ws.end()) have = it->second.cap; }
+            const size_t tile_budget = std::max<size_t>(have, std::min<size_t>(static_cast<size_t>(48) << 30, (free_b + have) / 3));
+            const long long chunk = static_cast<long long>(tile_budget / (per_wave * 4));
+            const bool split = option(OPT_MSA_BITVECTOR) != 2 && nbatch >= 4LL * c.num_cu && chunk >= 8LL * c.num_cu;
+            void* d_tb;
+            if (split) {
+                const long long per = std::min(chunk, nbatch);
+                SL_TRY(c.buffer("msa.tb0", static_cast<size_t>(per) * per_wave * 4, &d_tb));
+                a.tb = d_tb;
+                for (long long b0 = 0; b0 < nbatch; b0 += per) {
+                    a.batch0 = static_cast<int>(b0); a.batch1 = static_cast<int>(std::min(nbatch, b0 + per));
+                    const unsigned g = static_cast<unsigned>(a.batch1 - a.batch0);
+                    if (NWb == 4) {
+                        hipLaunchKernelGGL((k_msa_pairwise_bv<4, 1>), dim3(g), dim3(64), 0, s, a);
+                        hipLaunchKernelGGL((k_msa_pairwise_bv<4, 2>), dim3(g), dim3(64), 0, s, a);
+                    } else {
+                        hipLaunchKernelGGL((k_msa_pairwise_bv<8, 1>), dim3(g), dim3(64), 0, s, a);
+                        hipLaunchKernelGGL((k_msa_pairwise_bv<8, 2>), dim3(g), dim3(64), 0, s, a);
+                    }
+                }
+            } else {
+                long long grid = std::min<long long>(nbatch, static_cast<long long>(c.num_cu) * 16);
+                const size_t budget = static_cast<size_t>(24) << 30;
+                grid = std::min<long long>(grid, std::max<long long>(1, static_cast<long long>(budget / (per_wave * 4))));
+                SL_TRY(c.buffer("msa.tb0", static_cast<size_t>(grid) * per_wave * 4, &d_tb));
+                a.tb = d_tb; a.batch0 = 0; a.batch1 = static_cast<int>(nbatch);
+                if (NWb == 4) hipLaunchKernelGGL((k_msa_pairwise_bv<4, 0>), dim3(static_cast<unsigned>(grid)), dim3(64), 0, s, a);
+                else hipLaunchKernelGGL((k_msa_pairwise_bv<8, 0>), dim3(static_cast<unsigned>(grid)), dim3(64), 0, s, a);
+            }
             hipLaunchKernelGGL(k_msa_moves_expand, dim3(static_cast<unsigned>((cls_n[cls] + 3) / 4)), dim3(256), 0, s, a);
             SL_HIP(hipGetLastError());
             ctx().counts["msa_pairs_bitvector"] += static_cast<double>(cls_n[cls]);
             // traceback records: 2 NW words per centre column and pair, written once
             ctx().counts["msa_bitvector_tile_bytes"] += summary->cols[cls] * 2 * NWb * 4;
             ctx().counts["msa_bitvector_words"] = NWb;
+            ctx().counts["msa_bitvector_split"] = split ? 1 : 0;
             continue;
         }
         const size_t steps = 2 * static_cast<size_t>(cls_lr[cls]) + cls_band[cls];
