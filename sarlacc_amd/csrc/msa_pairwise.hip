@@ -769,6 +769,15 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
             inb[w] = n <= 0 ? ~0u : (n >= 32 ? 0u : ~((1u << n) - 1u));
             top[w] = (n >= 0 && n < 32) ? (1u << n) : 0u;
         }
+        // the distance itself, for the count of equal pairs: D moves by 1 - D0 from a cell to the next one on its diagonal, and
+        // the diagonal of the final cell keeps its bit; summed over the columns from |lc - lr| (rows above row 0 add nothing)
+        uint32_t fin[NW];
+        {
+            const int pbit = OFF + dhi - (lc - lr);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) fin[w] = (dp && (pbit >> 5) == w) ? (1u << (pbit & 31)) : 0u;
+        }
+        int dist = lc > lr ? lc - lr : lr - lc;
         if (dp) {
             for (int b = 0; b < B; ++b) {
                 const int i = b - dhi, bit = OFF + b;
@@ -837,7 +846,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
                 R2[w] = last ? ((R2[w] >> 1) | (((cn >> 2) & 1u) << 31)) : __builtin_amdgcn_alignbit(R2[w + (last ? 0 : 1)], R2[w], 1);
             }
             uint32_t Dg[NW], Up[NW];
-            uint32_t carry = 0u, ph_in = 0u, mh_in = 0u;
+            uint32_t carry = 0u, ph_in = 0u, mh_in = 0u, grew = 0u;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
                 const uint32_t Eq = ~((R0[w] ^ m0) | (R1[w] ^ m1) | (R2[w] ^ m2));
@@ -850,6 +859,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
                 const uint32_t Ph = Mv[w] | ~(Xh | band_pv);
                 const uint32_t Mh = band_pv & Xh;
                 Dg[w] = Eq | ~(Xh | Mv[w]);
+                grew |= ~(Xh | Mv[w]) & fin[w];   // D0 clear on the final cell's diagonal
                 const uint32_t Phs = (Ph << 1) | ph_in | top[w];   // Mh is zero below the band, so Mhs needs nothing at the edge
                 const uint32_t Mhs = (Mh << 1) | mh_in;
                 ph_in = Ph >> 31; mh_in = Mh >> 31;
@@ -857,6 +867,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
                 Mv[w] = Phs & Xv;
                 Up[w] = Pv[w];
             }
+            if (act && grew) ++dist;
             // record of the column into the lane's LDS block: piece 2 w = Dg[w] of the block's four columns, 2 w + 1 = Up[w]
             {
                 const int c4 = (j - 1) & 3;
@@ -881,6 +892,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
                 __syncthreads();
             }
         }
+        if (dp) A.stats[jobidx] = make_int2(dist, 0);   // for k_msa_moves_expand: equal pairs = diagonal moves - (distance - gaps)
         }
         if (PHASE == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -942,6 +954,8 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
 
 // The move strings of k_msa_pairwise_bv -> position maps and (equal, aligned) counts, one wavefront per pair: 64 moves per
 // step, their positions from prefix counts over the lanes (ballots), so the map entries of a step are written side by side.
+// The whole move string sits in registers first (word k of it in lane k % 64), and four steps' worth of positions are
+// worked out before their bases are fetched, so a step does not wait for the memory of the one before.
 __global__ void __launch_bounds__(256) k_msa_moves_expand(const MsaArgs A) {
     const int lane = threadIdx.x & 63;
     const int jobn = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -951,29 +965,44 @@ __global__ void __launch_bounds__(256) k_msa_moves_expand(const MsaArgs A) {
     if (msa_pair_bandwidth(A.bw, J.lr, J.lc) < 0) return;   // the diagonal alignment: written by the pairwise kernel itself
     uint16_t* const mapA = A.map + J.out_off;
     uint16_t* const mapB = A.map + J.out2_off;
-    const uint8_t* const rd = A.seq + J.read_off;
-    const uint8_t* const ct = A.seq + J.ctr_off;
     const uint32_t* const mv = A.moves + static_cast<size_t>(jobidx) * A.moves_stride;
     const int nmoves = static_cast<int>(mv[0]);
-    int i = J.lr, j = J.lc, nequal = 0, ndiag = 0;
+    const int nwords = (nmoves + 15) >> 4;
+    constexpr int MAXW = 16;   // 64 lanes x 16 words x 16 moves = 16 384 moves and more: longer strings read their words from memory
+    uint32_t wreg[MAXW];
+#pragma unroll
+    for (int q = 0; q < MAXW; ++q) wreg[q] = (q * 64 + lane < nwords) ? mv[1 + q * 64 + lane] : 0u;
+    int i = J.lr, j = J.lc, ndiag = 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int m0 = 0; m0 < nmoves; m0 += 64) {
-        const int m = m0 + lane;
-        uint32_t t = 3u;   // nothing
-        if (m < nmoves) t = (mv[1 + (m >> 4)] >> (2 * (m & 15))) & 3u;
-        const unsigned long long bi = __ballot(t == 0u || t == 1u), bj = __ballot(t == 0u || t == 2u);
-        const int im = i - __popcll(bi & lt), jm = j - __popcll(bj & lt);   // position before this lane's move
-        bool eq = false;
-        if (t == 0u) {
-            mapA[jm - 1] = static_cast<uint16_t>(im - 1);
-            mapB[im - 1] = static_cast<uint16_t>(jm - 1);
-            eq = dna5_code(rd[im - 1]) == dna5_code(ct[jm - 1]);
-        } else if (t == 1u) mapB[im - 1] = 0xFFFF;
-        else if (t == 2u) mapA[jm - 1] = 0xFFFF;
-        nequal += __popcll(__ballot(eq));
-        ndiag += __popcll(__ballot(t == 0u));
-        i -= __popcll(bi); j -= __popcll(bj);
+    for (int m0 = 0; m0 < nmoves; m0 += 256) {
+        uint32_t tq[4]; int iq[4], jq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = m0 + 64 * u + lane;
+            const int wi = m >> 4;                       // word of the move: register wi / 64 of lane wi % 64
+            uint32_t word = 0u;
+            const int q = (m0 + 64 * u) >> 10;           // the same for every lane of the step (64 moves span 4 words of one register index)
+#pragma unroll
+            for (int qq = 0; qq < MAXW; ++qq) if (qq == q) word = static_cast<uint32_t>(__shfl(static_cast<int>(wreg[qq]), wi & 63));
+            if (q >= MAXW && m < nmoves) word = mv[1 + wi];
+            const uint32_t tm = m < nmoves ? (word >> (2 * (m & 15))) & 3u : 3u;
+            const unsigned long long bi = __ballot(tm == 0u || tm == 1u), bj = __ballot(tm == 0u || tm == 2u);
+            tq[u] = tm; iq[u] = i - __popcll(bi & lt); jq[u] = j - __popcll(bj & lt);   // position before this lane's move
+            i -= __popcll(bi); j -= __popcll(bj);
+            ndiag += __popcll(__ballot(tm == 0u));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (tq[u] == 0u) {
+                mapA[jq[u] - 1] = static_cast<uint16_t>(iq[u] - 1);
+                mapB[iq[u] - 1] = static_cast<uint16_t>(jq[u] - 1);
+            } else if (tq[u] == 1u) mapB[iq[u] - 1] = 0xFFFF;
+            else if (tq[u] == 2u) mapA[jq[u] - 1] = 0xFFFF;
+        }
     }
+    // every move costs 1 except a diagonal move over equal bases: mismatches = distance - gaps
+    const int dist = A.stats[jobidx].x;
+    const int nequal = ndiag - (dist - (nmoves - ndiag));
     if (lane == 0) {
         A.stats[jobidx] = make_int2(nequal, ndiag);
         if (i != 0 || j != 0) atomicExch(A.stuck, 1);
