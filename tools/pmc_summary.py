@@ -89,6 +89,31 @@ def main():
         res["traffic_bytes_per_launch"] = (2.0 * sum(big_f) / len(big_f) + sum(big_w) / len(big_w)) * 1024.0
         res["traffic_correction"] = ("2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports half the bytes read), mean over the "
                                      "launches within a factor 2 of the largest (%d of %d)" % (len(big_f), len(fe)))
+    if kernel == "k_msa_pairwise" and "k_msa_pairwise_bv" in name:
+        # The pairwise stage on bit vectors is many launches: fill and walk kernels per chunk of batches plus one expansion.
+        # Its traffic is the sum over all of them, per stage (= per launch of k_msa_moves_expand); the counters below stay those
+        # of the dominant kernel (the fill).
+        stage = ("k_msa_pairwise_bv", "k_msa_moves_expand")
+        def total(sub, counter):
+            tot, nexp = 0.0, set()
+            for r in counter_rows(os.path.join(out_dir, sub)):
+                if r["Counter_Name"] != counter:
+                    continue
+                if any(k in r["Kernel_Name"] for k in stage):
+                    tot += float(r["Counter_Value"])
+                if "k_msa_moves_expand" in r["Kernel_Name"]:
+                    nexp.add(r["Dispatch_Id"])
+            return tot, len(nexp)
+        tf, nf = total("pmc_fetch", "FETCH_SIZE")
+        tw, nw = total("pmc_write", "WRITE_SIZE")
+        if nf and nw:
+            res["stage_launches_profiled"] = nf
+            res["traffic_bytes_per_launch"] = (2.0 * tf / nf + tw / nw) * 1024.0
+            res["traffic_scope"] = ("one pairwise stage = all launches of k_msa_pairwise_bv<NW, 1> (fill), <NW, 2> (walk) and k_msa_moves_expand "
+                                    "of one call, mean over %d stages of the bench run (pipeline passes and the pure-group passes)" % nf)
+            res["traffic_correction"] = "2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports half the bytes read), summed over the stage's launches"
+            res["fetch_bytes_per_stage"] = 2.0 * tf / nf * 1024.0
+            res["write_bytes_per_stage"] = tw / nw * 1024.0
     sq = {}
     for sub, names in (("pmc_sq", ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
                                    "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")),
