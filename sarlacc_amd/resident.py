@@ -214,17 +214,25 @@ class DeviceReads:
             return np.zeros(0), np.zeros(0, np.int32), np.zeros(0, np.int32), [np.zeros(0, np.int32)] * ns, [np.zeros(0, np.int32)] * ns
         enc = as_encoding(self.encoding if self.encoding is not None else phred_encoding())
         rf = adaptor.encode() if isinstance(adaptor, str) else bytes(adaptor)
-        scores, starts, ends = DevBuffer(8 * n), DevBuffer(4 * n), DevBuffer(4 * n)
-        so, sw = DevBuffer(4 * n * max(ns, 1)), DevBuffer(4 * n * max(ns, 1))
+        # one device block for the five result vectors and one download (five allocations and five copies per call were a
+        # third of adaptorAlign's time on a resident batch): scores | starts | ends | section starts | section widths
+        nsec = max(ns, 1)
+        o_st, o_en, o_so, o_sw = 8 * n, 12 * n, 16 * n, 16 * n + 4 * n * nsec
+        total = 16 * n + 8 * n * nsec
+        blk = DevBuffer(total)
+        base = blk.ptr.value
         pad = np.zeros(1, np.int32)
         check(_lib.lib().sarlacc_dev_align(
             self.seq.ptr, self.qual.ptr, self.off.ptr, C.c_int64(n), C.c_int32(self.max_len),
             ptr(enc.errors), enc.names, len(enc), C.c_double(gap_opening), C.c_double(gap_extension),
             rf, len(rf), 0, ptr(ss if ns else pad), ptr(se if ns else pad), ns,
-            scores.ptr, starts.ptr, ends.ptr, so.ptr, sw.ptr, None))
-        so_h, sw_h = so.to_numpy(np.int32, n * ns), sw.to_numpy(np.int32, n * ns)
-        return (scores.to_numpy(np.float64, n), starts.to_numpy(np.int32, n), ends.to_numpy(np.int32, n),
-                [so_h[k * n:(k + 1) * n] for k in range(ns)], [sw_h[k * n:(k + 1) * n] for k in range(ns)])
+            C.c_void_p(base), C.c_void_p(base + o_st), C.c_void_p(base + o_en), C.c_void_p(base + o_so), C.c_void_p(base + o_sw), None))
+        host = np.empty(total, np.uint8)
+        check(_lib.lib().sarlacc_dev_download(ptr(host), blk.ptr, C.c_int64(total)))
+        scores = host[:o_st].view(np.float64)
+        starts, ends = host[o_st:o_en].view(np.int32), host[o_en:o_so].view(np.int32)
+        so_h, sw_h = host[o_so:o_sw].view(np.int32), host[o_sw:].view(np.int32)
+        return (scores, starts, ends, [so_h[k * n:(k + 1) * n] for k in range(ns)], [sw_h[k * n:(k + 1) * n] for k in range(ns)])
 
     def align_scores(self, adaptor, gap_opening, gap_extension, local=True):
         """adaptor_align_score_only / barcode_align on the resident batch."""
