@@ -1132,6 +1132,11 @@ struct M2Batch {
     hipEvent_t pair_done = nullptr;   // the all-pairs alignments of the batch have finished (m2_prepare -> m2_merge)
 };
 
+static std::vector<MsaJob>& m2_job_pool() {
+    static thread_local std::vector<MsaJob> pool;
+    return pool;
+}
+
 // Host tables of a batch: groups, members, the pairwise jobs (4.4 million at C4).  The offsets come from one serial pass
 // over the groups; members and jobs are then filled by a few threads over disjoint ranges of groups.
 static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const int64_t* rel, bool exact_w, int bandwidth) {
@@ -1178,7 +1183,13 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
     B.tab_n = tab_pos;
     B.members.assign(static_cast<size_t>(mem_pos), M2Member{});
     B.member_group.assign(static_cast<size_t>(mem_pos), 0);
-    B.jobs.assign(static_cast<size_t>(job_pos), MsaJob{});
+    // the job table keeps its pages between calls (m2_job_pool): a fresh 180 MB vector costs the zero fill and a page fault
+    // per 4 KB before the threads below write every field anyway
+    {
+        std::vector<MsaJob>& pool = m2_job_pool();
+        if (B.jobs.empty() && !pool.empty()) B.jobs.swap(pool);
+        B.jobs.resize(static_cast<size_t>(job_pos));
+    }
     auto fill = [&](size_t q0, size_t q1, MsaJobSummary* sum) {
         for (size_t q = q0; q < q1; ++q) {
             const M2Group& G = B.groups[q];
@@ -1574,7 +1585,11 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             m2_host_time("rows", th);
             used = need;
             // (the host tables of the batch are not needed any more)
-            std::vector<MsaJob>().swap(B.jobs);
+            {   // back to the pool (the larger of the two survives)
+                std::vector<MsaJob>& pool = m2_job_pool();
+                if (B.jobs.capacity() > pool.capacity()) pool.swap(B.jobs);
+                std::vector<MsaJob>().swap(B.jobs);
+            }
         }
         todo.swap(again);
     }
