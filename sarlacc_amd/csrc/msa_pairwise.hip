@@ -1135,7 +1135,8 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
             SL_HIP(hipMemGetInfo(&free_b, &total_b));
             size_t have = 0;
             { auto it = c.ws.find("msa.tb0"); if (it != c.ws.end()) have = it->second.cap; }
-            const size_t tile_budget = std::max<size_t>(have, std::min<size_t>(static_cast<size_t>(48) << 30, (free_b + have) / 3));
+            const size_t tile_gb = option(OPT_MSA_BITVECTOR_TILE_GB) > 0 ? static_cast<size_t>(option(OPT_MSA_BITVECTOR_TILE_GB)) : 48;
+            const size_t tile_budget = std::min<size_t>(tile_gb << 30, std::max<size_t>(have, (free_b + have) / 3));
             const long long chunk = static_cast<long long>(tile_budget / (per_wave * 4));
             const bool split = option(OPT_MSA_BITVECTOR) != 2 && nbatch >= 4LL * c.num_cu && chunk >= 8LL * c.num_cu;
             void* d_tb;
