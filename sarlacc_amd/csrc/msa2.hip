@@ -1216,7 +1216,7 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
                     J->lr = Mb.len; J->lc = Ma.len;
                     J->out_off = Ma.map_base + static_cast<long long>(b - 1) * Ma.len;    // b among the others of a
                     J->out2_off = Mb.map_base + static_cast<long long>(a) * Mb.len;       // a among the others of b
-                    sum->add(bandwidth, J->lr, J->lc);
+                    sum->add(bandwidth, J->lr, J->lc, J - B.jobs.data());
                 }
         }
     };

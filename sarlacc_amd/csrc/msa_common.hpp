@@ -5,6 +5,8 @@
 
 #include "common.hpp"
 
+#include <vector>
+
 namespace sarlacc {
 
 // One banded global alignment: `read` (rows i) against `centre` (columns j).
@@ -32,6 +34,7 @@ struct MsaArgs {
     uint32_t* moves;        // bit-vector kernel: per job, the traceback as a move string (see k_msa_pairwise_bv)
     unsigned moves_stride;  // words per job
     int batch0, batch1;     // bit-vector kernel: the batches (of 64 jobs) this launch works on
+    int skip_wide;          // bit-vector kernel: the job list holds jobs of wider band classes too; their lanes stay idle
     int* stuck;             // set when a traceback exceeds its step bound (cannot happen with consistent codes;
                             // the bound is what guarantees that every wave leaves the walk)
 };
@@ -60,11 +63,14 @@ struct MsaJobSummary {
     int lr[3] = {0, 0, 0}, lc[3] = {0, 0, 0}, band[3] = {1, 1, 1};
     double cells = 0;   // rows x diagonals over all jobs
     double cols[3] = {0, 0, 0};   // centre columns per class
-    void add(int bandwidth, int jlr, int jlc) {
+    std::vector<int> wide[2];     // indices of the jobs of classes 1 and 2 (few), when the caller passes the job's index to add()
+    bool wide_listed = false;
+    void add(int bandwidth, int jlr, int jlc, long long index = -1) {
         const int b = msa_pair_band(bandwidth, jlr, jlc);   // capped at MSA_MAXBAND by the spec
         const int cls = b <= 256 ? 0 : (b <= 512 ? 1 : 2);
         ++n[cls];
         cols[cls] += jlc;
+        if (index >= 0) { wide_listed = true; if (cls > 0) wide[cls - 1].push_back(static_cast<int>(index)); }
         lr[cls] = jlr > lr[cls] ? jlr : lr[cls];
         lc[cls] = jlc > lc[cls] ? jlc : lc[cls];
         band[cls] = b > band[cls] ? b : band[cls];
@@ -78,6 +84,8 @@ struct MsaJobSummary {
             band[k] = o.band[k] > band[k] ? o.band[k] : band[k];
             cols[k] += o.cols[k];
         }
+        for (int k = 0; k < 2; ++k) wide[k].insert(wide[k].end(), o.wide[k].begin(), o.wide[k].end());
+        wide_listed = wide_listed || o.wide_listed;
         cells += o.cells;
     }
 };

@@ -731,10 +731,11 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
     for (int batch = A.batch0 + blockIdx.x; batch < A.batch1; batch += gridDim.x) {
         uint4* const tile = static_cast<uint4*>(A.tb) + static_cast<size_t>(PHASE == 0 ? blockIdx.x : batch - A.batch0) * (A.tb_per_wave / 4);
         const int jobn = batch * 64 + lane;
-        const bool on = jobn < A.njobs;
+        bool on = jobn < A.njobs;
         const int jobidx = on ? (A.order ? A.order[jobn] : jobn) : 0;
         MsaJob J{};
         if (on) J = A.jobs[jobidx];
+        if (A.skip_wide && on && msa_pair_band(A.bw, J.lr, J.lc) > 256) on = false;   // a job of a wider band class: the packed kernel's
         const int lr = on ? J.lr : 0, lc = on ? J.lc : 0;
         const int bw = msa_pair_bandwidth(A.bw, lr, lc);
         uint16_t* const mapA = A.map + J.out_off;
@@ -963,6 +964,7 @@ __global__ void __launch_bounds__(256) k_msa_moves_expand(const MsaArgs A) {
     const int jobidx = A.order ? A.order[jobn] : jobn;
     const MsaJob J = A.jobs[jobidx];
     if (msa_pair_bandwidth(A.bw, J.lr, J.lc) < 0) return;   // the diagonal alignment: written by the pairwise kernel itself
+    if (A.skip_wide && msa_pair_band(A.bw, J.lr, J.lc) > 256) return;
     uint16_t* const mapA = A.map + J.out_off;
     uint16_t* const mapB = A.map + J.out2_off;
     const uint32_t* const mv = A.moves + static_cast<size_t>(jobidx) * A.moves_stride;
@@ -1090,7 +1092,21 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
     const int *cls_lr = summary->lr, *cls_lc = summary->lc, *cls_band = summary->band;
     // the usual case -- every pair in one class -- needs no index list: the launch takes the jobs as they are
     const bool one_class = cls_n[0] == jobs.size() || cls_n[1] == jobs.size() || cls_n[2] == jobs.size();
-    if (!one_class) {
+    // The planner lists the few jobs of the wide classes itself (msa2.hip): the bit-vector kernels then take the whole job list
+    // and skip those lanes, and no 4-million-entry index list is built or uploaded for class 0.
+    const int cost_ok_ma = static_cast<int>(match), cost_ok_mm = static_cast<int>(mismatch), cost_ok_go = static_cast<int>(gap_opening),
+              cost_ok_ge = static_cast<int>(gap_extension);
+    int pm = 0, pg = 0, pe = 0;
+    const bool bv_class0 = out_mode == 1 && !option(OPT_MSA_INT32) && option(OPT_MSA_BITVECTOR) >= 0 &&
+                           cost_domain(cost_ok_ma, cost_ok_mm, cost_ok_go, cost_ok_ge, &pm, &pg, &pe) && pg <= pe && pm == pg && pg > 0 &&
+                           pk_range_ok(pm, pg, pe, cls_band[0]);
+    const bool implicit0 = !one_class && summary->wide_listed && bv_class0;
+    if (implicit0) {
+        order[1] = summary->wide[0];
+        order[2] = summary->wide[1];
+        std::sort(order[1].begin(), order[1].end());
+        std::sort(order[2].begin(), order[2].end());
+    } else if (!one_class) {
         for (int k = 0; k < 3; ++k) order[k].reserve(cls_n[k]);
         for (size_t q = 0; q < jobs.size(); ++q) {
             const int band = msa_pair_band(bandwidth, jobs[q].lr, jobs[q].lc);
@@ -1118,13 +1134,14 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
         // traceback tile of one resident wave, 4 bits per cell: packed kernel C/4 dwords per lane per 4 steps,
         // 32-bit kernel one (C = 16: 64-bit) word per lane per 2 SPW steps
         // unit-cost linear regime (the default scores), maps + stats, bands of up to 256 diagonals: the bit-vector kernels
-        if (packed && out_mode == 1 && cls == 0 && a.go <= a.ge && a.mm == a.go && a.go > 0 && option(OPT_MSA_BITVECTOR) >= 0) {
+        if (cls == 0 && bv_class0) {
             const int NWb = cls_band[cls] <= 128 ? 4 : 8;
             const size_t per_wave = (static_cast<size_t>(cls_lc[cls]) + 8) * 2 * NWb * 64;   // 32-bit words: 2 NW per column and pair, in blocks of four columns
-            const long long nbatch = (static_cast<long long>(cls_n[cls]) + 63) / 64;
+            const long long nbatch = ((implicit0 ? static_cast<long long>(jobs.size()) : static_cast<long long>(cls_n[cls])) + 63) / 64;
             int* d_order = nullptr;
-            if (!one_class) SL_TRY(upload("msa.ord0", order[cls].data(), order[cls].size(), &d_order, s));
-            a.order = d_order; a.njobs = static_cast<int>(cls_n[cls]);
+            if (!one_class && !implicit0) SL_TRY(upload("msa.ord0", order[cls].data(), order[cls].size(), &d_order, s));
+            a.order = d_order; a.njobs = implicit0 ? static_cast<int>(jobs.size()) : static_cast<int>(cls_n[cls]);
+            a.skip_wide = implicit0 ? 1 : 0;
             a.tb_per_wave = per_wave;
             // move strings: one word of length + 2 bits per move, at the job's index
             a.moves_stride = static_cast<unsigned>((cls_lr[cls] + cls_lc[cls] + 15) / 16 + 2);
@@ -1164,7 +1181,8 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
                 if (NWb == 4) hipLaunchKernelGGL((k_msa_pairwise_bv<4, 0>), dim3(static_cast<unsigned>(grid)), dim3(64), 0, s, a);
                 else hipLaunchKernelGGL((k_msa_pairwise_bv<8, 0>), dim3(static_cast<unsigned>(grid)), dim3(64), 0, s, a);
             }
-            hipLaunchKernelGGL(k_msa_moves_expand, dim3(static_cast<unsigned>((cls_n[cls] + 3) / 4)), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_msa_moves_expand, dim3(static_cast<unsigned>((static_cast<size_t>(a.njobs) + 3) / 4)), dim3(256), 0, s, a);
+            a.skip_wide = 0;
             SL_HIP(hipGetLastError());
             ctx().counts["msa_pairs_bitvector"] += static_cast<double>(cls_n[cls]);
             // traceback records: 2 NW words per centre column and pair, written once
