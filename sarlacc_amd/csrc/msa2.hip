@@ -1337,7 +1337,7 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
     // ---- guide trees, leaves, candidate tables ----
     SL_TRY(c.stage_begin("msa_merge", s));
     hipLaunchKernelGGL(k_m2_tree, dim3(m2_blocks(static_cast<long long>(ng), 64)), dim3(64), 0, s, a);
-    if (nm) hipLaunchKernelGGL(k_m2_init, dim3(std::max(1u, m2_blocks(B.max_len, 256)), static_cast<unsigned>(nm)), dim3(256), 0, s, a, d_mg, static_cast<int>(nm));
+    if (nm) hipLaunchKernelGGL(k_m2_init, dim3(std::min(2u, std::max(1u, m2_blocks(B.max_len, 256))), static_cast<unsigned>(nm)), dim3(256), 0, s, a, d_mg, static_cast<int>(nm));
     SL_HIP(hipGetLastError());
     const bool unitw = a.ma <= 1 && a.mm <= 1 && !option(OPT_MSA2_GENERAL_ROWS);
     M2Cand* d_tab = nullptr;
@@ -1450,7 +1450,9 @@ static int m2_write_batch(M2Batch& B, const std::string& pf, const std::vector<l
     }
     int maxw = 1;
     for (int32_t w : B.width) maxw = std::max(maxw, static_cast<int>(w));
-    hipLaunchKernelGGL(k_m2_write, dim3(std::max(1u, m2_blocks(maxw, 256)), static_cast<unsigned>(B.members.size())), dim3(256), 0, s, B.a,
+    // two workgroups per row at most (the kernel strides over the row): with one workgroup per 256 columns of the WIDEST group, most
+    // of the ~20 million workgroups of a 10^6-read batch found nothing to do and the launch rate, not the bytes, set the time
+    hipLaunchKernelGGL(k_m2_write, dim3(std::min(2u, std::max(1u, m2_blocks(maxw, 256))), static_cast<unsigned>(B.members.size())), dim3(256), 0, s, B.a,
                        B.d_member_group, static_cast<int>(B.members.size()), d_off);
     SL_HIP(hipGetLastError());
     return 0;
