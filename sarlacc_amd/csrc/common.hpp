@@ -53,7 +53,7 @@ enum Opt {
     OPT_MSA_INT32,            // pairwise MSA alignments by the 32-bit kernel
     OPT_MSA_AFFINE,           // pairwise MSA alignments by the full affine recurrence also where open <= extend makes it linear
     OPT_UMI_FULL_ROUNDS,      // greedy clustering of dense graphs: every round walks every live list (A/B of the candidate-set rounds)
-    OPT_UMI_TILE_SEARCH,      // neighbour search at thresholds 2 and 3 by the all-tile-pairs kernel (A/B of the split-key search)
+    OPT_UMI_TILE_SEARCH,      // neighbour search at thresholds 1 to 3 by the all-tile-pairs kernel (A/B of the split-key search)
     OPT_MSA_BITVECTOR,        // pairwise MSA alignments: -1 never by the bit-vector kernel of the unit-cost linear regime (A/B)
     OPT_MSA_BITVECTOR_TILE_GB,   // bit-vector pairwise kernel: GB of traceback records per chunk of batches (default 48; perf sweeps)
     OPT_ALIGN_INTERLEAVE,     // quality DP: -1 never two 8-lane alignments per DPP row (A/B of that shape); 1 with align_k: that shape

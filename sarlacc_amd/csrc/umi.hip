@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs_long(const PairArgs A) {
 }
 
 // ---------------------------------------------------------------------------
-// Split-key neighbour search for thresholds 2 and 3 on large sets.
+// Split-key neighbour search for thresholds 1 to 3 on large sets.
 //
 // The all-tile-pairs search above looks at every pair: at threshold 3 on 12-base UMIs its length, composition and
 // shifted-Hamming bounds pass most of them on to the exact DP.  The search below enumerates candidates instead.
@@ -633,7 +633,7 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs_long(const PairArgs A) {
 //     P(a,b): some prefix of b is within k1 edits of the first h bases of a,  or
 //     S(a,b): some suffix of b is within k2 edits of the last s bases of a
 // (the last s bases of a lie inside the second part, and the part of an alignment that covers them costs no more than
-// the whole).  With k1, k2 <= 1 the strings b that satisfy P(a, .) are those that start with one of the <= 8h + 5
+// the whole; threshold 1: k1 = k2 = 0, one of the two keys matches exactly).  With k1, k2 <= 1 the strings b that satisfy P(a, .) are those that start with one of the <= 8h + 5
 // one-edit variants of a[0..h) -- a union of contiguous ranges of the set in trie order; S(a, .) the same in the order
 // of the reversed strings.  Rows that share their first h bases share the ranges, so the work items are (row group,
 // 256 candidate columns); a lane holds one column as the pattern of a bit-vector edit distance (Myers 1999 / Hyyro
@@ -1530,8 +1530,8 @@ static int sk_plan(const std::string& p, const SortedUmis& S, int limit, SkPlan*
         const int h = std::min(L / 2, SK_MAX_KEY);
         plan->classes.push_back(SkClass{L, L == 2 * SK_MAX_KEY ? 32 : L, h, std::min(L - h, SK_MAX_KEY)});
     }
-    plan->k1 = 1;
-    plan->k2 = limit - 2;   // limit 2: the suffix key has to match exactly; limit 3: one edit
+    plan->k1 = limit >= 2 ? 1 : 0;   // limit 1: both keys have to match exactly; 2: the suffix key; 3: one edit in either
+    plan->k2 = limit - 1 - plan->k1;
     long long shorter = 0;
     for (int L = 0; L < SK_MIN_LEN; ++L) shorter += hist[L];
     plan->nspecial = shorter + hist[33];   // an upper bound (short strings with an N count twice)
@@ -1683,12 +1683,12 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
         SL_TRY(c.buffer((p + ".edges").c_str(), cap * sizeof(unsigned long long), &pe));
         d_edges = static_cast<unsigned long long*>(pe);
     }
-    // Thresholds 2 and 3 on a large set: candidates from the split keys (see k_sk_scan); the tile kernel then only
+    // Thresholds 1 to 3 on a large set: candidates from the split keys (see k_sk_scan); the tile kernel then only
     // looks at the pairs with a "special" member, if there are any.
     SkPlan plan;
     std::vector<SkScan> fwd, rev;
     const int min_n = option(OPT_UMI_SPLIT_MIN) > 0 ? option(OPT_UMI_SPLIT_MIN) : SK_MIN_N;
-    bool split = S.words == 1 && (limit == 2 || limit == 3) && n >= min_n && !option(OPT_UMI_TILE_SEARCH) &&
+    bool split = S.words == 1 && limit >= 1 && limit <= 3 && n >= min_n && !option(OPT_UMI_TILE_SEARCH) &&
                  n / std::max(S.ngroups, 1) >= min_n / 2;
     if (split) {
         SL_TRY(sk_plan(p, S, limit, &plan, s));

@@ -240,14 +240,14 @@ def test_split_key_search_small_sets(oracle, lo, hi, n_rate, short, split):
         calls.set_option("umi_split_min", 64)
         for rep in range(3):
             umis = noisy_umis(rng, 150, lo, hi, n_rate, short)
-            for t in (2, 3):
+            for t in (1, 2, 3):
                 got = calls.fast_levdist_test(umis, t)
                 assert _lib.stage_count("umi_split_search") == split
                 same_lists(got, oracle.fast_levdist_test(umis, t))
             n = len(umis)
             pre = rng.integers(0, 2, n)
             for groups in ([list(range(1, n + 1))], [(np.flatnonzero(pre == g) + 1).tolist() for g in range(2)]):
-                for t in (2, 3):
+                for t in (1, 2, 3):
                     try:
                         want = oracle.umi_group(umis, t, None, t, groups, fast=True)
                     except oracle.OracleError as e:
@@ -259,7 +259,7 @@ def test_split_key_search_small_sets(oracle, lo, hi, n_rate, short, split):
         calls.set_option("umi_split_min", 0)
 
 
-@pytest.mark.parametrize("threshold,n", [(2, 100000), (3, 40000)])
+@pytest.mark.parametrize("threshold,n", [(1, 100000), (2, 100000), (3, 40000)])
 def test_split_key_search_equals_tile_search_and_oracle(oracle, threshold, n):
     # BASELINE config 3's shape (12-base UMIs, 10 reads per molecule, mockReads errors) from the size on where the split-key
     # search takes over by itself: the same groups as the all-tile-pairs search and as the oracle
@@ -315,7 +315,7 @@ def test_tile_sharded_pairs_reproduce_umi_group(oracle, split_min):
             same_lists(want, oracle.umi_group(umis, limit, None, limit, g, fast=True))
             for world in (1, 3, 8):
                 parts = [calls.umi_pairs_shard(umis, limit, r, world) for r in range(world)]
-                assert _lib.stage_count("umi_split_search") == (1 if split_min and limit >= 2 else 0)
+                assert _lib.stage_count("umi_split_search") == (1 if split_min else 0)
                 allp = np.concatenate(parts)
                 assert len(np.unique(allp)) == allp.size            # no pair is found twice
                 same_lists(calls.umi_group_from_pairs(umis, limit, allp), want)
