@@ -445,6 +445,7 @@ def main():
                             "traceback_write_frac_of_peak": tile / pw_s / 1e9 / HBM_PEAK_GBS,
                             "tcups": cnt["msa_cells"] / pw_s / 1e12, "pairs_per_s": cnt["msa_pairs"] / pw_s,
                             "pairs_on_bit_vectors": cnt["msa_pairs_bitvector"],
+                            "pairs_run_again_with_whole_records": cnt.get("msa_bitvector_redone", 0.0),
                             "traffic": pm["traffic"], "traffic_source": pm["traffic_source"], "pmc": pm.get("derived"),
                             "traffic_ratio": pm["traffic"] / msa_alg_bytes if pm["traffic"] else None,
                             "note": "compulsory traffic (reads in, position maps out) is a few per cent of what the kernel writes as traceback records, "

@@ -55,6 +55,7 @@ enum Opt {
     OPT_UMI_FULL_ROUNDS,      // greedy clustering of dense graphs: every round walks every live list (A/B of the candidate-set rounds)
     OPT_UMI_TILE_SEARCH,      // neighbour search at thresholds 1 to 3 by the all-tile-pairs kernel (A/B of the split-key search)
     OPT_MSA_BITVECTOR,        // pairwise MSA alignments: -1 never by the bit-vector kernel of the unit-cost linear regime (A/B)
+    OPT_MSA_BITVECTOR_CORE,      // bit-vector pairwise kernel: -1 whole traceback records always; 1 walks may use ONE word of the partial records (tests of the second run)
     OPT_MSA_BITVECTOR_TILE_GB,   // bit-vector pairwise kernel: GB of traceback records per chunk of batches (default 48; perf sweeps)
     OPT_ALIGN_INTERLEAVE,     // quality DP: -1 never two 8-lane alignments per DPP row (A/B of that shape); 1 with align_k: that shape
     OPT_UMI_SPLIT_MIN,        // smallest set (and half of it: smallest average pre-group) that takes the split-key search (default 32768; tests lower it)

@@ -1680,7 +1680,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
                            "msa2_entries_kept", "msa2_joins", "msa2_joins_chain_in_hbm", "msa2_cycles_rows", "msa2_cycles_chain",
                            "msa2_cycles_walk", "msa2_cycles_renumber", "msa2_launches", "msa2_first_exit_s", "msa2_last_exit_s",
                            "msa2_exit_s_1wave", "msa2_exit_s_4waves", "msa2_exit_s_8waves", "msa_pairs_bitvector", "msa_bitvector_tile_bytes",
-                           "msa_bitvector_split"})
+                           "msa_bitvector_split", "msa_bitvector_redone"})
         c.counts[nm] = 0;
     if (v2.empty())
         return msa1_run(grp_off, grp, ngroups, seq, seq_off, nseq, match, mismatch, gap_extension, gap_opening, bandwidth, want_rows,

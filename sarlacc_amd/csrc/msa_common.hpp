@@ -34,6 +34,7 @@ struct MsaArgs {
     uint32_t* moves;        // bit-vector kernel: per job, the traceback as a move string (see k_msa_pairwise_bv)
     unsigned moves_stride;  // words per job
     int batch0, batch1;     // bit-vector kernel: the batches (of 64 jobs) this launch works on
+    int core_lo, core_hi;   // bit-vector kernel with partial records: the words a walk may use (inside the kept ones; tests narrow it)
     int skip_wide;          // bit-vector kernel: the job list holds jobs of wider band classes too; their lanes stay idle
     int* stuck;             // set when a traceback exceeds its step bound (cannot happen with consistent codes;
                             // the bound is what guarantees that every wave leaves the walk)

@@ -723,9 +723,18 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_pk(const MsaArgs A) {
 //     own tile -- all wavefronts of the first compute (instruction latency hidden by each other instead of sharing the SIMDs
 //     with waiting walks), the second runs at several times the residency (no LDS, few registers), which is what a walk
 //     that waits for memory needs.  PHASE 0: both in one kernel, one tile per resident wavefront (small job lists).
-template <int NW, int PHASE>
+//   * NS < NW: only the words CORE0 .. CORE0 + NS - 1 of every record are kept.  The diagonals from (0, 0) to (lr, lc) sit at
+//     bits 32 NW - 1 - bandwidth - |lc - lr| .. 32 NW - 1 - bandwidth whatever the pair (the band is anchored at its bottom
+//     bit), so for the usual bandwidths one fixed window of four words holds every path that drifts less than ~60 diagonals
+//     -- all alignments of reads of one molecule -- at half the records.  A walk that needs another word stops and marks its
+//     pair (move count BV_REDO); the marked pairs are collected and run again with whole records (k_bv_collect_redo).
+constexpr uint32_t BV_REDO = 0xFFFFFFFFu;
+constexpr int BV_CORE0 = 3, BV_CORE_WORDS = 4;   // NW = 8, bandwidths 96 .. 127: bits 96 .. 223 around the main diagonals (bits 128 - |lc - lr| .. 159)
+
+template <int NW, int PHASE, int NS>
 __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
-    constexpr int BV_LSTRIDE = 2 * NW * 4 + 4;   // dwords per pair in the LDS block (padded: the pairs' pieces spread over the banks)
+    constexpr int CORE0 = NS < NW ? BV_CORE0 : 0;
+    constexpr int BV_LSTRIDE = 2 * NS * 4 + 4;   // dwords per pair in the LDS block (padded: the pairs' pieces spread over the banks)
     __shared__ __align__(16) uint32_t s_rec[PHASE == 2 ? 4 : 64 * BV_LSTRIDE];
     const int lane = threadIdx.x;
     for (int batch = A.batch0 + blockIdx.x; batch < A.batch1; batch += gridDim.x) {
@@ -874,19 +883,21 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
                 const int c4 = (j - 1) & 3;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
-                    s_rec[lane * BV_LSTRIDE + (2 * w) * 4 + c4] = Dg[w];
-                    s_rec[lane * BV_LSTRIDE + (2 * w + 1) * 4 + c4] = Up[w];
+                    if (w >= CORE0 && w < CORE0 + NS) {
+                        s_rec[lane * BV_LSTRIDE + (2 * (w - CORE0)) * 4 + c4] = Dg[w];
+                        s_rec[lane * BV_LSTRIDE + (2 * (w - CORE0) + 1) * 4 + c4] = Up[w];
+                    }
                 }
             }
             if ((j & 3) == 0 || j == lcw) {
                 // four columns of all 64 pairs -> one block of the tile, [pair][piece] with 16 bytes per piece: every store
                 // instruction writes 1 KB of consecutive addresses, and a pair's record (2 NW pieces) is contiguous for the walk
                 __syncthreads();
-                const size_t blk = static_cast<size_t>((j - 1) >> 2) * (2 * NW * 64 / 4) * 4;   // uint4 index of the block
+                const size_t blk = static_cast<size_t>((j - 1) >> 2) * (2 * NS * 64 / 4) * 4;   // uint4 index of the block
 #pragma unroll
-                for (int sidx = 0; sidx < 2 * NW * 64 / 4 / 16; ++sidx) {
+                for (int sidx = 0; sidx < 2 * NS * 64 / 4 / 16; ++sidx) {
                     const int lin = sidx * 64 + lane;                // 16-byte unit inside the block
-                    const int pl = lin / (2 * NW), piece = lin % (2 * NW);
+                    const int pl = lin / (2 * NS), piece = lin % (2 * NS);
                     const uint4 v = *reinterpret_cast<const uint4*>(&s_rec[pl * BV_LSTRIDE + piece * 4]);
                     tile[blk + lin] = v;
                 }
@@ -912,6 +923,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
             uint32_t* const mv = A.moves + static_cast<size_t>(jobidx) * A.moves_stride;
             uint32_t macc = 0u;
             int nmoves = 0;
+            bool redo = false;
             auto push = [&](uint32_t m) {
                 macc |= m << (2 * (nmoves & 15));
                 ++nmoves;
@@ -928,8 +940,9 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
                 const int w = bit >> 5, sh = bit & 31;
                 // the pair's record of the four-column block that holds column j: pieces 2 w (Dg) and 2 w + 1 (Up)
                 const int c4 = (j - 1) & 3;
-                const uint4* const rec = tile + (static_cast<size_t>((j - 1) >> 2) * 64 + lane) * (2 * NW);
-                const uint4 dq = rec[2 * w], uq = rec[2 * w + 1];
+                if (NS < NW && (w < A.core_lo || w > A.core_hi)) { redo = true; i = j = 0; continue; }   // outside the kept words
+                const uint4* const rec = tile + (static_cast<size_t>((j - 1) >> 2) * 64 + lane) * (2 * NS);
+                const uint4 dq = rec[2 * (w - CORE0)], uq = rec[2 * (w - CORE0) + 1];
                 auto pick = [](const uint4& q, int c) -> uint32_t { return c == 0 ? q.x : (c == 1 ? q.y : (c == 2 ? q.z : q.w)); };
                 bool run = true;
 #pragma unroll
@@ -946,7 +959,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
             }
             if (dp) {
                 if (nmoves & 15) mv[1 + (nmoves >> 4)] = macc;
-                mv[0] = static_cast<uint32_t>(nmoves);
+                mv[0] = redo ? BV_REDO : static_cast<uint32_t>(nmoves);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -957,6 +970,26 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
 // step, their positions from prefix counts over the lanes (ballots), so the map entries of a step are written side by side.
 // The whole move string sits in registers first (word k of it in lane k % 64), and four steps' worth of positions are
 // worked out before their bases are fetched, so a step does not wait for the memory of the one before.
+// the jobs whose walk left the kept words of their records (see NS above), in job order
+__global__ void k_bv_collect_redo(const MsaArgs A, int* list, int* count) {
+    const int jobn = blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = false;
+    int jobidx = 0;
+    if (jobn < A.njobs) {
+        jobidx = A.order ? A.order[jobn] : jobn;
+        const MsaJob J = A.jobs[jobidx];
+        hit = msa_pair_bandwidth(A.bw, J.lr, J.lc) >= 0 && !(A.skip_wide && msa_pair_band(A.bw, J.lr, J.lc) > 256) &&
+              A.moves[static_cast<size_t>(jobidx) * A.moves_stride] == BV_REDO;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, 0);
+    if (hit) list[base + __popcll(m & ((1ull << lane) - 1ull))] = jobidx;
+}
+
 __global__ void __launch_bounds__(256) k_msa_moves_expand(const MsaArgs A) {
     const int lane = threadIdx.x & 63;
     const int jobn = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1136,13 +1169,20 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
         // unit-cost linear regime (the default scores), maps + stats, bands of up to 256 diagonals: the bit-vector kernels
         if (cls == 0 && bv_class0) {
             const int NWb = cls_band[cls] <= 128 ? 4 : 8;
-            const size_t per_wave = (static_cast<size_t>(cls_lc[cls]) + 8) * 2 * NWb * 64;   // 32-bit words: 2 NW per column and pair, in blocks of four columns
+            // partial records (the four words around the main diagonals) for the usual bandwidths on large lists; whole records otherwise
+            const int core_opt = option(OPT_MSA_BITVECTOR_CORE);
+            const bool core = NWb == 8 && bandwidth >= 96 && bandwidth <= 127 && core_opt >= 0;
+            const int NSb = core ? BV_CORE_WORDS : NWb;
+            const size_t per_full = (static_cast<size_t>(cls_lc[cls]) + 8) * 2 * NWb * 64;   // 32-bit words: 2 NW per column and pair, in blocks of four columns
+            const size_t per_wave = (static_cast<size_t>(cls_lc[cls]) + 8) * 2 * NSb * 64;
             const long long nbatch = ((implicit0 ? static_cast<long long>(jobs.size()) : static_cast<long long>(cls_n[cls])) + 63) / 64;
             int* d_order = nullptr;
             if (!one_class && !implicit0) SL_TRY(upload("msa.ord0", order[cls].data(), order[cls].size(), &d_order, s));
             a.order = d_order; a.njobs = implicit0 ? static_cast<int>(jobs.size()) : static_cast<int>(cls_n[cls]);
             a.skip_wide = implicit0 ? 1 : 0;
             a.tb_per_wave = per_wave;
+            a.core_lo = BV_CORE0; a.core_hi = BV_CORE0 + BV_CORE_WORDS - 1;
+            if (core_opt == 1) a.core_lo = a.core_hi = BV_CORE0 + 1;   // tests: one word only, most walks leave it and take the second run
             // move strings: one word of length + 2 bits per move, at the job's index
             a.moves_stride = static_cast<unsigned>((cls_lr[cls] + cls_lc[cls] + 15) / 16 + 2);
             SL_TRY(scratch("msa.moves", jobs.size() * static_cast<size_t>(a.moves_stride), &a.moves));
@@ -1157,36 +1197,71 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
             const long long chunk = static_cast<long long>(tile_budget / (per_wave * 4));
             const bool split = option(OPT_MSA_BITVECTOR) != 2 && nbatch >= 4LL * c.num_cu && chunk >= 8LL * c.num_cu;
             void* d_tb;
-            if (split) {
-                const long long per = std::min(chunk, nbatch);
-                SL_TRY(c.buffer("msa.tb0", static_cast<size_t>(per) * per_wave * 4, &d_tb));
-                a.tb = d_tb;
-                for (long long b0 = 0; b0 < nbatch; b0 += per) {
-                    a.batch0 = static_cast<int>(b0); a.batch1 = static_cast<int>(std::min(nbatch, b0 + per));
+            auto whole_records = [&](long long nb, const char* name) -> int {   // both phases in one kernel, one tile per resident wavefront
+                long long grid = std::min<long long>(nb, static_cast<long long>(c.num_cu) * 16);
+                const size_t budget = static_cast<size_t>(24) << 30;
+                grid = std::min<long long>(grid, std::max<long long>(1, static_cast<long long>(budget / (per_full * 4))));
+                SL_TRY(c.buffer(name, static_cast<size_t>(grid) * per_full * 4, &d_tb));
+                a.tb = d_tb; a.tb_per_wave = per_full; a.batch0 = 0; a.batch1 = static_cast<int>(nb);
+                if (NWb == 4) hipLaunchKernelGGL((k_msa_pairwise_bv<4, 0, 4>), dim3(static_cast<unsigned>(grid)), dim3(64), 0, s, a);
+                else hipLaunchKernelGGL((k_msa_pairwise_bv<8, 0, 8>), dim3(static_cast<unsigned>(grid)), dim3(64), 0, s, a);
+                return 0;
+            };
+            long long redone = 0;
+            // fill and walk kernels over chunks of `nb` batches; partial = only the core words of the records
+            auto chunks = [&](long long nb, bool partial) -> int {
+                const size_t pw = partial ? per_wave : per_full;
+                const long long per = std::max<long long>(1, std::min(static_cast<long long>(tile_budget / (pw * 4)), nb));
+                SL_TRY(c.buffer("msa.tb0", static_cast<size_t>(per) * pw * 4, &d_tb));
+                a.tb = d_tb; a.tb_per_wave = pw;
+                for (long long b0 = 0; b0 < nb; b0 += per) {
+                    a.batch0 = static_cast<int>(b0); a.batch1 = static_cast<int>(std::min(nb, b0 + per));
                     const unsigned g = static_cast<unsigned>(a.batch1 - a.batch0);
                     if (NWb == 4) {
-                        hipLaunchKernelGGL((k_msa_pairwise_bv<4, 1>), dim3(g), dim3(64), 0, s, a);
-                        hipLaunchKernelGGL((k_msa_pairwise_bv<4, 2>), dim3(g), dim3(64), 0, s, a);
+                        hipLaunchKernelGGL((k_msa_pairwise_bv<4, 1, 4>), dim3(g), dim3(64), 0, s, a);
+                        hipLaunchKernelGGL((k_msa_pairwise_bv<4, 2, 4>), dim3(g), dim3(64), 0, s, a);
+                    } else if (partial) {
+                        hipLaunchKernelGGL((k_msa_pairwise_bv<8, 1, BV_CORE_WORDS>), dim3(g), dim3(64), 0, s, a);
+                        hipLaunchKernelGGL((k_msa_pairwise_bv<8, 2, BV_CORE_WORDS>), dim3(g), dim3(64), 0, s, a);
                     } else {
-                        hipLaunchKernelGGL((k_msa_pairwise_bv<8, 1>), dim3(g), dim3(64), 0, s, a);
-                        hipLaunchKernelGGL((k_msa_pairwise_bv<8, 2>), dim3(g), dim3(64), 0, s, a);
+                        hipLaunchKernelGGL((k_msa_pairwise_bv<8, 1, 8>), dim3(g), dim3(64), 0, s, a);
+                        hipLaunchKernelGGL((k_msa_pairwise_bv<8, 2, 8>), dim3(g), dim3(64), 0, s, a);
+                    }
+                }
+                return 0;
+            };
+            if (split) {
+                SL_TRY(chunks(nbatch, core));
+                if (core) {
+                    // the pairs whose path left the kept words: collected, counted (one wait for the stream) and run again with whole records
+                    int *d_list, *d_cnt;
+                    SL_TRY(scratch("msa.redo", static_cast<size_t>(a.njobs) + 1, &d_list));
+                    SL_TRY(scratch("msa.redon", 1, &d_cnt));
+                    SL_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int), s));
+                    hipLaunchKernelGGL(k_bv_collect_redo, dim3(static_cast<unsigned>((static_cast<size_t>(a.njobs) + 255) / 256)), dim3(256), 0, s, a, d_list, d_cnt);
+                    int nredo = 0;
+                    SL_HIP(hipMemcpyAsync(&nredo, d_cnt, sizeof nredo, hipMemcpyDeviceToHost, s));
+                    SL_HIP(hipStreamSynchronize(s));
+                    redone = nredo;
+                    if (nredo > 0) {
+                        const MsaArgs keep = a;
+                        a.order = d_list; a.njobs = nredo; a.skip_wide = 0;
+                        const long long nb2 = (static_cast<long long>(nredo) + 63) / 64;
+                        if (nb2 >= 4LL * c.num_cu) SL_TRY(chunks(nb2, false)); else SL_TRY(whole_records(nb2, "msa.tb0"));
+                        a.order = keep.order; a.njobs = keep.njobs; a.skip_wide = keep.skip_wide;
                     }
                 }
             } else {
-                long long grid = std::min<long long>(nbatch, static_cast<long long>(c.num_cu) * 16);
-                const size_t budget = static_cast<size_t>(24) << 30;
-                grid = std::min<long long>(grid, std::max<long long>(1, static_cast<long long>(budget / (per_wave * 4))));
-                SL_TRY(c.buffer("msa.tb0", static_cast<size_t>(grid) * per_wave * 4, &d_tb));
-                a.tb = d_tb; a.batch0 = 0; a.batch1 = static_cast<int>(nbatch);
-                if (NWb == 4) hipLaunchKernelGGL((k_msa_pairwise_bv<4, 0>), dim3(static_cast<unsigned>(grid)), dim3(64), 0, s, a);
-                else hipLaunchKernelGGL((k_msa_pairwise_bv<8, 0>), dim3(static_cast<unsigned>(grid)), dim3(64), 0, s, a);
+                SL_TRY(whole_records(nbatch, "msa.tb0"));
             }
+            ctx().counts["msa_bitvector_redone"] += static_cast<double>(redone);
+            ctx().counts["msa_bitvector_core"] = (split && core) ? 1 : 0;
             hipLaunchKernelGGL(k_msa_moves_expand, dim3(static_cast<unsigned>((static_cast<size_t>(a.njobs) + 3) / 4)), dim3(256), 0, s, a);
             a.skip_wide = 0;
             SL_HIP(hipGetLastError());
             ctx().counts["msa_pairs_bitvector"] += static_cast<double>(cls_n[cls]);
             // traceback records: 2 NW words per centre column and pair, written once
-            ctx().counts["msa_bitvector_tile_bytes"] += summary->cols[cls] * 2 * NWb * 4;
+            ctx().counts["msa_bitvector_tile_bytes"] += summary->cols[cls] * 2 * ((split && core) ? BV_CORE_WORDS : NWb) * 4;
             ctx().counts["msa_bitvector_words"] = NWb;
             ctx().counts["msa_bitvector_split"] = split ? 1 : 0;
             continue;

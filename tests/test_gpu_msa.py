@@ -397,6 +397,53 @@ def test_pairwise_bitvector_kernel_edge_cases(oracle):
         calls.set_msa_spec(0)
 
 
+def test_pairwise_bitvector_partial_records_and_second_run(oracle):
+    """Large job lists keep only the four words of every traceback record that hold the main diagonals; a walk that needs
+    another word marks its pair, the marked pairs run again with whole records.  Enough pairs for that mode (>= 1024 batches of
+    64), some of them with indel-rich reads and length differences that push the path out of the window; the same rows with
+    whole records everywhere (msa_bitvector_core = -1), with walks confined to ONE word (= 1: most pairs take the second run),
+    and in a sample against the CPU statement."""
+    from sarlacc_amd import _lib, calls
+    from sarlacc_amd.mock import NUC, mutate
+    rng = np.random.default_rng(909)
+    reads, groups = [], []
+    for g in range(1500):
+        t = NUC[rng.integers(0, 4, 260)]
+        idx = []
+        for k in range(10):
+            if g % 25 == 0 and k % 3 == 0:      # a read with a long insertion or deletion: far from the straight diagonal
+                r = mutate(t, rng, 0.05, 0.02)
+                cut = int(rng.integers(40, 200))
+                r = np.concatenate([r[:cut], NUC[rng.integers(0, 4, 70)], r[cut:]]) if k % 2 else np.concatenate([r[:cut], r[cut + 70:]])
+            else:
+                r = mutate(t, rng, 0.05, 0.02)
+            reads.append(r.tobytes().decode())
+            idx.append(len(reads))
+        groups.append(idx)
+    params = (0, -1, -5, -1, 100)
+    calls.set_msa_spec(2)
+    try:
+        got = calls.quick_msa(groups, reads, *params)
+        assert _lib.stage_count("msa_bitvector_core") == 1
+        redone = _lib.stage_count("msa_bitvector_redone")
+        assert 0 < redone < 0.2 * _lib.stage_count("msa_pairs")
+        for val in (-1, 1):
+            calls.set_option("msa_bitvector_core", val)
+            try:
+                other = calls.quick_msa(groups, reads, *params)
+                if val == 1:
+                    assert _lib.stage_count("msa_bitvector_redone") > redone
+                else:
+                    assert _lib.stage_count("msa_bitvector_core") == 0
+            finally:
+                calls.set_option("msa_bitvector_core", 0)
+            assert got == other, val
+        sample = [0, 25, 26, 50, 75, 100, 777, 1499]
+        assert [got[g] for g in sample] == oracle.quick_msa([groups[g] for g in sample], reads, *params, spec=2)
+    finally:
+        calls.set_msa_spec(0)
+
+
 @pytest.mark.parametrize("seed,nmol,per,length", [(41, 2, 9, 500), (42, 3, 8, 400), (43, 2, 15, 900), (44, 4, 7, 250)])
 def test_msa_spec2_umi_collisions(oracle, seed, nmol, per, length):
     """Clusters of several unrelated molecules (UMI collisions: a quarter of the clusters at 10^5 molecules): their
