@@ -444,6 +444,39 @@ def test_pairwise_bitvector_partial_records_and_second_run(oracle):
         calls.set_msa_spec(0)
 
 
+def test_pairwise_bitvector_long_reads(oracle):
+    """Reads of 3 kb in the chunked mode (fill and walk kernels, partial records: >= 1024 batches of 64 pairs) and reads of
+    9 kb in the one-kernel mode, against the packed DP kernel; samples against the CPU statement."""
+    from sarlacc_amd import _lib, calls
+    from sarlacc_amd.mock import NUC, mutate
+    rng = np.random.default_rng(31337)
+    params = (0, -1, -5, -1, 100)
+    calls.set_msa_spec(2)
+    try:
+        for ngroups, per, length, sample in ((4400, 6, 3000, [0, 4399]), (6, 5, 9000, [0, 5])):
+            reads, groups = [], []
+            for g in range(ngroups):
+                t = NUC[rng.integers(0, 4, length)]
+                idx = []
+                for k in range(per):
+                    reads.append(mutate(t, rng, 0.04, 0.015).tobytes().decode())
+                    idx.append(len(reads))
+                groups.append(idx)
+            got = calls.quick_msa(groups, reads, *params)
+            # (all but the pairs whose length difference needs a band of more than 256 diagonals: those stay with the packed kernel)
+            assert _lib.stage_count("msa_pairs_bitvector") >= 0.5 * ngroups * per * (per - 1) // 2
+            assert _lib.stage_count("msa_bitvector_split") == (1 if ngroups > 1000 else 0)
+            calls.set_option("msa_bitvector", -1)
+            try:
+                other = calls.quick_msa(groups, reads, *params)
+            finally:
+                calls.set_option("msa_bitvector", 0)
+            assert got == other
+            assert [got[g] for g in sample] == oracle.quick_msa([groups[g] for g in sample], reads, *params, spec=2)
+    finally:
+        calls.set_msa_spec(0)
+
+
 @pytest.mark.parametrize("seed,nmol,per,length", [(41, 2, 9, 500), (42, 3, 8, 400), (43, 2, 15, 900), (44, 4, 7, 250)])
 def test_msa_spec2_umi_collisions(oracle, seed, nmol, per, length):
     """Clusters of several unrelated molecules (UMI collisions: a quarter of the clusters at 10^5 molecules): their
