@@ -757,11 +757,18 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
         };
         if (PHASE != 2 && on && bw < 0) {   // the diagonal alignment (msa_diagonal_pair), per lane
             const int k = min(lr, lc);
-            int nequal = 0;
-            for (int p = 0; p < lc; ++p) mapA[p] = p < k ? static_cast<uint16_t>(p) : static_cast<uint16_t>(0xFFFF);
-            for (int p = 0; p < lr; ++p) mapB[p] = p < k ? static_cast<uint16_t>(p) : static_cast<uint16_t>(0xFFFF);
-            for (int p = 0; p < k; ++p) nequal += code_of(rd[p]) == code_of(ct[p]);
-            A.stats[jobidx] = make_int2(nequal, k);
+            if (A.map) {
+                int nequal = 0;
+                for (int p = 0; p < lc; ++p) mapA[p] = p < k ? static_cast<uint16_t>(p) : static_cast<uint16_t>(0xFFFF);
+                for (int p = 0; p < lr; ++p) mapB[p] = p < k ? static_cast<uint16_t>(p) : static_cast<uint16_t>(0xFFFF);
+                for (int p = 0; p < k; ++p) nequal += code_of(rd[p]) == code_of(ct[p]);
+                A.stats[jobidx] = make_int2(nequal, k);
+            } else {   // spec v1's outputs: insertions before every centre position, centre bases matched
+                uint16_t* const ins = A.ins + J.out_off;
+                uint8_t* const aln = A.aln + J.out_off;
+                for (int p = 0; p <= lc; ++p) ins[p] = (p == lc && lr > lc) ? static_cast<uint16_t>(lr - lc) : static_cast<uint16_t>(0);
+                for (int p = 0; p < lc; ++p) aln[p] = p < k ? 1 : 0;
+            }
         }
         const bool dp = on && bw >= 0;
         const int dlo = min(0, lc - lr) - bw, dhi = max(0, lc - lr) + bw;
@@ -904,7 +911,7 @@ __global__ void __launch_bounds__(64) k_msa_pairwise_bv(const MsaArgs A) {
                 __syncthreads();
             }
         }
-        if (dp) A.stats[jobidx] = make_int2(dist, 0);   // for k_msa_moves_expand: equal pairs = diagonal moves - (distance - gaps)
+        if (dp && A.stats) A.stats[jobidx] = make_int2(dist, 0);   // for k_msa_moves_expand: equal pairs = diagonal moves - (distance - gaps)
         }
         if (PHASE == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -998,8 +1005,12 @@ __global__ void __launch_bounds__(256) k_msa_moves_expand(const MsaArgs A) {
     const MsaJob J = A.jobs[jobidx];
     if (msa_pair_bandwidth(A.bw, J.lr, J.lc) < 0) return;   // the diagonal alignment: written by the pairwise kernel itself
     if (A.skip_wide && msa_pair_band(A.bw, J.lr, J.lc) > 256) return;
+    const bool maps = A.map != nullptr;   // spec v2's position maps + counts; otherwise spec v1's insertion counts + matched flags
     uint16_t* const mapA = A.map + J.out_off;
     uint16_t* const mapB = A.map + J.out2_off;
+    uint16_t* const ins = A.ins + J.out_off;
+    uint8_t* const aln = A.aln + J.out_off;
+    int ups = 0;   // moves "up" (read bases opposite a gap) since the last move that consumed a centre column
     const uint32_t* const mv = A.moves + static_cast<size_t>(jobidx) * A.moves_stride;
     const int nmoves = static_cast<int>(mv[0]);
     const int nwords = (nmoves + 15) >> 4;
@@ -1026,14 +1037,39 @@ __global__ void __launch_bounds__(256) k_msa_moves_expand(const MsaArgs A) {
             i -= __popcll(bi); j -= __popcll(bj);
             ndiag += __popcll(__ballot(tm == 0u));
         }
+        if (maps) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (tq[u] == 0u) {
-                mapA[jq[u] - 1] = static_cast<uint16_t>(iq[u] - 1);
-                mapB[iq[u] - 1] = static_cast<uint16_t>(jq[u] - 1);
-            } else if (tq[u] == 1u) mapB[iq[u] - 1] = 0xFFFF;
-            else if (tq[u] == 2u) mapA[jq[u] - 1] = 0xFFFF;
+            for (int u = 0; u < 4; ++u) {
+                if (tq[u] == 0u) {
+                    mapA[jq[u] - 1] = static_cast<uint16_t>(iq[u] - 1);
+                    mapB[iq[u] - 1] = static_cast<uint16_t>(jq[u] - 1);
+                } else if (tq[u] == 1u) mapB[iq[u] - 1] = 0xFFFF;
+                else if (tq[u] == 2u) mapA[jq[u] - 1] = 0xFFFF;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // the read bases inserted before centre position j are the "up" moves met (walking back from the end) since the
+                // previous column-consuming move: the lanes between that move and this one, plus what earlier steps left over
+                const bool colmove = tq[u] == 0u || tq[u] == 2u;
+                const unsigned long long mc = __ballot(colmove), mvld = __ballot(tq[u] != 3u);
+                if (colmove) {
+                    const unsigned long long below = mc & lt;
+                    const int since = below ? lane - (63 - __builtin_clzll(below)) - 1 : lane + ups;
+                    ins[jq[u]] = static_cast<uint16_t>(since);
+                    aln[jq[u] - 1] = tq[u] == 0u ? 1 : 0;
+                }
+                const int nv = __popcll(mvld);
+                ups = mc ? nv - 1 - (63 - __builtin_clzll(mc)) : ups + nv;
+            }
         }
+    }
+    if (!maps) {
+        if (lane == 0) {
+            ins[0] = static_cast<uint16_t>(ups);
+            if (i != 0 || j != 0) atomicExch(A.stuck, 1);
+        }
+        return;
     }
     // every move costs 1 except a diagonal move over equal bases: mismatches = distance - gaps
     const int dist = A.stats[jobidx].x;
@@ -1130,7 +1166,7 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
     const int cost_ok_ma = static_cast<int>(match), cost_ok_mm = static_cast<int>(mismatch), cost_ok_go = static_cast<int>(gap_opening),
               cost_ok_ge = static_cast<int>(gap_extension);
     int pm = 0, pg = 0, pe = 0;
-    const bool bv_class0 = out_mode == 1 && !option(OPT_MSA_INT32) && option(OPT_MSA_BITVECTOR) >= 0 &&
+    const bool bv_class0 = !option(OPT_MSA_INT32) && option(OPT_MSA_BITVECTOR) >= 0 &&
                            cost_domain(cost_ok_ma, cost_ok_mm, cost_ok_go, cost_ok_ge, &pm, &pg, &pe) && pg <= pe && pm == pg && pg > 0 &&
                            pk_range_ok(pm, pg, pe, cls_band[0]);
     const bool implicit0 = !one_class && summary->wide_listed && bv_class0;

@@ -444,6 +444,43 @@ def test_pairwise_bitvector_partial_records_and_second_run(oracle):
         calls.set_msa_spec(0)
 
 
+def test_pairwise_bitvector_spec_v1_outputs(oracle):
+    """Spec v1 (centre-star) reads insertion counts and matched flags off the pairwise alignments instead of position maps:
+    the bit-vector kernel writes those from the same move strings.  Against the packed kernel and the CPU statement, with
+    empty and one-base reads, N and a pair beyond the band cap (diagonal alignment) in the groups."""
+    from sarlacc_amd import _lib, calls
+    from sarlacc_amd.mock import NUC, mutate
+    rng = np.random.default_rng(515)
+    reads, groups = [], []
+    for n, length in [(2, 300), (5, 150), (10, 700), (7, 0), (3, 1), (4, 1400)]:
+        t = NUC[rng.integers(0, 4, length)]
+        idx = []
+        for k in range(n):
+            r = mutate(t, rng, 0.05, 0.02).tobytes().decode()
+            if length == 1400 and k == 1:
+                r = r[:150]                      # |lc - lr| beyond the 1024-diagonal cap
+            if length == 700 and k == 2:
+                r = r[:100] + "N" + r[101:]
+            reads.append(r)
+            idx.append(len(reads))
+        groups.append(idx)
+    calls.set_msa_spec(1)
+    try:
+        for bw in (100, 10):
+            params = (0, -1, -5, -1, bw)
+            before = _lib.stage_count("msa_pairs_bitvector")
+            got = calls.quick_msa(groups, reads, *params)
+            assert _lib.stage_count("msa_pairs_bitvector") > before
+            assert got == oracle.quick_msa(groups, reads, *params, spec=1), bw
+            calls.set_option("msa_bitvector", -1)
+            try:
+                assert got == calls.quick_msa(groups, reads, *params), bw
+            finally:
+                calls.set_option("msa_bitvector", 0)
+    finally:
+        calls.set_msa_spec(0)
+
+
 def test_pairwise_bitvector_long_reads(oracle):
     """Reads of 3 kb in the chunked mode (fill and walk kernels, partial records: >= 1024 batches of 64 pairs) and reads of
     9 kb in the one-kernel mode, against the packed DP kernel; samples against the CPU statement."""
