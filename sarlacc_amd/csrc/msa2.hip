@@ -51,7 +51,7 @@ constexpr int M2_MAXN = 32;          // group sizes aligned by spec v2 (member s
 #ifndef M2_WAVES_EU
 #define M2_WAVES_EU 8   // wavefronts per SIMD the merge kernel is compiled for (its registers are capped accordingly)
 #endif
-constexpr int M2_NB = 20, M2_NC = 20; // groups of up to M2_NB reads: one wavefront; up to M2_NC: 4 (none at these settings); larger: 8 (k_m2_group; sweep: profiles/r03_exp_m2_class_thresholds_v1.txt)
+constexpr int M2_NB = 20, M2_NC = 24; // groups of up to M2_NB reads: one wavefront; up to M2_NC: 4; larger: 8 (k_m2_group; sweep: profiles/r03_exp_m2_class_thresholds_v1.txt)
 constexpr int M2_CAP = 16;           // partner columns per row (spec v2, step 5)
 constexpr unsigned M2_NONE = 0xFFFFu;
 // profile capacity of the first pass: same-molecule reads grow a profile by 10-20 %, one or two unrelated reads in
