@@ -94,26 +94,33 @@ def main():
         # Its traffic is the sum over all of them, per stage (= per launch of k_msa_moves_expand); the counters below stay those
         # of the dominant kernel (the fill).
         stage = ("k_msa_pairwise_bv", "k_msa_moves_expand")
-        def total(sub, counter):
-            tot, nexp = 0.0, set()
+        def stages(sub, counter):
+            # per stage: the counter summed over the stage's launches; a stage ends with its k_msa_moves_expand
+            per = {}
             for r in counter_rows(os.path.join(out_dir, sub)):
-                if r["Counter_Name"] != counter:
-                    continue
-                if any(k in r["Kernel_Name"] for k in stage):
-                    tot += float(r["Counter_Value"])
-                if "k_msa_moves_expand" in r["Kernel_Name"]:
-                    nexp.add(r["Dispatch_Id"])
-            return tot, len(nexp)
-        tf, nf = total("pmc_fetch", "FETCH_SIZE")
-        tw, nw = total("pmc_write", "WRITE_SIZE")
-        if nf and nw:
-            res["stage_launches_profiled"] = nf
-            res["traffic_bytes_per_launch"] = (2.0 * tf / nf + tw / nw) * 1024.0
-            res["traffic_scope"] = ("one pairwise stage = all launches of k_msa_pairwise_bv<NW, 1> (fill), <NW, 2> (walk) and k_msa_moves_expand "
-                                    "of one call, mean over %d stages of the bench run (pipeline passes and the pure-group passes)" % nf)
+                if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in stage):
+                    d = int(r["Dispatch_Id"])
+                    per.setdefault(d, [0.0, "k_msa_moves_expand" in r["Kernel_Name"]])[0] += float(r["Counter_Value"])
+            out, acc = [], 0.0
+            for d in sorted(per):
+                acc += per[d][0]
+                if per[d][1]:
+                    out.append(acc)
+                    acc = 0.0
+            return out
+        sf, sw = stages("pmc_fetch", "FETCH_SIZE"), stages("pmc_write", "WRITE_SIZE")
+        if sf and sw:
+            # the full-size stages only (the bench also runs the stage on spec v1's shorter job list)
+            bf = [x for x in sf if x >= 0.5 * max(sf)]
+            bw = [x for x in sw if x >= 0.5 * max(sw)]
+            res["stage_launches_profiled"] = len(sf)
+            res["fetch_bytes_per_stage"] = 2.0 * sum(bf) / len(bf) * 1024.0
+            res["write_bytes_per_stage"] = sum(bw) / len(bw) * 1024.0
+            res["traffic_bytes_per_launch"] = res["fetch_bytes_per_stage"] + res["write_bytes_per_stage"]
+            res["traffic_scope"] = ("one pairwise stage = all launches of k_msa_pairwise_bv<NW, 1, NS> (fill), <NW, 2, NS> (walk), the second run of the "
+                                    "pairs that left their partial records, and k_msa_moves_expand of one call; mean over the %d full-size stages "
+                                    "of the bench run (of %d: spec v1's shorter job list is left out)" % (len(bf), len(sf)))
             res["traffic_correction"] = "2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports half the bytes read), summed over the stage's launches"
-            res["fetch_bytes_per_stage"] = 2.0 * tf / nf * 1024.0
-            res["write_bytes_per_stage"] = tw / nw * 1024.0
     sq = {}
     for sub, names in (("pmc_sq", ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
                                    "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")),
