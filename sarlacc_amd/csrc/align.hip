@@ -182,7 +182,9 @@ static inline int snap_win(int R, int W) { return (SNAP_P + snap_head(R) + W + 7
 // (true instead of false), and the true flag is raw && !(previous cell's move is the same gap
 // kind) -- the traceback applies that from the neighbour's code, which it reads anyway.
 template <int K, int MODE, bool LOCAL, int ROWF, int KLAST, bool PENSEL>
-__global__ void __launch_bounds__(64 * NWAVES, MODE == 3 ? 6 : 5) k_align(const AlignArgs A) {
+// (six wavefronts per SIMD for the snapshot mode; five with eight alignments per wavefront: four columns per lane need the registers --
+// at six the recompute code spilled -- 2 182 -> 2 213 GCUPS on the same box)
+__global__ void __launch_bounds__(64 * NWAVES, (MODE == 3 && ROWF != 2) ? 6 : 5) k_align(const AlignArgs A) {
     constexpr bool ROW16 = ROWF != 0;                      // leaders keep their column-0 inputs through the DPP fill operand
     constexpr int NG = ROWF == 2 ? NGMAX2 : NGMAX;         // alignments per wavefront at most
     // uint16 entries per alignment's ring slot: 512 B slots let a ring address be base | offset; with eight
