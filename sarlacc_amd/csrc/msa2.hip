@@ -43,6 +43,7 @@
 #include <algorithm>
 #include <numeric>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace sarlacc {
@@ -1136,6 +1137,18 @@ static std::vector<MsaJob>& m2_job_pool() {
     static thread_local std::vector<MsaJob> pool;
     return pool;
 }
+// The pooled job table is page-locked (registered with the runtime) while it keeps its address: its 180 MB then go to the
+// device as one DMA transfer instead of through the runtime's staging buffer at the speed of a host memcpy (40 ms during which
+// the stream had nothing to run).  {address, bytes} of the current registration.
+static std::pair<void*, size_t>& m2_job_pin() {
+    static thread_local std::pair<void*, size_t> pin{nullptr, 0};
+    return pin;
+}
+static void m2_job_unpin() {
+    std::pair<void*, size_t>& pin = m2_job_pin();
+    if (pin.first) (void)hipHostUnregister(pin.first);
+    pin = {nullptr, 0};
+}
 
 // Host tables of a batch: groups, members, the pairwise jobs (4.4 million at C4).  The offsets come from one serial pass
 // over the groups; members and jobs are then filled by a few threads over disjoint ranges of groups.
@@ -1188,7 +1201,13 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
     {
         std::vector<MsaJob>& pool = m2_job_pool();
         if (B.jobs.empty() && !pool.empty()) B.jobs.swap(pool);
+        if (static_cast<size_t>(job_pos) > B.jobs.capacity() || B.jobs.data() != m2_job_pin().first) m2_job_unpin();   // the table moves (or is another one)
         B.jobs.resize(static_cast<size_t>(job_pos));
+        if (!m2_job_pin().first && job_pos >= (1 << 20)) {
+            const size_t bytes = B.jobs.capacity() * sizeof(MsaJob);
+            if (hipHostRegister(B.jobs.data(), bytes, hipHostRegisterDefault) == hipSuccess) m2_job_pin() = {B.jobs.data(), bytes};
+            else (void)hipGetLastError();   // (not page-locked then: the upload takes the slow way)
+        }
     }
     auto fill = [&](size_t q0, size_t q1, MsaJobSummary* sum) {
         for (size_t q = q0; q < q1; ++q) {
@@ -1590,6 +1609,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             {   // back to the pool (the larger of the two survives)
                 std::vector<MsaJob>& pool = m2_job_pool();
                 if (B.jobs.capacity() > pool.capacity()) pool.swap(B.jobs);
+                if (!B.jobs.empty() && B.jobs.data() == m2_job_pin().first) m2_job_unpin();   // (the table that is freed here)
                 std::vector<MsaJob>().swap(B.jobs);
             }
         }
