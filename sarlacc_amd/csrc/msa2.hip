@@ -1122,7 +1122,7 @@ struct M2Batch {
     std::vector<M2Group> groups;
     std::vector<M2Member> members;
     std::vector<int> member_group;
-    std::vector<MsaJob> jobs;
+    size_t njobs = 0;             // pairwise jobs of the batch (the table itself exists on the device only, k_m2_jobs)
     std::vector<int32_t> width;   // per group of the batch
     std::vector<int> ovf;
     M2Args a{};                   // device pointers
@@ -1133,25 +1133,37 @@ struct M2Batch {
     hipEvent_t pair_done = nullptr;   // the all-pairs alignments of the batch have finished (m2_prepare -> m2_merge)
 };
 
-static std::vector<MsaJob>& m2_job_pool() {
-    static thread_local std::vector<MsaJob> pool;
-    return pool;
-}
-// The pooled job table is page-locked (registered with the runtime) while it keeps its address: its 180 MB then go to the
-// device as one DMA transfer instead of through the runtime's staging buffer at the speed of a host memcpy (40 ms during which
-// the stream had nothing to run).  {address, bytes} of the current registration.
-static std::pair<void*, size_t>& m2_job_pin() {
-    static thread_local std::pair<void*, size_t> pin{nullptr, 0};
-    return pin;
-}
-static void m2_job_unpin() {
-    std::pair<void*, size_t>& pin = m2_job_pin();
-    if (pin.first) (void)hipHostUnregister(pin.first);
-    pin = {nullptr, 0};
+// The pairwise job table of a batch (4.4 million jobs, 180 MB at C4) is a function of the group and member tables: it is
+// written on the device (the host would fill it in 30 ms and the copy would hold the stream for 40 more; the host only counts
+// the band classes, MsaJobSummary).  One wavefront per group; job of (a, b), a < b, at M2Group::first_job + a n - a (a + 1) / 2 + b - a - 1,
+// rows = member b, columns = member a.
+__global__ __launch_bounds__(256) void k_m2_jobs(const M2Group* __restrict__ groups, const M2Member* __restrict__ members, int ngroups,
+                                                 MsaJob* __restrict__ jobs) {
+    const int q = static_cast<int>((static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= ngroups) return;
+    const M2Group G = groups[q];
+    const M2Member* const M = members + G.first_member;
+    const int n = G.n;
+    MsaJob* row = jobs + G.first_job;
+    for (int a = 0; a + 1 < n; ++a) {
+        const M2Member Ma = M[a];
+        for (int b = a + 1 + lane; b < n; b += 64) {
+            const M2Member Mb = M[b];
+            MsaJob J;
+            J.read_off = Mb.seq_off; J.ctr_off = Ma.seq_off;
+            J.lr = Mb.len; J.lc = Ma.len;
+            J.out_off = Ma.map_base + static_cast<long long>(b - 1) * Ma.len;    // b among the others of a
+            J.out2_off = Mb.map_base + static_cast<long long>(a) * Mb.len;       // a among the others of b
+            row[b - a - 1] = J;
+        }
+        row += n - a - 1;
+    }
 }
 
-// Host tables of a batch: groups, members, the pairwise jobs (4.4 million at C4).  The offsets come from one serial pass
-// over the groups; members and jobs are then filled by a few threads over disjoint ranges of groups.
+// Host tables of a batch: groups and members, and the band classes of the pairwise jobs (4.4 million at C4).  The offsets come
+// from one serial pass over the groups; the members are then filled and the jobs counted by a few threads over disjoint ranges
+// of groups.
 static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const int64_t* rel, bool exact_w, int bandwidth) {
     const size_t ngr = B.ids.size();
     B.groups.assign(ngr, M2Group{});
@@ -1196,19 +1208,7 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
     B.tab_n = tab_pos;
     B.members.assign(static_cast<size_t>(mem_pos), M2Member{});
     B.member_group.assign(static_cast<size_t>(mem_pos), 0);
-    // the job table keeps its pages between calls (m2_job_pool): a fresh 180 MB vector costs the zero fill and a page fault
-    // per 4 KB before the threads below write every field anyway
-    {
-        std::vector<MsaJob>& pool = m2_job_pool();
-        if (B.jobs.empty() && !pool.empty()) B.jobs.swap(pool);
-        if (static_cast<size_t>(job_pos) > B.jobs.capacity() || B.jobs.data() != m2_job_pin().first) m2_job_unpin();   // the table moves (or is another one)
-        B.jobs.resize(static_cast<size_t>(job_pos));
-        if (!m2_job_pin().first && job_pos >= (1 << 20)) {
-            const size_t bytes = B.jobs.capacity() * sizeof(MsaJob);
-            if (hipHostRegister(B.jobs.data(), bytes, hipHostRegisterDefault) == hipSuccess) m2_job_pin() = {B.jobs.data(), bytes};
-            else (void)hipGetLastError();   // (not page-locked then: the upload takes the slow way)
-        }
-    }
+    B.njobs = static_cast<size_t>(job_pos);
     auto fill = [&](size_t q0, size_t q1, MsaJobSummary* sum) {
         for (size_t q = q0; q < q1; ++q) {
             const M2Group& G = B.groups[q];
@@ -1226,17 +1226,9 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
                 cp += Me.len;
                 B.member_group[static_cast<size_t>(G.first_member) + a] = static_cast<int>(q);
             }
-            MsaJob* J = B.jobs.data() + G.first_job;
+            long long j = G.first_job;
             for (int a = 0; a < n; ++a)
-                for (int b = a + 1; b < n; ++b, ++J) {
-                    const M2Member& Ma = M[a];
-                    const M2Member& Mb = M[b];
-                    J->read_off = Mb.seq_off; J->ctr_off = Ma.seq_off;   // rows = b, columns = a
-                    J->lr = Mb.len; J->lc = Ma.len;
-                    J->out_off = Ma.map_base + static_cast<long long>(b - 1) * Ma.len;    // b among the others of a
-                    J->out2_off = Mb.map_base + static_cast<long long>(a) * Mb.len;       // a among the others of b
-                    sum->add(bandwidth, J->lr, J->lc, J - B.jobs.data());
-                }
+                for (int b = a + 1; b < n; ++b, ++j) sum->add(bandwidth, M[b].len, M[a].len, j);   // rows = b, columns = a (k_m2_jobs)
         }
     };
     const unsigned hw = std::thread::hardware_concurrency();
@@ -1311,11 +1303,13 @@ static int m2_prepare(M2Batch& B, const std::string& pf, const uint8_t* d_seq, d
     SL_TRY(upload((pf + ".groups").c_str(), B.groups.data(), ng, &d_groups, s));
     SL_TRY(upload((pf + ".members").c_str(), B.members.data(), nm, &d_members, s));
     SL_TRY(upload((pf + ".mg").c_str(), B.member_group.data(), nm, &d_mg, s));
-    SL_TRY(upload((pf + ".jobs").c_str(), B.jobs.data(), B.jobs.size(), &d_jobs, s));
+    SL_TRY(scratch((pf + ".jobs").c_str(), B.njobs + 1, &d_jobs));
+    hipLaunchKernelGGL(k_m2_jobs, dim3(static_cast<unsigned>((ng + 3) / 4)), dim3(256), 0, s, d_groups, d_members, static_cast<int>(ng), d_jobs);
+    SL_HIP(hipGetLastError());
     B.d_member_group = d_mg;
     uint16_t* d_map; int2* d_stats; double* d_dist; int2* d_joins; int* d_jtab; int* d_col; uint16_t* d_pos; int* d_ovf; int32_t* d_width;
     SL_TRY(scratch((pf + ".map").c_str(), static_cast<size_t>(map_n) + 1, &d_map));
-    SL_TRY(scratch((pf + ".stats").c_str(), B.jobs.size() + 1, &d_stats));
+    SL_TRY(scratch((pf + ".stats").c_str(), B.njobs + 1, &d_stats));
     SL_TRY(scratch((pf + ".dist").c_str(), static_cast<size_t>(dist_n) + 1, &d_dist));
     SL_TRY(scratch((pf + ".joins").c_str(), nm + 1, &d_joins));
     SL_TRY(scratch((pf + ".jtab").c_str(), nm + 1, &d_jtab));
@@ -1334,7 +1328,7 @@ static int m2_prepare(M2Batch& B, const std::string& pf, const uint8_t* d_seq, d
     th = m2_now();
     *cells += B.jsum.cells;
     SL_TRY(c.stage_begin("msa_pairwise", s));
-    SL_TRY(msa_pairwise_launch(B.jobs, d_jobs, d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, 1, nullptr, nullptr,
+    SL_TRY(msa_pairwise_launch(nullptr, B.njobs, d_jobs, d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, 1, nullptr, nullptr,
                                d_map, d_stats, s, &B.jsum, first_of_call));
     SL_TRY(c.stage_end("msa_pairwise", s));
     m2_host_time("pairwise_launch", th);
@@ -1571,7 +1565,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             m2_host_time("plan", th);
             B.pair_done = MS.pair[k & 1];
             SL_TRY(m2_prepare(B, pfs[k & 1], d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, &cells, first, sp));
-            pairs += static_cast<double>(B.jobs.size());
+            pairs += static_cast<double>(B.njobs);
             if (first && overlap) SL_TRY((*overlap)());
             first = false;
             return 0;
@@ -1605,13 +1599,6 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             SL_HIP(hipStreamSynchronize(s));   // the batch's host vectors and workspaces are reused by the batch after the next
             m2_host_time("rows", th);
             used = need;
-            // (the host tables of the batch are not needed any more)
-            {   // back to the pool (the larger of the two survives)
-                std::vector<MsaJob>& pool = m2_job_pool();
-                if (B.jobs.capacity() > pool.capacity()) pool.swap(B.jobs);
-                if (!B.jobs.empty() && B.jobs.data() == m2_job_pin().first) m2_job_unpin();   // (the table that is freed here)
-                std::vector<MsaJob>().swap(B.jobs);
-            }
         }
         todo.swap(again);
     }

@@ -91,12 +91,20 @@ struct MsaJobSummary {
     }
 };
 
-// Launches the pairwise kernels for `jobs` (host copy, for sizing and band classes; d_jobs the same on
-// the device) on stream s.  out_mode 0: ins/aln (spec v1), 1: maps + stats (spec v2).
-int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, const uint8_t* d_seq,
+// Launches the pairwise kernels for the njobs jobs at d_jobs on stream s.  `jobs` is the host's copy of the table, read
+// for band classes only: it may be null when `summary` comes with the wide jobs listed (msa2.hip builds its table on the
+// device and never holds one).  out_mode 0: ins/aln (spec v1), 1: maps + stats (spec v2).
+int msa_pairwise_launch(const MsaJob* jobs, size_t njobs, const MsaJob* d_jobs, const uint8_t* d_seq,
                         double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
                         int out_mode, uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats, hipStream_t s,
                         const MsaJobSummary* summary = nullptr, bool reset_stuck = true);
+inline int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, const uint8_t* d_seq,
+                               double match, double mismatch, double gap_extension, double gap_opening, int bandwidth,
+                               int out_mode, uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats, hipStream_t s,
+                               const MsaJobSummary* summary = nullptr, bool reset_stuck = true) {
+    return msa_pairwise_launch(jobs.data(), jobs.size(), d_jobs, d_seq, match, mismatch, gap_extension, gap_opening, bandwidth,
+                               out_mode, d_ins, d_aln, d_map, d_stats, s, summary, reset_stuck);
+}
 // (reset_stuck = false: the "traceback exceeded its step bound" flag of earlier launches of the same call is kept, the
 // caller reads it once at the end -- pipelined batches, msa2.hip)
 

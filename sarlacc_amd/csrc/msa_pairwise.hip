@@ -1144,23 +1144,24 @@ static int launch_class(bool packed, int C, const MsaArgs& a, int grid, size_t l
     return launch_ad<16, OUT>(a, grid, lds, s);
 }
 
-int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, const uint8_t* d_seq, double match,
+int msa_pairwise_launch(const MsaJob* jobs, size_t njobs, const MsaJob* d_jobs, const uint8_t* d_seq, double match,
                         double mismatch, double gap_extension, double gap_opening, int bandwidth, int out_mode,
                         uint16_t* d_ins, uint8_t* d_aln, uint16_t* d_map, int2* d_stats, hipStream_t s, const MsaJobSummary* summary, bool reset_stuck) {
-    if (jobs.empty()) return 0;
+    if (njobs == 0) return 0;
+    if (!jobs && !(summary && summary->wide_listed)) return fail("msa_pairwise_launch: no host copy of the jobs and no summary with the wide jobs listed");
     Context& c = ctx();
     // jobs by band class: 4, 8 or 16 diagonals per lane (bands up to 256 / 512 / 1024); one launch per
     // class, so the common narrow bands are not dragged to the widest job's shape
     std::vector<int> order[3];
     MsaJobSummary own;
     if (!summary) {
-        for (size_t q = 0; q < jobs.size(); ++q) own.add(bandwidth, jobs[q].lr, jobs[q].lc);
+        for (size_t q = 0; q < njobs; ++q) own.add(bandwidth, jobs[q].lr, jobs[q].lc);
         summary = &own;
     }
     const size_t* cls_n = summary->n;
     const int *cls_lr = summary->lr, *cls_lc = summary->lc, *cls_band = summary->band;
     // the usual case -- every pair in one class -- needs no index list: the launch takes the jobs as they are
-    const bool one_class = cls_n[0] == jobs.size() || cls_n[1] == jobs.size() || cls_n[2] == jobs.size();
+    const bool one_class = cls_n[0] == njobs || cls_n[1] == njobs || cls_n[2] == njobs;
     // The planner lists the few jobs of the wide classes itself (msa2.hip): the bit-vector kernels then take the whole job list
     // and skip those lanes, and no 4-million-entry index list is built or uploaded for class 0.
     const int cost_ok_ma = static_cast<int>(match), cost_ok_mm = static_cast<int>(mismatch), cost_ok_go = static_cast<int>(gap_opening),
@@ -1175,9 +1176,21 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
         order[2] = summary->wide[1];
         std::sort(order[1].begin(), order[1].end());
         std::sort(order[2].begin(), order[2].end());
+    } else if (!one_class && summary->wide_listed) {   // (other scorings: class 0 is what the two lists leave)
+        order[1] = summary->wide[0];
+        order[2] = summary->wide[1];
+        std::sort(order[1].begin(), order[1].end());
+        std::sort(order[2].begin(), order[2].end());
+        order[0].reserve(cls_n[0]);
+        size_t p1 = 0, p2 = 0;
+        for (size_t q = 0; q < njobs; ++q) {
+            if (p1 < order[1].size() && order[1][p1] == static_cast<int>(q)) { ++p1; continue; }
+            if (p2 < order[2].size() && order[2][p2] == static_cast<int>(q)) { ++p2; continue; }
+            order[0].push_back(static_cast<int>(q));
+        }
     } else if (!one_class) {
         for (int k = 0; k < 3; ++k) order[k].reserve(cls_n[k]);
-        for (size_t q = 0; q < jobs.size(); ++q) {
+        for (size_t q = 0; q < njobs; ++q) {
             const int band = msa_pair_band(bandwidth, jobs[q].lr, jobs[q].lc);
             order[band <= 256 ? 0 : (band <= 512 ? 1 : 2)].push_back(static_cast<int>(q));
         }
@@ -1211,17 +1224,17 @@ int msa_pairwise_launch(const std::vector<MsaJob>& jobs, const MsaJob* d_jobs, c
             const int NSb = core ? BV_CORE_WORDS : NWb;
             const size_t per_full = (static_cast<size_t>(cls_lc[cls]) + 8) * 2 * NWb * 64;   // 32-bit words: 2 NW per column and pair, in blocks of four columns
             const size_t per_wave = (static_cast<size_t>(cls_lc[cls]) + 8) * 2 * NSb * 64;
-            const long long nbatch = ((implicit0 ? static_cast<long long>(jobs.size()) : static_cast<long long>(cls_n[cls])) + 63) / 64;
+            const long long nbatch = ((implicit0 ? static_cast<long long>(njobs) : static_cast<long long>(cls_n[cls])) + 63) / 64;
             int* d_order = nullptr;
             if (!one_class && !implicit0) SL_TRY(upload("msa.ord0", order[cls].data(), order[cls].size(), &d_order, s));
-            a.order = d_order; a.njobs = implicit0 ? static_cast<int>(jobs.size()) : static_cast<int>(cls_n[cls]);
+            a.order = d_order; a.njobs = implicit0 ? static_cast<int>(njobs) : static_cast<int>(cls_n[cls]);
             a.skip_wide = implicit0 ? 1 : 0;
             a.tb_per_wave = per_wave;
             a.core_lo = BV_CORE0; a.core_hi = BV_CORE0 + BV_CORE_WORDS - 1;
             if (core_opt == 1) a.core_lo = a.core_hi = BV_CORE0 + 1;   // tests: one word only, most walks leave it and take the second run
             // move strings: one word of length + 2 bits per move, at the job's index
             a.moves_stride = static_cast<unsigned>((cls_lr[cls] + cls_lc[cls] + 15) / 16 + 2);
-            SL_TRY(scratch("msa.moves", jobs.size() * static_cast<size_t>(a.moves_stride), &a.moves));
+            SL_TRY(scratch("msa.moves", njobs * static_cast<size_t>(a.moves_stride), &a.moves));
             // Large lists: fill and walk as kernels of their own over chunks of batches, every batch of a chunk with its own
             // tile (up to 48 GB of records, a third of the free memory at most); otherwise both phases in one kernel.
             size_t free_b = 0, total_b = 0;
