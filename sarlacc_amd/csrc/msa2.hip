@@ -1164,25 +1164,20 @@ __global__ __launch_bounds__(256) void k_m2_jobs(const M2Group* __restrict__ gro
 // Host tables of a batch: groups and members, and the band classes of the pairwise jobs (4.4 million at C4).  The offsets come
 // from one serial pass over the groups; the members are then filled and the jobs counted by a few threads over disjoint ranges
 // of groups.
-static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const int64_t* rel, bool exact_w, int bandwidth) {
+static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const int64_t* rel, const long long* gsum, const int* gmx,
+                   bool exact_w, int bandwidth) {
     const size_t ngr = B.ids.size();
     B.groups.assign(ngr, M2Group{});
     B.max_len = 0; B.max_wcap = 0; B.max_n = 0;
     long long map_pos = 0, col_pos = 0, pos_pos = 0, dist_pos = 0, tab_pos = 0, mem_pos = 0, job_pos = 0;
     for (size_t q = 0; q < ngr; ++q) {
         const int64_t g = B.ids[q];
-        const int32_t* mem = grp + grp_off[g];
         const int n = static_cast<int>(grp_off[g + 1] - grp_off[g]);
         M2Group& G = B.groups[q];
         G.first_member = static_cast<int>(mem_pos);
         G.n = n;
-        long long sum = 0;
-        int mx = 0;
-        for (int a = 0; a < n; ++a) {
-            const int len = static_cast<int>(rel[mem[a]] - rel[mem[a] - 1]);
-            sum += len;
-            mx = std::max(mx, len);
-        }
+        const long long sum = gsum[B.slot[q]];   // sum and maximum of the group's read lengths (msa2_core)
+        const int mx = gmx[B.slot[q]];
         const long long fast_w = M2_FASTW(mx);
         // (65535 columns is the ceiling of spec v2: positions and columns are 16-bit; only reachable when the sum of
         // the read lengths exceeds it AND the alignment really is that wide)
@@ -1524,6 +1519,29 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
     // unrelated reads in one cluster), with profiles as wide as the sum of the read lengths.
     std::vector<size_t> todo(ids.size());
     std::iota(todo.begin(), todo.end(), size_t(0));
+    // sum and maximum of the read lengths of every group, once, by a few threads: the batch sizes below and every batch's plan
+    // start from them (a serial pass over the 10^6 reads of C4 is 5 ms during which the device has nothing to run)
+    std::vector<long long> gsum(ids.size());
+    std::vector<int> gmx(ids.size());
+    {
+        auto lens = [&](size_t q0, size_t q1) {
+            for (size_t q = q0; q < q1; ++q) {
+                const int32_t* mem = grp + grp_off[ids[q]];
+                const long long n = grp_off[ids[q] + 1] - grp_off[ids[q]];
+                long long sum = 0, mx = 0;
+                for (long long a = 0; a < n; ++a) { const long long len = rel[mem[a]] - rel[mem[a] - 1]; sum += len; mx = std::max(mx, len); }
+                gsum[q] = sum; gmx[q] = static_cast<int>(mx);
+            }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t nt = ids.size() < 20000 ? 1 : std::max<size_t>(1, std::min<size_t>(hw ? hw : 1, 8));
+        if (nt == 1) lens(0, ids.size());
+        else {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < nt; ++t) th.emplace_back(lens, ids.size() * t / nt, ids.size() * (t + 1) / nt);
+            for (std::thread& x : th) x.join();
+        }
+    }
     for (int pass = 0; pass < 2 && !todo.empty(); ++pass) {
         const bool exact_w = pass == 1;
         // processing order: by decreasing group size -- the workgroups of k_m2_group take the groups in this order, the
@@ -1536,8 +1554,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         for (size_t q : todo) {
             const int64_t g = ids[q];
             const long long n = grp_off[g + 1] - grp_off[g];
-            long long sum = 0, mx = 0;
-            for (long long a = 0; a < n; ++a) { const long long len = rel[grp[grp_off[g] + a]] - rel[grp[grp_off[g] + a] - 1]; sum += len; mx = std::max(mx, len); }
+            const long long sum = gsum[q], mx = gmx[q];
             const long long wc = exact_w ? sum : std::min(sum, static_cast<long long>(M2_FASTW(mx)));
             mem_all += 2 * (n - 1) * sum + 2 * n * wc + 4 * sum + 16 * m2_tab_entries(static_cast<int>(n));
             jobs_all += n * (n - 1) / 2;
@@ -1561,7 +1578,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         auto prepare = [&](size_t k) -> int {
             M2Batch& B = batches[k];
             double th = m2_now();
-            SL_TRY(m2_plan(B, grp_off, grp, rel.data(), exact_w, bandwidth));
+            SL_TRY(m2_plan(B, grp_off, grp, rel.data(), gsum.data(), gmx.data(), exact_w, bandwidth));
             m2_host_time("plan", th);
             B.pair_done = MS.pair[k & 1];
             SL_TRY(m2_prepare(B, pfs[k & 1], d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, &cells, first, sp));
