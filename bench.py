@@ -380,7 +380,11 @@ def main():
     if rank == 0 and not args.no_cpu:
         # the GPU box gives a one-GPU job a share of 16 host cores (more threads than that only contend)
         cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
-        cpu_sample = devsynth.to_host_strings(seq, qual, off, min(n, args.cpu_sample * cores)) + (cores,)
+        # the sample stays in HBM until the CPU leg at the end: pulled to the host here (some 10^5 Python strings, 0.8 GB through
+        # the allocator) the pipeline passes below measured 20-30 ms slower in their host-side copies
+        k = min(n, args.cpu_sample * cores)
+        end = int(off[k].item())
+        cpu_sample = (seq[:end].clone(), qual[:end].clone(), off[:k + 1].clone(), k, cores)
     del seq, qual, off, packed, nmask, scores, starts, ends, sso, swo
     torch.cuda.empty_cache()
     sarlacc_amd._lib.lib().sarlacc_release_workspace()
@@ -462,6 +466,7 @@ def main():
                 "reads": int(sm[0]), "reads_per_min": sm[0] / wall * 60.0, "seconds": wall, "first_pass_seconds": mx[1],
                 "consensus_reads": int(sm[1]), "consensus_bases": int(sm[2]), "reads_in_clusters": int(sm[3]),
                 "stage_s": dict(zip(names, mx[3:3 + len(names)])), "kernel_ms": kms,
+                "umi_group_host_s": last["umi_group_host_s"],
                 "all_gather": {"seconds": mx[2], "bytes_received_total": int(sm[4]), "backend": backend if world > 1 else None},
                 "n_ranks_seen": n_seen,
                 "clusters_all_ranks": last["clusters_all_ranks"],
@@ -561,7 +566,8 @@ def main():
 
     if rank == 0:
         if cpu_sample is not None:
-            out["cpu_baseline"] = cpu_baseline(*cpu_sample)
+            cs, cq, co, k, cores = cpu_sample
+            out["cpu_baseline"] = cpu_baseline(*(devsynth.to_host_strings(cs, cq, co, k) + (cores,)))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -73,6 +73,7 @@ def run_resident(umis, d_seq, d_qual, off_host, encoding, threshold=1, bandwidth
                                       np.arange(1, n + 1, dtype=np.int32))
     t1 = time.perf_counter()
     umi_ms = _lib.stage_ms("umi_pairs")
+    umi_host = {k: _lib.stage_count("umi_%s_s" % k) for k in ("encode_sort", "search_and_key_sort", "adjacency", "cluster")}
     gathered = None
     gather_s, gather_bytes = 0.0, 0
     clusters_all_ranks = int(coff.size - 1)
@@ -95,6 +96,7 @@ def run_resident(umis, d_seq, d_qual, off_host, encoding, threshold=1, bandwidth
     t4 = time.perf_counter()
     return {
         "cons": cons, "phred": phred, "coff": coff, "cmem": cmem, "goff": goff, "gflat": gflat, "gathered": gathered,
+        "umi_group_host_s": umi_host,
         "stage_s": {"umi_group": t1 - t0, "label_exchange": t2 - t1, "host_glue": t3 - t2, "msa_consensus": t4 - t3,
                     "total": t4 - t0},
         "all_gather_s": gather_s, "all_gather_bytes": gather_bytes, "clusters_all_ranks": clusters_all_ranks,

@@ -46,7 +46,7 @@ for rep in range(reps):
     print("rep %d spec %d: %.3f s  (%.1f M reads/min)  kernel ms %s  groups %d (max size %d, >10 reads: %d)  v1 fallback %d" % (
         rep, spec, dt, (off.size - 1) / dt * 60 / 1e6, {k: round(v, 1) for k, v in r["kernel_ms"].items()}, sizes.size,
         sizes.max(), int((sizes > 10).sum()), int(r["counts"]["msa_v1_fallback"])), flush=True)
-    print("      stage s %s" % {k: round(v, 4) for k, v in r["stage_s"].items()}, flush=True)
+    print("      stage s %s  umi_group host s %s" % ({k: round(v, 4) for k, v in r["stage_s"].items()}, {k: round(v, 4) for k, v in r["umi_group_host_s"].items()}), flush=True)
     print("      msa host s %s" % {k: round(_lib.stage_count("msa_host_%s_s" % k), 4) for k in ("plan", "upload_alloc", "pairwise_launch", "rows", "total")}, flush=True)
     if rep == 0:
         h = np.bincount(sizes)
