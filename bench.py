@@ -329,10 +329,10 @@ def main():
                                 DevBuffer.borrow(off.data_ptr(), 8 * (n + 1)), h_off, enc)
         sub1, sub2 = generics._setup_subseqs(ADAPTOR1), generics._setup_subseqs(ADAPTOR2)
         acc = {"kernel_ms": 0.0, "windows_s": 0.0, "subseq_s": 0.0, "wbases": 0}
-        orig = {k: getattr(DeviceReads, k) for k in ("align_map", "front_and_back", "subseq")}
+        orig = {k: getattr(DeviceReads, k) for k in ("align_block", "front_and_back", "subseq")}
 
         def timed_align(self, *a, **k):
-            out = orig["align_map"](self, *a, **k)
+            out = orig["align_block"](self, *a, **k)
             acc["kernel_ms"] += sarlacc_amd.last_kernel_ms()
             return out
 
@@ -350,7 +350,7 @@ def main():
             acc["subseq_s"] += time.perf_counter() - t
             return out
 
-        DeviceReads.align_map, DeviceReads.front_and_back, DeviceReads.subseq = timed_align, timed_windows, timed_subseq
+        DeviceReads.align_block, DeviceReads.front_and_back, DeviceReads.subseq = timed_align, timed_windows, timed_subseq
         best = None
         try:
             for _ in range(2):
@@ -365,7 +365,7 @@ def main():
                        "reads_per_s": n / dt, "reversed": int(rev.sum()),
                        "breakdown_s": {"windows_on_device": acc["windows_s"], "four_alignments_kernels": acc["kernel_ms"] * 1e-3,
                                        "subsequences_cut_on_device_and_downloaded": acc["subseq_s"],
-                                       "rest_result_downloads_and_strand_choice": dt - acc["windows_s"] - acc["kernel_ms"] * 1e-3 - acc["subseq_s"]}}
+                                       "rest_strand_choice_on_device_and_result_downloads": dt - acc["windows_s"] - acc["kernel_ms"] * 1e-3 - acc["subseq_s"]}}
                 best = cur if best is None or cur["seconds"] < best["seconds"] else best
                 del cs, ce
         finally:
@@ -405,6 +405,9 @@ def main():
             fence()
             r["wall"] = time.perf_counter() - t0
             runs.append(r)
+            if len(runs) == 1:   # (only the first pass's wall time is reported: its strings go back before the timed pass)
+                runs[0] = {"wall": r["wall"]}
+                del r
         # the same pass with the centre-star alignment (spec v1, round 1's algorithm) for comparison, on every rank
         calls.set_msa_spec(1)
         try:

@@ -149,10 +149,25 @@ int sarlacc_dev_malloc(void** p, int64_t bytes);
 int sarlacc_dev_free(void* p);
 int sarlacc_dev_upload(void* d, const void* h, int64_t bytes);
 int sarlacc_dev_download(void* h, const void* d, int64_t bytes);
+/* Page-locked host blocks for results (no reference counterpart: R hands its own vectors to .Call).  A device -> host copy
+ * into such a block is one DMA transfer; into pageable memory it goes through the runtime's staging buffer.  Blocks are
+ * pooled by size (powers of two from 1 MB); sarlacc_host_free returns a block to the pool, sarlacc_host_release frees the
+ * idle blocks.  Any host pointer of this interface may point into one. */
+int sarlacc_host_alloc(void** p, int64_t bytes);
+int sarlacc_host_free(void* p);
+int sarlacc_host_release(void);
 /* which = 0: first min(tol,width) bases; which = 1: reverse complement of the last
  * min(tol,width) bases with reversed qualities.  d_woff: offsets of the windows (n+1). */
 int sarlacc_dev_windows(const uint8_t* d_seq, const uint8_t* d_qual, const int64_t* d_off, int64_t n,
                         const int64_t* d_woff, int which, uint8_t* d_oseq, uint8_t* d_oqual, void* stream);
+/* .resolve_strand and the row selection of .align_AA_internal (R/adaptorAlign.R:112-122, :190-207) on the results of four
+ * sarlacc_dev_align calls that are still in HBM: cs / ce = adaptor 1 on the front windows / adaptor 2 on the back windows,
+ * rs / re = adaptor 1 on the back / adaptor 2 on the front.  Each is ONE block of n alignments with S sections (S = nsec1 for
+ * cs, rs, out1; nsec2 for ce, re, out2): double scores[n] | int32 starts[n] | int32 ends[n] | int32 section starts[max(S,1)][n]
+ * | int32 section widths[max(S,1)][n] (the five outputs of sarlacc_dev_align at these offsets).  d_rev[r] = 1 iff
+ * max(cs,0) + max(ce,0) < max(rs,0) + max(re,0); out1 row r = rs or cs, out2 row r = re or ce. */
+int sarlacc_dev_choose_strand(const void* d_cs, const void* d_ce, const void* d_rs, const void* d_re, int64_t n, int nsec1, int nsec2,
+                              void* d_out1, void* d_out2, uint8_t* d_rev, void* stream);
 /* Sub-sequences of resident reads, straight to host strings (XVector::subseq in .align_and_extract, R/adaptorAlign.R:160-174):
  * output r = width[r] bases from the 1-based position start[r] of read r of batch A -- or of batch B where from_b[r] != 0
  * (from_b may be NULL; adaptorAlign's strand choice takes, per read, the alignment on the front or on the back window).

@@ -6,6 +6,8 @@ device is usable, every compute call raises.
 import ctypes as C
 import os
 
+import numpy as np
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SARLACC_LIB_PATH") or os.path.join(_HERE, "libsarlacc_amd.so")   # override: experiment builds
 _lib = None
@@ -81,6 +83,34 @@ def ptr(a):
     if a is None:
         return None
     return a.ctypes.data_as(C.c_void_p)
+
+
+class _HostBlock:
+    """A page-locked block of sarlacc_host_alloc behind the array interface; goes back to the library's pool with its last view."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        check(lib().sarlacc_host_alloc(C.byref(p), C.c_int64(nbytes)))
+        self.address = p.value
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (self.address, False), "version": 3}
+
+    def __del__(self):
+        try:
+            if self.address:
+                lib().sarlacc_host_free(C.c_void_p(self.address))
+                self.address = 0
+        except Exception:
+            pass
+
+
+def host_array(count, dtype):
+    """Uninitialised numpy array for a result the device writes in full: page-locked from 1 MB on (sarlacc_host_alloc: the
+    download is one DMA transfer instead of a staged copy), ordinary memory below that."""
+    dt = np.dtype(dtype)
+    nbytes = int(count) * dt.itemsize
+    if nbytes < (1 << 20):
+        return np.empty(int(count), dt)
+    return np.asarray(_HostBlock(nbytes))[:nbytes].view(dt)
 
 
 def device_count():

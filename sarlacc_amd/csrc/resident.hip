@@ -7,6 +7,10 @@
 // score-only launch of the DP kernel on resident data.
 #include "common.hpp"
 
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "../../include/sarlacc_amd.h"
 
 namespace sarlacc {
@@ -110,9 +114,50 @@ __global__ void k_scramble(const uint8_t* seq, const uint8_t* qual, const int64_
     }
 }
 
+// .resolve_strand and the row selection of .align_AA_internal (R/adaptorAlign.R:112-122, :190-207) on result blocks of
+// sarlacc_dev_align that are still in HBM.  A block of n alignments with S sections: double scores[n] | int32 starts[n] |
+// int32 ends[n] | int32 section starts[max(S, 1)][n] | int32 section widths[max(S, 1)][n].  Read r is reversed iff
+// max(cs, 0) + max(ce, 0) < max(rs, 0) + max(re, 0) (strict, fp64 as the reference's R arithmetic); out1 takes row r of rs or
+// cs, out2 of re or ce.
+__device__ __forceinline__ void choose_row(const uint8_t* cur, const uint8_t* rc, uint8_t* out, bool rev, long long n, int S, long long r) {
+    const uint8_t* src = rev ? rc : cur;
+    reinterpret_cast<double*>(out)[r] = reinterpret_cast<const double*>(src)[r];
+    const int32_t* si = reinterpret_cast<const int32_t*>(src + 8 * n);
+    int32_t* oi = reinterpret_cast<int32_t*>(out + 8 * n);
+    const int rows = 2 + 2 * (S > 0 ? S : 1);
+    for (int k = 0; k < rows; ++k) oi[k * n + r] = si[k * n + r];
+}
+__global__ void k_choose_strand(const uint8_t* __restrict__ cs, const uint8_t* __restrict__ ce, const uint8_t* __restrict__ rs,
+                                const uint8_t* __restrict__ re, long long n, int S1, int S2, uint8_t* __restrict__ out1,
+                                uint8_t* __restrict__ out2, uint8_t* __restrict__ rev_out) {
+    const long long r = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const double fs = fmax(reinterpret_cast<const double*>(cs)[r], 0.0) + fmax(reinterpret_cast<const double*>(ce)[r], 0.0);
+    const double bs = fmax(reinterpret_cast<const double*>(rs)[r], 0.0) + fmax(reinterpret_cast<const double*>(re)[r], 0.0);
+    const bool rev = fs < bs;
+    rev_out[r] = rev ? 1 : 0;
+    choose_row(cs, rs, out1, rev, n, S1, r);
+    choose_row(ce, re, out2, rev, n, S2, r);
+}
+
 }  // namespace sarlacc
 
 using namespace sarlacc;
+
+// ---- page-locked host blocks for results ----
+// A device -> host copy into ordinary (pageable) memory goes through the runtime's staging buffer at the speed of a host memcpy
+// (the 360 MB of consensus strings of a 10^6-read pass: 35 ms; the four result blocks of adaptorAlign: 20 ms); into page-locked
+// memory it is one DMA transfer.  Page-locking costs far more than the copy it saves, so the blocks are pooled: sizes in
+// powers of two from 1 MB, a freed block waits for the next request of its size (sarlacc_host_release frees the pool).
+namespace {
+struct HostPool {
+    std::mutex mu;
+    std::map<size_t, std::vector<void*>> idle;   // by block size
+    std::map<void*, size_t> live;
+    size_t idle_bytes = 0;
+};
+HostPool& host_pool() { static HostPool p; return p; }
+}  // namespace
 
 extern "C" {
 
@@ -137,6 +182,49 @@ int sarlacc_dev_upload(void* d, const void* h, int64_t bytes) {
 int sarlacc_dev_download(void* h, const void* d, int64_t bytes) {
     SL_TRY(ensure_device());
     if (bytes > 0) SL_HIP(hipMemcpy(h, d, static_cast<size_t>(bytes), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sarlacc_host_alloc(void** p, int64_t bytes) {
+    if (!p || bytes < 0) return fail("sarlacc_amd: bad allocation request");
+    SL_TRY(ensure_device());
+    size_t size = size_t(1) << 20;
+    while (size < static_cast<size_t>(bytes)) size <<= 1;
+    HostPool& P = host_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    std::vector<void*>& idle = P.idle[size];
+    if (!idle.empty()) { *p = idle.back(); idle.pop_back(); P.idle_bytes -= size; }
+    else if (hipHostMalloc(p, size, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        // (make room once: the idle blocks of the other sizes)
+        for (auto& kv : P.idle) { for (void* q : kv.second) (void)hipHostFree(q); kv.second.clear(); }
+        P.idle_bytes = 0;
+        SL_HIP(hipHostMalloc(p, size, hipHostMallocDefault));
+    }
+    P.live[*p] = size;
+    return 0;
+}
+
+int sarlacc_host_free(void* p) {
+    if (!p) return 0;
+    HostPool& P = host_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    auto it = P.live.find(p);
+    if (it == P.live.end()) return fail("sarlacc_amd: sarlacc_host_free of a block that sarlacc_host_alloc did not hand out");
+    const size_t size = it->second;
+    P.live.erase(it);
+    // (at most 4 GB wait in the pool; beyond that the block goes back to the system)
+    if (P.idle_bytes + size > (size_t(4) << 30)) { SL_HIP(hipHostFree(p)); return 0; }
+    P.idle[size].push_back(p);
+    P.idle_bytes += size;
+    return 0;
+}
+
+int sarlacc_host_release(void) {
+    HostPool& P = host_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    for (auto& kv : P.idle) { for (void* q : kv.second) (void)hipHostFree(q); kv.second.clear(); }
+    P.idle_bytes = 0;
     return 0;
 }
 
@@ -190,6 +278,19 @@ int sarlacc_dev_subseq(const uint8_t* d_seq_a, const int64_t* d_off_a, const uin
     SL_HIP(hipMemcpyAsync(out_chars, d_out, static_cast<size_t>(out_off[n]), hipMemcpyDeviceToHost, s));
     SL_HIP(hipStreamSynchronize(s));
     if (bad != big) return fail("sarlacc_amd: sub-sequence of read %d lies outside the read", bad + 1);
+    return 0;
+}
+
+int sarlacc_dev_choose_strand(const void* d_cs, const void* d_ce, const void* d_rs, const void* d_re, int64_t n, int nsec1, int nsec2,
+                              void* d_out1, void* d_out2, uint8_t* d_rev, void* stream) {
+    if (n < 0 || nsec1 < 0 || nsec2 < 0) return fail("sarlacc_amd: bad strand choice request");
+    if (n == 0) return 0;
+    SL_TRY(ensure_device());
+    hipLaunchKernelGGL(k_choose_strand, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint8_t*>(d_cs), static_cast<const uint8_t*>(d_ce), static_cast<const uint8_t*>(d_rs),
+                       static_cast<const uint8_t*>(d_re), static_cast<long long>(n), nsec1, nsec2, static_cast<uint8_t*>(d_out1),
+                       static_cast<uint8_t*>(d_out2), d_rev);
+    SL_HIP(hipGetLastError());
     return 0;
 }
 

@@ -2215,6 +2215,8 @@ int sarlacc_umi_group(const char* umi1, const int64_t* off1, const char* umi2, c
         if (v < 1 || v > n) return fail("sarlacc_amd: pre-group index %d outside 1..%lld", v, static_cast<long long>(n));
     }
     SL_TRY(ensure_device());
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_in = now();
     hipStream_t s = nullptr;
     uint8_t *d_c1, *d_c2 = nullptr;
     int64_t *d_o1, *d_o2 = nullptr;
@@ -2237,7 +2239,6 @@ int sarlacc_umi_group(const char* umi1, const int64_t* off1, const char* umi2, c
         SL_TRY(upload("g.gid", gid.data(), static_cast<size_t>(N), &d_gid, s));
         SL_TRY(upload("g.single", single.data(), static_cast<size_t>(N), &d_single, s));
         DevAdj adj;
-        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t0 = now();
         SL_TRY(group_adjacency(d_c1, d_o1, d_c2, d_o2, d_grp, d_gid, d_single, static_cast<int>(ngroups), N, thresh1, thresh2, &adj, s));
         SL_HIP(hipStreamSynchronize(s));
@@ -2254,6 +2255,8 @@ int sarlacc_umi_group(const char* umi1, const int64_t* off1, const char* umi2, c
         if (res.total) SL_HIP(hipMemcpy(clu, res.d_out, sizeof(int32_t) * static_cast<size_t>(res.total), hipMemcpyDeviceToHost));
         for (long long c = 0; c <= res.nclu; ++c) clu_off[c] = co[c];
         nc = res.nclu;
+        ctx().counts["umi_tables_in_s"] = t0 - t_in;    // strings and pre-group tables to the device
+        ctx().counts["umi_clusters_out_s"] = now() - t2;
     }
     *nclusters = nc;
     return 0;

@@ -77,8 +77,8 @@ def dev_msa_consensus(grp_off, grp, d_seq, d_qual, off_host, match, mismatch, ga
     longest = np.maximum.reduceat(w[gvals[:int(goff[-1])].astype(np.int64) - 1], goff[:-1][sizes > 0]) if goff[-1] else np.zeros(0)
     cap = int(1.5 * longest.sum()) + 1024
     for attempt in range(2):
-        cons = np.zeros(cap, np.uint8)
-        phred = np.zeros(cap, np.uint8)
+        cons = _lib.host_array(cap, np.uint8)    # (page-locked: 360 MB come back at a 10^6-read pass)
+        phred = _lib.host_array(cap, np.uint8)
         try:
             check(_lib.lib().sarlacc_dev_msa_consensus(
                 ptr(goff), ptr(gvals), C.c_int64(ng), _dp(d_seq), _dp(d_qual), ptr(off), C.c_int64(n),

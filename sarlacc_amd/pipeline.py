@@ -73,7 +73,7 @@ def run_resident(umis, d_seq, d_qual, off_host, encoding, threshold=1, bandwidth
                                       np.arange(1, n + 1, dtype=np.int32))
     t1 = time.perf_counter()
     umi_ms = _lib.stage_ms("umi_pairs")
-    umi_host = {k: _lib.stage_count("umi_%s_s" % k) for k in ("encode_sort", "search_and_key_sort", "adjacency", "cluster")}
+    umi_host = {k: _lib.stage_count("umi_%s_s" % k) for k in ("tables_in", "encode_sort", "search_and_key_sort", "adjacency", "cluster", "clusters_out")}
     gathered = None
     gather_s, gather_bytes = 0.0, 0
     clusters_all_ranks = int(coff.size - 1)

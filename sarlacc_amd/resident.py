@@ -35,7 +35,7 @@ class DevBuffer:
         return b
 
     def to_numpy(self, dtype, count):
-        out = np.zeros(max(count, 1), dtype=dtype)
+        out = _lib.host_array(max(count, 1), dtype)
         check(_lib.lib().sarlacc_dev_download(ptr(out), self.ptr, C.c_int64(count * out.itemsize)))
         return out[:count]
 
@@ -168,7 +168,7 @@ class DeviceReads:
         wd = np.ascontiguousarray(np.maximum(np.asarray(width, dtype=np.int64), 0), dtype=np.int32)
         off = np.zeros(n + 1, np.int64)
         total = int(wd.sum(dtype=np.int64))
-        chars = np.zeros(max(total, 1), np.uint8)
+        chars = _lib.host_array(max(total, 1), np.uint8)
         sel = None if from_other is None else np.ascontiguousarray(from_other, dtype=np.uint8)
         check(_lib.lib().sarlacc_dev_subseq(self.seq.ptr, self.off.ptr, other.seq.ptr if other is not None else None,
                                             other.off.ptr if other is not None else None, ptr(sel) if sel is not None else None,
@@ -203,36 +203,62 @@ class DeviceReads:
                                               C.c_uint64(int(seed)), d.seq.ptr, d.qual.ptr, None))
         return d
 
-    def align_map(self, adaptor, gap_opening, gap_extension, sec_starts=(), sec_ends=()):
-        """adaptor_align (src/adaptor_align.cpp:11-77) on the resident batch: (scores, starts, ends,
-        [section starts], [section widths]) as numpy arrays, same conventions as calls.adaptor_align."""
+    def align_block(self, adaptor, gap_opening, gap_extension, sec_starts=(), sec_ends=()):
+        """adaptor_align (src/adaptor_align.cpp:11-77) on the resident batch, results left in HBM as ONE block (DevBuffer, n,
+        number of sections): scores | starts | ends | section starts | section widths (include/sarlacc_amd.h,
+        sarlacc_dev_choose_strand) -- one allocation per call, and one download for whoever wants them on the host."""
         n = len(self)
         ss = np.ascontiguousarray(sec_starts, dtype=np.int32).reshape(-1)
         se = np.ascontiguousarray(sec_ends, dtype=np.int32).reshape(-1)
         ns = ss.size
-        if n == 0:
-            return np.zeros(0), np.zeros(0, np.int32), np.zeros(0, np.int32), [np.zeros(0, np.int32)] * ns, [np.zeros(0, np.int32)] * ns
         enc = as_encoding(self.encoding if self.encoding is not None else phred_encoding())
         rf = adaptor.encode() if isinstance(adaptor, str) else bytes(adaptor)
-        # one device block for the five result vectors and one download (five allocations and five copies per call were a
-        # third of adaptorAlign's time on a resident batch): scores | starts | ends | section starts | section widths
         nsec = max(ns, 1)
-        o_st, o_en, o_so, o_sw = 8 * n, 12 * n, 16 * n, 16 * n + 4 * n * nsec
-        total = 16 * n + 8 * n * nsec
-        blk = DevBuffer(total)
+        blk = DevBuffer(16 * n + 8 * n * nsec)
         base = blk.ptr.value
         pad = np.zeros(1, np.int32)
         check(_lib.lib().sarlacc_dev_align(
             self.seq.ptr, self.qual.ptr, self.off.ptr, C.c_int64(n), C.c_int32(self.max_len),
             ptr(enc.errors), enc.names, len(enc), C.c_double(gap_opening), C.c_double(gap_extension),
             rf, len(rf), 0, ptr(ss if ns else pad), ptr(se if ns else pad), ns,
-            C.c_void_p(base), C.c_void_p(base + o_st), C.c_void_p(base + o_en), C.c_void_p(base + o_so), C.c_void_p(base + o_sw), None))
-        host = np.empty(total, np.uint8)
-        check(_lib.lib().sarlacc_dev_download(ptr(host), blk.ptr, C.c_int64(total)))
+            C.c_void_p(base), C.c_void_p(base + 8 * n), C.c_void_p(base + 12 * n), C.c_void_p(base + 16 * n),
+            C.c_void_p(base + 16 * n + 4 * n * nsec), None))
+        return blk, n, ns
+
+    @staticmethod
+    def block_to_host(block):
+        """A result block of align_block / choose_strand as (scores, starts, ends, [section starts], [section widths])."""
+        blk, n, ns = block
+        nsec = max(ns, 1)
+        o_st, o_en, o_so, o_sw = 8 * n, 12 * n, 16 * n, 16 * n + 4 * n * nsec
+        host = _lib.host_array(blk.nbytes, np.uint8)
+        check(_lib.lib().sarlacc_dev_download(ptr(host), blk.ptr, C.c_int64(blk.nbytes)))
         scores = host[:o_st].view(np.float64)
         starts, ends = host[o_st:o_en].view(np.int32), host[o_en:o_so].view(np.int32)
         so_h, sw_h = host[o_so:o_sw].view(np.int32), host[o_sw:].view(np.int32)
         return (scores, starts, ends, [so_h[k * n:(k + 1) * n] for k in range(ns)], [sw_h[k * n:(k + 1) * n] for k in range(ns)])
+
+    @staticmethod
+    def choose_strand(cs, ce, rs, re):
+        """.resolve_strand + the row selection of .align_AA_internal (R/adaptorAlign.R:112-122, :190-207) on four result blocks
+        in HBM (sarlacc_dev_choose_strand): (rows of adaptor 1, rows of adaptor 2, reversed) on the host -- half the bytes of
+        the four blocks cross PCIe and no host pass selects rows."""
+        n = cs[1]
+        if not (ce[1] == rs[1] == re[1] == n and cs[2] == rs[2] and ce[2] == re[2]):
+            raise _lib.SarlaccError("strand choice: result blocks of different shapes")
+        out1, out2, rev = DevBuffer(cs[0].nbytes), DevBuffer(ce[0].nbytes), DevBuffer(max(n, 1))
+        check(_lib.lib().sarlacc_dev_choose_strand(cs[0].ptr, ce[0].ptr, rs[0].ptr, re[0].ptr, C.c_int64(n), cs[2], ce[2],
+                                                   out1.ptr, out2.ptr, rev.ptr, None))
+        return (DeviceReads.block_to_host((out1, n, cs[2])), DeviceReads.block_to_host((out2, n, ce[2])),
+                rev.to_numpy(np.uint8, n).view(np.bool_))
+
+    def align_map(self, adaptor, gap_opening, gap_extension, sec_starts=(), sec_ends=()):
+        """adaptor_align (src/adaptor_align.cpp:11-77) on the resident batch: (scores, starts, ends,
+        [section starts], [section widths]) as numpy arrays, same conventions as calls.adaptor_align."""
+        ns = np.asarray(sec_starts).size
+        if len(self) == 0:
+            return np.zeros(0), np.zeros(0, np.int32), np.zeros(0, np.int32), [np.zeros(0, np.int32)] * ns, [np.zeros(0, np.int32)] * ns
+        return self.block_to_host(self.align_block(adaptor, gap_opening, gap_extension, sec_starts, sec_ends))
 
     def align_scores(self, adaptor, gap_opening, gap_extension, local=True):
         """adaptor_align_score_only / barcode_align on the resident batch."""

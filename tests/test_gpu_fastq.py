@@ -95,6 +95,42 @@ def test_adaptor_align_from_fastq_path(tmp_path):
         assert a[key]["subseq"] == b[key]["subseq"]
 
 
+def test_strand_choice_on_the_device_equals_the_host_rule():
+    """sarlacc_dev_choose_strand (.resolve_strand + the row selection of .align_AA_internal, R/adaptorAlign.R:112-122, :190-207)
+    against the same rule in numpy on the four downloaded result blocks: mixed strands, ties (both orientations see the same
+    windows: never reversed -- the comparison is strict), adaptors with different numbers of sections, an odd number of reads."""
+    from sarlacc_amd import generics as G
+    from sarlacc_amd.mock import mock_reads
+    from sarlacc_amd.resident import DeviceReads
+    sim = mock_reads(A1, A2, nmolecules=21, nreads=7, seqlen=300, seed=77)   # 147 reads
+    dev = DeviceReads.upload(G.Reads(sim["reads"], sim["quals"]))
+    front, back = dev.front_and_back(100)
+    sub1, sub2 = G._setup_subseqs(A1), G._setup_subseqs(A2)
+    assert len(sub1["starts"]) != len(sub2["starts"])
+
+    def block(ad, d, sb):
+        return d.align_block(ad, 5, 1, np.asarray(sb["starts"], dtype=np.int32) - 1, sb["ends"])
+
+    for wins in ((front, back), (front, front)):
+        cs, ce = block(A1, wins[0], sub1), block(A2, wins[1], sub2)
+        rs, re = block(A1, wins[1], sub1), block(A2, wins[0], sub2)
+        rows1, rows2, rev = DeviceReads.choose_strand(cs, ce, rs, re)
+        h = {k: DeviceReads.block_to_host(b) for k, b in (("cs", cs), ("ce", ce), ("rs", rs), ("re", re))}
+        want_rev, _ = G._resolve_strand(h["cs"][0], h["ce"][0], h["rs"][0], h["re"][0])
+        assert rev.dtype == np.bool_ and np.array_equal(rev, want_rev)
+        if wins[1] is front:
+            assert not rev.any()
+        else:
+            assert rev.any() and not rev.all()
+        for rows, cur, rc in ((rows1, h["cs"], h["rs"]), (rows2, h["ce"], h["re"])):
+            assert np.array_equal(rows[0].view(np.int64), np.where(rev, rc[0], cur[0]).view(np.int64))
+            assert np.array_equal(rows[1], np.where(rev, rc[1], cur[1])) and np.array_equal(rows[2], np.where(rev, rc[2], cur[2]))
+            assert len(rows[3]) == len(cur[3]) == len(rows[4])
+            for i in range(len(cur[3])):
+                assert np.array_equal(rows[3][i], np.where(rev, rc[3][i], cur[3][i]))
+                assert np.array_equal(rows[4][i], np.where(rev, rc[4][i], cur[4][i]))
+
+
 def test_filter_and_realize_reads(tmp_path):
     """filterReads + realizeReads (R/filterReads.R, R/realizeReads.R) on the adaptorAlign(filepath)
     result: the device orientation + trimming against the same operations on host strings."""

@@ -130,6 +130,48 @@ def test_extract_subseq_and_resident_barcodes(monkeypatch):
     assert want == sub
 
 
+def test_page_locked_result_blocks_are_pooled_and_hold_what_the_device_wrote():
+    """Large results come back into page-locked blocks of the library's pool (sarlacc_host_alloc, include/sarlacc_amd.h): a block
+    lives as long as any view of it, returns to the pool afterwards and is handed out again; small results stay in ordinary
+    memory; freeing a foreign pointer is an error, not a crash."""
+    import ctypes as C
+    import gc
+    from sarlacc_amd import _lib
+    from sarlacc_amd.resident import DevBuffer
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 256, 3 << 20, dtype=np.uint8)
+    dev = DevBuffer.from_numpy(data)
+    a = dev.to_numpy(np.uint8, data.size)
+    assert np.array_equal(a, data)
+    blk = a.base
+    while not isinstance(blk, _lib._HostBlock):
+        blk = blk.base
+    addr = blk.address
+    tail = a[-1000:]            # a view keeps the block
+    del a, blk
+    gc.collect()
+    b = _lib.host_array(3 << 20, np.uint8)   # same size class (4 MB): must be another block while `tail` lives
+    assert b.ctypes.data != addr
+    assert np.array_equal(tail, data[-1000:])
+    del tail, b
+    gc.collect()
+    c = _lib.host_array(1 << 20, np.int32)   # 4 MB again: one of the two pooled blocks
+    c[:] = 7
+    first = c.ctypes.data
+    del c
+    gc.collect()
+    d = _lib.host_array(1 << 20, np.int32)
+    assert d.ctypes.data == first and d.dtype == np.int32 and d.size == 1 << 20
+    small = _lib.host_array(100, np.float64)
+    assert small.base is None and small.size == 100
+    assert _lib.lib().sarlacc_host_free(C.c_void_p(small.ctypes.data)) != 0
+    assert b"did not hand out" in _lib.lib().sarlacc_last_error()
+    del d
+    gc.collect()
+    assert _lib.lib().sarlacc_host_release() == 0
+    assert np.array_equal(dev.to_numpy(np.uint8, data.size), data)   # (a fresh block after the release)
+
+
 def test_two_rank_pipeline_driver_matches_single_rank():
     """tools/run_pipeline.py (BASELINE config 5 in miniature) with two ranks sharing this GPU
     over gloo: read-range DP shards, tile-sharded UMI search + all-gather of neighbour pairs,

@@ -37,7 +37,9 @@ if pure:
         print("      msa2 %s" % {k: _lib.stage_count("msa2_" + k) for k in ("rows", "rows_capped", "entries_filtered", "entries_kept", "joins",
               "joins_chain_in_hbm", "cycles_rows", "cycles_chain", "cycles_walk", "cycles_renumber", "first_exit_s", "last_exit_s")}, flush=True)
     sys.exit(0)
+r = None
 for rep in range(reps):
+    r = None   # (the strings of the last pass go back to the page-locked pool before the next one asks for its own)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     r = pipeline.run_resident(umis, mol["seq"], mol["qual"], off, enc, threshold=1)
