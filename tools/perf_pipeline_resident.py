@@ -22,6 +22,8 @@ off = mol["off"].cpu().numpy()
 umis = StringSet(mol["umi"].cpu().numpy(), mol["umi_off"].cpu().numpy())
 enc = sarlacc_amd.phred_encoding()
 calls.set_msa_spec(spec)
+for kv in filter(None, os.environ.get("SARLACC_OPTS", "").split(",")):   # A/B switches, e.g. SARLACC_OPTS=msa_bitvector_tile_gb=12
+    calls.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 if pure:
     from sarlacc_amd import _lib, device
     n = off.size - 1
