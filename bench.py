@@ -411,7 +411,9 @@ def main():
         # the same pass with the centre-star alignment (spec v1, round 1's algorithm) for comparison, on every rank
         calls.set_msa_spec(1)
         try:
+            r1 = None
             for _ in range(2):   # (the first pass sizes spec v1's own workspaces)
+                r1 = None        # (its strings go back to the page-locked pool before the timed pass asks for its own)
                 fence()
                 t0 = time.perf_counter()
                 r1 = pipeline.run_resident(umis, mol["seq"], mol["qual"], off_host, enc, threshold=args.threshold, dist=D,
@@ -533,11 +535,12 @@ def main():
         # clustering in front, so no clusters of several molecules)
         goff_p = np.arange(0, nr + 1, args.copies, dtype=np.int64)
         gflat_p = np.arange(1, nr + 1, dtype=np.int32)
-        c4 = None
+        c4 = cons_p = _ph = None
         for _ in range(2):
+            cons_p = _ph = None
             fence()
             t0 = time.perf_counter()
-            cons_p, _ = sdev.dev_msa_consensus(goff_p, gflat_p, mol["seq"], mol["qual"], off_host, 0, -1, -5, -1, 100, 0.6, encoding=enc)
+            cons_p, _ph = sdev.dev_msa_consensus(goff_p, gflat_p, mol["seq"], mol["qual"], off_host, 0, -1, -5, -1, 100, 0.6, encoding=enc)
             fence()
             dt = time.perf_counter() - t0
             c4 = {"seconds": dt, "kernel_ms": {k: sarlacc_amd.stage_ms(k) for k in ("msa_pairwise", "msa_merge", "consensus")},
