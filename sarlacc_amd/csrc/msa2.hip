@@ -1221,9 +1221,33 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
                 cp += Me.len;
                 B.member_group[static_cast<size_t>(G.first_member) + a] = static_cast<int>(q);
             }
+            // band classes of the group's pairs (rows = b, columns = a: k_m2_jobs).  Where the longest and the shortest read of the
+            // group already fit the narrow class -- nearly every group -- no pair needs a look of its own: the summary's sums
+            // and maxima in closed form, the cell count from a branch-free loop.
+            if (n < 2) continue;
+            int lmin = M[0].len, lmax = M[0].len;
+            for (int a = 1; a < n; ++a) { lmin = std::min(lmin, M[a].len); lmax = std::max(lmax, M[a].len); }
+            const long long widest = static_cast<long long>(lmax - lmin) + 2LL * bandwidth + 1;
+            if (widest <= 256) {
+                sum->wide_listed = true;
+                sum->n[0] += static_cast<size_t>(n) * (n - 1) / 2;
+                sum->band[0] = std::max(sum->band[0], static_cast<int>(widest));
+                const long long base = 2LL * bandwidth + 1;
+                double cells = 0;
+                for (int a = 0; a < n; ++a) {
+                    const int la = M[a].len;
+                    if (a + 1 < n) { sum->cols[0] += static_cast<double>(la) * (n - 1 - a); sum->lc[0] = std::max(sum->lc[0], la); }
+                    if (a > 0) sum->lr[0] = std::max(sum->lr[0], la);
+                    long long acc = 0;
+                    for (int b = a + 1; b < n; ++b) { const long long lb = M[b].len; acc += lb * (base + (lb > la ? lb - la : la - lb)); }
+                    cells += static_cast<double>(acc);
+                }
+                sum->cells += cells;
+                continue;
+            }
             long long j = G.first_job;
             for (int a = 0; a < n; ++a)
-                for (int b = a + 1; b < n; ++b, ++j) sum->add(bandwidth, M[b].len, M[a].len, j);   // rows = b, columns = a (k_m2_jobs)
+                for (int b = a + 1; b < n; ++b, ++j) sum->add(bandwidth, M[b].len, M[a].len, j);
         }
     };
     const unsigned hw = std::thread::hardware_concurrency();
