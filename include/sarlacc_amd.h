@@ -44,7 +44,7 @@ int sarlacc_version(void);
 int sarlacc_device_count(void);
 /* Select the device used by this thread's subsequent calls (default 0). */
 int sarlacc_set_device(int device);
-/* Release cached device workspaces. */
+/* Release cached device workspaces (and the idle page-locked host blocks of sarlacc_host_alloc). */
 void sarlacc_release_workspace(void);
 /* Duration in ms of a named group of kernel launches of the last call that ran it (HIP events on
  * the launch stream, summed over the batches of the call): "msa_pairwise", "msa_merge", "consensus", "umi_pairs";

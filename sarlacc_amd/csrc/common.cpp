@@ -167,7 +167,10 @@ int sarlacc_set_device(int device) {
     return sarlacc::ensure_device();
 }
 
-void sarlacc_release_workspace(void) { sarlacc::ctx().release(); }
+void sarlacc_release_workspace(void) {
+    sarlacc::ctx().release();
+    (void)sarlacc_host_release();   // the idle page-locked result blocks as well
+}
 
 double sarlacc_stage_ms(const char* name) {
     sarlacc::Context& c = sarlacc::ctx();
