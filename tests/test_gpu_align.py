@@ -200,6 +200,38 @@ def test_ragged_and_long(oracle, oenc, enc):
     compare_adaptor(oracle, oenc, enc, reads, quals, "ACGTNNNNACGTRYACGT", 5, 1, [4], [8])
 
 
+def test_adaptor_anywhere_in_long_reads(oracle, oenc, enc):
+    """The traceback of adaptor_align restores a snapshot of the lane state above the landing row and recomputes a window; the
+    snapshots are dense near the read start and sparse beyond (align.hip, SNAP_DENSE / SNAP_SPARSE).  Adaptors planted so
+    that the alignment lands around every kind of boundary -- inside the dense part, on and just past its end, around the
+    sparse snapshots, at the very end of the read -- exact or with substitutions and indels, and once with a long stretch
+    of read inside the adaptor (the path leaves its window through the top and a second window is recomputed)."""
+    rng = np.random.default_rng(31)
+    nuc = np.array(list("ACGT"))
+    adaptor = "ACGATCAGC" + "N" * 12 + "GTCAGTCAG"
+    filled = "ACGATCAGC" + "ACGTTGCAAGTC" + "GTCAGTCAG"
+    reads = []
+    ends = [30, 64, 100, 192, 250, 256, 257, 290, 297, 298, 300, 330, 511, 512, 553, 554, 600, 767, 768, 810, 1024, 1065, 1500, 2000]
+    for e in ends:
+        for variant in range(3):
+            L = 2000 if e <= 1990 else e
+            body = "".join(nuc[rng.integers(0, 4, L)])
+            a = filled
+            if variant == 1:   # a substitution and a deletion
+                a = a[:5] + "T" + a[6:14] + a[15:]
+            if variant == 2:   # an insertion in the N stretch
+                a = a[:12] + "GGG" + a[12:]
+            start = max(e - len(a), 0)
+            reads.append(body[:start] + a + body[start + len(a):])
+    # 40 read bases inside the adaptor, landing row just past a sparse snapshot + head: the path runs 70 rows up
+    body = "".join(nuc[rng.integers(0, 4, 2000)])
+    reads.append(body[:500] + filled[:15] + "".join(nuc[rng.integers(0, 4, 40)]) + filled[15:] + body[570:])
+    reads.append(body[:230] + filled[:15] + "".join(nuc[rng.integers(0, 4, 40)]) + filled[15:] + body[300:])
+    quals = rand_quals(reads, 8, lo=40, hi=75)
+    out = compare_adaptor(oracle, oenc, enc, reads, quals, adaptor, 5, 1, [9], [21])
+    assert (out[0][:len(ends) * 3] > 10).all()    # every planted adaptor is what the alignment found
+
+
 def test_int32_directions_for_very_long_reads(oracle, oenc, enc):
     from sarlacc_amd.mock import random_reads
     reads, quals = random_reads(3, 33000, 34000, seed=9)
