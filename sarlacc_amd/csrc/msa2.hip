@@ -58,6 +58,14 @@ constexpr unsigned M2_NONE = 0xFFFFu;
 // profile capacity of the first pass: same-molecule reads grow a profile by 10-20 %, one or two unrelated reads in
 // the cluster by their length each
 #define M2_FASTW(maxlen) (3 * (maxlen) + 64)
+// ... by group size: a cluster of n reads out of umi_group holds about n / 10 molecules (UMI collisions), whose profiles do
+// not align -- one more read length per 8 reads beyond 11.  (With 3 maxlen + 64 for every size the clusters of three and
+// more molecules, the most expensive groups of a call, ran out of columns and were done twice, all-pairs alignments
+// included: 85 ms of the 657 ms merge stage of bench.py's pipeline workload.)
+static inline long long m2_fast_width(long long n, long long maxlen) {
+    if (option(OPT_MSA2_TIGHT_PROFILES)) return 2 * maxlen + 64;
+    return (3 + std::max(0LL, (n - 4) / 8)) * maxlen + 64;
+}
 
 struct M2Member {         // one read of a group
     long long seq_off;    // into d_seq
@@ -1178,7 +1186,7 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
         G.n = n;
         const long long sum = gsum[B.slot[q]];   // sum and maximum of the group's read lengths (msa2_core)
         const int mx = gmx[B.slot[q]];
-        const long long fast_w = M2_FASTW(mx);
+        const long long fast_w = m2_fast_width(n, mx);
         // (65535 columns is the ceiling of spec v2: positions and columns are 16-bit; only reachable when the sum of
         // the read lengths exceeds it AND the alignment really is that wide)
         G.wcap = static_cast<int>(std::min<long long>(65535, std::min<long long>(sum, exact_w ? sum : fast_w)));
@@ -1404,9 +1412,7 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
         }
         a.counters = d_cnt;
         a.chain_hbm = option(OPT_MSA2_CHAIN_HBM) ? 1 : 0;
-        const long long w_rows = (static_cast<long long>(B.max_wcap) + 63) / 64 * 64 + 64 * 9;   // (+ the slack of 8 row ranges)
-        const long long per_wg = w_rows * (M2_CAP * 12 + 4 * 4 + 8);
-        a.w_rows = w_rows;
+
         M2Streams& MS = m2_streams();
         SL_TRY(MS.ensure(2));
         SL_HIP(hipEventRecord(MS.fork, s));
@@ -1414,6 +1420,11 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
         const Cls cls[3] = {{0, iC, 8, ".c"}, {iC, iB, 4, ".b"}, {iB, nmulti, 1, ".a"}};
         for (int k = 0; k < 3; ++k) {
             if (cls[k].lo >= cls[k].hi) continue;
+            // scratch of a resident workgroup: as wide as the widest profile capacity of the class
+            int class_wcap = 1;
+            for (size_t q = cls[k].lo; q < cls[k].hi; ++q) class_wcap = std::max(class_wcap, B.groups[q].wcap);
+            const long long w_rows = (static_cast<long long>(class_wcap) + 63) / 64 * 64 + 64 * 9;   // (+ the slack of 8 row ranges)
+            const long long per_wg = w_rows * (M2_CAP * 12 + 4 * 4 + 8);
             hipStream_t sk = k < 2 ? MS.st[k] : s;
             if (k < 2) SL_HIP(hipStreamWaitEvent(sk, MS.fork, 0));
             const void* fn = !unitw ? reinterpret_cast<const void*>(&k_m2_group<false, 1, M2_MAXN>)
@@ -1427,6 +1438,7 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
             long long wgs = std::min<long long>(static_cast<long long>(per_cu) * std::max(1, c.num_cu), static_cast<long long>(cls[k].hi - cls[k].lo));
             wgs = std::max<long long>(1, std::min(wgs, (16LL << 30) / per_wg));   // (scratch of the resident workgroups: at most 16 GB per instantiation)
             M2Args am = a;
+            am.w_rows = w_rows;
             const std::string q = std::string("m2w") + cls[k].tag;   // (shared by the batches: their merging runs one after the other)
             SL_TRY(scratch((q + ".w_ent").c_str(), static_cast<size_t>(wgs * w_rows * M2_CAP), &am.w_ent));
             SL_TRY(scratch((q + ".w_pred").c_str(), static_cast<size_t>(wgs * w_rows * M2_CAP), &am.w_pred));
@@ -1532,6 +1544,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
     const long long job_budget = 12000000;
     double cells = 0, pairs = 0;
     double counters[M2C_N] = {};
+    double second_pass = 0;   // groups whose profiles outgrew the first-pass capacity
     long long used = 0;
     M2Streams& MS = m2_streams();
     SL_TRY(MS.ensure(3));
@@ -1579,7 +1592,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             const int64_t g = ids[q];
             const long long n = grp_off[g + 1] - grp_off[g];
             const long long sum = gsum[q], mx = gmx[q];
-            const long long wc = exact_w ? sum : std::min(sum, static_cast<long long>(M2_FASTW(mx)));
+            const long long wc = exact_w ? sum : std::min(sum, m2_fast_width(n, mx));
             mem_all += 2 * (n - 1) * sum + 2 * n * wc + 4 * sum + 16 * m2_tab_entries(static_cast<int>(n));
             jobs_all += n * (n - 1) / 2;
         }
@@ -1641,6 +1654,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             m2_host_time("rows", th);
             used = need;
         }
+        if (pass == 0) second_pass = static_cast<double>(again.size());
         todo.swap(again);
     }
     SL_HIP(hipStreamSynchronize(sp));
@@ -1661,6 +1675,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
     add("msa2_entries_kept", counters[M2C_ENT_KEPT]);
     add("msa2_joins", counters[M2C_JOINS]);
     add("msa2_joins_chain_in_hbm", counters[M2C_JOINS_HBMQ]);
+    add("msa2_groups_second_pass", second_pass);
     add("msa2_cycles_rows", counters[M2C_CYC_ROWS]);
     add("msa2_cycles_chain", counters[M2C_CYC_CHAIN]);
     add("msa2_cycles_walk", counters[M2C_CYC_WALK]);
@@ -1725,7 +1740,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         c.counts[nm] = 0;
     const double t_run = m2_now();
     for (const char* nm : {"msa_pairs", "msa_cells", "msa2_rows", "msa2_rows_capped", "msa2_entries_filtered", "msa2_rows_filtered",
-                           "msa2_entries_kept", "msa2_joins", "msa2_joins_chain_in_hbm", "msa2_cycles_rows", "msa2_cycles_chain",
+                           "msa2_entries_kept", "msa2_joins", "msa2_joins_chain_in_hbm", "msa2_groups_second_pass", "msa2_cycles_rows", "msa2_cycles_chain",
                            "msa2_cycles_walk", "msa2_cycles_renumber", "msa2_launches", "msa2_first_exit_s", "msa2_last_exit_s",
                            "msa2_exit_s_1wave", "msa2_exit_s_4waves", "msa2_exit_s_8waves", "msa_pairs_bitvector", "msa_bitvector_tile_bytes",
                            "msa_bitvector_split", "msa_bitvector_redone"})

@@ -548,6 +548,14 @@ def test_msa_spec2_umi_collisions(oracle, seed, nmol, per, length):
             assert a == b, "group %d differs" % g
         for rows, g in zip(got, groups):
             assert [r.replace("-", "") for r in rows] == [reads[i - 1] for i in g]
+        # the first-pass capacity grows with the group size (a cluster of n reads holds about n / 10 molecules), so these clusters
+        # fit it; with two read lengths for every group they outgrow it and take the second pass with exact capacity
+        calls.set_option("msa2_tight_profiles", 1)
+        try:
+            tight = calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)
+        finally:
+            calls.set_option("msa2_tight_profiles", 0)
+        assert tight == want
     finally:
         calls.set_msa_spec(0)
 

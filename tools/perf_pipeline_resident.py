@@ -57,5 +57,5 @@ for rep in range(reps):
         print("      group sizes: %s" % {int(k): int(v) for k, v in enumerate(h) if v}, flush=True)
     from sarlacc_amd import _lib
     print("      msa2 %s" % {k: _lib.stage_count("msa2_" + k) for k in ("rows", "rows_capped", "entries_filtered", "rows_filtered", "entries_kept",
-          "joins", "joins_chain_in_hbm", "cycles_rows", "cycles_chain", "cycles_walk", "cycles_renumber", "launches", "first_exit_s", "last_exit_s", "exit_s_1wave", "exit_s_4waves", "exit_s_8waves")}, flush=True)
+          "joins", "joins_chain_in_hbm", "groups_second_pass", "cycles_rows", "cycles_chain", "cycles_walk", "cycles_renumber", "launches", "first_exit_s", "last_exit_s", "exit_s_1wave", "exit_s_4waves", "exit_s_8waves")}, flush=True)
     print("      pairwise on bit vectors: %d pairs, %d run again with whole records" % (_lib.stage_count("msa_pairs_bitvector"), _lib.stage_count("msa_bitvector_redone")), flush=True)
