@@ -161,6 +161,112 @@ def cpu_baseline_pipeline(umi_strings, threshold, groups, read_strings, qual_str
     return out
 
 
+def giant_group_leg(args, rank, world, dist, device, gather_device, backend, enc, mol, fence, reduce):
+    """BASELINE configs[4] as it is worded, in the bench line for N > 1: the reads of ALL ranks as ONE pre-group (R/umiGroup.R:12-14:
+    no `groups` argument = one pre-group; src/umi_group.cpp:35) -- the one case of the path with a real exchange.  Row tiles of the
+    all-pairs neighbour search per rank (sarlacc_umi_pairs_shard), all-gather of the neighbour pairs over RCCL, the exact
+    clustering replicated on every rank, the clusters dealt to the ranks by their bases for multiReadAlign + consensusReadSeq.
+    Every rank holds every rank's reads in HBM (on a real run every rank reads the same FASTQ files; 4 GB per 10^6 reads), so
+    regrouping reads by cluster moves nothing.  Weak scaling like the rest of the line: N x --molecules molecules."""
+    import numpy as np
+    import torch
+    from sarlacc_amd import _lib, calls, devsynth, shard
+    from sarlacc_amd import device as sdev
+    from sarlacc_amd.strset import StringSet
+    # share r is what rank r's own pipeline pass ran on (seed 2000 + r)
+    seqs, quals, umis_c, lens, ulens = [], [], [], [], []
+    for r in range(world):
+        sh = mol if r == rank else devsynth.make_molecule_reads(args.molecules, args.copies, args.read_len, seed=2000 + r, device=device)
+        seqs.append(sh["seq"]); quals.append(sh["qual"])
+        lens.append(torch.diff(sh["off"]).cpu().numpy())
+        umis_c.append(sh["umi"].cpu().numpy()); ulens.append(torch.diff(sh["umi_off"]).cpu().numpy())
+        del sh
+    seq, qual = torch.cat(seqs), torch.cat(quals)
+    del seqs, quals
+    off = np.zeros(sum(x.size for x in lens) + 1, np.int64)
+    np.cumsum(np.concatenate(lens), out=off[1:])
+    uoff = np.zeros(off.size, np.int64)
+    np.cumsum(np.concatenate(ulens), out=uoff[1:])
+    umis = StringSet(np.concatenate(umis_c), uoff)
+    n_all = off.size - 1
+    widths = np.diff(off)
+
+    def one_pass():
+        st = {}
+        fence()
+        t0 = time.perf_counter()
+        coff, cmem = shard.sharded_umi_group_tiles(umis, args.threshold, calls, dist, gather_device, flat=True, stats=st)
+        t1 = time.perf_counter()
+        sizes = np.diff(coff)
+        big = np.flatnonzero(sizes >= 2)
+        bases = np.add.reduceat(widths[cmem.astype(np.int64) - 1], coff[:-1]) if cmem.size else np.zeros(0)
+        owner = shard.assign_groups_snake(bases[big], world)
+        keep = np.zeros(sizes.size, bool)
+        keep[big[owner == rank]] = True
+        goff, gflat = calls.csr_select(coff, cmem, keep)
+        t2 = time.perf_counter()
+        cons, phred = sdev.dev_msa_consensus(goff, gflat, seq, qual, off, 0, -1, -5, -1, 100, 0.6, encoding=enc)
+        fence()
+        t3 = time.perf_counter()
+        return {"t": (t1 - t0, t2 - t1, t3 - t2, t3 - t0), "st": st, "coff": coff, "cmem": cmem, "big": big, "owner": owner,
+                "cons": cons, "phred": phred, "gflat": gflat,
+                "kernel_ms": {k: _lib.stage_ms(k) for k in ("umi_pairs", "msa_pairwise", "msa_merge", "consensus")}}
+
+    first = one_pass()
+    first_t = first["t"][3]
+    del first
+    r = one_pass()
+    tm = reduce(list(r["t"]) + [first_t, r["st"].get("search_s", 0.0), r["st"].get("exchange_s", 0.0), r["st"].get("clustering_s", 0.0)]
+                + [r["kernel_ms"][k] for k in ("umi_pairs", "msa_pairwise", "msa_merge", "consensus")], dist.ReduceOp.MAX)
+    sm = reduce([float(len(r["cons"])), float(r["cons"].total), float(r["gflat"].size), float(r["st"].get("bytes_received", 0)),
+                 float(r["st"].get("pairs_here", 0)), 1.0], dist.ReduceOp.SUM)
+    # ---- identical to a single rank?  The clusters: rank 0 runs the unsharded umi_group on the same UMIs.  The consensus reads:
+    # a sample of clusters spread over the owners, recomputed by rank 0 (it holds every read) and compared with the owners' strings.
+    big, owner = r["big"], r["owner"]
+    pick = np.unique(np.linspace(0, big.size - 1, num=min(big.size, 256 * world)).astype(np.int64)) if big.size else np.zeros(0, np.int64)
+    mine_rank = np.cumsum(owner == rank) - 1   # position of an owned cluster among this rank's clusters (csr_select keeps the order)
+    sample = {}
+    for k in pick.tolist():
+        if owner[k] == rank:
+            j = int(mine_rank[k])
+            sample[int(k)] = (bytes(r["cons"].chars[r["cons"].off[j]:r["cons"].off[j + 1]]), bytes(r["phred"].chars[r["phred"].off[j]:r["phred"].off[j + 1]]))
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(sample, gathered, dst=0)
+    res = None
+    if rank == 0:
+        ref_off, ref_mem = calls.umi_group_flat(umis, args.threshold, None, args.threshold, np.array([0, n_all], np.int64),
+                                                np.arange(1, n_all + 1, dtype=np.int32))
+        clusters_same = bool(np.array_equal(ref_off, r["coff"]) and np.array_equal(ref_mem, r["cmem"]))
+        keep = np.zeros(r["coff"].size - 1, bool)
+        keep[big[pick]] = True
+        goff_s, gflat_s = calls.csr_select(r["coff"], r["cmem"], keep)
+        cons_s, phred_s = sdev.dev_msa_consensus(goff_s, gflat_s, seq, qual, off, 0, -1, -5, -1, 100, 0.6, encoding=enc)
+        got = {}
+        for d in gathered:
+            got.update(d)
+        same = len(got) == pick.size
+        for j, k in enumerate(pick.tolist()):   # (csr_select keeps the order of the clusters, so sample j is cluster pick[j])
+            a = (bytes(cons_s.chars[cons_s.off[j]:cons_s.off[j + 1]]), bytes(phred_s.chars[phred_s.off[j]:phred_s.off[j + 1]]))
+            same = same and got.get(int(k)) == a
+        wall = tm[3]
+        res = {"reads": int(n_all), "reads_per_min": n_all / wall * 60.0, "seconds": wall, "first_pass_seconds": tm[4],
+               "stage_s": {"umi_group_tiles_exchange_clustering": tm[0], "deal_clusters": tm[1], "msa_consensus": tm[2]},
+               "umi_group_s": {"tile_search": tm[5], "pair_exchange": tm[6], "replicated_clustering": tm[7]},
+               "kernel_ms": dict(zip(("umi_pairs", "msa_pairwise", "msa_merge", "consensus"), tm[8:12])),
+               "exchange": {"collective": "all_gather of the neighbour pairs (8 B each) + their counts", "backend": backend,
+                            "pairs": int(sm[4]), "bytes_received_total": int(sm[3]), "seconds": tm[6]},
+               "n_ranks_seen": int(sm[5]), "clusters": int(r["coff"].size - 1), "clusters_of_two_and_more": int(big.size),
+               "consensus_reads": int(sm[0]), "consensus_bases": int(sm[1]), "reads_in_clusters": int(sm[2]),
+               "identical_to_single_rank": {"clusters": clusters_same, "consensus_of_sampled_clusters": bool(same), "sampled_clusters": int(pick.size)},
+               "workload": "BASELINE configs[4] as worded, weak scaling: the %d x %d reads of all ranks as ONE pre-group (umiGroup without "
+                           "`groups`), threshold %d: tile-sharded neighbour search -> all-gather of the pairs -> replicated exact clustering -> "
+                           "clusters dealt to the ranks by their bases -> multiReadAlign + consensusReadSeq; every rank holds every read in HBM"
+                           % (world, args.molecules * args.copies, args.threshold)}
+    del seq, qual
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -466,6 +572,29 @@ def main():
                             "traffic": pm["traffic"], "traffic_source": pm["traffic_source"], "pmc": pm.get("derived"),
                             "algorithmic_bytes": msa_alg_bytes, "traffic_ratio": pm["traffic"] / msa_alg_bytes if pm["traffic"] else None}
             pc = pmc_record("k_consensus_code", ["consensus.hip", "msa_common.hpp"])
+            # k_m2_group, the merge stage of spec v2.  Algorithmic bytes: both position maps of every pair read
+            # once (2 B per base of either read), the columns of every base written once (4 B), the profiles' positions (2 B per cell
+            # of the final alignment) and the rows out as vote codes (2 B per cell).  What bounds it is the request rate of its small
+            # gathers, not the bytes: second entry, wave-wide gather instructions of the library walk against one per 16 cycles and CU
+            # (a wave64 dword gather occupies the address unit for 16 cycles).
+            gsz = np.diff(last["goff"]).astype(np.float64)
+            gbases = np.add.reduceat(np.diff(off_host)[last["gflat"].astype(np.int64) - 1], last["goff"][:-1]).astype(np.float64) if gsz.size else np.zeros(0)
+            m2_alg_bytes = float((2.0 * (gsz - 1.0) * gbases * 2.0).sum() + 4.0 * gbases.sum() + 4.0 * cnt["consensus_cells"])
+            pg = pmc_record("k_m2_group", ["msa2.hip", "msa_common.hpp"])
+            mg_s = kms["msa_merge"] * 1e-3
+            gather_peak = 256 * 2.4e9 / 16.0
+            cyc = {k: cnt.get("msa2_cycles_" + k, 0.0) for k in ("rows", "chain", "walk", "renumber")}
+            cyc_all = sum(cyc.values()) or 1.0
+            m2_roof = {"bound": "hbm", "kernel": "k_m2_group (1-, 4- and 8-wavefront instantiations side by side) + k_m2_tree / k_m2_tables / k_m2_init",
+                       "achieved": m2_alg_bytes / mg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": m2_alg_bytes / mg_s / 1e9 / HBM_PEAK_GBS,
+                       "algorithmic_bytes": m2_alg_bytes, "traffic": pg["traffic"], "traffic_source": pg["traffic_source"], "pmc": pg.get("derived"),
+                       "traffic_ratio": pg["traffic"] / m2_alg_bytes if pg["traffic"] else None,
+                       "gather_issue": {"bound": "gather request rate", "achieved": cnt.get("msa2_gathers", 0.0) / mg_s, "peak": gather_peak,
+                                        "unit": "wave-wide gathers/s", "frac": cnt.get("msa2_gathers", 0.0) / mg_s / gather_peak,
+                                        "gathers": cnt.get("msa2_gathers", 0.0),
+                                        "note": "library walk only (rows phase); one wave64 gather per 16 cycles and CU x 256 CUs x 2.4 GHz"},
+                       "phase_share_of_wavefront_cycles": {k: v / cyc_all for k, v in cyc.items()},
+                       "groups_second_pass": cnt.get("msa2_groups_second_pass", 0.0)}
             n_seen = dist.get_world_size() if world > 1 else 1
             out["pipeline"] = {
                 "reads": int(sm[0]), "reads_per_min": sm[0] / wall * 60.0, "seconds": wall, "first_pass_seconds": mx[1],
@@ -484,6 +613,7 @@ def main():
                 "msa_pairs": cnt["msa_pairs"], "msa_cells": cnt["msa_cells"], "consensus_cells": cnt["consensus_cells"],
                 "rooflines": {
                     "k_msa_pairwise": msa_roof,
+                    "k_m2_group": m2_roof,
                     "k_consensus_code": {"bound": "hbm", "achieved": cons_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": cons_gbs / HBM_PEAK_GBS, "algorithmic_bytes": cons_bytes,
                                        "traffic": pc["traffic"], "traffic_source": pc["traffic_source"], "pmc": pc.get("derived"),
@@ -555,6 +685,12 @@ def main():
                 "msa2_entries_filtered": c4["entries_filtered"],
                 "workload": "multiReadAlign + consensusReadSeq on %d groups x %d reads x %d bp per GPU (the molecules as groups)" % (
                     args.molecules, args.copies, args.read_len)}
+        if world > 1:
+            del cons_p, _ph
+            sarlacc_amd._lib.lib().sarlacc_release_workspace()
+            gg = giant_group_leg(args, rank, world, dist, device, gather_device, backend, enc, mol, fence, reduce)
+            if rank == 0:
+                out["pipeline"]["giant_group"] = gg
         if rank == 0 and not args.no_cpu:
             cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
             h_seq, h_qual = mol["seq"].cpu().numpy(), mol["qual"].cpu().numpy()

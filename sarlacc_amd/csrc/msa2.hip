@@ -88,6 +88,7 @@ struct M2Group {
 
 // counters of one call (sarlacc_stage_count): how often spec v2's own rules act, and the chain's fallback
 enum { M2C_ROWS, M2C_ROWS_CAPPED, M2C_ENT_FILTERED, M2C_ROWS_FILTERED, M2C_ENT_KEPT, M2C_JOINS, M2C_JOINS_HBMQ,
+       M2C_GATHERS,   // wave-wide gather instructions of the library walk (positions, maps, columns): its request-rate roofline
        // where the wavefronts' time goes (s_memtime cycles summed over the wavefronts) and when they leave (s_memrealtime, 100 MHz)
        M2C_CYC_ROWS, M2C_CYC_CHAIN, M2C_CYC_WALK, M2C_CYC_RENUMBER, M2C_T_START, M2C_T_FIRST_EXIT, M2C_T_LAST_EXIT,
        M2C_T_EXIT1, M2C_T_EXIT4, M2C_T_EXIT8,   // last exit of the instantiation with 1 / 4 / 8 wavefronts per group
@@ -428,7 +429,7 @@ constexpr unsigned M2_EMPTY = 0xFFFF0000u;
 
 __device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, const M2Join& J, const M2Cand* T, int i_lo, int i_hi,
                                             unsigned char* s_rows, M2Cand* s_tab, int cap, bool resident, m2_u64* ent, int* part,
-                                            unsigned& st_capped, unsigned& st_filtered, unsigned& st_rowsf) {
+                                            unsigned& st_capped, unsigned& st_filtered, unsigned& st_rowsf, unsigned long long& st_gath) {
     // s_rows (LDS, this wavefront's): rows 0 .. n - 1 of 64 positions each (position of the lane's base in member c), row n:
     // gaps.  s_tab (LDS): the join's candidates -- all of them (`resident`, staged by the caller) or room for `cap` at a time.
     const int lane = m2_lane();
@@ -460,6 +461,7 @@ __device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, c
             const bool havep = p != M2_NONE;
             if (!__ballot(havep)) continue;
             const M2Member Ma = A.members[fm + a];
+            st_gath += static_cast<unsigned>(1 + (n + 7) / 8 * 8 + (leafB ? E : 2 * E));   // (wave-uniform: scalar arithmetic)
             {   // positions in every other member: unconditional loads (clamped), selected afterwards
                 const unsigned pidx = havep ? p : 0u;
                 for (int c0 = 0; c0 < n; c0 += 8) {
@@ -942,7 +944,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
     int* const pb = A.w_pb + wb;
     m2_u64* const qg = A.w_q + wb;
     unsigned st_capped = 0, st_filtered = 0, st_rowsf = 0;
-    unsigned long long st_rows = 0, st_kept = 0, st_joins = 0, st_hbmq = 0;
+    unsigned long long st_rows = 0, st_kept = 0, st_joins = 0, st_hbmq = 0, st_gath = 0;
     unsigned long long cy_rows = 0, cy_chain = 0, cy_walk = 0, cy_renum = 0;
     if (threadIdx.x == 0) atomicMin(&A.counters[M2C_T_START], __builtin_amdgcn_s_memrealtime());
     for (;;) {
@@ -988,7 +990,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
                     __syncthreads();
                 } else if (NW > 1) { err = 3; }   // (cannot happen: the LDS of a multi-wavefront instantiation holds any table of its groups)
                 ne = err ? 0 : m2_rows_unit(A, G, J, T, i_lo, i_hi, smem + wave * rows_b, s_tab, cap, resident, ent + wave * stride, part, st_capped,
-                                            st_filtered, st_rowsf);
+                                            st_filtered, st_rowsf, st_gath);
             } else {
                 ne = m2_rows_general(A, G, J, i_lo, i_hi, smem, ent, part, st_capped, st_filtered, st_rowsf);
             }
@@ -1048,6 +1050,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
         atomicAdd(&A.counters[M2C_ROWS_CAPPED], static_cast<unsigned long long>(st_capped));
         atomicAdd(&A.counters[M2C_ENT_FILTERED], static_cast<unsigned long long>(st_filtered));
         atomicAdd(&A.counters[M2C_ROWS_FILTERED], static_cast<unsigned long long>(st_rowsf));
+        atomicAdd(&A.counters[M2C_GATHERS], st_gath);
         if (wave == 0) {
             atomicAdd(&A.counters[M2C_ROWS], st_rows);
             atomicAdd(&A.counters[M2C_ENT_KEPT], st_kept);
@@ -1675,6 +1678,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
     add("msa2_entries_kept", counters[M2C_ENT_KEPT]);
     add("msa2_joins", counters[M2C_JOINS]);
     add("msa2_joins_chain_in_hbm", counters[M2C_JOINS_HBMQ]);
+    add("msa2_gathers", counters[M2C_GATHERS]);
     add("msa2_groups_second_pass", second_pass);
     add("msa2_cycles_rows", counters[M2C_CYC_ROWS]);
     add("msa2_cycles_chain", counters[M2C_CYC_CHAIN]);
@@ -1740,7 +1744,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         c.counts[nm] = 0;
     const double t_run = m2_now();
     for (const char* nm : {"msa_pairs", "msa_cells", "msa2_rows", "msa2_rows_capped", "msa2_entries_filtered", "msa2_rows_filtered",
-                           "msa2_entries_kept", "msa2_joins", "msa2_joins_chain_in_hbm", "msa2_groups_second_pass", "msa2_cycles_rows", "msa2_cycles_chain",
+                           "msa2_entries_kept", "msa2_joins", "msa2_joins_chain_in_hbm", "msa2_gathers", "msa2_groups_second_pass", "msa2_cycles_rows", "msa2_cycles_chain",
                            "msa2_cycles_walk", "msa2_cycles_renumber", "msa2_launches", "msa2_first_exit_s", "msa2_last_exit_s",
                            "msa2_exit_s_1wave", "msa2_exit_s_4waves", "msa2_exit_s_8waves", "msa_pairs_bitvector", "msa_bitvector_tile_bytes",
                            "msa_bitvector_split", "msa_bitvector_redone"})

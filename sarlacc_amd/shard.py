@@ -132,17 +132,21 @@ def sharded_over_reads(fn, n, dist=None):
     return lo, hi, fn(lo, hi)
 
 
-def sharded_umi_group_tiles(umi, threshold, calls, dist=None, device=None, flat=False):
+def sharded_umi_group_tiles(umi, threshold, calls, dist=None, device=None, flat=False, stats=None):
     """umi_group of ONE giant pre-group with the row tiles of the all-pairs matrix spread over the
     ranks.  Every rank holds all UMIs (they are 12 bytes each), searches its
     share of the tiles, all-gathers the neighbour pairs (counts first, then the padded lists) and
     runs the clustering on the concatenation -- replicated, deterministic, identical to the
-    single-GPU result."""
-    if dist is None or dist.get_world_size() == 1:
+    single-GPU result.  `stats` (a dict, optional) receives the seconds of the search, of the exchange and of the
+    clustering, the pairs found here and overall, and the bytes this rank received."""
+    import time
+    if dist is None:   # (a process group of one rank goes through the collectives below: the RCCL path on a one-GPU box)
         return calls.umi_group_from_pairs(umi, threshold, calls.umi_pairs_shard(umi, threshold, 0, 1), **({"flat": True} if flat else {}))
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
+    t0 = time.perf_counter()
     mine = calls.umi_pairs_shard(umi, threshold, rank, world).astype(np.int64)  # values < 2^63: safe as int64
+    t1 = time.perf_counter()
     counts = _all_gather(np.array([mine.size], dtype=np.int32), dist, device)
     counts = [int(c[0]) for c in counts]
     width = max(max(counts), 1)
@@ -154,4 +158,9 @@ def sharded_umi_group_tiles(umi, threshold, calls, dist=None, device=None, flat=
     parts = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(parts, t)
     allpairs = np.concatenate([p.cpu().numpy()[:c] for p, c in zip(parts, counts)]).astype(np.uint64)
-    return calls.umi_group_from_pairs(umi, threshold, allpairs, **({"flat": True} if flat else {}))
+    t2 = time.perf_counter()
+    out = calls.umi_group_from_pairs(umi, threshold, allpairs, **({"flat": True} if flat else {}))
+    if stats is not None:
+        stats.update({"search_s": t1 - t0, "exchange_s": t2 - t1, "clustering_s": time.perf_counter() - t2, "pairs_here": int(mine.size),
+                      "pairs_all": int(allpairs.size), "bytes_received": int(8 * width * (world - 1) + 4 * (world - 1))})
+    return out

@@ -233,8 +233,17 @@ def test_bench_two_ranks_prints_the_contract_line():
     p = out["pipeline"]
     assert p["reads"] == 2 * 1500 * 6 and p["n_ranks_seen"] == 2
     assert p["all_gather"]["backend"] == "gloo" and p["all_gather"]["bytes_received_total"] == 2 * 2 * 4 * 1500 * 6
-    assert p["consensus_reads"] > 0 and p["reads_per_min"] > 0 and set(p["rooflines"]) == {"k_msa_pairwise", "k_consensus_code"}
+    assert p["consensus_reads"] > 0 and p["reads_per_min"] > 0 and set(p["rooflines"]) == {"k_msa_pairwise", "k_m2_group", "k_consensus_code"}
     assert p["clusters_all_ranks"] >= p["consensus_reads"]
+    assert p["rooflines"]["k_m2_group"]["gather_issue"]["gathers"] > 0 and 0 < p["rooflines"]["k_m2_group"]["frac"] < 1
+    # BASELINE configs[4] as worded: the reads of both ranks as ONE pre-group -- tile-sharded search, all-gather of the neighbour
+    # pairs, replicated clustering, clusters dealt to the ranks -- identical to what one rank computes
+    g = p["giant_group"]
+    assert g["reads"] == 2 * 1500 * 6 and g["n_ranks_seen"] == 2 and g["exchange"]["backend"] == "gloo"
+    assert g["exchange"]["pairs"] > 0 and g["exchange"]["bytes_received_total"] > 0
+    assert g["identical_to_single_rank"] == {"clusters": True, "consensus_of_sampled_clusters": True,
+                                             "sampled_clusters": g["identical_to_single_rank"]["sampled_clusters"]}
+    assert g["identical_to_single_rank"]["sampled_clusters"] > 0 and g["consensus_reads"] > 0 and g["reads_per_min"] > 0
 
 
 def test_bench_starts_its_own_ranks_and_refuses_missing_gpus():
@@ -296,6 +305,16 @@ labs, poss, secs, nbytes = pipeline.all_gather_labels(label, pos, dist, torch.de
 assert labs.shape == (1, n) and nbytes == 0 and secs >= 0
 c2, m2 = pipeline.clusters_from_labels(labs[0], poss[0])
 assert np.array_equal(c2, coff) and np.array_equal(m2, cmem)
+# the giant pre-group's exchange (bench.py pipeline.giant_group): tile search, all-gather of the neighbour pairs on device
+# tensors over RCCL, clustering on the gathered pairs -- the clusters of the plain call
+from sarlacc_amd import calls, shard
+from sarlacc_amd.mock import NUC, mutate
+truth = NUC[rng.integers(0, 4, (300, 12))]
+umis = [mutate(truth[k // 6], rng, 0.05, 0.01).tobytes().decode() for k in range(1800)]
+st = {}
+goff, gmem = shard.sharded_umi_group_tiles(umis, 1, calls, dist, torch.device("cuda", 0), flat=True, stats=st)
+roff, rmem = calls.umi_group_flat(umis, 1, None, 1, np.array([0, len(umis)], np.int64), np.arange(1, len(umis) + 1, dtype=np.int32))
+assert np.array_equal(goff, roff) and np.array_equal(gmem, rmem) and st["pairs_all"] == st["pairs_here"] > 0
 t = torch.arange(8, device="cuda", dtype=torch.float64)
 dist.all_reduce(t)
 torch.cuda.synchronize()
