@@ -280,14 +280,20 @@ int sarlacc_umi_group_from_pairs(const char* umi, const int64_t* off, int64_t n,
 /* Which written specification the MSA stage follows (the reference delegates to SeqAn's
  * T-Coffee, which cannot be run or pinned here): 2 (default) = consistency-based progressive alignment --
  * all-pairs banded alignments, primary library, triplet extension, neighbour-joining guide tree, progressive
- * heaviest-common-subsequence merging -- for groups of up to 32 reads, 1 = centre-star (also used by spec 2 for
- * larger groups and for reads beyond 21 823 bases).  0 restores the default (or SARLACC_MSA_SPEC). */
+ * heaviest-common-subsequence merging -- for groups of up to 64 reads, 1 = centre-star (also used by spec 2 for
+ * larger groups and for reads beyond 21 823 bases).  0 restores the default, spec 2 (SARLACC_MSA_SPEC only sets the
+ * value the process starts with: the environment is read once). */
 int sarlacc_set_msa_spec(int spec);
 
-/* A/B switches of the tests and the perf tools (every default, 0, is the product path): "msa_spec",
- * "msa2_general_rows", "msa2_chain_hbm", "msa2_waves_per_cu", "msa2_single_wave", "msa2_batches", "align_pensel", "align_chunks", "align_k", "align_waves_per_cu",
- * "consensus_chars", "consensus_generic", "msa_int32", "msa_affine".  The environment (SARLACC_<NAME>) is read once, when the
- * first option is asked for; afterwards only this call changes a value.  Nothing in the reference corresponds. */
+/* A/B switches of the tests and the perf tools (every default, 0, is the product path; the table is kOptNames in
+ * csrc/common.cpp, the meanings are at enum Opt in csrc/common.hpp and in INTEGRATION.md "Options"):
+ *   "msa_spec" (1 / 2), "msa2_general_rows", "msa2_chain_hbm", "msa2_waves_per_cu" (a count), "msa2_single_wave",
+ *   "msa2_batches" (a count), "msa2_tight_profiles", "align_pensel", "align_chunks" (a count), "align_k" (columns per lane),
+ *   "align_waves_per_cu" (a count), "align_interleave" (-1 never / 1 with align_k), "consensus_chars", "consensus_generic",
+ *   "msa_int32", "msa_affine", "msa_bitvector" (-1 never, 2 one kernel for fill and walk), "msa_bitvector_core" (-1 whole
+ *   records, 1 one word), "msa_bitvector_tile_gb" (GB), "umi_full_rounds", "umi_tile_search", "umi_split_min" (a set size).
+ * The environment (SARLACC_<NAME>) is read once, when the first option is asked for; afterwards only this call changes a
+ * value.  Nothing in the reference corresponds. */
 int sarlacc_set_option(const char* name, int value);
 
 /* replaces .Call quick_msa  (src/quick_msa.cpp:15-80); argument order as there

@@ -259,9 +259,9 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
         int64_t* mi = (int64_t*)malloc(sizeof(int64_t) * (size_t)mcap);
         int64_t* mj = (int64_t*)malloc(sizeof(int64_t) * (size_t)mcap);
         int64_t* mw = (int64_t*)malloc(sizeof(int64_t) * (size_t)mcap);
-        unsigned inA = 0, inB = 0;
-        for (int64_t u = 0; u < A->nmem; ++u) inA |= 1u << A->mem[u];
-        for (int64_t v = 0; v < B->nmem; ++v) inB |= 1u << B->mem[v];
+        uint64_t inA = 0, inB = 0;   /* member sets (spec v2 takes groups of up to 64 reads) */
+        for (int64_t u = 0; u < A->nmem; ++u) inA |= (uint64_t)1 << A->mem[u];
+        for (int64_t v = 0; v < B->nmem; ++v) inB |= (uint64_t)1 << B->mem[v];
         int64_t* idxA = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);   /* member slot of sequence a in posA */
         for (int64_t u = 0; u < A->nmem; ++u) idxA[A->mem[u]] = u;
         /* a row's list: MSA2_ROWCAP entries by the spec; every candidate column when the cap is switched off */

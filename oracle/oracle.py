@@ -345,7 +345,7 @@ def msa2_stats(reset=True):
     return dict(zip(MSA2_STAT_NAMES, buf.tolist()))
 
 
-def quick_msa(groupings, sequences, match, mismatch, gap_extension, gap_opening, bandwidth, spec=2, tcoffee_max=32):
+def quick_msa(groupings, sequences, match, mismatch, gap_extension, gap_opening, bandwidth, spec=2, tcoffee_max=64):
     """Same argument order as the reference .Call (src/quick_msa.cpp:15): note that
     the R caller passes (-gapOpening, -gapExtension) into (gap_extension, gap_opening)
     (R/multiReadAlign.R:47, SURVEY App.B Q15).  spec 2 (default): consistency-based progressive

@@ -42,13 +42,16 @@
 
 #include <algorithm>
 #include <numeric>
+#include <type_traits>
 #include <thread>
 #include <utility>
 #include <vector>
 
 namespace sarlacc {
 
-constexpr int M2_MAXN = 32;          // group sizes aligned by spec v2 (member sets are 32-bit masks)
+constexpr int M2_MAXN = 64;          // group sizes aligned by spec v2 (member sets are 64-bit masks; 32-bit ones in the kernels of groups of up to 32)
+constexpr int M2_N32 = 32;
+typedef unsigned long long m2_mask;
 #ifndef M2_WAVES_EU
 #define M2_WAVES_EU 8   // wavefronts per SIMD the merge kernel is compiled for (its registers are capped accordingly)
 #endif
@@ -156,25 +159,25 @@ __global__ void k_m2_tree(M2Args A) {
             D[b * n + a] = d;
         }
     }
-    unsigned active = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+    m2_mask active = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     int node[M2_MAXN];
     for (int i = 0; i < n; ++i) node[i] = i;
     int r = n, nj = 0;
     while (r > 3) {
         for (int i = 0; i < n; ++i) {
-            if (!((active >> i) & 1u)) continue;
+            if (!((active >> i) & 1ull)) continue;
             double sum = 0.0;
             for (int k = 0; k < n; ++k)
-                if (((active >> k) & 1u) && k != i) sum = sum + D[i * n + k];
+                if (((active >> k) & 1ull) && k != i) sum = sum + D[i * n + k];
             R[i] = sum;
         }
         int bi = -1, bj = -1;
         double best = 0.0;
         const double rm2 = static_cast<double>(r - 2);
         for (int i = 0; i < n; ++i) {
-            if (!((active >> i) & 1u)) continue;
+            if (!((active >> i) & 1ull)) continue;
             for (int j = i + 1; j < n; ++j) {
-                if (!((active >> j) & 1u)) continue;
+                if (!((active >> j) & 1ull)) continue;
                 const double q = (rm2 * D[i * n + j] - R[i]) - R[j];
                 if (bi < 0 || q < best) { best = q; bi = i; bj = j; }
             }
@@ -182,18 +185,18 @@ __global__ void k_m2_tree(M2Args A) {
         A.joins[fm + nj] = make_int2(node[bi], node[bj]);
         const double dij = D[bi * n + bj];
         for (int k = 0; k < n; ++k) {
-            if (!((active >> k) & 1u) || k == bi || k == bj) continue;
+            if (!((active >> k) & 1ull) || k == bi || k == bj) continue;
             const double v = ((D[bi * n + k] + D[bj * n + k]) - dij) * 0.5;
             D[bi * n + k] = v;
             D[k * n + bi] = v;
         }
-        active &= ~(1u << bj);
+        active &= ~(1ull << bj);
         node[bi] = n + nj;
         ++nj; --r;
     }
     int l[3], c = 0;
     for (int i = 0; i < n && c < 3; ++i)
-        if ((active >> i) & 1u) l[c++] = i;
+        if ((active >> i) & 1ull) l[c++] = i;
     if (c >= 2) {
         A.joins[fm + nj] = make_int2(node[l[0]], node[l[1]]);
         node[l[0]] = n + nj;
@@ -250,20 +253,20 @@ static inline long long m2_tab_entries(int n) { return static_cast<long long>(n)
 
 __global__ void __launch_bounds__(64) k_m2_tables(M2Args A, M2Cand* tab) {
     __shared__ int s_b[M2_MAXN];
-    __shared__ unsigned s_mask[2 * M2_MAXN];
+    __shared__ m2_mask s_mask[2 * M2_MAXN];
     const int g = blockIdx.x;
     const M2Group G = A.groups[g];
     const int n = G.n, fm = G.first_member;
     if (n < 2) return;
     const int lane = threadIdx.x;
-    if (lane < n) s_mask[lane] = 1u << lane;
+    if (lane < n) s_mask[lane] = 1ull << lane;
     __syncthreads();
     int off = 0;
     for (int k = 0; k + 1 < n; ++k) {
         const int2 jn = A.joins[fm + k];
-        const unsigned maskA = s_mask[jn.x], maskB = s_mask[jn.y];
-        if (lane < M2_MAXN && ((maskB >> lane) & 1u)) s_b[__popc(maskB & ((1u << lane) - 1u))] = lane;
-        const int nbm = __popc(maskB);
+        const m2_mask maskA = s_mask[jn.x], maskB = s_mask[jn.y];
+        if ((maskB >> lane) & 1ull) s_b[__popcll(maskB & ((1ull << lane) - 1ull))] = lane;
+        const int nbm = __popcll(maskB);
         __syncthreads();
         if (lane == 0) { s_mask[n + k] = maskA | maskB; A.join_tab[fm + k] = off; }
         M2Cand* const T = tab + G.tab_base + off;
@@ -307,11 +310,13 @@ __device__ __forceinline__ int m2_lane() {
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
 }
+__device__ __forceinline__ unsigned m2_readlane(unsigned v, int l) { return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), l)); }
 __device__ __forceinline__ m2_u64 m2_readlane64(m2_u64 v, int l) {
     const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), l));
     const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), l));
     return (static_cast<m2_u64>(hi) << 32) | lo;
 }
+__device__ __forceinline__ m2_u64 m2_readlane(m2_u64 v, int l) { return m2_readlane64(v, l); }
 // Wave-wide scans of an int by DPP: row shifts inside the rows of 16 lanes, then the last lane of row 0 / 2 broadcast
 // into row 1 / 3 and lane 31 into rows 2 and 3; lanes without a source read the identity.  (Not __shfl: its
 // ds_bpermute needs a lane-address register per step, and the compiler keeps those alive through the whole kernel.)
@@ -351,11 +356,14 @@ __device__ __forceinline__ m2_u64 m2_scan_max64(m2_u64 v) {
     return v;
 }
 
-struct M2Join {       // wave-uniform description of one join
+template <typename MASK>
+struct M2JoinT {      // wave-uniform description of one join (MASK: unsigned for groups of up to 32 reads, m2_mask beyond)
     int n, fm;
-    unsigned maskA, maskB;
+    MASK maskA, maskB;
     int nA, nB;
 };
+__device__ __forceinline__ int m2_popc(unsigned m) { return __popc(m); }
+__device__ __forceinline__ int m2_popc(m2_mask m) { return __popcll(m); }
 
 // A row's list -> filter, order by column, append to the match list.  ej[k] < 0: empty slot.
 // (macro: the lists must stay in registers, every index a compile-time constant)
@@ -427,14 +435,15 @@ constexpr unsigned M2_EMPTY = 0xFFFF0000u;
         }                                                                                              \
     }
 
-__device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, const M2Join& J, const M2Cand* T, int i_lo, int i_hi,
+template <typename MASK>
+__device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, const M2JoinT<MASK>& J, const M2Cand* T, int i_lo, int i_hi,
                                             unsigned char* s_rows, M2Cand* s_tab, int cap, bool resident, m2_u64* ent, int* part,
                                             unsigned& st_capped, unsigned& st_filtered, unsigned& st_rowsf, unsigned long long& st_gath) {
     // s_rows (LDS, this wavefront's): rows 0 .. n - 1 of 64 positions each (position of the lane's base in member c), row n:
     // gaps.  s_tab (LDS): the join's candidates -- all of them (`resident`, staged by the caller) or room for `cap` at a time.
     const int lane = m2_lane();
     const int n = J.n, fm = J.fm, nA = J.nA;
-    const int nbm = __popc(J.maskB);
+    const int nbm = m2_popc(J.maskB);
     const bool leafB = nbm == 1;   // (a single member in the second child is a leaf of the guide tree: col = position)
     const int E = m2_round_batch(nbm) + m2_round_batch(nbm * n);
     uint16_t* const s_rl = reinterpret_cast<uint16_t*>(s_rows) + lane;     // (every lane reads its own column of the rows only)
@@ -456,7 +465,7 @@ __device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, c
         bool capped = false;
         const bool row = i < nA;
         for (int a = 0; a < n; ++a) {
-            if (!((J.maskA >> a) & 1u)) continue;
+            if (!((J.maskA >> a) & 1)) continue;
             const unsigned p = row ? A.pos[G.pos_base + static_cast<long long>(a) * G.wcap + i] : M2_NONE;
             const bool havep = p != M2_NONE;
             if (!__ballot(havep)) continue;
@@ -586,7 +595,8 @@ __device__ __forceinline__ long long m2_uniform64(long long v) {   // a wave-uni
         }                                                                                              \
     }
 
-__device__ __forceinline__ int m2_rows_general(const M2Args& A, const M2Group& G, const M2Join& J, int i_lo, int i_hi, unsigned char* smem,
+template <typename MASK>
+__device__ __forceinline__ int m2_rows_general(const M2Args& A, const M2Group& G, const M2JoinT<MASK>& J, int i_lo, int i_hi, unsigned char* smem,
                                                m2_u64* ent, int* part, unsigned& st_capped, unsigned& st_filtered, unsigned& st_rowsf) {
     uint16_t (*s_r)[64] = reinterpret_cast<uint16_t (*)[64]>(smem);                                  // [M2_MAXN][64]
     long long* const s_mapbase = reinterpret_cast<long long*>(smem + (M2_MAXN + 1) * 128);            // the members' descriptors
@@ -596,13 +606,13 @@ __device__ __forceinline__ int m2_rows_general(const M2Args& A, const M2Group& G
     int* const s_b = s_len + M2_MAXN;                                                                 // the second child's members, ascending
     const int lane = m2_lane();
     const int n = J.n, fm = J.fm, nA = J.nA;
-    const unsigned maskB = J.maskB;
+    const MASK maskB = J.maskB;
     if (lane < M2_MAXN) {
         const M2Member Me = A.members[fm + min(lane, n - 1)];
         s_mapbase[lane] = Me.map_base; s_colbase[lane] = Me.col_base; s_seqoff[lane] = Me.seq_off; s_len[lane] = lane < n ? Me.len : 0;
-        if ((maskB >> lane) & 1u) s_b[__popc(maskB & ((1u << lane) - 1u))] = lane;
+        if ((static_cast<m2_mask>(maskB) >> lane) & 1ull) s_b[__popcll(static_cast<m2_mask>(maskB) & ((1ull << lane) - 1ull))] = lane;
     }
-    const int nbm = __popc(maskB);
+    const int nbm = m2_popc(maskB);
     __syncthreads();
     int ne = 0;
     for (int i0 = i_lo; i0 < i_hi; i0 += 64) {
@@ -614,7 +624,7 @@ __device__ __forceinline__ int m2_rows_general(const M2Args& A, const M2Group& G
         bool capped = false;
         const bool row = i < nA;
         for (int a = 0; a < n; ++a) {
-            if (!((J.maskA >> a) & 1u)) continue;
+            if (!((J.maskA >> a) & 1)) continue;
             const unsigned p = row ? A.pos[G.pos_base + static_cast<long long>(a) * G.wcap + i] : M2_NONE;
             const bool havep = p != M2_NONE;
             if (!__ballot(havep)) continue;
@@ -832,8 +842,8 @@ __device__ __forceinline__ void m2_chain_walk(const m2_u64* ent, const M2Segs& S
 
 // ---- new column numbers, col / pos of every member: the scans on the first wavefront, the rest on all NW ----
 // returns the width of the joined profile, or -1 when it exceeds the capacity
-template <int NW>
-__device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, const M2Join& J, const int* part, int* nca, int* ncb, int* pb,
+template <int NW, typename MASK>
+__device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, const M2JoinT<MASK>& J, const int* part, int* nca, int* ncb, int* pb,
                                            int* s_newW) {
     const int lane = m2_lane();
     const int wave = m2_rfl(static_cast<int>(threadIdx.x >> 6));
@@ -892,17 +902,17 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
     const int newW = m2_rfl(*s_newW);
     if (newW > G.wcap) return -1;
     // clear the members' rows of pos, then scatter the new columns
-    const unsigned both = J.maskA | J.maskB;
+    const MASK both = J.maskA | J.maskB;
     for (int a = 0; a < n; ++a) {
-        if (!((both >> a) & 1u)) continue;
+        if (!((both >> a) & 1)) continue;
         uint16_t* row = A.pos + G.pos_base + static_cast<long long>(a) * G.wcap;
         for (int c = tid; c < newW; c += NT) row[c] = static_cast<uint16_t>(M2_NONE);
     }
     __threadfence_block();
     __syncthreads();
     for (int a = 0; a < n; ++a) {
-        const bool inA = (J.maskA >> a) & 1u;
-        if (!((both >> a) & 1u)) continue;
+        const bool inA = (J.maskA >> a) & 1;
+        if (!((both >> a) & 1)) continue;
         const M2Member Me = A.members[fm + a];
         const int* nc = inA ? nca : ncb;
         uint16_t* row = A.pos + G.pos_base + static_cast<long long>(a) * G.wcap;
@@ -922,17 +932,19 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
 // tables go through in chunks.  NW wavefronts per group (groups of up to NMAX reads): the whole table of any join fits.
 constexpr int m2_lds_bytes(bool unitw, int nw, int nmax) {
     return !unitw ? (M2_MAXN + 1) * 128 + M2_MAXN * 3 * 8 + M2_MAXN * 2 * 4
-                  : (nw == 1 ? M2_LDS_UNIT : nw * (nmax + 1) * 128 + ((nmax - 1 + M2_UBATCH) + ((nmax - 1) * nmax + M2_UBATCH)) * 16);
+                  : (nw == 1 ? (nmax > M2_N32 ? (nmax + 1) * 128 + 64 * 16 : M2_LDS_UNIT) : nw * (nmax + 1) * 128 + ((nmax - 1 + M2_UBATCH) + ((nmax - 1) * nmax + M2_UBATCH)) * 16);
 }
-static_assert(M2_LDS_UNIT >= M2_QW * 8 && M2_LDS_UNIT >= (M2_MAXN + 1) * 128 + 16 * M2_UBATCH, "the chain's ring and the rows' staging share the LDS");
+static_assert(M2_LDS_UNIT >= M2_QW * 8 && M2_LDS_UNIT >= (M2_N32 + 1) * 128 + 16 * M2_UBATCH, "the chain's ring and the rows' staging share the LDS");
 
 // One workgroup of NW wavefronts per group (groups of up to NMAX reads; NW = 1 takes any).  The rows of a join are
 // cut into NW ranges, one per wavefront; the chain runs on the first wavefront; the renumbering's copies on all.
 template <bool UNITW, int NW, int NMAX>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? M2_WAVES_EU : 4, 8))) k_m2_group(M2Args A, const M2Cand* tab) {
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? (UNITW ? M2_WAVES_EU : 4) : (NMAX > 32 ? 2 : 4), 8))) k_m2_group(M2Args A, const M2Cand* tab) {
     __shared__ __align__(16) unsigned char smem[m2_lds_bytes(UNITW, NW, NMAX)];
     __shared__ int s_cnt[NW], s_pfx[NW + 1], s_ctl[4];
     static_assert(UNITW || NW == 1, "the any-weights walk runs on one wavefront");
+    typedef typename std::conditional<(NMAX > 32), m2_mask, unsigned>::type MASK;
+    constexpr bool TWO = NMAX > 32;
     const int lane = threadIdx.x & 63;
     const int wave = m2_rfl(static_cast<int>(threadIdx.x >> 6));
     const long long wb = static_cast<long long>(blockIdx.x) * A.w_rows;
@@ -957,19 +969,21 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
         const int n = G.n, fm = G.first_member;
         if (n < 2) continue;
         // the nodes of the guide tree live in the lanes (of every wavefront): lane k = node k (leaves 0 .. n - 1, join k creates n + k)
-        unsigned nmask = lane < n ? (1u << lane) : 0u;
-        int ncols = lane < n ? A.members[fm + lane].len : 0;
+        // (a group of up to 32 reads has at most 63 nodes: one per lane, 32-bit member masks; beyond, nodes 64 .. 126 live in a
+        // second pair of registers and the masks have 64 bits)
+        MASK nmask = lane < n ? (static_cast<MASK>(1) << lane) : static_cast<MASK>(0), nmask2 = 0;
+        int ncols = lane < n ? A.members[fm + lane].len : 0, ncols2 = 0;
         int err = 0, width = 0;
         bool over = n > NMAX;   // (the host sends a group to an instantiation that holds it)
         for (int round = 0; round + 1 < n && !over; ++round) {
             const int2 jn = A.joins[fm + round];
             const int jx = m2_rfl(jn.x), jy = m2_rfl(jn.y);
-            M2Join J;
+            M2JoinT<MASK> J;
             J.n = n; J.fm = fm;
-            J.maskA = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(nmask), jx));
-            J.maskB = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(nmask), jy));
-            J.nA = __builtin_amdgcn_readlane(ncols, jx);
-            J.nB = __builtin_amdgcn_readlane(ncols, jy);
+            J.maskA = (TWO && jx >= 64) ? m2_readlane(nmask2, jx - 64) : m2_readlane(nmask, jx);
+            J.maskB = (TWO && jy >= 64) ? m2_readlane(nmask2, jy - 64) : m2_readlane(nmask, jy);
+            J.nA = (TWO && jx >= 64) ? __builtin_amdgcn_readlane(ncols2, jx - 64) : __builtin_amdgcn_readlane(ncols, jx);
+            J.nB = (TWO && jy >= 64) ? __builtin_amdgcn_readlane(ncols2, jy - 64) : __builtin_amdgcn_readlane(ncols, jy);
             __syncthreads();
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             // ---- rows: wavefront w takes the blocks of 64 rows [w bpw, (w + 1) bpw) and writes its matches at ent + w stride ----
@@ -982,7 +996,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
                 const int rows_b = (n + 1) * 128;
                 M2Cand* const s_tab = reinterpret_cast<M2Cand*>(smem + NW * rows_b);
                 const int cap = ((m2_lds_bytes(UNITW, NW, NMAX) - NW * rows_b) / 16) & ~(M2_UBATCH - 1);
-                const int nbm = __popc(J.maskB);
+                const int nbm = m2_popc(J.maskB);
                 const int E = m2_round_batch(nbm) + m2_round_batch(nbm * n);
                 const bool resident = E <= cap;
                 if (resident) {
@@ -1030,11 +1044,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
             __syncthreads();
             err = m2_rfl(s_ctl[1]) | err;
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-            const int newW = m2_renumber<NW>(A, G, J, part, nca, ncb, pb, &s_ctl[2]);
+            const int newW = m2_renumber<NW, MASK>(A, G, J, part, nca, ncb, pb, &s_ctl[2]);
             const unsigned long long t4 = __builtin_amdgcn_s_memtime();
             if (wave == 0) { cy_rows += t1 - t0; cy_chain += t2 - t1; cy_walk += t3 - t2; cy_renum += t4 - t3; }
             if (newW < 0 || err) { over = true; break; }
-            if (lane == n + round) { nmask = J.maskA | J.maskB; ncols = newW; }
+            if (!TWO || n + round < 64) { if (lane == n + round) { nmask = J.maskA | J.maskB; ncols = newW; } }
+            else if (lane == n + round - 64) { nmask2 = J.maskA | J.maskB; ncols2 = newW; }
             width = newW;
         }
         if (threadIdx.x == 0) {
@@ -1392,15 +1407,21 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
     // ---- progressive merging: every join of every group in ONE round of launches ----
     // Groups are ordered by decreasing size.  A group is merged by one workgroup: one wavefront for the bulk (up to
     // M2_NB reads), 4 wavefronts up to M2_NC reads, 8 beyond -- the cost of a group grows with the cube of its size, and
-    // the longest group sets the length of the launch.  The three instantiations run side by side on streams of their own.
+    // the longest group sets the length of the launch; groups of 33 to M2_MAXN reads have an instantiation of their own
+    // (64-bit member masks, up to 127 tree nodes, LDS for 65 staged rows per wavefront and tables of up to 4 100 candidates).
+    // The instantiations run side by side on streams of their own.
     size_t nmulti = 0;
     while (nmulti < ng && B.groups[nmulti].n >= 2) ++nmulti;
     if (nmulti) {
-        size_t iC = 0, iB = 0;
-        if (unitw && !option(OPT_MSA2_SINGLE_WAVE)) {
-            while (iC < nmulti && B.groups[iC].n > M2_NC) ++iC;
-            iB = iC;
-            while (iB < nmulti && B.groups[iB].n > M2_NB) ++iB;
+        size_t iD = 0, iC = 0, iB = 0;
+        if (unitw) {
+            while (iD < nmulti && B.groups[iD].n > M2_N32) ++iD;
+            iC = iB = iD;
+            if (!option(OPT_MSA2_SINGLE_WAVE)) {
+                while (iC < nmulti && B.groups[iC].n > M2_NC) ++iC;
+                iB = iC;
+                while (iB < nmulti && B.groups[iB].n > M2_NB) ++iB;
+            }
         }
         unsigned long long* d_cnt;
         int* d_next;
@@ -1417,23 +1438,24 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
         a.chain_hbm = option(OPT_MSA2_CHAIN_HBM) ? 1 : 0;
 
         M2Streams& MS = m2_streams();
-        SL_TRY(MS.ensure(2));
+        SL_TRY(MS.ensure(4));
         SL_HIP(hipEventRecord(MS.fork, s));
-        struct Cls { size_t lo, hi; int nw; const char* tag; };
-        const Cls cls[3] = {{0, iC, 8, ".c"}, {iC, iB, 4, ".b"}, {iB, nmulti, 1, ".a"}};
-        for (int k = 0; k < 3; ++k) {
+        struct Cls { size_t lo, hi; int nw; const char* tag; int stream; };   // stream: index into MS.st (2 is the alignments' own), -1 = s
+        const Cls cls[4] = {{0, iD, 8, ".d", 3}, {iD, iC, 8, ".c", 0}, {iC, iB, 4, ".b", 1}, {iB, nmulti, 1, ".a", -1}};
+        for (int k = 0; k < 4; ++k) {
             if (cls[k].lo >= cls[k].hi) continue;
             // scratch of a resident workgroup: as wide as the widest profile capacity of the class
             int class_wcap = 1;
             for (size_t q = cls[k].lo; q < cls[k].hi; ++q) class_wcap = std::max(class_wcap, B.groups[q].wcap);
             const long long w_rows = (static_cast<long long>(class_wcap) + 63) / 64 * 64 + 64 * 9;   // (+ the slack of 8 row ranges)
             const long long per_wg = w_rows * (M2_CAP * 12 + 4 * 4 + 8);
-            hipStream_t sk = k < 2 ? MS.st[k] : s;
-            if (k < 2) SL_HIP(hipStreamWaitEvent(sk, MS.fork, 0));
+            hipStream_t sk = cls[k].stream >= 0 ? MS.st[cls[k].stream] : s;
+            if (cls[k].stream >= 0) SL_HIP(hipStreamWaitEvent(sk, MS.fork, 0));
             const void* fn = !unitw ? reinterpret_cast<const void*>(&k_m2_group<false, 1, M2_MAXN>)
                              : k == 0 ? reinterpret_cast<const void*>(&k_m2_group<true, 8, M2_MAXN>)
-                             : k == 1 ? reinterpret_cast<const void*>(&k_m2_group<true, 4, M2_NC>)
-                                      : reinterpret_cast<const void*>(&k_m2_group<true, 1, M2_MAXN>);
+                             : k == 1 ? reinterpret_cast<const void*>(&k_m2_group<true, 8, M2_N32>)
+                             : k == 2 ? reinterpret_cast<const void*>(&k_m2_group<true, 4, M2_NC>)
+                                      : reinterpret_cast<const void*>(&k_m2_group<true, 1, M2_N32>);
             int per_cu = 0;
             SL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * cls[k].nw, 0));
             per_cu = std::max(1, std::min(per_cu, 32 / cls[k].nw));
@@ -1455,10 +1477,11 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
             const dim3 grid(static_cast<unsigned>(wgs)), block(64 * cls[k].nw);
             if (!unitw) hipLaunchKernelGGL((k_m2_group<false, 1, M2_MAXN>), grid, block, 0, sk, am, d_tab);
             else if (k == 0) hipLaunchKernelGGL((k_m2_group<true, 8, M2_MAXN>), grid, block, 0, sk, am, d_tab);
-            else if (k == 1) hipLaunchKernelGGL((k_m2_group<true, 4, M2_NC>), grid, block, 0, sk, am, d_tab);
-            else hipLaunchKernelGGL((k_m2_group<true, 1, M2_MAXN>), grid, block, 0, sk, am, d_tab);
+            else if (k == 1) hipLaunchKernelGGL((k_m2_group<true, 8, M2_N32>), grid, block, 0, sk, am, d_tab);
+            else if (k == 2) hipLaunchKernelGGL((k_m2_group<true, 4, M2_NC>), grid, block, 0, sk, am, d_tab);
+            else hipLaunchKernelGGL((k_m2_group<true, 1, M2_N32>), grid, block, 0, sk, am, d_tab);
             SL_HIP(hipGetLastError());
-            if (k < 2) { SL_HIP(hipEventRecord(MS.join[k], sk)); SL_HIP(hipStreamWaitEvent(s, MS.join[k], 0)); }
+            if (cls[k].stream >= 0) { SL_HIP(hipEventRecord(MS.join[cls[k].stream], sk)); SL_HIP(hipStreamWaitEvent(s, MS.join[cls[k].stream], 0)); }
         }
     }
     SL_TRY(c.stage_end("msa_merge", s));

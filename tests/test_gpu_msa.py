@@ -189,8 +189,8 @@ def test_msa_long_reads(oracle):
 
 
 def test_msa_spec2_mixed_group_sizes(oracle):
-    """One call with groups for both specs: more than 32 reads -> centre-star, the rest -> spec v2;
-    rows of both kinds come back in group order."""
+    """One call with groups for both specs: more than 64 reads -> centre-star, the rest -> spec v2 (groups of 33 to 64
+    reads by the instantiation with 64-bit member sets); rows of both kinds come back in group order."""
     from sarlacc_amd import calls
     rng = np.random.default_rng(31)
     reads, groups, _ = sim_groups(rng, 6, 6, 120)
@@ -198,11 +198,13 @@ def test_msa_spec2_mixed_group_sizes(oracle):
     from sarlacc_amd.mock import NUC, mutate
     truth = NUC[rng.integers(0, 4, 150)]
     big = []
-    for _ in range(40):
+    for _ in range(70):
         reads.append(mutate(truth, rng, 0.05, 0.01).tobytes().decode())
         big.append(len(reads))
     groups.insert(2, big)
+    groups.append(big[:65])
     groups.append(big[:33])
+    groups.append(big[3:67])
     want = oracle.quick_msa(groups, reads, 0, -1, -5, -1, 100)
     got = calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)
     assert got == want
@@ -325,7 +327,8 @@ def test_msa_spec2_code_paths_agree(oracle):
     from sarlacc_amd.mock import NUC, mutate
     rng = np.random.default_rng(77)
     reads, groups = [], []
-    for n, length, nmol in [(2, 300, 1), (3, 150, 1), (10, 700, 1), (16, 400, 2), (32, 200, 3), (7, 0, 1), (9, 1100, 1)]:
+    for n, length, nmol in [(2, 300, 1), (3, 150, 1), (10, 700, 1), (16, 400, 2), (32, 200, 3), (7, 0, 1), (9, 1100, 1),
+                            (33, 160, 1), (48, 120, 2), (64, 90, 3)]:
         truths = [NUC[rng.integers(0, 4, length)] for _ in range(nmol)]
         idx = []
         for k in range(n):

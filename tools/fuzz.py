@@ -176,11 +176,11 @@ def case_msa(rng):
     if rng.random() < 0.2 and len(groups) >= 2 and groups[0] and groups[1]:   # a UMI collision: two molecules in one cluster
         groups[0] = groups[0] + groups[1]
         groups[1] = []
-    if rng.random() < 0.25:   # a large cluster of one to four molecules: 13-32 reads, the 4- and 8-wavefront workgroups of spec v2
+    if rng.random() < 0.25:   # a large cluster of one to four molecules: 13-64 reads, the 4- and 8-wavefront workgroups of spec v2 (64-bit member sets from 33 on)
         L = int(rng.choice([30, 80, 200]))
         truths = [NUC[rng.integers(0, 4, int(L * rng.uniform(0.7, 1.3)))] for _ in range(int(rng.integers(1, 5)))]
         idx = []
-        for k in range(int(rng.integers(13, 33))):
+        for k in range(int(rng.integers(13, 33)) if rng.random() < 0.7 else int(rng.integers(33, 65))):
             reads.append(mutate(truths[int(rng.integers(0, len(truths)))], rng, 0.06, 0.02).tobytes().decode())
             idx.append(len(reads))
         groups.insert(int(rng.integers(0, len(groups) + 1)), idx)
