@@ -78,7 +78,11 @@ def pmc_record(kernel, sources):
             continue
         # gfx950: FETCH_SIZE counts 128-byte requests as 64 bytes (MI355X_MICROARCH.md, HBM) -- reads are doubled
         return {"traffic": d.get("traffic_bytes_per_launch", (2.0 * sum(fe) / len(fe) + sum(wr) / len(wr)) * 1024.0),
-                "traffic_source": os.path.relpath(f, ROOT), "workload": d.get("workload"), "derived": d.get("derived")}
+                "traffic_source": {"file": os.path.relpath(f, ROOT), "box": d.get("box"), "same_box_bench": d.get("same_box_bench"),
+                                   "profiled_kernel_avg_ms": (d.get("kernel_stats") or {}).get("avg_ms"),
+                                   "note": "counters and timings of the profiled run (its box, its own bench line, the profiler's kernel average): "
+                                           "compare with this line's kernel_ms before reading traffic against it"},
+                "workload": d.get("workload"), "derived": d.get("derived")}
     return {"traffic": None, "traffic_source": None}
 
 
@@ -594,7 +598,10 @@ def main():
                                         "gathers": cnt.get("msa2_gathers", 0.0),
                                         "note": "library walk only (rows phase); one wave64 gather per 16 cycles and CU x 256 CUs x 2.4 GHz"},
                        "phase_share_of_wavefront_cycles": {k: v / cyc_all for k, v in cyc.items()},
-                       "groups_second_pass": cnt.get("msa2_groups_second_pass", 0.0)}
+                       "groups_second_pass": cnt.get("msa2_groups_second_pass", 0.0), "batches": cnt.get("msa2_batches", 1.0)}
+            if cnt.get("msa2_batches", 1.0) > 1.0:   # (pipelined batches: the alignments of batch k + 1 run under the merging of batch k)
+                for rf in (m2_roof, msa_roof):
+                    rf["note_batches"] = "the call was cut into %d pipelined batches: the stage timers overlap, the fractions are lower bounds" % int(cnt["msa2_batches"])
             n_seen = dist.get_world_size() if world > 1 else 1
             out["pipeline"] = {
                 "reads": int(sm[0]), "reads_per_min": sm[0] / wall * 60.0, "seconds": wall, "first_pass_seconds": mx[1],

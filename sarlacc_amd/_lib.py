@@ -103,14 +103,22 @@ class _HostBlock:
             pass
 
 
+_DEBUG_ZERO = os.environ.get("SARLACC_DEBUG_ZERO_HOST") == "1"
+
+
 def host_array(count, dtype):
     """Uninitialised numpy array for a result the device writes in full: page-locked from 1 MB on (sarlacc_host_alloc: the
-    download is one DMA transfer instead of a staged copy), ordinary memory below that."""
+    download is one DMA transfer instead of a staged copy), ordinary memory below that.  Contents beyond what the C call
+    wrote are UNDEFINED (a pooled block keeps what its last user left): callers read only the range the call reports
+    (offsets[-1] of a string set, the returned count); SARLACC_DEBUG_ZERO_HOST=1 zero-fills for debugging."""
     dt = np.dtype(dtype)
     nbytes = int(count) * dt.itemsize
     if nbytes < (1 << 20):
-        return np.empty(int(count), dt)
-    return np.asarray(_HostBlock(nbytes))[:nbytes].view(dt)
+        return np.zeros(int(count), dt) if _DEBUG_ZERO else np.empty(int(count), dt)
+    arr = np.asarray(_HostBlock(nbytes))[:nbytes].view(dt)
+    if _DEBUG_ZERO:
+        arr[:] = 0
+    return arr
 
 
 def device_count():

@@ -1461,7 +1461,7 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
             per_cu = std::max(1, std::min(per_cu, 32 / cls[k].nw));
             if (option(OPT_MSA2_WAVES_PER_CU) > 0) per_cu = std::max(1, std::min(per_cu, option(OPT_MSA2_WAVES_PER_CU) / cls[k].nw));
             long long wgs = std::min<long long>(static_cast<long long>(per_cu) * std::max(1, c.num_cu), static_cast<long long>(cls[k].hi - cls[k].lo));
-            wgs = std::max<long long>(1, std::min(wgs, (16LL << 30) / per_wg));   // (scratch of the resident workgroups: at most 16 GB per instantiation)
+            wgs = std::max<long long>(1, std::min(wgs, (8LL << 30) / per_wg));   // (scratch of the resident workgroups: at most 8 GB per instantiation)
             M2Args am = a;
             am.w_rows = w_rows;
             const std::string q = std::string("m2w") + cls[k].tag;   // (shared by the batches: their merging runs one after the other)
@@ -1571,6 +1571,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
     double cells = 0, pairs = 0;
     double counters[M2C_N] = {};
     double second_pass = 0;   // groups whose profiles outgrew the first-pass capacity
+    double nbatches = 0;      // batches of the call (from two on the stage timers of alignments and merging overlap)
     long long used = 0;
     M2Streams& MS = m2_streams();
     SL_TRY(MS.ensure(3));
@@ -1620,6 +1621,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             const long long sum = gsum[q], mx = gmx[q];
             const long long wc = exact_w ? sum : std::min(sum, m2_fast_width(n, mx));
             mem_all += 2 * (n - 1) * sum + 2 * n * wc + 4 * sum + 16 * m2_tab_entries(static_cast<int>(n));
+            mem_all += n * (n - 1) / 2 * ((2 * mx) / 16 + 2) * 4;   // the move strings of the bit-vector pairwise kernel (msa_pairwise.hip)
             jobs_all += n * (n - 1) / 2;
         }
         // batches: as many as memory and the job list demand, a few more for the overlap once there is enough work; every
@@ -1631,6 +1633,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         const long long want = option(OPT_MSA2_BATCHES) > 0 ? option(OPT_MSA2_BATCHES) : 1;
         if (std::max(nb, want) > 1) nb = std::max<long long>(want, std::max((2 * mem_all + mem_budget - 1) / mem_budget, (jobs_all + job_budget - 1) / job_budget));
         nb = std::min<long long>(nb, static_cast<long long>(todo.size()));
+        nbatches += static_cast<double>(nb);
         std::vector<M2Batch> batches(static_cast<size_t>(nb));
         for (size_t q = 0; q < todo.size(); ++q) {
             M2Batch& B = batches[q % static_cast<size_t>(nb)];
@@ -1703,6 +1706,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
     add("msa2_joins_chain_in_hbm", counters[M2C_JOINS_HBMQ]);
     add("msa2_gathers", counters[M2C_GATHERS]);
     add("msa2_groups_second_pass", second_pass);
+    add("msa2_batches", nbatches);
     add("msa2_cycles_rows", counters[M2C_CYC_ROWS]);
     add("msa2_cycles_chain", counters[M2C_CYC_CHAIN]);
     add("msa2_cycles_walk", counters[M2C_CYC_WALK]);
@@ -1767,7 +1771,7 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         c.counts[nm] = 0;
     const double t_run = m2_now();
     for (const char* nm : {"msa_pairs", "msa_cells", "msa2_rows", "msa2_rows_capped", "msa2_entries_filtered", "msa2_rows_filtered",
-                           "msa2_entries_kept", "msa2_joins", "msa2_joins_chain_in_hbm", "msa2_gathers", "msa2_groups_second_pass", "msa2_cycles_rows", "msa2_cycles_chain",
+                           "msa2_entries_kept", "msa2_joins", "msa2_joins_chain_in_hbm", "msa2_gathers", "msa2_groups_second_pass", "msa2_batches", "msa2_cycles_rows", "msa2_cycles_chain",
                            "msa2_cycles_walk", "msa2_cycles_renumber", "msa2_launches", "msa2_first_exit_s", "msa2_last_exit_s",
                            "msa2_exit_s_1wave", "msa2_exit_s_4waves", "msa2_exit_s_8waves", "msa_pairs_bitvector", "msa_bitvector_tile_bytes",
                            "msa_bitvector_split", "msa_bitvector_redone"})

@@ -196,7 +196,7 @@ int sarlacc_host_alloc(void** p, int64_t bytes) {
     if (!idle.empty()) { *p = idle.back(); idle.pop_back(); P.idle_bytes -= size; }
     else if (hipHostMalloc(p, size, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
-        // (make room once: the idle blocks of the other sizes)
+        // (make room once: every idle block goes back to the system, then the request is tried again)
         for (auto& kv : P.idle) { for (void* q : kv.second) (void)hipHostFree(q); kv.second.clear(); }
         P.idle_bytes = 0;
         SL_HIP(hipHostMalloc(p, size, hipHostMallocDefault));
@@ -213,8 +213,9 @@ int sarlacc_host_free(void* p) {
     if (it == P.live.end()) return fail("sarlacc_amd: sarlacc_host_free of a block that sarlacc_host_alloc did not hand out");
     const size_t size = it->second;
     P.live.erase(it);
-    // (at most 4 GB wait in the pool; beyond that the block goes back to the system)
-    if (P.idle_bytes + size > (size_t(4) << 30)) { SL_HIP(hipHostFree(p)); return 0; }
+    // (at most 1.5 GB wait in the pool -- the two result blocks of a 10^6-read pass --; beyond that the block goes back to the
+    // system: page-locked memory cannot be swapped, and on an 8-GPU node every rank has a pool of its own)
+    if (P.idle_bytes + size > (size_t(3) << 29)) { SL_HIP(hipHostFree(p)); return 0; }
     P.idle[size].push_back(p);
     P.idle_bytes += size;
     return 0;

@@ -1242,7 +1242,7 @@ __global__ void k_cl_collect(ClusterState S, ClusterTop T, int delta) {
     base = __shfl(base, 0);
     if (in) {
         const int slot = base + __popcll(ball & ((1ull << lane) - 1ull));
-        if (slot < T.cap) T.cand[slot] = v; else T.counts[2] = 1;
+        if (slot < T.cap) T.cand[slot] = v; else atomicExch(&T.counts[2], 1);
     }
 }
 
@@ -1403,11 +1403,16 @@ struct SortedUmis {
     int n;
     int words;     // 1: every string has at most 32 bases; UMI_LONG_WORDS otherwise
     int ngroups;   // pre-groups (1 when gid is nullptr)
+    int nskip = 0;       // elements that are never compared (pre-groups of one read: encoded as empty strings)
+    int max_group = 0;   // size of the largest pre-group (0: unknown, the whole set)
 };
 
 // Encode one set of UMIs (optionally the members of a pre-group) and order it like the trie.
 static int encode_and_rank(const std::string& p, const uint8_t* d_chars, const int64_t* d_off, const int32_t* d_members,
-                           const int* d_gid, int ngroups, int n, SortedUmis* out, hipStream_t s, const uint8_t* d_skip = nullptr) {
+                           const int* d_gid, int ngroups, int n, SortedUmis* out, hipStream_t s, const uint8_t* d_skip = nullptr,
+                           int nskip = 0, int max_group = 0) {
+    out->nskip = d_skip ? nskip : 0;
+    out->max_group = max_group > 0 ? max_group : n;
     UmiArrays raw;
     SL_TRY(alloc_umi(p + ".raw", n, &raw));
     SL_TRY(alloc_umi(p + ".srt", n, &out->U));
@@ -1688,11 +1693,14 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
     SkPlan plan;
     std::vector<SkScan> fwd, rev;
     const int min_n = option(OPT_UMI_SPLIT_MIN) > 0 ? option(OPT_UMI_SPLIT_MIN) : SK_MIN_N;
-    bool split = S.words == 1 && limit >= 1 && limit <= 3 && n >= min_n && !option(OPT_UMI_TILE_SEARCH) &&
-                 n / std::max(S.ngroups, 1) >= min_n / 2;
+    // (the largest pre-group decides, not the average: a set with one large pre-group among thousands of small ones has the
+    // quadratic tile search to lose; the reads that sit alone in their pre-group are encoded as empty strings, take no part
+    // in any comparison and are not "special")
+    bool split = S.words == 1 && limit >= 1 && limit <= 3 && n >= min_n && !option(OPT_UMI_TILE_SEARCH) && S.max_group >= min_n / 2;
     if (split) {
         SL_TRY(sk_plan(p, S, limit, &plan, s));
-        split = !plan.classes.empty() && 4 * plan.nspecial <= n;
+        plan.nspecial = std::max<long long>(0, plan.nspecial - S.nskip);
+        split = !plan.classes.empty() && 4 * plan.nspecial <= n - S.nskip;
     }
     if (split) SL_TRY(sk_build(p, S, plan, &fwd, &rev, s));
     const int special_lreq = split ? SK_MIN_LEN : -1;
@@ -1873,12 +1881,12 @@ static int adjacency_from_keys(const std::string& p, const unsigned long long* k
 // (src/umi_group.cpp:59-103).
 static int group_adjacency(const uint8_t* d_c1, const int64_t* d_o1, const uint8_t* d_c2, const int64_t* d_o2,
                            const int32_t* d_members, const int* d_gid, const uint8_t* d_single, int ngroups, int n,
-                           int limit1, int limit2, DevAdj* adj, hipStream_t s) {
+                           int limit1, int limit2, DevAdj* adj, hipStream_t s, int nsingle = 0, int max_group = 0) {
     SortedUmis S1;
     DirectedKeys K1;
     auto now = [&] { (void)hipStreamSynchronize(s); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    SL_TRY(encode_and_rank("u1", d_c1, d_o1, d_members, d_gid, ngroups, n, &S1, s, d_single));
+    SL_TRY(encode_and_rank("u1", d_c1, d_o1, d_members, d_gid, ngroups, n, &S1, s, d_single, nsingle, max_group));
     const double t1 = now();
     SL_TRY(neighbour_keys("u1", S1, limit1, d_single, &K1, s));
     const double t2 = now();
@@ -1896,7 +1904,7 @@ static int group_adjacency(const uint8_t* d_c1, const int64_t* d_o1, const uint8
     }
     SortedUmis S2;
     DirectedKeys K2;
-    SL_TRY(encode_and_rank("u2", d_c2, d_o2, d_members, d_gid, ngroups, n, &S2, s, d_single));
+    SL_TRY(encode_and_rank("u2", d_c2, d_o2, d_members, d_gid, ngroups, n, &S2, s, d_single, nsingle, max_group));
     SL_TRY(neighbour_keys("u2", S2, limit2, d_single, &K2, s));
     int* d_keep; long long* d_pos;
     SL_TRY(scratch("u2.keep", static_cast<size_t>(K2.nk) + 1, &d_keep));
@@ -2228,9 +2236,12 @@ int sarlacc_umi_group(const char* umi1, const int64_t* off1, const char* umi2, c
     const int N = static_cast<int>(total);
     std::vector<int> gid(static_cast<size_t>(N) + 1);
     std::vector<uint8_t> single(static_cast<size_t>(N) + 1, 0);
+    int64_t nsingle = 0, max_group = 0;
     for (int64_t g = 0; g < ngroups; ++g) {
         const int64_t a = grp_off[g] - grp_off[0], b = grp_off[g + 1] - grp_off[0];
         for (int64_t i = a; i < b; ++i) { gid[i] = static_cast<int>(g); single[i] = (b - a == 1); }
+        nsingle += (b - a == 1) ? 1 : 0;
+        max_group = std::max<int64_t>(max_group, b - a);
     }
     int64_t nc = 0;
     if (N > 0) {
@@ -2240,7 +2251,8 @@ int sarlacc_umi_group(const char* umi1, const int64_t* off1, const char* umi2, c
         SL_TRY(upload("g.single", single.data(), static_cast<size_t>(N), &d_single, s));
         DevAdj adj;
         const double t0 = now();
-        SL_TRY(group_adjacency(d_c1, d_o1, d_c2, d_o2, d_grp, d_gid, d_single, static_cast<int>(ngroups), N, thresh1, thresh2, &adj, s));
+        SL_TRY(group_adjacency(d_c1, d_o1, d_c2, d_o2, d_grp, d_gid, d_single, static_cast<int>(ngroups), N, thresh1, thresh2, &adj, s,
+                               static_cast<int>(nsingle), static_cast<int>(max_group)));
         SL_HIP(hipStreamSynchronize(s));
         const double t1 = now();
         ClusterResult res;

@@ -106,6 +106,6 @@ def run_resident(umis, d_seq, d_qual, off_host, encoding, threshold=1, bandwidth
                    "consensus_cells": _lib.stage_count("consensus_cells"), "msa_v1_fallback": _lib.stage_count("msa_v1_fallback"),
                    **{k: _lib.stage_count(k) for k in ("msa2_rows", "msa2_rows_capped", "msa2_rows_filtered", "msa2_entries_filtered",
                                                        "msa2_entries_kept", "msa2_joins", "msa2_joins_chain_in_hbm", "msa2_gathers",
-                                                       "msa2_groups_second_pass", "msa2_cycles_rows", "msa2_cycles_chain", "msa2_cycles_walk",
+                                                       "msa2_groups_second_pass", "msa2_batches", "msa2_cycles_rows", "msa2_cycles_chain", "msa2_cycles_walk",
                                                        "msa2_cycles_renumber", "msa_pairs_bitvector", "msa_bitvector_tile_bytes", "msa_bitvector_redone")}},
     }

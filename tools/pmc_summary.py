@@ -71,7 +71,19 @@ def main():
             with open(bj) as fh:
                 b = json.loads(fh.read().strip().splitlines()[-1])
             res["workload"] = b["config"]["workload"] if kernel == "k_align" else b.get("pipeline", {}).get("workload")
+            # what the SAME box measured without the profiler (tools/profile_round.sh runs the plain bench first): a reader of a
+            # bench line that quotes these counters sees at once whether its own timings come from another machine
+            res["same_box_bench"] = ({"kernel_ms": b.get("kernel_ms"), "value": b.get("value"), "ms_per_step": b.get("ms_per_step")} if kernel == "k_align"
+                                     else {"kernel_ms": b.get("pipeline", {}).get("kernel_ms"), "pipeline_seconds": b.get("pipeline", {}).get("seconds")})
         except (ValueError, KeyError, IndexError):
+            pass
+    bx = os.path.join(out_dir, "box.json")
+    if os.path.exists(bx):
+        try:
+            with open(bx) as fh:
+                box = json.load(fh)
+            res["box"] = {"hostname": box.get("hostname"), "gpu": [a for a in box.get("gpu_agents", []) if "Uuid" in a and "GPU" in a][:1]}
+        except ValueError:
             pass
     res["kernel_stats"] = kernel_stats(os.path.join(out_dir, "stats"), kernel)
     name = res["kernel_stats"]["name"] if res["kernel_stats"] else kernel
@@ -120,6 +132,34 @@ def main():
             res["traffic_scope"] = ("one pairwise stage = all launches of k_msa_pairwise_bv<NW, 1, NS> (fill), <NW, 2, NS> (walk), the second run of the "
                                     "pairs that left their partial records, and k_msa_moves_expand of one call; mean over the %d full-size stages "
                                     "of the bench run (of %d: spec v1's shorter job list is left out)" % (len(bf), len(sf)))
+            res["traffic_correction"] = "2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports half the bytes read), summed over the stage's launches"
+    if kernel == "k_m2_group":
+        # The merge stage of spec v2 is up to four instantiations of k_m2_group side by side (1, 4, 8 wavefronts per group) plus
+        # k_m2_tree / k_m2_init / k_m2_tables: its traffic is the sum over all of them, per stage (a stage starts with its k_m2_tree).
+        def stages(sub, counter):
+            per = {}
+            for r in counter_rows(os.path.join(out_dir, sub)):
+                if r["Counter_Name"] == counter and "k_m2_" in r["Kernel_Name"] and "k_m2_jobs" not in r["Kernel_Name"] and "k_m2_write" not in r["Kernel_Name"]:
+                    d = int(r["Dispatch_Id"])
+                    per.setdefault(d, [0.0, "k_m2_tree" in r["Kernel_Name"]])[0] += float(r["Counter_Value"])
+            out = []
+            for d in sorted(per):
+                if per[d][1] or not out:
+                    out.append(0.0)
+                out[-1] += per[d][0]
+            return out
+        sf, sw = stages("pmc_fetch", "FETCH_SIZE"), stages("pmc_write", "WRITE_SIZE")
+        if sf and sw:
+            bf = [x for x in sf if x >= 0.75 * max(sf)]   # the pipeline's clusters (the pure groups of configs[3] move about half as much)
+            bw = [x for x in sw if x >= 0.75 * max(sw)]
+            res["stage_launches_profiled"] = len(sf)
+            res["fetch_bytes_per_stage"] = 2.0 * sum(bf) / len(bf) * 1024.0
+            res["write_bytes_per_stage"] = sum(bw) / len(bw) * 1024.0
+            res["traffic_bytes_per_launch"] = res["fetch_bytes_per_stage"] + res["write_bytes_per_stage"]
+            res["traffic_bytes_per_stage_all"] = [(2.0 * a + b) * 1024.0 for a, b in zip(sf, sw)]
+            res["traffic_scope"] = ("one merge stage = k_m2_tree + k_m2_init + k_m2_tables + every instantiation of k_m2_group of one call; mean over "
+                                    "the %d stages on the pipeline's clusters (of %d: the pure groups of configs[3] are listed in traffic_bytes_per_stage_all)"
+                                    % (len(bf), len(sf)))
             res["traffic_correction"] = "2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports half the bytes read), summed over the stage's launches"
     sq = {}
     for sub, names in (("pmc_sq", ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",

@@ -5,11 +5,30 @@
 # tools/pmc_summary.py turns the counter CSVs into one JSON per dominant kernel
 # (k_align, k_msa_pairwise, k_consensus_code) -- the files bench.py reads from profiles/.
 #   usage: tools/profile_round.sh <tag> [extra bench.py args]
-set -e
+set -euo pipefail
 TAG=${1:-prof}; shift || true
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# which machine this is: timings and counters of different boxes of the pool differ by 7-9 %, so every summary carries it
+python3 - "$OUT/box.json" <<'PY'
+import json, os, socket, subprocess, sys
+def run(cmd):
+    try:
+        return subprocess.run(cmd, capture_output=True, text=True, timeout=60).stdout
+    except Exception as e:   # noqa: BLE001
+        return "unavailable: %s" % e
+info = {"hostname": socket.gethostname(), "cpus": len(os.sched_getaffinity(0))}
+smi = run(["rocm-smi", "--showuniqueid", "--showserial", "--showproductname", "--showclocks", "--json"])
+try:
+    info["rocm_smi"] = json.loads(smi)
+except ValueError:
+    info["rocm_smi"] = smi[-2000:]
+rinfo = run(["rocminfo"])
+info["gpu_agents"] = [l.strip() for l in rinfo.splitlines() if "Marketing Name" in l or "Uuid" in l or "Max Clock Freq" in l][:24]
+json.dump(info, open(sys.argv[1], "w"), indent=1)
+print("box:", info["hostname"], [a for a in info["gpu_agents"] if "Uuid" in a and "GPU" in a][:1])
+PY
 BENCH="python3 $PWD/bench.py --steps 2 --warmup 1 --no-cpu --no-host-pointer $*"
 python3 bench.py "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "bench done"; tail -c 1500 "$OUT/bench.json"
