@@ -38,7 +38,9 @@ int orc_fail(const char* msg) {
 int orc_check_encoding(const double* errors, const char* names, int n) {
     if (n <= 0) return orc_fail("encoding vector must be non-empty and named");
     for (int i = 1; i < n; ++i) {
-        if (names[i] != (char)(names[i - 1] + 1))
+        /* `curval != last + 1` compares a char with an int (src/quality_encoding.cpp:21): on a platform whose char is signed
+         * (x86) a table that runs past byte 127 -- Biostrings' PhredQuality to Q 99 is '!' .. byte 132 -- is rejected here */
+        if ((int)(signed char)names[i] != (int)(signed char)names[i - 1] + 1)
             return orc_fail("names of encoding vector should increase consecutively");
         if (errors[i] > errors[i - 1])
             return orc_fail("error probabilities should decrease");

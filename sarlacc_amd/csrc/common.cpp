@@ -128,7 +128,10 @@ void Context::release() {
 int check_encoding(const double* errors, const char* names, int n) {
     if (n <= 0 || !errors || !names) return fail("encoding vector must be non-empty and named");
     for (int i = 1; i < n; ++i) {
-        if (names[i] != static_cast<char>(names[i - 1] + 1))
+        // `curval != last + 1` compares a char with an int (src/quality_encoding.cpp:21): with the reference's signed char (x86) a
+        // table that runs past byte 127 -- Biostrings' PhredQuality to Q 99 is '!' .. byte 132 -- is rejected by the reference
+        // itself, which is why the tables of sarlacc_amd/encoding.py stop at '~'
+        if (static_cast<int>(static_cast<signed char>(names[i])) != static_cast<int>(static_cast<signed char>(names[i - 1])) + 1)
             return fail("names of encoding vector should increase consecutively");
         if (errors[i] > errors[i - 1]) return fail("error probabilities should decrease");
     }

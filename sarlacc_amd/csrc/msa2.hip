@@ -1461,7 +1461,9 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
             per_cu = std::max(1, std::min(per_cu, 32 / cls[k].nw));
             if (option(OPT_MSA2_WAVES_PER_CU) > 0) per_cu = std::max(1, std::min(per_cu, option(OPT_MSA2_WAVES_PER_CU) / cls[k].nw));
             long long wgs = std::min<long long>(static_cast<long long>(per_cu) * std::max(1, c.num_cu), static_cast<long long>(cls[k].hi - cls[k].lo));
-            wgs = std::max<long long>(1, std::min(wgs, (8LL << 30) / per_wg));   // (scratch of the resident workgroups: at most 8 GB per instantiation)
+            // (scratch of the resident workgroups: at most 16 GB per instantiation -- 8 GB left the one-wavefront instantiation with
+            // 6 000 of its 8 192 workgroups at 2-kb reads and cost 18 % of the merge stage)
+            wgs = std::max<long long>(1, std::min(wgs, (16LL << 30) / per_wg));
             M2Args am = a;
             am.w_rows = w_rows;
             const std::string q = std::string("m2w") + cls[k].tag;   // (shared by the batches: their merging runs one after the other)

@@ -184,6 +184,13 @@ def test_errors(oracle, oenc):
         oracle.adaptor_align(["ACGT"], ["II I"], oenc, 5, 1, ADAPTOR)
     with pytest.raises(oracle.OracleError, match="error probabilities should decrease"):
         oracle.adaptor_align(["ACGT"], ["!!!!"], (np.array([0.1, 0.2]), b"!\""), 5, 1, ADAPTOR)
+    # Biostrings' PhredQuality runs to Q 99 = byte 132; the reference's check compares a (signed) char with an int
+    # (src/quality_encoding.cpp:21), so a table that runs past byte 127 is rejected by the reference itself on x86
+    full = (np.power(10.0, -np.arange(100) / 10.0), bytes(range(33, 133)))
+    with pytest.raises(oracle.OracleError, match="should increase consecutively"):
+        oracle.adaptor_align(["ACGT"], ["IIII"], full, 5, 1, ADAPTOR)
+    printable = (np.power(10.0, -np.arange(95) / 10.0), bytes(range(33, 128)))   # up to byte 127: accepted
+    oracle.adaptor_align(["ACGT"], ["IIII"], printable, 5, 1, ADAPTOR)
 
 
 def test_mask_bad_bases(oracle, oenc):
