@@ -12,7 +12,7 @@
 //   map   uint16  for every ordered pair (a, b) of a group: position of b aligned to position p of a
 //                 (0xFFFF = gap) -- both directions of every pairwise alignment, written by the walk of
 //                 msa_pairwise.hip (OUT 1);
-//   col   int32   column of every base in the profile that currently holds its read;
+//   col   uint16  column of every base in the profile that currently holds its read;
 //   pos   uint16  per group n x wcap: position of read a at column c of its profile (0xFFFF = gap);
 //   tab   M2Cand  per group and join: the (third read, second-child member) candidates of the library walk as
 //                 16-byte descriptors (k_m2_tables, once per batch), staged into LDS by the wavefront that walks them.
@@ -55,7 +55,7 @@ typedef unsigned long long m2_mask;
 #ifndef M2_WAVES_EU
 #define M2_WAVES_EU 8   // wavefronts per SIMD the merge kernel is compiled for (its registers are capped accordingly)
 #endif
-constexpr int M2_NB = 20, M2_NC = 24; // groups of up to M2_NB reads: one wavefront; up to M2_NC: 4; larger: 8 (k_m2_group; sweep: profiles/r03_exp_m2_class_thresholds_v1.txt)
+constexpr int M2_NB = 24, M2_NC = 24; // groups of up to M2_NB reads: one wavefront; up to M2_NC: 4; larger: 8 (k_m2_group; sweep: profiles/r03_exp_m2_class_thresholds_v1.txt)
 constexpr int M2_CAP = 16;           // partner columns per row (spec v2, step 5)
 constexpr unsigned M2_NONE = 0xFFFFu;
 // profile capacity of the first pass: same-molecule reads grow a profile by 10-20 %, one or two unrelated reads in
@@ -108,7 +108,7 @@ struct M2Args {
     double* dist;
     int2* joins;
     int* join_tab;                 // per join (first_member + k): start of its candidates inside the group's table
-    int* col;
+    uint16_t* col;                 // (a column is < 65535: 16 bits halve the bytes of the walk's column gathers)
     uint16_t* pos;
     int* ovf;                      // per group: a profile outgrew its capacity
     int32_t* width;                // per group: columns of the final profile
@@ -213,7 +213,7 @@ __global__ void k_m2_init(M2Args A, const int* member_group, int nmembers) {
     const M2Member Me = A.members[m];
     const int a = m - G.first_member;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < Me.len; p += gridDim.x * blockDim.x) {
-        A.col[Me.col_base + p] = p;
+        A.col[Me.col_base + p] = static_cast<uint16_t>(p);
         A.pos[G.pos_base + static_cast<long long>(a) * G.wcap + p] = static_cast<uint16_t>(p);
     }
 }
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(64) k_m2_tables(M2Args A, M2Cand* tab) {
                 const int b = s_b[x % nbm];
                 const int cu = direct ? b : x / nbm;
                 const M2Member Mc = A.members[fm + cu], Mb = A.members[fm + b];
-                C.col_boff = static_cast<unsigned>((Mb.col_base - G.col0) * 4);
+                C.col_boff = static_cast<unsigned>((Mb.col_base - G.col0) * 2);
                 const unsigned lenb = static_cast<unsigned>(max(Mb.len - 1, 0));
                 if (direct) { C.lens = lenb << 16; C.row = (static_cast<unsigned>(b) * 128u) | M2_DIRECT; }
                 else {
@@ -438,7 +438,7 @@ constexpr unsigned M2_EMPTY = 0xFFFF0000u;
 template <typename MASK>
 __device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, const M2JoinT<MASK>& J, const M2Cand* T, int i_lo, int i_hi,
                                             unsigned char* s_rows, M2Cand* s_tab, int cap, bool resident, m2_u64* ent, int* part,
-                                            unsigned& st_capped, unsigned& st_filtered, unsigned& st_rowsf, unsigned long long& st_gath) {
+                                            unsigned& st_capped, unsigned& st_filtered, unsigned& st_rowsf) {
     // s_rows (LDS, this wavefront's): rows 0 .. n - 1 of 64 positions each (position of the lane's base in member c), row n:
     // gaps.  s_tab (LDS): the join's candidates -- all of them (`resident`, staged by the caller) or room for `cap` at a time.
     const int lane = m2_lane();
@@ -470,7 +470,6 @@ __device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, c
             const bool havep = p != M2_NONE;
             if (!__ballot(havep)) continue;
             const M2Member Ma = A.members[fm + a];
-            st_gath += static_cast<unsigned>(1 + (n + 7) / 8 * 8 + (leafB ? E : 2 * E));   // (wave-uniform: scalar arithmetic)
             {   // positions in every other member: unconditional loads (clamped), selected afterwards
                 const unsigned pidx = havep ? p : 0u;
                 for (int c0 = 0; c0 < n; c0 += 8) {
@@ -507,7 +506,7 @@ __device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, c
                         for (int u = 0; u < M2_UBATCH; ++u) jj[u] = static_cast<int>(qq[u]);
                     } else {
 #pragma unroll
-                        for (int u = 0; u < M2_UBATCH; ++u) jj[u] = *((m2_gi32*)(colb + (cb[u] + (min(qq[u], ln[u]) << 2))));
+                        for (int u = 0; u < M2_UBATCH; ++u) jj[u] = *((m2_gu16*)(colb + (cb[u] + (min(qq[u], ln[u]) << 1))));
                     }
 #pragma unroll
                     for (int u = 0; u < M2_UBATCH; ++u) M2_ADD1(jj[u], rr[u] != M2_NONE && qq[u] != M2_NONE)
@@ -918,7 +917,7 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
         uint16_t* row = A.pos + G.pos_base + static_cast<long long>(a) * G.wcap;
         for (int p = tid; p < Me.len; p += NT) {
             const int c = nc[A.col[Me.col_base + p]];
-            A.col[Me.col_base + p] = c;
+            A.col[Me.col_base + p] = static_cast<uint16_t>(c);
             row[c] = static_cast<uint16_t>(p);
         }
     }
@@ -1004,7 +1003,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
                     __syncthreads();
                 } else if (NW > 1) { err = 3; }   // (cannot happen: the LDS of a multi-wavefront instantiation holds any table of its groups)
                 ne = err ? 0 : m2_rows_unit(A, G, J, T, i_lo, i_hi, smem + wave * rows_b, s_tab, cap, resident, ent + wave * stride, part, st_capped,
-                                            st_filtered, st_rowsf, st_gath);
+                                            st_filtered, st_rowsf);
+                // wave-wide gather instructions of this wavefront's walk: per block of 64 columns and member of the first child one load of
+                // its positions, the positions in every member (batches of 8) and one or two gathers per table entry (a member without a
+                // base in a whole block skips its walk: counted all the same, an upper bound by a fraction of a per cent)
+                st_gath += static_cast<unsigned long long>((i_hi - i_lo + 63) / 64) * static_cast<unsigned>(m2_popc(J.maskA)) *
+                           static_cast<unsigned>(1 + (n + 7) / 8 * 8 + (nbm == 1 ? E : 2 * E));
             } else {
                 ne = m2_rows_general(A, G, J, i_lo, i_hi, smem, ent, part, st_capped, st_filtered, st_rowsf);
             }
@@ -1352,7 +1356,7 @@ static int m2_prepare(M2Batch& B, const std::string& pf, const uint8_t* d_seq, d
     hipLaunchKernelGGL(k_m2_jobs, dim3(static_cast<unsigned>((ng + 3) / 4)), dim3(256), 0, s, d_groups, d_members, static_cast<int>(ng), d_jobs);
     SL_HIP(hipGetLastError());
     B.d_member_group = d_mg;
-    uint16_t* d_map; int2* d_stats; double* d_dist; int2* d_joins; int* d_jtab; int* d_col; uint16_t* d_pos; int* d_ovf; int32_t* d_width;
+    uint16_t* d_map; int2* d_stats; double* d_dist; int2* d_joins; int* d_jtab; uint16_t* d_col; uint16_t* d_pos; int* d_ovf; int32_t* d_width;
     SL_TRY(scratch((pf + ".map").c_str(), static_cast<size_t>(map_n) + 1, &d_map));
     SL_TRY(scratch((pf + ".stats").c_str(), B.njobs + 1, &d_stats));
     SL_TRY(scratch((pf + ".dist").c_str(), static_cast<size_t>(dist_n) + 1, &d_dist));
@@ -1483,8 +1487,13 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
             else if (k == 2) hipLaunchKernelGGL((k_m2_group<true, 4, M2_NC>), grid, block, 0, sk, am, d_tab);
             else hipLaunchKernelGGL((k_m2_group<true, 1, M2_N32>), grid, block, 0, sk, am, d_tab);
             SL_HIP(hipGetLastError());
-            if (cls[k].stream >= 0) { SL_HIP(hipEventRecord(MS.join[cls[k].stream], sk)); SL_HIP(hipStreamWaitEvent(s, MS.join[cls[k].stream], 0)); }
+            if (cls[k].stream >= 0) SL_HIP(hipEventRecord(MS.join[cls[k].stream], sk));
         }
+        // the caller's stream joins the side streams only now, AFTER its own instantiation is queued (waiting inside the loop
+        // made the one-wavefront launch -- last in the loop, on `s` -- start when the others had finished: the classes ran one
+        // after the other, 0.18 s of the 0.58 s merge stage of bench.py's pipeline workload)
+        for (int k = 0; k < 4; ++k)
+            if (cls[k].lo < cls[k].hi && cls[k].stream >= 0) SL_HIP(hipStreamWaitEvent(s, MS.join[cls[k].stream], 0));
     }
     SL_TRY(c.stage_end("msa_merge", s));
     B.width.resize(ng);
@@ -1622,7 +1631,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             const long long n = grp_off[g + 1] - grp_off[g];
             const long long sum = gsum[q], mx = gmx[q];
             const long long wc = exact_w ? sum : std::min(sum, m2_fast_width(n, mx));
-            mem_all += 2 * (n - 1) * sum + 2 * n * wc + 4 * sum + 16 * m2_tab_entries(static_cast<int>(n));
+            mem_all += 2 * (n - 1) * sum + 2 * n * wc + 2 * sum + 16 * m2_tab_entries(static_cast<int>(n));
             mem_all += n * (n - 1) / 2 * ((2 * mx) / 16 + 2) * 4;   // the move strings of the bit-vector pairwise kernel (msa_pairwise.hip)
             jobs_all += n * (n - 1) / 2;
         }
