@@ -1,8 +1,9 @@
 // flatten.h -- SEXP <-> flat arrays of the C ABI (include/sarlacc_amd.h).  Takes the place of
 // /root/reference/src/DNA_input.{h,cpp} and src/quality_encoding.{h,cpp} in the shimmed package:
 // the shims only marshal, every check that needs the data itself happens behind the ABI.
-// Not compiled in this repository (no R / Rcpp / Biostrings in the build image);
-// tests/test_rglue.py checks every sarlacc_* call below against the header.
+// Not built in this repository (no R / Rcpp / Biostrings in the build image); tests/test_rglue.py checks every
+// sarlacc_* call below against the header and runs every shim through g++ -fsyntax-only against declaration-only
+// stand-ins for the Rcpp / Biostrings headers (tests/rglue_stubs) and the real include/sarlacc_amd.h.
 #ifndef SARLACC_FLATTEN_H
 #define SARLACC_FLATTEN_H
 

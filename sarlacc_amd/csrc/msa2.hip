@@ -138,71 +138,98 @@ __device__ __forceinline__ int m2_w0(int x, int y, int ma, int mm) {
     return s > 1 ? s : 1;
 }
 
-// ---- guide tree: one thread per group (oracle/msa2.c nj_tree, operation for operation) ----
-__global__ void k_m2_tree(M2Args A) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- guide tree: one wavefront per group (oracle/msa2.c nj_tree, operation for operation) ----
+// Lane i = slot i of the distance matrix (n <= 64 slots, the matrix in LDS).  Per round: every live lane sums its row in slot
+// order (the oracle's order of additions), finds the first minimum of the Saitou-Nei criterion among its partners j > i, the
+// wavefront takes the smallest value and, among equal ones, the smallest (i, j) -- the oracle's "first minimum in (i, j) order" --
+// and the live lanes update their distance to the joined node.  (Round 3 ran one THREAD per group: a 39-read cluster kept the
+// stage waiting 11 ms for 59 000 dependent iterations; a 64-read one would take 50.)
+__global__ void __launch_bounds__(64) k_m2_tree(M2Args A) {
+    __shared__ double s_D[M2_MAXN * M2_MAXN];
+    __shared__ double s_R[M2_MAXN];
+    const int g = blockIdx.x;
     if (g >= A.ngroups) return;
     const M2Group G = A.groups[g];
     const int n = G.n;
     const int fm = G.first_member;
-    A.width[g] = n == 1 ? A.members[fm].len : 0;   // (groups of two and more: written by k_m2_group)
+    const int lane = threadIdx.x;
+    if (lane == 0) A.width[g] = n == 1 ? A.members[fm].len : 0;   // (groups of two and more: written by k_m2_group)
     if (n < 2) return;
-    double* D = A.dist + G.dist_base;
-    double* R = D + static_cast<long long>(n) * n;
-    for (int a = 0; a < n; ++a) {
-        D[a * n + a] = 0.0;
-        for (int b = a + 1; b < n; ++b) {
-            const int2 st = A.stats[G.first_job + static_cast<long long>(a) * n - static_cast<long long>(a) * (a + 1) / 2 + b - a - 1];
-            const long long alen = static_cast<long long>(A.members[fm + a].len) + A.members[fm + b].len - st.y;
+    if (lane < n) {
+        s_D[lane * n + lane] = 0.0;
+        const int lena = A.members[fm + lane].len;
+        for (int b = lane + 1; b < n; ++b) {
+            const int2 st = A.stats[G.first_job + static_cast<long long>(lane) * n - static_cast<long long>(lane) * (lane + 1) / 2 + b - lane - 1];
+            const long long alen = static_cast<long long>(lena) + A.members[fm + b].len - st.y;
             const double d = alen > 0 ? 1.0 - static_cast<double>(st.x) / static_cast<double>(alen) : 0.0;
-            D[a * n + b] = d;
-            D[b * n + a] = d;
+            s_D[lane * n + b] = d;
+            s_D[b * n + lane] = d;
         }
     }
+    __syncthreads();
     m2_mask active = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-    int node[M2_MAXN];
-    for (int i = 0; i < n; ++i) node[i] = i;
+    int node = lane;   // the tree node in this lane's slot
     int r = n, nj = 0;
     while (r > 3) {
-        for (int i = 0; i < n; ++i) {
-            if (!((active >> i) & 1ull)) continue;
+        const bool live = lane < n && ((active >> lane) & 1ull);
+        if (live) {
             double sum = 0.0;
             for (int k = 0; k < n; ++k)
-                if (((active >> k) & 1ull) && k != i) sum = sum + D[i * n + k];
-            R[i] = sum;
+                if (((active >> k) & 1ull) && k != lane) sum = sum + s_D[lane * n + k];
+            s_R[lane] = sum;
         }
-        int bi = -1, bj = -1;
-        double best = 0.0;
+        __syncthreads();
+        // this lane's first minimum over its partners j > lane
         const double rm2 = static_cast<double>(r - 2);
-        for (int i = 0; i < n; ++i) {
-            if (!((active >> i) & 1ull)) continue;
-            for (int j = i + 1; j < n; ++j) {
+        double best = 0.0;
+        int bj = -1;
+        if (live) {
+            const double Ri = s_R[lane];
+            for (int j = lane + 1; j < n; ++j) {
                 if (!((active >> j) & 1ull)) continue;
-                const double q = (rm2 * D[i * n + j] - R[i]) - R[j];
-                if (bi < 0 || q < best) { best = q; bi = i; bj = j; }
+                const double q = (rm2 * s_D[lane * n + j] - Ri) - s_R[j];
+                if (bj < 0 || q < best) { best = q; bj = j; }
             }
         }
-        A.joins[fm + nj] = make_int2(node[bi], node[bj]);
-        const double dij = D[bi * n + bj];
-        for (int k = 0; k < n; ++k) {
-            if (!((active >> k) & 1ull) || k == bi || k == bj) continue;
-            const double v = ((D[bi * n + k] + D[bj * n + k]) - dij) * 0.5;
-            D[bi * n + k] = v;
-            D[k * n + bi] = v;
+        // the wavefront's: smallest value, then smallest lane (a lane without partners takes no part)
+        double wbest = best;
+        int wi = bj >= 0 ? lane : 0x7fffffff, wj = bj;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double ob = __shfl_xor(wbest, d);
+            const int oi = __shfl_xor(wi, d), oj = __shfl_xor(wj, d);
+            const bool take = oi != 0x7fffffff && (wi == 0x7fffffff || ob < wbest || (ob == wbest && oi < wi));
+            wbest = take ? ob : wbest; wi = take ? oi : wi; wj = take ? oj : wj;
         }
-        active &= ~(1ull << bj);
-        node[bi] = n + nj;
+        const int bi = __builtin_amdgcn_readfirstlane(wi), bjj = __builtin_amdgcn_readfirstlane(wj);
+        const int node_i = __builtin_amdgcn_readlane(node, bi), node_j = __builtin_amdgcn_readlane(node, bjj);
+        if (lane == 0) A.joins[fm + nj] = make_int2(node_i, node_j);
+        const double dij = s_D[bi * n + bjj];
+        __syncthreads();
+        if (live && lane != bi && lane != bjj) {
+            const double v = ((s_D[bi * n + lane] + s_D[bjj * n + lane]) - dij) * 0.5;
+            s_D[bi * n + lane] = v;
+            s_D[lane * n + bi] = v;
+        }
+        active &= ~(1ull << bjj);
+        if (lane == bi) node = n + nj;
         ++nj; --r;
+        __syncthreads();
     }
+    // the remaining two or three nodes: lowest slots first
     int l[3], c = 0;
     for (int i = 0; i < n && c < 3; ++i)
         if ((active >> i) & 1ull) l[c++] = i;
     if (c >= 2) {
-        A.joins[fm + nj] = make_int2(node[l[0]], node[l[1]]);
-        node[l[0]] = n + nj;
+        const int n0 = __builtin_amdgcn_readlane(node, l[0]), n1 = __builtin_amdgcn_readlane(node, l[1]);
+        if (lane == 0) A.joins[fm + nj] = make_int2(n0, n1);
+        if (lane == l[0]) node = n + nj;
         ++nj;
     }
-    if (c == 3) A.joins[fm + nj] = make_int2(node[l[0]], node[l[2]]);
+    if (c == 3) {
+        const int n0 = __builtin_amdgcn_readlane(node, l[0]), n2 = __builtin_amdgcn_readlane(node, l[2]);
+        if (lane == 0) A.joins[fm + nj] = make_int2(n0, n2);
+    }
 }
 
 // ---- leaves: col = position, pos = identity ----
@@ -1359,7 +1386,7 @@ static int m2_prepare(M2Batch& B, const std::string& pf, const uint8_t* d_seq, d
     uint16_t* d_map; int2* d_stats; double* d_dist; int2* d_joins; int* d_jtab; uint16_t* d_col; uint16_t* d_pos; int* d_ovf; int32_t* d_width;
     SL_TRY(scratch((pf + ".map").c_str(), static_cast<size_t>(map_n) + 1, &d_map));
     SL_TRY(scratch((pf + ".stats").c_str(), B.njobs + 1, &d_stats));
-    SL_TRY(scratch((pf + ".dist").c_str(), static_cast<size_t>(dist_n) + 1, &d_dist));
+    d_dist = nullptr;   // (the tree kernel keeps its distance matrix in LDS since round 4)
     SL_TRY(scratch((pf + ".joins").c_str(), nm + 1, &d_joins));
     SL_TRY(scratch((pf + ".jtab").c_str(), nm + 1, &d_jtab));
     SL_TRY(scratch((pf + ".col").c_str(), static_cast<size_t>(col_n) + 1, &d_col));
@@ -1398,7 +1425,7 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
     SL_HIP(hipStreamWaitEvent(s, B.pair_done, 0));
     // ---- guide trees, leaves, candidate tables ----
     SL_TRY(c.stage_begin("msa_merge", s));
-    hipLaunchKernelGGL(k_m2_tree, dim3(m2_blocks(static_cast<long long>(ng), 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_m2_tree, dim3(static_cast<unsigned>(ng)), dim3(64), 0, s, a);
     if (nm) hipLaunchKernelGGL(k_m2_init, dim3(std::min(2u, std::max(1u, m2_blocks(B.max_len, 256))), static_cast<unsigned>(nm)), dim3(256), 0, s, a, d_mg, static_cast<int>(nm));
     SL_HIP(hipGetLastError());
     const bool unitw = a.ma <= 1 && a.mm <= 1 && !option(OPT_MSA2_GENERAL_ROWS);

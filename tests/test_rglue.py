@@ -112,3 +112,35 @@ def test_shims_wrap_their_bodies_for_rcpp_and_check_status():
 def test_makevars_links_the_library():
     mk = open(os.path.join(GLUE, "Makevars")).read()
     assert "-lsarlacc_amd" in mk and "-I$(SARLACC_AMD_HOME)/include" in mk
+
+
+def test_shims_parse_and_type_check():
+    """Every shim goes through the compiler's front end (g++ -fsyntax-only) against declaration-only stand-ins for the
+    headers it includes (tests/rglue_stubs: the shapes of the Rcpp / Biostrings calls the shims make, the reference
+    package's own sarlacc.h / utils.h) and the REAL include/sarlacc_amd.h: a typo, a missing argument or a wrong
+    pointer type inside a shim body fails here, which the text checks above cannot see.  Nothing is built or linked."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    stubs = os.path.join(ROOT, "tests", "rglue_stubs")
+    shims = sorted(f for f in os.listdir(GLUE) if f.endswith(".cpp"))
+    assert len(shims) >= 13
+    for f in shims:
+        res = subprocess.run([gxx, "-std=c++14", "-fsyntax-only", "-Wall", "-Werror=return-type", "-I", stubs,
+                              "-I", os.path.join(ROOT, "include"), "-I", GLUE, os.path.join(GLUE, f)],
+                             capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, "%s:\n%s" % (f, res.stderr[-3000:])
+    # and the check bites: a shim with a wrong argument type does not pass
+    bad = os.path.join(stubs, "_bad_probe.cpp")
+    with open(bad, "w") as fh:
+        fh.write('#include "sarlacc.h"\n#include "utils.h"\n#include "flatten.h"\n'
+                 'SEXP mask_bad_bases(SEXP a, SEXP b, SEXP c, SEXP d) { BEGIN_RCPP Flat s = flatten(a, true); '
+                 'return Rcpp::List::create(sarlacc_mask_bad_bases(s.off.data())); END_RCPP }\n')
+    try:
+        res = subprocess.run([gxx, "-std=c++14", "-fsyntax-only", "-I", stubs, "-I", os.path.join(ROOT, "include"), "-I", GLUE, bad],
+                             capture_output=True, text=True, timeout=120)
+        assert res.returncode != 0
+    finally:
+        os.remove(bad)
