@@ -1700,7 +1700,13 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             long long need = used;
             std::vector<long long> boff(B.groups.size(), 0);
             std::vector<int32_t> bw = B.width;
-            for (size_t q = 0; q < B.groups.size(); ++q) {
+            // The rows of a batch are laid out in the CALLER's group order (the batch itself is ordered by group size): when one
+            // batch holds every group -- the usual case -- the buffer is then already what msa_run hands on, and its gathering
+            // copy (4.6 GB of vote codes at 10^6 reads: 5 ms) is skipped.
+            std::vector<size_t> byslot(B.groups.size());
+            std::iota(byslot.begin(), byslot.end(), size_t(0));
+            std::sort(byslot.begin(), byslot.end(), [&](size_t x, size_t y) { return B.slot[x] < B.slot[y]; });
+            for (size_t q : byslot) {
                 if (B.ovf[q]) {   // profile capacity exceeded: next pass
                     if (exact_w) return fail("sarlacc_amd: an alignment wider than 65535 columns is beyond spec v2 (select spec 1 with sarlacc_set_msa_spec)");
                     again.push_back(B.slot[q]);
@@ -1863,6 +1869,16 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         }
     }
     if (want_rows && out_cap >= 0 && out_cap < out_off[ngroups]) return fail("sarlacc_amd: MSA output buffer too small (%lld needed)", static_cast<long long>(out_off[ngroups]));
+    // spec v2's buffer already in group order (one batch, no group by spec v1, none that needed the second pass): it IS the result
+    bool in_place = v1.empty();
+    for (int64_t g = 0; g < ngroups && in_place; ++g) in_place = src_off[g] == dst_off[g];
+    if (in_place) {
+        SL_HIP(hipStreamSynchronize(s));
+        if (res->code.want) res->d_codes = reinterpret_cast<uint16_t*>(d_rows2);
+        else res->d_out = d_rows2;
+        m2_host_time("total", t_run);
+        return 0;
+    }
     // (offsets and sizes so far are in cells; a cell is one character, or one 16-bit vote code)
     const long long cs = res->code.want ? 2 : 1;
     uint8_t* d_final;
