@@ -1206,17 +1206,29 @@ __global__ void __launch_bounds__(256) k_cl_decrement_w(ClusterState S, int roun
 struct ClusterTop {
     int* maxrem;                // largest remaining of a live node, this round
     int* cand;                  // candidate list
-    int* counts;                // [0] candidates, [1] picks, [2] 1 when the list was cut off at `cap`
+    int* counts;                // [0] candidates, [1] picks, [2] 1 when the list was cut off at `cap`, [3] nodes clustered this round
     unsigned long long* hop1;
     int cap;
+    int* marked;                // the nodes clustered this round (two picks of a round share no neighbour: no node twice)
+    int* ctl;                   // the rounds' control block, see k_cl_control
 };
+// Control block of the candidate-set rounds.  The decisions between two rounds -- is anything left, did the last candidate
+// list overflow, how wide is the next one -- need three counters of the round before; taken on the host they cost one
+// read-back per round (190 us per round with its six launches, 330 rounds at threshold 3 on 10^6 12-base UMIs).  k_cl_control
+// takes them on the device, every kernel of a round looks at the mode first, and the host enqueues CL_GROUP rounds at a time.
+enum { CTL_MODE, CTL_DELTA, CTL_WAS_TOP, CTL_ROUNDS, CTL_MAXREM, CTL_N = 8 };
+enum { CL_DONE = 0, CL_TOP = 1, CL_WANTS_FULL = 3 };   // CL_WANTS_FULL: the list was cut off -- the host runs one round over every list
+constexpr int CL_GROUP = 8;
 
 __global__ void __launch_bounds__(1024) k_cl_keys_top(ClusterState S, ClusterTop T) {
     __shared__ int s_live[16], s_max[16];
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     int rem = 0;
     if (v < S.n && S.state[v] == 0 && S.remaining[v] > 0) rem = S.remaining[v];
-    if (v < S.n) S.key[v] = rem ? ((static_cast<unsigned long long>(rem) << 32) | static_cast<unsigned>(v)) : 0ull;
+    if (v < S.n) {
+        S.key[v] = rem ? ((static_cast<unsigned long long>(rem) << 32) | static_cast<unsigned>(v)) : 0ull;
+        if (T.ctl) T.hop1[v] = 0ull;   // (device-controlled rounds: the round's maxima start here instead of in a memset)
+    }
     const unsigned long long live = __ballot(rem > 0);
     int m = rem;
 #pragma unroll
@@ -1230,9 +1242,31 @@ __global__ void __launch_bounds__(1024) k_cl_keys_top(ClusterState S, ClusterTop
     }
 }
 
+// One thread between the key pass and the candidate pass of a round: the host loop's decisions (see ClusterTop).
+__global__ void k_cl_control(ClusterState S, ClusterTop T) {
+    int* const c = T.ctl;
+    const int live = *S.live;
+    c[CTL_MAXREM] = *T.maxrem;
+    *S.live = 0; *T.maxrem = 0;
+    if (c[CTL_MODE] != CL_TOP) return;   // finished, or waiting for the host's round over every list
+    if (live == 0) { c[CTL_MODE] = CL_DONE; return; }
+    int delta = c[CTL_DELTA];
+    if (c[CTL_WAS_TOP]) {
+        // the candidate list of the previous round: cut off -> a round over every list and the window shrinks;
+        // a productive list (a quarter or more of it picked) may be hiding picks just below it -> widen
+        const long long nc = T.counts[0], np = T.counts[1];
+        if (T.counts[2]) { c[CTL_DELTA] = delta / 2; c[CTL_MODE] = CL_WANTS_FULL; c[CTL_WAS_TOP] = 0; return; }
+        if (4 * np >= nc) delta = 2 * delta + 1;
+        else if (64 * np < nc && nc > 256) delta /= 2;
+    }
+    c[CTL_DELTA] = delta; c[CTL_WAS_TOP] = 1; c[CTL_ROUNDS] += 1;
+    T.counts[0] = T.counts[1] = T.counts[2] = T.counts[3] = 0;
+}
+
 __global__ void k_cl_collect(ClusterState S, ClusterTop T, int delta) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    const int t = max(1, *T.maxrem - delta);
+    if (T.ctl && T.ctl[CTL_MODE] != CL_TOP) return;
+    const int t = T.ctl ? max(1, T.ctl[CTL_MAXREM] - T.ctl[CTL_DELTA]) : max(1, *T.maxrem - delta);
     const bool in = v < S.n && static_cast<int>(S.key[v] >> 32) >= t;
     const unsigned long long ball = __ballot(in);
     if (!ball) return;
@@ -1247,6 +1281,7 @@ __global__ void k_cl_collect(ClusterState S, ClusterTop T, int delta) {
 }
 
 __global__ void __launch_bounds__(256) k_cl_mark_top(ClusterState S, ClusterTop T) {
+    if (T.ctl && T.ctl[CTL_MODE] != CL_TOP) return;
     if (T.counts[2]) return;
     const int nc = T.counts[0], lane = threadIdx.x & 63;
     for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < nc; c += gridDim.x * 4) {
@@ -1260,6 +1295,7 @@ __global__ void __launch_bounds__(256) k_cl_mark_top(ClusterState S, ClusterTop 
 }
 
 __global__ void __launch_bounds__(256) k_cl_pick_top(ClusterState S, ClusterTop T, int round) {
+    if (T.ctl && T.ctl[CTL_MODE] != CL_TOP) return;
     if (T.counts[2]) return;
     const int nc = T.counts[0], lane = threadIdx.x & 63;
     for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < nc; c += gridDim.x * 4) {
@@ -1280,13 +1316,42 @@ __global__ void __launch_bounds__(256) k_cl_pick_top(ClusterState S, ClusterTop 
             const int w = p < b ? S.nbr[p] : -1;
             const bool live = w >= 0 && S.state[w] == 0;
             const unsigned long long ball = __ballot(live);
+            int lbase = 0;
+            if (T.marked && ball) {
+                if (lane == 0) lbase = atomicAdd(&T.counts[3], __popcll(ball));
+                lbase = __shfl(lbase, 0);
+            }
             if (live) {
-                S.memb[a + cnt + __popcll(ball & ((1ull << lane) - 1ull))] = w;
+                const int before = __popcll(ball & ((1ull << lane) - 1ull));
+                S.memb[a + cnt + before] = w;
                 S.mark[w] = round;
+                if (T.marked) T.marked[lbase + before] = w;
             }
             cnt += __popcll(ball);
         }
         if (lane == 0) { S.csize[v] = cnt; S.seed[v] = 1; S.pickkey[v] = k; atomicAdd(&T.counts[1], 1); }
+    }
+}
+
+// commit and decrement of a device-controlled round, over the list of the nodes it clustered instead of over all nodes
+__global__ void __launch_bounds__(256) k_cl_commit_list(ClusterState S, ClusterTop T) {
+    if (T.ctl[CTL_MODE] != CL_TOP) return;
+    const int nm = T.counts[3];
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nm; q += gridDim.x * blockDim.x) {
+        const int w = T.marked[q];
+        S.state[w] = 2; S.remaining[w] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cl_decrement_list(ClusterState S, ClusterTop T) {
+    if (T.ctl[CTL_MODE] != CL_TOP) return;
+    const int nm = T.counts[3], lane = threadIdx.x & 63;
+    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nm; q += gridDim.x * 4) {
+        const int v = T.marked[q];
+        for (long long p = S.off[v] + lane; p < S.off[v + 1]; p += 64) {
+            const int x = S.nbr[p];
+            if (S.state[x] == 0) atomicSub(&S.remaining[x], 1);
+        }
     }
 }
 
@@ -1837,6 +1902,12 @@ static int keys_from_edges(const std::string& p, const SortedUmis& S, int limit,
     SL_HIP(hipMemcpyAsync(&nself, d_pos + n, sizeof nself, hipMemcpyDeviceToHost, s));
     SL_HIP(hipStreamSynchronize(s));
     const long long nk = 2 * static_cast<long long>(m) + nself;
+    // The neighbour lists are explicit (as the reference's are, src/umi_group.cpp:59-103): 20 bytes per link while they are
+    // sorted.  Measured up to 2.8e9 links (7e5 12-base UMIs at threshold 4: 4 000 neighbours each); beyond 2^32 the
+    // call stops here instead of running out of memory half way.
+    if (nk > 0xFFFFFFFFll)
+        return fail("sarlacc_amd: %lld neighbour links in one call (at most 4294967295): the threshold joins most of the set -- "
+                    "lower it or split the reads into pre-groups", nk);
     unsigned long long *d_k0, *d_k1;
     SL_TRY(scratch((p + ".k0").c_str(), static_cast<size_t>(nk), &d_k0));
     SL_TRY(scratch((p + ".k1").c_str(), static_cast<size_t>(nk), &d_k1));
@@ -1979,60 +2050,75 @@ static int cluster_dev(const DevAdj& adj, int n, const int32_t* d_members, const
         SL_HIP(hipMemsetAsync(T.counts, 0, 4 * sizeof(int), s));
     }
     const bool top_rounds = dense && !option(OPT_UMI_FULL_ROUNDS);
-    int delta = 0;            // candidates: remaining >= (largest remaining) - delta
-    bool was_top = false;     // the previous round ran on a candidate set; its counts are in T.counts
     long long top_rounds_run = 0, full_rounds_run = 0;
-    for (int round = 0;; ++round) {
-        int hc[4] = {0, 0, 0, 0};
-        if (was_top) SL_HIP(hipMemcpyAsync(hc, T.counts, sizeof hc, hipMemcpyDeviceToHost, s));
+    int rounds_total = 0;
+    if (top_rounds) {
+        // Candidate-set rounds under the device's control (k_cl_control): CL_GROUP rounds per read-back.  A round whose list
+        // was cut off parks the control block (CL_WANTS_FULL; the rounds still queued behind it do nothing) and the host
+        // runs that round over every list, as before.
+        SL_TRY(scratch("cl.marked", nn, &T.marked));
+        SL_TRY(scratch("cl.ctl", CTL_N, &T.ctl));
+        int hctl[CTL_N] = {CL_TOP, 0, 0, 0, 0, 0, 0, 0};
+        SL_HIP(hipMemcpyAsync(T.ctl, hctl, sizeof hctl, hipMemcpyHostToDevice, s));
         SL_HIP(hipMemsetAsync(S.live, 0, sizeof(int), s));
-        if (top_rounds) {
-            SL_HIP(hipMemsetAsync(T.maxrem, 0, sizeof(int), s));
-            hipLaunchKernelGGL(k_cl_keys_top, dim3(nblk(n, 1024)), dim3(1024), 0, s, S, T);
-        } else {
+        SL_HIP(hipMemsetAsync(T.maxrem, 0, sizeof(int), s));
+        int round = 0;
+        for (;;) {
+            for (int q = 0; q < CL_GROUP; ++q, ++round) {
+                hipLaunchKernelGGL(k_cl_keys_top, dim3(nblk(n, 1024)), dim3(1024), 0, s, S, T);
+                hipLaunchKernelGGL(k_cl_control, dim3(1), dim3(1), 0, s, S, T);
+                hipLaunchKernelGGL(k_cl_collect, g, b, 0, s, S, T, 0);
+                hipLaunchKernelGGL(k_cl_mark_top, dim3(1024), b, 0, s, S, T);
+                hipLaunchKernelGGL(k_cl_pick_top, dim3(1024), b, 0, s, S, T, round);
+                hipLaunchKernelGGL(k_cl_commit_list, dim3(64), b, 0, s, S, T);
+                hipLaunchKernelGGL(k_cl_decrement_list, dim3(1024), b, 0, s, S, T);
+            }
+            SL_HIP(hipGetLastError());
+            SL_HIP(hipMemcpyAsync(hctl, T.ctl, sizeof hctl, hipMemcpyDeviceToHost, s));
+            SL_HIP(hipStreamSynchronize(s));
+            if (hctl[CTL_MODE] == CL_DONE) break;
+            if (hctl[CTL_MODE] == CL_WANTS_FULL) {   // (the keys are those of the round that asked: nothing changed since)
+                hipLaunchKernelGGL(k_cl_m1_w, gw, b, 0, s, S);
+                hipLaunchKernelGGL(k_cl_pick_w, gw, b, 0, s, S, round);
+                hipLaunchKernelGGL(k_cl_commit, g, b, 0, s, S, round);
+                hipLaunchKernelGGL(k_cl_decrement_w, gw, b, 0, s, S, round);
+                ++round; ++full_rounds_run;
+                const int back[3] = {CL_TOP, hctl[CTL_DELTA], 0};
+                SL_HIP(hipMemcpyAsync(T.ctl, back, sizeof back, hipMemcpyHostToDevice, s));
+                SL_HIP(hipStreamSynchronize(s));   // (`back` is on this frame)
+            }
+            if (hctl[CTL_ROUNDS] + full_rounds_run > 4LL * n + 16) return fail("sarlacc_amd: clustering did not converge");
+        }
+        top_rounds_run = hctl[CTL_ROUNDS];
+        rounds_total = static_cast<int>(top_rounds_run + full_rounds_run);
+    } else {
+        for (int round = 0;; ++round) {
+            SL_HIP(hipMemsetAsync(S.live, 0, sizeof(int), s));
             hipLaunchKernelGGL(k_cl_keys, g, b, 0, s, S);
-        }
-        int live = 0;
-        SL_HIP(hipMemcpyAsync(&live, S.live, sizeof live, hipMemcpyDeviceToHost, s));
-        SL_HIP(hipStreamSynchronize(s));
-        if (live == 0) break;
-        bool full = !top_rounds;
-        if (top_rounds && was_top) {
-            // the candidate list of the previous round: cut off -> this round walks every list and the window shrinks;
-            // a productive list (a quarter or more of it picked) may be hiding picks just below it -> widen
-            if (hc[2]) { full = true; delta /= 2; }
-            else if (4ll * hc[1] >= hc[0]) delta = 2 * delta + 1;
-            else if (64ll * hc[1] < hc[0] && hc[0] > 256) delta /= 2;
-        }
-        was_top = false;
-        if (!full) {
-            SL_HIP(hipMemsetAsync(T.counts, 0, 4 * sizeof(int), s));
-            SL_HIP(hipMemsetAsync(T.hop1, 0, sizeof(unsigned long long) * static_cast<size_t>(n), s));
-            hipLaunchKernelGGL(k_cl_collect, g, b, 0, s, S, T, delta);
-            hipLaunchKernelGGL(k_cl_mark_top, dim3(1024), b, 0, s, S, T);
-            hipLaunchKernelGGL(k_cl_pick_top, dim3(1024), b, 0, s, S, T, round);
-            hipLaunchKernelGGL(k_cl_commit, g, b, 0, s, S, round);
-            hipLaunchKernelGGL(k_cl_decrement_w, gw, b, 0, s, S, round);
-            was_top = true;
-            ++top_rounds_run;
-        } else if (dense) {
+            int live = 0;
+            SL_HIP(hipMemcpyAsync(&live, S.live, sizeof live, hipMemcpyDeviceToHost, s));
+            SL_HIP(hipStreamSynchronize(s));
+            if (live == 0) break;
+            if (dense) {
+                hipLaunchKernelGGL(k_cl_m1_w, gw, b, 0, s, S);
+                hipLaunchKernelGGL(k_cl_pick_w, gw, b, 0, s, S, round);
+                hipLaunchKernelGGL(k_cl_commit, g, b, 0, s, S, round);
+                hipLaunchKernelGGL(k_cl_decrement_w, gw, b, 0, s, S, round);
+            } else {
+                hipLaunchKernelGGL(k_cl_m1, g, b, 0, s, S);
+                hipLaunchKernelGGL(k_cl_pick, g, b, 0, s, S, round);
+                hipLaunchKernelGGL(k_cl_commit, g, b, 0, s, S, round);
+                hipLaunchKernelGGL(k_cl_decrement, g, b, 0, s, S, round);
+            }
+            SL_HIP(hipGetLastError());
+            if (round > 4 * n + 16) return fail("sarlacc_amd: clustering did not converge");
             ++full_rounds_run;
-            hipLaunchKernelGGL(k_cl_m1_w, gw, b, 0, s, S);
-            hipLaunchKernelGGL(k_cl_pick_w, gw, b, 0, s, S, round);
-            hipLaunchKernelGGL(k_cl_commit, g, b, 0, s, S, round);
-            hipLaunchKernelGGL(k_cl_decrement_w, gw, b, 0, s, S, round);
-        } else {
-            hipLaunchKernelGGL(k_cl_m1, g, b, 0, s, S);
-            hipLaunchKernelGGL(k_cl_pick, g, b, 0, s, S, round);
-            hipLaunchKernelGGL(k_cl_commit, g, b, 0, s, S, round);
-            hipLaunchKernelGGL(k_cl_decrement, g, b, 0, s, S, round);
+            rounds_total = round + 1;
         }
-        SL_HIP(hipGetLastError());
-        if (round > 4 * n + 16) return fail("sarlacc_amd: clustering did not converge");
-        ctx().counts["umi_cluster_rounds"] = round + 1;
-        ctx().counts["umi_cluster_candidate_rounds"] = static_cast<double>(top_rounds_run);
-        ctx().counts["umi_cluster_full_rounds"] = static_cast<double>(full_rounds_run);
     }
+    ctx().counts["umi_cluster_rounds"] = rounds_total;
+    ctx().counts["umi_cluster_candidate_rounds"] = static_cast<double>(top_rounds_run);
+    ctx().counts["umi_cluster_full_rounds"] = static_cast<double>(full_rounds_run);
 
     // ---- output order: solos by index, then picks by key descending ----
     int *d_issolo, *d_isseed, *d_order, *d_val, *d_val2, *d_sizes;

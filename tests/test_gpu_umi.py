@@ -206,6 +206,22 @@ def test_dense_neighbourhoods_both_round_schemes(oracle):
         calls.set_option("umi_full_rounds", 0)
 
 
+def test_candidate_rounds_cut_off_list_falls_back_to_a_full_round(oracle):
+    # 2 500 copies of one UMI all carry the same count: the candidate list of the first round (at most max(1024, n / 8)
+    # entries) is cut off, the device parks its control block and the host runs that round over every list; the
+    # candidate rounds then go on with what is left (a second family of neighbours, some loners)
+    from sarlacc_amd import _lib, calls
+    rng = np.random.default_rng(77)
+    umis = ["ACGTTGCAAC"] * 2500 + ["ACGTTGCAAG"] * 40 + ["TTTTGGGGCC"] * 300 + ["".join(rng.choice(list("ACGT"), 10)) for _ in range(200)]
+    umis = [umis[i] for i in rng.permutation(len(umis))]
+    g = [list(range(1, len(umis) + 1))]
+    for t in (1, 2):
+        want = oracle.umi_group(umis, t, None, t, g, fast=True)
+        same_lists(calls.umi_group(umis, t, None, t, g), want)
+        assert _lib.stage_count("umi_links") >= 24 * len(umis)
+        assert _lib.stage_count("umi_cluster_full_rounds") >= 1 and _lib.stage_count("umi_cluster_candidate_rounds") >= 1
+
+
 def noisy_umis(rng, molecules, lo, hi, n_rate=0.0, short=0):
     """Copies of random molecules with substitutions, insertions and deletions; optionally Ns and a few short strings."""
     out = []
