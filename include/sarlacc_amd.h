@@ -291,7 +291,8 @@ int sarlacc_set_msa_spec(int spec);
  *   "msa2_batches" (a count), "msa2_tight_profiles", "align_pensel", "align_chunks" (a count), "align_k" (columns per lane),
  *   "align_waves_per_cu" (a count), "align_interleave" (-1 never / 1 with align_k), "consensus_chars", "consensus_generic",
  *   "msa_int32", "msa_affine", "msa_bitvector" (-1 never, 2 one kernel for fill and walk), "msa_bitvector_core" (-1 whole
- *   records, 1 one word), "msa_bitvector_tile_gb" (GB), "umi_full_rounds", "umi_tile_search", "umi_split_min" (a set size).
+ *   records, 1 one word), "msa_bitvector_tile_gb" (GB), "umi_full_rounds", "umi_tile_search", "umi_split_min" (a set size),
+ *   "umi_scan_single".
  * The environment (SARLACC_<NAME>) is read once, when the first option is asked for; afterwards only this call changes a
  * value.  Nothing in the reference corresponds. */
 int sarlacc_set_option(const char* name, int value);

@@ -60,6 +60,7 @@ enum Opt {
     OPT_ALIGN_INTERLEAVE,     // quality DP: -1 never two 8-lane alignments per DPP row (A/B of that shape); 1 with align_k: that shape
     OPT_UMI_SPLIT_MIN,        // smallest set (and half of it: smallest average pre-group) that takes the split-key search (default 32768; tests lower it)
     OPT_MSA2_TIGHT_PROFILES,  // spec v2: first-pass profile capacity of 2 read lengths whatever the group size (tests of the second pass with exact capacity)
+    OPT_UMI_SCAN_SINGLE,      // split-key search: one candidate column per lane also where two fit (A/B of k_sk_scan_pk)
     OPT_N
 };
 int option(Opt o);

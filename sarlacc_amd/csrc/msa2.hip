@@ -1368,9 +1368,9 @@ static int m2_prepare(M2Batch& B, const std::string& pf, const uint8_t* d_seq, d
     Context& c = ctx();
     const size_t ng = B.groups.size(), nm = B.members.size();
     if (ng == 0) return 0;
-    long long map_n = 0, col_n = 0, pos_n = 0, dist_n = 0;
+    long long map_n = 0, col_n = 0, pos_n = 0;
     for (const M2Member& Me : B.members) col_n += Me.len;
-    for (const M2Group& G : B.groups) { pos_n += static_cast<long long>(G.n) * G.wcap; dist_n += static_cast<long long>(G.n) * G.n + G.n; }
+    for (const M2Group& G : B.groups) pos_n += static_cast<long long>(G.n) * G.wcap;
     if (!B.members.empty()) { const M2Member& L = B.members.back(); const M2Group& G = B.groups[B.member_group.back()]; map_n = L.map_base + static_cast<long long>(std::max(0, G.n - 1)) * L.len; }
     M2Args& a = B.a;
     a = M2Args{};

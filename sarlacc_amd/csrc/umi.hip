@@ -907,7 +907,7 @@ __global__ void __launch_bounds__(SK_COLS) k_sk_scan(const SkScanArgs A) {
         if (((rmeta >> 6) & 1u) || la < A.len_lo || la > A.len_hi) continue;
         if (rrank < A.row_lo || rrank >= A.row_hi) continue;
         const uint32_t tlo = __builtin_amdgcn_readfirstlane(R.plo), thi = __builtin_amdgcn_readfirstlane(R.phi);
-        uint32_t Pv = pat, Mv = 0u, HP = 0u, HM = 0u;
+        uint32_t Pv = pat, Mv = 0u;
         for (int j = 0; j < la; ++j) {
             const uint32_t m0 = 0u - ((tlo >> j) & 1u), m1 = 0u - ((thi >> j) & 1u);
             const uint32_t Eq = ~((pl ^ m0) | (ph ^ m1)) & pat;
@@ -915,14 +915,13 @@ __global__ void __launch_bounds__(SK_COLS) k_sk_scan(const SkScanArgs A) {
             const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
             uint32_t Ph = Mv | ~(Xh | Pv);
             uint32_t Mh = Pv & Xh;
-            HP = __builtin_amdgcn_alignbit(HP, Ph, 31);
-            HM = __builtin_amdgcn_alignbit(HM, Mh, 31);
             Ph = (Ph << 1) | low;
             Mh <<= 1;
             Pv = Mh | ~(Xv | Ph);
             Mv = Ph & Xv;
         }
-        const int d = lb + __popc(HP) - __popc(HM);
+        // D[lb][la] = D[0][la] + the vertical deltas down the last column (row 0 of a global alignment holds j)
+        const int d = la + __popc(Pv & pat) - __popc(Mv & pat);
         bool hit = valid && d <= A.limit && e.rank > rrank;   // a pair is reported from its lower-ranked member
         if (SUFFIX) hit = hit && !sk_prefix_within(rmeta >> 8, cfwd, lb, A.h, A.k1);
         const unsigned long long ball = __ballot(hit);
@@ -933,6 +932,109 @@ __global__ void __launch_bounds__(SK_COLS) k_sk_scan(const SkScanArgs A) {
                 flush(64);
                 const unsigned long long moved = (64 + lane < nq) ? q[64 + lane] : 0ull;
                 if (64 + lane < nq) q[lane] = moved;
+                nq -= 64;
+            }
+        }
+    }
+    if (nq) flush(nq);
+}
+
+// The same scan with TWO candidate columns per lane, for the rows of up to 15 - limit bases (12-base UMIs; a string of 16
+// and more bases is no neighbour of such a row whatever it holds, so those columns are not valid here):
+// the two patterns sit top-aligned in the halves of one 32-bit word, so every operation of the recurrence advances both.
+// What crosses from the lower half into the upper one lands on bits below the upper pattern: the carry of the addition
+// (bit 16 holds no pattern bit as long as the upper string has at most 15 bases, and nothing is added there, so it goes no
+// further), the top bit of Ph << 1 (overwritten by `low`, the row-0 deltas) and the top bit of Mh << 1 (masked out).
+// Work items, candidate ranges and the pairs reported are those of k_sk_scan; half the threads per item.
+template <bool SUFFIX>
+__global__ void __launch_bounds__(SK_COLS / 2) k_sk_scan_pk(const SkScanArgs A) {
+    __shared__ int2 s_rng[SK_MAXR];
+    __shared__ unsigned long long s_q[SK_COLS / 128][192];
+    __shared__ SkElem s_rows[SK_ROWS];
+    const int t = threadIdx.x, lane = t & 63;
+    const long long item = static_cast<long long>(blockIdx.x) * A.item_stride;
+    int g = 0;
+    {
+        int lo = 0, hi = A.nrg;   // item_off[lo] <= item < item_off[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (A.item_off[mid] <= item) lo = mid; else hi = mid; }
+        g = lo;
+    }
+    const int r0g = A.rg_start[g], r1g = A.rg_start[g + 1];
+    const int C = A.ctotal[g], ncc = (C + SK_COLS - 1) / SK_COLS;
+    const long long local = item - A.item_off[g];
+    const int rc = static_cast<int>(local / ncc), cc = static_cast<int>(local % ncc);
+    const int r0 = r0g + rc * SK_ROWS, r1 = min(r0 + SK_ROWS, r1g);
+    const int nr = A.nranges[g];
+    if (t < nr) s_rng[t] = A.ranges[static_cast<long long>(g) * SK_MAXR + t];
+    for (int q = t; q < r1 - r0; q += SK_COLS / 2) s_rows[q] = A.el[r0 + q];
+    __syncthreads();
+    auto column = [&](int vc) -> int {
+        if (vc >= C) return -1;
+        int a = 0, b = nr;
+        while (b - a > 1) { const int m = (a + b) >> 1; if (s_rng[m].y <= vc) a = m; else b = m; }
+        return s_rng[a].x + (vc - s_rng[a].y);
+    };
+    const int col0 = column(cc * SK_COLS + t), col1 = column(cc * SK_COLS + SK_COLS / 2 + t);
+    const SkElem none{0u, 0u, 1u | (1u << 6), 0u};
+    const SkElem e0 = col0 >= 0 ? A.el[col0] : none, e1 = col1 >= 0 ? A.el[col1] : none;
+    const int lb0 = e0.meta & 63, lb1 = e1.meta & 63;
+    const bool valid0 = col0 >= 0 && !((e0.meta >> 6) & 1u) && lb0 < 16, valid1 = col1 >= 0 && !((e1.meta >> 6) & 1u) && lb1 < 16;
+    const int sh0 = 16 - (valid0 ? lb0 : 1), sh1 = 16 - (valid1 ? lb1 : 1);
+    const uint32_t F = 0xFFFFu;
+    const uint32_t pl = ((e0.plo << sh0) & F) | (((e1.plo << sh1) & F) << 16), ph = ((e0.phi << sh0) & F) | (((e1.phi << sh1) & F) << 16);
+    const uint32_t pat = ((F << sh0) & F) | (((F << sh1) & F) << 16);
+    const uint32_t low = ((2u << sh0) - 1u) | (((2u << sh1) - 1u) << 16), keep = ~low;
+    const uint32_t cfwd0 = e0.meta >> 8, cfwd1 = e1.meta >> 8;
+    unsigned long long* const q = s_q[t >> 6];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int nq = 0;
+    auto flush = [&](int count) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(A.count, static_cast<unsigned long long>(count));
+        base = (static_cast<unsigned long long>(__shfl(static_cast<int>(base >> 32), 0)) << 32) | static_cast<unsigned>(__shfl(static_cast<int>(base), 0));
+        if (lane < count && base + lane < A.cap) A.edges[base + lane] = q[lane];
+    };
+    for (int r = r0; r < r1; ++r) {
+        const SkElem R = s_rows[r - r0];   // the same address in every lane: one broadcast read
+        const uint32_t rmeta = __builtin_amdgcn_readfirstlane(R.meta);
+        const uint32_t rrank = __builtin_amdgcn_readfirstlane(R.rank);
+        const int la = rmeta & 63;
+        if (((rmeta >> 6) & 1u) || la < A.len_lo || la > A.len_hi) continue;
+        if (rrank < A.row_lo || rrank >= A.row_hi) continue;
+        const uint32_t tlo = __builtin_amdgcn_readfirstlane(R.plo), thi = __builtin_amdgcn_readfirstlane(R.phi);
+        uint32_t Pv = pat, Mv = 0u;
+        for (int j = 0; j < la; ++j) {
+            const uint32_t m0 = 0u - ((tlo >> j) & 1u), m1 = 0u - ((thi >> j) & 1u);
+            const uint32_t Eq = ~((pl ^ m0) | (ph ^ m1)) & pat;
+            const uint32_t Xv = Eq | Mv;
+            const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            uint32_t Ph = Mv | ~(Xh | Pv);
+            uint32_t Mh = Pv & Xh;
+            Ph = (Ph << 1) | low;
+            Mh = (Mh << 1) & keep;
+            Pv = Mh | ~(Xv | Ph);
+            Mv = Ph & Xv;
+        }
+        const uint32_t pv = Pv & pat, mv = Mv & pat;
+        const int d0 = la + __popc(pv & F) - __popc(mv & F), d1 = la + __popc(pv >> 16) - __popc(mv >> 16);
+        bool hit0 = valid0 && d0 <= A.limit && e0.rank > rrank;   // a pair is reported from its lower-ranked member
+        bool hit1 = valid1 && d1 <= A.limit && e1.rank > rrank;
+        if (SUFFIX) {
+            hit0 = hit0 && !sk_prefix_within(rmeta >> 8, cfwd0, lb0, A.h, A.k1);
+            hit1 = hit1 && !sk_prefix_within(rmeta >> 8, cfwd1, lb1, A.h, A.k1);
+        }
+        const unsigned long long ball0 = __ballot(hit0), ball1 = __ballot(hit1);
+        if (ball0 | ball1) {
+            if (hit0) q[nq + __popcll(ball0 & lt)] = (static_cast<unsigned long long>(rrank) << 32) | e0.rank;
+            nq += __popcll(ball0);
+            if (hit1) q[nq + __popcll(ball1 & lt)] = (static_cast<unsigned long long>(rrank) << 32) | e1.rank;
+            nq += __popcll(ball1);
+            while (nq >= 64) {
+                flush(64);
+                for (int k = 64; k < nq; k += 64) {
+                    const unsigned long long moved = (k + lane < nq) ? q[k + lane] : 0ull;
+                    if (k + lane < nq) q[k - 64 + lane] = moved;
+                }
                 nq -= 64;
             }
         }
@@ -1692,6 +1794,7 @@ static int sk_build(const std::string& p, const SortedUmis& S, const SkPlan& pla
 static long long sk_launch(const std::vector<SkScan>& F, const std::vector<SkScan>& R, const SkPlan& plan, int limit, uint32_t row_lo, uint32_t row_hi,
                            unsigned stride, unsigned long long* edges, unsigned long long* count, unsigned long long cap, hipStream_t s) {
     long long items = 0;
+    ctx().counts["umi_scan_two_columns"] = 0;   // launches of k_sk_scan_pk
     for (const SkClass& c : plan.classes)
         for (int pass = 0; pass < 2; ++pass) {
             const SkScan* Q = nullptr;
@@ -1702,7 +1805,14 @@ static long long sk_launch(const std::vector<SkScan>& F, const std::vector<SkSca
             items += Q->nitems;
             SkScanArgs a{Q->O.el, Q->rg_start, Q->nrg, Q->ranges, Q->nranges, Q->ctotal, Q->item_off, stride, limit, c.h, plan.k1,
                          c.len_lo, c.len_hi, row_lo, row_hi, edges, count, cap};
-            if (pass) hipLaunchKernelGGL(k_sk_scan<true>, dim3(static_cast<unsigned>(blocks)), dim3(SK_COLS), 0, s, a);
+            // two candidate columns per lane for the rows no string of 16 and more bases can be a neighbour of (the lengths of
+            // neighbours differ by `limit` at most; such columns are simply not valid there)
+            const bool two = c.len_hi + limit < 16 && !option(OPT_UMI_SCAN_SINGLE);
+            if (two) ctx().counts["umi_scan_two_columns"] += 1;
+            if (two) {
+                if (pass) hipLaunchKernelGGL(k_sk_scan_pk<true>, dim3(static_cast<unsigned>(blocks)), dim3(SK_COLS / 2), 0, s, a);
+                else hipLaunchKernelGGL(k_sk_scan_pk<false>, dim3(static_cast<unsigned>(blocks)), dim3(SK_COLS / 2), 0, s, a);
+            } else if (pass) hipLaunchKernelGGL(k_sk_scan<true>, dim3(static_cast<unsigned>(blocks)), dim3(SK_COLS), 0, s, a);
             else hipLaunchKernelGGL(k_sk_scan<false>, dim3(static_cast<unsigned>(blocks)), dim3(SK_COLS), 0, s, a);
         }
     return items;

@@ -257,9 +257,16 @@ def test_split_key_search_small_sets(oracle, lo, hi, n_rate, short, split):
         for rep in range(3):
             umis = noisy_umis(rng, 150, lo, hi, n_rate, short)
             for t in (1, 2, 3):
-                got = calls.fast_levdist_test(umis, t)
-                assert _lib.stage_count("umi_split_search") == split
-                same_lists(got, oracle.fast_levdist_test(umis, t))
+                want = oracle.fast_levdist_test(umis, t)
+                for single in (0, 1):   # two candidate columns per lane where every string is shorter than 16 bases, and one
+                    calls.set_option("umi_scan_single", single)
+                    got = calls.fast_levdist_test(umis, t)
+                    assert _lib.stage_count("umi_split_search") == split
+                    if split:
+                        # (the rows of up to 15 - t bases scan two columns per lane)
+                        assert (_lib.stage_count("umi_scan_two_columns") > 0) == (any(8 <= len(u) <= 15 - t for u in umis) and not single)
+                    same_lists(got, want)
+                calls.set_option("umi_scan_single", 0)
             n = len(umis)
             pre = rng.integers(0, 2, n)
             for groups in ([list(range(1, n + 1))], [(np.flatnonzero(pre == g) + 1).tolist() for g in range(2)]):
@@ -273,6 +280,7 @@ def test_split_key_search_small_sets(oracle, lo, hi, n_rate, short, split):
                     same_lists(calls.umi_group(umis, t, None, t, groups), want)
     finally:
         calls.set_option("umi_split_min", 0)
+        calls.set_option("umi_scan_single", 0)
 
 
 @pytest.mark.parametrize("threshold,n", [(1, 100000), (2, 100000), (3, 40000)])
