@@ -833,6 +833,236 @@ __global__ void k_align_emptyref(const int64_t* off, long long n, int local, dou
 }
 
 // ---------------------------------------------------------------------------
+// References of more than MAX_REF columns (qualityAlign against a transcript or a genomic
+// region, src/general_align.cpp:12-16; src/reference_align.cpp:7-13 takes any length).
+// k_align keeps one alignment inside a wavefront (at most 64 lanes x 16 columns); here ONE
+// WORKGROUP holds the alignment: thread t owns K consecutive columns, threads are skewed by one
+// read row exactly as k_align's lanes are, and the row state (score of the column to the left,
+// "that cell was a horizontal gap", running horizontal jump score) goes to the next thread
+// through a double-buffered LDS slot, one barrier per step.  The recurrence is the reference's
+// statement for statement (explicit penalty selects, strict >, src/reference_align.cpp:108-181),
+// fp64, -ffp-contract=off.  Traceback: 4 bits per cell -- move (0 diagonal, 1 horizontal,
+// 2 vertical) + "horizontal jump continued here" + "vertical jump continued here" -- one word per
+// thread and step, stored by step so that a step's words are contiguous; the jump LENGTHS the
+// reference stores (:131,147) are 1 + the run of continued flags that ends in the cell, and the
+// walk (thread 0) counts them.  Read positions are staged WIDE_CH rows at a time into an LDS
+// ring as (base code * row bytes + quality * 8), the byte offset inside a column's cost rows.
+constexpr int WIDE_CH = 512;      // rows staged per refill
+constexpr int WIDE_RING = 2048;   // ring entries (> WIDE_CH + 1024 threads)
+constexpr int WIDE_MAXT = 1024;
+
+template <int K>
+struct WideWord { using type = uint32_t; };
+template <>
+struct WideWord<16> { using type = unsigned long long; };
+
+// MODE 0 scores, 1 scores + map + sections, 2 scores + strings + edit distance
+template <int K, int MODE>
+__global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
+    using Word = typename WideWord<K>::type;
+    extern __shared__ __align__(16) unsigned char w_smem[];
+    const int T = static_cast<int>(blockDim.x);
+    const int t = static_cast<int>(threadIdx.x);
+    const int R = A.R;
+    double* const s_tab = reinterpret_cast<double*>(w_smem);
+    double* const h_s = s_tab + A.tab_doubles;                        // [2][T] score handed to the next thread
+    double* const h_lj = h_s + 2 * T;                                 // [2][T] running horizontal jump score
+    int* const h_fl = reinterpret_cast<int*>(h_lj + 2 * T);           // [2][T] the cell was a horizontal gap
+    uint16_t* const s_ring = reinterpret_cast<uint16_t*>(h_fl + 2 * T);   // [WIDE_RING]
+    for (int e = t; e < A.tab_doubles; e += T) s_tab[e] = A.tables[e];
+    const double NEG_INF = -__builtin_huge_val();
+    const double GO = A.GO, GE = A.GE;
+    const bool local = A.local != 0;
+    int cb[K];
+    double rz[K], rzl[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int col = min(t * K + k + 1, R);
+        cb[k] = static_cast<int>(A.colbase[col]);
+        rz[k] = A.rowzero[col];
+        rzl[k] = A.rowzero[col - 1];
+    }
+    const int ncolv = max(0, min(K, R - t * K));   // this thread's columns inside the reference
+    const int tR = (R - 1) / K, kR = (R - 1) % K;
+    const long long Rw = T;                        // words per step
+    Word* const dirs = MODE ? reinterpret_cast<Word*>(A.dirs) + static_cast<size_t>(blockIdx.x) * A.dirs_per_wave : nullptr;
+    for (long long read = blockIdx.x; read < A.n; read += gridDim.x) {
+        __syncthreads();
+        const long long start = A.off[read];
+        const int L = static_cast<int>(A.off[read + 1] - start);
+        double Sc[K], Dg[K], UJ[K];
+        unsigned upneg = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { Sc[k] = rz[k]; Dg[k] = rzl[k]; UJ[k] = NEG_INF; }
+        const int nsteps = L > 0 ? L + tR : 0;   // thread tR finishes row L at step L + tR
+        for (int s = 1; s <= nsteps; ++s) {
+            if ((s - 1) % WIDE_CH == 0) {   // rows s .. s + WIDE_CH - 1 into the ring (thread 0 needs row s now)
+                for (int e = t; e < WIDE_CH; e += T) {
+                    const int row = s + e;
+                    uint32_t ent = 0;
+                    if (row <= L) {
+                        const long long idx = start + row - 1;
+                        int qi = static_cast<int>(static_cast<signed char>(A.qual[idx])) - A.qoffset;
+                        if (qi < 0) atomicMin(A.badqual, A.read_base + static_cast<int>(read));
+                        qi = qi < 0 ? 0 : (qi >= A.navail ? A.navail - 1 : qi);
+                        uint32_t code;
+                        if (A.nmask) {
+                            code = ((A.nmask[idx >> 3] >> (idx & 7)) & 1u) ? 4u : ((A.seq[idx >> 2] >> ((idx & 3) * 2)) & 3u);
+                        } else {
+                            const uint32_t b = A.seq[idx];
+                            code = b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u;
+                        }
+                        ent = code * static_cast<uint32_t>(A.row_bytes) + static_cast<uint32_t>(qi << 3);
+                    }
+                    s_ring[row & (WIDE_RING - 1)] = static_cast<uint16_t>(ent);
+                }
+                __syncthreads();
+            }
+            const int i = s - t;
+            const int par = s & 1;
+            if (i >= 1 && i <= L && ncolv > 0) {
+                double ls, lj;
+                bool lpos;
+                if (t == 0) {   // DP column 0 (src/reference_align.cpp:63-78)
+                    ls = local ? 0.0 : (-GO - GE * static_cast<double>(i - 1));
+                    lj = NEG_INF;
+                    lpos = false;
+                } else {
+                    ls = h_s[(par ^ 1) * T + t - 1];
+                    lj = h_lj[(par ^ 1) * T + t - 1];
+                    lpos = h_fl[(par ^ 1) * T + t - 1] != 0;
+                }
+                const int ent = s_ring[i & (WIDE_RING - 1)];
+                Word w = 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (k < ncolv) {
+                        const bool lastcol = local && (t * K + k + 1 == R);   // free vertical gaps in the last column (:93)
+                        double horiz = ls - (lpos ? GE : GO);
+                        lj -= GE;
+                        const bool hc = lj > horiz;
+                        if (hc) horiz = lj; else lj = horiz;
+                        const double vgo = lastcol ? 0.0 : GO, vge = lastcol ? 0.0 : GE;
+                        double vert = Sc[k] - (((upneg >> k) & 1u) ? vge : vgo);
+                        double uj = UJ[k] - vge;
+                        const bool vc = uj > vert;
+                        if (vc) vert = uj; else uj = vert;
+                        UJ[k] = uj;
+                        const double cost = *reinterpret_cast<const double*>(reinterpret_cast<const unsigned char*>(s_tab) + cb[k] + ent);
+                        const double match = Dg[k] + cost;
+                        Dg[k] = ls;
+                        unsigned kind;
+                        double cur;
+                        if (match > horiz && match > vert) { cur = match; kind = 0u; }
+                        else if (horiz > vert) { cur = horiz; kind = 1u; }
+                        else { cur = vert; kind = 2u; }
+                        Sc[k] = cur;
+                        upneg = (upneg & ~(1u << k)) | ((kind == 2u ? 1u : 0u) << k);
+                        ls = cur;
+                        lpos = kind == 1u;
+                        if (MODE) w |= static_cast<Word>(kind | (hc ? 4u : 0u) | (vc ? 8u : 0u)) << (4 * k);
+                    }
+                }
+                h_s[par * T + t] = ls;
+                h_lj[par * T + t] = lj;
+                h_fl[par * T + t] = lpos ? 1 : 0;
+                if (MODE) __builtin_nontemporal_store(w, &dirs[static_cast<long long>(s) * Rw + t]);
+            }
+            __syncthreads();
+        }
+        if (t == tR) {
+            double sc = Sc[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) sc = (k == kR) ? Sc[k] : sc;
+            if (L == 0) sc = A.rowzero[R];   // no rows: row 0 of the last column (:115-118)
+            A.scores[read] = sc;
+        }
+        if (MODE) {
+            __threadfence();
+            __syncthreads();
+            if (t == 0) {
+                auto nibble = [&](int c, int row) -> unsigned {   // 1 <= c <= R, 1 <= row <= L
+                    const int tt = (c - 1) / K, kk = (c - 1) % K;
+                    const Word w = dirs[static_cast<long long>(row + tt) * Rw + tt];
+                    return static_cast<unsigned>(w >> (4 * kk)) & 15u;
+                };
+                // direction value the reference stores at (row, c): 0 diagonal, +length horizontal, -length vertical
+                auto loadD = [&](int c, int row) -> int {
+                    if (row <= 0) return 1;   // D[c][0] = 1 (:118)
+                    const unsigned nb = nibble(c, row);
+                    if ((nb & 3u) == 0u) return 0;
+                    int len = 1;
+                    if ((nb & 3u) == 1u) {
+                        unsigned f = nb;
+                        for (int x = c; (f & 4u) && x > 1;) { ++len; --x; f = nibble(x, row); }
+                        return len;
+                    }
+                    unsigned f = nb;
+                    for (int y = row; (f & 8u) && y > 1;) { ++len; --y; f = nibble(c, y); }
+                    return -len;
+                };
+                int row = L, c = R;
+                if (MODE == 1) {
+                    const unsigned long long map_words = (static_cast<unsigned long long>(R + 1) * 4 + sizeof(Word) - 1) / sizeof(Word);
+                    int32_t* const map = reinterpret_cast<int32_t*>(dirs + (A.dirs_per_wave - map_words));   // (behind the codes)
+                    while (c > 0) {
+                        int d = loadD(c, row);
+                        while (row > 0 && d < 0) { row += d; d = loadD(c, row); }
+                        if (d == 0) { map[c] = row * 2 + 1; --row; --c; }
+                        else { for (int x = 0; x < d && c > 0; ++x) { map[c] = (row + 1) * 2; --c; } }
+                    }
+                    auto interval = [&](int a, int b, bool gaps, unsigned& st, unsigned& en) {   // (:307-351), size_t wrap kept via unsigned
+                        if (!gaps) {
+                            st = map[a + 1] >> 1;
+                            en = (map[b] >> 1) + (map[b] & 1);
+                        } else {
+                            st = (a == 0) ? 1u : static_cast<unsigned>((map[a] >> 1) + (map[a] & 1));
+                            en = (b + 1 == R + 1) ? static_cast<unsigned>(L + 1) : static_cast<unsigned>(map[b + 1] >> 1);
+                        }
+                        st -= 1;
+                        en -= 1;
+                    };
+                    unsigned st, en;
+                    interval(0, R, false, st, en);
+                    const bool nonempty = st < en;
+                    A.starts[read] = nonempty ? static_cast<int32_t>(st + 1) : 0;
+                    A.ends[read] = nonempty ? static_cast<int32_t>(en) : 0;
+                    for (int x = 0; x < A.nsec; ++x) {
+                        interval(A.sec_s[x], A.sec_e[x], true, st, en);
+                        A.sec_so[static_cast<long long>(x) * A.sec_stride + read] = static_cast<int32_t>(st + 1);
+                        A.sec_wo[static_cast<long long>(x) * A.sec_stride + read] = static_cast<int32_t>(en - st);
+                    }
+                } else {   // gapped strings, emitted from the end (:353-389)
+                    const long long base = start + read * static_cast<long long>(R);
+                    uint8_t* const oref = A.aln_ref + base;
+                    uint8_t* const oqry = A.aln_qry + base;
+                    const uint8_t* const sq = A.seq + start;
+                    int m = 0, ed = 0;
+                    while (c > 0) {
+                        int d = loadD(c, row);
+                        while (row > 0 && d < 0) {
+                            for (int x = 0; x < -d; ++x) { oref[m] = '-'; oqry[m] = sq[row - 1]; ++m; ++ed; --row; }
+                            d = loadD(c, row);
+                        }
+                        if (d == 0) {
+                            const uint8_t rc = A.refchars[c - 1], qc = sq[row - 1];
+                            oref[m] = rc; oqry[m] = qc; ++m;
+                            ed += rc != qc;
+                            --row; --c;
+                        } else {
+                            for (int x = 0; x < d && c > 0; ++x) { oref[m] = A.refchars[c - 1]; oqry[m] = '-'; ++m; ++ed; --c; }
+                        }
+                    }
+                    while (row > 0) { oref[m] = '-'; oqry[m] = sq[row - 1]; ++m; ++ed; --row; }
+                    A.aln_len[read] = m;
+                    A.edits[read] = ed;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 
 // Per-column lookup info: which fp64 table a column reads, decided by the
@@ -997,6 +1227,36 @@ struct AlignOut {
     int32_t* d_edits = nullptr;
 };
 
+// References beyond MAX_REF columns: one workgroup per alignment (k_align_wide).  `a` is complete except for the scratch.
+static int launch_wide(AlignArgs& a, int R, int kernel_mode, int32_t max_len, long long n, hipStream_t stream) {
+    Context& c = ctx();
+    const int K = R <= 8 * WIDE_MAXT ? 8 : 16;
+    if ((R + K - 1) / K > WIDE_MAXT) return fail("sarlacc_amd: reference longer than %d columns is not supported", 16 * WIDE_MAXT);
+    if (kernel_mode == 2 && a.nmask) return fail("sarlacc_amd: alignment strings need ASCII reads");
+    const int T = ((R + K - 1) / K + 63) / 64 * 64;
+    const size_t word = K == 16 ? 8 : 4;
+    size_t per_wg = 0;   // words: codes of every step, then the reference -> read map
+    if (kernel_mode) per_wg = (static_cast<size_t>(max_len) + T + 1) * T + ((static_cast<size_t>(R) + 1) * 4 + word - 1) / word;
+    long long grid = std::min<long long>(n, static_cast<long long>(c.num_cu) * std::max(1, 2048 / T));
+    if (kernel_mode) {
+        const size_t budget = static_cast<size_t>(16) << 30;
+        grid = std::min(grid, std::max<long long>(1, static_cast<long long>(budget / (per_wg * word))));
+    }
+    void* d_dirs = nullptr;
+    if (kernel_mode) SL_TRY(c.buffer("align.dirs", static_cast<size_t>(grid) * per_wg * word, &d_dirs));
+    a.dirs = d_dirs;
+    a.dirs_per_wave = per_wg;
+    const size_t lds = sizeof(double) * a.tab_doubles + static_cast<size_t>(T) * (2 * 8 + 2 * 8 + 2 * 4) + WIDE_RING * sizeof(uint16_t);
+    if (lds > 64 * 1024) return fail("sarlacc_amd: alignment tables do not fit in LDS");
+    const dim3 g(static_cast<unsigned>(grid)), b(static_cast<unsigned>(T));
+#define WIDE_LAUNCH(KK, MM) hipLaunchKernelGGL((k_align_wide<KK, MM>), g, b, lds, stream, a)
+    if (K == 8) { if (kernel_mode == 0) WIDE_LAUNCH(8, 0); else if (kernel_mode == 1) WIDE_LAUNCH(8, 1); else WIDE_LAUNCH(8, 2); }
+    else { if (kernel_mode == 0) WIDE_LAUNCH(16, 0); else if (kernel_mode == 1) WIDE_LAUNCH(16, 1); else WIDE_LAUNCH(16, 2); }
+#undef WIDE_LAUNCH
+    SL_HIP(hipGetLastError());
+    return 0;
+}
+
 // kernel_mode: 0 scores, 1 map, 2 strings.  Returns in *bad_qual_read the smallest
 // index of a read with a quality character below the encoding offset (or INT_MAX).
 // A host call may hand its batch over in chunks so that the upload of chunk k+1 overlaps the
@@ -1016,7 +1276,7 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     Context& c = ctx();
     if (co.init_bad) *bad_qual_read = std::numeric_limits<int>::max();
     if (n <= 0) return 0;
-    if (R > MAX_REF) return fail("sarlacc_amd: reference longer than %d columns is not supported", MAX_REF);
+    const bool wide = R > MAX_REF;   // one workgroup per alignment instead of (a part of) one wavefront
     if (enc_n > 256) return fail("sarlacc_amd: encoding vector longer than 256 entries");
     if (n > std::numeric_limits<int>::max() - 8) return fail("sarlacc_amd: more than 2^31 reads in one call");
     const double GO = gapopen + gapext, GE = gapext;  // (src/reference_align.cpp:8)
@@ -1077,7 +1337,7 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
     // gapopen >= 0 (GO >= GE): no penalty selects on the device, see k_align
     bool pensel = !(GO >= GE);
     pensel = pensel || option(OPT_ALIGN_PENSEL) != 0;  // testing: force the general path
-    Shape sh = pick_shape(R);
+    Shape sh = wide ? Shape{1, 64, 1, 0} : pick_shape(R);
     // interleaved alignments exist for the local modes without penalty selects (adaptor_align by snapshots, score-only);
     // align_interleave = -1: the A/B without them
     const bool il_mode = local && !pensel && (kernel_mode == 0 || kernel_mode == 1);
@@ -1120,7 +1380,7 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
         grid = std::min(grid, fit);
     }
     void* d_dirs = nullptr;
-    if (kernel_mode) SL_TRY(c.buffer("align.dirs", static_cast<size_t>(grid) * NWAVES * per_wave_elems * word_bytes, &d_dirs));
+    if (kernel_mode && !wide) SL_TRY(c.buffer("align.dirs", static_cast<size_t>(grid) * NWAVES * per_wave_elems * word_bytes, &d_dirs));
 
     a.seq = d_seq; a.nmask = d_nmask; a.qual = d_qual; a.off = d_off; a.n = n;
     a.R = R; a.W = sh.W; a.ngroups = sh.ngroups; a.local = local ? 1 : 0;
@@ -1137,9 +1397,10 @@ static int run_align(const uint8_t* d_seq, const uint8_t* d_nmask, const uint8_t
 
     const size_t lds = sizeof(uint16_t) * NWAVES * (sh.rowf == 2 ? NGMAX2 * (RING + RING_MIRROR) : NGMAX * RING_SLOT) + sizeof(double) * rows.size() +
                        sizeof(int32_t) * NWAVES * sh.ngroups * (R + 1) + 16;
-    if (lds > 64 * 1024) return fail("sarlacc_amd: alignment tables do not fit in LDS");
+    if (!wide && lds > 64 * 1024) return fail("sarlacc_amd: alignment tables do not fit in LDS");
     SL_HIP(hipEventRecord(c.ev_start, stream));
-    SL_TRY(launch_k(sh.K, sh.rowf, R, pensel, kernel_mode, local, a, static_cast<int>(grid), lds, stream));
+    if (wide) SL_TRY(launch_wide(a, R, kernel_mode == 3 ? 1 : kernel_mode, max_len, n, stream));
+    else SL_TRY(launch_k(sh.K, sh.rowf, R, pensel, kernel_mode, local, a, static_cast<int>(grid), lds, stream));
     SL_HIP(hipEventRecord(c.ev_stop, stream));
     c.timed = true;
 

@@ -286,6 +286,52 @@ def test_general_align(oracle, oenc, enc):
     assert np.array_equal(bits(a[0]), bits(b[0])) and a[2] == b[2] and a[3] == b[3] and np.array_equal(a[1], b[1])
 
 
+def _mutate(rng, s, sub=0.05, indel=0.03):
+    out = []
+    for ch in s:
+        u = rng.random()
+        if u < indel / 2:
+            continue
+        if u < indel:
+            out.append("ACGT"[rng.integers(0, 4)])
+        out.append("ACGT"[rng.integers(0, 4)] if rng.random() < sub else ch)
+    return "".join(out)
+
+
+def test_references_beyond_1024_columns(oracle, oenc, enc):
+    """References longer than one wavefront's 64 x 16 columns (qualityAlign of consensus reads against a transcript:
+    R/qualityAlign.R:13-15, src/general_align.cpp:12-16; src/reference_align.cpp:7-13 takes any length) run with one
+    workgroup per alignment (k_align_wide): scores bit for bit, edit distances, gapped strings, and the adaptor-mode map
+    (starts, ends, sections) -- global and local, IUPAC columns, gap opening below zero, empty and short reads, and the
+    16-columns-per-thread class (references beyond 8 192 columns)."""
+    from sarlacc_amd import calls
+    rng = np.random.default_rng(1025)
+    nuc = list("ACGT")
+    for R, nreads, go in ((1025, 12, 5), (2000, 10, 5), (3000, 6, -0.5), (8200, 5, 5)):
+        ref = "".join(rng.choice(nuc, R))
+        if R == 2000:   # ambiguity codes in the reference (2-fold, 3-fold, N)
+            ref = ref[:100] + "RYNNB" + ref[105:1500] + "N" * 20 + ref[1520:]
+        core = ref.replace("R", "A").replace("Y", "C").replace("N", "G").replace("B", "T")
+        reads = [_mutate(rng, core) for _ in range(nreads - 3)]
+        reads += ["", core[:37], _mutate(rng, core[200:900])]
+        reads[0] = reads[0][:500] + "N" * 7 + reads[0][507:]
+        quals = rand_quals(reads, R, lo=40, hi=83)
+        a = oracle.general_align(reads, quals, oenc, go, 1, ref)
+        b = calls.general_align(reads, quals, enc, go, 1, ref, False)
+        assert np.array_equal(bits(a[0]), bits(b[0])), "scores differ (R = %d)" % R
+        assert np.array_equal(a[1], b[1]), "edit distances differ (R = %d)" % R
+        assert a[2] == b[2] and a[3] == b[3]
+        for r, q, read in zip(b[2], b[3], reads):
+            assert r.replace("-", "") == ref and q.replace("-", "") == read
+        c = calls.general_align(reads, quals, enc, go, 1, ref, True)
+        assert np.array_equal(a[1], c[1])
+        # global scores alone (barcode_align) and the local mode with its map (adaptor_align)
+        assert np.array_equal(bits(oracle.barcode_align(reads, quals, oenc, go, 1, ref)), bits(calls.barcode_align(reads, quals, enc, go, 1, ref)))
+        if R <= 3000:
+            long_reads = [rd + "".join(rng.choice(nuc, 300)) for rd in reads]
+            compare_adaptor(oracle, oenc, enc, long_reads, rand_quals(long_reads, R + 1, lo=40, hi=83), ref, go, 1, [10, 0, 1500 % R], [R - 5, 40, R])
+
+
 def test_error_behaviour(oracle, oenc, enc):
     from sarlacc_amd import SarlaccError, calls
     with pytest.raises(SarlaccError, match="same length"):
