@@ -486,6 +486,29 @@ def main():
                         "cells = window bases x adaptor length")
         out["generic_level"] = best
         del dev_reads
+    # qualityAlign-shaped call (R/qualityAlign.R:13-15 -> src/general_align.cpp): the batch's first reads, globally, against a
+    # reference as long as they are -- beyond the 1 024 columns one wavefront holds, so one workgroup per alignment (k_align_wide)
+    if rank == 0 and not args.no_host_pointer:
+        nq = min(n, 10000)
+        h_off = off[:nq + 1].cpu().numpy()
+        end = int(h_off[-1])
+        hs = StringSet(seq[:end].cpu().numpy(), h_off)
+        hq = StringSet(qual[:end].cpu().numpy(), h_off.copy())
+        rng_q = np.random.default_rng(2)
+        qref = np.frombuffer(b"ACGT", np.uint8)[rng_q.integers(0, 4, args.read_len)].tobytes().decode()
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            calls.general_align(hs, hq, enc, GAP_OPEN, GAP_EXT, qref, True)
+            dt = time.perf_counter() - t0
+            cur = {"seconds": dt, "kernel_ms": sarlacc_amd.last_kernel_ms()}
+            best = cur if best is None or cur["seconds"] < best["seconds"] else best
+        qcells = float(end) * args.read_len
+        out["quality_align_2kb"] = {"reads": nq, "reference_len": args.read_len, "seconds": best["seconds"], "kernel_ms": best["kernel_ms"],
+                                    "gcups": qcells / best["seconds"] / 1e9, "kernel_gcups": qcells / (best["kernel_ms"] * 1e-3) / 1e9,
+                                    "note": "sarlacc_general_align (edit distances, traceback of every alignment) on host buffers; "
+                                            "k_align_wide: one workgroup per alignment, thread = 8 reference columns"}
+        del hs, hq
     cpu_sample = None
     if rank == 0 and not args.no_cpu:
         # the GPU box gives a one-GPU job a share of 16 host cores (more threads than that only contend)

@@ -79,6 +79,47 @@ def case_align(rng):
             assert g[2] == o[2] and g[3] == o[3], "general strings"
 
 
+def case_align_wide(rng):
+    """References beyond 1 024 columns (k_align_wide: one workgroup per alignment): every mode, reads from empty to longer
+    than the reference, with and without a noisy copy of the reference inside."""
+    R = int(rng.choice([1025, 1030, 1088, 1500, 2047, 2048, 2049, 2600]))
+    n = int(rng.integers(1, 7))
+    ref = rstr(rng, R, IUPAC if rng.random() < 0.3 else "ACGT")
+    core = "".join(c if c in "ACGT" else "ACGT"[int(rng.integers(0, 4))] for c in ref)
+    reads = []
+    for _ in range(n):
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            reads.append(rstr(rng, int(rng.integers(0, 60)), "ACGTN"))
+        elif kind == 1:
+            lo = int(rng.integers(0, R - 200)); hi = int(rng.integers(lo + 1, R + 1))
+            reads.append("".join(c for c in core[lo:hi] if rng.random() > 0.03))
+        else:   # a noisy copy, sometimes with flanks
+            body = "".join(("ACGT"[int(rng.integers(0, 4))] if rng.random() < 0.06 else c) for c in core if rng.random() > 0.02)
+            reads.append(rstr(rng, int(rng.integers(0, 80)) * (kind == 3), "ACGT") + body + rstr(rng, int(rng.integers(0, 80)) * (kind == 3), "ACGT"))
+    quals = [rqual(rng, len(r), 40, int(rng.choice([75, 126]))) for r in reads]
+    go, ge = [(5, 1), (20, 1), (1, 1), (2.5, 0.75), (0, 1), (3, 0), (-1, 2), (-0.5, 0.5)][int(rng.integers(0, 8))]
+    g, o, err = both(lambda: calls.general_align(reads, quals, enc, go, ge, ref, False),
+                     lambda: O.general_align(reads, quals, oenc, go, ge, ref))
+    if not err:
+        assert np.array_equal(bits(g[0]), bits(o[0])) and np.array_equal(g[1], o[1]), "wide general scores/edits"
+        assert g[2] == o[2] and g[3] == o[3], "wide general strings"
+    nsec = int(rng.integers(0, 4))
+    ss = sorted(int(x) for x in rng.integers(0, R, nsec))
+    se = [int(rng.integers(s_, R) + 1) for s_ in ss]
+    g, o, err = both(lambda: calls.adaptor_align(reads, quals, enc, go, ge, ref, ss, se),
+                     lambda: O.adaptor_align(reads, quals, oenc, go, ge, ref, ss, se))
+    if not err:
+        assert np.array_equal(bits(g[0]), bits(o[0])), "wide adaptor scores"
+        assert np.array_equal(g[1], o[1]) and np.array_equal(g[2], o[2]), "wide adaptor positions"
+        for a, b in zip(g[3] + g[4], o[3] + o[4]):
+            assert np.array_equal(a, b), "wide sections"
+    g, o, err = both(lambda: calls.barcode_align(reads, quals, enc, go, ge, ref),
+                     lambda: O.barcode_align(reads, quals, oenc, go, ge, ref))
+    if not err:
+        assert np.array_equal(bits(g), bits(o)), "wide barcode scores"
+
+
 def umi_switches(rng):
     """Thresholds 2 and 3 through the split-key search also on small sets (half of the cases), dense graphs clustered
     by rounds over every list instead of candidate sets (a quarter)."""
@@ -390,7 +431,7 @@ if __name__ == "__main__":
     while time.time() - t0 < budget:
         seed = seed0 * 1_000_003 + k
         rng = np.random.default_rng(seed)
-        fn = case_umi_large if k % 97 == 96 else CASES[k % len(CASES)]
+        fn = case_umi_large if k % 97 == 96 else (case_align_wide if k % 41 == 40 else CASES[k % len(CASES)])
         try:
             fn(rng)
         except Exception:
