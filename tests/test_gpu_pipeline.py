@@ -72,6 +72,85 @@ def test_strand_flip_case(tmp_path):
     assert len(empty["read.width"]) == 0
 
 
+@pytest.mark.parametrize("tolerance", [250, 25])
+def test_adaptor_align_generic_follows_the_reference_tests_rule(tmp_path, tolerance):
+    """The check of the reference's own test of the generic (tests/testthat/test-adaptor-align.R:142-184), restated read by
+    read and WITHOUT generics.py's code: for every read of adaptorAlign's table, the oriented read (reverse-complemented if
+    `reversed`) aligned directly to adaptor 1 gives the row's score / start / end / UMI sub-sequence, its reverse complement
+    aligned to adaptor 2 gives the second row with coordinates flipped as width - x + 1 (:180-181); the orientation itself
+    follows .resolve_strand (R/adaptorAlign.R:112-122).  The direct alignments are single-read C-ABI calls on host strings
+    -- windows, reverse complements and coordinate flips are this test's own (the reference test uses Biostrings'
+    pairwiseAlignment there; tolerance 25 adds R/adaptorAlign.R:86-95's windows, which that test never reaches)."""
+    import sarlacc_amd
+    from sarlacc_amd import calls, generics
+    from sarlacc_amd.mock import revcomp
+    enc = sarlacc_amd.phred_encoding()
+    a1, a2 = "ACGATCAGCTAGNNNNNCGACTAGCTAGCTAG", "CACACTGAGCAGCGACTAGA"
+    rng = np.random.default_rng(141002)
+    nuc = list("ACGT")
+    reads = []
+    for i in range(60):
+        body = "".join(rng.choice(nuc, int(rng.integers(20, 81))))
+        if i % 3 == 1:     # the adaptors where the protocol puts them ...
+            body = a1.replace("N", "A")[:int(rng.integers(20, 33))] + body + revcomp(a2)
+        if i % 6 == 4:     # ... and on the other strand
+            body = revcomp(body)
+        reads.append(body)
+    quals = ["".join(chr(33 + int(q)) for q in np.round(10 * rng.uniform(1, 5, len(r)))) for r in reads]
+    path = str(tmp_path / "r.fastq")
+    generics.write_fastq(path, generics.Reads(reads, quals, ["READ_%d" % (i + 1) for i in range(len(reads))]))
+    out = generics.adaptorAlign(a1, a2, path, tolerance=tolerance)
+    ss, se = [12], [17]    # the run of N in adaptor 1: 0-based start, 1-based end (.setup_subseqs, subseq.starts - 1L)
+
+    def direct(adaptor, seq, qual, sec_s=(), sec_e=()):
+        r = calls.adaptor_align([seq], [qual], enc, 5, 1, adaptor, list(sec_s), list(sec_e))
+        sub = [seq[int(s[0]) - 1:int(s[0]) - 1 + int(w[0])] for s, w in zip(r[3], r[4])]
+        return float(r[0][0]), int(r[1][0]), int(r[2][0]), sub
+
+    assert out["read.width"].tolist() == [len(r) for r in reads]
+    n_rev = 0
+    for i, (r, q) in enumerate(zip(reads, quals)):
+        tol = min(tolerance, len(r))
+        front, qfront = r[:tol], q[:tol]
+        back, qback = revcomp(r[len(r) - tol:]), q[len(r) - tol:][::-1]
+        f = max(direct(a1, front, qfront)[0], 0) + max(direct(a2, back, qback)[0], 0)
+        b = max(direct(a1, back, qback)[0], 0) + max(direct(a2, front, qfront)[0], 0)
+        assert bool(out["reversed"][i]) == (f < b)
+        n_rev += f < b
+        query, qquery = (revcomp(r), q[::-1]) if out["reversed"][i] else (r, q)
+        s1, st1, en1, sub1 = direct(a1, query[:tol], qquery[:tol], ss, se)
+        assert out["adaptor1"]["score"][i] == s1 and out["adaptor1"]["start"][i] == st1 and out["adaptor1"]["end"][i] == en1
+        assert out["adaptor1"]["subseq"]["Sub1"][i] == sub1[0]
+        s2, st2, en2, _ = direct(a2, revcomp(query[len(r) - tol:]), qquery[len(r) - tol:][::-1])
+        assert out["adaptor2"]["score"][i] == s2
+        assert out["adaptor2"]["start"][i] == len(r) - st2 + 1 and out["adaptor2"]["end"][i] == len(r) - en2 + 1
+    assert 5 <= n_rev <= 55    # both orientations occur
+
+
+def test_barcode_align_generic_read_by_read():
+    """R/barcodeAlign.R:20-36 restated as a loop over single reads and single barcodes (the generic keeps the reads
+    resident and reduces on arrays): best barcode = the first to reach the maximum (strict >), the gap is best minus
+    next best, where next best starts at -Inf and a score equal to the best one counts as next best."""
+    import sarlacc_amd
+    from sarlacc_amd import calls, generics
+    from sarlacc_amd.mock import random_reads
+    enc = sarlacc_amd.phred_encoding()
+    seqs, quals = random_reads(30, 8, 16, seed=11, qual_lo=40, qual_hi=80)
+    barcodes = ["ACGTACGTACGT", "TTTTGGGGCCCC", "ACGTACGTACGT", "ACGTTGCAACGT"]   # (a duplicate: ties between barcodes)
+    out = generics.barcodeAlign(generics.Reads(seqs, quals), barcodes)
+    for i, (s, q) in enumerate(zip(seqs, quals)):
+        cur, nxt, cid = -np.inf, -np.inf, None
+        for b, bc in enumerate(barcodes):
+            sc = float(calls.barcode_align([s], [q], enc, 5, 1, bc)[0])
+            if sc > cur:
+                cid, nxt, cur = b + 1, cur, sc
+            elif sc > nxt:
+                nxt = sc
+        assert out["barcode"][i] == cid and out["score"][i] == cur and out["gap"][i] == cur - nxt
+    single = generics.barcodeAlign(generics.Reads(seqs[:3], quals[:3]), barcodes[:1])
+    assert np.all(np.isinf(single["gap"])) and single["barcode"].tolist() == [1, 1, 1]
+
+
 def test_barcode_quality_expected(monkeypatch):
     from sarlacc_amd import generics
     from sarlacc_amd.mock import random_reads
