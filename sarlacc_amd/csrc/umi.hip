@@ -41,6 +41,12 @@ namespace sarlacc {
 constexpr int UMI_MAXLEN = 32;        // one 64-bit word of 2-bit codes: the fast path (all filters, queued DP)
 constexpr int UMI_LONG_WORDS = 4;     // strings of 33..128 bases: the same search on 4-word codes (k_umi_pairs_long)
 constexpr int UMI_LONG_MAX = 32 * UMI_LONG_WORDS;
+constexpr int UMI_XL_WORDS = 32;      // strings of 129..1024 bases: as many words as the longest string needs, read from HBM (k_umi_pairs_long<K, true>)
+constexpr int UMI_XL_MAX = 32 * UMI_XL_WORDS;
+// meta word of a string: length | number of N << 12 (12 bits each)
+__host__ __device__ __forceinline__ int umi_len(uint32_t meta) { return static_cast<int>(meta & 0xfffu); }
+__host__ __device__ __forceinline__ int umi_nn(uint32_t meta) { return static_cast<int>((meta >> 12) & 0xfffu); }
+constexpr uint32_t UMI_META_NONE = 0xffffffu;   // a padding column: length 4095, never within any limit of a real string
 constexpr int UMI_KEY_BASES = 21;     // bases per 64-bit sort key (3 bits each)
 constexpr int UMI_LONG_KEYS = (UMI_LONG_MAX + UMI_KEY_BASES - 1) / UMI_KEY_BASES;
 constexpr int TILE = 256;
@@ -53,7 +59,7 @@ struct UmiArrays {
     unsigned long long* code;   // 2 bits per base (N stored as 0); word w of string s at code[w * stride + s]
     uint32_t* nmask;            // bit i set: base i is N; same layout
     uint32_t* comp;             // counts of A,C,G,T, one byte each
-    uint32_t* meta;             // len | nN << 8
+    uint32_t* meta;             // len | nN << 12 (umi_len, umi_nn)
     long long stride;           // strings per word plane (one plane on the fast path)
 };
 
@@ -96,23 +102,23 @@ __global__ void k_umi_encode(const uint8_t* chars, const int64_t* off, const int
         else klo |= k << (3 * (20 - (i - 21)));
     }
     U.code[s] = code; U.nmask[s] = nmask; U.comp[s] = comp;
-    U.meta[s] = static_cast<uint32_t>(len) | (static_cast<uint32_t>(__popc(nmask)) << 8);
+    U.meta[s] = static_cast<uint32_t>(len) | (static_cast<uint32_t>(__popc(nmask)) << 12);
     key_hi[s] = khi; key_lo[s] = klo;
 }
 
 // The same for strings of up to UMI_LONG_MAX bases: UMI_LONG_WORDS code / mask words, one sort key per 21 bases.
 __global__ void k_umi_encode_long(const uint8_t* chars, const int64_t* off, const int32_t* members, int n,
-                                  UmiArrays U, unsigned long long* keys /* [UMI_LONG_KEYS][n] */, int* idx,
-                                  const uint8_t* skip, int* bad) {
+                                  UmiArrays U, unsigned long long* keys /* [nkeys][n] */, int* idx,
+                                  const uint8_t* skip, int* bad, int words, int nkeys) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     const long long id = members ? static_cast<long long>(members[s]) - 1 : s;
     const long long o = off[id];
-    const int len = (skip && skip[s]) ? 0 : static_cast<int>(off[id + 1] - o);   // <= UMI_LONG_MAX: checked by the caller
+    const int len = (skip && skip[s]) ? 0 : static_cast<int>(off[id + 1] - o);   // <= 32 words: checked by the caller
     idx[s] = s;
     uint32_t comp = 0;
     int nN = 0;
-    for (int w = 0; w < UMI_LONG_WORDS; ++w) {
+    for (int w = 0; w < words; ++w) {
         unsigned long long code = 0;
         uint32_t nmask = 0;
         const int hi = min(len - 32 * w, 32);
@@ -133,7 +139,7 @@ __global__ void k_umi_encode_long(const uint8_t* chars, const int64_t* off, cons
         U.code[w * U.stride + s] = code;
         U.nmask[w * U.stride + s] = nmask;
     }
-    for (int k = 0; k < UMI_LONG_KEYS; ++k) {
+    for (int k = 0; k < nkeys; ++k) {
         unsigned long long key = 0;
         const int hi = min(len - UMI_KEY_BASES * k, UMI_KEY_BASES);
         for (int i = 0; i < hi; ++i) {
@@ -143,8 +149,8 @@ __global__ void k_umi_encode_long(const uint8_t* chars, const int64_t* off, cons
         }
         keys[static_cast<long long>(k) * n + s] = key;
     }
-    U.comp[s] = comp;   // byte counters: at most 128 per letter
-    U.meta[s] = static_cast<uint32_t>(len) | (static_cast<uint32_t>(nN) << 8);
+    U.comp[s] = words > UMI_LONG_WORDS ? 0u : comp;   // byte counters: at most 128 per letter (beyond 4 words the composition bound is not used)
+    U.meta[s] = static_cast<uint32_t>(len) | (static_cast<uint32_t>(nN) << 12);
 }
 
 __global__ void k_gather_u64(const unsigned long long* src, const int* perm, unsigned long long* dst, int n) {
@@ -256,12 +262,12 @@ __global__ void __launch_bounds__(BLK) k_tile_info(UmiArrays U, const int* gid, 
     const int i = t0 + threadIdx.x;
     const uint32_t nm = i < n ? U.nmask[i] : 0u;
     const int anyN = __syncthreads_or(nm != 0u);
-    const int anyShort = __syncthreads_or(i < n && static_cast<int>(U.meta[i] & 0xff) < lreq);
+    const int anyShort = __syncthreads_or(i < n && umi_len(U.meta[i]) < lreq);
     if (threadIdx.x != 0) return;
     TileInfo ti{0ull, -1, (anyN || anyShort) ? 1 : 0};
     if (!anyN && (!gid || gid[t0] == gid[t1])) {
         const unsigned long long a = U.code[t0], b = U.code[t1];
-        const int la = U.meta[t0] & 0xff, lb = U.meta[t1] & 0xff;
+        const int la = umi_len(U.meta[t0]), lb = umi_len(U.meta[t1]);
         const unsigned long long x = a ^ b;
         int cp = x ? (__builtin_ctzll(x) >> 1) : 32;
         cp = min(cp, min(la, lb));
@@ -370,16 +376,16 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
         c_code[t] = A.U.code[jcol]; c_nmask[t] = A.U.nmask[jcol]; c_meta[t] = A.U.meta[jcol];
         c_key[t] = make_uint4(A.gid ? static_cast<uint32_t>(A.gid[jcol]) : 0u, A.U.meta[jcol], A.U.comp[jcol], A.U.nmask[jcol]);
     } else {
-        c_code[t] = 0; c_nmask[t] = 0; c_meta[t] = 0xffffu;  // len 255: never matches
-        c_key[t] = make_uint4(0xffffffffu, 0xffffu, 0u, 0u);
+        c_code[t] = 0; c_nmask[t] = 0; c_meta[t] = UMI_META_NONE;  // never matches
+        c_key[t] = make_uint4(0xffffffffu, UMI_META_NONE, 0u, 0u);
     }
     const int i = bi * TILE + t;
     const bool row_on = i < A.n;
     const unsigned long long ca = row_on ? A.U.code[i] : 0ull;
-    const uint32_t na = row_on ? A.U.nmask[i] : 0u, compa = row_on ? A.U.comp[i] : 0u, ma = row_on ? A.U.meta[i] : 0xffffu;
+    const uint32_t na = row_on ? A.U.nmask[i] : 0u, compa = row_on ? A.U.comp[i] : 0u, ma = row_on ? A.U.meta[i] : UMI_META_NONE;
     r_code[t] = ca; r_nmask[t] = na; r_meta[t] = ma;
     __syncthreads();
-    const int la = ma & 0xff, nNa = (ma >> 8) & 0xff;
+    const int la = umi_len(ma), nNa = umi_nn(ma);
     const int gi = (row_on && A.gid) ? A.gid[i] : (row_on ? 0 : -2);
     const int limit = A.lim2 / 2;
     const bool row_special = A.special_lreq < 0 || na != 0u || la < A.special_lreq;
@@ -395,7 +401,7 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
             const uint32_t e = q2[lane];
             const int ti = e >> 8, jj = e & 0xff;
             const uint32_t mra = r_meta[ti], mcb = c_meta[jj];
-            const int d = banded_lev2<K>(r_code[ti], r_nmask[ti], mra & 0xff, c_code[jj], c_nmask[jj], mcb & 0xff, A.lim2);
+            const int d = banded_lev2<K>(r_code[ti], r_nmask[ti], umi_len(mra), c_code[jj], c_nmask[jj], umi_len(mcb), A.lim2);
             if (d <= A.lim2) {
                 const unsigned long long slot = atomicAdd(A.count, 1ull);
                 if (slot < A.cap)
@@ -424,7 +430,7 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
             const int ti = e >> 8, jj = e & 0xff;
             keep = true;
             if (K <= 8 && (r_nmask[ti] | c_nmask[jj]) == 0u)
-                keep = !shd_reject<(K <= 8 ? K : 0)>(r_code[ti], r_meta[ti] & 0xff, c_code[jj], c_meta[jj] & 0xff, limit);
+                keep = !shd_reject<(K <= 8 ? K : 0)>(r_code[ti], umi_len(r_meta[ti]), c_code[jj], umi_len(c_meta[jj]), limit);
         }
         push2(keep, e);
     };
@@ -465,7 +471,7 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs(const PairArgs A) {
         const uint4 ck = c_key[jj];
         bool pass = row_ok && row_on && static_cast<int>(ck.x) == gi && (bi != bj || jj > t);
         {
-            const int lb = ck.y & 0xff, nNb = (ck.y >> 8) & 0xff;
+            const int lb = umi_len(ck.y), nNb = umi_nn(ck.y);
             const int dl = la > lb ? la - lb : lb - la;
             // composition lower bound: every edit costs >= 1 and moves the 5-letter composition by
             // <= 2 (<= its cost when no N is involved)
@@ -546,8 +552,9 @@ __device__ __forceinline__ int banded_lev2_long(const LongStr a, int la, const L
 
 // full (unbanded) doubled masked Levenshtein distance, one row in thread-private memory; gives up with
 // INF_D once a whole row exceeds lim2.  For thresholds beyond 16 and for the dense distances.
+template <int MAXL>
 __device__ __forceinline__ int full_lev2_long(const LongStr a, int la, const LongStr b, int lb, int lim2) {
-    int row[UMI_LONG_MAX + 1];
+    int row[MAXL + 1];
     for (int i = 0; i <= la; ++i) row[i] = 2 * i;
     for (int j = 1; j <= lb; ++j) {
         const unsigned cbj = b.base(j - 1), nbj = b.isn(j - 1);
@@ -566,13 +573,16 @@ __device__ __forceinline__ int full_lev2_long(const LongStr a, int la, const Lon
     return row[la];
 }
 
-// K: band held in registers; K < 0: full DP
-template <int K>
+// K: band held in registers; K < 0: full DP.  XL: strings of more than UMI_LONG_MAX bases -- as many words as the longest
+// needs (up to UMI_XL_WORDS), read where they lie in HBM instead of from a staged tile (the planes of a tile's 256 strings
+// are 2 KB runs each; the words a band touches stay in L1 / L2), no composition bound (its byte counters stop at 255).
+template <int K, bool XL>
 __global__ void __launch_bounds__(TILE) k_umi_pairs_long(const PairArgs A) {
     const int bi = blockIdx.x + A.tile_lo, bj = blockIdx.y;
     if (bj < bi) return;
-    __shared__ unsigned long long c_code[UMI_LONG_WORDS * TILE], r_code[UMI_LONG_WORDS * TILE];
-    __shared__ uint32_t c_nmask[UMI_LONG_WORDS * TILE], r_nmask[UMI_LONG_WORDS * TILE];
+    constexpr int SW = XL ? 1 : UMI_LONG_WORDS;   // staged words per string
+    __shared__ unsigned long long c_code[SW * TILE], r_code[SW * TILE];
+    __shared__ uint32_t c_nmask[SW * TILE], r_nmask[SW * TILE];
     __shared__ uint4 c_key[TILE];  // {pre-group, meta, composition, any N}
     const int t = threadIdx.x;
     if (A.gid && bj > bi) {
@@ -582,39 +592,45 @@ __global__ void __launch_bounds__(TILE) k_umi_pairs_long(const PairArgs A) {
     const int jcol = bj * TILE + t, i = bi * TILE + t;
     const bool row_on = i < A.n;
     uint32_t anyN_col = 0, na = 0;
-    for (int w = 0; w < UMI_LONG_WORDS; ++w) {
-        const bool on = jcol < A.n;
-        c_code[w * TILE + t] = on ? A.U.code[w * A.U.stride + jcol] : 0ull;
-        const uint32_t m = on ? A.U.nmask[w * A.U.stride + jcol] : 0u;
-        c_nmask[w * TILE + t] = m;
-        anyN_col |= m;
-        r_code[w * TILE + t] = row_on ? A.U.code[w * A.U.stride + i] : 0ull;
-        const uint32_t mr = row_on ? A.U.nmask[w * A.U.stride + i] : 0u;
-        r_nmask[w * TILE + t] = mr;
-        na |= mr;
+    if (XL) {   // only "some base is N" is needed up front
+        anyN_col = (jcol < A.n && umi_nn(A.U.meta[jcol]) > 0) ? 1u : 0u;
+        na = (row_on && umi_nn(A.U.meta[i]) > 0) ? 1u : 0u;
+    } else {
+        for (int w = 0; w < UMI_LONG_WORDS; ++w) {
+            const bool on = jcol < A.n;
+            c_code[w * TILE + t] = on ? A.U.code[w * A.U.stride + jcol] : 0ull;
+            const uint32_t m = on ? A.U.nmask[w * A.U.stride + jcol] : 0u;
+            c_nmask[w * TILE + t] = m;
+            anyN_col |= m;
+            r_code[w * TILE + t] = row_on ? A.U.code[w * A.U.stride + i] : 0ull;
+            const uint32_t mr = row_on ? A.U.nmask[w * A.U.stride + i] : 0u;
+            r_nmask[w * TILE + t] = mr;
+            na |= mr;
+        }
     }
     c_key[t] = jcol < A.n ? make_uint4(A.gid ? static_cast<uint32_t>(A.gid[jcol]) : 0u, A.U.meta[jcol], A.U.comp[jcol], anyN_col)
-                          : make_uint4(0xffffffffu, 0xffffu, 0u, 0u);
+                          : make_uint4(0xffffffffu, UMI_META_NONE, 0u, 0u);
     __syncthreads();
-    const uint32_t compa = row_on ? A.U.comp[i] : 0u, ma = row_on ? A.U.meta[i] : 0xffffu;
-    const int la = ma & 0xff, nNa = (ma >> 8) & 0xff;
+    const uint32_t compa = row_on ? A.U.comp[i] : 0u, ma = row_on ? A.U.meta[i] : UMI_META_NONE;
+    const int la = umi_len(ma), nNa = umi_nn(ma);
     const int gi = (row_on && A.gid) ? A.gid[i] : (row_on ? 0 : -2);
-    const LongStr sa{r_code + t, r_nmask + t, TILE};
+    const int gstride = static_cast<int>(A.U.stride);
+    const LongStr sa = XL ? LongStr{A.U.code + (row_on ? i : 0), A.U.nmask + (row_on ? i : 0), gstride} : LongStr{r_code + t, r_nmask + t, TILE};
     const int jn = min(TILE, A.n - bj * TILE);
     for (int jj = 0; jj < jn; ++jj) {
         const uint4 ck = c_key[jj];
         bool pass = row_on && static_cast<int>(ck.x) == gi && (bi != bj || jj > t);
-        const int lb = ck.y & 0xff, nNb = (ck.y >> 8) & 0xff;
+        const int lb = umi_len(ck.y), nNb = umi_nn(ck.y);
         const int dl = la > lb ? la - lb : lb - la;
         // the composition bound of k_umi_pairs; the byte counters hold up to 128 per letter, sad_u8 is exact
         const int l1 = static_cast<int>(__builtin_amdgcn_sad_u8(compa, ck.z, 0u)) + (nNa > nNb ? nNa - nNb : nNb - nNa);
         const bool anyN = (na | ck.w) != 0u;
         pass = pass && 2 * dl <= A.lim2 && l1 <= (anyN ? 2 * A.lim2 : A.lim2);
         if (!pass) continue;
-        const LongStr sb{c_code + jj, c_nmask + jj, TILE};
+        const LongStr sb = XL ? LongStr{A.U.code + bj * TILE + jj, A.U.nmask + bj * TILE + jj, gstride} : LongStr{c_code + jj, c_nmask + jj, TILE};
         int d;
         if constexpr (K >= 0) d = banded_lev2_long<(K >= 0 ? K : 0)>(sa, la, sb, lb, A.lim2);
-        else d = full_lev2_long(sa, la, sb, lb, A.lim2);
+        else d = full_lev2_long<(XL ? UMI_XL_MAX : UMI_LONG_MAX)>(sa, la, sb, lb, A.lim2);
         if (d <= A.lim2) {
             const unsigned long long slot = atomicAdd(A.count, 1ull);
             if (slot < A.cap)
@@ -684,7 +700,7 @@ __global__ void __launch_bounds__(256) k_sk_lenhist(UmiArrays U, int n, unsigned
     if (threadIdx.x < 34) s_h[threadIdx.x] = 0u;
     __syncthreads();
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        atomicAdd(&s_h[min(static_cast<int>(U.meta[i] & 0xff), 32)], 1u);
+        atomicAdd(&s_h[min(umi_len(U.meta[i]), 32)], 1u);
         if (U.nmask[i]) atomicAdd(&s_h[33], 1u);
     }
     __syncthreads();
@@ -698,7 +714,7 @@ __global__ void k_sk_elems(UmiArrays U, int n, int lreq, SkElem* el, unsigned lo
     if (i >= n) return;
     const unsigned long long code = U.code[i];
     const uint32_t nm = U.nmask[i];
-    const int len = U.meta[i] & 0xff;
+    const int len = umi_len(U.meta[i]);
     uint32_t plo = sk_even_bits(code), phi = sk_even_bits(code >> 1), nmo = nm;
     if (REV && len > 0) { plo = __brev(plo) >> (32 - len); phi = __brev(phi) >> (32 - len); nmo = __brev(nm) >> (32 - len); }
     const uint32_t special = (nm != 0u || len < lreq) ? 1u : 0u;
@@ -1042,6 +1058,7 @@ __global__ void __launch_bounds__(SK_COLS / 2) k_sk_scan_pk(const SkScanArgs A) 
     if (nq) flush(nq);
 }
 
+template <int MAXL>
 __global__ void k_lev_dense_long(UmiArrays U, int n, double* out) {
     const long long p = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
     const long long npairs = static_cast<long long>(n) * (n - 1) / 2;
@@ -1052,7 +1069,7 @@ __global__ void k_lev_dense_long(UmiArrays U, int n, double* out) {
     while (start(i + 1) <= p) ++i;
     const long long j = i + 1 + (p - start(i));
     const LongStr a{U.code + i, U.nmask + i, static_cast<int>(U.stride)}, b{U.code + j, U.nmask + j, static_cast<int>(U.stride)};
-    const int d = full_lev2_long(a, U.meta[i] & 0xff, b, U.meta[j] & 0xff, 8 * UMI_LONG_MAX);
+    const int d = full_lev2_long<MAXL>(a, umi_len(U.meta[i]), b, umi_len(U.meta[j]), 8 * MAXL);
     out[p] = static_cast<double>(d) / 2.0;
 }
 
@@ -1069,7 +1086,7 @@ __global__ void k_lev_dense(UmiArrays U, int n, double* out) {
     while (start(i + 1) <= p) ++i;
     const long long j = i + 1 + (p - start(i));
     const uint32_t ma = U.meta[i], mb = U.meta[j];
-    const int d = banded_lev2<UMI_MAXLEN>(U.code[i], U.nmask[i], ma & 0xff, U.code[j], U.nmask[j], mb & 0xff, 4 * UMI_MAXLEN);
+    const int d = banded_lev2<UMI_MAXLEN>(U.code[i], U.nmask[i], umi_len(ma), U.code[j], U.nmask[j], umi_len(mb), 4 * UMI_MAXLEN);
     out[p] = static_cast<double>(d) / 2.0;
 }
 
@@ -1091,7 +1108,7 @@ __global__ void k_expand_edges(const unsigned long long* edges, unsigned long lo
 __global__ void k_self_flags(UmiArrays U, int n, int lim2, const uint8_t* single, const int* perm, int* flag) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const bool self = static_cast<int>((U.meta[r] >> 8) & 0xff) <= lim2;  // d2(x,x) = #N (App.B Q10)
+    const bool self = umi_nn(U.meta[r]) <= lim2;  // d2(x,x) = #N (App.B Q10)
     flag[r] = (self || (single && single[perm[r]])) ? 1 : 0;
 }
 
@@ -1568,7 +1585,7 @@ struct SortedUmis {
     int* perm;     // rank -> local index
     int* gid;      // pre-group per rank (nullptr: a single group)
     int n;
-    int words;     // 1: every string has at most 32 bases; UMI_LONG_WORDS otherwise
+    int words;     // 1: every string has at most 32 bases; UMI_LONG_WORDS up to 128 bases; beyond, what the longest string needs
     int ngroups;   // pre-groups (1 when gid is nullptr)
     int nskip = 0;       // elements that are never compared (pre-groups of one read: encoded as empty strings)
     int max_group = 0;   // size of the largest pre-group (0: unknown, the whole set)
@@ -1602,21 +1619,22 @@ static int encode_and_rank(const std::string& p, const uint8_t* d_chars, const i
     if (hbad[1] != init[1]) {
         // some string has more than 32 bases: the whole call runs on 4-word codes
         const int maxlen = -hbad[2];
-        if (maxlen > UMI_LONG_MAX) return fail("sarlacc_amd: UMI longer than %d bases is not supported", UMI_LONG_MAX);
-        out->words = UMI_LONG_WORDS;
-        SL_TRY(alloc_umi(p + ".rawL", n, &raw, UMI_LONG_WORDS));
-        SL_TRY(alloc_umi(p + ".srtL", n, &out->U, UMI_LONG_WORDS));
+        if (maxlen > UMI_XL_MAX) return fail("sarlacc_amd: UMI longer than %d bases is not supported", UMI_XL_MAX);
+        // 33..128 bases: 4 words per string, tiles staged in LDS; beyond: as many words as the longest string needs
+        out->words = maxlen <= UMI_LONG_MAX ? UMI_LONG_WORDS : (maxlen + 31) / 32;
+        const int nkeys = (maxlen + UMI_KEY_BASES - 1) / UMI_KEY_BASES;
+        SL_TRY(alloc_umi(p + ".rawL", n, &raw, out->words));
+        SL_TRY(alloc_umi(p + ".srtL", n, &out->U, out->words));
         unsigned long long* keys;
-        SL_TRY(scratch((p + ".keysL").c_str(), static_cast<size_t>(n) * UMI_LONG_KEYS, &keys));
+        SL_TRY(scratch((p + ".keysL").c_str(), static_cast<size_t>(n) * nkeys, &keys));
         SL_HIP(hipMemcpyAsync(bad, init, sizeof init, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_umi_encode_long, dim3(nblk(n, 256)), dim3(256), 0, s, d_chars, d_off, d_members, n, raw, keys, idx, d_skip, bad);
+        hipLaunchKernelGGL(k_umi_encode_long, dim3(nblk(n, 256)), dim3(256), 0, s, d_chars, d_off, d_members, n, raw, keys, idx, d_skip, bad, out->words, nkeys);
         SL_HIP(hipGetLastError());
         SL_HIP(hipMemcpyAsync(hbad, bad, sizeof hbad, hipMemcpyDeviceToHost, s));
         SL_HIP(hipStreamSynchronize(s));
         if (hbad[0] != init[0])
             return fail("sarlacc_amd: UMI contains a character outside ACGTN (the reference silently drops such strings)");
         // stable sorts, least-significant key first (only the keys some string reaches)
-        const int nkeys = (maxlen + UMI_KEY_BASES - 1) / UMI_KEY_BASES;
         int *from = idx, *to = idx2;
         for (int k = nkeys - 1; k >= 0; --k) {
             hipLaunchKernelGGL(k_gather_u64, dim3(nblk(n, 256)), dim3(256), 0, s, keys + static_cast<size_t>(k) * n, from, klo, n);
@@ -1931,14 +1949,20 @@ static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int 
         if (S.words > 1) {
             if (tile_hi > tile_lo) {
                 const dim3 grid(static_cast<unsigned>(tile_hi - tile_lo), static_cast<unsigned>(nt));
-                if (limit <= 0) hipLaunchKernelGGL(k_umi_pairs_long<0>, grid, dim3(TILE), 0, s, a);
-                else if (limit == 1) hipLaunchKernelGGL(k_umi_pairs_long<1>, grid, dim3(TILE), 0, s, a);
-                else if (limit == 2) hipLaunchKernelGGL(k_umi_pairs_long<2>, grid, dim3(TILE), 0, s, a);
-                else if (limit == 3) hipLaunchKernelGGL(k_umi_pairs_long<3>, grid, dim3(TILE), 0, s, a);
-                else if (limit <= 5) hipLaunchKernelGGL(k_umi_pairs_long<5>, grid, dim3(TILE), 0, s, a);
-                else if (limit <= 8) hipLaunchKernelGGL(k_umi_pairs_long<8>, grid, dim3(TILE), 0, s, a);
-                else if (limit <= 16) hipLaunchKernelGGL(k_umi_pairs_long<16>, grid, dim3(TILE), 0, s, a);
-                else hipLaunchKernelGGL(k_umi_pairs_long<-1>, grid, dim3(TILE), 0, s, a);
+#define UMI_LONG_LAUNCH(KK)                                                                                  \
+    {                                                                                                        \
+        if (S.words > UMI_LONG_WORDS) hipLaunchKernelGGL((k_umi_pairs_long<KK, true>), grid, dim3(TILE), 0, s, a);   \
+        else hipLaunchKernelGGL((k_umi_pairs_long<KK, false>), grid, dim3(TILE), 0, s, a);                   \
+    }
+                if (limit <= 0) UMI_LONG_LAUNCH(0)
+                else if (limit == 1) UMI_LONG_LAUNCH(1)
+                else if (limit == 2) UMI_LONG_LAUNCH(2)
+                else if (limit == 3) UMI_LONG_LAUNCH(3)
+                else if (limit <= 5) UMI_LONG_LAUNCH(5)
+                else if (limit <= 8) UMI_LONG_LAUNCH(8)
+                else if (limit <= 16) UMI_LONG_LAUNCH(16)
+                else UMI_LONG_LAUNCH(-1)
+#undef UMI_LONG_LAUNCH
             }
         }
         else if (K <= 0) launch_pairs<0>(a, tile_hi, listed, s);
@@ -2329,13 +2353,17 @@ int sarlacc_compute_lev_masked(const char* seq, const int64_t* off, int64_t n, d
     SL_HIP(hipMemcpyAsync(hbad, bad, sizeof hbad, hipMemcpyDeviceToHost, s));
     SL_HIP(hipStreamSynchronize(s));
     const bool is_long = hbad[1] != init[1];
+    bool xl = false;
     if (is_long) {
-        if (-hbad[2] > UMI_LONG_MAX) return fail("sarlacc_amd: sequence longer than %d bases is not supported", UMI_LONG_MAX);
-        SL_TRY(alloc_umi("lev.rawL", n, &U, UMI_LONG_WORDS));
+        const int maxlen = -hbad[2];
+        if (maxlen > UMI_XL_MAX) return fail("sarlacc_amd: sequence longer than %d bases is not supported", UMI_XL_MAX);
+        xl = maxlen > UMI_LONG_MAX;
+        const int words = xl ? (maxlen + 31) / 32 : UMI_LONG_WORDS, nkeys = (maxlen + UMI_KEY_BASES - 1) / UMI_KEY_BASES;
+        SL_TRY(alloc_umi("lev.rawL", n, &U, words));
         unsigned long long* keys;
-        SL_TRY(scratch("lev.keysL", static_cast<size_t>(n) * UMI_LONG_KEYS, &keys));
+        SL_TRY(scratch("lev.keysL", static_cast<size_t>(n) * nkeys, &keys));
         SL_HIP(hipMemcpyAsync(bad, init, sizeof init, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_umi_encode_long, dim3(nblk(n, 256)), dim3(256), 0, s, d_c, d_o, static_cast<const int32_t*>(nullptr), static_cast<int>(n), U, keys, idx, static_cast<const uint8_t*>(nullptr), bad);
+        hipLaunchKernelGGL(k_umi_encode_long, dim3(nblk(n, 256)), dim3(256), 0, s, d_c, d_o, static_cast<const int32_t*>(nullptr), static_cast<int>(n), U, keys, idx, static_cast<const uint8_t*>(nullptr), bad, words, nkeys);
         SL_HIP(hipMemcpyAsync(hbad, bad, sizeof hbad, hipMemcpyDeviceToHost, s));
         SL_HIP(hipStreamSynchronize(s));
     }
@@ -2345,7 +2373,8 @@ int sarlacc_compute_lev_masked(const char* seq, const int64_t* off, int64_t n, d
     const long long npairs = n * (n - 1) / 2;
     double* d_out;
     SL_TRY(scratch("lev.out", static_cast<size_t>(npairs), &d_out));
-    if (is_long) hipLaunchKernelGGL(k_lev_dense_long, dim3(nblk(npairs, 128)), dim3(128), 0, s, U, static_cast<int>(n), d_out);
+    if (is_long && xl) hipLaunchKernelGGL(k_lev_dense_long<UMI_XL_MAX>, dim3(nblk(npairs, 128)), dim3(128), 0, s, U, static_cast<int>(n), d_out);
+    else if (is_long) hipLaunchKernelGGL(k_lev_dense_long<UMI_LONG_MAX>, dim3(nblk(npairs, 128)), dim3(128), 0, s, U, static_cast<int>(n), d_out);
     else hipLaunchKernelGGL(k_lev_dense, dim3(nblk(npairs, 128)), dim3(128), 0, s, U, static_cast<int>(n), d_out);
     SL_HIP(hipGetLastError());
     SL_HIP(hipMemcpy(out, d_out, sizeof(double) * static_cast<size_t>(npairs), hipMemcpyDeviceToHost));

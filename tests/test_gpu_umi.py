@@ -425,8 +425,39 @@ def test_umi_group_long(oracle):
         many += umisim(rng, 10, 40, rate=0.03)
     g = [list(range(1, len(many) + 1))]
     same_lists(calls.umi_group(many, 2, None, 2, g), oracle.umi_group(many, 2, None, 2, g))
-    with pytest.raises(SarlaccError, match="longer than 128 bases"):
-        calls.umi_group(["A" * 129, "C" * 10], 1, None, 1, [[1, 2]])
+    with pytest.raises(SarlaccError, match="longer than 1024 bases"):
+        calls.umi_group(["A" * 1025, "C" * 10], 1, None, 1, [[1, 2]])
+
+
+@pytest.mark.parametrize("length,alphabet", [(129, "ACGT"), (160, "ACGTN"), (300, "ACGT"), (1024, "ACGT")])
+def test_strings_beyond_128_bases(oracle, length, alphabet):
+    """Strings of 129..1 024 bases (src/sorted_trie.cpp:39-71 takes any length): as many code words as the longest string
+    needs, read from HBM (k_umi_pairs_long<K, true>).  Neighbour lists in trie order -- sort keys of 21 bases, so the order
+    is decided up to 49 keys deep --, the dense distances and the groups, with shorter strings in the same call."""
+    from sarlacc_amd import calls
+    rng = np.random.default_rng(length)
+    seqs = []
+    for _ in range(10):
+        fam = umisim(rng, 8, length, rate=0.01, alphabet=alphabet)
+        for k, u in enumerate(fam):     # indels near the end and in the middle, a few shorter relatives
+            if k % 3 == 1:
+                u = u[:-1]
+            if k % 4 == 2:
+                u = u[:length // 2] + u[length // 2 + 1:]
+            seqs.append(u[:length])
+    seqs += seqs[:5]                     # duplicates
+    seqs += seqsim(rng, 10, 1, 60, "ACGT")   # short strings in the same call
+    for limit in (0, 1, 2, 3, 5, 9, 20):
+        same_lists(calls.fast_levdist_test(seqs, limit, True), oracle.fast_levdist_test(seqs, limit))
+    sub = seqs[:24] + seqs[-6:]
+    assert calls.compute_lev_masked(sub).tolist() == oracle.compute_lev_masked(sub).tolist()
+    second = [u[:40] for u in seqs]
+    everything = [list(range(1, len(seqs) + 1))]
+    halves = [list(range(1, len(seqs) // 2 + 1)), list(range(len(seqs) // 2 + 1, len(seqs) + 1))]
+    for groups in (everything, halves):
+        for t in (1, 4, 12):
+            same_lists(calls.umi_group(seqs, t, None, t, groups), oracle.umi_group(seqs, t, None, t, groups))
+        same_lists(calls.umi_group(seqs, 6, second, 2, groups), oracle.umi_group(seqs, 6, second, 2, groups))
 
 
 def test_singleton_pregroups_pass_through_unchecked(oracle):

@@ -129,8 +129,8 @@ def umi_switches(rng):
 
 def case_umi(rng):
     n = int(rng.integers(2, 400))
-    length = int(rng.choice([0, 3, 8, 12, 20, 32, 33, 48, 80, 127]))   # beyond 32: the 4-word path (up to 128 bases)
-    base = [rstr(rng, min(127, max(0, length + int(rng.integers(-2, 3)))), "ACGT") for _ in range(max(1, n // 8))]
+    length = int(rng.choice([0, 3, 8, 12, 20, 32, 33, 48, 80, 127, 129, 260]))   # beyond 32: the 4-word path (up to 128 bases); beyond 128: words from HBM
+    base = [rstr(rng, min(127 if length <= 127 else 1023, max(0, length + int(rng.integers(-2, 3)))), "ACGT") for _ in range(max(1, n // 8))]
     alpha = "ACGT" if rng.random() < 0.7 else "ACGTN"
     umis = []
     for _ in range(n):
@@ -140,7 +140,7 @@ def case_umi(rng):
                 b[k] = alpha[int(rng.integers(0, len(alpha)))]
         if b and rng.random() < 0.1:
             del b[int(rng.integers(0, len(b)))]
-        if len(b) < 128 and rng.random() < 0.1:
+        if len(b) < (128 if length <= 127 else 1024) and rng.random() < 0.1:
             b.insert(int(rng.integers(0, len(b) + 1)), "ACGT"[int(rng.integers(0, 4))])
         umis.append("".join(b))
     limit = int(rng.integers(0, 5))
