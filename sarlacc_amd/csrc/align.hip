@@ -874,14 +874,8 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
     const double GO = A.GO, GE = A.GE;
     const bool local = A.local != 0;
     int cb[K];
-    double rz[K], rzl[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int col = min(t * K + k + 1, R);
-        cb[k] = static_cast<int>(A.colbase[col]);
-        rz[k] = A.rowzero[col];
-        rzl[k] = A.rowzero[col - 1];
-    }
+    for (int k = 0; k < K; ++k) cb[k] = static_cast<int>(A.colbase[min(t * K + k + 1, R)]);
     const int ncolv = max(0, min(K, R - t * K));   // this thread's columns inside the reference
     const int tR = (R - 1) / K, kR = (R - 1) % K;
     const long long Rw = T;                        // words per step
@@ -893,7 +887,10 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
         double Sc[K], Dg[K], UJ[K];
         unsigned upneg = 0;
 #pragma unroll
-        for (int k = 0; k < K; ++k) { Sc[k] = rz[k]; Dg[k] = rzl[k]; UJ[k] = NEG_INF; }
+        for (int k = 0; k < K; ++k) {   // DP row 0 of the thread's columns and of the column to their left (re-read per alignment: 2 K registers less)
+            const int col = min(t * K + k + 1, R);
+            Sc[k] = A.rowzero[col]; Dg[k] = A.rowzero[col - 1]; UJ[k] = NEG_INF;
+        }
         const int nsteps = L > 0 ? L + tR : 0;   // thread tR finishes row L at step L + tR
         for (int s = 1; s <= nsteps; ++s) {
             if ((s - 1) % WIDE_CH == 0) {   // rows s .. s + WIDE_CH - 1 into the ring (thread 0 needs row s now)
@@ -1230,6 +1227,7 @@ struct AlignOut {
 // References beyond MAX_REF columns: one workgroup per alignment (k_align_wide).  `a` is complete except for the scratch.
 static int launch_wide(AlignArgs& a, int R, int kernel_mode, int32_t max_len, long long n, hipStream_t stream) {
     Context& c = ctx();
+    // (12 or 16 columns per thread at 2 kb: 3 x slower -- the unrolled columns spill at the 128 registers a 1 024-thread bound leaves)
     const int K = R <= 8 * WIDE_MAXT ? 8 : 16;
     if ((R + K - 1) / K > WIDE_MAXT) return fail("sarlacc_amd: reference longer than %d columns is not supported", 16 * WIDE_MAXT);
     if (kernel_mode == 2 && a.nmask) return fail("sarlacc_amd: alignment strings need ASCII reads");
