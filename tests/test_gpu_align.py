@@ -330,6 +330,9 @@ def test_references_beyond_1024_columns(oracle, oenc, enc):
         if R <= 3000:
             long_reads = [rd + "".join(rng.choice(nuc, 300)) for rd in reads]
             compare_adaptor(oracle, oenc, enc, long_reads, rand_quals(long_reads, R + 1, lo=40, hi=83), ref, go, 1, [10, 0, 1500 % R], [R - 5, 40, R])
+    from sarlacc_amd import SarlaccError
+    with pytest.raises(SarlaccError, match="longer than 16384 columns"):
+        calls.barcode_align(["ACGT"], ["IIII"], enc, 5, 1, "A" * 16385)
 
 
 def test_error_behaviour(oracle, oenc, enc):
