@@ -856,8 +856,13 @@ struct WideWord { using type = uint32_t; };
 template <>
 struct WideWord<16> { using type = unsigned long long; };
 
-// MODE 0 scores, 1 scores + map + sections, 2 scores + strings + edit distance
-template <int K, int MODE>
+// MODE 0 scores, 1 scores + map + sections, 2 scores + strings + edit distance.  PENSEL: the reference's penalty selects spelled
+// out (needed when gapopen < 0).  Otherwise the "Penalty selection" argument of k_align applies cell for cell: a gap step out of
+// a cell that was itself entered by the same kind of gap finds the running jump score equal to that cell's score, bit for bit,
+// so with open >= extension max(jump - extension, score - open) is the double the reference computes either way, and its
+// "jump continued" flag is the raw comparison AND NOT "that cell was entered by this kind of gap" -- both at hand here, so
+// the codes, and the walk, are the same in both instantiations.
+template <int K, int MODE, bool PENSEL>
 __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
     using Word = typename WideWord<K>::type;
     extern __shared__ __align__(16) unsigned char w_smem[];
@@ -935,16 +940,31 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
                 for (int k = 0; k < K; ++k) {
                     if (k < ncolv) {
                         const bool lastcol = local && (t * K + k + 1 == R);   // free vertical gaps in the last column (:93)
-                        double horiz = ls - (lpos ? GE : GO);
-                        lj -= GE;
-                        const bool hc = lj > horiz;
-                        if (hc) horiz = lj; else lj = horiz;
                         const double vgo = lastcol ? 0.0 : GO, vge = lastcol ? 0.0 : GE;
-                        double vert = Sc[k] - (((upneg >> k) & 1u) ? vge : vgo);
-                        double uj = UJ[k] - vge;
-                        const bool vc = uj > vert;
-                        if (vc) vert = uj; else uj = vert;
-                        UJ[k] = uj;
+                        const bool upn = ((upneg >> k) & 1u) != 0u;
+                        double horiz, vert;
+                        bool hc, vc;
+                        if (PENSEL) {
+                            horiz = ls - (lpos ? GE : GO);
+                            lj -= GE;
+                            hc = lj > horiz;
+                            if (hc) horiz = lj; else lj = horiz;
+                            vert = Sc[k] - (upn ? vge : vgo);
+                            double uj = UJ[k] - vge;
+                            vc = uj > vert;
+                            if (vc) vert = uj; else uj = vert;
+                            UJ[k] = uj;
+                        } else {
+                            const double hopen = ls - GO, vopen = Sc[k] - vgo;
+                            lj -= GE;
+                            hc = lj > hopen && !lpos;
+                            horiz = fmax(lj, hopen);
+                            lj = horiz;
+                            const double uj = UJ[k] - vge;
+                            vc = uj > vopen && !upn;
+                            vert = fmax(uj, vopen);
+                            UJ[k] = vert;
+                        }
                         const double cost = *reinterpret_cast<const double*>(reinterpret_cast<const unsigned char*>(s_tab) + cb[k] + ent);
                         const double match = Dg[k] + cost;
                         Dg[k] = ls;
@@ -977,7 +997,12 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
         if (MODE) {
             __threadfence();
             __syncthreads();
-            if (t == 0) {
+            if (t < 64) {
+                // The walk, on the first wavefront: the path of a global alignment of like sequences is mostly diagonal, so lane m
+                // looks at the cell m steps up the diagonal from (row, c), a ballot gives the length of the diagonal run and its
+                // moves are written side by side -- one memory round trip per run instead of one per cell; gaps are taken one
+                // run at a time (every lane follows, the outputs are spread over the lanes).
+                const int lane = t;
                 auto nibble = [&](int c, int row) -> unsigned {   // 1 <= c <= R, 1 <= row <= L
                     const int tt = (c - 1) / K, kk = (c - 1) % K;
                     const Word w = dirs[static_cast<long long>(row + tt) * Rw + tt];
@@ -998,36 +1023,51 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
                     for (int y = row; (f & 8u) && y > 1;) { ++len; --y; f = nibble(c, y); }
                     return -len;
                 };
+                auto diag_run = [&](int c, int row) -> int {   // diagonal moves from (row, c) on, at most 64
+                    const int rr = row - lane, cc = c - lane;
+                    const bool stop = !(rr >= 1 && cc >= 1) || (nibble(cc, rr) & 3u) != 0u;
+                    const unsigned long long nd = __ballot(stop);
+                    return nd ? static_cast<int>(__builtin_ctzll(nd)) : 64;
+                };
                 int row = L, c = R;
                 if (MODE == 1) {
                     const unsigned long long map_words = (static_cast<unsigned long long>(R + 1) * 4 + sizeof(Word) - 1) / sizeof(Word);
                     int32_t* const map = reinterpret_cast<int32_t*>(dirs + (A.dirs_per_wave - map_words));   // (behind the codes)
                     while (c > 0) {
-                        int d = loadD(c, row);
-                        while (row > 0 && d < 0) { row += d; d = loadD(c, row); }
-                        if (d == 0) { map[c] = row * 2 + 1; --row; --c; }
-                        else { for (int x = 0; x < d && c > 0; ++x) { map[c] = (row + 1) * 2; --c; } }
-                    }
-                    auto interval = [&](int a, int b, bool gaps, unsigned& st, unsigned& en) {   // (:307-351), size_t wrap kept via unsigned
-                        if (!gaps) {
-                            st = map[a + 1] >> 1;
-                            en = (map[b] >> 1) + (map[b] & 1);
-                        } else {
-                            st = (a == 0) ? 1u : static_cast<unsigned>((map[a] >> 1) + (map[a] & 1));
-                            en = (b + 1 == R + 1) ? static_cast<unsigned>(L + 1) : static_cast<unsigned>(map[b + 1] >> 1);
+                        const int run = diag_run(c, row);
+                        if (run > 0) {
+                            if (lane < run) map[c - lane] = (row - lane) * 2 + 1;
+                            row -= run; c -= run;
+                            continue;
                         }
-                        st -= 1;
-                        en -= 1;
-                    };
-                    unsigned st, en;
-                    interval(0, R, false, st, en);
-                    const bool nonempty = st < en;
-                    A.starts[read] = nonempty ? static_cast<int32_t>(st + 1) : 0;
-                    A.ends[read] = nonempty ? static_cast<int32_t>(en) : 0;
-                    for (int x = 0; x < A.nsec; ++x) {
-                        interval(A.sec_s[x], A.sec_e[x], true, st, en);
-                        A.sec_so[static_cast<long long>(x) * A.sec_stride + read] = static_cast<int32_t>(st + 1);
-                        A.sec_wo[static_cast<long long>(x) * A.sec_stride + read] = static_cast<int32_t>(en - st);
+                        const int d = loadD(c, row);
+                        if (d < 0) { row += d; continue; }   // up moves leave the map untouched (:286)
+                        for (int x = lane; x < d && c - x > 0; x += 64) map[c - x] = (row + 1) * 2;
+                        c -= min(d, c);
+                    }
+                    __threadfence();
+                    if (lane == 0) {
+                        auto interval = [&](int a, int b, bool gaps, unsigned& st, unsigned& en) {   // (:307-351), size_t wrap kept via unsigned
+                            if (!gaps) {
+                                st = map[a + 1] >> 1;
+                                en = (map[b] >> 1) + (map[b] & 1);
+                            } else {
+                                st = (a == 0) ? 1u : static_cast<unsigned>((map[a] >> 1) + (map[a] & 1));
+                                en = (b + 1 == R + 1) ? static_cast<unsigned>(L + 1) : static_cast<unsigned>(map[b + 1] >> 1);
+                            }
+                            st -= 1;
+                            en -= 1;
+                        };
+                        unsigned st, en;
+                        interval(0, R, false, st, en);
+                        const bool nonempty = st < en;
+                        A.starts[read] = nonempty ? static_cast<int32_t>(st + 1) : 0;
+                        A.ends[read] = nonempty ? static_cast<int32_t>(en) : 0;
+                        for (int x = 0; x < A.nsec; ++x) {
+                            interval(A.sec_s[x], A.sec_e[x], true, st, en);
+                            A.sec_so[static_cast<long long>(x) * A.sec_stride + read] = static_cast<int32_t>(st + 1);
+                            A.sec_wo[static_cast<long long>(x) * A.sec_stride + read] = static_cast<int32_t>(en - st);
+                        }
                     }
                 } else {   // gapped strings, emitted from the end (:353-389)
                     const long long base = start + read * static_cast<long long>(R);
@@ -1036,23 +1076,31 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
                     const uint8_t* const sq = A.seq + start;
                     int m = 0, ed = 0;
                     while (c > 0) {
-                        int d = loadD(c, row);
-                        while (row > 0 && d < 0) {
-                            for (int x = 0; x < -d; ++x) { oref[m] = '-'; oqry[m] = sq[row - 1]; ++m; ++ed; --row; }
-                            d = loadD(c, row);
+                        const int run = diag_run(c, row);
+                        if (run > 0) {
+                            bool diff = false;
+                            if (lane < run) {
+                                const uint8_t rc = A.refchars[c - 1 - lane], qc = sq[row - 1 - lane];
+                                oref[m + lane] = rc; oqry[m + lane] = qc;
+                                diff = rc != qc;
+                            }
+                            ed += static_cast<int>(__popcll(__ballot(diff)));
+                            m += run; row -= run; c -= run;
+                            continue;
                         }
-                        if (d == 0) {
-                            const uint8_t rc = A.refchars[c - 1], qc = sq[row - 1];
-                            oref[m] = rc; oqry[m] = qc; ++m;
-                            ed += rc != qc;
-                            --row; --c;
-                        } else {
-                            for (int x = 0; x < d && c > 0; ++x) { oref[m] = A.refchars[c - 1]; oqry[m] = '-'; ++m; ++ed; --c; }
+                        const int d = loadD(c, row);
+                        if (d < 0) {   // read bases opposite a gap
+                            for (int x = lane; x < -d; x += 64) { oref[m + x] = '-'; oqry[m + x] = sq[row - 1 - x]; }
+                            m -= d; ed -= d; row += d;
+                        } else {       // reference characters opposite a gap
+                            const int dd = min(d, c);
+                            for (int x = lane; x < dd; x += 64) { oref[m + x] = A.refchars[c - 1 - x]; oqry[m + x] = '-'; }
+                            m += dd; ed += dd; c -= dd;
                         }
                     }
-                    while (row > 0) { oref[m] = '-'; oqry[m] = sq[row - 1]; ++m; ++ed; --row; }
-                    A.aln_len[read] = m;
-                    A.edits[read] = ed;
+                    for (int x = lane; x < row; x += 64) { oref[m + x] = '-'; oqry[m + x] = sq[row - 1 - x]; }
+                    m += max(row, 0); ed += max(row, 0);
+                    if (lane == 0) { A.aln_len[read] = m; A.edits[read] = ed; }
                 }
             }
         }
@@ -1247,9 +1295,14 @@ static int launch_wide(AlignArgs& a, int R, int kernel_mode, int32_t max_len, lo
     const size_t lds = sizeof(double) * a.tab_doubles + static_cast<size_t>(T) * (2 * 8 + 2 * 8 + 2 * 4) + WIDE_RING * sizeof(uint16_t);
     if (lds > 64 * 1024) return fail("sarlacc_amd: alignment tables do not fit in LDS");
     const dim3 g(static_cast<unsigned>(grid)), b(static_cast<unsigned>(T));
-#define WIDE_LAUNCH(KK, MM) hipLaunchKernelGGL((k_align_wide<KK, MM>), g, b, lds, stream, a)
-    if (K == 8) { if (kernel_mode == 0) WIDE_LAUNCH(8, 0); else if (kernel_mode == 1) WIDE_LAUNCH(8, 1); else WIDE_LAUNCH(8, 2); }
-    else { if (kernel_mode == 0) WIDE_LAUNCH(16, 0); else if (kernel_mode == 1) WIDE_LAUNCH(16, 1); else WIDE_LAUNCH(16, 2); }
+    const bool pensel = !(a.GO >= a.GE) || option(OPT_ALIGN_PENSEL) != 0;   // (gapopen < 0, or the tests' switch)
+#define WIDE_LAUNCH(KK, MM)                                                                   \
+    {                                                                                         \
+        if (pensel) hipLaunchKernelGGL((k_align_wide<KK, MM, true>), g, b, lds, stream, a);   \
+        else hipLaunchKernelGGL((k_align_wide<KK, MM, false>), g, b, lds, stream, a);         \
+    }
+    if (K == 8) { if (kernel_mode == 0) WIDE_LAUNCH(8, 0) else if (kernel_mode == 1) WIDE_LAUNCH(8, 1) else WIDE_LAUNCH(8, 2) }
+    else { if (kernel_mode == 0) WIDE_LAUNCH(16, 0) else if (kernel_mode == 1) WIDE_LAUNCH(16, 1) else WIDE_LAUNCH(16, 2) }
 #undef WIDE_LAUNCH
     SL_HIP(hipGetLastError());
     return 0;
