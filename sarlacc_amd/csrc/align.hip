@@ -968,11 +968,11 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
                         const double cost = *reinterpret_cast<const double*>(reinterpret_cast<const unsigned char*>(s_tab) + cb[k] + ent);
                         const double match = Dg[k] + cost;
                         Dg[k] = ls;
-                        unsigned kind;
-                        double cur;
-                        if (match > horiz && match > vert) { cur = match; kind = 0u; }
-                        else if (horiz > vert) { cur = horiz; kind = 1u; }
-                        else { cur = vert; kind = 2u; }
+                        // (:164-177) the diagonal if it beats both gaps, else the horizontal gap if it beats the vertical one; the score is
+                        // the maximum of the three either way (no NaN, no -0 on this path: the selected operand bit for bit)
+                        const double hv = fmax(horiz, vert);
+                        const double cur = fmax(match, hv);
+                        const unsigned kind = match > hv ? 0u : (horiz > vert ? 1u : 2u);
                         Sc[k] = cur;
                         upneg = (upneg & ~(1u << k)) | ((kind == 2u ? 1u : 0u) << k);
                         ls = cur;
