@@ -61,8 +61,8 @@ double sarlacc_last_kernel_ms(void);
 /* quality-weighted read-vs-reference DP                                 */
 
 /* Reference (adaptor / barcode) length, all entry points of this section: up to 1 024 columns an alignment runs
- * inside a wavefront (k_align), beyond that one workgroup holds it (k_align_wide, up to 16 384 columns); longer
- * references fail with a message.  The reference itself (src/reference_align.cpp:7-13) has no limit. */
+ * inside a wavefront (k_align), beyond that one workgroup holds it (k_align_wide: strips of 8 192 columns for
+ * longer references); beyond 2^20 columns a call fails with a message.  The reference itself (src/reference_align.cpp:7-13) has no limit. */
 
 /* replaces .Call adaptor_align  (src/adaptor_align.cpp:11-77)
  * sec_starts 0-based, sec_ends 1-based (as passed by R/adaptorAlign.R:158).

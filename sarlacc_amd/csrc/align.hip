@@ -79,6 +79,8 @@ struct AlignArgs {
     uint8_t* aln_qry;
     int32_t* aln_len;
     int32_t* edits;
+    int wide_maxlen;                   // k_align_wide: the longest read of the launch (sizes of its code tiles and boundary arrays)
+    double* wide_bnd;                  // k_align_wide with several strips: per workgroup [2][3][wide_maxlen + 2] row states at a strip's last column
 };
 
 // Traceback code of one cell, 4 bits -- the raw outcomes of the cell's four comparisons:
@@ -853,8 +855,6 @@ constexpr int WIDE_MAXT = 1024;
 
 template <int K>
 struct WideWord { using type = uint32_t; };
-template <>
-struct WideWord<16> { using type = unsigned long long; };
 
 // MODE 0 scores, 1 scores + map + sections, 2 scores + strings + edit distance.  PENSEL: the reference's penalty selects spelled
 // out (needed when gapopen < 0).  Otherwise the "Penalty selection" argument of k_align applies cell for cell: a gap step out of
@@ -862,38 +862,57 @@ struct WideWord<16> { using type = unsigned long long; };
 // so with open >= extension max(jump - extension, score - open) is the double the reference computes either way, and its
 // "jump continued" flag is the raw comparison AND NOT "that cell was entered by this kind of gap" -- both at hand here, so
 // the codes, and the walk, are the same in both instantiations.
-template <int K, int MODE, bool PENSEL>
+template <int K, int MODE, bool PENSEL, bool STRIPS>
 __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
     using Word = typename WideWord<K>::type;
     extern __shared__ __align__(16) unsigned char w_smem[];
     const int T = static_cast<int>(blockDim.x);
     const int t = static_cast<int>(threadIdx.x);
     const int R = A.R;
+    // References of more than T K columns go through in STRIPS of T K columns, one after the other for every alignment: the last
+    // column of a strip leaves its row state (score, running horizontal jump score, "was a horizontal gap") in a boundary array
+    // in the workgroup's scratch, row by row, and the first thread of the next strip takes its left inputs from there (staged
+    // WIDE_CH rows at a time like the read) instead of from DP column 0.  Codes: one tile per strip.
+    const int CS = T * K;                                             // columns per strip
+    const int nstrips = STRIPS ? (R + CS - 1) / CS : 1;               // (STRIPS = false: the instantiation for references of one strip, without the boundary code)
     double* const s_tab = reinterpret_cast<double*>(w_smem);
     double* const h_s = s_tab + A.tab_doubles;                        // [2][T] score handed to the next thread
     double* const h_lj = h_s + 2 * T;                                 // [2][T] running horizontal jump score
-    int* const h_fl = reinterpret_cast<int*>(h_lj + 2 * T);           // [2][T] the cell was a horizontal gap
-    uint16_t* const s_ring = reinterpret_cast<uint16_t*>(h_fl + 2 * T);   // [WIDE_RING]
+    double* const b_s = h_lj + 2 * T;                                 // [WIDE_CH] boundary rows staged for thread 0: score ...
+    double* const b_lj = b_s + WIDE_CH;                               // ... jump score ...
+    int* const h_fl = reinterpret_cast<int*>(b_lj + WIDE_CH);         // [2][T] the cell was a horizontal gap
+    int* const b_fl = h_fl + 2 * T;                                   // [WIDE_CH] ... and flag
+    uint16_t* const s_ring = reinterpret_cast<uint16_t*>(b_fl + WIDE_CH);   // [WIDE_RING]
     for (int e = t; e < A.tab_doubles; e += T) s_tab[e] = A.tables[e];
     const double NEG_INF = -__builtin_huge_val();
     const double GO = A.GO, GE = A.GE;
     const bool local = A.local != 0;
-    int cb[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) cb[k] = static_cast<int>(A.colbase[min(t * K + k + 1, R)]);
-    const int ncolv = max(0, min(K, R - t * K));   // this thread's columns inside the reference
-    const int tR = (R - 1) / K, kR = (R - 1) % K;
     const long long Rw = T;                        // words per step
+    const long long strip_words = (static_cast<long long>(A.wide_maxlen) + T + 1) * Rw;
     Word* const dirs = MODE ? reinterpret_cast<Word*>(A.dirs) + static_cast<size_t>(blockIdx.x) * A.dirs_per_wave : nullptr;
+    // boundary arrays of the workgroup (two sets, strips alternate): [2][3][longest read + 2] doubles
+    const size_t bstride = static_cast<size_t>(A.wide_maxlen) + 2;
+    double* const bnd = A.wide_bnd + static_cast<size_t>(blockIdx.x) * 6 * bstride;
+    double Sc[K], Dg[K], UJ[K];
     for (long long read = blockIdx.x; read < A.n; read += gridDim.x) {
-        __syncthreads();
         const long long start = A.off[read];
         const int L = static_cast<int>(A.off[read + 1] - start);
-        double Sc[K], Dg[K], UJ[K];
+        for (int st = 0; st < nstrips; ++st) {
+        __syncthreads();
+        const int col0 = st * CS;                                     // columns col0 + 1 .. col0 + Rs
+        const int Rs = min(CS, R - col0);
+        const int ncolv = max(0, min(K, Rs - t * K));                 // this thread's columns inside the strip
+        const int tR = (Rs - 1) / K;
+        const bool bnd_in = STRIPS && st > 0, bnd_out = STRIPS && st + 1 < nstrips;
+        const double* const bi_s = bnd + static_cast<size_t>((st + 1) & 1) * 3 * bstride;   // written by the strip before
+        double* const bo_s = bnd + static_cast<size_t>(st & 1) * 3 * bstride;
+        Word* const sdirs = MODE ? dirs + st * strip_words : nullptr;
+        int cb[K];
         unsigned upneg = 0;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {   // DP row 0 of the thread's columns and of the column to their left (re-read per alignment: 2 K registers less)
-            const int col = min(t * K + k + 1, R);
+        for (int k = 0; k < K; ++k) {   // DP row 0 of the thread's columns and of the column to their left
+            const int col = min(col0 + t * K + k + 1, R);
+            cb[k] = static_cast<int>(A.colbase[col]);
             Sc[k] = A.rowzero[col]; Dg[k] = A.rowzero[col - 1]; UJ[k] = NEG_INF;
         }
         const int nsteps = L > 0 ? L + tR : 0;   // thread tR finishes row L at step L + tR
@@ -915,6 +934,10 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
                             code = b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u;
                         }
                         ent = code * static_cast<uint32_t>(A.row_bytes) + static_cast<uint32_t>(qi << 3);
+                        if (bnd_in) {   // the row state the strip before left in its last column
+                            b_s[e] = bi_s[row]; b_lj[e] = bi_s[bstride + row];
+                            b_fl[e] = static_cast<int>(reinterpret_cast<const long long*>(bi_s + 2 * bstride)[row]);
+                        }
                     }
                     s_ring[row & (WIDE_RING - 1)] = static_cast<uint16_t>(ent);
                 }
@@ -925,10 +948,15 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
             if (i >= 1 && i <= L && ncolv > 0) {
                 double ls, lj;
                 bool lpos;
-                if (t == 0) {   // DP column 0 (src/reference_align.cpp:63-78)
-                    ls = local ? 0.0 : (-GO - GE * static_cast<double>(i - 1));
-                    lj = NEG_INF;
-                    lpos = false;
+                if (t == 0) {
+                    if (bnd_in) {   // (thread 0 is at row s: entry (s - 1) % WIDE_CH of the staged boundary rows)
+                        const int e = (i - 1) % WIDE_CH;
+                        ls = b_s[e]; lj = b_lj[e]; lpos = b_fl[e] != 0;
+                    } else {        // DP column 0 (src/reference_align.cpp:63-78)
+                        ls = local ? 0.0 : (-GO - GE * static_cast<double>(i - 1));
+                        lj = NEG_INF;
+                        lpos = false;
+                    }
                 } else {
                     ls = h_s[(par ^ 1) * T + t - 1];
                     lj = h_lj[(par ^ 1) * T + t - 1];
@@ -939,7 +967,7 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     if (k < ncolv) {
-                        const bool lastcol = local && (t * K + k + 1 == R);   // free vertical gaps in the last column (:93)
+                        const bool lastcol = local && (col0 + t * K + k + 1 == R);   // free vertical gaps in the last column (:93)
                         const double vgo = lastcol ? 0.0 : GO, vge = lastcol ? 0.0 : GE;
                         const bool upn = ((upneg >> k) & 1u) != 0u;
                         double horiz, vert;
@@ -983,10 +1011,17 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
                 h_s[par * T + t] = ls;
                 h_lj[par * T + t] = lj;
                 h_fl[par * T + t] = lpos ? 1 : 0;
-                if (MODE) __builtin_nontemporal_store(w, &dirs[static_cast<long long>(s) * Rw + t]);
+                if (bnd_out && t == tR) {   // the strip's last column: its row state for the next strip
+                    bo_s[i] = ls; bo_s[bstride + i] = lj;
+                    reinterpret_cast<long long*>(bo_s + 2 * bstride)[i] = lpos ? 1 : 0;
+                }
+                if (MODE) __builtin_nontemporal_store(w, &sdirs[static_cast<long long>(s) * Rw + t]);
             }
             __syncthreads();
         }
+        if (bnd_out) __threadfence();
+        if (st + 1 < nstrips) continue;
+        const int kR = (Rs - 1) % K;
         if (t == tR) {
             double sc = Sc[0];
 #pragma unroll
@@ -1004,8 +1039,9 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
                 // run at a time (every lane follows, the outputs are spread over the lanes).
                 const int lane = t;
                 auto nibble = [&](int c, int row) -> unsigned {   // 1 <= c <= R, 1 <= row <= L
-                    const int tt = (c - 1) / K, kk = (c - 1) % K;
-                    const Word w = dirs[static_cast<long long>(row + tt) * Rw + tt];
+                    const int sc = STRIPS ? (c - 1) / CS : 0, cc = (c - 1) - sc * CS;   // strip, column inside it
+                    const int tt = cc / K, kk = cc % K;
+                    const Word w = dirs[sc * strip_words + static_cast<long long>(row + tt) * Rw + tt];
                     return static_cast<unsigned>(w >> (4 * kk)) & 15u;
                 };
                 // direction value the reference stores at (row, c): 0 diagonal, +length horizontal, -length vertical
@@ -1104,6 +1140,7 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
                 }
             }
         }
+        }   // (strips)
     }
 }
 
@@ -1275,14 +1312,15 @@ struct AlignOut {
 // References beyond MAX_REF columns: one workgroup per alignment (k_align_wide).  `a` is complete except for the scratch.
 static int launch_wide(AlignArgs& a, int R, int kernel_mode, int32_t max_len, long long n, hipStream_t stream) {
     Context& c = ctx();
-    // (12 or 16 columns per thread at 2 kb: 3 x slower -- the unrolled columns spill at the 128 registers a 1 024-thread bound leaves)
-    const int K = R <= 8 * WIDE_MAXT ? 8 : 16;
-    if ((R + K - 1) / K > WIDE_MAXT) return fail("sarlacc_amd: reference longer than %d columns is not supported", 16 * WIDE_MAXT);
+    constexpr int K = 8;   // (12 or 16 columns per thread at 2 kb: 3 x slower -- the unrolled columns spill at the 128 registers a 1 024-thread bound leaves)
+    if (R > (1 << 20)) return fail("sarlacc_amd: reference longer than %d columns is not supported", 1 << 20);
     if (kernel_mode == 2 && a.nmask) return fail("sarlacc_amd: alignment strings need ASCII reads");
-    const int T = ((R + K - 1) / K + 63) / 64 * 64;
-    const size_t word = K == 16 ? 8 : 4;
-    size_t per_wg = 0;   // words: codes of every step, then the reference -> read map
-    if (kernel_mode) per_wg = (static_cast<size_t>(max_len) + T + 1) * T + ((static_cast<size_t>(R) + 1) * 4 + word - 1) / word;
+    // up to 8 192 columns one strip of as many threads as the columns need; beyond, strips of 1 024 threads x 8 columns
+    const int T = R <= K * WIDE_MAXT ? ((R + K - 1) / K + 63) / 64 * 64 : WIDE_MAXT;
+    const int nstrips = (R + T * K - 1) / (T * K);
+    const size_t word = 4;
+    size_t per_wg = 0;   // words: codes of every step of every strip, then the reference -> read map
+    if (kernel_mode) per_wg = static_cast<size_t>(nstrips) * (static_cast<size_t>(max_len) + T + 1) * T + ((static_cast<size_t>(R) + 1) * 4 + word - 1) / word;
     long long grid = std::min<long long>(n, static_cast<long long>(c.num_cu) * std::max(1, 2048 / T));
     if (kernel_mode) {
         const size_t budget = static_cast<size_t>(16) << 30;
@@ -1290,20 +1328,29 @@ static int launch_wide(AlignArgs& a, int R, int kernel_mode, int32_t max_len, lo
     }
     void* d_dirs = nullptr;
     if (kernel_mode) SL_TRY(c.buffer("align.dirs", static_cast<size_t>(grid) * per_wg * word, &d_dirs));
+    double* d_bnd = nullptr;
+    SL_TRY(scratch("align.bnd", nstrips > 1 ? static_cast<size_t>(grid) * 6 * (static_cast<size_t>(max_len) + 2) : 8, &d_bnd));
     a.dirs = d_dirs;
     a.dirs_per_wave = per_wg;
-    const size_t lds = sizeof(double) * a.tab_doubles + static_cast<size_t>(T) * (2 * 8 + 2 * 8 + 2 * 4) + WIDE_RING * sizeof(uint16_t);
-    if (lds > 64 * 1024) return fail("sarlacc_amd: alignment tables do not fit in LDS");
+    a.wide_maxlen = max_len;
+    a.wide_bnd = d_bnd;
+    const size_t lds = sizeof(double) * a.tab_doubles + static_cast<size_t>(T) * (2 * 8 + 2 * 8 + 2 * 4) + static_cast<size_t>(WIDE_CH) * (8 + 8 + 4) +
+                       WIDE_RING * sizeof(uint16_t);
+    if (lds > 150 * 1024) return fail("sarlacc_amd: alignment tables do not fit in LDS");
     const dim3 g(static_cast<unsigned>(grid)), b(static_cast<unsigned>(T));
     const bool pensel = !(a.GO >= a.GE) || option(OPT_ALIGN_PENSEL) != 0;   // (gapopen < 0, or the tests' switch)
-#define WIDE_LAUNCH(KK, MM)                                                                   \
-    {                                                                                         \
-        if (pensel) hipLaunchKernelGGL((k_align_wide<KK, MM, true>), g, b, lds, stream, a);   \
-        else hipLaunchKernelGGL((k_align_wide<KK, MM, false>), g, b, lds, stream, a);         \
+#define WIDE_LAUNCH2(MM, PP, SS)                                                                                                   \
+    {                                                                                                                              \
+        if (lds > 48 * 1024)                                                                                                       \
+            SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_align_wide<K, MM, PP, SS>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       static_cast<int>(lds)));                                                                    \
+        hipLaunchKernelGGL((k_align_wide<K, MM, PP, SS>), g, b, lds, stream, a);                                                   \
     }
-    if (K == 8) { if (kernel_mode == 0) WIDE_LAUNCH(8, 0) else if (kernel_mode == 1) WIDE_LAUNCH(8, 1) else WIDE_LAUNCH(8, 2) }
-    else { if (kernel_mode == 0) WIDE_LAUNCH(16, 0) else if (kernel_mode == 1) WIDE_LAUNCH(16, 1) else WIDE_LAUNCH(16, 2) }
+#define WIDE_LAUNCH(MM, PP) { if (nstrips > 1) WIDE_LAUNCH2(MM, PP, true) else WIDE_LAUNCH2(MM, PP, false) }
+    if (pensel) { if (kernel_mode == 0) WIDE_LAUNCH(0, true) else if (kernel_mode == 1) WIDE_LAUNCH(1, true) else WIDE_LAUNCH(2, true) }
+    else { if (kernel_mode == 0) WIDE_LAUNCH(0, false) else if (kernel_mode == 1) WIDE_LAUNCH(1, false) else WIDE_LAUNCH(2, false) }
 #undef WIDE_LAUNCH
+#undef WIDE_LAUNCH2
     SL_HIP(hipGetLastError());
     return 0;
 }

@@ -302,12 +302,13 @@ def test_references_beyond_1024_columns(oracle, oenc, enc):
     """References longer than one wavefront's 64 x 16 columns (qualityAlign of consensus reads against a transcript:
     R/qualityAlign.R:13-15, src/general_align.cpp:12-16; src/reference_align.cpp:7-13 takes any length) run with one
     workgroup per alignment (k_align_wide): scores bit for bit, edit distances, gapped strings, and the adaptor-mode map
-    (starts, ends, sections) -- global and local, IUPAC columns, gap opening below zero, empty and short reads, and the
-    16-columns-per-thread class (references beyond 8 192 columns)."""
+    (starts, ends, sections) -- global and local, IUPAC columns, gap opening below zero, empty and short reads, and
+    references beyond 8 192 columns, which go through in strips of 8 192 (the row state at a strip's last column reaches the
+    next strip through HBM)."""
     from sarlacc_amd import calls
     rng = np.random.default_rng(1025)
     nuc = list("ACGT")
-    for R, nreads, go in ((1025, 12, 5), (2000, 10, 5), (3000, 6, -0.5), (8200, 5, 5)):
+    for R, nreads, go in ((1025, 12, 5), (2000, 10, 5), (3000, 6, -0.5), (8200, 5, 5), (16500, 4, 5)):   # (8 200: two strips of columns; 16 500: three)
         ref = "".join(rng.choice(nuc, R))
         if R == 2000:   # ambiguity codes in the reference (2-fold, 3-fold, N)
             ref = ref[:100] + "RYNNB" + ref[105:1500] + "N" * 20 + ref[1520:]
@@ -331,8 +332,8 @@ def test_references_beyond_1024_columns(oracle, oenc, enc):
             long_reads = [rd + "".join(rng.choice(nuc, 300)) for rd in reads]
             compare_adaptor(oracle, oenc, enc, long_reads, rand_quals(long_reads, R + 1, lo=40, hi=83), ref, go, 1, [10, 0, 1500 % R], [R - 5, 40, R])
     from sarlacc_amd import SarlaccError
-    with pytest.raises(SarlaccError, match="longer than 16384 columns"):
-        calls.barcode_align(["ACGT"], ["IIII"], enc, 5, 1, "A" * 16385)
+    with pytest.raises(SarlaccError, match="longer than 1048576 columns"):
+        calls.barcode_align(["ACGT"], ["IIII"], enc, 5, 1, "A" * ((1 << 20) + 1))
 
 
 def test_error_behaviour(oracle, oenc, enc):

@@ -83,16 +83,19 @@ def case_align_wide(rng):
     """References beyond 1 024 columns (k_align_wide: one workgroup per alignment): every mode, reads from empty to longer
     than the reference, with and without a noisy copy of the reference inside."""
     R = int(rng.choice([1025, 1030, 1088, 1500, 2047, 2048, 2049, 2600]))
+    strips = rng.random() < 0.08   # beyond 8 192 columns: strips of columns (short reads only: the oracle fills every cell)
+    if strips:
+        R = int(rng.choice([8193, 8200, 9000, 16390]))
     n = int(rng.integers(1, 7))
     ref = rstr(rng, R, IUPAC if rng.random() < 0.3 else "ACGT")
     core = "".join(c if c in "ACGT" else "ACGT"[int(rng.integers(0, 4))] for c in ref)
     reads = []
     for _ in range(n):
-        kind = int(rng.integers(0, 4))
+        kind = int(rng.integers(0, 2 if strips else 4))
         if kind == 0:
             reads.append(rstr(rng, int(rng.integers(0, 60)), "ACGTN"))
         elif kind == 1:
-            lo = int(rng.integers(0, R - 200)); hi = int(rng.integers(lo + 1, R + 1))
+            lo = int(rng.integers(0, R - 200)); hi = int(rng.integers(lo + 1, min(R, lo + 600 if strips else R) + 1))
             reads.append("".join(c for c in core[lo:hi] if rng.random() > 0.03))
         else:   # a noisy copy, sometimes with flanks
             body = "".join(("ACGT"[int(rng.integers(0, 4))] if rng.random() < 0.06 else c) for c in core if rng.random() > 0.02)
