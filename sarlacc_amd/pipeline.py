@@ -77,8 +77,8 @@ def run_resident(umis, d_seq, d_qual, off_host, encoding, threshold=1, bandwidth
     gathered = None
     gather_s, gather_bytes = 0.0, 0
     clusters_all_ranks = int(coff.size - 1)
-    label, pos = labels_from_clusters(coff, cmem, n)
     if dist is not None and dist.get_world_size() > 1:
+        label, pos = labels_from_clusters(coff, cmem, n)   # (the wire format of the exchange: nothing to build for a single rank)
         labs, poss, gather_s, gather_bytes = all_gather_labels(label, pos, dist, gather_device)
         gathered = (labs, poss)
         # the exchange's result is what the rest of the pass runs on: this rank's clusters are rebuilt from its
