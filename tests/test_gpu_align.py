@@ -399,6 +399,70 @@ def test_device_resident_and_packed_paths(oracle, oenc, enc):
         assert np.array_equal(bits(sc2.cpu().numpy()), bits(oracle.barcode_align(reads, quals, oenc, 5, 1, adaptor)))
 
 
+def test_wide_references_on_resident_packed_and_chunked_paths(oracle, oenc, enc):
+    """k_align_wide behind the other entry points: sarlacc_dev_align on resident ASCII reads and on the 2-bit packed format
+    (reads with non-ACGT bases; local mode with sections, global scores), and a host call cut into upload chunks
+    (option align_chunks: every chunk one launch on a slice, sections strided over the whole batch, the first bad quality of
+    the batch reported)."""
+    torch = pytest.importorskip("torch")
+    from sarlacc_amd import SarlaccError, calls
+    from sarlacc_amd import device as sdev
+    from sarlacc_amd.mock import random_reads
+    from sarlacc_amd.strset import StringSet
+    rng = np.random.default_rng(1500)
+    ref = "".join(rng.choice(list("ACGT"), 1500))
+    ref = ref[:700] + "NNNNRY" + ref[706:]
+    reads, quals = random_reads(60, 0, 500, seed=78, alphabet=b"ACGTACGTACGTNR")
+    for k in range(0, 60, 7):   # some reads that carry a piece of the reference
+        lo = int(rng.integers(0, 1200))
+        piece = ref[lo:lo + int(rng.integers(50, 300))].replace("N", "A").replace("R", "G").replace("Y", "T")
+        reads[k] = reads[k][:100] + piece + reads[k][100:]
+        quals[k] = quals[k][:100] + "I" * len(piece) + quals[k][100:]
+    want = oracle.adaptor_align(reads, quals, oenc, 5, 1, ref, [700, 10], [706, 1400])
+    want_global = oracle.barcode_align(reads, quals, oenc, 5, 1, ref)
+    s, q = StringSet.from_strings(reads), StringSet.from_strings(quals)
+    dev = torch.device("cuda", 0)
+    n, total = len(s), s.total
+    d_seq = torch.from_numpy(s.chars).to(dev)
+    d_qual = torch.from_numpy(q.chars).to(dev)
+    d_off = torch.from_numpy(s.off).to(dev)
+    max_len = int(s.widths().max())
+    stream = torch.cuda.current_stream().cuda_stream
+    packed = torch.zeros(total // 4 + 2, dtype=torch.uint8, device=dev)
+    nmask = torch.zeros(total // 8 + 1, dtype=torch.uint8, device=dev)
+    sdev.dev_pack_reads(d_seq, total, packed, nmask, stream)
+    for seq_buf, mask in ((d_seq, None), (packed, nmask)):
+        sc = torch.zeros(n, dtype=torch.float64, device=dev)
+        st = torch.zeros(n, dtype=torch.int32, device=dev)
+        en = torch.zeros_like(st)
+        so = torch.zeros(2 * n, dtype=torch.int32, device=dev)
+        sw = torch.zeros_like(so)
+        sdev.dev_align(seq_buf, d_qual, d_off, n, max_len, enc, 5, 1, ref, True, [700, 10], [706, 1400], sc, st, en, so, sw,
+                       stream, d_nmask=mask)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(sc.cpu().numpy()), bits(want[0]))
+        assert np.array_equal(st.cpu().numpy(), want[1]) and np.array_equal(en.cpu().numpy(), want[2])
+        assert np.array_equal(so.cpu().numpy().reshape(2, n), np.stack(want[3])) and np.array_equal(sw.cpu().numpy().reshape(2, n), np.stack(want[4]))
+        sc2 = torch.zeros(n, dtype=torch.float64, device=dev)
+        sdev.dev_align(seq_buf, d_qual, d_off, n, max_len, enc, 5, 1, ref, False, (), (), sc2, None, None, None, None,
+                       stream, d_nmask=mask)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(sc2.cpu().numpy()), bits(want_global))
+    calls.set_option("align_chunks", 3)
+    try:
+        got = calls.adaptor_align(reads, quals, enc, 5, 1, ref, [700, 10], [706, 1400])
+        assert np.array_equal(bits(got[0]), bits(want[0])) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+        for k in range(2):
+            assert np.array_equal(got[3][k], want[3][k]) and np.array_equal(got[4][k], want[4][k])
+        assert np.array_equal(bits(calls.barcode_align(reads, quals, enc, 5, 1, ref)), bits(want_global))
+        bad_q = list(quals)
+        bad_q[50] = " " + bad_q[50][1:]
+        with pytest.raises(SarlaccError, match="quality cannot be lower"):
+            calls.adaptor_align(reads, bad_q, enc, 5, 1, ref, [700], [706])
+    finally:
+        calls.set_option("align_chunks", 0)
+
+
 def test_unmask_alignment(oracle):
     """unmask_alignment (src/unmask_alignment.cpp): reference literals, random rows wider than one
     wave step, and the reference's error cases (tests/testthat/test-masking.R:45-100)."""
