@@ -350,6 +350,27 @@ def test_tile_sharded_pairs_reproduce_umi_group(oracle, split_min):
         calls.set_option("umi_split_min", 0)
 
 
+@pytest.mark.parametrize("length", [50, 200])
+def test_tile_sharded_pairs_of_long_strings(oracle, length):
+    """The same for strings beyond one code word (4 words up to 128 bases, word planes from HBM beyond): the shards of the
+    multi-GPU search put together give umi_group's result."""
+    from sarlacc_amd import calls
+    rng = np.random.default_rng(length)
+    umis = []
+    for _ in range(90):
+        umis += umisim(rng, 8, length, rate=0.02)
+    umis = [umis[i] for i in rng.permutation(len(umis))]
+    g = [list(range(1, len(umis) + 1))]
+    for limit in (1, 4):
+        want = calls.umi_group(umis, limit, None, limit, g)
+        same_lists(want, oracle.umi_group(umis, limit, None, limit, g))
+        for world in (1, 3):
+            parts = [calls.umi_pairs_shard(umis, limit, r, world) for r in range(world)]
+            allp = np.concatenate(parts)
+            assert len(np.unique(allp)) == allp.size
+            same_lists(calls.umi_group_from_pairs(umis, limit, allp), want)
+
+
 def test_umi_group_flat_matches_lists():
     """CSR in / CSR out variant used by the large-batch pipeline: same clusters, same order."""
     from sarlacc_amd import calls
