@@ -894,11 +894,6 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
     const size_t bstride = static_cast<size_t>(A.wide_maxlen) + 2;
     double* const bnd = A.wide_bnd + static_cast<size_t>(blockIdx.x) * 6 * bstride;
     double Sc[K], Dg[K], UJ[K];
-    // Without penalty selects the flags of the traceback modes stay lane masks in scalar registers, as in k_align: a comparison
-    // writes its mask, the flag logic is scalar, and a code bit enters the word by one v_addc (push_bit) -- the codes of a cell
-    // cost 4 comparisons + 4 vector instructions instead of 4 + ~12 (bools in vector registers, shifts and ors).
-    constexpr bool MASKS = MODE != 0 && !PENSEL;
-    mask_t upm[K];   // MASKS: per column, "the cell above was a vertical gap"
     for (long long read = blockIdx.x; read < A.n; read += gridDim.x) {
         const long long start = A.off[read];
         const int L = static_cast<int>(A.off[read + 1] - start);
@@ -914,8 +909,6 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
         Word* const sdirs = MODE ? dirs + st * strip_words : nullptr;
         int cb[K];
         unsigned upneg = 0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) upm[k] = 0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {   // DP row 0 of the thread's columns and of the column to their left
             const int col = min(col0 + t * K + k + 1, R);
@@ -971,40 +964,6 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
                 }
                 const int ent = s_ring[i & (WIDE_RING - 1)];
                 Word w = 0;
-                if constexpr (MASKS) {
-                    mask_t lposm = __ballot(lpos);
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        if (k < ncolv) {
-                            const bool lastcol = local && (col0 + t * K + k + 1 == R);   // free vertical gaps in the last column (:93)
-                            const double vgo = lastcol ? 0.0 : GO, vge = lastcol ? 0.0 : GE;
-                            const mask_t on = __ballot(true);
-                            const double hopen = ls - GO, vopen = Sc[k] - vgo;
-                            lj -= GE;
-                            const mask_t m_hc = __ballot(lj > hopen) & ~lposm;
-                            const double horiz = fmax(lj, hopen);
-                            lj = horiz;
-                            const double uj = UJ[k] - vge;
-                            const mask_t m_vc = __ballot(uj > vopen) & ~upm[k];
-                            const double vert = fmax(uj, vopen);
-                            UJ[k] = vert;
-                            const double cost = *reinterpret_cast<const double*>(reinterpret_cast<const unsigned char*>(s_tab) + cb[k] + ent);
-                            const double match = Dg[k] + cost;
-                            Dg[k] = ls;
-                            const double hv = fmax(horiz, vert);
-                            const double cur = fmax(match, hv);
-                            const mask_t m_d = __ballot(match > hv), m_h = __ballot(horiz > vert);
-                            Sc[k] = cur;
-                            ls = cur;
-                            lposm = m_h & ~m_d;                 // this cell is a horizontal gap
-                            upm[k] = on & ~m_h & ~m_d;          // ... a vertical one
-                            // nibble, first bit on top: diagonal | horizontal beats vertical | horizontal jump continued | vertical jump continued
-                            w = push_bit(push_bit(push_bit(push_bit(static_cast<uint32_t>(w), m_d), m_h), m_hc), m_vc);
-                        }
-                    }
-                    w <<= 4 * (K - ncolv);   // (cell k of the thread always sits in nibble K - 1 - k)
-                    lpos = sel32(0, 1, lposm) != 0;
-                } else {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     if (k < ncolv) {
@@ -1049,7 +1008,6 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
                         if (MODE) w |= static_cast<Word>(kind | (hc ? 4u : 0u) | (vc ? 8u : 0u)) << (4 * k);
                     }
                 }
-                }
                 h_s[par * T + t] = ls;
                 h_lj[par * T + t] = lj;
                 h_fl[par * T + t] = lpos ? 1 : 0;
@@ -1084,10 +1042,6 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
                     const int sc = STRIPS ? (c - 1) / CS : 0, cc = (c - 1) - sc * CS;   // strip, column inside it
                     const int tt = cc / K, kk = cc % K;
                     const Word w = dirs[sc * strip_words + static_cast<long long>(row + tt) * Rw + tt];
-                    if (MASKS) {   // the fill's own bit order (see there) -> move | horizontal continued << 2 | vertical continued << 3
-                        const unsigned nb = static_cast<unsigned>(w >> (4 * (K - 1 - kk))) & 15u;
-                        return ((nb & 8u) ? 0u : ((nb & 4u) ? 1u : 2u)) | ((nb & 2u) << 1) | ((nb & 1u) << 3);
-                    }
                     return static_cast<unsigned>(w >> (4 * kk)) & 15u;
                 };
                 // direction value the reference stores at (row, c): 0 diagonal, +length horizontal, -length vertical
