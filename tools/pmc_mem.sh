@@ -48,8 +48,10 @@ for k in sorted(tot):
     for c in sorted(t):
         print("   %-44s %16.6g  (%d launches)" % (c, t[c], calls[(k, c)]))
     g = lambda n: t.get(n, float("nan"))
-    cyc = g("GRBM_GUI_ACTIVE@m1")
+    cyc = g("GRBM_GUI_ACTIVE@m1") / 8.0   # (the counter comes summed over the 8 XCDs)
+    print("   kernel cycles (per XCD)                     %.4g" % cyc)
     print("   TA busy per TA and cycle (256 TAs)          %.3f" % (g("TA_TA_BUSY_sum") / (cyc * 256)))
+    print("   L1 stalled on pending data, per L1 and cycle %.3f" % (g("TCP_PENDING_STALL_CYCLES_sum") / (g("GRBM_GUI_ACTIVE@m2b") / 8.0 * 256)))
     print("   cycles per wave-wide read in the TAs        %.1f" % (g("TA_TA_BUSY_sum") / g("TA_FLAT_READ_WAVEFRONTS_sum")))
     print("   L1 -> L2 read latency (cycles)              %.0f" % (g("TCP_TCC_READ_REQ_LATENCY_sum") / g("TCP_TCC_READ_REQ_sum")))
     print("   L1 accesses per L1 -> L2 read request       %.2f" % (g("TCP_TOTAL_CACHE_ACCESSES_sum") / g("TCP_TCC_READ_REQ_sum")))
@@ -60,7 +62,7 @@ for k in sorted(tot):
     print("   L2 -> fabric read latency (cycles)          %.0f" % (g("TCC_EA0_RDREQ_LEVEL_sum") / rd))
     wr = g("TCC_EA0_WRREQ_sum"); w64 = g("TCC_EA0_WRREQ_64B_sum")
     print("   fabric writes: %.4g requests (64 B: %.3g) = %.4g bytes" % (wr, w64, 64 * w64 + 32 * (wr - w64)))
-    print("   DRAM read credit stall cycles / (cycles x 16 channels x 8 XCDs) %.3f" % (g("TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum") / (g("GRBM_GUI_ACTIVE@m6") * 128)))
+    print("   DRAM read credit stall cycles / (cycles x 16 channels x 8 XCDs) %.3f" % (g("TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum") / (g("GRBM_GUI_ACTIVE@m6") / 8.0 * 128)))
 PY
 find "$OUT" -name "*counter_collection.csv" -size +20M -delete
 find "$OUT" -type f ! -name '*.csv' ! -name '*.log' -delete
