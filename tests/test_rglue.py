@@ -114,33 +114,50 @@ def test_makevars_links_the_library():
     assert "-lsarlacc_amd" in mk and "-I$(SARLACC_AMD_HOME)/include" in mk
 
 
-def test_shims_parse_and_type_check():
+# the four scalar checkers of the reference package's utils.h that the shims call: name -> C++ return type
+CHECKERS = {"check_integer_scalar": "int", "check_numeric_scalar": "double", "check_logical_scalar": "bool", "check_string": "std::string"}
+
+
+def _write_package_headers(where):
+    """sarlacc.h and utils.h of the shimmed package stay in that package; for the syntax check their declarations are written
+    here from the tables above (routine -> arity; checker -> return type), nothing is kept in the tree."""
+    with open(os.path.join(where, "sarlacc.h"), "w") as fh:
+        fh.write('#pragma once\n#include "Rcpp.h"\nextern "C" {\n')
+        for name, arity in ROUTINES.items():
+            fh.write("SEXP %s(%s);\n" % (name, ", ".join(["SEXP"] * arity)))
+        fh.write("}\n")
+    with open(os.path.join(where, "utils.h"), "w") as fh:
+        fh.write('#pragma once\n#include "Rcpp.h"\n#include <string>\n')
+        for name, ret in CHECKERS.items():
+            fh.write("%s %s(Rcpp::RObject, const char*);\n" % (ret, name))
+
+
+def test_shims_parse_and_type_check(tmp_path):
     """Every shim goes through the compiler's front end (g++ -fsyntax-only) against declaration-only stand-ins for the
-    headers it includes (tests/rglue_stubs: the shapes of the Rcpp / Biostrings calls the shims make, the reference
-    package's own sarlacc.h / utils.h) and the REAL include/sarlacc_amd.h: a typo, a missing argument or a wrong
-    pointer type inside a shim body fails here, which the text checks above cannot see.  Nothing is built or linked."""
+    headers it includes (tests/rglue_stubs: the shapes of the Rcpp / Biostrings calls the shims make; the shimmed package's
+    own sarlacc.h / utils.h are generated into tmp_path from ROUTINES / CHECKERS) and the REAL include/sarlacc_amd.h: a typo,
+    a missing argument or a wrong pointer type inside a shim body fails here, which the text checks above cannot see.
+    Nothing is built or linked."""
     import shutil
     import subprocess
     gxx = shutil.which("g++")
     if gxx is None:
         pytest.skip("no g++")
     stubs = os.path.join(ROOT, "tests", "rglue_stubs")
+    gen = str(tmp_path)
+    _write_package_headers(gen)
+    inc = ["-I", gen, "-I", stubs, "-I", os.path.join(ROOT, "include"), "-I", GLUE]
     shims = sorted(f for f in os.listdir(GLUE) if f.endswith(".cpp"))
     assert len(shims) >= 13
     for f in shims:
-        res = subprocess.run([gxx, "-std=c++14", "-fsyntax-only", "-Wall", "-Werror=return-type", "-I", stubs,
-                              "-I", os.path.join(ROOT, "include"), "-I", GLUE, os.path.join(GLUE, f)],
+        res = subprocess.run([gxx, "-std=c++14", "-fsyntax-only", "-Wall", "-Werror=return-type"] + inc + [os.path.join(GLUE, f)],
                              capture_output=True, text=True, timeout=120)
         assert res.returncode == 0, "%s:\n%s" % (f, res.stderr[-3000:])
     # and the check bites: a shim with a wrong argument type does not pass
-    bad = os.path.join(stubs, "_bad_probe.cpp")
+    bad = os.path.join(gen, "_bad_probe.cpp")
     with open(bad, "w") as fh:
         fh.write('#include "sarlacc.h"\n#include "utils.h"\n#include "flatten.h"\n'
                  'SEXP mask_bad_bases(SEXP a, SEXP b, SEXP c, SEXP d) { BEGIN_RCPP Flat s = flatten(a, true); '
                  'return Rcpp::List::create(sarlacc_mask_bad_bases(s.off.data())); END_RCPP }\n')
-    try:
-        res = subprocess.run([gxx, "-std=c++14", "-fsyntax-only", "-I", stubs, "-I", os.path.join(ROOT, "include"), "-I", GLUE, bad],
-                             capture_output=True, text=True, timeout=120)
-        assert res.returncode != 0
-    finally:
-        os.remove(bad)
+    res = subprocess.run([gxx, "-std=c++14", "-fsyntax-only"] + inc + [bad], capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0
