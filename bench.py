@@ -168,79 +168,144 @@ def cpu_baseline_pipeline(umi_strings, threshold, groups, read_strings, qual_str
 def giant_group_leg(args, rank, world, dist, device, gather_device, backend, enc, mol, fence, reduce):
     """BASELINE configs[4] as it is worded, in the bench line for N > 1: the reads of ALL ranks as ONE pre-group (R/umiGroup.R:12-14:
     no `groups` argument = one pre-group; src/umi_group.cpp:35) -- the one case of the path with a real exchange.  Row tiles of the
-    all-pairs neighbour search per rank (sarlacc_umi_pairs_shard), all-gather of the neighbour pairs over RCCL, the exact
-    clustering replicated on every rank, the clusters dealt to the ranks by their bases for multiReadAlign + consensusReadSeq.
-    Every rank holds every rank's reads in HBM (on a real run every rank reads the same FASTQ files; 4 GB per 10^6 reads), so
-    regrouping reads by cluster moves nothing.  Weak scaling like the rest of the line: N x --molecules molecules."""
+    all-pairs neighbour search per rank (sarlacc_dev_umi_pairs_shard), all-gather of the neighbour pairs over RCCL (device tensors,
+    the pairs never leave HBM), the exact clustering replicated on every rank, the clusters dealt to the ranks by their bases for
+    multiReadAlign + consensusReadSeq.  Every rank holds every rank's reads in HBM (on a real run every rank reads the same FASTQ
+    files; 4 GB per 10^6 reads), so regrouping reads by cluster moves nothing.  Weak scaling like the rest of the line:
+    N x --giant-molecules molecules.
+
+    FAIL-SAFE: the leg never takes the bench line down.  Every local step runs under try/except and the ranks agree on its outcome
+    (shard.agree: a 4-byte all-reduce) BEFORE the next collective, so a failure on one rank -- out of memory, the 2^32-link stop --
+    is raised on all of them together instead of leaving the others waiting; whatever is raised ends up as {"error": ...} in the
+    line, which still carries the headline and the pipeline legs.
+
+    `--giant-virtual-ranks V` on ONE GPU (world == 1) rehearses the leg at the size an N = V run has: V shares of reads, the whole
+    tile search, the exchange through a one-rank RCCL group, the replicated clustering at full size, the clusters dealt to V
+    owners and the MSA + consensus of owner 0's share -- the single-GPU cost of every step of an N = V run but the xGMI transfer."""
+    import torch
+    from sarlacc_amd import shard
+    virtual = world == 1
+    own_group = False
+    try:
+        if virtual and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group(backend, rank=0, world_size=1)
+            own_group = True
+        return _giant_group_leg(args, rank, world, dist, device, gather_device, backend, enc, mol, fence, reduce)
+    except Exception as e:   # noqa: BLE001 -- the leg reports, it never raises (see the docstring)
+        import traceback
+        free_b, total_b = torch.cuda.mem_get_info()
+        mem = {"hbm_free_gb": free_b / 1e9, "hbm_total_gb": total_b / 1e9, "torch_allocated_gb": torch.cuda.memory_allocated() / 1e9,
+               "torch_reserved_gb": torch.cuda.memory_reserved() / 1e9}
+        torch.cuda.empty_cache()
+        return {"error": "%s: %s" % (type(e).__name__, e), "where": traceback.format_exc(limit=3).strip().splitlines()[-3:], "memory_at_failure": mem,
+                "note": "the giant pre-group leg failed (agreed by all ranks before the next collective); the rest of the line is unaffected"}
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+
+
+def _giant_group_leg(args, rank, world, dist, device, gather_device, backend, enc, mol, fence, reduce):
     import numpy as np
     import torch
     from sarlacc_amd import _lib, calls, devsynth, shard
     from sarlacc_amd import device as sdev
     from sarlacc_amd.strset import StringSet
-    # share r is what rank r's own pipeline pass ran on (seed 2000 + r)
-    seqs, quals, umis_c, lens, ulens = [], [], [], [], []
-    for r in range(world):
-        sh = mol if r == rank else devsynth.make_molecule_reads(args.molecules, args.copies, args.read_len, seed=2000 + r, device=device)
-        seqs.append(sh["seq"]); quals.append(sh["qual"])
-        lens.append(torch.diff(sh["off"]).cpu().numpy())
-        umis_c.append(sh["umi"].cpu().numpy()); ulens.append(torch.diff(sh["umi_off"]).cpu().numpy())
-        del sh
-    seq, qual = torch.cat(seqs), torch.cat(quals)
-    del seqs, quals
-    off = np.zeros(sum(x.size for x in lens) + 1, np.int64)
-    np.cumsum(np.concatenate(lens), out=off[1:])
-    uoff = np.zeros(off.size, np.int64)
-    np.cumsum(np.concatenate(ulens), out=uoff[1:])
-    umis = StringSet(np.concatenate(umis_c), uoff)
-    n_all = off.size - 1
-    widths = np.diff(off)
+    shares = args.giant_virtual_ranks if world == 1 else world   # shares of reads = owners of clusters
+    molecules = args.giant_molecules if args.giant_molecules > 0 else args.molecules
+    # share r is what rank r's own pipeline pass ran on (seed 2000 + r) when the sizes are the pipeline's
+    err = None
+    seq = qual = off = umis = widths = None
+    n_all = 0
+    try:
+        seqs, quals, umis_c, lens, ulens = [], [], [], [], []
+        for r in range(shares):
+            reuse = mol is not None and r == rank and molecules == args.molecules
+            sh = mol if reuse else devsynth.make_molecule_reads(molecules, args.copies, args.read_len, seed=2000 + r, device=device)
+            seqs.append(sh["seq"]); quals.append(sh["qual"])
+            lens.append(torch.diff(sh["off"]).cpu().numpy())
+            umis_c.append(sh["umi"].cpu().numpy()); ulens.append(torch.diff(sh["umi_off"]).cpu().numpy())
+            del sh
+        seq = torch.cat(seqs)
+        del seqs
+        qual = torch.cat(quals)
+        del quals
+        off = np.zeros(sum(x.size for x in lens) + 1, np.int64)
+        np.cumsum(np.concatenate(lens), out=off[1:])
+        uoff = np.zeros(off.size, np.int64)
+        np.cumsum(np.concatenate(ulens), out=uoff[1:])
+        umis = StringSet(np.concatenate(umis_c), uoff)
+        n_all = off.size - 1
+        widths = np.diff(off)
+        torch.cuda.empty_cache()   # (the generator's temporaries and the shares' own copies go back to the device: the library allocates beside torch)
+    except Exception as e:   # noqa: BLE001
+        err = e
+    shard.agree(dist, err, gather_device)
 
     def one_pass():
         st = {}
         fence()
         t0 = time.perf_counter()
-        coff, cmem = shard.sharded_umi_group_tiles(umis, args.threshold, calls, dist, gather_device, flat=True, stats=st)
+        coff, cmem = shard.sharded_umi_group_tiles(umis, args.threshold, calls, dist, gather_device, flat=True, stats=st)   # (agrees by itself)
         t1 = time.perf_counter()
-        sizes = np.diff(coff)
-        big = np.flatnonzero(sizes >= 2)
-        bases = np.add.reduceat(widths[cmem.astype(np.int64) - 1], coff[:-1]) if cmem.size else np.zeros(0)
-        owner = shard.assign_groups_snake(bases[big], world)
-        keep = np.zeros(sizes.size, bool)
-        keep[big[owner == rank]] = True
-        goff, gflat = calls.csr_select(coff, cmem, keep)
-        t2 = time.perf_counter()
-        cons, phred = sdev.dev_msa_consensus(goff, gflat, seq, qual, off, 0, -1, -5, -1, 100, 0.6, encoding=enc)
+        e1, res = None, None
+        try:
+            umi_stats = {k: _lib.stage_count(k) for k in ("umi_links", "umi_cluster_rounds", "umi_adjacency_s", "umi_cluster_s")}
+            umi_ms = _lib.stage_ms("umi_pairs")
+            umi_ws = _lib.release_umi_workspace()   # (17 GB at 8 x 10^6 reads: the MSA stage's batches are sized from what is free)
+            sizes = np.diff(coff)
+            big = np.flatnonzero(sizes >= 2)
+            bases = np.add.reduceat(widths[cmem.astype(np.int64) - 1], coff[:-1]) if cmem.size else np.zeros(0)
+            owner = shard.assign_groups_snake(bases[big], shares)
+            keep = np.zeros(sizes.size, bool)
+            keep[big[owner == rank]] = True
+            goff, gflat = calls.csr_select(coff, cmem, keep)
+            t2 = time.perf_counter()
+            cons, phred = sdev.dev_msa_consensus(goff, gflat, seq, qual, off, 0, -1, -5, -1, 100, 0.6, encoding=enc)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            free_b, total_b = torch.cuda.mem_get_info()
+            res = {"t": (t1 - t0, t2 - t1, t3 - t2, t3 - t0), "st": st, "coff": coff, "cmem": cmem, "big": big, "owner": owner,
+                   "cons": cons, "phred": phred, "gflat": gflat, "largest_cluster": int(sizes.max()) if sizes.size else 0,
+                   "hbm_in_use_gb": (total_b - free_b) / 1e9, "v1_fallback": _lib.stage_count("msa_v1_fallback"),
+                   "kernel_ms": dict({k: _lib.stage_ms(k) for k in ("msa_pairwise", "msa_merge", "consensus")}, umi_pairs=umi_ms),
+                   "umi": umi_stats, "umi_workspace_gb": umi_ws / 1e9}
+        except Exception as e:   # noqa: BLE001
+            e1 = e
+        shard.agree(dist, e1, gather_device)
         fence()
-        t3 = time.perf_counter()
-        return {"t": (t1 - t0, t2 - t1, t3 - t2, t3 - t0), "st": st, "coff": coff, "cmem": cmem, "big": big, "owner": owner,
-                "cons": cons, "phred": phred, "gflat": gflat,
-                "kernel_ms": {k: _lib.stage_ms(k) for k in ("umi_pairs", "msa_pairwise", "msa_merge", "consensus")}}
+        return res
 
     first = one_pass()
     first_t = first["t"][3]
     del first
     r = one_pass()
     tm = reduce(list(r["t"]) + [first_t, r["st"].get("search_s", 0.0), r["st"].get("exchange_s", 0.0), r["st"].get("clustering_s", 0.0)]
-                + [r["kernel_ms"][k] for k in ("umi_pairs", "msa_pairwise", "msa_merge", "consensus")], dist.ReduceOp.MAX)
+                + [r["kernel_ms"][k] for k in ("umi_pairs", "msa_pairwise", "msa_merge", "consensus")] + [r["hbm_in_use_gb"]], dist.ReduceOp.MAX)
     sm = reduce([float(len(r["cons"])), float(r["cons"].total), float(r["gflat"].size), float(r["st"].get("bytes_received", 0)),
-                 float(r["st"].get("pairs_here", 0)), 1.0], dist.ReduceOp.SUM)
+                 float(r["st"].get("pairs_here", 0)), 1.0, float(r["v1_fallback"])], dist.ReduceOp.SUM)
     # ---- identical to a single rank?  The clusters: rank 0 runs the unsharded umi_group on the same UMIs.  The consensus reads:
     # a sample of clusters spread over the owners, recomputed by rank 0 (it holds every read) and compared with the owners' strings.
     big, owner = r["big"], r["owner"]
-    pick = np.unique(np.linspace(0, big.size - 1, num=min(big.size, 256 * world)).astype(np.int64)) if big.size else np.zeros(0, np.int64)
+    pick = np.unique(np.linspace(0, big.size - 1, num=min(big.size, 256 * shares)).astype(np.int64)) if big.size else np.zeros(0, np.int64)
     mine_rank = np.cumsum(owner == rank) - 1   # position of an owned cluster among this rank's clusters (csr_select keeps the order)
     sample = {}
     for k in pick.tolist():
         if owner[k] == rank:
             j = int(mine_rank[k])
             sample[int(k)] = (bytes(r["cons"].chars[r["cons"].off[j]:r["cons"].off[j + 1]]), bytes(r["phred"].chars[r["phred"].off[j]:r["phred"].off[j + 1]]))
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(sample, gathered, dst=0)
+    gathered = [None] * max(world, 1)
+    dist.all_gather_object(gathered, sample)   # (all_gather underneath: the one object collective every backend here carries)
     res = None
-    if rank == 0:
+    if rank == 0:   # (no collective below this line)
+        t0 = time.perf_counter()
         ref_off, ref_mem = calls.umi_group_flat(umis, args.threshold, None, args.threshold, np.array([0, n_all], np.int64),
                                                 np.arange(1, n_all + 1, dtype=np.int32))
+        single_s = time.perf_counter() - t0
         clusters_same = bool(np.array_equal(ref_off, r["coff"]) and np.array_equal(ref_mem, r["cmem"]))
+        if world == 1:   # (rehearsal: only owner 0's share was aligned here)
+            pick = pick[owner[pick] == 0]
         keep = np.zeros(r["coff"].size - 1, bool)
         keep[big[pick]] = True
         goff_s, gflat_s = calls.csr_select(r["coff"], r["cmem"], keep)
@@ -255,17 +320,27 @@ def giant_group_leg(args, rank, world, dist, device, gather_device, backend, enc
         wall = tm[3]
         res = {"reads": int(n_all), "reads_per_min": n_all / wall * 60.0, "seconds": wall, "first_pass_seconds": tm[4],
                "stage_s": {"umi_group_tiles_exchange_clustering": tm[0], "deal_clusters": tm[1], "msa_consensus": tm[2]},
-               "umi_group_s": {"tile_search": tm[5], "pair_exchange": tm[6], "replicated_clustering": tm[7]},
+               "umi_group_s": {"tile_search": tm[5], "pair_exchange": tm[6], "replicated_clustering": tm[7],
+                               "replicated_clustering_kernels_only": {"adjacency_from_pairs": r["umi"]["umi_adjacency_s"], "greedy_rounds": r["umi"]["umi_cluster_s"],
+                                                                      "rounds": int(r["umi"]["umi_cluster_rounds"]), "links": r["umi"]["umi_links"]},
+                               "unsharded_umi_group_on_rank_0": single_s},
                "kernel_ms": dict(zip(("umi_pairs", "msa_pairwise", "msa_merge", "consensus"), tm[8:12])),
-               "exchange": {"collective": "all_gather of the neighbour pairs (8 B each) + their counts", "backend": backend,
-                            "pairs": int(sm[4]), "bytes_received_total": int(sm[3]), "seconds": tm[6]},
+               "exchange": {"collective": "all_gather_into_tensor of the neighbour pairs (8 B each) + their counts", "backend": backend,
+                            "pairs": int(sm[4]), "bytes_received_total": int(sm[3]), "seconds": tm[6],
+                            "pairs_stay_in_hbm": bool(r["st"].get("pairs_on_device", False))},
                "n_ranks_seen": int(sm[5]), "clusters": int(r["coff"].size - 1), "clusters_of_two_and_more": int(big.size),
+               "largest_cluster": r["largest_cluster"], "groups_aligned_by_spec_v1": int(sm[6]), "hbm_in_use_gb_max": tm[12],
+               "umi_workspace_released_before_msa_gb": r["umi_workspace_gb"],
                "consensus_reads": int(sm[0]), "consensus_bases": int(sm[1]), "reads_in_clusters": int(sm[2]),
                "identical_to_single_rank": {"clusters": clusters_same, "consensus_of_sampled_clusters": bool(same), "sampled_clusters": int(pick.size)},
                "workload": "BASELINE configs[4] as worded, weak scaling: the %d x %d reads of all ranks as ONE pre-group (umiGroup without "
                            "`groups`), threshold %d: tile-sharded neighbour search -> all-gather of the pairs -> replicated exact clustering -> "
                            "clusters dealt to the ranks by their bases -> multiReadAlign + consensusReadSeq; every rank holds every read in HBM"
-                           % (world, args.molecules * args.copies, args.threshold)}
+                           % (shares, molecules * args.copies, args.threshold)}
+        if world == 1:
+            res["rehearsal"] = ("ONE GPU standing in for rank 0 of %d: the whole tile search (an N = %d rank does 1/%d of it), the exchange through a one-rank "
+                                "RCCL group, the replicated clustering at full size, owner 0's share of the clusters aligned; reads_per_min is not a "
+                                "throughput claim" % (shares, shares, shares))
     del seq, qual
     torch.cuda.empty_cache()
     return res
@@ -285,6 +360,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
     ap.add_argument("--no-host-pointer", action="store_true", help="skip the PCIe-inclusive host-pointer figures")
+    ap.add_argument("--giant-molecules", type=int, default=0,
+                    help="molecules per GPU of the giant pre-group leg (N > 1; 0 = --molecules).  Rehearsed on one GPU up to 10^6 "
+                         "molecules = 10^7 reads in one pre-group (profiles/r05_giant_*): the default is inside that at N = 8")
+    ap.add_argument("--giant-virtual-ranks", type=int, default=0,
+                    help="on ONE GPU: rehearse the giant pre-group leg at the size of an N = V run (see giant_group_leg)")
+    ap.add_argument("--no-giant", action="store_true", help="skip the giant pre-group leg of N > 1 runs")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
@@ -715,10 +796,10 @@ def main():
                 "msa2_entries_filtered": c4["entries_filtered"],
                 "workload": "multiReadAlign + consensusReadSeq on %d groups x %d reads x %d bp per GPU (the molecules as groups)" % (
                     args.molecules, args.copies, args.read_len)}
-        if world > 1:
+        if (world > 1 and not args.no_giant) or (world == 1 and args.giant_virtual_ranks > 0):
             del cons_p, _ph
             sarlacc_amd._lib.lib().sarlacc_release_workspace()
-            gg = giant_group_leg(args, rank, world, dist, device, gather_device, backend, enc, mol, fence, reduce)
+            gg = giant_group_leg(args, rank, world, dist, device, device if world == 1 else gather_device, backend, enc, mol, fence, reduce)
             if rank == 0:
                 out["pipeline"]["giant_group"] = gg
         if rank == 0 and not args.no_cpu:

@@ -46,6 +46,10 @@ int sarlacc_device_count(void);
 int sarlacc_set_device(int device);
 /* Release cached device workspaces (and the idle page-locked host blocks of sarlacc_host_alloc). */
 void sarlacc_release_workspace(void);
+/* Frees only the cached device buffers of the umi_group stage (the neighbour search, the sorted link lists, the clustering:
+ * 17 GB after a call on 8 x 10^6 UMIs) -- for pipelines that go on to the MSA stage in the same process and want that memory
+ * for it.  Returns the number of bytes given back. */
+int64_t sarlacc_release_umi_workspace(void);
 /* Duration in ms of a named group of kernel launches of the last call that ran it (HIP events on
  * the launch stream, summed over the batches of the call): "msa_pairwise", "msa_merge", "consensus", "umi_pairs";
  * <0 if it never ran. */
@@ -277,6 +281,22 @@ int sarlacc_umi_pairs_shard(const char* umi, const int64_t* off, int64_t n, int 
 int sarlacc_umi_group_from_pairs(const char* umi, const int64_t* off, int64_t n, int limit,
                                  const uint64_t* pairs, int64_t npairs,
                                  int64_t* nclusters, int64_t* clu_off, int32_t* clu);
+
+/* The same exchange with the pairs kept in HBM (at 8 x 10^6 reads the lists hold 10^8 pairs; nothing of them crosses
+ * PCIe): sarlacc_dev_umi_pairs_shard searches the shard's row tiles and leaves its pairs in the library's workspace on the
+ * device, reporting their number; sarlacc_dev_umi_pairs_fetch copies them (device to device) into a caller buffer of at
+ * least that many entries -- e.g. the send buffer of an RCCL all-gather -- and must be the next library call of the thread;
+ * sarlacc_dev_umi_group_from_pairs clusters from a DEVICE array of pairs (validated on the device; the call waits for the
+ * device first, so a collective on another stream has finished writing them).
+ * Limits shared by every umi_group entry point: strings of at most 1024 bases (longer ones only alone in their pre-group),
+ * characters ACGTN only, and at most 2^32 - 1 neighbour links (self links included) per call -- the lists are explicit as in
+ * src/umi_group.cpp:59-103; a threshold that joins most of a large set must be lowered or the reads split into pre-groups. */
+int sarlacc_dev_umi_pairs_shard(const char* umi, const int64_t* off, int64_t n, int limit,
+                                int shard_index, int shard_count, int64_t* npairs);
+int sarlacc_dev_umi_pairs_fetch(uint64_t* d_pairs, int64_t cap);
+int sarlacc_dev_umi_group_from_pairs(const char* umi, const int64_t* off, int64_t n, int limit,
+                                     const uint64_t* d_pairs, int64_t npairs,
+                                     int64_t* nclusters, int64_t* clu_off, int32_t* clu);
 
 /* ------------------------------------------------------------------ */
 /* per-group MSA and consensus                                           */

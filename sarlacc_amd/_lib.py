@@ -70,6 +70,7 @@ def lib():
         _lib.sarlacc_last_kernel_ms.restype = C.c_double
         _lib.sarlacc_stage_ms.restype = C.c_double
         _lib.sarlacc_stage_count.restype = C.c_double
+        _lib.sarlacc_release_umi_workspace.restype = C.c_int64
     return _lib
 
 
@@ -127,6 +128,11 @@ def device_count():
 
 def set_device(device):
     check(lib().sarlacc_set_device(int(device)))
+
+
+def release_umi_workspace():
+    """sarlacc_release_umi_workspace: gives the umi_group stage's cached device buffers back (bytes freed)."""
+    return int(lib().sarlacc_release_umi_workspace())
 
 
 def stage_ms(name):

@@ -505,6 +505,38 @@ def umi_group_from_pairs(umi, limit, pairs, flat=False):
     return lists_from_csr(co, cl, ncl.value)
 
 
+def dev_umi_pairs_shard(umi, limit, shard_index, shard_count):
+    """sarlacc_dev_umi_pairs_shard: the shard's neighbour pairs stay in the library's workspace on the device; returns
+    their number.  dev_umi_pairs_fetch must be the next library call."""
+    s = StringSet.from_strings(umi)
+    need = C.c_int64(0)
+    check(_lib.lib().sarlacc_dev_umi_pairs_shard(ptr(s.chars), ptr(s.off), C.c_int64(len(s)), _integer(limit, "limit"), int(shard_index),
+                                                 int(shard_count), C.byref(need)))
+    return int(need.value)
+
+
+def dev_umi_pairs_fetch(d_pairs, cap):
+    """sarlacc_dev_umi_pairs_fetch: copies the pairs of the shard search just run into device memory (a torch tensor of
+    8-byte elements or a raw address) holding at least `cap` entries."""
+    addr = d_pairs.data_ptr() if hasattr(d_pairs, "data_ptr") else int(d_pairs)
+    check(_lib.lib().sarlacc_dev_umi_pairs_fetch(C.c_void_p(addr), C.c_int64(int(cap))))
+
+
+def dev_umi_group_from_pairs(umi, limit, d_pairs, npairs, flat=False):
+    """sarlacc_dev_umi_group_from_pairs: umi_group of a single pre-group from neighbour pairs held in device memory."""
+    s = StringSet.from_strings(umi)
+    n = len(s)
+    ncl = C.c_int64(0)
+    co = np.zeros(n + 2, np.int64)
+    cl = np.zeros(max(n, 1), np.int32)
+    addr = d_pairs.data_ptr() if hasattr(d_pairs, "data_ptr") else int(d_pairs or 0)
+    check(_lib.lib().sarlacc_dev_umi_group_from_pairs(ptr(s.chars), ptr(s.off), C.c_int64(n), _integer(limit, "limit"), C.c_void_p(addr),
+                                                      C.c_int64(int(npairs)), C.byref(ncl), ptr(co), ptr(cl)))
+    if flat:
+        return co[:ncl.value + 1], cl[:int(co[ncl.value])]
+    return lists_from_csr(co, cl, ncl.value)
+
+
 # ---------------------------------------------------------------------------
 # alignment profiling (SURVEY 8 f4)
 def find_homopolymers(sequences):

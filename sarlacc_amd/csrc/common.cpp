@@ -175,6 +175,29 @@ void sarlacc_release_workspace(void) {
     (void)sarlacc_host_release();   // the idle page-locked result blocks as well
 }
 
+int64_t sarlacc_release_umi_workspace(void) {
+    // every buffer umi.hip asks for carries one of these prefixes (encode_and_rank / pair_edges: "u1.", "u2."; the uploads of
+    // the entry points: "g1.", "g2.", "g.", "ps", "lv", "lev"; adjacency "adj."; clustering "cl.")
+    static const char* const prefixes[] = {"u1.", "u2.", "g1.", "g2.", "g.", "ps.", "ps", "lv.", "lv", "lev.", "lev", "adj.", "cl."};
+    sarlacc::Context& c = sarlacc::ctx();
+    int64_t freed = 0;
+    for (auto it = c.ws.begin(); it != c.ws.end();) {
+        bool mine = false;
+        for (const char* pf : prefixes) {
+            const size_t n = std::strlen(pf);
+            const bool whole = pf[n - 1] != '.';   // names without a dot must match entirely
+            if (whole ? it->first == pf : it->first.compare(0, n, pf) == 0) { mine = true; break; }
+        }
+        if (mine) {
+            if (it->second.ptr) { (void)hipFree(it->second.ptr); freed += static_cast<int64_t>(it->second.cap); }
+            it = c.ws.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    return freed;
+}
+
 double sarlacc_stage_ms(const char* name) {
     sarlacc::Context& c = sarlacc::ctx();
     if (!c.ready || !name) return -1.0;

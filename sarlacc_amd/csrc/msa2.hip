@@ -1584,7 +1584,14 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         if (rows_ws.cap >= need) return 0;
         const size_t want = std::max(need, rows_ws.cap + rows_ws.cap / 2) + 4096;
         void* np = nullptr;
-        if (hipMalloc(&np, want) != hipSuccess) return fail("sarlacc_amd: cannot allocate %zu bytes of device memory for the alignment rows", want);
+        if (hipMalloc(&np, want) != hipSuccess) {
+            size_t fb = 0, tb = 0;
+            (void)hipGetLastError();
+            (void)hipMemGetInfo(&fb, &tb);
+            size_t held = 0;
+            for (const auto& kv : c.ws) held += kv.second.cap;
+            return fail("sarlacc_amd: cannot allocate %zu bytes of device memory for the alignment rows (%zu free of %zu, the library's workspaces hold %zu)", want, fb, tb, held);
+        }
         if (rows_ws.ptr) {
             if (used) SL_HIP(hipMemcpyAsync(np, rows_ws.ptr, used, hipMemcpyDeviceToDevice, s));
             SL_HIP(hipStreamSynchronize(s));

@@ -1861,11 +1861,15 @@ struct DirectedKeys {
 // All neighbour pairs within `limit`, as sorted directed keys (self links included).
 // Undirected neighbour pairs (rank_i << 32 | rank_j) of the row tiles [tile_lo, tile_hi)
 // (tile_hi < 0: all tiles).  The buffer stays on the device: *d_edges_out, *m_out.
+// number of pairs the last sarlacc_dev_umi_pairs_shard of this thread left in the workspace (-1: none)
+static thread_local long long g_shard_pairs = -1;
+
 static int pair_edges(const std::string& p, const SortedUmis& S, int limit, int tile_lo, int tile_hi,
                       unsigned long long** d_edges_out, unsigned long long* m_out, hipStream_t s) {
     Context& c = ctx();
     const int n = S.n;
     const int nt = static_cast<int>(nblk(n, TILE));
+    g_shard_pairs = -1;   // (the buffer a sarlacc_dev_umi_pairs_shard call left its pairs in is about to be reused)
     if (tile_hi < 0) { tile_lo = 0; tile_hi = nt; }
     tile_lo = std::max(0, std::min(tile_lo, nt));
     tile_hi = std::max(tile_lo, std::min(tile_hi, nt));
@@ -2313,6 +2317,14 @@ static int cluster_dev(const DevAdj& adj, int n, const int32_t* d_members, const
     return 0;
 }
 
+// pairs handed in from outside (the exchange of a tile-sharded search): i < j < n, rank_i << 32 | rank_j
+__global__ void k_check_pairs(const unsigned long long* __restrict__ pairs, long long m, unsigned long long n, int* __restrict__ bad) {
+    const long long e = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= m) return;
+    const unsigned long long a = pairs[e] >> 32, b = pairs[e] & 0xffffffffull;
+    if (a >= n || b >= n || a >= b) *bad = 1;
+}
+
 static int upload_strings(const char* tag, const char* chars, const int64_t* off, int64_t n, uint8_t** d_chars,
                           int64_t** d_off, hipStream_t s) {
     const int64_t base = n ? off[0] : 0;
@@ -2538,6 +2550,40 @@ int sarlacc_umi_pairs_shard(const char* umi, const int64_t* off, int64_t n, int 
     return 0;
 }
 
+// clustering of ONE pre-group from its neighbour pairs, which are already on the device (validated there)
+static int group_from_device_pairs(const char* umi, const int64_t* off, int64_t n, int limit, const unsigned long long* d_edges,
+                                   int64_t npairs, int64_t* nclusters, int64_t* clu_off, int32_t* clu, hipStream_t s) {
+    uint8_t* d_c; int64_t* d_o;
+    SL_TRY(upload_strings("ps", umi, off, n, &d_c, &d_o, s));
+    SortedUmis S;
+    SL_TRY(encode_and_rank("u1", d_c, d_o, nullptr, nullptr, 1, static_cast<int>(n), &S, s));
+    int* d_bad;
+    SL_TRY(scratch("ps.badpair", 1, &d_bad));
+    SL_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), s));
+    if (npairs) hipLaunchKernelGGL(k_check_pairs, dim3(nblk(npairs, 256)), dim3(256), 0, s, d_edges, static_cast<long long>(npairs), static_cast<unsigned long long>(n), d_bad);
+    int bad = 0;
+    SL_HIP(hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    if (bad) return fail("sarlacc_amd: malformed neighbour pair");
+    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    DirectedKeys K;
+    SL_TRY(keys_from_edges("u1", S, limit < 0 ? -1 : limit, nullptr, d_edges, static_cast<unsigned long long>(npairs), &K, s));
+    DevAdj adj;
+    SL_TRY(adjacency_from_keys("adj", K.keys, K.nk, S.perm, static_cast<int>(n), &adj, s));
+    SL_HIP(hipStreamSynchronize(s));
+    const double t1 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    ClusterResult res;
+    SL_TRY(cluster_dev(adj, static_cast<int>(n), nullptr, nullptr, 1, false, &res, s));
+    ctx().counts["umi_adjacency_s"] = t1 - t0;
+    ctx().counts["umi_cluster_s"] = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t1;
+    std::vector<long long> co(static_cast<size_t>(res.nclu) + 1);
+    SL_HIP(hipMemcpy(co.data(), res.d_coff, sizeof(long long) * co.size(), hipMemcpyDeviceToHost));
+    if (res.total) SL_HIP(hipMemcpy(clu, res.d_out, sizeof(int32_t) * static_cast<size_t>(res.total), hipMemcpyDeviceToHost));
+    for (long long c = 0; c <= res.nclu; ++c) clu_off[c] = co[c];
+    *nclusters = res.nclu;
+    return 0;
+}
+
 int sarlacc_umi_group_from_pairs(const char* umi, const int64_t* off, int64_t n, int limit, const uint64_t* pairs,
                                  int64_t npairs, int64_t* nclusters, int64_t* clu_off, int32_t* clu) {
     if (n < 0 || npairs < 0) return fail("sarlacc_amd: negative sizes");
@@ -2548,29 +2594,64 @@ int sarlacc_umi_group_from_pairs(const char* umi, const int64_t* off, int64_t n,
         clu[0] = 1; clu_off[1] = 1; *nclusters = 1;
         return 0;
     }
-    for (int64_t e = 0; e < npairs; ++e) {
-        const uint64_t a = pairs[e] >> 32, b = pairs[e] & 0xffffffffull;
-        if (a >= static_cast<uint64_t>(n) || b >= static_cast<uint64_t>(n) || a >= b) return fail("sarlacc_amd: malformed neighbour pair");
-    }
     SL_TRY(ensure_device());
     hipStream_t s = nullptr;
+    unsigned long long* d_edges;
+    SL_TRY(upload("u1.edges_in", reinterpret_cast<const unsigned long long*>(pairs), static_cast<size_t>(npairs), &d_edges, s));
+    return group_from_device_pairs(umi, off, n, limit, d_edges, npairs, nclusters, clu_off, clu, s);
+}
+
+// ---- the pair exchange with the pairs kept in HBM (one giant pre-group over several GPUs: 10^8 pairs at 8 x 10^6 reads) ----
+int sarlacc_dev_umi_pairs_shard(const char* umi, const int64_t* off, int64_t n, int limit, int shard_index,
+                                int shard_count, int64_t* npairs) {
+    if (n < 0 || shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail("sarlacc_amd: bad shard request");
+    *npairs = 0;
+    g_shard_pairs = -1;
+    SL_TRY(ensure_device());
+    hipStream_t s = nullptr;
+    if (n == 0 || limit < 0) { g_shard_pairs = 0; return 0; }
     uint8_t* d_c; int64_t* d_o;
     SL_TRY(upload_strings("ps", umi, off, n, &d_c, &d_o, s));
     SortedUmis S;
     SL_TRY(encode_and_rank("u1", d_c, d_o, nullptr, nullptr, 1, static_cast<int>(n), &S, s));
+    int lo, hi;
+    shard_tiles(static_cast<int>(nblk(n, TILE)), shard_index, shard_count, &lo, &hi);
     unsigned long long* d_edges;
-    SL_TRY(upload("u1.edges_in", reinterpret_cast<const unsigned long long*>(pairs), static_cast<size_t>(npairs), &d_edges, s));
-    DirectedKeys K;
-    SL_TRY(keys_from_edges("u1", S, limit < 0 ? -1 : limit, nullptr, d_edges, static_cast<unsigned long long>(npairs), &K, s));
-    DevAdj adj;
-    SL_TRY(adjacency_from_keys("adj", K.keys, K.nk, S.perm, static_cast<int>(n), &adj, s));
-    ClusterResult res;
-    SL_TRY(cluster_dev(adj, static_cast<int>(n), nullptr, nullptr, 1, false, &res, s));
-    std::vector<long long> co(static_cast<size_t>(res.nclu) + 1);
-    SL_HIP(hipMemcpy(co.data(), res.d_coff, sizeof(long long) * co.size(), hipMemcpyDeviceToHost));
-    if (res.total) SL_HIP(hipMemcpy(clu, res.d_out, sizeof(int32_t) * static_cast<size_t>(res.total), hipMemcpyDeviceToHost));
-    for (long long c = 0; c <= res.nclu; ++c) clu_off[c] = co[c];
-    *nclusters = res.nclu;
+    unsigned long long m;
+    SL_TRY(pair_edges("u1", S, limit, lo, hi, &d_edges, &m, s));
+    g_shard_pairs = static_cast<long long>(m);   // (they stay in the workspace buffer "u1.edges" until the next search or release)
+    *npairs = static_cast<int64_t>(m);
     return 0;
+}
+
+int sarlacc_dev_umi_pairs_fetch(uint64_t* d_pairs, int64_t cap) {
+    if (g_shard_pairs < 0) return fail("sarlacc_amd: no neighbour pairs to fetch (sarlacc_dev_umi_pairs_shard must be the call before)");
+    if (cap < g_shard_pairs) return fail("sarlacc_amd: pair buffer too small (%lld needed)", g_shard_pairs);
+    if (g_shard_pairs == 0) return 0;
+    auto it = ctx().ws.find("u1.edges");
+    if (it == ctx().ws.end() || !it->second.ptr || it->second.cap < sizeof(uint64_t) * static_cast<size_t>(g_shard_pairs)) {
+        g_shard_pairs = -1;
+        return fail("sarlacc_amd: the neighbour pairs of the last shard search are gone (workspace released)");
+    }
+    if (!d_pairs) return fail("sarlacc_amd: null pair buffer");
+    SL_HIP(hipMemcpy(d_pairs, it->second.ptr, sizeof(uint64_t) * static_cast<size_t>(g_shard_pairs), hipMemcpyDeviceToDevice));
+    return 0;
+}
+
+int sarlacc_dev_umi_group_from_pairs(const char* umi, const int64_t* off, int64_t n, int limit, const uint64_t* d_pairs,
+                                     int64_t npairs, int64_t* nclusters, int64_t* clu_off, int32_t* clu) {
+    if (n < 0 || npairs < 0) return fail("sarlacc_amd: negative sizes");
+    if (npairs && !d_pairs) return fail("sarlacc_amd: null pair buffer");
+    *nclusters = 0;
+    clu_off[0] = 0;
+    if (n == 0) return 0;
+    if (n == 1) {  // a pre-group of one read passes through (src/umi_group.cpp:39-42)
+        clu[0] = 1; clu_off[1] = 1; *nclusters = 1;
+        return 0;
+    }
+    SL_TRY(ensure_device());
+    hipStream_t s = nullptr;
+    SL_HIP(hipDeviceSynchronize());   // the caller's collective wrote d_pairs on a stream of its own
+    return group_from_device_pairs(umi, off, n, limit, reinterpret_cast<const unsigned long long*>(d_pairs), npairs, nclusters, clu_off, clu, s);
 }
 }

@@ -132,35 +132,96 @@ def sharded_over_reads(fn, n, dist=None):
     return lo, hi, fn(lo, hi)
 
 
+class ShardError(RuntimeError):
+    """A step of a sharded call failed on some rank; raised on EVERY rank (see agree)."""
+
+
+def agree(dist, error=None, device=None):
+    """Every rank reports whether its last local step worked (error = None) and all learn whether every rank's did: one
+    4-byte all-reduce.  A rank that failed must not simply raise -- the others would wait in the next collective for
+    ever -- so local steps run under try/except and meet here; if any rank failed, all raise ShardError."""
+    import torch
+    flag = torch.tensor([0 if error is None else 1], dtype=torch.int32, device=device if device is not None else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        raise ShardError("rank %d: %s" % (dist.get_rank(), error) if error is not None else "another rank failed (rank %d did not)" % dist.get_rank())
+
+
 def sharded_umi_group_tiles(umi, threshold, calls, dist=None, device=None, flat=False, stats=None):
     """umi_group of ONE giant pre-group with the row tiles of the all-pairs matrix spread over the
     ranks.  Every rank holds all UMIs (they are 12 bytes each), searches its
     share of the tiles, all-gathers the neighbour pairs (counts first, then the padded lists) and
     runs the clustering on the concatenation -- replicated, deterministic, identical to the
-    single-GPU result.  `stats` (a dict, optional) receives the seconds of the search, of the exchange and of the
-    clustering, the pairs found here and overall, and the bytes this rank received."""
+    single-GPU result.  With `device` (RCCL) the pairs never leave HBM: the search leaves them in the library's workspace,
+    they are fetched into the send buffer, gathered with all_gather_into_tensor and clustered from the device
+    (sarlacc_dev_umi_pairs_shard / _fetch / sarlacc_dev_umi_group_from_pairs); without (gloo, CPU tensors) they go through
+    host arrays.  A local failure on any rank (out of memory, too many links) is agreed between the ranks before the next
+    collective and raised on all of them as ShardError.  `stats` (a dict, optional) receives the seconds of the search, of
+    the exchange and of the clustering, the pairs found here and overall, and the bytes this rank received."""
     import time
+    kw = {"flat": True} if flat else {}
     if dist is None:   # (a process group of one rank goes through the collectives below: the RCCL path on a one-GPU box)
-        return calls.umi_group_from_pairs(umi, threshold, calls.umi_pairs_shard(umi, threshold, 0, 1), **({"flat": True} if flat else {}))
+        return calls.umi_group_from_pairs(umi, threshold, calls.umi_pairs_shard(umi, threshold, 0, 1), **kw)
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
+    on_device = device is not None
     t0 = time.perf_counter()
-    mine = calls.umi_pairs_shard(umi, threshold, rank, world).astype(np.int64)  # values < 2^63: safe as int64
+    mine, m, err = None, -1, None
+    try:
+        if on_device:
+            m = calls.dev_umi_pairs_shard(umi, threshold, rank, world)
+        else:
+            mine = calls.umi_pairs_shard(umi, threshold, rank, world).astype(np.int64)  # values < 2^63: safe as int64
+            m = int(mine.size)
+    except Exception as e:   # noqa: BLE001 -- whatever it was, the other ranks must hear of it
+        err = e
     t1 = time.perf_counter()
-    counts = _all_gather(np.array([mine.size], dtype=np.int32), dist, device)
-    counts = [int(c[0]) for c in counts]
-    width = max(max(counts), 1)
-    padded = np.zeros(width, dtype=np.int64)
-    padded[:mine.size] = mine
-    t = torch.from_numpy(padded)
-    if device is not None:
-        t = t.to(device)
-    parts = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(parts, t)
-    allpairs = np.concatenate([p.cpu().numpy()[:c] for p, c in zip(parts, counts)]).astype(np.uint64)
-    t2 = time.perf_counter()
-    out = calls.umi_group_from_pairs(umi, threshold, allpairs, **({"flat": True} if flat else {}))
+    # the counts double as the agreement on the search: -1 = this rank's search failed
+    cnt = torch.tensor([m], dtype=torch.int64, device=device if on_device else "cpu")
+    cnts = torch.empty(world, dtype=torch.int64, device=cnt.device)
+    dist.all_gather_into_tensor(cnts, cnt)
+    counts = [int(c) for c in cnts.cpu().tolist()]
+    if min(counts) < 0:
+        raise ShardError("rank %d: %s" % (rank, err) if err is not None else "the neighbour search failed on rank %d" % counts.index(min(counts)))
+    width, total = max(max(counts), 1), sum(counts)
+    send = parts = None
+    try:
+        if on_device:
+            send = torch.empty(width, dtype=torch.int64, device=device)
+            calls.dev_umi_pairs_fetch(send, width)
+            if width > m:
+                send[m:].zero_()
+        else:
+            padded = np.zeros(width, dtype=np.int64)
+            padded[:m] = mine
+            send = torch.from_numpy(padded)
+        parts = torch.empty(world * width, dtype=torch.int64, device=send.device)
+    except Exception as e:   # noqa: BLE001
+        err = e
+    agree(dist, err, device)
+    dist.all_gather_into_tensor(parts, send)
+    out = None
+    try:
+        del send
+        if any(c != width for c in counts):   # ragged shards: close the gaps (on the device: one concatenation of views)
+            allpairs = torch.cat([parts[r * width:r * width + c] for r, c in enumerate(counts)])
+            del parts
+        else:
+            allpairs = parts
+        if on_device:
+            torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        if on_device:
+            out = calls.dev_umi_group_from_pairs(umi, threshold, allpairs, total, **kw)
+        else:
+            out = calls.umi_group_from_pairs(umi, threshold, allpairs.numpy().view(np.uint64), **kw)
+        del allpairs
+    except Exception as e:   # noqa: BLE001
+        err = e
+        t2 = time.perf_counter()
+    agree(dist, err, device)
     if stats is not None:
-        stats.update({"search_s": t1 - t0, "exchange_s": t2 - t1, "clustering_s": time.perf_counter() - t2, "pairs_here": int(mine.size),
-                      "pairs_all": int(allpairs.size), "bytes_received": int(8 * width * (world - 1) + 4 * (world - 1))})
+        stats.update({"search_s": t1 - t0, "exchange_s": t2 - t1, "clustering_s": time.perf_counter() - t2, "pairs_here": m,
+                      "pairs_all": total, "bytes_received": int(8 * width * (world - 1) + 8 * (world - 1)),
+                      "pairs_on_device": bool(on_device)})
     return out

@@ -194,3 +194,67 @@ def test_two_rank_label_all_gather():
         rebuilt = [cmem[coff[k]:coff[k + 1]].tolist() for k in range(coff.size - 1)]
         assert rebuilt == results[r][1]
         assert results[r][4] == 2 * 4 * len(results[0][2][r])   # bytes received from the one other rank
+
+
+class _FailingCalls:
+    """oracle_calls with one step failing on one rank: what a rank out of memory, or at the 2^32-link stop, looks like"""
+
+    def __init__(self, base, step, on_rank, rank):
+        self._base, self._step, self._fail = base, step, on_rank == rank
+
+    def __getattr__(self, name):
+        fn = getattr(self._base, name)
+        if name == self._step and self._fail:
+            def boom(*a, **k):
+                raise RuntimeError("injected failure in " + name)
+            return boom
+        return fn
+
+
+def _worker_tiles_failing(rank, world, port, q, step, on_rank):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from sarlacc_amd import shard
+    from tests import oracle_calls
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        from tests.test_oracle_umi import umisim
+        rng = np.random.default_rng(3)
+        umis = []
+        for _ in range(20):
+            umis += umisim(rng, 9, 10)
+        try:
+            shard.sharded_umi_group_tiles(umis, 1, _FailingCalls(oracle_calls, step, on_rank, rank), dist)
+            q.put((rank, "no error"))
+        except shard.ShardError as e:
+            q.put((rank, "ShardError: %s" % e))
+        # the ranks left the call TOGETHER: the next collective still works, and so does a second, healthy call
+        dist.barrier()
+        out = shard.sharded_umi_group_tiles(umis, 1, oracle_calls, dist)
+        q.put((rank, len(out)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("step,on_rank", [("umi_pairs_shard", 1), ("umi_group_from_pairs", 0)])
+def test_a_failure_on_one_rank_is_raised_on_all_before_the_next_collective(step, on_rank):
+    """bench.py's giant pre-group leg must never hang an N-GPU run: a local failure -- in the tile search of one rank, in the
+    replicated clustering of another -- is agreed between the ranks (shard.agree) and raised on every one of them as
+    ShardError; nobody is left waiting in the all-gather, and the process group stays usable."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_tiles_failing, args=(r, 2, port, q, step, on_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    msgs = {r: m for r, m in got if isinstance(m, str)}
+    assert set(msgs) == {0, 1} and all(m.startswith("ShardError") for m in msgs.values()), msgs
+    assert "injected failure in " + step in msgs[on_rank]            # the failing rank names its error,
+    assert "injected failure" not in msgs[1 - on_rank]               # the other one only learns that somebody failed
+    counts = [m for r, m in got if isinstance(m, int)]
+    assert len(counts) == 2 and counts[0] == counts[1] > 0

@@ -371,6 +371,61 @@ def test_tile_sharded_pairs_of_long_strings(oracle, length):
             same_lists(calls.umi_group_from_pairs(umis, limit, allp), want)
 
 
+def test_pair_exchange_with_the_pairs_kept_on_the_device(oracle):
+    """The device-resident form of the exchange (sarlacc_dev_umi_pairs_shard / _fetch / sarlacc_dev_umi_group_from_pairs: what
+    shard.sharded_umi_group_tiles runs over RCCL): the shards' pairs, fetched into device tensors and put together on the
+    device, are the host entry points' pairs and give umi_group's clusters; misuse is refused with a message."""
+    import torch
+    from sarlacc_amd import _lib, calls
+    from sarlacc_amd._lib import SarlaccError
+    rng = np.random.default_rng(33)
+    umis = []
+    for _ in range(260):
+        umis += umisim(rng, 8, 12, rate=0.06)
+    umis = [umis[i] for i in rng.permutation(len(umis))]
+    g = [list(range(1, len(umis) + 1))]
+    for limit in (1, 2):
+        want = calls.umi_group(umis, limit, None, limit, g)
+        same_lists(want, oracle.umi_group(umis, limit, None, limit, g, fast=True))
+        for world in (1, 3):
+            parts = []
+            for r in range(world):
+                m = calls.dev_umi_pairs_shard(umis, limit, r, world)
+                t = torch.full((m + 3,), -1, dtype=torch.int64, device="cuda")
+                calls.dev_umi_pairs_fetch(t, m + 3)
+                assert bool((t[m:] == -1).all())                      # nothing written beyond the count
+                assert np.array_equal(np.sort(t[:m].cpu().numpy().view(np.uint64)), np.sort(calls.umi_pairs_shard(umis, limit, r, world)))
+                parts.append(t[:m])
+            allp = torch.cat(parts)
+            same_lists(calls.dev_umi_group_from_pairs(umis, limit, allp, allp.numel()), want)
+            co, cm = calls.dev_umi_group_from_pairs(umis, limit, allp, allp.numel(), flat=True)
+            assert [cm[co[k]:co[k + 1]].tolist() for k in range(co.size - 1)] == [list(c) for c in want]
+    # a fetch that does not follow a shard search, a buffer that is too small, a malformed pair
+    calls.umi_group(umis, 1, None, 1, g)
+    with pytest.raises(SarlaccError, match="no neighbour pairs to fetch"):
+        calls.dev_umi_pairs_fetch(torch.zeros(8, dtype=torch.int64, device="cuda"), 8)
+    m = calls.dev_umi_pairs_shard(umis, 1, 0, 1)
+    assert m > 8
+    with pytest.raises(SarlaccError, match="pair buffer too small"):
+        calls.dev_umi_pairs_fetch(torch.zeros(8, dtype=torch.int64, device="cuda"), 8)
+    bad = torch.tensor([(5 << 32) | 5], dtype=torch.int64, device="cuda")   # i < j is required
+    with pytest.raises(SarlaccError, match="malformed neighbour pair"):
+        calls.dev_umi_group_from_pairs(umis, 1, bad, 1)
+    with pytest.raises(SarlaccError, match="malformed neighbour pair"):
+        calls.umi_group_from_pairs(umis, 1, np.array([(5 << 32) | len(umis)], np.uint64))
+    # no pairs at all: every read alone (and a self link each, threshold 0 on distinct strings aside)
+    solo = calls.dev_umi_group_from_pairs(["ACGTACGTAAAA", "TTTTGGGGCCCC", "GAGAGAGAGAGA"], 1, None, 0)
+    same_lists(solo, calls.umi_group(["ACGTACGTAAAA", "TTTTGGGGCCCC", "GAGAGAGAGAGA"], 1, None, 1, [[1, 2, 3]]))
+    m = calls.dev_umi_pairs_shard(umis, 1, 0, 1)
+    assert _lib.release_umi_workspace() > 8 * m and _lib.release_umi_workspace() == 0   # (the stage's buffers only, and only once)
+    with pytest.raises(SarlaccError, match="are gone"):
+        calls.dev_umi_pairs_fetch(torch.zeros(m, dtype=torch.int64, device="cuda"), m)
+    same_lists(calls.umi_group(umis, 1, None, 1, g), oracle.umi_group(umis, 1, None, 1, g, fast=True))   # and the stage simply allocates again
+    _lib.lib().sarlacc_release_workspace()
+    with pytest.raises(SarlaccError, match="no neighbour pairs to fetch|are gone"):
+        calls.dev_umi_pairs_fetch(torch.zeros(8, dtype=torch.int64, device="cuda"), 8)
+
+
 def test_umi_group_flat_matches_lists():
     """CSR in / CSR out variant used by the large-batch pipeline: same clusters, same order."""
     from sarlacc_amd import calls

@@ -47,6 +47,12 @@ for n in sizes:
                   _lib.stage_count("umi_cluster_s"), int(_lib.stage_count("umi_cluster_rounds")), int(_lib.stage_count("umi_cluster_candidate_rounds")),
                   int(_lib.stage_count("umi_cluster_full_rounds")), sz.size, int((sz == 1).sum()), int(sz.max()), float(sz[sz > 1].mean()) if (sz > 1).any() else 0.0,
                   (total - free) / 1e9, part, same), flush=True)
+    bins = [2, 3, 5, 9, 13, 17, 25, 33, 49, 65, 10**9]
+    big = sz[sz >= 2].astype(np.float64)
+    cube = big ** 3
+    print("      clusters of two and more by size (count, share of the reads in them, share of sum n^3 = the merge stage's work): " + "; ".join(
+        "%d-%s: %d, %.3f, %.3f" % (lo, ("%d" % (hi - 1)) if hi < 10**9 else "", int(((big >= lo) & (big < hi)).sum()), big[(big >= lo) & (big < hi)].sum() / big.sum(),
+                                   cube[(big >= lo) & (big < hi)].sum() / cube.sum()) for lo, hi in zip(bins[:-1], bins[1:])), flush=True)
     if tiles:
         st = {}
         torch.cuda.synchronize()
