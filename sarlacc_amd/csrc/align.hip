@@ -856,6 +856,118 @@ constexpr int WIDE_MAXT = 1024;
 template <int K>
 struct WideWord { using type = uint32_t; };
 
+// The walk of one alignment of k_align_wide / k_align_wide_q, run by ONE wavefront (lane = 0 .. 63) after the codes of every
+// strip are in `dirs` (word of thread tt at step s: dirs[strip * strip_words + s * Rw + tt], column k of the thread in nibble K - 1 - k).
+template <int K, int MODE, bool STRIPS>
+__device__ __forceinline__ void wide_walk(const AlignArgs& A, typename WideWord<K>::type* dirs, long long strip_words, int CS, long long Rw,
+                                          int L, int R, long long read, long long start, int lane) {
+    using Word = typename WideWord<K>::type;
+    // The walk, on the first wavefront: the path of a global alignment of like sequences is mostly diagonal, so lane m
+    // looks at the cell m steps up the diagonal from (row, c), a ballot gives the length of the diagonal run and its
+    // moves are written side by side -- one memory round trip per run instead of one per cell; gaps are taken one
+    // run at a time (every lane follows, the outputs are spread over the lanes).
+    auto nibble = [&](int c, int row) -> unsigned {   // 1 <= c <= R, 1 <= row <= L
+        const int sc = STRIPS ? (c - 1) / CS : 0, cc = (c - 1) - sc * CS;   // strip, column inside it
+        const int tt = cc / K, kk = cc % K;
+        const Word w = dirs[sc * strip_words + static_cast<long long>(row + tt) * Rw + tt];
+        return static_cast<unsigned>(w >> (4 * (K - 1 - kk))) & 15u;
+    };
+    // direction value the reference stores at (row, c): 0 diagonal, +length horizontal, -length vertical
+    auto loadD = [&](int c, int row) -> int {
+        if (row <= 0) return 1;   // D[c][0] = 1 (:118)
+        const unsigned nb = nibble(c, row);
+        if ((nb & 3u) == 0u) return 0;
+        int len = 1;
+        if ((nb & 3u) == 1u) {
+            unsigned f = nb;
+            for (int x = c; (f & 4u) && x > 1;) { ++len; --x; f = nibble(x, row); }
+            return len;
+        }
+        unsigned f = nb;
+        for (int y = row; (f & 8u) && y > 1;) { ++len; --y; f = nibble(c, y); }
+        return -len;
+    };
+    auto diag_run = [&](int c, int row) -> int {   // diagonal moves from (row, c) on, at most 64
+        const int rr = row - lane, cc = c - lane;
+        const bool stop = !(rr >= 1 && cc >= 1) || (nibble(cc, rr) & 3u) != 0u;
+        const unsigned long long nd = __ballot(stop);
+        return nd ? static_cast<int>(__builtin_ctzll(nd)) : 64;
+    };
+    int row = L, c = R;
+    if (MODE == 1) {
+        const unsigned long long map_words = (static_cast<unsigned long long>(R + 1) * 4 + sizeof(Word) - 1) / sizeof(Word);
+        int32_t* const map = reinterpret_cast<int32_t*>(dirs + (A.dirs_per_wave - map_words));   // (behind the codes)
+        while (c > 0) {
+            const int run = diag_run(c, row);
+            if (run > 0) {
+                if (lane < run) map[c - lane] = (row - lane) * 2 + 1;
+                row -= run; c -= run;
+                continue;
+            }
+            const int d = loadD(c, row);
+            if (d < 0) { row += d; continue; }   // up moves leave the map untouched (:286)
+            for (int x = lane; x < d && c - x > 0; x += 64) map[c - x] = (row + 1) * 2;
+            c -= min(d, c);
+        }
+        __threadfence();
+        if (lane == 0) {
+            auto interval = [&](int a, int b, bool gaps, unsigned& st, unsigned& en) {   // (:307-351), size_t wrap kept via unsigned
+                if (!gaps) {
+                    st = map[a + 1] >> 1;
+                    en = (map[b] >> 1) + (map[b] & 1);
+                } else {
+                    st = (a == 0) ? 1u : static_cast<unsigned>((map[a] >> 1) + (map[a] & 1));
+                    en = (b + 1 == R + 1) ? static_cast<unsigned>(L + 1) : static_cast<unsigned>(map[b + 1] >> 1);
+                }
+                st -= 1;
+                en -= 1;
+            };
+            unsigned st, en;
+            interval(0, R, false, st, en);
+            const bool nonempty = st < en;
+            A.starts[read] = nonempty ? static_cast<int32_t>(st + 1) : 0;
+            A.ends[read] = nonempty ? static_cast<int32_t>(en) : 0;
+            for (int x = 0; x < A.nsec; ++x) {
+                interval(A.sec_s[x], A.sec_e[x], true, st, en);
+                A.sec_so[static_cast<long long>(x) * A.sec_stride + read] = static_cast<int32_t>(st + 1);
+                A.sec_wo[static_cast<long long>(x) * A.sec_stride + read] = static_cast<int32_t>(en - st);
+            }
+        }
+    } else {   // gapped strings, emitted from the end (:353-389)
+        const long long base = start + read * static_cast<long long>(R);
+        uint8_t* const oref = A.aln_ref + base;
+        uint8_t* const oqry = A.aln_qry + base;
+        const uint8_t* const sq = A.seq + start;
+        int m = 0, ed = 0;
+        while (c > 0) {
+            const int run = diag_run(c, row);
+            if (run > 0) {
+                bool diff = false;
+                if (lane < run) {
+                    const uint8_t rc = A.refchars[c - 1 - lane], qc = sq[row - 1 - lane];
+                    oref[m + lane] = rc; oqry[m + lane] = qc;
+                    diff = rc != qc;
+                }
+                ed += static_cast<int>(__popcll(__ballot(diff)));
+                m += run; row -= run; c -= run;
+                continue;
+            }
+            const int d = loadD(c, row);
+            if (d < 0) {   // read bases opposite a gap
+                for (int x = lane; x < -d; x += 64) { oref[m + x] = '-'; oqry[m + x] = sq[row - 1 - x]; }
+                m -= d; ed -= d; row += d;
+            } else {       // reference characters opposite a gap
+                const int dd = min(d, c);
+                for (int x = lane; x < dd; x += 64) { oref[m + x] = A.refchars[c - 1 - x]; oqry[m + x] = '-'; }
+                m += dd; ed += dd; c -= dd;
+            }
+        }
+        for (int x = lane; x < row; x += 64) { oref[m + x] = '-'; oqry[m + x] = sq[row - 1 - x]; }
+        m += max(row, 0); ed += max(row, 0);
+        if (lane == 0) { A.aln_len[read] = m; A.edits[read] = ed; }
+    }
+}
+
 // MODE 0 scores, 1 scores + map + sections, 2 scores + strings + edit distance.  PENSEL: the reference's penalty selects spelled
 // out (needed when gapopen < 0).  Otherwise the "Penalty selection" argument of k_align applies cell for cell: a gap step out of
 // a cell that was itself entered by the same kind of gap finds the running jump score equal to that cell's score, bit for bit,
@@ -1005,7 +1117,7 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
                         upneg = (upneg & ~(1u << k)) | ((kind == 2u ? 1u : 0u) << k);
                         ls = cur;
                         lpos = kind == 1u;
-                        if (MODE) w |= static_cast<Word>(kind | (hc ? 4u : 0u) | (vc ? 8u : 0u)) << (4 * k);
+                        if (MODE) w |= static_cast<Word>(kind | (hc ? 4u : 0u) | (vc ? 8u : 0u)) << (4 * (K - 1 - k));   // (column k in nibble K - 1 - k: what k_align_wide_q's bit pushes leave)
                     }
                 }
                 h_s[par * T + t] = ls;
@@ -1032,115 +1144,302 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
         if (MODE) {
             __threadfence();
             __syncthreads();
-            if (t < 64) {
-                // The walk, on the first wavefront: the path of a global alignment of like sequences is mostly diagonal, so lane m
-                // looks at the cell m steps up the diagonal from (row, c), a ballot gives the length of the diagonal run and its
-                // moves are written side by side -- one memory round trip per run instead of one per cell; gaps are taken one
-                // run at a time (every lane follows, the outputs are spread over the lanes).
-                const int lane = t;
-                auto nibble = [&](int c, int row) -> unsigned {   // 1 <= c <= R, 1 <= row <= L
-                    const int sc = STRIPS ? (c - 1) / CS : 0, cc = (c - 1) - sc * CS;   // strip, column inside it
-                    const int tt = cc / K, kk = cc % K;
-                    const Word w = dirs[sc * strip_words + static_cast<long long>(row + tt) * Rw + tt];
-                    return static_cast<unsigned>(w >> (4 * kk)) & 15u;
-                };
-                // direction value the reference stores at (row, c): 0 diagonal, +length horizontal, -length vertical
-                auto loadD = [&](int c, int row) -> int {
-                    if (row <= 0) return 1;   // D[c][0] = 1 (:118)
-                    const unsigned nb = nibble(c, row);
-                    if ((nb & 3u) == 0u) return 0;
-                    int len = 1;
-                    if ((nb & 3u) == 1u) {
-                        unsigned f = nb;
-                        for (int x = c; (f & 4u) && x > 1;) { ++len; --x; f = nibble(x, row); }
-                        return len;
-                    }
-                    unsigned f = nb;
-                    for (int y = row; (f & 8u) && y > 1;) { ++len; --y; f = nibble(c, y); }
-                    return -len;
-                };
-                auto diag_run = [&](int c, int row) -> int {   // diagonal moves from (row, c) on, at most 64
-                    const int rr = row - lane, cc = c - lane;
-                    const bool stop = !(rr >= 1 && cc >= 1) || (nibble(cc, rr) & 3u) != 0u;
-                    const unsigned long long nd = __ballot(stop);
-                    return nd ? static_cast<int>(__builtin_ctzll(nd)) : 64;
-                };
-                int row = L, c = R;
-                if (MODE == 1) {
-                    const unsigned long long map_words = (static_cast<unsigned long long>(R + 1) * 4 + sizeof(Word) - 1) / sizeof(Word);
-                    int32_t* const map = reinterpret_cast<int32_t*>(dirs + (A.dirs_per_wave - map_words));   // (behind the codes)
-                    while (c > 0) {
-                        const int run = diag_run(c, row);
-                        if (run > 0) {
-                            if (lane < run) map[c - lane] = (row - lane) * 2 + 1;
-                            row -= run; c -= run;
-                            continue;
-                        }
-                        const int d = loadD(c, row);
-                        if (d < 0) { row += d; continue; }   // up moves leave the map untouched (:286)
-                        for (int x = lane; x < d && c - x > 0; x += 64) map[c - x] = (row + 1) * 2;
-                        c -= min(d, c);
-                    }
-                    __threadfence();
-                    if (lane == 0) {
-                        auto interval = [&](int a, int b, bool gaps, unsigned& st, unsigned& en) {   // (:307-351), size_t wrap kept via unsigned
-                            if (!gaps) {
-                                st = map[a + 1] >> 1;
-                                en = (map[b] >> 1) + (map[b] & 1);
-                            } else {
-                                st = (a == 0) ? 1u : static_cast<unsigned>((map[a] >> 1) + (map[a] & 1));
-                                en = (b + 1 == R + 1) ? static_cast<unsigned>(L + 1) : static_cast<unsigned>(map[b + 1] >> 1);
-                            }
-                            st -= 1;
-                            en -= 1;
-                        };
-                        unsigned st, en;
-                        interval(0, R, false, st, en);
-                        const bool nonempty = st < en;
-                        A.starts[read] = nonempty ? static_cast<int32_t>(st + 1) : 0;
-                        A.ends[read] = nonempty ? static_cast<int32_t>(en) : 0;
-                        for (int x = 0; x < A.nsec; ++x) {
-                            interval(A.sec_s[x], A.sec_e[x], true, st, en);
-                            A.sec_so[static_cast<long long>(x) * A.sec_stride + read] = static_cast<int32_t>(st + 1);
-                            A.sec_wo[static_cast<long long>(x) * A.sec_stride + read] = static_cast<int32_t>(en - st);
-                        }
-                    }
-                } else {   // gapped strings, emitted from the end (:353-389)
-                    const long long base = start + read * static_cast<long long>(R);
-                    uint8_t* const oref = A.aln_ref + base;
-                    uint8_t* const oqry = A.aln_qry + base;
-                    const uint8_t* const sq = A.seq + start;
-                    int m = 0, ed = 0;
-                    while (c > 0) {
-                        const int run = diag_run(c, row);
-                        if (run > 0) {
-                            bool diff = false;
-                            if (lane < run) {
-                                const uint8_t rc = A.refchars[c - 1 - lane], qc = sq[row - 1 - lane];
-                                oref[m + lane] = rc; oqry[m + lane] = qc;
-                                diff = rc != qc;
-                            }
-                            ed += static_cast<int>(__popcll(__ballot(diff)));
-                            m += run; row -= run; c -= run;
-                            continue;
-                        }
-                        const int d = loadD(c, row);
-                        if (d < 0) {   // read bases opposite a gap
-                            for (int x = lane; x < -d; x += 64) { oref[m + x] = '-'; oqry[m + x] = sq[row - 1 - x]; }
-                            m -= d; ed -= d; row += d;
-                        } else {       // reference characters opposite a gap
-                            const int dd = min(d, c);
-                            for (int x = lane; x < dd; x += 64) { oref[m + x] = A.refchars[c - 1 - x]; oqry[m + x] = '-'; }
-                            m += dd; ed += dd; c -= dd;
-                        }
-                    }
-                    for (int x = lane; x < row; x += 64) { oref[m + x] = '-'; oqry[m + x] = sq[row - 1 - x]; }
-                    m += max(row, 0); ed += max(row, 0);
-                    if (lane == 0) { A.aln_len[read] = m; A.edits[read] = ed; }
+            if (t < 64) wide_walk<K, MODE, STRIPS>(A, dirs, strip_words, CS, Rw, L, R, read, start, t);
+        }
+        }   // (strips)
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_align_wide_q: the same alignment without a barrier per step (global mode, gapopen >= 0, one strip: the qualityAlign shape).
+// k_align_wide hands the row state from thread to thread through LDS with one workgroup barrier per step; measured at 2 kb x
+// 2 kb the vector units idle half of the time -- every step is a round trip LDS write -> barrier -> LDS read in front of a
+// chain of 8 dependent cells.  Here a WAVEFRONT is the unit: inside it the row state goes to the next lane with DPP moves
+// (wave_shr:1, lane 0 keeps the fill operand), exactly as in k_align, and only between consecutive wavefronts does it go
+// through LDS -- a queue of WQ_B rows per wavefront boundary, filled by lane 63 of the producer and read by lane 0 of the
+// consumer, which runs 64 rows behind by construction.  The two look at each other's progress counters once per WQ_SYNC
+// steps (consumer: "are my next WQ_SYNC rows there", producer: "are the slots of my next WQ_SYNC rows free") and otherwise
+// run freely; every wait is bounded and sets the abort flag, which every wavefront sees at its next look, so the grid drains
+// whatever happens.  Read rows are staged per wavefront, 64 at a time one refill ahead, in a 128-entry ring (k_align's
+// scheme).  All flags are lane masks in scalar registers, inactive lanes (ramp-up and ramp-down of the skew) are switched
+// off by EXEC alone.  Codes, tile layout and walk are k_align_wide's.
+constexpr int WQ_B = 128;       // rows of a queue (power of two; producer and consumer are 64 rows apart + WQ_SYNC of slack each way)
+constexpr int WQ_SYNC = 16;     // steps between two looks at the neighbours' progress
+constexpr int WQ_SPINS = 1 << 22;
+
+__device__ __forceinline__ int wq_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void wq_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// wait until *p >= need; false: gave up (another wavefront did, or the bound was reached) -- the caller leaves its loop
+__device__ __forceinline__ bool wq_wait(const int* p, int need, int* abort_flag) {
+    for (int spins = 0; wq_load(p) < need; ++spins) {
+        if (wq_load(abort_flag) != 0 || spins > WQ_SPINS) { wq_store(abort_flag, 1); return false; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return true;
+}
+__device__ __forceinline__ double dpp_wave_shr1(double v, double lane0) {
+    const int hi = __builtin_amdgcn_update_dpp(hi32(lane0), hi32(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(lo32(lane0), lo32(v), 0x138, 0xf, 0xf, false);
+    return mk64(hi, lo);
+}
+
+// v_max_f64 as the instruction itself: fmax() of a value that arrives through a loop-carried register makes the compiler
+// canonicalise it first (one more v_max_f64 x, x, x per use), which costs what carrying the value saves; what follows a
+// raw maximum in the chain of a cell is raw too.  (No NaN reaches these: maximum of two numbers, bit for bit the greater.)
+__device__ __forceinline__ double max_f64_raw(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <int K, int MODE>
+__global__ void __launch_bounds__(WIDE_MAXT) k_align_wide_q(const AlignArgs A) {
+    using Word = typename WideWord<K>::type;
+    extern __shared__ __align__(16) unsigned char w_smem[];
+    const int T = static_cast<int>(blockDim.x);
+    const int t = static_cast<int>(threadIdx.x);
+    const int lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int NWV = T >> 6;
+    const int R = A.R;
+    double* const s_tab = reinterpret_cast<double*>(w_smem);
+    double* const q_s = s_tab + A.tab_doubles;                          // [NWV][WQ_B] score of a wavefront's last column, by row
+    double* const q_lj = q_s + NWV * WQ_B;                              // ... its running horizontal jump score
+    int* const q_fl = reinterpret_cast<int*>(q_lj + NWV * WQ_B);        // ... "that cell was a horizontal gap"
+    int* const s_prog = q_fl + NWV * WQ_B;                              // [NWV] rows a wavefront's lane 63 has written
+    int* const s_cons = s_prog + NWV;                                   // [NWV] rows a wavefront's lane 0 has taken
+    int* const s_abort = s_cons + NWV;                                  // [1] (+ padding)
+    uint16_t* const s_ring = reinterpret_cast<uint16_t*>(s_abort + 2) + wv * 128;   // [NWV][128] staged read rows of this wavefront
+    for (int e = t; e < A.tab_doubles; e += T) s_tab[e] = A.tables[e];
+    const double NEG_INF = -__builtin_huge_val();
+    const double GO = A.GO, GE = A.GE;
+    Word* const dirs = MODE ? reinterpret_cast<Word*>(A.dirs) + static_cast<size_t>(blockIdx.x) * A.dirs_per_wave : nullptr;
+    const int tR = (R - 1) / K, kR = (R - 1) % K;
+    // (threads beyond column R -- the spare columns of thread tR, the padding of the last wavefront -- compute on column R's
+    // tables values nobody reads)
+    const bool has_next = wv + 1 < NWV;
+    int cb[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) cb[k] = static_cast<int>(A.colbase[min(t * K + k + 1, R)]);
+    const unsigned char* const tabb = reinterpret_cast<const unsigned char*>(s_tab);
+    // Per column: Sg = score of the row above MINUS the opening penalty (what the vertical candidate of this row and the
+    // horizontal candidate of the next column both are: one subtraction per cell serves both), Dg = score of the column to the
+    // left in the row above (this row's diagonal), UJ = running vertical jump score.
+    double Sg[K], Dg[K], UJ[K];
+    for (long long read = blockIdx.x; read < A.n; read += gridDim.x) {
+        const long long start = A.off[read];
+        const int L = static_cast<int>(A.off[read + 1] - start);
+        __syncthreads();   // (the walk of the alignment before is done with the tile; the tables are in place)
+        if (lane == 0) { s_prog[wv] = 0; s_cons[wv] = 0; }
+        if (t == 0) *s_abort = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k) {   // DP row 0 of the thread's columns and of the column to their left
+            const int col = min(t * K + k + 1, R);
+            Sg[k] = A.rowzero[col] - GO; Dg[k] = A.rowzero[col - 1]; UJ[k] = NEG_INF;
+        }
+        double ls_out = 0.0, lj_out = NEG_INF;
+        double final_score = A.rowzero[R];   // (no rows: row 0 of the last column, :115-118)
+        // A read row is requested one refill (64 steps) before it is staged: the loads (quality byte, base byte or its two packed
+        // bytes) are issued and left in flight, the entry -- byte offset inside a column's cost rows -- is made from them when the
+        // ring takes it, so no step waits for memory.
+        struct RawRow { uint32_t q, b, m; };
+        auto request_row = [&](int row) -> RawRow {
+            RawRow r{0u, 0u, 0u};
+            if (row > L) return r;
+            const long long idx = start + row - 1;
+            r.q = A.qual[idx];
+            if (A.nmask) { r.m = A.nmask[idx >> 3]; r.b = A.seq[idx >> 2]; }
+            else r.b = A.seq[idx];
+            return r;
+        };
+        auto entry_of = [&](const RawRow& r, int row) -> uint32_t {
+            if (row > L) return 0u;
+            const long long idx = start + row - 1;
+            int qi = static_cast<int>(static_cast<signed char>(r.q)) - A.qoffset;
+            if (qi < 0) atomicMin(A.badqual, A.read_base + static_cast<int>(read));
+            qi = qi < 0 ? 0 : (qi >= A.navail ? A.navail - 1 : qi);
+            uint32_t code;
+            if (A.nmask) code = ((r.m >> (idx & 7)) & 1u) ? 4u : ((r.b >> ((idx & 3) * 2)) & 3u);
+            else code = r.b == 'A' ? 0u : r.b == 'C' ? 1u : r.b == 'G' ? 2u : r.b == 'T' ? 3u : 4u;
+            return code * static_cast<uint32_t>(A.row_bytes) + static_cast<uint32_t>(qi << 3);
+        };
+        RawRow pf = request_row(1 + lane);
+        const int nsteps = L > 0 ? L + 63 : 0;   // lane 63 finishes row L at step L + 62
+        bool aborted = false;
+        // what every step starts with: the ring refill and, every WQ_SYNC steps, the look at the neighbours; false: give up
+        auto step_head = [&](int sg) -> bool {
+            if ((sg & 63) == 0) {   // rows sg + 1 .. sg + 64 into the ring (lane 0 needs row sg + 1 now); the next 64 requested
+                s_ring[(sg + lane) & 127] = static_cast<uint16_t>(entry_of(pf, sg + 1 + lane));
+                pf = request_row(sg + 65 + lane);
+            }
+            if ((sg & (WQ_SYNC - 1)) == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (lane 63's queue entries of the steps before, in front of the counters)
+                int ok = 1;
+                if (lane == 0) {
+                    // what this wavefront has taken and written so far -- published before it waits for anybody
+                    wq_store(&s_cons[wv], min(sg, L));
+                    wq_store(&s_prog[wv], min(max(sg - 63, 0), L));
+                    if (wv > 0) ok = wq_wait(&s_prog[wv - 1], min(L, sg + WQ_SYNC), s_abort) ? 1 : 0;                    // my next rows are there
+                    if (ok && has_next) ok = wq_wait(&s_cons[wv + 1], min(L, sg - 47) - WQ_B, s_abort) ? 1 : 0;         // the slots of my next rows are free
+                    if (wq_load(s_abort) != 0) ok = 0;
+                }
+                ok = __builtin_amdgcn_readfirstlane(ok);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (!ok) return false;
+            }
+            return true;
+        };
+        // the row state of the column to lane 0's left at step sg (row sg + 1): DP column 0 (first wavefront,
+        // src/reference_align.cpp:63-78, global mode) or the queue of the wavefront before
+        auto lane0_in = [&](int sg, double& l0, double& j0, int& f0) {
+            if (wv == 0) {
+                l0 = -GO - GE * static_cast<double>(sg);   // -GO - GE (i - 1)
+                j0 = NEG_INF;
+                f0 = 0;
+            } else {
+                const int e = (wv - 1) * WQ_B + (sg & (WQ_B - 1));   // row sg + 1 sits in slot (row - 1) mod WQ_B
+                l0 = q_s[e]; j0 = q_lj[e];
+                f0 = MODE ? q_fl[e] : 0;
+            }
+        };
+
+        // ---- steps 0 .. 62: the lanes enter the read one by one.  Per-lane flags, the cells under `if (active)` (a lane that has
+        // not entered keeps DP row 0 in its columns; also every step of a read of fewer than 64 rows' start) ----
+        unsigned upneg = 0;      // bit k: the move of column k's cell in the row above was a vertical gap (row 0: no)
+        int lpos_out = 0;        // my last column's cell was a horizontal gap, of the step before
+        int sg = 0;
+        for (; sg < min(nsteps, 63); ++sg) {
+            if (!step_head(sg)) { aborted = true; break; }
+            const int i = sg - lane + 1;
+            const bool active = i >= 1 && i <= L;
+            double l0, j0;
+            int f0;
+            lane0_in(sg, l0, j0, f0);
+            double ls = dpp_wave_shr1(ls_out, l0);
+            double lj = dpp_wave_shr1(lj_out, j0);
+            bool lpos = __builtin_amdgcn_update_dpp(f0, lpos_out, 0x138 /* wave_shr:1 */, 0xf, 0xf, false) != 0;
+            if (active) {
+                const int ent = s_ring[(sg - lane) & 127];
+                uint32_t w = 0;
+                double hopen = ls - GO;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const double vopen = Sg[k];
+                    const double ljm = lj - GE;
+                    const bool hc = ljm > hopen && !lpos;
+                    const double horiz = fmax(ljm, hopen);
+                    lj = horiz;
+                    const double ujm = UJ[k] - GE;
+                    const bool vc = ujm > vopen && ((upneg >> k) & 1u) == 0u;
+                    const double vert = max_f64_raw(ujm, vopen);
+                    UJ[k] = vert;
+                    const double match = Dg[k] + *reinterpret_cast<const double*>(tabb + cb[k] + ent);
+                    Dg[k] = ls;
+                    const double hv = max_f64_raw(horiz, vert);
+                    const double cur = max_f64_raw(match, hv);
+                    const unsigned kind = match > hv ? 0u : (horiz > vert ? 1u : 2u);
+                    upneg = (upneg & ~(1u << k)) | ((kind == 2u ? 1u : 0u) << k);
+                    lpos = kind == 1u;
+                    if (MODE) w |= static_cast<uint32_t>(kind | (hc ? 4u : 0u) | (vc ? 8u : 0u)) << (4 * (K - 1 - k));
+                    ls = cur;
+                    hopen = cur - GO;
+                    Sg[k] = hopen;
+                    if (t == tR && i == L && k == kR) final_score = cur;   // (a read of fewer than 64 rows can end here)
+                }
+                ls_out = ls;
+                lj_out = lj;
+                lpos_out = lpos ? 1 : 0;
+                if (MODE) __builtin_nontemporal_store(static_cast<Word>(w), &dirs[static_cast<long long>(i + t) * T + t]);
+                if (has_next && lane == 63) {
+                    const int e = wv * WQ_B + ((i - 1) & (WQ_B - 1));
+                    q_s[e] = ls; q_lj[e] = lj;
+                    if (MODE) q_fl[e] = lpos ? 1 : 0;
                 }
             }
         }
-        }   // (strips)
+
+        // ---- steps 63 .. L + 62: every lane has entered.  Nothing in the cells is predicated and every flag is a wave-uniform
+        // lane mask in scalar registers.  A lane past row L computes all the same; what it computes is never used: codes and
+        // queue entries are stored for rows 1 .. L only, the score is taken at row L, and nobody takes the outputs of a lane
+        // that is not at a row of the read. ----
+        mask_t m_up[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) m_up[k] = MODE ? __builtin_amdgcn_ballot_w64(((upneg >> k) & 1u) != 0u) : 0;
+        mask_t m_lp_out = MODE ? __builtin_amdgcn_ballot_w64(lpos_out != 0) : 0;
+        for (; !aborted && sg < nsteps; ++sg) {
+            if (!step_head(sg)) { aborted = true; break; }
+            const int i = sg - lane + 1;
+            const bool active = i <= L;
+            double l0, j0;
+            int f0;
+            lane0_in(sg, l0, j0, f0);
+            double ls = dpp_wave_shr1(ls_out, l0);
+            double lj = dpp_wave_shr1(lj_out, j0);
+            mask_t m_lp = (m_lp_out << 1) | (MODE ? (__builtin_amdgcn_ballot_w64(f0 != 0) & 1ull) : 0ull);
+            const int ent = s_ring[(sg - lane) & 127];   // (a lane past the read finds the 0 the refill staged for rows beyond L: a valid table address)
+            uint32_t w = 0;
+            double cost[K], curs[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) cost[k] = *reinterpret_cast<const double*>(tabb + cb[k] + ent);   // (requested back to back, ahead of the chain of cells)
+            double hopen = ls - GO;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                // (src/reference_align.cpp:125-177 without the penalty selects: see k_align's "Penalty selection")
+                const double vopen = Sg[k];
+                const double ljm = lj - GE;
+                const mask_t m_hcr = __builtin_amdgcn_ballot_w64(ljm > hopen);
+                const double horiz = fmax(ljm, hopen);
+                lj = horiz;
+                const double ujm = UJ[k] - GE;
+                const mask_t m_vcr = __builtin_amdgcn_ballot_w64(ujm > vopen);
+                const double vert = max_f64_raw(ujm, vopen);
+                UJ[k] = vert;
+                const double match = Dg[k] + cost[k];
+                Dg[k] = ls;
+                const double hv = max_f64_raw(horiz, vert);
+                const double cur = max_f64_raw(match, hv);
+                if (MODE) {
+                    const mask_t m_tm = __builtin_amdgcn_ballot_w64(match > hv), m_hv = __builtin_amdgcn_ballot_w64(horiz > vert);
+                    const mask_t m_k1 = m_hv & ~m_tm, m_k2 = ~(m_hv | m_tm);   // horizontal gap / vertical gap (neither: diagonal)
+                    const mask_t m_hc = m_hcr & ~m_lp, m_vc = m_vcr & ~m_up[k];   // the jumps really continued
+                    m_lp = m_k1;
+                    m_up[k] = m_k2;
+                    w = push_bit(push_bit(push_bit(push_bit(w, m_vc), m_hc), m_k2), m_k1);   // column k ends up in nibble K - 1 - k
+                }
+                curs[k] = cur;
+                ls = cur;
+                hopen = cur - GO;   // the next column's horizontal candidate and, one step on, this column's vertical one
+                Sg[k] = hopen;
+            }
+            ls_out = ls;
+            lj_out = lj;
+            if (MODE) m_lp_out = m_lp;
+            if (sg == L - 1 + (tR & 63) && wv == NWV - 1) {   // thread tR is at row L: the score (one step of one wavefront)
+                double sc = curs[0];
+#pragma unroll
+                for (int k = 1; k < K; ++k) sc = (k == kR) ? curs[k] : sc;
+                if (t == tR) final_score = sc;
+            }
+            if (active) {
+                // (word of thread t at its step i + t = sg + 1 + 64 wv, the same for every lane: a scalar row address + the lane's offset)
+                if (MODE) __builtin_nontemporal_store(static_cast<Word>(w), dirs + static_cast<long long>(sg + 1 + 64 * wv) * T + t);
+                if (has_next && lane == 63) {   // my last column's row state for the wavefront after me
+                    const int e = wv * WQ_B + ((i - 1) & (WQ_B - 1));
+                    q_s[e] = ls; q_lj[e] = lj;
+                    if (MODE) q_fl[e] = static_cast<int>((m_lp >> 63) & 1ull);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) { wq_store(&s_cons[wv], L); wq_store(&s_prog[wv], aborted ? 0 : L); }
+        if (aborted && lane == 0) atomicExch(A.badqual + 1, 1);
+        if (t == tR) A.scores[read] = final_score;
+        if (MODE) {
+            __threadfence();
+            __syncthreads();
+            if (t < 64 && wq_load(s_abort) == 0) wide_walk<K, MODE, false>(A, dirs, 0, T * K, T, L, R, read, start, t);
+        }
     }
 }
 
@@ -1324,6 +1623,11 @@ static int launch_wide(AlignArgs& a, int R, int kernel_mode, int32_t max_len, lo
     long long grid = std::min<long long>(n, static_cast<long long>(c.num_cu) * std::max(1, 2048 / T));
     if (kernel_mode) {
         const size_t budget = static_cast<size_t>(16) << 30;
+        // (4 bits per cell of the whole matrix per alignment in flight: a 2^20-column reference against 100-kb reads would be 50 GB)
+        if (per_wg * word > budget)
+            return fail("sarlacc_amd: the traceback of one alignment of %d reference columns against reads of up to %d bases needs %.1f GB "
+                        "of scratch (at most 16): ask for scores only (barcode_align) or align shorter pieces", R, max_len,
+                        static_cast<double>(per_wg * word) / 1073741824.0);
         grid = std::min(grid, std::max<long long>(1, static_cast<long long>(budget / (per_wg * word))));
     }
     void* d_dirs = nullptr;
@@ -1339,11 +1643,35 @@ static int launch_wide(AlignArgs& a, int R, int kernel_mode, int32_t max_len, lo
     if (lds > 150 * 1024) return fail("sarlacc_amd: alignment tables do not fit in LDS");
     const dim3 g(static_cast<unsigned>(grid)), b(static_cast<unsigned>(T));
     const bool pensel = !(a.GO >= a.GE) || option(OPT_ALIGN_PENSEL) != 0;   // (gapopen < 0, or the tests' switch)
+    // global mode, no penalty selects, one strip: the kernel without a barrier per step (k_align_wide_q); align_wide_barrier = 1: the A/B
+    if (!pensel && !a.local && nstrips == 1 && !option(OPT_ALIGN_WIDE_BARRIER)) {
+        const int NWV = T / 64;
+        const size_t ldq = sizeof(double) * a.tab_doubles + static_cast<size_t>(NWV) * WQ_B * (8 + 8 + 4) + static_cast<size_t>(2 * NWV + 2) * 4 +
+                           static_cast<size_t>(NWV) * 128 * sizeof(uint16_t);
+        if (ldq > 150 * 1024) return fail("sarlacc_amd: alignment tables do not fit in LDS");
+#define WIDEQ_LAUNCH(MM)                                                                                                          \
+    {                                                                                                                              \
+        static thread_local size_t lds_set = 0;   /* (per instantiation: the attribute is raised once, not at every launch) */      \
+        if (ldq > 48 * 1024 && ldq > lds_set) {                                                                                    \
+            SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_align_wide_q<K, MM>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       static_cast<int>(ldq)));                                                                    \
+            lds_set = ldq;                                                                                                         \
+        }                                                                                                                          \
+        hipLaunchKernelGGL((k_align_wide_q<K, MM>), g, b, ldq, stream, a);                                                         \
+    }
+        if (kernel_mode == 0) WIDEQ_LAUNCH(0) else if (kernel_mode == 1) WIDEQ_LAUNCH(1) else WIDEQ_LAUNCH(2)
+#undef WIDEQ_LAUNCH
+        SL_HIP(hipGetLastError());
+        return 0;
+    }
 #define WIDE_LAUNCH2(MM, PP, SS)                                                                                                   \
     {                                                                                                                              \
-        if (lds > 48 * 1024)                                                                                                       \
+        static thread_local size_t lds_set = 0;   /* (per instantiation: the attribute is raised once, not at every launch) */      \
+        if (lds > 48 * 1024 && lds > lds_set) {                                                                                    \
             SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_align_wide<K, MM, PP, SS>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        static_cast<int>(lds)));                                                                    \
+            lds_set = lds;                                                                                                         \
+        }                                                                                                                          \
         hipLaunchKernelGGL((k_align_wide<K, MM, PP, SS>), g, b, lds, stream, a);                                                   \
     }
 #define WIDE_LAUNCH(MM, PP) { if (nstrips > 1) WIDE_LAUNCH2(MM, PP, true) else WIDE_LAUNCH2(MM, PP, false) }

@@ -336,6 +336,51 @@ def test_references_beyond_1024_columns(oracle, oenc, enc):
         calls.barcode_align(["ACGT"], ["IIII"], enc, 5, 1, "A" * ((1 << 20) + 1))
 
 
+def test_wide_references_both_kernels(oracle, oenc, enc):
+    """Global mode with gapopen >= 0 on a reference of one strip runs on k_align_wide_q (wavefronts hand the row state over
+    through LDS queues, no barrier per step); `align_wide_barrier` = 1 keeps k_align_wide, which everything else still takes
+    (local mode, gapopen < 0, strips).  Both against the oracle on the same calls: reads from empty to longer than the
+    reference, fewer rows than a wavefront has lanes, 2 to 16 wavefronts per alignment, packed input through the chunked
+    host path."""
+    from sarlacc_amd import _lib, calls
+    rng = np.random.default_rng(4242)
+    nuc = list("ACGT")
+    try:
+        for R in (1025, 1100, 2048, 4100, 8192):
+            ref = "".join(rng.choice(nuc, R))
+            reads = [_mutate(rng, ref) for _ in range(3)]
+            reads += ["", ref[:5], ref[100:163], ref[7:71], ref[:700] + "N" * 9 + ref[709:1000],
+                      "".join(rng.choice(nuc, 90)) + ref + "".join(rng.choice(nuc, 150))]
+            quals = rand_quals(reads, R, lo=35, hi=90)
+            want = oracle.general_align(reads, quals, oenc, 2.5, 0.75, ref)
+            want_s = oracle.barcode_align(reads, quals, oenc, 0, 1, ref)
+            for barrier in (0, 1):
+                calls.set_option("align_wide_barrier", barrier)
+                got = calls.general_align(reads, quals, enc, 2.5, 0.75, ref, False)
+                assert np.array_equal(bits(want[0]), bits(got[0])) and np.array_equal(want[1], got[1]), (R, barrier)
+                assert want[2] == got[2] and want[3] == got[3], (R, barrier)
+                assert np.array_equal(bits(want_s), bits(calls.barcode_align(reads, quals, enc, 0, 1, ref))), (R, barrier)
+    finally:
+        calls.set_option("align_wide_barrier", 0)
+
+
+def test_wide_local_mode_across_strips(oracle, oenc, enc):
+    """adaptor_align against references of two and three strips of 8 192 columns with reads of 1 to 3 kb: free vertical gaps only in
+    the last column of the LAST strip, the map walk crossing strip tiles, boundary rows staged in several refills (reads longer
+    than the 512 rows of one), sections straddling column 8 192."""
+    rng = np.random.default_rng(8200)
+    nuc = list("ACGT")
+    for R in (8200, 16500):
+        ref = "".join(rng.choice(nuc, R))
+        reads = []
+        for lo, n in ((7300, 1800), (R - 2600, 2500), (6000, 3000), (8100, 1000)):
+            body = _mutate(rng, ref[lo:lo + n])
+            reads.append("".join(rng.choice(nuc, int(rng.integers(0, 200)))) + body + "".join(rng.choice(nuc, int(rng.integers(0, 200)))))
+        reads.append(ref[8150:8230])
+        quals = rand_quals(reads, R, lo=40, hi=83)
+        compare_adaptor(oracle, oenc, enc, reads, quals, ref, 5, 1, [0, 8000, 8100, 8191], [8192, min(8300, R), R, 8193])
+
+
 def test_error_behaviour(oracle, oenc, enc):
     from sarlacc_amd import SarlaccError, calls
     with pytest.raises(SarlaccError, match="same length"):

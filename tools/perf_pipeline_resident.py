@@ -1,5 +1,7 @@
 """umi_group -> msa_consensus on device-generated molecules (bench.py's pipeline pass), stage and kernel-group times.
-    python tools/perf_pipeline_resident.py [molecules] [spec] [reps]"""
+    python tools/perf_pipeline_resident.py [molecules] [spec] [reps] [pure|clusters] [UMI length]
+A shorter UMI at fewer molecules reproduces the cluster sizes of a denser set: 50 000 molecules with 10-base UMIs collide like the
+8 x 10^5 molecules of an 8-GPU giant pre-group with 12-base UMIs (molecules / 4^length = 0.048) at a sixteenth of the reads."""
 import os
 import sys
 import time
@@ -16,8 +18,9 @@ G = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 spec = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 pure = len(sys.argv) > 4 and sys.argv[4] == "pure"   # groups = the molecules themselves (no UMI clustering, no mixed clusters)
+umi_len = int(sys.argv[5]) if len(sys.argv) > 5 else 12
 dev = torch.device("cuda:0")
-mol = devsynth.make_molecule_reads(G, 10, 2000, seed=2000, device=dev)
+mol = devsynth.make_molecule_reads(G, 10, 2000, seed=2000, device=dev, umi_len=umi_len)
 off = mol["off"].cpu().numpy()
 umis = StringSet(mol["umi"].cpu().numpy(), mol["umi_off"].cpu().numpy())
 enc = sarlacc_amd.phred_encoding()

@@ -17,10 +17,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SOURCES = {"k_align": ["align.hip"], "k_msa_pairwise": ["msa_pairwise.hip", "msa_common.hpp"], "k_consensus_code": ["consensus.hip", "msa_common.hpp"],
-           "k_m2_group": ["msa2.hip", "msa_common.hpp"]}
+           "k_m2_group": ["msa2.hip", "msa_common.hpp"], "k_align_wide": ["align.hip"]}
 # share of fp64 instructions (4 issue cycles per wave64 instruction on a SIMD-32; everything else
 # 2) in the kernel's VALU stream, from the disassembly of its main loop
-FP64_SHARE = {"k_align": 0.75, "k_msa_pairwise": 0.0, "k_consensus_code": 0.18, "k_m2_group": 0.0}
+FP64_SHARE = {"k_align": 0.75, "k_msa_pairwise": 0.0, "k_consensus_code": 0.18, "k_m2_group": 0.0, "k_align_wide": 0.53}
 
 
 def source_sha(names):
@@ -52,7 +52,7 @@ def kernel_stats(d, kernel):
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         with open(f, newline="") as fh:
             for r in csv.DictReader(fh):
-                if kernel in r["Name"]:
+                if ((kernel + "<") in r["Name"]) if kernel == "k_align" else (kernel in r["Name"]):   # ("k_align" is also the start of k_align_wide_q)
                     rec = {"name": r["Name"], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                            "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6,
                            "total_ms": float(r["TotalDurationNs"]) / 1e6}
@@ -70,10 +70,12 @@ def main():
         try:
             with open(bj) as fh:
                 b = json.loads(fh.read().strip().splitlines()[-1])
-            res["workload"] = b["config"]["workload"] if kernel == "k_align" else b.get("pipeline", {}).get("workload")
+            res["workload"] = (b["config"]["workload"] if kernel == "k_align" else b.get("quality_align_2kb", {}).get("note") if kernel == "k_align_wide"
+                               else b.get("pipeline", {}).get("workload"))
             # what the SAME box measured without the profiler (tools/profile_round.sh runs the plain bench first): a reader of a
             # bench line that quotes these counters sees at once whether its own timings come from another machine
             res["same_box_bench"] = ({"kernel_ms": b.get("kernel_ms"), "value": b.get("value"), "ms_per_step": b.get("ms_per_step")} if kernel == "k_align"
+                                     else {"kernel_ms": b.get("quality_align_2kb", {}).get("kernel_ms"), "kernel_gcups": b.get("quality_align_2kb", {}).get("kernel_gcups")} if kernel == "k_align_wide"
                                      else {"kernel_ms": b.get("pipeline", {}).get("kernel_ms"), "pipeline_seconds": b.get("pipeline", {}).get("seconds")})
         except (ValueError, KeyError, IndexError):
             pass
@@ -86,6 +88,12 @@ def main():
         except ValueError:
             pass
     res["kernel_stats"] = kernel_stats(os.path.join(out_dir, "stats"), kernel)
+    # the profiler's average duration beside what the same box measured without it (HIP events inside the plain bench run
+    # that tools/profile_round.sh makes first): the spread between the two is stated where the fractions are computed
+    unprof = (res.get("same_box_bench") or {}).get("kernel_ms")
+    if res["kernel_stats"] and isinstance(unprof, (int, float)) and unprof > 0:
+        res["kernel_stats"]["same_box_unprofiled_ms"] = unprof
+        res["kernel_stats"]["profiled_over_unprofiled"] = res["kernel_stats"]["avg_ms"] / unprof
     name = res["kernel_stats"]["name"] if res["kernel_stats"] else kernel
     # counters of the dominant instantiation only (band classes / template variants are separate kernels)
     key = name.split("(")[0] if res["kernel_stats"] else kernel

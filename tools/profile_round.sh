@@ -3,7 +3,7 @@
 # PMC passes (FETCH_SIZE, WRITE_SIZE, two SQ/GRBM sets -- MI355X_MICROARCH.md "rocprofv3 PMC
 # slots") of the SAME bench command (DP steps + the 10^6-read pipeline), all into gpurun_out/<tag>/.
 # tools/pmc_summary.py turns the counter CSVs into one JSON per dominant kernel
-# (k_align, k_msa_pairwise, k_consensus_code) -- the files bench.py reads from profiles/.
+# (k_align, k_msa_pairwise, k_consensus_code, k_m2_group, k_align_wide) -- the files bench.py reads from profiles/.
 #   usage: tools/profile_round.sh <tag> [extra bench.py args]
 set -euo pipefail
 TAG=${1:-prof}; shift || true
@@ -46,7 +46,7 @@ rocprofv3 --output-format csv --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_
     -d "$OUT/pmc_sq2" -o pmc -- $BENCH > "$OUT/pmc_sq2.log" 2>&1 || echo "sq2 pass failed (counter names?)"
 echo "sq2 done"
 cd - > /dev/null
-for K in k_align k_msa_pairwise k_consensus_code k_m2_group; do
+for K in k_align k_msa_pairwise k_consensus_code k_m2_group k_align_wide; do
     python3 tools/pmc_summary.py "$OUT" $K > "$OUT/pmc_$K.json"
 done
 cat "$OUT"/pmc_k_*.json
