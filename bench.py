@@ -272,7 +272,10 @@ def _giant_group_leg(args, rank, world, dist, device, gather_device, backend, en
                    "cons": cons, "phred": phred, "gflat": gflat, "largest_cluster": int(sizes.max()) if sizes.size else 0,
                    "hbm_in_use_gb": (total_b - free_b) / 1e9, "v1_fallback": _lib.stage_count("msa_v1_fallback"),
                    "kernel_ms": dict({k: _lib.stage_ms(k) for k in ("msa_pairwise", "msa_merge", "consensus")}, umi_pairs=umi_ms),
-                   "umi": umi_stats, "umi_workspace_gb": umi_ws / 1e9}
+                   "umi": umi_stats, "umi_workspace_gb": umi_ws / 1e9,
+                   "msa": dict({k: _lib.stage_count("msa_host_%s_s" % k) for k in ("plan", "upload_alloc", "pairwise_launch", "rows", "total")},
+                               **{k: _lib.stage_count("msa2_" + k) for k in ("batches", "groups_second_pass", "first_exit_s", "last_exit_s", "exit_s_1wave", "exit_s_8waves")},
+                               pairs=_lib.stage_count("msa_pairs"), pairs_run_again=_lib.stage_count("msa_bitvector_redone"))}
         except Exception as e:   # noqa: BLE001
             e1 = e
         shard.agree(dist, e1, gather_device)
@@ -332,7 +335,7 @@ def _giant_group_leg(args, rank, world, dist, device, gather_device, backend, en
                             "pairs_stay_in_hbm": bool(r["st"].get("pairs_on_device", False))},
                "n_ranks_seen": int(sm[5]), "clusters": int(r["coff"].size - 1), "clusters_of_two_and_more": int(big.size),
                "largest_cluster": r["largest_cluster"], "groups_aligned_by_spec_v1": int(sm[6]), "hbm_in_use_gb_max": tm[12],
-               "umi_workspace_released_before_msa_gb": r["umi_workspace_gb"],
+               "umi_workspace_released_before_msa_gb": r["umi_workspace_gb"], "msa_stage_rank0": r["msa"],
                "consensus_reads": int(sm[0]), "consensus_bases": int(sm[1]), "reads_in_clusters": int(sm[2]),
                "identical_to_single_rank": {"clusters": clusters_same, "consensus_of_sampled_clusters": bool(same), "sampled_clusters": int(pick.size)},
                "workload": "BASELINE configs[4] as worded, weak scaling: the %d x %d reads of all ranks as ONE pre-group (umiGroup without "
@@ -574,13 +577,26 @@ def main():
     # reference as long as they are -- beyond the 1 024 columns one wavefront holds, so one workgroup per alignment: k_align_wide_q
     # (global mode, gapopen >= 0, one strip: wavefronts hand the row state on through LDS queues)
     if rank == 0 and not args.no_quality_align:
+        # (reads of ONE molecule against that molecule -- what qualityAlign is called on: mockReads' error process, 5 % substitutions
+        # and 1 % indel events, on host arrays; qualities of the DP batch)
         nq = min(n, 20000)
-        h_off = off[:nq + 1].cpu().numpy()
-        end = int(h_off[-1])
-        hs = StringSet(seq[:end].cpu().numpy(), h_off)
-        hq = StringSet(qual[:end].cpu().numpy(), h_off.copy())
         rng_q = np.random.default_rng(2)
-        qref = np.frombuffer(b"ACGT", np.uint8)[rng_q.integers(0, 4, args.read_len)].tobytes().decode()
+        nucq = np.frombuffer(b"ACGT", np.uint8)
+        qmol = nucq[rng_q.integers(0, 4, args.read_len)]
+        qref = qmol.tobytes().decode()
+        body = np.repeat(qmol[None, :], nq, axis=0)
+        sub = rng_q.random(body.shape) < 0.05
+        body[sub] = nucq[rng_q.integers(0, 4, int(sub.sum()))]
+        cnt = np.ones(body.shape, np.int64)
+        ind = rng_q.random(body.shape) < 0.01
+        cnt[ind] = np.array([0, 2, 3, 4, 5])[rng_q.integers(0, 5, int(ind.sum()))]
+        flat = np.repeat(body.reshape(-1), cnt.reshape(-1))
+        h_off = np.zeros(nq + 1, np.int64)
+        np.cumsum(cnt.sum(1), out=h_off[1:])
+        end = int(h_off[-1])
+        hs = StringSet(flat, h_off)
+        hq = StringSet(qual[:end].cpu().numpy(), h_off.copy())
+        del body, sub, cnt, ind
         best = best0 = None
         for _ in range(2):
             t0 = time.perf_counter()

@@ -361,8 +361,10 @@ int sarlacc_create_consensus_quality_loop(const char* aln, const int64_t* aln_of
  * through the group lists), so nothing is re-marshalled between the two stages.  Results are
  * those of sarlacc_quick_msa + sarlacc_create_consensus_{quality,basic}_loop on the same input.
  * qual == NULL selects the basic vote (pseudo_count used), otherwise the quality-weighted vote.
- * cons/phred need sum over groups of the alignment width (reported in the error message when
- * cons_cap is too small; 1.5 x the longest member per group is a safe first guess). */
+ * cons/phred need the KEPT columns of every group (at most the alignment's width; the exact total is reported in the error
+ * message when cons_cap is too small -- the vote has run by then; 1.5 x the longest member per group is a safe first guess:
+ * same-molecule groups keep about one read length, and a cluster of several molecules, whose alignment is several reads
+ * wide, keeps the columns its majority covers). */
 int sarlacc_msa_consensus(const int64_t* grp_off, const int32_t* grp, int64_t ngroups,
                           const char* seq, const int64_t* seq_off,
                           const char* qual, const int64_t* qual_off, int64_t nseq,

@@ -906,7 +906,7 @@ static char phred_char(double le) {
 static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_eval, int64_t rows_eval, int64_t total,
                           const std::vector<int64_t>& out_off, const char* aln_host, int struct_err_kind,
                           double min_cov, double pseudo, const double* enc_errors, const char* enc_names, int enc_n,
-                          char* cons, char* phred, int64_t* cons_off, double* lerr, hipStream_t s) {
+                          char* cons, char* phred, int64_t* cons_off, double* lerr, hipStream_t s, int64_t cons_cap = -1) {
     Context& c = ctx();
     int64_t* d_ooff = const_cast<int64_t*>(a.out_off);
     std::vector<double> right, wrong;
@@ -1067,6 +1067,10 @@ static int consensus_core(bool quality, ConsArgs a, int64_t ngroups, int64_t ng_
     std::vector<long long> dst(static_cast<size_t>(ngroups) + 1, 0);
     for (int64_t g = 0; g < ngroups; ++g) dst[g + 1] = dst[g] + len[g];
     const long long kept = dst[ngroups];
+    // (the caller's buffers hold the KEPT columns: their number is known only now -- the alignments of clusters of several
+    // molecules are several reads wide and keep one read's worth of columns, so a bound from the widths would refuse, and make a
+    // caller repeat, calls whose results fit easily)
+    if (cons_cap >= 0 && kept > cons_cap) return fail("sarlacc_amd: consensus output buffer too small (%lld needed)", kept);
     // results land directly in the caller's buffers (no intermediate host copies)
     uint8_t* const hc = reinterpret_cast<uint8_t*>(cons);
     uint8_t* const hp = reinterpret_cast<uint8_t*>(phred);
@@ -1259,9 +1263,6 @@ static int msa_consensus_impl(const int64_t* grp_off, const int32_t* grp, int64_
     if (msa_rc) return msa_rc;
     if (quality && !d_q) return fail("sarlacc_amd: quality upload did not run");
     const int64_t total = res.out_off[ngroups];
-    int64_t need = 0;
-    for (int64_t g = 0; g < ngroups; ++g) need += res.width[g];
-    if (cons_cap < need) return fail("sarlacc_amd: consensus output buffer too small (%lld needed)", static_cast<long long>(need));
     if (total == 0) {
         for (int64_t g = 0; g < ngroups; ++g) cons_off[g + 1] = 0;
         return 0;
@@ -1292,7 +1293,7 @@ static int msa_consensus_impl(const int64_t* grp_off, const int32_t* grp, int64_
     if (codes) { a.codes = res.d_codes; a.code_bad = res.code.d_bad; }
     if (quality) { a.qual = d_q; a.qual_off = d_qoff; a.row_read = res.d_members; a.qual_bytes = qrel[static_cast<size_t>(nseq)]; }
     return consensus_core(quality, a, ngroups, ngroups, nrows, total, out_off, nullptr, 0, min_cov, pseudo_count, enc_errors,
-                          enc_names, enc_n, cons, phred, cons_off, nullptr, s);
+                          enc_names, enc_n, cons, phred, cons_off, nullptr, s, cons_cap);
 }
 
 int sarlacc_msa_consensus(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const char* seq,

@@ -55,6 +55,9 @@ typedef unsigned long long m2_mask;
 #ifndef M2_WAVES_EU
 #define M2_WAVES_EU 8   // wavefronts per SIMD the merge kernel is compiled for (its registers are capped accordingly)
 #endif
+#ifndef M2_NWD
+#define M2_NWD 4   // wavefronts per group of 33 .. 64 reads
+#endif
 constexpr int M2_NB = 24, M2_NC = 24; // groups of up to M2_NB reads: one wavefront; up to M2_NC: 4; larger: 8 (k_m2_group; sweep: profiles/r03_exp_m2_class_thresholds_v1.txt)
 constexpr int M2_CAP = 16;           // partner columns per row (spec v2, step 5)
 constexpr unsigned M2_NONE = 0xFFFFu;
@@ -476,9 +479,8 @@ __device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, c
     uint16_t* const s_rl = reinterpret_cast<uint16_t*>(s_rows) + lane;     // (every lane reads its own column of the rows only)
     const unsigned char* const s_rlane = reinterpret_cast<const unsigned char*>(s_rl);
     s_rl[n * 64] = static_cast<uint16_t>(M2_NONE);
-    auto stage = [&](int c0, int cnt) {   // (single-wavefront workgroups only)
+    auto stage = [&](int c0, int cnt) {   // (s_tab is this wavefront's own strip then: LDS is in order inside a wavefront, nobody to wait for)
         for (int e = lane; e < cnt; e += 64) s_tab[e] = T[c0 + e];
-        __syncthreads();
     };
     const char* const mapb = reinterpret_cast<const char*>(A.map + G.map0);
     const char* const colb = reinterpret_cast<const char*>(A.col + G.col0);
@@ -514,7 +516,7 @@ __device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, c
             }
             for (int c0 = 0; c0 < E; c0 += cap) {
                 const int ce = min(cap, E - c0);
-                if (!resident) { __syncthreads(); stage(c0, ce); }
+                if (!resident) stage(c0, ce);
                 for (int f0 = 0; f0 < ce; f0 += M2_UBATCH) {
                     unsigned rr[M2_UBATCH], qq[M2_UBATCH], cb[M2_UBATCH], ln[M2_UBATCH], dr[M2_UBATCH];
                     int jj[M2_UBATCH];
@@ -958,14 +960,18 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
 // tables go through in chunks.  NW wavefronts per group (groups of up to NMAX reads): the whole table of any join fits.
 constexpr int m2_lds_bytes(bool unitw, int nw, int nmax) {
     return !unitw ? (M2_MAXN + 1) * 128 + M2_MAXN * 3 * 8 + M2_MAXN * 2 * 4
-                  : (nw == 1 ? (nmax > M2_N32 ? (nmax + 1) * 128 + 64 * 16 : M2_LDS_UNIT) : nw * (nmax + 1) * 128 + ((nmax - 1 + M2_UBATCH) + ((nmax - 1) * nmax + M2_UBATCH)) * 16);
+                  : (nw == 1 ? (nmax > M2_N32 ? (nmax + 1) * 128 + 64 * 16 : M2_LDS_UNIT)
+                             // several wavefronts per group: up to 32 reads every table of a join fits (at most 31 + 31 x 32 candidates); beyond,
+                             // a wavefront stages the table 64 candidates at a time in a strip of its own (132 KB of LDS for whole tables left
+                             // ONE workgroup per CU for the groups that cost the most)
+                             : nw * (nmax + 1) * 128 + (nmax > M2_N32 ? nw * 64 : ((nmax - 1 + M2_UBATCH) + ((nmax - 1) * nmax + M2_UBATCH))) * 16);
 }
 static_assert(M2_LDS_UNIT >= M2_QW * 8 && M2_LDS_UNIT >= (M2_N32 + 1) * 128 + 16 * M2_UBATCH, "the chain's ring and the rows' staging share the LDS");
 
 // One workgroup of NW wavefronts per group (groups of up to NMAX reads; NW = 1 takes any).  The rows of a join are
 // cut into NW ranges, one per wavefront; the chain runs on the first wavefront; the renumbering's copies on all.
 template <bool UNITW, int NW, int NMAX>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? (UNITW ? M2_WAVES_EU : 4) : (NMAX > 32 ? 2 : 4), 8))) k_m2_group(M2Args A, const M2Cand* tab) {
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? (UNITW ? M2_WAVES_EU : 4) : 4, 8))) k_m2_group(M2Args A, const M2Cand* tab) {
     __shared__ __align__(16) unsigned char smem[m2_lds_bytes(UNITW, NW, NMAX)];
     __shared__ int s_cnt[NW], s_pfx[NW + 1], s_ctl[4];
     static_assert(UNITW || NW == 1, "the any-weights walk runs on one wavefront");
@@ -1021,16 +1027,20 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
                 const M2Cand* const T = tab + G.tab_base + m2_rfl(A.join_tab[fm + round]);
                 const int rows_b = (n + 1) * 128;
                 M2Cand* const s_tab = reinterpret_cast<M2Cand*>(smem + NW * rows_b);
-                const int cap = ((m2_lds_bytes(UNITW, NW, NMAX) - NW * rows_b) / 16) & ~(M2_UBATCH - 1);
+                // the join's table: whole in LDS, staged by everybody, where it fits behind the rows of this group's n; else every
+                // wavefront walks it in pieces staged in a strip of its own
+                const int tab_bytes = m2_lds_bytes(UNITW, NW, NMAX) - NW * rows_b;
+                const int cap = (tab_bytes / 16) & ~(M2_UBATCH - 1);
+                const int cap_w = (tab_bytes / NW / 16) & ~(M2_UBATCH - 1);
                 const int nbm = m2_popc(J.maskB);
                 const int E = m2_round_batch(nbm) + m2_round_batch(nbm * n);
                 const bool resident = E <= cap;
                 if (resident) {
                     for (int e = threadIdx.x; e < E; e += 64 * NW) s_tab[e] = T[e];
                     __syncthreads();
-                } else if (NW > 1) { err = 3; }   // (cannot happen: the LDS of a multi-wavefront instantiation holds any table of its groups)
-                ne = err ? 0 : m2_rows_unit(A, G, J, T, i_lo, i_hi, smem + wave * rows_b, s_tab, cap, resident, ent + wave * stride, part, st_capped,
-                                            st_filtered, st_rowsf);
+                }
+                ne = m2_rows_unit(A, G, J, T, i_lo, i_hi, smem + wave * rows_b, resident ? s_tab : s_tab + wave * cap_w, resident ? cap : cap_w, resident,
+                                  ent + wave * stride, part, st_capped, st_filtered, st_rowsf);
                 // wave-wide gather instructions of this wavefront's walk: per block of 64 columns and member of the first child one load of
                 // its positions, the positions in every member (batches of 8) and one or two gathers per table entry (a member without a
                 // base in a whole block skips its walk: counted all the same, an upper bound by a fraction of a per cent)
@@ -1109,7 +1119,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
             const unsigned long long tx = __builtin_amdgcn_s_memrealtime();
             atomicMin(&A.counters[M2C_T_FIRST_EXIT], tx);
             atomicMax(&A.counters[M2C_T_LAST_EXIT], tx);
-            atomicMax(&A.counters[NW == 1 ? M2C_T_EXIT1 : (NW == 4 ? M2C_T_EXIT4 : M2C_T_EXIT8)], tx);
+            atomicMax(&A.counters[NW == 1 ? M2C_T_EXIT1 : (NW == 4 && NMAX <= M2_N32 ? M2C_T_EXIT4 : M2C_T_EXIT8)], tx);
         }
     }
 }
@@ -1472,7 +1482,7 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
         SL_TRY(MS.ensure(4));
         SL_HIP(hipEventRecord(MS.fork, s));
         struct Cls { size_t lo, hi; int nw; const char* tag; int stream; };   // stream: index into MS.st (2 is the alignments' own), -1 = s
-        const Cls cls[4] = {{0, iD, 8, ".d", 3}, {iD, iC, 8, ".c", 0}, {iC, iB, 4, ".b", 1}, {iB, nmulti, 1, ".a", -1}};
+        const Cls cls[4] = {{0, iD, M2_NWD, ".d", 3}, {iD, iC, 8, ".c", 0}, {iC, iB, 4, ".b", 1}, {iB, nmulti, 1, ".a", -1}};
         for (int k = 0; k < 4; ++k) {
             if (cls[k].lo >= cls[k].hi) continue;
             // scratch of a resident workgroup: as wide as the widest profile capacity of the class
@@ -1483,7 +1493,7 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
             hipStream_t sk = cls[k].stream >= 0 ? MS.st[cls[k].stream] : s;
             if (cls[k].stream >= 0) SL_HIP(hipStreamWaitEvent(sk, MS.fork, 0));
             const void* fn = !unitw ? reinterpret_cast<const void*>(&k_m2_group<false, 1, M2_MAXN>)
-                             : k == 0 ? reinterpret_cast<const void*>(&k_m2_group<true, 8, M2_MAXN>)
+                             : k == 0 ? reinterpret_cast<const void*>(&k_m2_group<true, M2_NWD, M2_MAXN>)
                              : k == 1 ? reinterpret_cast<const void*>(&k_m2_group<true, 8, M2_N32>)
                              : k == 2 ? reinterpret_cast<const void*>(&k_m2_group<true, 4, M2_NC>)
                                       : reinterpret_cast<const void*>(&k_m2_group<true, 1, M2_N32>);
@@ -1509,7 +1519,7 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
             am.next = d_next + k;
             const dim3 grid(static_cast<unsigned>(wgs)), block(64 * cls[k].nw);
             if (!unitw) hipLaunchKernelGGL((k_m2_group<false, 1, M2_MAXN>), grid, block, 0, sk, am, d_tab);
-            else if (k == 0) hipLaunchKernelGGL((k_m2_group<true, 8, M2_MAXN>), grid, block, 0, sk, am, d_tab);
+            else if (k == 0) hipLaunchKernelGGL((k_m2_group<true, M2_NWD, M2_MAXN>), grid, block, 0, sk, am, d_tab);
             else if (k == 1) hipLaunchKernelGGL((k_m2_group<true, 8, M2_N32>), grid, block, 0, sk, am, d_tab);
             else if (k == 2) hipLaunchKernelGGL((k_m2_group<true, 4, M2_NC>), grid, block, 0, sk, am, d_tab);
             else hipLaunchKernelGGL((k_m2_group<true, 1, M2_N32>), grid, block, 0, sk, am, d_tab);
