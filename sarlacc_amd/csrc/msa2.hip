@@ -58,7 +58,7 @@ typedef unsigned long long m2_mask;
 #ifndef M2_NWD
 #define M2_NWD 4   // wavefronts per group of 33 .. 64 reads
 #endif
-constexpr int M2_NB = 24, M2_NC = 24; // groups of up to M2_NB reads: one wavefront; up to M2_NC: 4; larger: 8 (k_m2_group; sweep: profiles/r03_exp_m2_class_thresholds_v1.txt)
+constexpr int M2_NB = 24;   // groups of up to M2_NB reads: one wavefront; up to 32: 8 wavefronts; 33 .. 64: M2_NWD (k_m2_group; sweeps: profiles/r03_exp_m2_class_thresholds_v1.txt, r04_exp_m2_classes_v1.txt -- a 4-wavefront class between the first two lost in every sweep and is gone)
 constexpr int M2_CAP = 16;           // partner columns per row (spec v2, step 5)
 constexpr unsigned M2_NONE = 0xFFFFu;
 // profile capacity of the first pass: same-molecule reads grow a profile by 10-20 %, one or two unrelated reads in
@@ -97,7 +97,7 @@ enum { M2C_ROWS, M2C_ROWS_CAPPED, M2C_ENT_FILTERED, M2C_ROWS_FILTERED, M2C_ENT_K
        M2C_GATHERS,   // wave-wide gather instructions of the library walk (positions, maps, columns): its request-rate roofline
        // where the wavefronts' time goes (s_memtime cycles summed over the wavefronts) and when they leave (s_memrealtime, 100 MHz)
        M2C_CYC_ROWS, M2C_CYC_CHAIN, M2C_CYC_WALK, M2C_CYC_RENUMBER, M2C_T_START, M2C_T_FIRST_EXIT, M2C_T_LAST_EXIT,
-       M2C_T_EXIT1, M2C_T_EXIT4, M2C_T_EXIT8,   // last exit of the instantiation with 1 / 4 / 8 wavefronts per group
+       M2C_T_EXIT1, M2C_T_EXIT4, M2C_T_EXIT8,   // last exit of the instantiations: one wavefront per group / groups of 33 .. 64 reads / 8 wavefronts
        M2C_N };
 
 struct M2Args {
@@ -1119,7 +1119,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
             const unsigned long long tx = __builtin_amdgcn_s_memrealtime();
             atomicMin(&A.counters[M2C_T_FIRST_EXIT], tx);
             atomicMax(&A.counters[M2C_T_LAST_EXIT], tx);
-            atomicMax(&A.counters[NW == 1 ? M2C_T_EXIT1 : (NW == 4 && NMAX <= M2_N32 ? M2C_T_EXIT4 : M2C_T_EXIT8)], tx);
+            atomicMax(&A.counters[NW == 1 ? M2C_T_EXIT1 : (NMAX > M2_N32 ? M2C_T_EXIT4 : M2C_T_EXIT8)], tx);   // (EXIT4: the class of 33 .. 64 reads)
         }
     }
 }
@@ -1446,23 +1446,20 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
         SL_HIP(hipGetLastError());
     }
     // ---- progressive merging: every join of every group in ONE round of launches ----
-    // Groups are ordered by decreasing size.  A group is merged by one workgroup: one wavefront for the bulk (up to
-    // M2_NB reads), 4 wavefronts up to M2_NC reads, 8 beyond -- the cost of a group grows with the cube of its size, and
-    // the longest group sets the length of the launch; groups of 33 to M2_MAXN reads have an instantiation of their own
-    // (64-bit member masks, up to 127 tree nodes, LDS for 65 staged rows per wavefront and tables of up to 4 100 candidates).
-    // The instantiations run side by side on streams of their own.
+    // Groups are ordered by decreasing size.  A group is merged by one workgroup: one wavefront for the bulk (up to M2_NB reads),
+    // 8 wavefronts up to 32 reads -- the cost of a group grows with the cube of its size, and the longest group sets the length of
+    // the launch --, M2_NWD wavefronts for groups of 33 to M2_MAXN reads, which have an instantiation of their own (64-bit member
+    // masks, up to 127 tree nodes, 65 staged rows per wavefront, candidate tables staged in pieces per wavefront).  The
+    // instantiations run side by side on streams of their own.
     size_t nmulti = 0;
     while (nmulti < ng && B.groups[nmulti].n >= 2) ++nmulti;
     if (nmulti) {
-        size_t iD = 0, iC = 0, iB = 0;
+        size_t iD = 0, iC = 0;
         if (unitw) {
             while (iD < nmulti && B.groups[iD].n > M2_N32) ++iD;
-            iC = iB = iD;
-            if (!option(OPT_MSA2_SINGLE_WAVE)) {
-                while (iC < nmulti && B.groups[iC].n > M2_NC) ++iC;
-                iB = iC;
-                while (iB < nmulti && B.groups[iB].n > M2_NB) ++iB;
-            }
+            iC = iD;
+            if (!option(OPT_MSA2_SINGLE_WAVE))
+                while (iC < nmulti && B.groups[iC].n > M2_NB) ++iC;
         }
         unsigned long long* d_cnt;
         int* d_next;
@@ -1482,8 +1479,8 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
         SL_TRY(MS.ensure(4));
         SL_HIP(hipEventRecord(MS.fork, s));
         struct Cls { size_t lo, hi; int nw; const char* tag; int stream; };   // stream: index into MS.st (2 is the alignments' own), -1 = s
-        const Cls cls[4] = {{0, iD, M2_NWD, ".d", 3}, {iD, iC, 8, ".c", 0}, {iC, iB, 4, ".b", 1}, {iB, nmulti, 1, ".a", -1}};
-        for (int k = 0; k < 4; ++k) {
+        const Cls cls[3] = {{0, iD, M2_NWD, ".d", 3}, {iD, iC, 8, ".c", 0}, {iC, nmulti, 1, ".a", -1}};
+        for (int k = 0; k < 3; ++k) {
             if (cls[k].lo >= cls[k].hi) continue;
             // scratch of a resident workgroup: as wide as the widest profile capacity of the class
             int class_wcap = 1;
@@ -1495,7 +1492,6 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
             const void* fn = !unitw ? reinterpret_cast<const void*>(&k_m2_group<false, 1, M2_MAXN>)
                              : k == 0 ? reinterpret_cast<const void*>(&k_m2_group<true, M2_NWD, M2_MAXN>)
                              : k == 1 ? reinterpret_cast<const void*>(&k_m2_group<true, 8, M2_N32>)
-                             : k == 2 ? reinterpret_cast<const void*>(&k_m2_group<true, 4, M2_NC>)
                                       : reinterpret_cast<const void*>(&k_m2_group<true, 1, M2_N32>);
             int per_cu = 0;
             SL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * cls[k].nw, 0));
@@ -1521,7 +1517,6 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
             if (!unitw) hipLaunchKernelGGL((k_m2_group<false, 1, M2_MAXN>), grid, block, 0, sk, am, d_tab);
             else if (k == 0) hipLaunchKernelGGL((k_m2_group<true, M2_NWD, M2_MAXN>), grid, block, 0, sk, am, d_tab);
             else if (k == 1) hipLaunchKernelGGL((k_m2_group<true, 8, M2_N32>), grid, block, 0, sk, am, d_tab);
-            else if (k == 2) hipLaunchKernelGGL((k_m2_group<true, 4, M2_NC>), grid, block, 0, sk, am, d_tab);
             else hipLaunchKernelGGL((k_m2_group<true, 1, M2_N32>), grid, block, 0, sk, am, d_tab);
             SL_HIP(hipGetLastError());
             if (cls[k].stream >= 0) SL_HIP(hipEventRecord(MS.join[cls[k].stream], sk));
@@ -1529,7 +1524,7 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
         // the caller's stream joins the side streams only now, AFTER its own instantiation is queued (waiting inside the loop
         // made the one-wavefront launch -- last in the loop, on `s` -- start when the others had finished: the classes ran one
         // after the other, 0.18 s of the 0.58 s merge stage of bench.py's pipeline workload)
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 3; ++k)
             if (cls[k].lo < cls[k].hi && cls[k].stream >= 0) SL_HIP(hipStreamWaitEvent(s, MS.join[cls[k].stream], 0));
     }
     SL_TRY(c.stage_end("msa_merge", s));

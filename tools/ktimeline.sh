@@ -18,6 +18,8 @@ rows = [r for r in rows if r[0] >= t_end - 1_200_000_000]
 def short(n):
     n = n.replace("void ", "").replace("sarlacc::", "")
     return n.split("(")[0][:46]
+if not rows:
+    raise SystemExit("no kernel in the trace (did the command run on the GPU?)")
 out, prev_end, acc = [], None, {}
 for s, e, n in rows:
     gap = 0 if prev_end is None else (s - prev_end) / 1e6

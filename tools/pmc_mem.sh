@@ -48,21 +48,23 @@ for k in sorted(tot):
     for c in sorted(t):
         print("   %-44s %16.6g  (%d launches)" % (c, t[c], calls[(k, c)]))
     g = lambda n: t.get(n, float("nan"))
+    def ratio(a, b):   # (a failed pass gives NaN on purpose; a counter that read zero -- no flat reads, no L2 requests -- must not end the printout)
+        return a / b if b == b and b != 0 else float("nan")
     cyc = g("GRBM_GUI_ACTIVE@m1") / 8.0   # (the counter comes summed over the 8 XCDs)
     print("   kernel cycles (per XCD)                     %.4g" % cyc)
-    print("   TA busy per TA and cycle (256 TAs)          %.3f" % (g("TA_TA_BUSY_sum") / (cyc * 256)))
-    print("   L1 stalled on pending data, per L1 and cycle %.3f" % (g("TCP_PENDING_STALL_CYCLES_sum") / (g("GRBM_GUI_ACTIVE@m2b") / 8.0 * 256)))
-    print("   cycles per wave-wide read in the TAs        %.1f" % (g("TA_TA_BUSY_sum") / g("TA_FLAT_READ_WAVEFRONTS_sum")))
-    print("   L1 -> L2 read latency (cycles)              %.0f" % (g("TCP_TCC_READ_REQ_LATENCY_sum") / g("TCP_TCC_READ_REQ_sum")))
-    print("   L1 accesses per L1 -> L2 read request       %.2f" % (g("TCP_TOTAL_CACHE_ACCESSES_sum") / g("TCP_TCC_READ_REQ_sum")))
-    print("   L2 hit share of its requests                %.3f" % (g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))))
+    print("   TA busy per TA and cycle (256 TAs)          %.3f" % ratio(g("TA_TA_BUSY_sum"), cyc * 256))
+    print("   L1 stalled on pending data, per L1 and cycle %.3f" % ratio(g("TCP_PENDING_STALL_CYCLES_sum"), g("GRBM_GUI_ACTIVE@m2b") / 8.0 * 256))
+    print("   cycles per wave-wide read in the TAs        %.1f" % ratio(g("TA_TA_BUSY_sum"), g("TA_FLAT_READ_WAVEFRONTS_sum")))
+    print("   L1 -> L2 read latency (cycles)              %.0f" % ratio(g("TCP_TCC_READ_REQ_LATENCY_sum"), g("TCP_TCC_READ_REQ_sum")))
+    print("   L1 accesses per L1 -> L2 read request       %.2f" % ratio(g("TCP_TOTAL_CACHE_ACCESSES_sum"), g("TCP_TCC_READ_REQ_sum")))
+    print("   L2 hit share of its requests                %.3f" % ratio(g("TCC_HIT_sum"), g("TCC_HIT_sum") + g("TCC_MISS_sum")))
     rd = g("TCC_EA0_RDREQ_sum"); r32 = g("TCC_EA0_RDREQ_32B_sum"); r128 = g("TCC_EA0_RDREQ_128B_sum")
     rbytes = 32 * r32 + 128 * r128 + 64 * (rd - r32 - r128)
     print("   fabric reads: %.4g requests (32 B: %.3g, 128 B: %.3g) = %.4g bytes" % (rd, r32, r128, rbytes))
-    print("   L2 -> fabric read latency (cycles)          %.0f" % (g("TCC_EA0_RDREQ_LEVEL_sum") / rd))
+    print("   L2 -> fabric read latency (cycles)          %.0f" % ratio(g("TCC_EA0_RDREQ_LEVEL_sum"), rd))
     wr = g("TCC_EA0_WRREQ_sum"); w64 = g("TCC_EA0_WRREQ_64B_sum")
     print("   fabric writes: %.4g requests (64 B: %.3g) = %.4g bytes" % (wr, w64, 64 * w64 + 32 * (wr - w64)))
-    print("   DRAM read credit stall cycles / (cycles x 16 channels x 8 XCDs) %.3f" % (g("TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum") / (g("GRBM_GUI_ACTIVE@m6") / 8.0 * 128)))
+    print("   DRAM read credit stall cycles / (cycles x 16 channels x 8 XCDs) %.3f" % ratio(g("TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum"), g("GRBM_GUI_ACTIVE@m6") / 8.0 * 128))
 PY
 find "$OUT" -name "*counter_collection.csv" -size +20M -delete
 find "$OUT" -type f ! -name '*.csv' ! -name '*.log' -delete
