@@ -1665,7 +1665,9 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         });
         std::vector<size_t> again;
         long long mem_all = 0, jobs_all = 0;
-        for (size_t q : todo) {
+        std::vector<long long> cmem(todo.size() + 1, 0), cjobs(todo.size() + 1, 0);   // cumulative over the sorted list
+        for (size_t x = 0; x < todo.size(); ++x) {
+            const size_t q = todo[x];
             const int64_t g = ids[q];
             const long long n = grp_off[g + 1] - grp_off[g];
             const long long sum = gsum[q], mx = gmx[q];
@@ -1673,9 +1675,15 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             mem_all += 2 * (n - 1) * sum + 2 * n * wc + 2 * sum + 16 * m2_tab_entries(static_cast<int>(n));
             mem_all += n * (n - 1) / 2 * ((2 * mx) / 16 + 2) * 4;   // the move strings of the bit-vector pairwise kernel (msa_pairwise.hip)
             jobs_all += n * (n - 1) / 2;
+            cmem[x + 1] = mem_all; cjobs[x + 1] = jobs_all;
         }
-        // batches: as many as memory and the job list demand, a few more for the overlap once there is enough work; every
-        // batch gets every nb-th group of the sorted list, so all of them hold the same mix of sizes
+        // batches: as many as memory and the job list demand, a few more for the overlap once there is enough work.  (Until round 5
+        // every batch got every nb-th group of the sorted list, "the same mix of sizes" -- and so every batch held some of the
+        // largest groups, whose merging is the longest chain of dependent joins of the call: a 64-read cluster keeps its workgroup
+        // busy for about 2 s, and the merge stage of a call took nb x that -- the same clusters in 1 / 3 / 5 batches: 2.96 / 6.6 /
+        // 9.6 s.  Now the LARGE groups go to the batches in contiguous pieces of the sorted list -- the largest share the first
+        // batch, the longest group of every later batch is shorter than that of the one before -- and only the bulk of
+        // one-wavefront groups is dealt round robin.)
         // (one batch when everything fits -- then the stage timers do not overlap either; from two on the two workspace
         // sets share the budget.  Measured at C4 with two pipelined batches: pure groups 5 % faster end to end, clusters
         // of several molecules unchanged -- the alignments saturate the vector units by themselves.)
@@ -1683,13 +1691,31 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         const long long want = option(OPT_MSA2_BATCHES) > 0 ? option(OPT_MSA2_BATCHES) : 1;
         if (std::max(nb, want) > 1) nb = std::max<long long>(want, std::max((2 * mem_all + mem_budget - 1) / mem_budget, (jobs_all + job_budget - 1) / job_budget));
         nb = std::min<long long>(nb, static_cast<long long>(todo.size()));
-        nbatches += static_cast<double>(nb);
         std::vector<M2Batch> batches(static_cast<size_t>(nb));
-        for (size_t q = 0; q < todo.size(); ++q) {
-            M2Batch& B = batches[q % static_cast<size_t>(nb)];
-            B.ids.push_back(ids[todo[q]]);
-            B.slot.push_back(todo[q]);
+        {
+            // groups of more than M2_NB reads (several wavefronts each, the long chains of joins): contiguous pieces of the sorted
+            // list, by their share of the memory and of the jobs of all such groups; the rest: every nb-th group, so that every
+            // batch has the same bulk of one-wavefront groups to fill the chip beside its large ones
+            size_t nbig = 0;
+            while (nbig < todo.size() && grp_off[ids[todo[nbig]] + 1] - grp_off[ids[todo[nbig]]] > M2_NB) ++nbig;
+            const long long bmem = cmem[nbig], bjobs = cjobs[nbig];
+            size_t k = 0;
+            for (size_t x = 0; x < nbig; ++x) {
+                const double share = std::max(bmem > 0 ? static_cast<double>(cmem[x]) / static_cast<double>(bmem) : 0.0,
+                                              bjobs > 0 ? static_cast<double>(cjobs[x]) / static_cast<double>(bjobs) : 0.0);
+                while (k + 1 < static_cast<size_t>(nb) && share * static_cast<double>(nb) >= static_cast<double>(k + 1)) ++k;
+                batches[k].ids.push_back(ids[todo[x]]);
+                batches[k].slot.push_back(todo[x]);
+            }
+            for (size_t x = nbig; x < todo.size(); ++x) {
+                M2Batch& B = batches[(x - nbig) % static_cast<size_t>(nb)];
+                B.ids.push_back(ids[todo[x]]);
+                B.slot.push_back(todo[x]);
+            }
+            // (a call with fewer groups than batches, or one huge group taking the share of two pieces, leaves a batch without groups)
+            batches.erase(std::remove_if(batches.begin(), batches.end(), [](const M2Batch& B) { return B.ids.empty(); }), batches.end());
         }
+        nbatches += static_cast<double>(batches.size());
         const char* const pfs[2] = {"m2a", "m2b"};
         auto prepare = [&](size_t k) -> int {
             M2Batch& B = batches[k];
