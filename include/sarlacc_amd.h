@@ -155,6 +155,9 @@ int sarlacc_dev_align_packed(const uint8_t* d_packed, const uint8_t* d_nmask, co
  * (R/adaptorAlign.R:86-95) and .scramble_input (R/getAdaptorThresholds.R:68-92) on the device. */
 int sarlacc_dev_malloc(void** p, int64_t bytes);
 int sarlacc_dev_free(void* p);
+/* (blocks of 1 MB and more are pooled by size -- powers of two, at most 4 GB idle per device --: a freed block waits for the
+ * next request of its size; sarlacc_dev_pool_release, and sarlacc_release_workspace, give the idle ones back) */
+int sarlacc_dev_pool_release(void);
 int sarlacc_dev_upload(void* d, const void* h, int64_t bytes);
 int sarlacc_dev_download(void* h, const void* d, int64_t bytes);
 /* Page-locked host blocks for results (no reference counterpart: R hands its own vectors to .Call).  A device -> host copy

@@ -173,6 +173,7 @@ int sarlacc_set_device(int device) {
 void sarlacc_release_workspace(void) {
     sarlacc::ctx().release();
     (void)sarlacc_host_release();   // the idle page-locked result blocks as well
+    (void)sarlacc_dev_pool_release();   // ... and the idle device blocks of sarlacc_dev_malloc
 }
 
 int64_t sarlacc_release_umi_workspace(void) {

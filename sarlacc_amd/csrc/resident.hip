@@ -159,17 +159,68 @@ struct HostPool {
 HostPool& host_pool() { static HostPool p; return p; }
 }  // namespace
 
+// Device blocks of the resident read batches (windows, realized reads ...) are pooled like the page-locked host blocks: hipMalloc
+// + hipFree of the four 250-MB window arrays of a 10^6-read adaptorAlign cost 3 ms on one box of the pool and 25-35 ms on
+// another -- more than the kernels that fill them.  Sizes in powers of two from 1 MB (smaller ones go to hipMalloc directly),
+// at most 4 GB idle per device; sarlacc_release_workspace empties the pool.
+namespace {
+struct DevPool {
+    std::mutex mu;
+    std::map<std::pair<int, size_t>, std::vector<void*>> idle;   // by (device, block size)
+    std::map<void*, std::pair<int, size_t>> live;               // pooled blocks handed out
+    std::map<int, size_t> idle_bytes;
+};
+DevPool& dev_pool() { static DevPool p; return p; }
+}  // namespace
+
 extern "C" {
 
 int sarlacc_dev_malloc(void** p, int64_t bytes) {
     if (!p || bytes < 0) return fail("sarlacc_amd: bad allocation request");
     SL_TRY(ensure_device());
-    SL_HIP(hipMalloc(p, static_cast<size_t>(bytes > 0 ? bytes : 1)));
+    if (bytes < (1 << 20)) { SL_HIP(hipMalloc(p, static_cast<size_t>(bytes > 0 ? bytes : 1))); return 0; }
+    size_t size = size_t(1) << 20;
+    while (size < static_cast<size_t>(bytes)) size <<= 1;
+    int dev = 0;
+    SL_HIP(hipGetDevice(&dev));
+    DevPool& P = dev_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    std::vector<void*>& idle = P.idle[{dev, size}];
+    if (!idle.empty()) { *p = idle.back(); idle.pop_back(); P.idle_bytes[dev] -= size; }
+    else if (hipMalloc(p, size) != hipSuccess) {
+        (void)hipGetLastError();
+        // (make room once: the idle blocks of this device go back, then the exact size is asked for)
+        for (auto& kv : P.idle)
+            if (kv.first.first == dev) { for (void* q : kv.second) (void)hipFree(q); kv.second.clear(); }
+        P.idle_bytes[dev] = 0;
+        SL_HIP(hipMalloc(p, static_cast<size_t>(bytes)));
+        return 0;   // (not pooled: its size is not a pool size)
+    }
+    P.live[*p] = {dev, size};
     return 0;
 }
 
 int sarlacc_dev_free(void* p) {
-    if (p) SL_HIP(hipFree(p));
+    if (!p) return 0;
+    DevPool& P = dev_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    auto it = P.live.find(p);
+    if (it == P.live.end()) { SL_HIP(hipFree(p)); return 0; }   // a small block, or one allocated outside the pool sizes
+    const int dev = it->second.first;
+    const size_t size = it->second.second;
+    P.live.erase(it);
+    if (P.idle_bytes[dev] + size > (size_t(4) << 30)) { SL_HIP(hipFree(p)); return 0; }
+    // (the block may still be read by kernels queued on the null stream; the next user's work is queued behind them there)
+    P.idle[{dev, size}].push_back(p);
+    P.idle_bytes[dev] += size;
+    return 0;
+}
+
+int sarlacc_dev_pool_release(void) {
+    DevPool& P = dev_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    for (auto& kv : P.idle) { for (void* q : kv.second) (void)hipFree(q); kv.second.clear(); }
+    P.idle_bytes.clear();
     return 0;
 }
 
