@@ -319,7 +319,8 @@ int sarlacc_set_msa_spec(int spec);
  *   "align_waves_per_cu" (a count), "align_interleave" (-1 never / 1 with align_k), "consensus_chars", "consensus_generic",
  *   "msa_int32", "msa_affine", "msa_bitvector" (-1 never, 2 one kernel for fill and walk), "msa_bitvector_core" (-1 whole
  *   records, 1 one word), "msa_bitvector_tile_gb" (GB), "umi_full_rounds", "umi_tile_search", "umi_split_min" (a set size),
- *   "umi_scan_single", "align_wide_barrier" (references beyond 1 024 columns: the kernel with a barrier per step everywhere).
+ *   "umi_scan_single", "align_wide_barrier" (references beyond 1 024 columns: the kernel with a barrier per step everywhere),
+ *   "align_wide_band" (rows either side of the main diagonal whose cells carry traceback codes in k_align_wide_q's first launch; -1: all).
  * The environment (SARLACC_<NAME>) is read once, when the first option is asked for; afterwards only this call changes a
  * value.  Nothing in the reference corresponds. */
 int sarlacc_set_option(const char* name, int value);

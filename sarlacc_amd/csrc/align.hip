@@ -81,6 +81,10 @@ struct AlignArgs {
     int32_t* edits;
     int wide_maxlen;                   // k_align_wide: the longest read of the launch (sizes of its code tiles and boundary arrays)
     double* wide_bnd;                  // k_align_wide with several strips: per workgroup [2][3][wide_maxlen + 2] row states at a strip's last column
+    int wide_band;                     // k_align_wide_q with traceback: codes only for the steps that can hold cells within this many rows of the
+                                       // main diagonal (0: codes of every cell); a walk that leaves them puts its read on the redo list
+    int* wide_redo;                    // [0] number of reads on the list, [1 ...] their indices (written by the banded launch)
+    const int* wide_list;              // the redo launch: the reads to align (count read from the device: wide_list[-1]); null: reads 0 .. n - 1
 };
 
 // Traceback code of one cell, 4 bits -- the raw outcomes of the cell's four comparisons:
@@ -858,10 +862,29 @@ struct WideWord { using type = uint32_t; };
 
 // The walk of one alignment of k_align_wide / k_align_wide_q, run by ONE wavefront (lane = 0 .. 63) after the codes of every
 // strip are in `dirs` (word of thread tt at step s: dirs[strip * strip_words + s * Rw + tt], column k of the thread in nibble K - 1 - k).
+// k_align_wide_q's band of steps that carry codes, per wavefront w of an alignment of L rows against R columns (K = 8 columns per
+// lane): the cells within `band` rows of the main diagonal i = c L / R sit, for the 512 columns of wavefront w, at its steps
+// [lo, hi] (lane l is at row sg - l + 1).  The fill switches its codes on one step before lo (the flags a cell's codes take from the
+// row above are then in place at lo); the walk may read the codes of a cell iff its step lies in [lo, hi] or in the first 63
+// steps of its wavefront, which always carry codes.
+struct WideBand {
+    int band, L, R;
+    __device__ __forceinline__ int lo(int w) const { return static_cast<int>(512ll * w * L / R) - band - 2; }
+    __device__ __forceinline__ int hi(int w) const { return static_cast<int>((512ll * (w + 1) * L + R - 1) / R) + band + 64; }
+    __device__ __forceinline__ bool stored(int c, int row) const {   // 1 <= c <= R, 1 <= row <= L
+        if (band <= 0) return true;
+        const int t = (c - 1) >> 3, w = t >> 6, sg = row + (t & 63) - 1;
+        return sg < 63 || (sg >= lo(w) && sg <= hi(w));
+    }
+};
+
+// (`wb`: the band of stored codes, null = every cell; a walk that needs a cell outside it stops and returns false -- nothing it wrote counts)
 template <int K, int MODE, bool STRIPS>
-__device__ __forceinline__ void wide_walk(const AlignArgs& A, typename WideWord<K>::type* dirs, long long strip_words, int CS, long long Rw,
-                                          int L, int R, long long read, long long start, int lane) {
+__device__ __forceinline__ bool wide_walk(const AlignArgs& A, typename WideWord<K>::type* dirs, long long strip_words, int CS, long long Rw,
+                                          int L, int R, long long read, long long start, int lane, const WideBand* wb = nullptr) {
     using Word = typename WideWord<K>::type;
+    bool left_band = false;
+    auto ok = [&](int c, int row) -> bool { return !wb || wb->stored(c, row); };
     // The walk, on the first wavefront: the path of a global alignment of like sequences is mostly diagonal, so lane m
     // looks at the cell m steps up the diagonal from (row, c), a ballot gives the length of the diagonal run and its
     // moves are written side by side -- one memory round trip per run instead of one per cell; gaps are taken one
@@ -875,21 +898,30 @@ __device__ __forceinline__ void wide_walk(const AlignArgs& A, typename WideWord<
     // direction value the reference stores at (row, c): 0 diagonal, +length horizontal, -length vertical
     auto loadD = [&](int c, int row) -> int {
         if (row <= 0) return 1;   // D[c][0] = 1 (:118)
+        if (!ok(c, row)) { left_band = true; return 0; }
         const unsigned nb = nibble(c, row);
         if ((nb & 3u) == 0u) return 0;
         int len = 1;
         if ((nb & 3u) == 1u) {
             unsigned f = nb;
-            for (int x = c; (f & 4u) && x > 1;) { ++len; --x; f = nibble(x, row); }
+            for (int x = c; (f & 4u) && x > 1;) {
+                ++len; --x;
+                if (!ok(x, row)) { left_band = true; break; }
+                f = nibble(x, row);
+            }
             return len;
         }
         unsigned f = nb;
-        for (int y = row; (f & 8u) && y > 1;) { ++len; --y; f = nibble(c, y); }
+        for (int y = row; (f & 8u) && y > 1;) {
+            ++len; --y;
+            if (!ok(c, y)) { left_band = true; break; }
+            f = nibble(c, y);
+        }
         return -len;
     };
-    auto diag_run = [&](int c, int row) -> int {   // diagonal moves from (row, c) on, at most 64
+    auto diag_run = [&](int c, int row) -> int {   // diagonal moves from (row, c) on, at most 64 (a cell without codes ends the run: the walk meets it next)
         const int rr = row - lane, cc = c - lane;
-        const bool stop = !(rr >= 1 && cc >= 1) || (nibble(cc, rr) & 3u) != 0u;
+        const bool stop = !(rr >= 1 && cc >= 1) || !ok(cc, rr) || (nibble(cc, rr) & 3u) != 0u;
         const unsigned long long nd = __ballot(stop);
         return nd ? static_cast<int>(__builtin_ctzll(nd)) : 64;
     };
@@ -905,6 +937,7 @@ __device__ __forceinline__ void wide_walk(const AlignArgs& A, typename WideWord<
                 continue;
             }
             const int d = loadD(c, row);
+            if (left_band) return false;
             if (d < 0) { row += d; continue; }   // up moves leave the map untouched (:286)
             for (int x = lane; x < d && c - x > 0; x += 64) map[c - x] = (row + 1) * 2;
             c -= min(d, c);
@@ -953,6 +986,7 @@ __device__ __forceinline__ void wide_walk(const AlignArgs& A, typename WideWord<
                 continue;
             }
             const int d = loadD(c, row);
+            if (left_band) return false;
             if (d < 0) {   // read bases opposite a gap
                 for (int x = lane; x < -d; x += 64) { oref[m + x] = '-'; oqry[m + x] = sq[row - 1 - x]; }
                 m -= d; ed -= d; row += d;
@@ -966,6 +1000,7 @@ __device__ __forceinline__ void wide_walk(const AlignArgs& A, typename WideWord<
         m += max(row, 0); ed += max(row, 0);
         if (lane == 0) { A.aln_len[read] = m; A.edits[read] = ed; }
     }
+    return true;
 }
 
 // MODE 0 scores, 1 scores + map + sections, 2 scores + strings + edit distance.  PENSEL: the reference's penalty selects spelled
@@ -1144,7 +1179,7 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
         if (MODE) {
             __threadfence();
             __syncthreads();
-            if (t < 64) wide_walk<K, MODE, STRIPS>(A, dirs, strip_words, CS, Rw, L, R, read, start, t);
+            if (t < 64) (void)wide_walk<K, MODE, STRIPS>(A, dirs, strip_words, CS, Rw, L, R, read, start, t);
         }
         }   // (strips)
     }
@@ -1166,6 +1201,7 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide(const AlignArgs A) {
 constexpr int WQ_B = 128;       // rows of a queue (power of two; producer and consumer are 64 rows apart + WQ_SYNC of slack each way)
 constexpr int WQ_SYNC = 16;     // steps between two looks at the neighbours' progress
 constexpr int WQ_SPINS = 1 << 22;
+constexpr int WIDE_BAND = 96;   // rows either side of the main diagonal whose cells carry codes in the first launch (reads with 1 % indel events drift by a few dozen)
 
 __device__ __forceinline__ int wq_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wq_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -1226,7 +1262,10 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide_q(const AlignArgs A) {
     // horizontal candidate of the next column both are: one subtraction per cell serves both), Dg = score of the column to the
     // left in the row above (this row's diagonal), UJ = running vertical jump score.
     double Sg[K], Dg[K], UJ[K];
-    for (long long read = blockIdx.x; read < A.n; read += gridDim.x) {
+    // the reads of this launch: 0 .. n - 1, or (the launch behind a banded one) the reads whose walks left the band
+    const long long nwork = A.wide_list ? static_cast<long long>(A.wide_list[-1]) : A.n;
+    for (long long item = blockIdx.x; item < nwork; item += gridDim.x) {
+        const long long read = A.wide_list ? static_cast<long long>(A.wide_list[item]) : item;
         const long long start = A.off[read];
         const int L = static_cast<int>(A.off[read + 1] - start);
         __syncthreads();   // (the walk of the alignment before is done with the tile; the tables are in place)
@@ -1266,6 +1305,12 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide_q(const AlignArgs A) {
         };
         RawRow pf = request_row(1 + lane);
         const int nsteps = L > 0 ? L + 63 : 0;   // lane 63 finishes row L at step L + 62
+        // Codes for the cells near the main diagonal only (wide_band > 0): the steps [c_lo, c_hi] of this wavefront.  Outside them
+        // a step still takes the two comparisons that say which move a cell made -- the flags the next row, the next column and the
+        // next wavefront take from it stay right everywhere -- but not the two jump comparisons, the four bit pushes and the store.
+        const WideBand wband{MODE ? A.wide_band : 0, L, R};
+        const bool banded = MODE != 0 && A.wide_band > 0;
+        const int c_lo = banded ? wband.lo(wv) : 0, c_hi = banded ? wband.hi(wv) : 0x7fffffff;
         bool aborted = false;
         // what every step starts with: the ring refill and, every WQ_SYNC steps, the look at the neighbours; false: give up
         auto step_head = [&](int sg) -> bool {
@@ -1367,7 +1412,11 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide_q(const AlignArgs A) {
 #pragma unroll
         for (int k = 0; k < K; ++k) m_up[k] = MODE ? __builtin_amdgcn_ballot_w64(((upneg >> k) & 1u) != 0u) : 0;
         mask_t m_lp_out = MODE ? __builtin_amdgcn_ballot_w64(lpos_out != 0) : 0;
-        for (; !aborted && sg < nsteps; ++sg) {
+        // (three loops -- before, inside and behind the steps that carry codes -- rather than one loop with both versions of the cells:
+        // with both in one loop the allocator spilled in the cells, 65 -> 102 ms)
+        auto main_steps = [&](auto coded_tag, int s_end) {
+          constexpr bool CODED = decltype(coded_tag)::value;
+          for (; !aborted && sg < s_end; ++sg) {
             if (!step_head(sg)) { aborted = true; break; }
             const int i = sg - lane + 1;
             const bool active = i <= L;
@@ -1382,35 +1431,39 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide_q(const AlignArgs A) {
             double cost[K], curs[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) cost[k] = *reinterpret_cast<const double*>(tabb + cb[k] + ent);   // (requested back to back, ahead of the chain of cells)
-            double hopen = ls - GO;
+            {
+                double hopen = ls - GO;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                // (src/reference_align.cpp:125-177 without the penalty selects: see k_align's "Penalty selection")
-                const double vopen = Sg[k];
-                const double ljm = lj - GE;
-                const mask_t m_hcr = __builtin_amdgcn_ballot_w64(ljm > hopen);
-                const double horiz = fmax(ljm, hopen);
-                lj = horiz;
-                const double ujm = UJ[k] - GE;
-                const mask_t m_vcr = __builtin_amdgcn_ballot_w64(ujm > vopen);
-                const double vert = max_f64_raw(ujm, vopen);
-                UJ[k] = vert;
-                const double match = Dg[k] + cost[k];
-                Dg[k] = ls;
-                const double hv = max_f64_raw(horiz, vert);
-                const double cur = max_f64_raw(match, hv);
-                if (MODE) {
-                    const mask_t m_tm = __builtin_amdgcn_ballot_w64(match > hv), m_hv = __builtin_amdgcn_ballot_w64(horiz > vert);
-                    const mask_t m_k1 = m_hv & ~m_tm, m_k2 = ~(m_hv | m_tm);   // horizontal gap / vertical gap (neither: diagonal)
-                    const mask_t m_hc = m_hcr & ~m_lp, m_vc = m_vcr & ~m_up[k];   // the jumps really continued
-                    m_lp = m_k1;
-                    m_up[k] = m_k2;
-                    w = push_bit(push_bit(push_bit(push_bit(w, m_vc), m_hc), m_k2), m_k1);   // column k ends up in nibble K - 1 - k
+                for (int k = 0; k < K; ++k) {
+                    // (src/reference_align.cpp:125-177 without the penalty selects: see k_align's "Penalty selection")
+                    const double vopen = Sg[k];
+                    const double ljm = lj - GE;
+                    const mask_t m_hcr = CODED ? __builtin_amdgcn_ballot_w64(ljm > hopen) : 0;
+                    const double horiz = fmax(ljm, hopen);
+                    lj = horiz;
+                    const double ujm = UJ[k] - GE;
+                    const mask_t m_vcr = CODED ? __builtin_amdgcn_ballot_w64(ujm > vopen) : 0;
+                    const double vert = max_f64_raw(ujm, vopen);
+                    UJ[k] = vert;
+                    const double match = Dg[k] + cost[k];
+                    Dg[k] = ls;
+                    const double hv = max_f64_raw(horiz, vert);
+                    const double cur = max_f64_raw(match, hv);
+                    if (MODE) {
+                        const mask_t m_tm = __builtin_amdgcn_ballot_w64(match > hv), m_hv = __builtin_amdgcn_ballot_w64(horiz > vert);
+                        const mask_t m_k1 = m_hv & ~m_tm, m_k2 = ~(m_hv | m_tm);   // horizontal gap / vertical gap (neither: diagonal)
+                        if (CODED) {
+                            const mask_t m_hc = m_hcr & ~m_lp, m_vc = m_vcr & ~m_up[k];   // the jumps really continued
+                            w = push_bit(push_bit(push_bit(push_bit(w, m_vc), m_hc), m_k2), m_k1);   // column k ends up in nibble K - 1 - k
+                        }
+                        m_lp = m_k1;
+                        m_up[k] = m_k2;
+                    }
+                    curs[k] = cur;
+                    ls = cur;
+                    hopen = cur - GO;   // the next column's horizontal candidate and, one step on, this column's vertical one
+                    Sg[k] = hopen;
                 }
-                curs[k] = cur;
-                ls = cur;
-                hopen = cur - GO;   // the next column's horizontal candidate and, one step on, this column's vertical one
-                Sg[k] = hopen;
             }
             ls_out = ls;
             lj_out = lj;
@@ -1423,14 +1476,18 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide_q(const AlignArgs A) {
             }
             if (active) {
                 // (word of thread t at its step i + t = sg + 1 + 64 wv, the same for every lane: a scalar row address + the lane's offset)
-                if (MODE) __builtin_nontemporal_store(static_cast<Word>(w), dirs + static_cast<long long>(sg + 1 + 64 * wv) * T + t);
+                if (MODE && CODED) __builtin_nontemporal_store(static_cast<Word>(w), dirs + static_cast<long long>(sg + 1 + 64 * wv) * T + t);
                 if (has_next && lane == 63) {   // my last column's row state for the wavefront after me
                     const int e = wv * WQ_B + ((i - 1) & (WQ_B - 1));
                     q_s[e] = ls; q_lj[e] = lj;
                     if (MODE) q_fl[e] = static_cast<int>((m_lp >> 63) & 1ull);
                 }
             }
-        }
+          }
+        };
+        if (MODE != 0) main_steps(Flag<false>{}, min(nsteps, c_lo));
+        main_steps(Flag<MODE != 0>{}, c_hi < nsteps - 1 ? c_hi + 1 : nsteps);
+        if (MODE != 0) main_steps(Flag<false>{}, nsteps);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) { wq_store(&s_cons[wv], L); wq_store(&s_prog[wv], aborted ? 0 : L); }
         if (aborted && lane == 0) atomicExch(A.badqual + 1, 1);
@@ -1438,7 +1495,10 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide_q(const AlignArgs A) {
         if (MODE) {
             __threadfence();
             __syncthreads();
-            if (t < 64 && wq_load(s_abort) == 0) wide_walk<K, MODE, false>(A, dirs, 0, T * K, T, L, R, read, start, t);
+            if (t < 64 && wq_load(s_abort) == 0) {
+                const bool done = wide_walk<K, MODE, false>(A, dirs, 0, T * K, T, L, R, read, start, t, banded ? &wband : nullptr);
+                if (!done && t == 0) A.wide_redo[1 + atomicAdd(A.wide_redo, 1)] = static_cast<int>(read);   // again, with the codes of every cell
+            }
         }
     }
 }
@@ -1659,7 +1719,21 @@ static int launch_wide(AlignArgs& a, int R, int kernel_mode, int32_t max_len, lo
         }                                                                                                                          \
         hipLaunchKernelGGL((k_align_wide_q<K, MM>), g, b, ldq, stream, a);                                                         \
     }
+        // With traceback: codes only for the steps that can hold cells within WIDE_BAND rows of the main diagonal (40 % of the steps
+        // at 2 kb x 2 kb), then a second launch, with the codes of every cell, over the reads whose walks left them (their count
+        // stays on the device: no wait in between; none for reads of the reference's molecule).  align_wide_band = -1: no band.
+        const int band = kernel_mode == 0 || option(OPT_ALIGN_WIDE_BAND) < 0 ? 0 : (option(OPT_ALIGN_WIDE_BAND) > 0 ? option(OPT_ALIGN_WIDE_BAND) : WIDE_BAND);
+        int* d_redo = nullptr;
+        if (band > 0) {
+            SL_TRY(scratch("align.redo", static_cast<size_t>(n) + 2, &d_redo));
+            SL_HIP(hipMemsetAsync(d_redo, 0, sizeof(int), stream));
+        }
+        a.wide_band = band; a.wide_redo = d_redo; a.wide_list = nullptr;
         if (kernel_mode == 0) WIDEQ_LAUNCH(0) else if (kernel_mode == 1) WIDEQ_LAUNCH(1) else WIDEQ_LAUNCH(2)
+        if (band > 0) {
+            a.wide_band = 0; a.wide_list = d_redo + 1;
+            if (kernel_mode == 1) WIDEQ_LAUNCH(1) else WIDEQ_LAUNCH(2)
+        }
 #undef WIDEQ_LAUNCH
         SL_HIP(hipGetLastError());
         return 0;

@@ -350,18 +350,25 @@ def test_wide_references_both_kernels(oracle, oenc, enc):
             ref = "".join(rng.choice(nuc, R))
             reads = [_mutate(rng, ref) for _ in range(3)]
             reads += ["", ref[:5], ref[100:163], ref[7:71], ref[:700] + "N" * 9 + ref[709:1000],
-                      "".join(rng.choice(nuc, 90)) + ref + "".join(rng.choice(nuc, 150))]
+                      "".join(rng.choice(nuc, 90)) + ref + "".join(rng.choice(nuc, 150)),
+                      "".join(rng.choice(nuc, R - 40)), ref[R // 2:], ref[:R // 3] + ref[R // 3 + 150:]]   # unrelated; half; a 150-base deletion
             quals = rand_quals(reads, R, lo=35, hi=90)
             want = oracle.general_align(reads, quals, oenc, 2.5, 0.75, ref)
             want_s = oracle.barcode_align(reads, quals, oenc, 0, 1, ref)
-            for barrier in (0, 1):
+            # (barrier, band): the old kernel; the queue kernel with the codes of every cell, with its default band of codes around
+            # the main diagonal (the unrelated reads and the ones with flanks leave it: second launch), and with a band of 8 rows
+            # (nearly every read is aligned twice)
+            for barrier, band in ((1, 0), (0, -1), (0, 0), (0, 8)):
                 calls.set_option("align_wide_barrier", barrier)
+                calls.set_option("align_wide_band", band)
                 got = calls.general_align(reads, quals, enc, 2.5, 0.75, ref, False)
-                assert np.array_equal(bits(want[0]), bits(got[0])) and np.array_equal(want[1], got[1]), (R, barrier)
-                assert want[2] == got[2] and want[3] == got[3], (R, barrier)
-                assert np.array_equal(bits(want_s), bits(calls.barcode_align(reads, quals, enc, 0, 1, ref))), (R, barrier)
+                assert np.array_equal(bits(want[0]), bits(got[0])) and np.array_equal(want[1], got[1]), (R, barrier, band)
+                assert want[2] == got[2] and want[3] == got[3], (R, barrier, band)
+                assert np.array_equal(want[1], calls.general_align(reads, quals, enc, 2.5, 0.75, ref, True)[1]), (R, barrier, band)
+                assert np.array_equal(bits(want_s), bits(calls.barcode_align(reads, quals, enc, 0, 1, ref))), (R, barrier, band)
     finally:
         calls.set_option("align_wide_barrier", 0)
+        calls.set_option("align_wide_band", 0)
 
 
 def test_wide_local_mode_across_strips(oracle, oenc, enc):
