@@ -1233,10 +1233,15 @@ __global__ void __launch_bounds__(WIDE_MAXT) k_align_wide_q(const AlignArgs A) {
     using Word = typename WideWord<K>::type;
     extern __shared__ __align__(16) unsigned char w_smem[];
     const int T = static_cast<int>(blockDim.x);
-    const int t = static_cast<int>(threadIdx.x);
-    const int lane = t & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lane = static_cast<int>(threadIdx.x) & 63;
     const int NWV = T >> 6;
+    // Which 512 columns a wavefront takes is rotated from workgroup to workgroup: hardware wavefront h of every workgroup sits on
+    // SIMD h mod 4, and with the codes confined to a band the wavefronts near the diagonal have more to issue than the others --
+    // without the rotation the four SIMDs of a CU take turns at being the busy one.  `wv` and `t` are the LOGICAL indices (the
+    // wavefront's position along the reference, the thread's position among the column owners) everywhere below.
+    const int hw = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    const int wv = (hw + static_cast<int>((blockIdx.x * 2654435761u) >> 16)) % NWV;
+    const int t = wv * 64 + lane;
     const int R = A.R;
     double* const s_tab = reinterpret_cast<double*>(w_smem);
     double* const q_s = s_tab + A.tab_doubles;                          // [NWV][WQ_B] score of a wavefront's last column, by row
