@@ -274,7 +274,7 @@ def _giant_group_leg(args, rank, world, dist, device, gather_device, backend, en
                    "kernel_ms": dict({k: _lib.stage_ms(k) for k in ("msa_pairwise", "msa_merge", "consensus")}, umi_pairs=umi_ms),
                    "umi": umi_stats, "umi_workspace_gb": umi_ws / 1e9,
                    "msa": dict({k: _lib.stage_count("msa_host_%s_s" % k) for k in ("plan", "upload_alloc", "pairwise_launch", "rows", "total")},
-                               **{k: _lib.stage_count("msa2_" + k) for k in ("batches", "groups_second_pass", "first_exit_s", "last_exit_s", "exit_s_1wave", "exit_s_8waves")},
+                               **{k: _lib.stage_count("msa2_" + k) for k in ("batches", "groups_second_pass", "first_exit_s", "last_exit_s", "exit_s_1wave", "exit_s_8waves", "mem_all_gb", "mem_budget_gb")},
                                pairs=_lib.stage_count("msa_pairs"), pairs_run_again=_lib.stage_count("msa_bitvector_redone"))}
         except Exception as e:   # noqa: BLE001
             e1 = e

@@ -1613,10 +1613,18 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
     // own under the merging of batch k (memory-latency bound); two sets of workspaces alternate.
     size_t free_b = 0, total_b = 0;
     SL_HIP(hipMemGetInfo(&free_b, &total_b));
-    long long reusable = 0;   // the workspaces of an earlier call are grown in place, not added
-    for (const char* pfx : {"m2a", "m2b"})
-        for (const char* nm : {".map", ".pos", ".col", ".tab"}) { auto it = c.ws.find(std::string(pfx) + nm); if (it != c.ws.end()) reusable += static_cast<long long>(it->second.cap); }
-    const long long mem_budget = std::max<long long>(1LL << 30, std::min<long long>(96LL << 30, (static_cast<long long>(free_b) + reusable) / 2));
+    // the workspaces an earlier call left are grown in place, not added: everything this stage holds -- the batches' maps, positions,
+    // columns and tables, but also the pairwise kernel's traceback records and move strings, the merging's per-workgroup scratch and
+    // the rows (counting only the first four made the SECOND of two equal calls see half the room and cut itself into 5 batches
+    // where the first took 3)
+    long long reusable = 0;
+    for (const auto& kv : c.ws)
+        if (kv.first.compare(0, 2, "m2") == 0 || kv.first.compare(0, 4, "msa.") == 0 || kv.first.compare(0, 5, "msa2.") == 0)
+            reusable += static_cast<long long>(kv.second.cap);
+    // (msa2_budget_gb: the cap in GB, tests and sweeps; the default leaves the other half of what is free to the traceback records of
+    // the pairwise kernel, the per-workgroup scratch of the merging and the rows)
+    const long long budget_cap = option(OPT_MSA2_BUDGET_GB) > 0 ? static_cast<long long>(option(OPT_MSA2_BUDGET_GB)) << 30 : 96LL << 30;
+    const long long mem_budget = std::max<long long>(1LL << 30, std::min<long long>(budget_cap, (static_cast<long long>(free_b) + reusable) / 2));
     const long long job_budget = 12000000;
     double cells = 0, pairs = 0;
     double counters[M2C_N] = {};
@@ -1687,6 +1695,8 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         // (one batch when everything fits -- then the stage timers do not overlap either; from two on the two workspace
         // sets share the budget.  Measured at C4 with two pipelined batches: pure groups 5 % faster end to end, clusters
         // of several molecules unchanged -- the alignments saturate the vector units by themselves.)
+        c.counts["msa2_mem_all_gb"] = static_cast<double>(mem_all) / 1073741824.0;
+        c.counts["msa2_mem_budget_gb"] = static_cast<double>(mem_budget) / 1073741824.0;
         long long nb = std::max<long long>(1, std::max((mem_all + mem_budget - 1) / mem_budget, (jobs_all + job_budget - 1) / job_budget));
         const long long want = option(OPT_MSA2_BATCHES) > 0 ? option(OPT_MSA2_BATCHES) : 1;
         if (std::max(nb, want) > 1) nb = std::max<long long>(want, std::max((2 * mem_all + mem_budget - 1) / mem_budget, (jobs_all + job_budget - 1) / job_budget));
