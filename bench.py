@@ -268,7 +268,9 @@ def _giant_group_leg(args, rank, world, dist, device, gather_device, backend, en
             torch.cuda.synchronize()
             t3 = time.perf_counter()
             free_b, total_b = torch.cuda.mem_get_info()
-            res = {"t": (t1 - t0, t2 - t1, t3 - t2, t3 - t0), "st": st, "coff": coff, "cmem": cmem, "big": big, "owner": owner,
+            ws_total, ws_top = _lib.workspace_report(10)
+            res = {"t": (t1 - t0, t2 - t1, t3 - t2, t3 - t0), "ws": {"library_workspaces_gb": ws_total / 1e9, "largest_gb": {n: b / 1e9 for n, b in ws_top},
+                                                                     "torch_allocated_gb": torch.cuda.memory_allocated() / 1e9, "torch_reserved_gb": torch.cuda.memory_reserved() / 1e9}, "st": st, "coff": coff, "cmem": cmem, "big": big, "owner": owner,
                    "cons": cons, "phred": phred, "gflat": gflat, "largest_cluster": int(sizes.max()) if sizes.size else 0,
                    "hbm_in_use_gb": (total_b - free_b) / 1e9, "v1_fallback": _lib.stage_count("msa_v1_fallback"),
                    "kernel_ms": dict({k: _lib.stage_ms(k) for k in ("msa_pairwise", "msa_merge", "consensus")}, umi_pairs=umi_ms),
@@ -335,7 +337,7 @@ def _giant_group_leg(args, rank, world, dist, device, gather_device, backend, en
                             "pairs_stay_in_hbm": bool(r["st"].get("pairs_on_device", False))},
                "n_ranks_seen": int(sm[5]), "clusters": int(r["coff"].size - 1), "clusters_of_two_and_more": int(big.size),
                "largest_cluster": r["largest_cluster"], "groups_aligned_by_spec_v1": int(sm[6]), "hbm_in_use_gb_max": tm[12],
-               "umi_workspace_released_before_msa_gb": r["umi_workspace_gb"], "msa_stage_rank0": r["msa"],
+               "umi_workspace_released_before_msa_gb": r["umi_workspace_gb"], "msa_stage_rank0": r["msa"], "memory_rank0": r["ws"],
                "consensus_reads": int(sm[0]), "consensus_bases": int(sm[1]), "reads_in_clusters": int(sm[2]),
                "identical_to_single_rank": {"clusters": clusters_same, "consensus_of_sampled_clusters": bool(same), "sampled_clusters": int(pick.size)},
                "workload": "BASELINE configs[4] as worded, weak scaling: the %d x %d reads of all ranks as ONE pre-group (umiGroup without "

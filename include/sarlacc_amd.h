@@ -50,6 +50,9 @@ void sarlacc_release_workspace(void);
  * 17 GB after a call on 8 x 10^6 UMIs) -- for pipelines that go on to the MSA stage in the same process and want that memory
  * for it.  Returns the number of bytes given back. */
 int64_t sarlacc_release_umi_workspace(void);
+/* What the library's cached device buffers hold right now: "name bytes" lines, largest first, into buf (truncated at cap);
+ * returns the total in bytes (diagnostics: bench.py reports the largest ones of the giant pre-group leg). */
+int64_t sarlacc_workspace_report(char* buf, int64_t cap);
 /* Duration in ms of a named group of kernel launches of the last call that ran it (HIP events on
  * the launch stream, summed over the batches of the call): "msa_pairwise", "msa_merge", "consensus", "umi_pairs";
  * <0 if it never ran. */

@@ -71,6 +71,7 @@ def lib():
         _lib.sarlacc_stage_ms.restype = C.c_double
         _lib.sarlacc_stage_count.restype = C.c_double
         _lib.sarlacc_release_umi_workspace.restype = C.c_int64
+        _lib.sarlacc_workspace_report.restype = C.c_int64
     return _lib
 
 
@@ -133,6 +134,14 @@ def set_device(device):
 def release_umi_workspace():
     """sarlacc_release_umi_workspace: gives the umi_group stage's cached device buffers back (bytes freed)."""
     return int(lib().sarlacc_release_umi_workspace())
+
+
+def workspace_report(top=12):
+    """sarlacc_workspace_report: (total bytes, [(name, bytes), ...] of the `top` largest cached device buffers)."""
+    buf = C.create_string_buffer(1 << 16)
+    total = int(lib().sarlacc_workspace_report(buf, C.c_int64(len(buf))))
+    rows = [ln.rsplit(" ", 1) for ln in buf.value.decode().splitlines() if ln]
+    return total, [(n, int(b)) for n, b in rows[:top]]
 
 
 def stage_ms(name):

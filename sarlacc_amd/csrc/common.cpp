@@ -1,6 +1,9 @@
 // common.cpp -- error reporting, device context and workspace cache.
 #include "common.hpp"
 
+#include <algorithm>
+#include <vector>
+
 #include <cstdlib>
 
 #include "../../include/sarlacc_amd.h"
@@ -78,7 +81,9 @@ int Context::buffer(const char* name, size_t bytes, void** out) {
         if (w.ptr) SL_HIP(hipFree(w.ptr));
         w.ptr = nullptr;
         w.cap = 0;
-        size_t want = bytes + bytes / 4 + 256;
+        // a quarter of slack so that a slowly growing request does not reallocate every call -- but at most 256 MB of it: on the
+        // 48-GB tile of traceback records and the 30-GB map sets of a large MSA call a quarter was 30 GB of HBM nobody used
+        size_t want = bytes + std::min<size_t>(bytes / 4, size_t(256) << 20) + 256;
         hipError_t e = hipMalloc(&w.ptr, want);
         if (e != hipSuccess) {
             want = bytes;
@@ -197,6 +202,23 @@ int64_t sarlacc_release_umi_workspace(void) {
         }
     }
     return freed;
+}
+
+int64_t sarlacc_workspace_report(char* buf, int64_t cap) {
+    // "name bytes" lines of the cached device buffers of this thread, largest first; returns their total
+    sarlacc::Context& c = sarlacc::ctx();
+    std::vector<std::pair<size_t, std::string>> v;
+    int64_t total = 0;
+    for (const auto& kv : c.ws) { v.emplace_back(kv.second.cap, kv.first); total += static_cast<int64_t>(kv.second.cap); }
+    std::sort(v.begin(), v.end(), [](const std::pair<size_t, std::string>& a, const std::pair<size_t, std::string>& b) { return a.first > b.first; });
+    std::string out;
+    for (const auto& e : v) out += e.second + " " + std::to_string(e.first) + "\n";
+    if (buf && cap > 0) {
+        const size_t nbytes = std::min<size_t>(static_cast<size_t>(cap) - 1, out.size());
+        std::memcpy(buf, out.data(), nbytes);
+        buf[nbytes] = 0;
+    }
+    return total;
 }
 
 double sarlacc_stage_ms(const char* name) {
