@@ -311,7 +311,7 @@ int sarlacc_dev_umi_group_from_pairs(const char* umi, const int64_t* off, int64_
  * T-Coffee, which cannot be run or pinned here): 2 (default) = consistency-based progressive alignment --
  * all-pairs banded alignments, primary library, triplet extension, neighbour-joining guide tree, progressive
  * heaviest-common-subsequence merging -- for groups of up to 64 reads, 1 = centre-star (also used by spec 2 for
- * larger groups and for reads beyond 21 823 bases).  0 restores the default, spec 2 (SARLACC_MSA_SPEC only sets the
+ * larger groups, for reads beyond 65 471 bases and for alignments wider than 65 535 columns).  0 restores the default, spec 2 (SARLACC_MSA_SPEC only sets the
  * value the process starts with: the environment is read once). */
 int sarlacc_set_msa_spec(int spec);
 

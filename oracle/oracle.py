@@ -345,12 +345,12 @@ def msa2_stats(reset=True):
     return dict(zip(MSA2_STAT_NAMES, buf.tolist()))
 
 
-def quick_msa(groupings, sequences, match, mismatch, gap_extension, gap_opening, bandwidth, spec=2, tcoffee_max=64):
+def quick_msa(groupings, sequences, match, mismatch, gap_extension, gap_opening, bandwidth, spec=2, tcoffee_max=64, max_columns=65535):
     """Same argument order as the reference .Call (src/quick_msa.cpp:15): note that
     the R caller passes (-gapOpening, -gapExtension) into (gap_extension, gap_opening)
     (R/multiReadAlign.R:47, SURVEY App.B Q15).  spec 2 (default): consistency-based progressive
-    alignment (msa2.c) for groups of up to `tcoffee_max` reads no longer than 21 823 bases, spec 1
-    (centre-star, msa.c) beyond that and when spec == 1 -- the same policy as the product."""
+    alignment (msa2.c) for groups of up to `tcoffee_max` reads of at most 65 471 bases whose alignment has at most 65 535
+    columns, spec 1 (centre-star, msa.c) beyond that and when spec == 1 -- the same policy as the product."""
     out = []
     for g in groupings:
         reads = [sequences[i - 1] for i in g]
@@ -363,9 +363,13 @@ def quick_msa(groupings, sequences, match, mismatch, gap_extension, gap_opening,
         buf = np.zeros(cap, np.uint8)
         width = C.c_int64()
         longest = int(np.diff(so).max()) if m else 0
-        fn = lib().orc_msa2_group if (spec == 2 and m <= tcoffee_max and 3 * longest + 64 <= 65535) else lib().orc_msa_group
+        v2 = spec == 2 and m <= tcoffee_max and longest + 64 <= 65535
+        fn = lib().orc_msa2_group if v2 else lib().orc_msa_group
         _check(fn(_p(sb), _p(so), C.c_int64(m), int(match), int(mismatch), int(gap_opening),
                   int(gap_extension), int(bandwidth), _p(buf), C.c_int64(cap), C.byref(width)))
+        if v2 and width.value > max_columns:   # (an alignment wider than 16-bit columns: spec v1, as the product decides after the fact)
+            _check(lib().orc_msa_group(_p(sb), _p(so), C.c_int64(m), int(match), int(mismatch), int(gap_opening),
+                                       int(gap_extension), int(bandwidth), _p(buf), C.c_int64(cap), C.byref(width)))
         W = width.value
         out.append([buf[r * W:(r + 1) * W].tobytes().decode() for r in range(m)])
     return out

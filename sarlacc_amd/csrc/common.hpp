@@ -63,6 +63,7 @@ enum Opt {
     OPT_UMI_SCAN_SINGLE,      // split-key search: one candidate column per lane also where two fit (A/B of k_sk_scan_pk)
     OPT_ALIGN_WIDE_BARRIER,   // references beyond 1 024 columns: the kernel with a barrier per step also where the queue kernel applies (A/B)
     OPT_MSA2_BUDGET_GB,       // spec v2: cap (GB) of the memory one batch of groups may take (default 96; at most half of what is free)
+    OPT_MSA2_MAX_COLUMNS,     // spec v2: alignments wider than this go to spec v1 (default and maximum 65535: 16-bit columns; tests lower it)
     OPT_ALIGN_WIDE_BAND,      // k_align_wide_q with traceback: rows either side of the main diagonal that carry codes in the first launch (default 96; -1: every cell)
     OPT_N
 };

@@ -63,7 +63,6 @@ constexpr int M2_CAP = 16;           // partner columns per row (spec v2, step 5
 constexpr unsigned M2_NONE = 0xFFFFu;
 // profile capacity of the first pass: same-molecule reads grow a profile by 10-20 %, one or two unrelated reads in
 // the cluster by their length each
-#define M2_FASTW(maxlen) (3 * (maxlen) + 64)
 // ... by group size: a cluster of n reads out of umi_group holds about n / 10 molecules (UMI collisions), whose profiles do
 // not align -- one more read length per 8 reads beyond 11.  (With 3 maxlen + 64 for every size the clusters of three and
 // more molecules, the most expensive groups of a call, ran out of columns and were done twice, all-pairs alignments
@@ -1248,7 +1247,9 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
         const long long fast_w = m2_fast_width(n, mx);
         // (65535 columns is the ceiling of spec v2: positions and columns are 16-bit; only reachable when the sum of
         // the read lengths exceeds it AND the alignment really is that wide)
-        G.wcap = static_cast<int>(std::min<long long>(65535, std::min<long long>(sum, exact_w ? sum : fast_w)));
+        // (msa2_max_columns: a lower ceiling, for the tests of the hand-over to spec v1)
+        const long long ceiling = option(OPT_MSA2_MAX_COLUMNS) > 0 ? std::min(65535, option(OPT_MSA2_MAX_COLUMNS)) : 65535;
+        G.wcap = static_cast<int>(std::min<long long>(ceiling, std::min<long long>(sum, exact_w ? sum : fast_w)));
         if (G.wcap < 1) G.wcap = 1;
         G.pos_base = pos_pos;
         G.first_job = job_pos;
@@ -1576,7 +1577,7 @@ static int m2_write_batch(M2Batch& B, const std::string& pf, const std::vector<l
 static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vector<int64_t>& ids, const uint8_t* d_seq,
                      const std::vector<int64_t>& rel, double match, double mismatch, double gap_extension, double gap_opening,
                      int bandwidth, std::vector<int32_t>& width, std::vector<long long>& off, uint8_t** d_rows,
-                     const std::function<int()>* overlap, const CodeSpec& code, hipStream_t s) {
+                     const std::function<int()>* overlap, const CodeSpec& code, hipStream_t s, std::vector<size_t>* gave_up) {
     Context& c = ctx();
     const size_t cs = code.want ? 2 : 1;   // bytes per cell of the row buffer (offsets and widths stay in cells)
     bool waited = false;
@@ -1756,8 +1757,9 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             std::sort(byslot.begin(), byslot.end(), [&](size_t x, size_t y) { return B.slot[x] < B.slot[y]; });
             for (size_t q : byslot) {
                 if (B.ovf[q]) {   // profile capacity exceeded: next pass
-                    if (exact_w) return fail("sarlacc_amd: an alignment wider than 65535 columns is beyond spec v2 (select spec 1 with sarlacc_set_msa_spec)");
-                    again.push_back(B.slot[q]);
+                    // (with profiles as wide as 16-bit columns allow and still too narrow: the alignment is wider than 65 535 columns,
+                    // beyond spec v2 -- the caller hands the group to spec v1)
+                    if (exact_w) gave_up->push_back(B.slot[q]); else again.push_back(B.slot[q]);
                     bw[q] = 0;
                     continue;
                 }
@@ -1851,7 +1853,9 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
         int64_t mx = 0;
         for (int64_t a = 0; a < n; ++a) { const int32_t id = grp[grp_off[g] + a]; mx = std::max<int64_t>(mx, rel[id] - rel[id - 1]); }
         if (mx > 60000) return fail("sarlacc_amd: reads longer than 60000 bases are not supported by the MSA stage");
-        if (n <= M2_MAXN && M2_FASTW(mx) <= 65535) v2.push_back(g); else v1.push_back(g);
+        // spec v2: up to M2_MAXN reads, each short enough for 16-bit positions (a profile that outgrows 65 535 COLUMNS sends its group
+        // to spec v1 afterwards: msa2_core's gave_up)
+        if (n <= M2_MAXN && mx + 64 <= 65535) v2.push_back(g); else v1.push_back(g);
     }
     SL_TRY(ensure_device());
     Context& c = ctx();
@@ -1882,8 +1886,14 @@ int msa_run(const int64_t* grp_off, const int32_t* grp, int64_t ngroups, const c
     std::vector<int32_t> w2;
     std::vector<long long> o2;
     uint8_t* d_rows2 = nullptr;
-    SL_TRY(msa2_core(grp_off, grp, v2, d_seq, rel, match, mismatch, gap_extension, gap_opening, bandwidth, w2, o2, &d_rows2, overlap, res->code, s));
+    std::vector<size_t> gave_up;
+    SL_TRY(msa2_core(grp_off, grp, v2, d_seq, rel, match, mismatch, gap_extension, gap_opening, bandwidth, w2, o2, &d_rows2, overlap, res->code, s, &gave_up));
+    if (!gave_up.empty()) {   // alignments wider than 65 535 columns: spec v1 (the list stays in group order)
+        for (size_t q : gave_up) v1.push_back(v2[q]);
+        std::sort(v1.begin(), v1.end());
+    }
     c.counts["msa_v1_fallback"] = static_cast<double>(v1.size());
+    c.counts["msa_v1_fallback_too_wide"] = static_cast<double>(gave_up.size());
     // spec v1 part on a compacted group list: more than M2_MAXN reads, reads too long, or dropped by the guard
     MsaResult r1;
     std::vector<int64_t> g1off(v1.size() + 1, 0);

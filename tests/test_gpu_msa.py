@@ -176,16 +176,72 @@ def test_pairwise_linear_gap_kernel_equals_affine(oracle, spec, params):
 
 
 def test_msa_long_reads(oracle):
-    """40-kb reads: read and centre codes take more than the default 64 KB of dynamic LDS."""
-    from sarlacc_amd import calls
+    """40-kb reads: read and centre codes take more than the default 64 KB of dynamic LDS.  Under spec v1 (what such reads got
+    until round 5) and under spec v2, which takes reads of up to 65 471 bases since: positions and columns are 16-bit, so the
+    limit is the alignment's 65 535 columns, not three read lengths of profile capacity."""
+    from sarlacc_amd import _lib, calls
     from sarlacc_amd.mock import NUC, mutate
     rng = np.random.default_rng(8)
     truth = NUC[rng.integers(0, 4, 40000)]
     reads = [mutate(truth, rng, 0.03, 0.005).tobytes().decode() for _ in range(3)]
     groups = [[1, 2, 3]]
+    try:
+        for spec in (1, 2):
+            calls.set_msa_spec(spec)
+            got = calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)
+            assert got == oracle.quick_msa(groups, reads, 0, -1, -5, -1, 100, spec=spec)
+            assert len({len(r) for r in got[0]}) == 1
+            assert spec == 1 or _lib.stage_count("msa_v1_fallback") == 0
+    finally:
+        calls.set_msa_spec(0)
+
+
+def test_msa_spec2_30kb_group(oracle):
+    """A group of four 30-kb reads of one molecule under spec v2 (the round-4 review's case: such reads went to spec v1 because THREE
+    read lengths of first-pass profile capacity do not fit 16-bit columns; the capacity is capped at 65 535 now), with a small
+    group beside it in the same call."""
+    from sarlacc_amd import _lib, calls
+    from sarlacc_amd.mock import NUC, mutate
+    rng = np.random.default_rng(30)
+    truth = NUC[rng.integers(0, 4, 30000)]
+    reads = [mutate(truth, rng, 0.04, 0.008).tobytes().decode() for _ in range(4)]
+    small = NUC[rng.integers(0, 4, 300)]
+    reads += [mutate(small, rng, 0.05, 0.01).tobytes().decode() for _ in range(4)]
+    groups = [[1, 2, 3, 4], [5, 6, 7, 8]]
     got = calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)
+    assert _lib.stage_count("msa_v1_fallback") == 0
     assert got == oracle.quick_msa(groups, reads, 0, -1, -5, -1, 100)
-    assert len({len(r) for r in got[0]}) == 1
+    assert 30000 < len(got[0][0]) < 40000
+    for rows, g in zip(got, groups):
+        assert [r.replace("-", "") for r in rows] == [reads[i - 1] for i in g]
+
+
+def test_msa_spec2_alignment_wider_than_its_columns_goes_to_spec_v1(oracle):
+    """An alignment that outgrows 16-bit columns is handed to spec v1 AFTER spec v2's second pass (`msa_v1_fallback_too_wide`; before
+    round 5 such a call failed).  65 535 columns need more unmatched bases than a test should align, so the ceiling is lowered
+    (option msa2_max_columns, the oracle's `max_columns`): groups of unrelated reads are wider than 480 columns here, groups of one
+    molecule are not -- both kinds in one call, rows in group order."""
+    from sarlacc_amd import _lib, calls
+    from sarlacc_amd.mock import NUC, mutate
+    rng = np.random.default_rng(31)
+    reads, groups = [], []
+    for g in range(8):
+        if g % 2:
+            members = ["".join(rng.choice(list("ACGT"), 400)) for _ in range(4)]
+        else:
+            t = NUC[rng.integers(0, 4, 400)]
+            members = [mutate(t, rng, 0.05, 0.01).tobytes().decode() for _ in range(int(rng.integers(3, 7)))]
+        groups.append(list(range(len(reads) + 1, len(reads) + len(members) + 1)))
+        reads += members
+    try:
+        calls.set_option("msa2_max_columns", 480)
+        got = calls.quick_msa(groups, reads, 0, -1, -5, -1, 100)
+        wide = int(_lib.stage_count("msa_v1_fallback_too_wide"))
+    finally:
+        calls.set_option("msa2_max_columns", 0)
+    want = oracle.quick_msa(groups, reads, 0, -1, -5, -1, 100, max_columns=480)
+    assert got == want
+    assert 1 <= wide <= 4 and wide == sum(1 for rows in oracle.quick_msa(groups, reads, 0, -1, -5, -1, 100) if len(rows[0]) > 480)
 
 
 def test_msa_spec2_mixed_group_sizes(oracle):
