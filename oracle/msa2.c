@@ -22,13 +22,21 @@
  *   4. primary library at base resolution: every aligned pair (a,p)-(b,q) is an edge of weight
  *      w0 = max(1, score(a_p, b_q)).   [SeqAn: buildAlignmentGraph(..., ReScore): segment score, raised to 1
  *      when not positive; SeqAn refines matches to common segments, here every segment is one base]
- *   5. full triplet extension: W(a,p,b,q) = w0[direct] + sum over c of min(w0(a_p,c_r), w0(c_r,b_q))
- *      for every c whose pairwise alignments link p - r - q.                    [SeqAn: tripletLibraryExtension]
- *      Bounded rows: for one column of the first child the candidates are enumerated for a ascending -- first
- *      the direct edges (b ascending), then the triplets (c ascending, b ascending) -- and a candidate whose
- *      partner column is not among the first MSA2_ROWCAP (16) distinct columns seen is ignored.  Same-molecule
- *      reads never come near the bound; it keeps clusters of unrelated reads (UMI collisions), whose library
- *      is dense noise, from costing orders of magnitude more than real ones.   [own rule]
+ *   5. triplet extension with a bounded library: for an ordered pair of reads (a, b) and a position p of a the
+ *      extended library holds at most FOUR partner positions of b --
+ *        slot 0: the direct partner q0 = the position aligned to p in the pairwise alignment of a and b (if any),
+ *                weight w0(a_p, b_q0) + the sum of min(w0(a_p, c_r), w0(c_r, b_q0)) over the third reads c whose
+ *                pairwise alignments link p - r - q0;
+ *        slots 1-3: the first MSA2_LIBRARY (3) OTHER positions of b that a triplet p - r - q names, third reads c in
+ *                ascending order, each with the sum of its triplets' weights;
+ *      triplets that name a further position are ignored.                     [SeqAn: tripletLibraryExtension keeps every
+ *      position; bounded library: own rule -- it makes the library a function of (a, p, b) alone, of fixed size, which is
+ *      what lets the extension run once per group, outside the progressive merging.  Rounds 2-4 kept every position and
+ *      bounded only the ROW; the bound can be moved or the old enumeration switched back for comparison,
+ *      orc_msa2_set_library, tools/msa2_rules.py.]
+ *      A row (column i of the first child) sums the library over its members: a ascending, b ascending, slots 0 to 3,
+ *      weight onto the partner's column.  Bounded rows: a candidate whose partner column is not among the first
+ *      MSA2_ROWCAP (16) distinct columns seen in that order is ignored.       [own rule]
  *      Noise filter: of a row's entries those lighter than half the heaviest are dropped -- the partner
  *      columns reached only through reads unrelated to the rest of the cluster.   [own rule]
  *   6. progressive alignment along the tree: two profiles (lists of columns) are merged by the heaviest
@@ -53,13 +61,17 @@ int orc_fail(const char* msg);
 /* The two own rules of step 5 can be switched off, and their effect counted, to bound what they change
  * (tests/test_oracle_msa2_rules.py, tools/msa2_rules.py).  Process-wide; the defaults are the spec. */
 static int g_nocap = 0, g_nofilter = 0;
+#define MSA2_XMAX 63
+#define MSA2_LIBRARY 3
+static int g_library = MSA2_LIBRARY;   /* other partner positions kept per (a, p, b) beside the direct one: 3 by the spec; -1: the unbounded library of rounds 2-4 */
 enum { ST_JOINS, ST_ROWS, ST_ROWS_WITH_CAND, ST_ROWS_CAPPED, ST_CAND_IGNORED, ST_ENT_BEFORE_FILTER, ST_ENT_FILTERED,
        ST_ROWS_FILTERED, ST_ENT_KEPT, ST_TRIPLES, ST_TRIPLES_2Q, ST_TRIPLES_3Q, ST_TRIPLES_GAPDIRECT, ST_CANDIDATES,
-       ST_ROWS_MULTI, ST_MAX_ROW_ENTRIES, ST_N };
+       ST_ROWS_MULTI, ST_MAX_ROW_ENTRIES, ST_LIB_IGNORED, ST_N };
 static int64_t g_stats[ST_N];
 #define STAT_ADD(k, v) __atomic_fetch_add(&g_stats[k], (int64_t)(v), __ATOMIC_RELAXED)
 
 void orc_msa2_set_rules(int nocap, int nofilter) { g_nocap = nocap; g_nofilter = nofilter; }
+void orc_msa2_set_library(int others) { g_library = others > MSA2_XMAX ? MSA2_XMAX : others; }
 int orc_msa2_stats(int64_t* out, int64_t cap, int reset) {
     for (int k = 0; k < ST_N && k < cap; ++k) out[k] = __atomic_load_n(&g_stats[k], __ATOMIC_RELAXED);
     if (reset) for (int k = 0; k < ST_N; ++k) __atomic_store_n(&g_stats[k], 0, __ATOMIC_RELAXED);
@@ -279,39 +291,59 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t n, int ma, int m
                 const int64_t p = posA[idxA[a] * nA + i];
                 if (p < 0) continue;
                 const char xa = SEQ(&L, a)[p];
-                for (int64_t b = 0; b < n; ++b) {          /* direct edges */
-                    if (!((inB >> b) & 1u)) continue;
-                    const int64_t q = L.map[a * n + b][p];
-                    {   /* statistics only: how many different positions of b do the direct edge and the triplets name */
-                        int64_t q1 = q, q2 = -1, third = 0;
-                        for (int64_t c = 0; c < n; ++c) {
-                            if (c == a || c == b) continue;
-                            const int64_t r = L.map[a * n + c][p];
-                            if (r < 0) continue;
-                            const int64_t qc = L.map[c * n + b][r];
-                            if (qc < 0 || qc == q1 || qc == q2) continue;
-                            if (q1 < 0) q1 = qc; else if (q2 < 0) q2 = qc; else third = 1;
-                        }
-                        STAT_ADD(ST_TRIPLES, 1);
-                        if (q2 >= 0) STAT_ADD(ST_TRIPLES_2Q, 1);
-                        if (third) STAT_ADD(ST_TRIPLES_3Q, 1);
-                        if (q < 0 && q1 >= 0) STAT_ADD(ST_TRIPLES_GAPDIRECT, 1);
+                if (g_library < 0) {   /* the enumeration of rounds 2-4 (kept for tools/msa2_rules.py): unbounded library */
+                    for (int64_t b = 0; b < n; ++b) {          /* direct edges */
+                        if (!((inB >> b) & 1u)) continue;
+                        const int64_t q = L.map[a * n + b][p];
+                        if (q < 0) continue;
+                        ADD(col[L.off[b] + q], w0(xa, SEQ(&L, b)[q], ma, mm));
                     }
-                    if (q < 0) continue;
-                    ADD(col[L.off[b] + q], w0(xa, SEQ(&L, b)[q], ma, mm));
+                    for (int64_t c = 0; c < n; ++c) {          /* through sequence c */
+                        if (c == a) continue;
+                        const int64_t r = L.map[a * n + c][p];
+                        if (r < 0) continue;
+                        const int w1 = w0(xa, SEQ(&L, c)[r], ma, mm);
+                        for (int64_t b = 0; b < n; ++b) {
+                            if (!((inB >> b) & 1u) || b == c) continue;
+                            const int64_t q = L.map[c * n + b][r];
+                            if (q < 0) continue;
+                            const int w2 = w0(SEQ(&L, c)[r], SEQ(&L, b)[q], ma, mm);
+                            ADD(col[L.off[b] + q], w1 < w2 ? w1 : w2);
+                        }
+                    }
+                    continue;
                 }
-                for (int64_t c = 0; c < n; ++c) {          /* through sequence c */
-                    if (c == a) continue;
-                    const int64_t r = L.map[a * n + c][p];
-                    if (r < 0) continue;
-                    const int w1 = w0(xa, SEQ(&L, c)[r], ma, mm);
-                    for (int64_t b = 0; b < n; ++b) {
-                        if (!((inB >> b) & 1u) || b == c) continue;
+                for (int64_t b = 0; b < n; ++b) {
+                    if (!((inB >> b) & 1u)) continue;
+                    /* the extended library of (a, p) towards b: slot 0 = the direct partner, slots 1 .. = the first other
+                     * positions of b named by a triplet, in order of c */
+                    int64_t eq[1 + MSA2_XMAX], ew[1 + MSA2_XMAX];
+                    int64_t ne = 1, ndist = 0;
+                    eq[0] = L.map[a * n + b][p];
+                    ew[0] = eq[0] >= 0 ? w0(xa, SEQ(&L, b)[eq[0]], ma, mm) : 0;
+                    for (int64_t c = 0; c < n; ++c) {
+                        if (c == a || c == b) continue;
+                        const int64_t r = L.map[a * n + c][p];
+                        if (r < 0) continue;
                         const int64_t q = L.map[c * n + b][r];
                         if (q < 0) continue;
+                        const int w1 = w0(xa, SEQ(&L, c)[r], ma, mm);
                         const int w2 = w0(SEQ(&L, c)[r], SEQ(&L, b)[q], ma, mm);
-                        ADD(col[L.off[b] + q], w1 < w2 ? w1 : w2);
+                        const int w = w1 < w2 ? w1 : w2;
+                        int64_t k;
+                        for (k = 0; k < ne; ++k) if (eq[k] == q) { ew[k] += w; break; }
+                        if (k == ne) {
+                            ++ndist;
+                            if (ne < 1 + g_library) { eq[ne] = q; ew[ne] = w; ++ne; }
+                            else STAT_ADD(ST_LIB_IGNORED, 1);
+                        }
                     }
+                    STAT_ADD(ST_TRIPLES, 1);
+                    if (ndist + (eq[0] >= 0) >= 2) STAT_ADD(ST_TRIPLES_2Q, 1);
+                    if (ndist + (eq[0] >= 0) >= 3) STAT_ADD(ST_TRIPLES_3Q, 1);
+                    if (eq[0] < 0 && ndist) STAT_ADD(ST_TRIPLES_GAPDIRECT, 1);
+                    for (int64_t k = 0; k < ne; ++k)
+                        if (eq[k] >= 0) ADD(col[L.off[b] + eq[k]], ew[k]);
                 }
             }
 #undef ADD

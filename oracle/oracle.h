@@ -167,8 +167,11 @@ int orc_msa2_group(const char* seq, const int64_t* off, int64_t nreads,
 /* spec v2's own rules (row cap, noise filter) switched off for A/B runs, and counters of how often they act:
  * joins, rows, rows with candidates, rows capped, candidates ignored by the cap, entries before the filter,
  * entries filtered, rows filtered, entries kept, (a,p,b) triples, triples naming >= 2 / >= 3 positions of b,
- * triples whose direct edge is a gap, candidates, rows with > 1 entry, most entries in a row. */
+ * triples whose direct edge is a gap, candidates, rows with > 1 entry, most entries in a row, partner positions the
+ * bounded library ignored. */
 void orc_msa2_set_rules(int nocap, int nofilter);
+/* other partner positions kept per (a, p, b) beside the direct one (spec: 3); -1 = the unbounded library of rounds 2-4 */
+void orc_msa2_set_library(int others);
 int orc_msa2_stats(int64_t* out, int64_t cap, int reset);
 int orc_msa2_tree(const char* seq, const int64_t* off, int64_t nreads,
                   int match, int mismatch, int gapopen, int gapext, int bandwidth,

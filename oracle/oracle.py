@@ -329,13 +329,20 @@ def msa2_tree(reads, match, mismatch, gap_extension, gap_opening, bandwidth):
 MSA2_STAT_NAMES = ("joins", "rows", "rows_with_candidates", "rows_capped", "candidates_ignored_by_cap",
                    "entries_before_filter", "entries_filtered", "rows_filtered", "entries_kept", "triples",
                    "triples_2_positions", "triples_3_positions", "triples_gap_direct", "candidates",
-                   "rows_multi_entry", "max_row_entries")
+                   "rows_multi_entry", "max_row_entries", "library_positions_ignored")
 
 
 def msa2_set_rules(nocap=False, nofilter=False):
     """Switch spec v2's own rules (row cap of 16 partner columns, half-the-heaviest noise filter) off / on."""
     lib().orc_msa2_set_rules.restype = None
     lib().orc_msa2_set_rules(int(bool(nocap)), int(bool(nofilter)))
+
+
+def msa2_set_library(others=3):
+    """Partner positions the extended library keeps per (a, p, b) beside the direct one (spec v2: 3); -1: the unbounded
+    library of rounds 2-4 (tools/msa2_rules.py compares them)."""
+    lib().orc_msa2_set_library.restype = None
+    lib().orc_msa2_set_library(int(others))
 
 
 def msa2_stats(reset=True):

@@ -14,13 +14,13 @@
 //                 msa_pairwise.hip (OUT 1);
 //   col   uint16  column of every base in the profile that currently holds its read;
 //   pos   uint16  per group n x wcap: position of read a at column c of its profile (0xFFFF = gap);
-//   tab   M2Cand  per group and join: the (third read, second-child member) candidates of the library walk as
-//                 16-byte descriptors (k_m2_tables, once per batch), staged into LDS by the wavefront that walks them.
+//   ext   uint32  the extended library: per group, pair and position of the pair's first-child member the partner positions
+//                 and weights of spec v2 step 5 (k_m2_extend, once per batch, before the merging).
 // Groups are independent (src/quick_msa.cpp:39); only the joins INSIDE a group are ordered.  So after the pairwise
 // alignments and the guide trees ONE launch does all the merging: k_m2_group, one wavefront per group, groups
 // pulled from an atomic counter in order of decreasing size, and for every join of its group the wavefront runs
-//   rows      lane = column i of the first child; walks the library (map -> map -> col) for every member pair
-//             and third read, sums the weights per partner column in a private list (registers), applies the
+//   rows      lane = column i of the first child; reads the extended library of every member pair at the lane's
+//             position, sums the weights per partner column in a private list (registers), applies the
 //             row cap and the noise filter of spec v2 step 5 and appends the row's entries, by column, to a
 //             compact match list (row, column, weight) in the wavefront's scratch;
 //   chain     heaviest chain over the match list, 64 matches per step: prefix maxima over the second child's
@@ -83,12 +83,12 @@ struct M2Group {
     int first_member;     // member a of the group is members[first_member + a]; joins at first_member + k
     int n;
     int wcap;             // capacity of a profile in columns
-    int pad;
+    int lmax;             // the group's longest read: stride of the extended library's records per pair
     long long pos_base;   // into d_pos: n * wcap
     long long first_job;  // pairwise job of (a, b), a < b: first_job + a n - a (a + 1) / 2 + b - a - 1
     long long dist_base;  // into the tree kernel's scratch: n * n + n doubles
-    long long tab_base;   // into the candidate tables (unit weights)
-    long long map0, col0; // map_base / col_base of the group's first member: the candidates address both relative to them
+    long long ext_base;   // into a plane of the extended library: n (n - 1) / 2 pairs x lmax records
+    long long map0, col0; // map_base / col_base of the group's first member
 };
 
 // counters of one call (sarlacc_stage_count): how often spec v2's own rules act, and the chain's fallback
@@ -109,7 +109,9 @@ struct M2Args {
     const int2* stats;
     double* dist;
     int2* joins;
-    int* join_tab;                 // per join (first_member + k): start of its candidates inside the group's table
+    m2_mask* first;                // per member: the members it meets as part of the FIRST child (k_m2_first)
+    uint32_t* ext;                 // the extended library (k_m2_extend): 3 (unit weights) or 4 planes of ext_plane records
+    long long ext_plane;
     uint16_t* col;                 // (a column is < 65535: 16 bits halve the bytes of the walk's column gathers)
     uint16_t* pos;
     int* ovf;                      // per group: a profile outgrew its capacity
@@ -247,85 +249,6 @@ __global__ void k_m2_init(M2Args A, const int* member_group, int nmembers) {
     }
 }
 
-// ---- unit weights (the default scores): the candidates of every join as tables of descriptors ----
-// A join's table: first the direct edges (c = b), then for c = 0 .. n - 1 the triplets through member c, each for the
-// second child's members b ascending -- the canonical candidate order of spec v2 step 5, with the block of c == a left in
-// (the lane's position "in a itself" is a gap by construction, so those entries add nothing).  Both sections are padded to
-// whole batches of M2_UBATCH entries.
-//   M2Cand { byte offset of the map (c -> b), byte offset of the columns of b, len(c) - 1 | (len(b) - 1) << 16,
-//            byte offset of the LDS row of c | direct << 31 }
-// -- offsets relative to the group's first map / column array, so that every lookup is `scalar base + 32-bit lane
-// offset`.  A direct edge carries the flag instead of a map (the position in b is the staged position itself); an entry
-// that does not count (c == b in a triplet pass, padding) names the LDS row that holds only gaps.  The walk therefore
-// has no special cases: every entry is
-//   r = row[c][lane];  q = direct ? r : map[min(r, len(c) - 1)];  j = col[min(q, len(b) - 1)];  valid = r, q are not gaps.
-// The tables depend only on the tree, so k_m2_tables writes them once per batch, for all joins, before the merging
-// starts; the wavefront that merges a group stages the table of the current join into its LDS (all of it when it fits
-// beside the staged rows, otherwise chunk by chunk) and reads the descriptors from there with wave-uniform addresses.
-// (Round 2 read 32-byte descriptors by scalar loads: with one wavefront per group the scalar cache of a CU would have
-// to hold 32 different tables; a quarter of those loads missed it and every miss parks the wavefront.)
-constexpr int M2_UBATCH = 4;   // candidates looked up side by side
-constexpr int M2_LDS_UNIT = 5056;   // LDS of a wavefront of k_m2_group (unit weights): 32 of them per CU
-typedef const __attribute__((address_space(1))) uint16_t m2_gu16;
-typedef const __attribute__((address_space(1))) int m2_gi32;
-struct __attribute__((aligned(16))) M2Cand {
-    unsigned map_boff;   // bytes from the group's first map
-    unsigned col_boff;   // bytes from the group's first column array
-    unsigned lens;       // len(c) - 1 | (len(b) - 1) << 16
-    unsigned row;        // LDS byte offset of the row of c (row n: gaps) | 0x80000000 for a direct edge
-};
-static_assert(sizeof(M2Cand) == 16, "M2Cand is one 128-bit LDS read");
-constexpr unsigned M2_DIRECT = 0x80000000u;
-__host__ __device__ __forceinline__ int m2_round_batch(int x) { return (x + M2_UBATCH - 1) / M2_UBATCH * M2_UBATCH; }
-// worst case over all trees: every pair of reads is joined once, so the sum over the joins of |B| is at most n (n - 1) / 2
-static inline long long m2_tab_entries(int n) { return static_cast<long long>(n) * (n - 1) / 2 * (n + 1) + 2LL * std::max(0, n - 1) * (M2_UBATCH - 1) + 1; }
-
-__global__ void __launch_bounds__(64) k_m2_tables(M2Args A, M2Cand* tab) {
-    __shared__ int s_b[M2_MAXN];
-    __shared__ m2_mask s_mask[2 * M2_MAXN];
-    const int g = blockIdx.x;
-    const M2Group G = A.groups[g];
-    const int n = G.n, fm = G.first_member;
-    if (n < 2) return;
-    const int lane = threadIdx.x;
-    if (lane < n) s_mask[lane] = 1ull << lane;
-    __syncthreads();
-    int off = 0;
-    for (int k = 0; k + 1 < n; ++k) {
-        const int2 jn = A.joins[fm + k];
-        const m2_mask maskA = s_mask[jn.x], maskB = s_mask[jn.y];
-        if ((maskB >> lane) & 1ull) s_b[__popcll(maskB & ((1ull << lane) - 1ull))] = lane;
-        const int nbm = __popcll(maskB);
-        __syncthreads();
-        if (lane == 0) { s_mask[n + k] = maskA | maskB; A.join_tab[fm + k] = off; }
-        M2Cand* const T = tab + G.tab_base + off;
-        const int Ed = m2_round_batch(nbm), Et = m2_round_batch(nbm * n);
-        for (int e = lane; e < Ed + Et; e += 64) {
-            M2Cand C;
-            C.map_boff = 0; C.col_boff = 0; C.lens = 0; C.row = static_cast<unsigned>(n) * 128u;   // padding: the gaps row
-            const bool direct = e < Ed;
-            const int x = direct ? e : e - Ed;
-            if (x < (direct ? nbm : nbm * n)) {
-                const int b = s_b[x % nbm];
-                const int cu = direct ? b : x / nbm;
-                const M2Member Mc = A.members[fm + cu], Mb = A.members[fm + b];
-                C.col_boff = static_cast<unsigned>((Mb.col_base - G.col0) * 2);
-                const unsigned lenb = static_cast<unsigned>(max(Mb.len - 1, 0));
-                if (direct) { C.lens = lenb << 16; C.row = (static_cast<unsigned>(b) * 128u) | M2_DIRECT; }
-                else {
-                    const int bslot = cu == b ? 0 : (b < cu ? b : b - 1);
-                    C.map_boff = static_cast<unsigned>((Mc.map_base - G.map0 + static_cast<long long>(bslot) * Mc.len) * 2);
-                    C.lens = static_cast<unsigned>(max(Mc.len - 1, 0)) | (lenb << 16);
-                    C.row = static_cast<unsigned>(cu == b ? n : cu) * 128u;
-                }
-            }
-            T[e] = C;
-        }
-        off += Ed + Et;
-        __syncthreads();
-    }
-}
-
 // =============================================================================================
 // k_m2_group: all joins of one group on one wavefront
 
@@ -385,6 +308,143 @@ __device__ __forceinline__ m2_u64 m2_scan_max64(m2_u64 v) {
     return v;
 }
 
+// ---- the extended library (spec v2, step 5), once per group before the merging ----
+// For an ordered pair of reads (a, b) and a position p of a the library holds the direct partner q0 = map(a -> b)[p] with
+// its weight and the first M2_LIB OTHER positions of b named by a triplet p - r - q through a third read c (c ascending),
+// each with the sum of its triplets' weights: a function of (a, p, b) alone.  Rounds 2-4 walked the triplets inside
+// k_m2_group, per join and per column of the first child, with two dependent 2-byte gathers and a 16-entry list insertion per
+// (a, b, c): n^3 L gathers from maps that no cache held (1.6 TB of fabric traffic per merge stage at bench.py's pipeline
+// workload, 18 x the maps) at ~90 instructions per candidate.  Now k_m2_extend does the n^3 L part once, one wavefront per 64
+// positions of a: the positions of its lanes in every third read staged in LDS, one nearly contiguous 2-byte gather per
+// candidate, four compares; the merging reads the result, |A| |B| records per column instead of |A| |B| n candidates.
+// Only the pairs' orientation that the merging reads is computed: a in the FIRST child of the join that brings a and b
+// together (k_m2_first: one 64-bit mask of such b per read).
+//   record of (a, b, p), unit weights: plane 0 = w0 (6 bits) | others (2) | w1 (8) | q1 (16); plane 1 = w2 | q2 << 16; plane 2 = w3 | q3 << 16
+//                        any weights:  plane 0 = w0 | others << 16; plane k = wk | qk << 16 (k = 1 .. 3)
+//   at ext + plane * ext_plane + group's ext_base + pair_index(a, b) * lmax + p   (lmax: the group's longest read)
+constexpr int M2_LIB = 3;   // oracle/msa2.c MSA2_LIBRARY
+constexpr int M2_EXT_WAVES = 4;
+static_assert(M2_LIB == 3, "the records of k_m2_extend hold three further partner positions");
+typedef const __attribute__((address_space(1))) uint16_t m2_gu16;
+__host__ __device__ __forceinline__ long long m2_pair_index(int a, int b, int n) {   // a != b
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    return static_cast<long long>(lo) * n - static_cast<long long>(lo) * (lo + 1) / 2 + hi - lo - 1;
+}
+static inline int m2_ext_planes(bool unitw) { return unitw ? 3 : 4; }
+
+// first[m] = the members b of m's group for which m is in the first child of the join that brings the two together
+__global__ void __launch_bounds__(64) k_m2_first(M2Args A) {
+    __shared__ m2_mask s_mask[2 * M2_MAXN];
+    const int g = blockIdx.x;
+    const M2Group G = A.groups[g];
+    const int n = G.n, fm = G.first_member;
+    const int lane = threadIdx.x;
+    if (n < 2) {
+        if (lane < n) A.first[fm + lane] = 0;
+        return;
+    }
+    if (lane < n) s_mask[lane] = 1ull << lane;
+    __syncthreads();
+    m2_mask F = 0;
+    for (int k = 0; k + 1 < n; ++k) {
+        const int2 jn = A.joins[fm + k];
+        const m2_mask mA = s_mask[jn.x], mB = s_mask[jn.y];
+        if ((mA >> lane) & 1ull) F |= mB;
+        if (lane == 0) s_mask[n + k] = mA | mB;   // (a new slot: nobody reads it before the barrier)
+        __syncthreads();
+    }
+    if (lane < n) A.first[fm + lane] = F;
+}
+
+// One wavefront per 64 positions of member m (blockIdx.y = m; the block's 4 wavefronts take 4 consecutive windows, the grid's
+// x extent strides over the read).  gridDim.x = 8 puts the same windows of consecutive members -- the reads of one group, which
+// gather from the same maps -- on the same XCD, i.e. behind the same L2.
+template <bool UNITW>
+__global__ void __launch_bounds__(64 * M2_EXT_WAVES) k_m2_extend(M2Args A, const int* member_group, int nmembers, int maxn) {
+    extern __shared__ __align__(16) unsigned char m2_xs[];
+    const int m = blockIdx.y;
+    if (m >= nmembers) return;
+    const m2_mask F = A.first[m];
+    if (!F) return;
+    const M2Group G = A.groups[member_group[m]];
+    const int n = G.n, fm = G.first_member, a = m - fm;
+    const int lane = threadIdx.x & 63;
+    const int wave = m2_rfl(static_cast<int>(threadIdx.x >> 6));
+    uint16_t* const s_r = reinterpret_cast<uint16_t*>(m2_xs) + static_cast<size_t>(wave) * maxn * 64 + lane;   // [c * 64]: this wavefront's, this lane's column
+    // the members' descriptors live in the lanes: lane c = member c
+    const M2Member Ml = A.members[fm + min(lane, n - 1)];
+    const M2Member Ma = A.members[m];
+    const int nwin = (Ma.len + 63) / 64;
+    unsigned long long gath = 0;
+    for (int w = blockIdx.x * M2_EXT_WAVES + wave; w < nwin; w += gridDim.x * M2_EXT_WAVES) {
+        const int p = w * 64 + lane;
+        const bool in = p < Ma.len;
+        const unsigned pidx = in ? static_cast<unsigned>(p) : 0u;
+        for (int c = 0; c < n; ++c) {
+            const int slot = c < a ? c : c - 1;
+            const unsigned r = c == a ? M2_NONE : A.map[Ma.map_base + static_cast<long long>(c == a ? 0 : slot) * Ma.len + pidx];
+            s_r[c * 64] = static_cast<uint16_t>(in ? r : M2_NONE);
+        }
+        int xa = 0;
+        if (!UNITW) xa = dna5_code(A.seq[Ma.seq_off + pidx]);
+        gath += static_cast<unsigned>(n - 1);
+        for (int b = 0; b < n; ++b) {
+            if (!((F >> b) & 1ull)) continue;
+            const long long seqb = m2_readlane64(static_cast<m2_u64>(Ml.seq_off), b);
+            const unsigned q0 = s_r[b * 64];
+            unsigned w0 = 0;
+            if (q0 != M2_NONE) w0 = UNITW ? 1u : static_cast<unsigned>(m2_w0(xa, dna5_code(A.seq[seqb + q0]), A.ma, A.mm));
+            unsigned q1 = M2_NONE, q2 = M2_NONE, q3 = M2_NONE, w1 = 0, w2 = 0, w3 = 0, nalt = 0;
+            for (int c = 0; c < n; ++c) {
+                const bool use = c != a && c != b;
+                const int lenc = __builtin_amdgcn_readlane(Ml.len, c);
+                const long long basec = static_cast<long long>(m2_readlane64(static_cast<m2_u64>(Ml.map_base), c)) +
+                                        static_cast<long long>(!use ? 0 : (b < c ? b : b - 1)) * lenc;
+                const unsigned r = s_r[c * 64];
+                const bool hr = use && r != M2_NONE;
+                const unsigned ridx = hr ? r : 0u;
+                const unsigned q = A.map[basec + ridx];
+                const bool v = hr && q != M2_NONE;
+                unsigned wt = 1;
+                if (!UNITW) {
+                    const long long seqc = m2_readlane64(static_cast<m2_u64>(Ml.seq_off), c);
+                    const int xc = dna5_code(A.seq[seqc + ridx]);
+                    const int xb = dna5_code(A.seq[seqb + (v ? q : 0u)]);
+                    const int wac = m2_w0(xa, xc, A.ma, A.mm), wcb = m2_w0(xc, xb, A.ma, A.mm);
+                    wt = static_cast<unsigned>(wac < wcb ? wac : wcb);
+                }
+                const bool m0 = v && q == q0;
+                w0 += m0 ? wt : 0u;
+                if (__ballot(v && !m0)) {   // (same-molecule reads: nearly every triplet names the direct partner)
+                    const bool m1 = v && q == q1, m2 = v && q == q2, m3 = v && q == q3;
+                    w1 += m1 ? wt : 0u; w2 += m2 ? wt : 0u; w3 += m3 ? wt : 0u;
+                    const bool fresh = v && !m0 && !m1 && !m2 && !m3;   // a position not seen yet: the next free slot, if any
+                    const bool t1 = fresh && nalt == 0, t2 = fresh && nalt == 1, t3 = fresh && nalt == 2;
+                    q1 = t1 ? q : q1; w1 = t1 ? wt : w1;
+                    q2 = t2 ? q : q2; w2 = t2 ? wt : w2;
+                    q3 = t3 ? q : q3; w3 = t3 ? wt : w3;
+                    nalt += (t1 || t2 || t3) ? 1u : 0u;
+                }
+            }
+            gath += static_cast<unsigned>(n - 2);
+            if (in) {
+                uint32_t* const E = A.ext + G.ext_base + m2_pair_index(a, b, n) * G.lmax + p;
+                if (UNITW) {
+                    E[0] = w0 | (nalt << 6) | (w1 << 8) | (q1 << 16);
+                    if (nalt >= 2) E[A.ext_plane] = w2 | (q2 << 16);
+                    if (nalt >= 3) E[2 * A.ext_plane] = w3 | (q3 << 16);
+                } else {
+                    E[0] = w0 | (nalt << 16);
+                    if (nalt >= 1) E[A.ext_plane] = w1 | (q1 << 16);
+                    if (nalt >= 2) E[2 * A.ext_plane] = w2 | (q2 << 16);
+                    if (nalt >= 3) E[3 * A.ext_plane] = w3 | (q3 << 16);
+                }
+            }
+        }
+    }
+    if (lane == 0 && gath) atomicAdd(&A.counters[M2C_GATHERS], gath);
+}
+
 template <typename MASK>
 struct M2JoinT {      // wave-uniform description of one join (MASK: unsigned for groups of up to 32 reads, m2_mask beyond)
     int n, fm;
@@ -426,30 +486,34 @@ __device__ __forceinline__ int m2_popc(m2_mask m) { return __popcll(m); }
         ne += __builtin_amdgcn_readlane(incl, 63);                                                                       \
     }
 
-// ---- rows of one join, unit weights ----
-// A list entry is one register, (column << 16) | weight (a column is < 65535, a weight at most
-// |A| |B| (n + 1) <= 8448); 0xFFFF0000 is an empty slot, an invalid candidate carries a column no entry can hold.
+// ---- rows of one join: the library of its member pairs summed per column of the first child ----
+// Lane = column i of the first child.  For its members a (ascending) with a base p in this column and the second child's
+// members b (ascending): the record of (a, b, p) -- the direct partner from the map, the others from the extension --, each
+// partner position turned into its column through col[] and added to the lane's private list of at most M2_CAP partner columns
+// (spec v2, step 5: the first M2_CAP distinct columns in this order count).
+// Unit weights: a list entry is one register, (column << 16) | weight (a column is < 65535, a weight at most
+// |A| |B| (n - 1) <= 64512); 0xFFFF0000 is an empty slot, an invalid candidate carries a column no entry can hold.
 // The columns of a list are distinct, so at most one entry matches.  Three tiers, each behind a wave-wide test:
-// entries 0-3; entries 4-7 and the append into 0-7 (some lane of the wave meets a new column at most steps, so
-// this tier has to be short); entries 8-15.
+// entries 0-3; entries 4-7 and the append into 0-7; entries 8-15.
 constexpr unsigned M2_EMPTY = 0xFFFF0000u;
 #define M2_MATCH1(K0, K1)                                                                              \
     _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                           \
         const bool m_ = (pe[k_] >> 16) == j_;                                                          \
-        pe[k_] += m_ ? 1u : 0u;                                                                        \
+        pe[k_] += m_ ? w_ : 0u;                                                                        \
         hit_ = hit_ || m_;                                                                             \
     }
 #define M2_APPEND1(K0, K1)                                                                             \
     {                                                                                                  \
         const bool app_ = !hit_ && cnt < (K1);                                                         \
-        _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) pe[k_] = (app_ && cnt == k_) ? ((j_ << 16) | 1u) : pe[k_]; \
+        _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) pe[k_] = (app_ && cnt == k_) ? ((j_ << 16) | w_) : pe[k_]; \
         cnt += app_ ? 1 : 0;                                                                           \
         hit_ = hit_ || app_;                                                                           \
     }
-#define M2_ADD1(J, VALID)                                                                              \
+#define M2_ADD1(J, W, VALID)                                                                           \
     {                                                                                                  \
         const bool v_ = (VALID);                                                                       \
         const unsigned j_ = v_ ? static_cast<unsigned>(J) : 0x1FFFFu;                                  \
+        const unsigned w_ = static_cast<unsigned>(W);                                                  \
         bool hit_ = !v_;                                                                               \
         M2_MATCH1(0, 4)                                                                                \
         if (__ballot(!hit_)) {                                                                         \
@@ -463,141 +527,10 @@ constexpr unsigned M2_EMPTY = 0xFFFF0000u;
             }                                                                                          \
         }                                                                                              \
     }
-
-template <typename MASK>
-__device__ __forceinline__ int m2_rows_unit(const M2Args& A, const M2Group& G, const M2JoinT<MASK>& J, const M2Cand* T, int i_lo, int i_hi,
-                                            unsigned char* s_rows, M2Cand* s_tab, int cap, bool resident, m2_u64* ent, int* part,
-                                            unsigned& st_capped, unsigned& st_filtered, unsigned& st_rowsf) {
-    // s_rows (LDS, this wavefront's): rows 0 .. n - 1 of 64 positions each (position of the lane's base in member c), row n:
-    // gaps.  s_tab (LDS): the join's candidates -- all of them (`resident`, staged by the caller) or room for `cap` at a time.
-    const int lane = m2_lane();
-    const int n = J.n, fm = J.fm, nA = J.nA;
-    const int nbm = m2_popc(J.maskB);
-    const bool leafB = nbm == 1;   // (a single member in the second child is a leaf of the guide tree: col = position)
-    const int E = m2_round_batch(nbm) + m2_round_batch(nbm * n);
-    uint16_t* const s_rl = reinterpret_cast<uint16_t*>(s_rows) + lane;     // (every lane reads its own column of the rows only)
-    const unsigned char* const s_rlane = reinterpret_cast<const unsigned char*>(s_rl);
-    s_rl[n * 64] = static_cast<uint16_t>(M2_NONE);
-    auto stage = [&](int c0, int cnt) {   // (s_tab is this wavefront's own strip then: LDS is in order inside a wavefront, nobody to wait for)
-        for (int e = lane; e < cnt; e += 64) s_tab[e] = T[c0 + e];
-    };
-    const char* const mapb = reinterpret_cast<const char*>(A.map + G.map0);
-    const char* const colb = reinterpret_cast<const char*>(A.col + G.col0);
-    int ne = 0;
-    for (int i0 = i_lo; i0 < i_hi; i0 += 64) {
-        const int i = i0 + lane;
-        unsigned pe[M2_CAP];
-#pragma unroll
-        for (int k = 0; k < M2_CAP; ++k) pe[k] = M2_EMPTY;
-        int cnt = 0;
-        bool capped = false;
-        const bool row = i < nA;
-        for (int a = 0; a < n; ++a) {
-            if (!((J.maskA >> a) & 1)) continue;
-            const unsigned p = row ? A.pos[G.pos_base + static_cast<long long>(a) * G.wcap + i] : M2_NONE;
-            const bool havep = p != M2_NONE;
-            if (!__ballot(havep)) continue;
-            const M2Member Ma = A.members[fm + a];
-            {   // positions in every other member: unconditional loads (clamped), selected afterwards
-                const unsigned pidx = havep ? p : 0u;
-                for (int c0 = 0; c0 < n; c0 += 8) {
-                    uint16_t rv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int c = min(c0 + u, n - 1);
-                        const int slot = c == a ? 0 : (c < a ? c : c - 1);
-                        rv[u] = A.map[Ma.map_base + static_cast<long long>(slot) * Ma.len + pidx];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (c0 + u < n) s_rl[(c0 + u) * 64] = (c0 + u != a && havep) ? rv[u] : static_cast<uint16_t>(M2_NONE);
-                }
-            }
-            for (int c0 = 0; c0 < E; c0 += cap) {
-                const int ce = min(cap, E - c0);
-                if (!resident) stage(c0, ce);
-                for (int f0 = 0; f0 < ce; f0 += M2_UBATCH) {
-                    unsigned rr[M2_UBATCH], qq[M2_UBATCH], cb[M2_UBATCH], ln[M2_UBATCH], dr[M2_UBATCH];
-                    int jj[M2_UBATCH];
-                    // the map lookups of the batch, then the column lookups, each requested back to back
-#pragma unroll
-                    for (int u = 0; u < M2_UBATCH; ++u) {
-                        const M2Cand C = s_tab[f0 + u];   // (wave-uniform address: one broadcast read)
-                        rr[u] = *reinterpret_cast<const uint16_t*>(s_rlane + (C.row & 0xffffu));
-                        cb[u] = C.col_boff; ln[u] = C.lens >> 16; dr[u] = C.row;
-                        qq[u] = *((m2_gu16*)(mapb + (C.map_boff + (min(rr[u], C.lens & 0xffffu) << 1))));   // (a gap clamps to a valid index)
-                    }
-#pragma unroll
-                    for (int u = 0; u < M2_UBATCH; ++u) qq[u] = (dr[u] & M2_DIRECT) ? rr[u] : qq[u];
-                    if (leafB) {   // the second child is one read that has not been merged yet: its columns are its positions
-#pragma unroll
-                        for (int u = 0; u < M2_UBATCH; ++u) jj[u] = static_cast<int>(qq[u]);
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < M2_UBATCH; ++u) jj[u] = *((m2_gu16*)(colb + (cb[u] + (min(qq[u], ln[u]) << 1))));
-                    }
-#pragma unroll
-                    for (int u = 0; u < M2_UBATCH; ++u) M2_ADD1(jj[u], rr[u] != M2_NONE && qq[u] != M2_NONE)
-                }
-            }
-        }
-        st_capped += (row && capped) ? 1u : 0u;
-        {   // filter, order by column, append -- on the packed entries: (column << 16) | weight orders by column
-            unsigned wmax = 0;
-#pragma unroll
-            for (int k = 0; k < M2_CAP; ++k) wmax = max(wmax, k < cnt ? (pe[k] & 0xffffu) : 0u);
-            int kept = 0;
-#pragma unroll
-            for (int k = 0; k < M2_CAP; ++k) {
-                // noise filter (spec v2, step 5): entries lighter than half the row's heaviest are dropped
-                const bool keep = k < cnt && 2u * (pe[k] & 0xffffu) >= wmax;
-                pe[k] = keep ? pe[k] : 0xFFFFFFFFu;   // (sorts behind every kept entry)
-                kept += keep ? 1 : 0;
-            }
-            if (!row) kept = 0;
-            st_filtered += row ? static_cast<unsigned>(cnt - kept) : 0u;
-            st_rowsf += (row && kept < cnt) ? 1u : 0u;
-            const int incl = m2_incl_sum(kept);
-            m2_u64* const mine = ent + ne + (incl - kept);
-            if (row) {
-                const m2_u64 rowbits = static_cast<m2_u64>(static_cast<unsigned>(i)) << 48;
-#pragma unroll
-                for (int k = 0; k < M2_CAP; ++k) {
-                    if (pe[k] != 0xFFFFFFFFu) {   // rank of the entry among the kept ones (columns are distinct)
-                        int rank = 0;
-#pragma unroll
-                        for (int q = 0; q < M2_CAP; ++q) rank += pe[q] < pe[k] ? 1 : 0;
-                        mine[rank] = rowbits | (static_cast<m2_u64>(pe[k] >> 16) << 32) | (pe[k] & 0xffffu);
-                    }
-                }
-                part[i] = -1;
-            }
-            ne += __builtin_amdgcn_readlane(incl, 63);
-        }
-    }
-    return ne;
-}
-#undef M2_ADD1
-#undef M2_MATCH1
-#undef M2_APPEND1
-
-// ---- rows of one join, any weights ----
-// The row's list (first M2_CAP distinct partner columns in the canonical enumeration order of spec v2, step 5:
-// a ascending; direct edges b ascending; then c ascending, b ascending) lives in registers; a candidate is
-// compared with the first entries before anything else (same-molecule reads agree on 1-3 columns).  Loads are
-// issued in independent batches: the positions r_c of every third sequence first (LDS), then up to M2_BATCH (c, b)
-// pairs at a time -- the dependent chain map -> map -> col of one candidate is three memory latencies long.
-constexpr int M2_BATCH = 4;
-
-__device__ __forceinline__ long long m2_uniform64(long long v) {   // a wave-uniform 64-bit value into scalar registers
-    const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
-    const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32)));
-    return static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
-}
-
+// any weights: columns and weights in registers of their own
 #define M2_ADD(J, W, VALID)                                                                            \
     {                                                                                                  \
-        const int j_ = (J), w_ = (W);                                                                  \
+        const int j_ = static_cast<int>(J), w_ = static_cast<int>(W);                                  \
         bool hit_ = !(VALID);                                                                          \
         _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                                             \
             const bool m_ = !hit_ && ej[k_] == j_;                                                     \
@@ -622,31 +555,24 @@ __device__ __forceinline__ long long m2_uniform64(long long v) {   // a wave-uni
         }                                                                                              \
     }
 
-template <typename MASK>
-__device__ __forceinline__ int m2_rows_general(const M2Args& A, const M2Group& G, const M2JoinT<MASK>& J, int i_lo, int i_hi, unsigned char* smem,
-                                               m2_u64* ent, int* part, unsigned& st_capped, unsigned& st_filtered, unsigned& st_rowsf) {
-    uint16_t (*s_r)[64] = reinterpret_cast<uint16_t (*)[64]>(smem);                                  // [M2_MAXN][64]
-    long long* const s_mapbase = reinterpret_cast<long long*>(smem + (M2_MAXN + 1) * 128);            // the members' descriptors
-    long long* const s_colbase = s_mapbase + M2_MAXN;
-    long long* const s_seqoff = s_colbase + M2_MAXN;
-    int* const s_len = reinterpret_cast<int*>(s_seqoff + M2_MAXN);
-    int* const s_b = s_len + M2_MAXN;                                                                 // the second child's members, ascending
+template <bool UNITW, typename MASK>
+__device__ __forceinline__ int m2_rows_ext(const M2Args& A, const M2Group& G, const M2JoinT<MASK>& J, int i_lo, int i_hi, m2_u64* ent, int* part,
+                                           unsigned& st_capped, unsigned& st_filtered, unsigned& st_rowsf) {
     const int lane = m2_lane();
     const int n = J.n, fm = J.fm, nA = J.nA;
-    const MASK maskB = J.maskB;
-    if (lane < M2_MAXN) {
-        const M2Member Me = A.members[fm + min(lane, n - 1)];
-        s_mapbase[lane] = Me.map_base; s_colbase[lane] = Me.col_base; s_seqoff[lane] = Me.seq_off; s_len[lane] = lane < n ? Me.len : 0;
-        if ((static_cast<m2_mask>(maskB) >> lane) & 1ull) s_b[__popcll(static_cast<m2_mask>(maskB) & ((1ull << lane) - 1ull))] = lane;
-    }
-    const int nbm = m2_popc(maskB);
-    __syncthreads();
+    const bool leafB = m2_popc(J.maskB) == 1;   // (a single member in the second child is a leaf of the guide tree: col = position)
     int ne = 0;
     for (int i0 = i_lo; i0 < i_hi; i0 += 64) {
         const int i = i0 + lane;
-        int ej[M2_CAP], ew[M2_CAP];
+        unsigned pe[M2_CAP];
+        int ej[M2_CAP], ew[M2_CAP];   // (the instantiation's other list is never touched and disappears)
+        if constexpr (UNITW) {
 #pragma unroll
-        for (int k = 0; k < M2_CAP; ++k) { ej[k] = -1; ew[k] = 0; }
+            for (int k = 0; k < M2_CAP; ++k) pe[k] = M2_EMPTY;
+        } else {
+#pragma unroll
+            for (int k = 0; k < M2_CAP; ++k) { ej[k] = -1; ew[k] = 0; }
+        }
         int cnt = 0;
         bool capped = false;
         const bool row = i < nA;
@@ -656,78 +582,85 @@ __device__ __forceinline__ int m2_rows_general(const M2Args& A, const M2Group& G
             const bool havep = p != M2_NONE;
             if (!__ballot(havep)) continue;
             const M2Member Ma = A.members[fm + a];
-            const int xa = !havep ? 0 : dna5_code(A.seq[Ma.seq_off + p]);
-            {
-                const unsigned pidx = havep ? p : 0u;
-                for (int c0 = 0; c0 < n; c0 += 8) {
-                    uint16_t rv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int c = min(c0 + u, n - 1);
-                        const int slot = c == a ? 0 : (c < a ? c : c - 1);
-                        rv[u] = A.map[Ma.map_base + static_cast<long long>(slot) * Ma.len + pidx];
+            const unsigned pidx = havep ? p : 0u;
+            for (int b = 0; b < n; ++b) {
+                if (!((J.maskB >> b) & 1)) continue;
+                const M2Member Mb = A.members[fm + b];
+                const uint16_t* const colb = A.col + Mb.col_base;
+                const unsigned lenb1 = static_cast<unsigned>(max(Mb.len - 1, 0));
+                const uint32_t* const E = A.ext + G.ext_base + m2_pair_index(a, b, n) * G.lmax + pidx;
+                const unsigned q0 = A.map[Ma.map_base + static_cast<long long>(b < a ? b : b - 1) * Ma.len + pidx];
+                const unsigned e0 = E[0];
+                unsigned w0, nalt, q1 = M2_NONE, w1 = 0;
+                if (UNITW) { w0 = e0 & 63u; nalt = (e0 >> 6) & 3u; w1 = (e0 >> 8) & 255u; q1 = e0 >> 16; }
+                else { w0 = e0 & 0xffffu; nalt = e0 >> 16; }
+                nalt = havep ? nalt : 0u;
+                const bool v0 = havep && q0 != M2_NONE;
+                const unsigned j0 = leafB ? q0 : colb[min(q0, lenb1)];
+#define M2_ADD_ANY(Jx, Wx, Vx) { if constexpr (UNITW) M2_ADD1(Jx, Wx, Vx) else M2_ADD(Jx, Wx, Vx) }
+                M2_ADD_ANY(j0, w0, v0)
+                if (__ballot(nalt >= 1u)) {
+                    if (!UNITW) { const unsigned e1 = nalt >= 1u ? E[A.ext_plane] : 0u; w1 = e1 & 0xffffu; q1 = e1 >> 16; }
+                    const unsigned j1 = leafB ? q1 : colb[min(q1, lenb1)];
+                    M2_ADD_ANY(j1, w1, nalt >= 1u)
+                    if (__ballot(nalt >= 2u)) {
+                        const unsigned e2 = nalt >= 2u ? E[(UNITW ? 1 : 2) * A.ext_plane] : 0u;
+                        const unsigned q2 = e2 >> 16;
+                        const unsigned j2 = leafB ? q2 : colb[min(q2, lenb1)];
+                        M2_ADD_ANY(j2, e2 & 0xffffu, nalt >= 2u)
+                        if (__ballot(nalt >= 3u)) {
+                            const unsigned e3 = nalt >= 3u ? E[(UNITW ? 2 : 3) * A.ext_plane] : 0u;
+                            const unsigned q3 = e3 >> 16;
+                            const unsigned j3 = leafB ? q3 : colb[min(q3, lenb1)];
+                            M2_ADD_ANY(j3, e3 & 0xffffu, nalt >= 3u)
+                        }
                     }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (c0 + u < n) s_r[c0 + u][lane] = (c0 + u != a && havep) ? rv[u] : static_cast<uint16_t>(M2_NONE);
                 }
-            }
-            // canonical order of the candidates: the direct edges (c = b) for b in B ascending, then for c ascending the
-            // triplets (c, b), b in B ascending, b != c -- a flat list of nbm + (n - 1) nbm entries
-            const int total = nbm * n;   // direct pass (ci = 0) + the n - 1 third sequences
-            int ci = 0, bi = 0;          // position in the flat list: pass ci (0 = direct; ci >= 1: c = ci - 1, skipping a), member bi
-            for (int f0 = 0; f0 < total; f0 += M2_BATCH) {
-                unsigned qq[M2_BATCH];
-                int jj[M2_BATCH], ww[M2_BATCH], bq[M2_BATCH];
-                bool ok[M2_BATCH];
-                unsigned rr[M2_BATCH], mm[M2_BATCH], rix[M2_BATCH];
-                int cuq[M2_BATCH], flg[M2_BATCH];   // flg: bit 0 candidate exists, bit 1 direct edge (c = b), bit 2 counted (direct or b != c)
-#pragma unroll
-                for (int u = 0; u < M2_BATCH; ++u) {
-                    const bool in = f0 + u < total;
-                    const int b = __builtin_amdgcn_readfirstlane(s_b[bi]);
-                    const int cu = ci == 0 ? b : ((ci - 1) + ((ci - 1) >= a ? 1 : 0));
-                    const unsigned r = s_r[cu][lane];
-                    const int bslot = cu == b ? 0 : (b < cu ? b : b - 1);
-                    const int lencu = __builtin_amdgcn_readfirstlane(s_len[cu]);
-                    const long long mbase = m2_uniform64(s_mapbase[cu]) + static_cast<long long>(bslot) * lencu;
-                    const unsigned ridx = min(r != M2_NONE ? r : 0u, static_cast<unsigned>(max(lencu - 1, 0)));
-                    mm[u] = A.map[mbase + ridx];
-                    rr[u] = r; rix[u] = ridx; cuq[u] = cu; bq[u] = b;
-                    flg[u] = (in ? 1 : 0) | (cu == b ? 2 : 0) | ((ci == 0 || b != cu) ? 4 : 0);
-                    bi = in ? bi + 1 : bi;
-                    const bool wrap = bi == nbm;
-                    bi = wrap ? 0 : bi;
-                    ci = wrap ? ci + 1 : ci;
-                }
-#pragma unroll
-                for (int u = 0; u < M2_BATCH; ++u) {
-                    qq[u] = (flg[u] & 2) ? rr[u] : mm[u];
-                    ok[u] = (flg[u] & 1) && (flg[u] & 4) && rr[u] != M2_NONE && qq[u] != M2_NONE;
-                    const int xc = dna5_code(A.seq[s_seqoff[cuq[u]] + rix[u]]);
-                    ww[u] = (xc << 16) | (((flg[u] & 2) ? 1 : 0) << 15) | m2_w0(xa, xc, A.ma, A.mm);   // (finished below)
-                }
-#pragma unroll
-                for (int u = 0; u < M2_BATCH; ++u) {
-                    const int b = __builtin_amdgcn_readfirstlane(bq[u]);
-                    const int lenb = __builtin_amdgcn_readfirstlane(s_len[b]);
-                    const unsigned qidx = min(ok[u] ? qq[u] : 0u, static_cast<unsigned>(max(lenb - 1, 0)));
-                    jj[u] = A.col[m2_uniform64(s_colbase[b]) + qidx];
-                    const int xc = ww[u] >> 16, wac = ww[u] & 0x7fff;
-                    const bool direct = (ww[u] >> 15) & 1;
-                    const int wcb = m2_w0(xc, dna5_code(A.seq[s_seqoff[b] + qidx]), A.ma, A.mm);
-                    ww[u] = direct ? wac : (wac < wcb ? wac : wcb);
-                }
-#pragma unroll
-                for (int u = 0; u < M2_BATCH; ++u)
-                    if (f0 + u < total) M2_ADD(jj[u], ww[u], ok[u])
+#undef M2_ADD_ANY
             }
         }
         st_capped += (row && capped) ? 1u : 0u;
-        M2_FINISH_ROW()
+        if constexpr (UNITW) {   // filter, order by column, append -- on the packed entries: (column << 16) | weight orders by column
+            unsigned wmax = 0;
+#pragma unroll
+            for (int k = 0; k < M2_CAP; ++k) wmax = max(wmax, k < cnt ? (pe[k] & 0xffffu) : 0u);
+            int kept = 0;
+#pragma unroll
+            for (int k = 0; k < M2_CAP; ++k) {
+                // noise filter (spec v2, step 5): entries lighter than half the row's heaviest are dropped
+                const bool keep = k < cnt && 2u * (pe[k] & 0xffffu) >= wmax;
+                pe[k] = keep ? pe[k] : 0xFFFFFFFFu;   // (sorts behind every kept entry)
+                kept += keep ? 1 : 0;
+            }
+            if (!row) kept = 0;
+            st_filtered += row ? static_cast<unsigned>(cnt - kept) : 0u;
+            st_rowsf += (row && kept < cnt) ? 1u : 0u;
+            const int incl = m2_incl_sum(kept);
+            m2_u64* const mine = ent + ne + (incl - kept);
+            if (row) {
+                const m2_u64 rowbits = static_cast<m2_u64>(static_cast<unsigned>(i)) << 48;
+#pragma unroll
+                for (int k = 0; k < M2_CAP; ++k) {
+                    const unsigned ek = pe[k];
+                    if (ek != 0xFFFFFFFFu) {   // rank of the entry among the kept ones (columns are distinct)
+                        int rank = 0;
+#pragma unroll
+                        for (int q = 0; q < M2_CAP; ++q) rank += pe[q] < ek ? 1 : 0;
+                        mine[rank] = rowbits | (static_cast<m2_u64>(ek >> 16) << 32) | (ek & 0xffffu);
+                    }
+                }
+                part[i] = -1;
+            }
+            ne += __builtin_amdgcn_readlane(incl, 63);
+        } else {
+            M2_FINISH_ROW()
+        }
     }
     return ne;
 }
+#undef M2_ADD1
+#undef M2_MATCH1
+#undef M2_APPEND1
 #undef M2_ADD
 #undef M2_FINISH_ROW
 
@@ -954,26 +887,16 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
     return newW;
 }
 
-// LDS of a workgroup: per wavefront the rows' staging ((n + 1) rows of 128 B), behind them the join's candidates; the
-// chain's ring (4096 B, first wavefront) reuses the front.  One wavefront per group: 5 KB, 32 workgroups per CU, larger
-// tables go through in chunks.  NW wavefronts per group (groups of up to NMAX reads): the whole table of any join fits.
-constexpr int m2_lds_bytes(bool unitw, int nw, int nmax) {
-    return !unitw ? (M2_MAXN + 1) * 128 + M2_MAXN * 3 * 8 + M2_MAXN * 2 * 4
-                  : (nw == 1 ? (nmax > M2_N32 ? (nmax + 1) * 128 + 64 * 16 : M2_LDS_UNIT)
-                             // several wavefronts per group: up to 32 reads every table of a join fits (at most 31 + 31 x 32 candidates); beyond,
-                             // a wavefront stages the table 64 candidates at a time in a strip of its own (132 KB of LDS for whole tables left
-                             // ONE workgroup per CU for the groups that cost the most)
-                             : nw * (nmax + 1) * 128 + (nmax > M2_N32 ? nw * 64 : ((nmax - 1 + M2_UBATCH) + ((nmax - 1) * nmax + M2_UBATCH))) * 16);
-}
-static_assert(M2_LDS_UNIT >= M2_QW * 8 && M2_LDS_UNIT >= (M2_N32 + 1) * 128 + 16 * M2_UBATCH, "the chain's ring and the rows' staging share the LDS");
+// LDS of a workgroup: the chain's ring (first wavefront).  (Until round 5 the rows phase staged positions and candidate
+// tables here: 5 KB per wavefront, 37 KB for the workgroups of 33 .. 64 reads.)
+constexpr int M2_LDS = M2_QW * 8;
 
 // One workgroup of NW wavefronts per group (groups of up to NMAX reads; NW = 1 takes any).  The rows of a join are
 // cut into NW ranges, one per wavefront; the chain runs on the first wavefront; the renumbering's copies on all.
 template <bool UNITW, int NW, int NMAX>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? (UNITW ? M2_WAVES_EU : 4) : 4, 8))) k_m2_group(M2Args A, const M2Cand* tab) {
-    __shared__ __align__(16) unsigned char smem[m2_lds_bytes(UNITW, NW, NMAX)];
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? (UNITW ? M2_WAVES_EU : 4) : 4, 8))) k_m2_group(M2Args A) {
+    __shared__ __align__(16) unsigned char smem[M2_LDS];
     __shared__ int s_cnt[NW], s_pfx[NW + 1], s_ctl[4];
-    static_assert(UNITW || NW == 1, "the any-weights walk runs on one wavefront");
     typedef typename std::conditional<(NMAX > 32), m2_mask, unsigned>::type MASK;
     constexpr bool TWO = NMAX > 32;
     const int lane = threadIdx.x & 63;
@@ -1021,33 +944,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
             const int bpw = ((J.nA + 63) / 64 + NW - 1) / NW;
             const long long stride = static_cast<long long>(bpw) * 64 * M2_CAP;
             const int i_lo = min(wave * bpw * 64, J.nA), i_hi = min((wave + 1) * bpw * 64, J.nA);
-            int ne;
-            if (UNITW) {
-                const M2Cand* const T = tab + G.tab_base + m2_rfl(A.join_tab[fm + round]);
-                const int rows_b = (n + 1) * 128;
-                M2Cand* const s_tab = reinterpret_cast<M2Cand*>(smem + NW * rows_b);
-                // the join's table: whole in LDS, staged by everybody, where it fits behind the rows of this group's n; else every
-                // wavefront walks it in pieces staged in a strip of its own
-                const int tab_bytes = m2_lds_bytes(UNITW, NW, NMAX) - NW * rows_b;
-                const int cap = (tab_bytes / 16) & ~(M2_UBATCH - 1);
-                const int cap_w = (tab_bytes / NW / 16) & ~(M2_UBATCH - 1);
-                const int nbm = m2_popc(J.maskB);
-                const int E = m2_round_batch(nbm) + m2_round_batch(nbm * n);
-                const bool resident = E <= cap;
-                if (resident) {
-                    for (int e = threadIdx.x; e < E; e += 64 * NW) s_tab[e] = T[e];
-                    __syncthreads();
-                }
-                ne = m2_rows_unit(A, G, J, T, i_lo, i_hi, smem + wave * rows_b, resident ? s_tab : s_tab + wave * cap_w, resident ? cap : cap_w, resident,
-                                  ent + wave * stride, part, st_capped, st_filtered, st_rowsf);
-                // wave-wide gather instructions of this wavefront's walk: per block of 64 columns and member of the first child one load of
-                // its positions, the positions in every member (batches of 8) and one or two gathers per table entry (a member without a
-                // base in a whole block skips its walk: counted all the same, an upper bound by a fraction of a per cent)
-                st_gath += static_cast<unsigned long long>((i_hi - i_lo + 63) / 64) * static_cast<unsigned>(m2_popc(J.maskA)) *
-                           static_cast<unsigned>(1 + (n + 7) / 8 * 8 + (nbm == 1 ? E : 2 * E));
-            } else {
-                ne = m2_rows_general(A, G, J, i_lo, i_hi, smem, ent, part, st_capped, st_filtered, st_rowsf);
-            }
+            const int ne = m2_rows_ext<UNITW, MASK>(A, G, J, i_lo, i_hi, ent + wave * stride, part, st_capped, st_filtered, st_rowsf);
+            // wave-wide gather instructions of this wavefront's rows: per block of 64 columns and member of the first child its
+            // positions, then per member of the second child the direct partner, the record and the partner's column (further
+            // partner positions of a record: not counted, a lower bound)
+            st_gath += static_cast<unsigned long long>((i_hi - i_lo + 63) / 64) * static_cast<unsigned>(m2_popc(J.maskA)) *
+                       static_cast<unsigned>(1 + m2_popc(J.maskB) * (m2_popc(J.maskB) == 1 ? 2 : 3));
             if (lane == 0) s_cnt[wave] = ne;
             __threadfence_block();
             __syncthreads();
@@ -1194,7 +1096,7 @@ struct M2Batch {
     M2Args a{};                   // device pointers
     int* d_member_group = nullptr;
     int max_len = 0, max_wcap = 0, max_n = 0;
-    long long tab_n = 0;
+    long long ext_n = 0;          // records per plane of the extended library
     MsaJobSummary jsum;           // band classes and cell count of `jobs`
     hipEvent_t pair_done = nullptr;   // the all-pairs alignments of the batch have finished (m2_prepare -> m2_merge)
 };
@@ -1235,7 +1137,7 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
     const size_t ngr = B.ids.size();
     B.groups.assign(ngr, M2Group{});
     B.max_len = 0; B.max_wcap = 0; B.max_n = 0;
-    long long map_pos = 0, col_pos = 0, pos_pos = 0, dist_pos = 0, tab_pos = 0, mem_pos = 0, job_pos = 0;
+    long long map_pos = 0, col_pos = 0, pos_pos = 0, dist_pos = 0, ext_pos = 0, mem_pos = 0, job_pos = 0;
     for (size_t q = 0; q < ngr; ++q) {
         const int64_t g = B.ids[q];
         const int n = static_cast<int>(grp_off[g + 1] - grp_off[g]);
@@ -1254,12 +1156,13 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
         G.pos_base = pos_pos;
         G.first_job = job_pos;
         G.dist_base = dist_pos;
-        G.tab_base = tab_pos;
+        G.ext_base = ext_pos;
+        G.lmax = mx;
         G.map0 = map_pos;
         G.col0 = col_pos;
         pos_pos += static_cast<long long>(n) * G.wcap;
         dist_pos += static_cast<long long>(n) * n + n;
-        tab_pos += m2_tab_entries(n);
+        ext_pos += static_cast<long long>(n) * (n - 1) / 2 * mx;
         map_pos += static_cast<long long>(std::max(0, n - 1)) * sum;
         col_pos += sum;
         mem_pos += n;
@@ -1268,7 +1171,7 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
         B.max_wcap = std::max(B.max_wcap, G.wcap);
         B.max_n = std::max(B.max_n, n);
     }
-    B.tab_n = tab_pos;
+    B.ext_n = ext_pos;
     B.members.assign(static_cast<size_t>(mem_pos), M2Member{});
     B.member_group.assign(static_cast<size_t>(mem_pos), 0);
     B.njobs = static_cast<size_t>(job_pos);
@@ -1394,12 +1297,12 @@ static int m2_prepare(M2Batch& B, const std::string& pf, const uint8_t* d_seq, d
     hipLaunchKernelGGL(k_m2_jobs, dim3(static_cast<unsigned>((ng + 3) / 4)), dim3(256), 0, s, d_groups, d_members, static_cast<int>(ng), d_jobs);
     SL_HIP(hipGetLastError());
     B.d_member_group = d_mg;
-    uint16_t* d_map; int2* d_stats; double* d_dist; int2* d_joins; int* d_jtab; uint16_t* d_col; uint16_t* d_pos; int* d_ovf; int32_t* d_width;
+    uint16_t* d_map; int2* d_stats; double* d_dist; int2* d_joins; m2_mask* d_first; uint16_t* d_col; uint16_t* d_pos; int* d_ovf; int32_t* d_width;
     SL_TRY(scratch((pf + ".map").c_str(), static_cast<size_t>(map_n) + 1, &d_map));
     SL_TRY(scratch((pf + ".stats").c_str(), B.njobs + 1, &d_stats));
     d_dist = nullptr;   // (the tree kernel keeps its distance matrix in LDS since round 4)
     SL_TRY(scratch((pf + ".joins").c_str(), nm + 1, &d_joins));
-    SL_TRY(scratch((pf + ".jtab").c_str(), nm + 1, &d_jtab));
+    SL_TRY(scratch((pf + ".first").c_str(), nm + 1, &d_first));
     SL_TRY(scratch((pf + ".col").c_str(), static_cast<size_t>(col_n) + 1, &d_col));
     SL_TRY(scratch((pf + ".pos").c_str(), static_cast<size_t>(pos_n) + 1, &d_pos));
     SL_TRY(scratch((pf + ".ovf").c_str(), ng, &d_ovf));
@@ -1407,7 +1310,7 @@ static int m2_prepare(M2Batch& B, const std::string& pf, const uint8_t* d_seq, d
     SL_HIP(hipMemsetAsync(d_ovf, 0, sizeof(int) * ng, s));
     a.seq = d_seq; a.groups = d_groups; a.members = d_members; a.ngroups = static_cast<int>(ng);
     a.ma = static_cast<int>(match); a.mm = static_cast<int>(mismatch);
-    a.map = d_map; a.stats = d_stats; a.dist = d_dist; a.joins = d_joins; a.join_tab = d_jtab;
+    a.map = d_map; a.stats = d_stats; a.dist = d_dist; a.joins = d_joins; a.first = d_first;
     a.col = d_col; a.pos = d_pos; a.ovf = d_ovf; a.width = d_width;
 
     m2_host_time("upload_alloc", th);
@@ -1440,40 +1343,43 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
     if (nm) hipLaunchKernelGGL(k_m2_init, dim3(std::min(2u, std::max(1u, m2_blocks(B.max_len, 256))), static_cast<unsigned>(nm)), dim3(256), 0, s, a, d_mg, static_cast<int>(nm));
     SL_HIP(hipGetLastError());
     const bool unitw = a.ma <= 1 && a.mm <= 1 && !option(OPT_MSA2_GENERAL_ROWS);
-    M2Cand* d_tab = nullptr;
-    if (unitw) {
-        SL_TRY(scratch((pf + ".tab").c_str(), static_cast<size_t>(B.tab_n) + 1, &d_tab));
-        hipLaunchKernelGGL(k_m2_tables, dim3(static_cast<unsigned>(ng)), dim3(64), 0, s, a, d_tab);
+    unsigned long long* d_cnt;
+    SL_TRY(scratch((pf + ".cnt").c_str(), M2C_N, &d_cnt));
+    {
+        unsigned long long init[M2C_N] = {};
+        init[M2C_T_START] = init[M2C_T_FIRST_EXIT] = ~0ull;
+        SL_HIP(hipMemcpyAsync(d_cnt, init, sizeof init, hipMemcpyHostToDevice, s));
+        SL_HIP(hipStreamSynchronize(s));   // (init is on this frame's stack)
+    }
+    a.counters = d_cnt;
+    // ---- the extended library of every group (spec v2, step 5) ----
+    if (B.ext_n > 0) {
+        const int planes = m2_ext_planes(unitw);
+        a.ext_plane = B.ext_n;
+        SL_TRY(scratch((pf + ".ext").c_str(), static_cast<size_t>(B.ext_n) * planes + 1, &a.ext));
+        hipLaunchKernelGGL(k_m2_first, dim3(static_cast<unsigned>(ng)), dim3(64), 0, s, a);
+        const unsigned gx = std::max(1u, std::min(8u, m2_blocks(B.max_len, 64 * M2_EXT_WAVES)));
+        const size_t lds = static_cast<size_t>(M2_EXT_WAVES) * std::max(B.max_n, 1) * 128;
+        if (unitw) hipLaunchKernelGGL((k_m2_extend<true>), dim3(gx, static_cast<unsigned>(nm)), dim3(64 * M2_EXT_WAVES), lds, s, a, d_mg, static_cast<int>(nm), B.max_n);
+        else hipLaunchKernelGGL((k_m2_extend<false>), dim3(gx, static_cast<unsigned>(nm)), dim3(64 * M2_EXT_WAVES), lds, s, a, d_mg, static_cast<int>(nm), B.max_n);
         SL_HIP(hipGetLastError());
     }
     // ---- progressive merging: every join of every group in ONE round of launches ----
     // Groups are ordered by decreasing size.  A group is merged by one workgroup: one wavefront for the bulk (up to M2_NB reads),
     // 8 wavefronts up to 32 reads -- the cost of a group grows with the cube of its size, and the longest group sets the length of
     // the launch --, M2_NWD wavefronts for groups of 33 to M2_MAXN reads, which have an instantiation of their own (64-bit member
-    // masks, up to 127 tree nodes, 65 staged rows per wavefront, candidate tables staged in pieces per wavefront).  The
-    // instantiations run side by side on streams of their own.
+    // masks, up to 127 tree nodes).  The instantiations run side by side on streams of their own.
     size_t nmulti = 0;
     while (nmulti < ng && B.groups[nmulti].n >= 2) ++nmulti;
     if (nmulti) {
         size_t iD = 0, iC = 0;
-        if (unitw) {
-            while (iD < nmulti && B.groups[iD].n > M2_N32) ++iD;
-            iC = iD;
-            if (!option(OPT_MSA2_SINGLE_WAVE))
-                while (iC < nmulti && B.groups[iC].n > M2_NB) ++iC;
-        }
-        unsigned long long* d_cnt;
+        while (iD < nmulti && B.groups[iD].n > M2_N32) ++iD;
+        iC = iD;
+        if (!option(OPT_MSA2_SINGLE_WAVE))
+            while (iC < nmulti && B.groups[iC].n > M2_NB) ++iC;
         int* d_next;
         SL_TRY(scratch((pf + ".next").c_str(), 4, &d_next));
-        SL_TRY(scratch((pf + ".cnt").c_str(), M2C_N, &d_cnt));
         SL_HIP(hipMemsetAsync(d_next, 0, 4 * sizeof(int), s));
-        {
-            unsigned long long init[M2C_N] = {};
-            init[M2C_T_START] = init[M2C_T_FIRST_EXIT] = ~0ull;
-            SL_HIP(hipMemcpyAsync(d_cnt, init, sizeof init, hipMemcpyHostToDevice, s));
-            SL_HIP(hipStreamSynchronize(s));   // (init is on this frame's stack)
-        }
-        a.counters = d_cnt;
         a.chain_hbm = option(OPT_MSA2_CHAIN_HBM) ? 1 : 0;
 
         M2Streams& MS = m2_streams();
@@ -1490,10 +1396,12 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
             const long long per_wg = w_rows * (M2_CAP * 12 + 4 * 4 + 8);
             hipStream_t sk = cls[k].stream >= 0 ? MS.st[cls[k].stream] : s;
             if (cls[k].stream >= 0) SL_HIP(hipStreamWaitEvent(sk, MS.fork, 0));
-            const void* fn = !unitw ? reinterpret_cast<const void*>(&k_m2_group<false, 1, M2_MAXN>)
-                             : k == 0 ? reinterpret_cast<const void*>(&k_m2_group<true, M2_NWD, M2_MAXN>)
-                             : k == 1 ? reinterpret_cast<const void*>(&k_m2_group<true, 8, M2_N32>)
-                                      : reinterpret_cast<const void*>(&k_m2_group<true, 1, M2_N32>);
+            const void* fn = unitw ? (k == 0 ? reinterpret_cast<const void*>(&k_m2_group<true, M2_NWD, M2_MAXN>)
+                                      : k == 1 ? reinterpret_cast<const void*>(&k_m2_group<true, 8, M2_N32>)
+                                               : reinterpret_cast<const void*>(&k_m2_group<true, 1, M2_N32>))
+                                   : (k == 0 ? reinterpret_cast<const void*>(&k_m2_group<false, M2_NWD, M2_MAXN>)
+                                      : k == 1 ? reinterpret_cast<const void*>(&k_m2_group<false, 8, M2_N32>)
+                                               : reinterpret_cast<const void*>(&k_m2_group<false, 1, M2_N32>));
             int per_cu = 0;
             SL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * cls[k].nw, 0));
             per_cu = std::max(1, std::min(per_cu, 32 / cls[k].nw));
@@ -1515,10 +1423,15 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
             am.g0 = static_cast<int>(cls[k].lo); am.g1 = static_cast<int>(cls[k].hi);
             am.next = d_next + k;
             const dim3 grid(static_cast<unsigned>(wgs)), block(64 * cls[k].nw);
-            if (!unitw) hipLaunchKernelGGL((k_m2_group<false, 1, M2_MAXN>), grid, block, 0, sk, am, d_tab);
-            else if (k == 0) hipLaunchKernelGGL((k_m2_group<true, M2_NWD, M2_MAXN>), grid, block, 0, sk, am, d_tab);
-            else if (k == 1) hipLaunchKernelGGL((k_m2_group<true, 8, M2_N32>), grid, block, 0, sk, am, d_tab);
-            else hipLaunchKernelGGL((k_m2_group<true, 1, M2_N32>), grid, block, 0, sk, am, d_tab);
+            if (unitw) {
+                if (k == 0) hipLaunchKernelGGL((k_m2_group<true, M2_NWD, M2_MAXN>), grid, block, 0, sk, am);
+                else if (k == 1) hipLaunchKernelGGL((k_m2_group<true, 8, M2_N32>), grid, block, 0, sk, am);
+                else hipLaunchKernelGGL((k_m2_group<true, 1, M2_N32>), grid, block, 0, sk, am);
+            } else {
+                if (k == 0) hipLaunchKernelGGL((k_m2_group<false, M2_NWD, M2_MAXN>), grid, block, 0, sk, am);
+                else if (k == 1) hipLaunchKernelGGL((k_m2_group<false, 8, M2_N32>), grid, block, 0, sk, am);
+                else hipLaunchKernelGGL((k_m2_group<false, 1, M2_N32>), grid, block, 0, sk, am);
+            }
             SL_HIP(hipGetLastError());
             if (cls[k].stream >= 0) SL_HIP(hipEventRecord(MS.join[cls[k].stream], sk));
         }
@@ -1534,7 +1447,7 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
     unsigned long long hc[M2C_N] = {};
     SL_HIP(hipMemcpyAsync(B.width.data(), d_width, sizeof(int32_t) * ng, hipMemcpyDeviceToHost, s));
     SL_HIP(hipMemcpyAsync(B.ovf.data(), d_ovf, sizeof(int) * ng, hipMemcpyDeviceToHost, s));
-    if (nmulti) SL_HIP(hipMemcpyAsync(hc, a.counters, sizeof hc, hipMemcpyDeviceToHost, s));
+    SL_HIP(hipMemcpyAsync(hc, a.counters, sizeof hc, hipMemcpyDeviceToHost, s));
     SL_HIP(hipStreamSynchronize(s));
     if (nmulti) {
         for (int k = 0; k < M2C_T_START; ++k) counters[k] += static_cast<double>(hc[k]);
@@ -1629,6 +1542,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
     const long long job_budget = 12000000;
     double cells = 0, pairs = 0;
     double counters[M2C_N] = {};
+    const bool unitw_plan = static_cast<int>(match) <= 1 && static_cast<int>(mismatch) <= 1 && !option(OPT_MSA2_GENERAL_ROWS);   // (m2_merge)
     double second_pass = 0;   // groups whose profiles outgrew the first-pass capacity
     double nbatches = 0;      // batches of the call (from two on the stage timers of alignments and merging overlap)
     long long used = 0;
@@ -1681,7 +1595,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             const long long n = grp_off[g + 1] - grp_off[g];
             const long long sum = gsum[q], mx = gmx[q];
             const long long wc = exact_w ? sum : std::min(sum, m2_fast_width(n, mx));
-            mem_all += 2 * (n - 1) * sum + 2 * n * wc + 2 * sum + 16 * m2_tab_entries(static_cast<int>(n));
+            mem_all += 2 * (n - 1) * sum + 2 * n * wc + 2 * sum + n * (n - 1) / 2 * mx * 4 * m2_ext_planes(unitw_plan);
             mem_all += n * (n - 1) / 2 * ((2 * mx) / 16 + 2) * 4;   // the move strings of the bit-vector pairwise kernel (msa_pairwise.hip)
             jobs_all += n * (n - 1) / 2;
             cmem[x + 1] = mem_all; cjobs[x + 1] = jobs_all;

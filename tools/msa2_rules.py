@@ -1,6 +1,7 @@
-"""What do the two own rules of MSA spec v2 change?  CPU only (oracle/msa2.c with its
+"""What do the own rules of MSA spec v2 change?  CPU only (oracle/msa2.c with its
 rule switches): rows and consensus error against the simulated molecule with the rules as specified, without the row cap
-(16 partner columns), without the noise filter (entries lighter than half the row's heaviest) and without both, on
+(16 partner columns), without the noise filter (entries lighter than half the row's heaviest) and without both, with a narrower and a wider library (1 + 1, 1 + 2, 1 + 63 partner positions per (a, p, b)) and with the unbounded library and
+row-major enumeration of rounds 2-4, on
   pure       same-molecule clusters, 10 reads x 2 kb, mockReads error process (BASELINE config 4 shape)
   mixed      clusters of two molecules, 9 + 3 reads x 1 kb (a UMI collision: the consensus should be the majority's)
   hard       3-5 reads x 400 bases, 10 % substitutions, 3 % indel events, every third cluster with a chimeric read
@@ -18,7 +19,11 @@ from oracle import oracle as O
 from sarlacc_amd.mock import NUC, mutate
 
 PARAMS = (0, -1, -5, -1, 100)
-MODES = [("spec v2 (cap 16, filter)", False, False), ("no cap", True, False), ("no filter", False, True), ("neither rule", True, True)]
+# (name, row cap off, noise filter off, partner positions per (a, p, b) beside the direct one; -1: the unbounded library of rounds 2-4)
+MODES = [("spec v2 (library 1+3, cap 16, filter)", False, False, 3), ("no cap", True, False, 3), ("no filter", False, True, 3),
+         ("neither rule", True, True, 3), ("library 1+1", False, False, 1), ("library 1+2", False, False, 2), ("library 1+63", False, False, 63),
+         ("library 1+63, neither rule", True, True, 63), ("rounds 2-4 (unbounded library, cap 16, filter)", False, False, -1),
+         ("rounds 2-4, neither rule", True, True, -1)]
 
 
 def make(kind, rng, n):
@@ -77,13 +82,15 @@ def main():
             rng = np.random.default_rng(9000 + 17 * seed + len(kind))
             reads, groups, truths = make(kind, rng, n)
             base = None
-            for name, nocap, nofilter in MODES:
+            for name, nocap, nofilter, library in MODES:
                 O.msa2_set_rules(nocap, nofilter)
+                O.msa2_set_library(library)
                 O.msa2_stats()
                 try:
                     aln = run(reads, groups, cores)
                 finally:
                     O.msa2_set_rules(False, False)
+                    O.msa2_set_library(3)
                 st = O.msa2_stats()
                 if base is None:
                     base = aln
@@ -100,9 +107,11 @@ def main():
         print("    entries before the filter %d, dropped by it %d (%.1f %%) in %d rows (%.1f %% of the rows); most entries in a row %d"
               % (stats["entries_before_filter"], stats["entries_filtered"], 100.0 * stats["entries_filtered"] / max(stats["entries_before_filter"], 1),
                  stats["rows_filtered"], 100.0 * stats["rows_filtered"] / max(stats["rows"], 1), stats["max_row_entries"]))
-        for name, _, _ in MODES:
+        print("    (a, p, b) triples %d, naming two positions of b %d, three or more %d; partner positions the bounded library ignored %d"
+              % (stats["triples"], stats["triples_2_positions"], stats["triples_3_positions"], stats["library_positions_ignored"]))
+        for name, _, _, _ in MODES:
             e, l = tot[name]
-            print("  %-26s consensus error %.3e per base (%g edits / %g bases)   clusters with rows identical to the spec's: %d of %d   "
+            print("  %-48s consensus error %.3e per base (%g edits / %g bases)   clusters with rows identical to the spec's: %d of %d   "
                   "width difference summed: %g columns" % (name, e / l, e, l, same[name], ngroups, cols_diff[name]))
 
 
