@@ -26,7 +26,7 @@ int fail(const char* fmt, ...) {
 }
 
 static const char* const kOptNames[OPT_N] = {"msa_spec", "msa2_general_rows", "msa2_chain_hbm", "msa2_waves_per_cu", "msa2_single_wave", "msa2_batches", "align_pensel", "align_chunks",
-                                             "align_k", "align_waves_per_cu", "consensus_chars", "consensus_generic", "msa_int32", "msa_affine", "umi_full_rounds", "umi_tile_search", "msa_bitvector", "msa_bitvector_core", "msa_bitvector_tile_gb", "align_interleave", "umi_split_min", "msa2_tight_profiles", "umi_scan_single", "align_wide_barrier", "msa2_budget_gb", "msa2_max_columns", "align_wide_band"};
+                                             "align_k", "align_waves_per_cu", "consensus_chars", "consensus_generic", "msa_int32", "msa_affine", "umi_full_rounds", "umi_tile_search", "msa_bitvector", "msa_bitvector_core", "msa_bitvector_tile_gb", "align_interleave", "umi_split_min", "msa2_tight_profiles", "umi_scan_single", "align_wide_barrier", "msa2_budget_gb", "msa2_max_columns", "align_wide_band", "msa2_simple_extend", "msa2_wide_extend"};
 static int* option_values() {
     static int values[OPT_N];
     static const bool parsed = [] {

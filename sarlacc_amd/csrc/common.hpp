@@ -65,6 +65,8 @@ enum Opt {
     OPT_MSA2_BUDGET_GB,       // spec v2: cap (GB) of the memory one batch of groups may take (default 96; at most half of what is free)
     OPT_MSA2_MAX_COLUMNS,     // spec v2: alignments wider than this go to spec v1 (default and maximum 65535: 16-bit columns; tests lower it)
     OPT_ALIGN_WIDE_BAND,      // k_align_wide_q with traceback: rows either side of the main diagonal that carry codes in the first launch (default 96; -1: every cell)
+    OPT_MSA2_SIMPLE_EXTEND,   // spec v2: the extended library by the one-position-per-lane kernel also for unit weights (A/B, tests)
+    OPT_MSA2_WIDE_EXTEND,     // spec v2: the four-positions-per-lane extension kernel also for groups of more than 24 reads (A/B)
     OPT_N
 };
 int option(Opt o);

@@ -76,8 +76,11 @@ struct M2Member {         // one read of a group
     long long seq_off;    // into d_seq
     long long map_base;   // into d_map: (n - 1) arrays of `len` entries, the other members in member order
     long long col_base;   // into d_col
+    long long ext_base;   // the group's (M2Group::ext_base): k_m2_extend works from the member table alone
     int len;
-    int pad;
+    int first_member;     // of its group
+    int n;                // reads in its group
+    int lmax;             // the group's longest read
 };
 struct M2Group {
     int first_member;     // member a of the group is members[first_member + a]; joins at first_member + k
@@ -110,8 +113,8 @@ struct M2Args {
     double* dist;
     int2* joins;
     m2_mask* first;                // per member: the members it meets as part of the FIRST child (k_m2_first)
-    uint32_t* ext;                 // the extended library (k_m2_extend): 3 (unit weights) or 4 planes of ext_plane records
-    long long ext_plane;
+    uint32_t* ext;                 // the extended library (k_m2_extend): plane 0 here, planes 1 .. 2 (unit weights) or 1 .. 3 at
+    long long ext_off1, ext_plane; //   ext + ext_off1 + (k - 1) ext_plane -- plane 0 may live in a buffer of its own (m2_merge)
     uint16_t* col;                 // (a column is < 65535: 16 bits halve the bytes of the walk's column gathers)
     uint16_t* pos;
     int* ovf;                      // per group: a profile outgrew its capacity
@@ -360,10 +363,10 @@ __global__ void __launch_bounds__(64) k_m2_first(M2Args A) {
 // x extent strides over the read).  gridDim.x = 8 puts the same windows of consecutive members -- the reads of one group, which
 // gather from the same maps -- on the same XCD, i.e. behind the same L2.
 template <bool UNITW>
-__global__ void __launch_bounds__(64 * M2_EXT_WAVES) k_m2_extend(M2Args A, const int* member_group, int nmembers, int maxn) {
+__global__ void __launch_bounds__(64 * M2_EXT_WAVES) k_m2_extend(M2Args A, const int* member_group, int m0, int m1, int maxn) {   // members [m0, m1)
     extern __shared__ __align__(16) unsigned char m2_xs[];
-    const int m = blockIdx.y;
-    if (m >= nmembers) return;
+    const int m = m0 + static_cast<int>(blockIdx.y);
+    if (m >= m1) return;
     const m2_mask F = A.first[m];
     if (!F) return;
     const M2Group G = A.groups[member_group[m]];
@@ -375,7 +378,6 @@ __global__ void __launch_bounds__(64 * M2_EXT_WAVES) k_m2_extend(M2Args A, const
     const M2Member Ml = A.members[fm + min(lane, n - 1)];
     const M2Member Ma = A.members[m];
     const int nwin = (Ma.len + 63) / 64;
-    unsigned long long gath = 0;
     for (int w = blockIdx.x * M2_EXT_WAVES + wave; w < nwin; w += gridDim.x * M2_EXT_WAVES) {
         const int p = w * 64 + lane;
         const bool in = p < Ma.len;
@@ -387,7 +389,6 @@ __global__ void __launch_bounds__(64 * M2_EXT_WAVES) k_m2_extend(M2Args A, const
         }
         int xa = 0;
         if (!UNITW) xa = dna5_code(A.seq[Ma.seq_off + pidx]);
-        gath += static_cast<unsigned>(n - 1);
         for (int b = 0; b < n; ++b) {
             if (!((F >> b) & 1ull)) continue;
             const long long seqb = m2_readlane64(static_cast<m2_u64>(Ml.seq_off), b);
@@ -395,54 +396,205 @@ __global__ void __launch_bounds__(64 * M2_EXT_WAVES) k_m2_extend(M2Args A, const
             unsigned w0 = 0;
             if (q0 != M2_NONE) w0 = UNITW ? 1u : static_cast<unsigned>(m2_w0(xa, dna5_code(A.seq[seqb + q0]), A.ma, A.mm));
             unsigned q1 = M2_NONE, q2 = M2_NONE, q3 = M2_NONE, w1 = 0, w2 = 0, w3 = 0, nalt = 0;
-            for (int c = 0; c < n; ++c) {
-                const bool use = c != a && c != b;
-                const int lenc = __builtin_amdgcn_readlane(Ml.len, c);
-                const long long basec = static_cast<long long>(m2_readlane64(static_cast<m2_u64>(Ml.map_base), c)) +
-                                        static_cast<long long>(!use ? 0 : (b < c ? b : b - 1)) * lenc;
-                const unsigned r = s_r[c * 64];
-                const bool hr = use && r != M2_NONE;
-                const unsigned ridx = hr ? r : 0u;
-                const unsigned q = A.map[basec + ridx];
-                const bool v = hr && q != M2_NONE;
-                unsigned wt = 1;
-                if (!UNITW) {
-                    const long long seqc = m2_readlane64(static_cast<m2_u64>(Ml.seq_off), c);
-                    const int xc = dna5_code(A.seq[seqc + ridx]);
-                    const int xb = dna5_code(A.seq[seqb + (v ? q : 0u)]);
-                    const int wac = m2_w0(xa, xc, A.ma, A.mm), wcb = m2_w0(xc, xb, A.ma, A.mm);
-                    wt = static_cast<unsigned>(wac < wcb ? wac : wcb);
+            // the third reads eight at a time: their gathers are requested back to back, then the records updated in order of c
+            for (int c0 = 0; c0 < n; c0 += 8) {
+                unsigned qq[8], ri[8];
+                bool hv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = min(c0 + u, n - 1);
+                    const bool use = c0 + u < n && c != a && c != b;
+                    const int lenc = __builtin_amdgcn_readlane(Ml.len, c);
+                    const long long basec = static_cast<long long>(m2_readlane64(static_cast<m2_u64>(Ml.map_base), c)) +
+                                            static_cast<long long>(!use ? 0 : (b < c ? b : b - 1)) * lenc;
+                    const unsigned r = s_r[c * 64];
+                    hv[u] = use && r != M2_NONE;
+                    ri[u] = hv[u] ? r : 0u;
+                    qq[u] = A.map[basec + ri[u]];
                 }
-                const bool m0 = v && q == q0;
-                w0 += m0 ? wt : 0u;
-                if (__ballot(v && !m0)) {   // (same-molecule reads: nearly every triplet names the direct partner)
-                    const bool m1 = v && q == q1, m2 = v && q == q2, m3 = v && q == q3;
-                    w1 += m1 ? wt : 0u; w2 += m2 ? wt : 0u; w3 += m3 ? wt : 0u;
-                    const bool fresh = v && !m0 && !m1 && !m2 && !m3;   // a position not seen yet: the next free slot, if any
-                    const bool t1 = fresh && nalt == 0, t2 = fresh && nalt == 1, t3 = fresh && nalt == 2;
-                    q1 = t1 ? q : q1; w1 = t1 ? wt : w1;
-                    q2 = t2 ? q : q2; w2 = t2 ? wt : w2;
-                    q3 = t3 ? q : q3; w3 = t3 ? wt : w3;
-                    nalt += (t1 || t2 || t3) ? 1u : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned q = qq[u];
+                    const bool v = hv[u] && q != M2_NONE;
+                    unsigned wt = 1;
+                    if (!UNITW) {
+                        const int c = min(c0 + u, n - 1);
+                        const long long seqc = m2_readlane64(static_cast<m2_u64>(Ml.seq_off), c);
+                        const int xc = dna5_code(A.seq[seqc + ri[u]]);
+                        const int xb = dna5_code(A.seq[seqb + (v ? q : 0u)]);
+                        const int wac = m2_w0(xa, xc, A.ma, A.mm), wcb = m2_w0(xc, xb, A.ma, A.mm);
+                        wt = static_cast<unsigned>(wac < wcb ? wac : wcb);
+                    }
+                    const bool m0 = v && q == q0;
+                    w0 += m0 ? wt : 0u;
+                    if (__ballot(v && !m0)) {   // (same-molecule reads: nearly every triplet names the direct partner)
+                        const bool m1 = v && q == q1, m2 = v && q == q2, m3 = v && q == q3;
+                        w1 += m1 ? wt : 0u; w2 += m2 ? wt : 0u; w3 += m3 ? wt : 0u;
+                        const bool fresh = v && !m0 && !m1 && !m2 && !m3;   // a position not seen yet: the next free slot, if any
+                        const bool t1 = fresh && nalt == 0, t2 = fresh && nalt == 1, t3 = fresh && nalt == 2;
+                        q1 = t1 ? q : q1; w1 = t1 ? wt : w1;
+                        q2 = t2 ? q : q2; w2 = t2 ? wt : w2;
+                        q3 = t3 ? q : q3; w3 = t3 ? wt : w3;
+                        nalt += (t1 || t2 || t3) ? 1u : 0u;
+                    }
                 }
             }
-            gath += static_cast<unsigned>(n - 2);
             if (in) {
                 uint32_t* const E = A.ext + G.ext_base + m2_pair_index(a, b, n) * G.lmax + p;
                 if (UNITW) {
                     E[0] = w0 | (nalt << 6) | (w1 << 8) | (q1 << 16);
-                    if (nalt >= 2) E[A.ext_plane] = w2 | (q2 << 16);
-                    if (nalt >= 3) E[2 * A.ext_plane] = w3 | (q3 << 16);
+                    if (nalt >= 2) E[A.ext_off1] = w2 | (q2 << 16);
+                    if (nalt >= 3) E[A.ext_off1 + A.ext_plane] = w3 | (q3 << 16);
                 } else {
                     E[0] = w0 | (nalt << 16);
-                    if (nalt >= 1) E[A.ext_plane] = w1 | (q1 << 16);
-                    if (nalt >= 2) E[2 * A.ext_plane] = w2 | (q2 << 16);
-                    if (nalt >= 3) E[3 * A.ext_plane] = w3 | (q3 << 16);
+                    if (nalt >= 1) E[A.ext_off1] = w1 | (q1 << 16);
+                    if (nalt >= 2) E[A.ext_off1 + A.ext_plane] = w2 | (q2 << 16);
+                    if (nalt >= 3) E[A.ext_off1 + 2 * A.ext_plane] = w3 | (q3 << 16);
                 }
             }
         }
     }
-    if (lane == 0 && gath) atomicAdd(&A.counters[M2C_GATHERS], gath);
+}
+
+// Unit weights (the default scores): the same records from 256 positions per wavefront, FOUR consecutive positions per lane.
+// The positions r of the lane's bases in a third read c are four consecutive entries of map(a -> c) -- one 8-byte load per
+// read, staged in LDS once per window for every b --, and their partners in b four entries of map(c -> b) that lie within a
+// few positions of each other: ONE 16-byte load at the first valid r covers r .. r + 7 (2-byte aligned: gfx950 takes it), a
+// lane whose four positions span more than that (an insertion of more than four bases inside four positions) gathers the
+// stragglers one by one.  So a (b, c) candidate costs one wide load per 256 positions instead of four 2-byte gathers, and the
+// records leave as 16-byte stores.  (The first version, one position per lane and one gather per candidate like
+// k_m2_extend<false> below, spent 150 ms per 10^6 reads waiting for its round trips; the request rate of its gathers alone
+// would have allowed 15.)
+struct __attribute__((packed, aligned(2))) m2_u16x4 { unsigned lo, hi; };
+struct __attribute__((packed, aligned(2))) m2_u16x8 { unsigned x, y, z, w; };
+struct __attribute__((packed, aligned(4))) m2_u32x4 { unsigned x, y, z, w; };
+__device__ __forceinline__ unsigned m2_pick16(const m2_u16x8& W, unsigned d) {   // entry d (0 .. 7) of a 16-byte window
+    const unsigned long long lo = (static_cast<unsigned long long>(W.y) << 32) | W.x, hi = (static_cast<unsigned long long>(W.w) << 32) | W.z;
+    const unsigned long long h = (d & 4u) ? hi : lo;
+    return static_cast<unsigned>(h >> ((d & 3u) * 16u)) & 0xffffu;
+}
+constexpr int M2_XC = 4;   // third reads requested side by side
+__global__ void __launch_bounds__(64) k_m2_extend_unit(M2Args A, int m0, int m1) {   // members [m0, m1)
+    extern __shared__ __align__(16) unsigned char m2_xs[];
+    const int m = m0 + static_cast<int>(blockIdx.y);
+    if (m >= m1) return;
+    const m2_mask F = A.first[m];
+    const M2Member Ma = A.members[m];
+    if (!F) return;
+    const int n = Ma.n, fm = Ma.first_member, a = m - fm;
+    const int lane = threadIdx.x;
+    uint16_t* const s_r = reinterpret_cast<uint16_t*>(m2_xs) + 4 * lane;   // [c * 256]: this lane's four positions in read c
+    const M2Member Ml = A.members[fm + min(lane, n - 1)];                   // lane c = member c
+    const int nwin = (Ma.len + 255) / 256;
+    for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
+        const int P = w * 256 + 4 * lane;
+        const int nin = max(0, min(4, Ma.len - P));   // of the lane's four positions, those inside the read
+        for (int c = 0; c < n; ++c) {
+            m2_u16x4 v;
+            v.lo = v.hi = 0xFFFFFFFFu;
+            if (c != a && nin > 0) {
+                v = *reinterpret_cast<const m2_u16x4*>(A.map + Ma.map_base + static_cast<long long>(c < a ? c : c - 1) * Ma.len + P);
+                if (nin < 4) {   // (the load ran into the next array: its slack, the next map, is readable)
+                    v.hi = nin <= 2 ? 0xFFFFFFFFu : (v.hi | 0xFFFF0000u);
+                    v.lo = nin <= 1 ? (v.lo | 0xFFFF0000u) : v.lo;
+                }
+            }
+            *reinterpret_cast<m2_u16x4*>(s_r + c * 256) = v;
+        }
+        for (int b = 0; b < n; ++b) {
+            if (!((F >> b) & 1ull)) continue;
+            const m2_u16x4 dv = *reinterpret_cast<const m2_u16x4*>(s_r + b * 256);
+            unsigned q0[4] = {dv.lo & 0xffffu, dv.lo >> 16, dv.hi & 0xffffu, dv.hi >> 16};
+            unsigned wp[4], q1[4], q2[4], q3[4], nalt[4];   // wp: the four weights of a position, a byte each
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { wp[k] = q0[k] != M2_NONE ? 1u : 0u; q1[k] = q2[k] = q3[k] = M2_NONE; nalt[k] = 0; }
+            // the third reads: every member but a and b, M2_XC at a time
+            const int lo_ab = min(a, b), hi_ab = max(a, b);
+            for (int k0 = 0; k0 < n - 2; k0 += M2_XC) {
+                m2_u16x8 W[M2_XC];
+                m2_u16x4 rv[M2_XC];
+                unsigned first[M2_XC];
+#pragma unroll
+                for (int u = 0; u < M2_XC; ++u) {
+                    const bool use = k0 + u < n - 2;
+                    int c = min(k0 + u, n - 3);
+                    c += c >= lo_ab ? 1 : 0;
+                    c += c >= hi_ab ? 1 : 0;
+                    const int lenc = __builtin_amdgcn_readlane(Ml.len, c);
+                    const long long basec = static_cast<long long>(m2_readlane64(static_cast<m2_u64>(Ml.map_base), c)) + static_cast<long long>(b < c ? b : b - 1) * lenc;
+                    rv[u] = *reinterpret_cast<const m2_u16x4*>(s_r + c * 256);
+                    if (!use) rv[u].lo = rv[u].hi = 0xFFFFFFFFu;
+                    const unsigned r0 = rv[u].lo & 0xffffu, r1 = rv[u].lo >> 16, r2 = rv[u].hi & 0xffffu, r3 = rv[u].hi >> 16;
+                    // (positions ascend along a pairwise alignment: the first valid one is the smallest)
+                    first[u] = r0 != M2_NONE ? r0 : (r1 != M2_NONE ? r1 : (r2 != M2_NONE ? r2 : (r3 != M2_NONE ? r3 : 0u)));
+                    W[u] = *reinterpret_cast<const m2_u16x8*>(A.map + basec + first[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < M2_XC; ++u) {
+                    const unsigned rr[4] = {rv[u].lo & 0xffffu, rv[u].lo >> 16, rv[u].hi & 0xffffu, rv[u].hi >> 16};
+                    unsigned q[4];
+                    bool far = false;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned d = rr[k] - first[u];
+                        q[k] = rr[k] != M2_NONE ? m2_pick16(W[u], d & 7u) : M2_NONE;
+                        far = far || (rr[k] != M2_NONE && d > 7u);
+                    }
+                    if (__ballot(far)) {   // beyond the window: gathers of their own
+                        int c = min(k0 + u, n - 3);
+                        c += c >= lo_ab ? 1 : 0;
+                        c += c >= hi_ab ? 1 : 0;
+                        const int lenc = __builtin_amdgcn_readlane(Ml.len, c);
+                        const long long basec = static_cast<long long>(m2_readlane64(static_cast<m2_u64>(Ml.map_base), c)) + static_cast<long long>(b < c ? b : b - 1) * lenc;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (rr[k] != M2_NONE && rr[k] - first[u] > 7u) q[k] = A.map[basec + rr[k]];
+                    }
+                    bool other = false;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool m0 = q[k] != M2_NONE && q[k] == q0[k];
+                        wp[k] += m0 ? 1u : 0u;
+                        other = other || (q[k] != M2_NONE && !m0);
+                    }
+                    if (__ballot(other)) {   // (same-molecule reads: nearly every triplet names the direct partner)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bool v = q[k] != M2_NONE && q[k] != q0[k];
+                            const bool m1 = v && q[k] == q1[k], m2 = v && q[k] == q2[k], m3 = v && q[k] == q3[k];
+                            const bool fresh = v && !m1 && !m2 && !m3;   // a position not seen yet: the next free slot, if any
+                            const bool t1 = fresh && nalt[k] == 0, t2 = fresh && nalt[k] == 1, t3 = fresh && nalt[k] == 2;
+                            wp[k] += ((m1 || t1) ? 0x100u : 0u) + ((m2 || t2) ? 0x10000u : 0u) + ((m3 || t3) ? 0x1000000u : 0u);
+                            q1[k] = t1 ? q[k] : q1[k];
+                            q2[k] = t2 ? q[k] : q2[k];
+                            q3[k] = t3 ? q[k] : q3[k];
+                            nalt[k] += (t1 || t2 || t3) ? 1u : 0u;
+                        }
+                    }
+                }
+            }
+            uint32_t* const E = A.ext + Ma.ext_base + m2_pair_index(a, b, n) * Ma.lmax + P;
+            unsigned e0[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e0[k] = (wp[k] & 63u) | (nalt[k] << 6) | (((wp[k] >> 8) & 255u) << 8) | (q1[k] << 16);
+            if (nin == 4) {
+                m2_u32x4 o;
+                o.x = e0[0]; o.y = e0[1]; o.z = e0[2]; o.w = e0[3];
+                *reinterpret_cast<m2_u32x4*>(E) = o;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < nin) E[k] = e0[k];
+            }
+            if (__ballot(nin > 0 && (nalt[0] | nalt[1] | nalt[2] | nalt[3]) >= 2u)) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k < nin && nalt[k] >= 2u) E[A.ext_off1 + k] = ((wp[k] >> 16) & 255u) | (q2[k] << 16);
+                    if (k < nin && nalt[k] >= 3u) E[A.ext_off1 + A.ext_plane + k] = (wp[k] >> 24) | (q3[k] << 16);
+                }
+            }
+        }
+    }
 }
 
 template <typename MASK>
@@ -453,6 +605,8 @@ struct M2JoinT {      // wave-uniform description of one join (MASK: unsigned fo
 };
 __device__ __forceinline__ int m2_popc(unsigned m) { return __popc(m); }
 __device__ __forceinline__ int m2_popc(m2_mask m) { return __popcll(m); }
+__device__ __forceinline__ int m2_ctz(unsigned m) { return __builtin_ctz(m); }
+__device__ __forceinline__ int m2_ctz(m2_mask m) { return __builtin_ctzll(m); }
 
 // A row's list -> filter, order by column, append to the match list.  ej[k] < 0: empty slot.
 // (macro: the lists must stay in registers, every index a compile-time constant)
@@ -496,6 +650,13 @@ __device__ __forceinline__ int m2_popc(m2_mask m) { return __popcll(m); }
 // The columns of a list are distinct, so at most one entry matches.  Three tiers, each behind a wave-wide test:
 // entries 0-3; entries 4-7 and the append into 0-7; entries 8-15.
 constexpr unsigned M2_EMPTY = 0xFFFF0000u;
+#ifndef M2_RB1
+#define M2_RB1 1   // members of the second child whose records a row requests together: one wavefront per group (64 registers) ...
+#endif
+#ifndef M2_RBN
+#define M2_RBN 1   // ... and the workgroups of several wavefronts.  (2 / 4 and 4 / 4: 490 and 563 ms against 449 at bench.py's pipeline workload --
+                   // the registers of a batch cost more resident wavefronts than its shorter chain of round trips gains)
+#endif
 #define M2_MATCH1(K0, K1)                                                                              \
     _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                           \
         const bool m_ = (pe[k_] >> 16) == j_;                                                          \
@@ -555,7 +716,7 @@ constexpr unsigned M2_EMPTY = 0xFFFF0000u;
         }                                                                                              \
     }
 
-template <bool UNITW, typename MASK>
+template <bool UNITW, int M2_RB, typename MASK>
 __device__ __forceinline__ int m2_rows_ext(const M2Args& A, const M2Group& G, const M2JoinT<MASK>& J, int i_lo, int i_hi, m2_u64* ent, int* part,
                                            unsigned& st_capped, unsigned& st_filtered, unsigned& st_rowsf) {
     const int lane = m2_lane();
@@ -583,41 +744,68 @@ __device__ __forceinline__ int m2_rows_ext(const M2Args& A, const M2Group& G, co
             if (!__ballot(havep)) continue;
             const M2Member Ma = A.members[fm + a];
             const unsigned pidx = havep ? p : 0u;
-            for (int b = 0; b < n; ++b) {
-                if (!((J.maskB >> b) & 1)) continue;
-                const M2Member Mb = A.members[fm + b];
-                const uint16_t* const colb = A.col + Mb.col_base;
-                const unsigned lenb1 = static_cast<unsigned>(max(Mb.len - 1, 0));
-                const uint32_t* const E = A.ext + G.ext_base + m2_pair_index(a, b, n) * G.lmax + pidx;
-                const unsigned q0 = A.map[Ma.map_base + static_cast<long long>(b < a ? b : b - 1) * Ma.len + pidx];
-                const unsigned e0 = E[0];
-                unsigned w0, nalt, q1 = M2_NONE, w1 = 0;
-                if (UNITW) { w0 = e0 & 63u; nalt = (e0 >> 6) & 3u; w1 = (e0 >> 8) & 255u; q1 = e0 >> 16; }
-                else { w0 = e0 & 0xffffu; nalt = e0 >> 16; }
-                nalt = havep ? nalt : 0u;
-                const bool v0 = havep && q0 != M2_NONE;
-                const unsigned j0 = leafB ? q0 : colb[min(q0, lenb1)];
+            // the second child's members in ascending order, M2_RB at a time: their map entries and records are requested together,
+            // then the partners' columns and the further records, then the columns of those -- three round trips per M2_RB members
+            // (one member at a time, each with up to six dependent round trips, left the wavefront waiting most of the time)
 #define M2_ADD_ANY(Jx, Wx, Vx) { if constexpr (UNITW) M2_ADD1(Jx, Wx, Vx) else M2_ADD(Jx, Wx, Vx) }
-                M2_ADD_ANY(j0, w0, v0)
-                if (__ballot(nalt >= 1u)) {
-                    if (!UNITW) { const unsigned e1 = nalt >= 1u ? E[A.ext_plane] : 0u; w1 = e1 & 0xffffu; q1 = e1 >> 16; }
-                    const unsigned j1 = leafB ? q1 : colb[min(q1, lenb1)];
-                    M2_ADD_ANY(j1, w1, nalt >= 1u)
-                    if (__ballot(nalt >= 2u)) {
-                        const unsigned e2 = nalt >= 2u ? E[(UNITW ? 1 : 2) * A.ext_plane] : 0u;
-                        const unsigned q2 = e2 >> 16;
-                        const unsigned j2 = leafB ? q2 : colb[min(q2, lenb1)];
-                        M2_ADD_ANY(j2, e2 & 0xffffu, nalt >= 2u)
-                        if (__ballot(nalt >= 3u)) {
-                            const unsigned e3 = nalt >= 3u ? E[(UNITW ? 2 : 3) * A.ext_plane] : 0u;
-                            const unsigned q3 = e3 >> 16;
-                            const unsigned j3 = leafB ? q3 : colb[min(q3, lenb1)];
-                            M2_ADD_ANY(j3, e3 & 0xffffu, nalt >= 3u)
-                        }
+            MASK rest = J.maskB;
+            while (rest) {
+                int bb[M2_RB], nbb = 0;
+#pragma unroll
+                for (int u = 0; u < M2_RB; ++u) {
+                    const bool has = rest != 0;
+                    bb[u] = has ? m2_ctz(rest) : bb[u > 0 ? u - 1 : 0];
+                    rest = has ? (rest & (rest - 1)) : rest;
+                    nbb += has ? 1 : 0;
+                }
+                unsigned q0[M2_RB], e0[M2_RB];
+#pragma unroll
+                for (int u = 0; u < M2_RB; ++u) {   // (a batch that is not full repeats its last member: harmless loads)
+                    const int b = bb[u];
+                    q0[u] = A.map[Ma.map_base + static_cast<long long>(b < a ? b : b - 1) * Ma.len + pidx];
+                    e0[u] = A.ext[G.ext_base + m2_pair_index(a, b, n) * G.lmax + pidx];
+                }
+                unsigned j0[M2_RB], x1[M2_RB], x2[M2_RB], x3[M2_RB], nal[M2_RB];
+                bool any1[M2_RB], any2[M2_RB], any3[M2_RB];
+#pragma unroll
+                for (int u = 0; u < M2_RB; ++u) {
+                    const M2Member Mb = A.members[fm + bb[u]];
+                    const uint16_t* const colb = A.col + Mb.col_base;
+                    const unsigned lenb1 = static_cast<unsigned>(max(Mb.len - 1, 0));
+                    const uint32_t* const E = A.ext + G.ext_base + m2_pair_index(a, bb[u], n) * G.lmax + pidx;
+                    nal[u] = (havep && u < nbb) ? (UNITW ? ((e0[u] >> 6) & 3u) : (e0[u] >> 16)) : 0u;
+                    any1[u] = __ballot(nal[u] >= 1u) != 0; any2[u] = __ballot(nal[u] >= 2u) != 0; any3[u] = __ballot(nal[u] >= 3u) != 0;
+                    j0[u] = leafB ? q0[u] : colb[min(q0[u], lenb1)];
+                    x1[u] = x2[u] = x3[u] = 0;
+                    if (UNITW) {
+                        const unsigned q1 = e0[u] >> 16;
+                        if (any1[u]) x1[u] = ((leafB ? q1 : colb[min(q1, lenb1)]) << 16) | ((e0[u] >> 8) & 255u);
+                    } else if (any1[u]) x1[u] = nal[u] >= 1u ? E[A.ext_off1] : 0u;
+                    if (any2[u]) x2[u] = nal[u] >= 2u ? E[A.ext_off1 + (UNITW ? 0 : 1) * A.ext_plane] : 0u;
+                    if (any3[u]) x3[u] = nal[u] >= 3u ? E[A.ext_off1 + (UNITW ? 1 : 2) * A.ext_plane] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < M2_RB; ++u) {   // the columns of the further partners: x = (column << 16) | weight from here on
+                    const M2Member Mb = A.members[fm + bb[u]];
+                    const uint16_t* const colb = A.col + Mb.col_base;
+                    const unsigned lenb1 = static_cast<unsigned>(max(Mb.len - 1, 0));
+                    if (!UNITW && any1[u]) x1[u] = ((leafB ? (x1[u] >> 16) : colb[min(x1[u] >> 16, lenb1)]) << 16) | (x1[u] & 0xffffu);
+                    if (any2[u]) x2[u] = ((leafB ? (x2[u] >> 16) : colb[min(x2[u] >> 16, lenb1)]) << 16) | (x2[u] & 0xffffu);
+                    if (any3[u]) x3[u] = ((leafB ? (x3[u] >> 16) : colb[min(x3[u] >> 16, lenb1)]) << 16) | (x3[u] & 0xffffu);
+                }
+#pragma unroll
+                for (int u = 0; u < M2_RB; ++u) {
+                    if (u >= nbb) break;
+                    const unsigned w0 = UNITW ? (e0[u] & 63u) : (e0[u] & 0xffffu);
+                    M2_ADD_ANY(j0[u], w0, havep && q0[u] != M2_NONE)
+                    if (any1[u]) {
+                        M2_ADD_ANY(x1[u] >> 16, x1[u] & 0xffffu, nal[u] >= 1u)
+                        if (any2[u]) M2_ADD_ANY(x2[u] >> 16, x2[u] & 0xffffu, nal[u] >= 2u)
+                        if (any3[u]) M2_ADD_ANY(x3[u] >> 16, x3[u] & 0xffffu, nal[u] >= 3u)
                     }
                 }
-#undef M2_ADD_ANY
             }
+#undef M2_ADD_ANY
         }
         st_capped += (row && capped) ? 1u : 0u;
         if constexpr (UNITW) {   // filter, order by column, append -- on the packed entries: (column << 16) | weight orders by column
@@ -944,7 +1132,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
             const int bpw = ((J.nA + 63) / 64 + NW - 1) / NW;
             const long long stride = static_cast<long long>(bpw) * 64 * M2_CAP;
             const int i_lo = min(wave * bpw * 64, J.nA), i_hi = min((wave + 1) * bpw * 64, J.nA);
-            const int ne = m2_rows_ext<UNITW, MASK>(A, G, J, i_lo, i_hi, ent + wave * stride, part, st_capped, st_filtered, st_rowsf);
+            const int ne = m2_rows_ext<UNITW, (NW == 1 ? M2_RB1 : M2_RBN), MASK>(A, G, J, i_lo, i_hi, ent + wave * stride, part, st_capped, st_filtered, st_rowsf);
             // wave-wide gather instructions of this wavefront's rows: per block of 64 columns and member of the first child its
             // positions, then per member of the second child the direct partner, the record and the partner's column (further
             // partner positions of a record: not counted, a lower bound)
@@ -1097,6 +1285,7 @@ struct M2Batch {
     int* d_member_group = nullptr;
     int max_len = 0, max_wcap = 0, max_n = 0;
     long long ext_n = 0;          // records per plane of the extended library
+    bool alias_tiles = false;     // plane 0 of the library in the pairwise kernel's tile buffer (a call of one batch)
     MsaJobSummary jsum;           // band classes and cell count of `jobs`
     hipEvent_t pair_done = nullptr;   // the all-pairs alignments of the batch have finished (m2_prepare -> m2_merge)
 };
@@ -1188,6 +1377,7 @@ static int m2_plan(M2Batch& B, const int64_t* grp_off, const int32_t* grp, const
                 Me.len = static_cast<int>(rel[mem[a]] - rel[mem[a] - 1]);
                 Me.map_base = mp;
                 Me.col_base = cp;
+                Me.ext_base = G.ext_base; Me.first_member = G.first_member; Me.n = n; Me.lmax = G.lmax;
                 mp += static_cast<long long>(std::max(0, n - 1)) * Me.len;
                 cp += Me.len;
                 B.member_group[static_cast<size_t>(G.first_member) + a] = static_cast<int>(q);
@@ -1314,6 +1504,10 @@ static int m2_prepare(M2Batch& B, const std::string& pf, const uint8_t* d_seq, d
     a.col = d_col; a.pos = d_pos; a.ovf = d_ovf; a.width = d_width;
 
     m2_host_time("upload_alloc", th);
+    if (B.alias_tiles && B.ext_n > 0) {   // (before the alignments take their pointer to it)
+        void* tb;
+        SL_TRY(c.buffer("msa.tb0", static_cast<size_t>(B.ext_n) * 4 + 16, &tb));
+    }
     // ---- all pairs ----
     th = m2_now();
     *cells += B.jsum.cells;
@@ -1356,12 +1550,50 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
     if (B.ext_n > 0) {
         const int planes = m2_ext_planes(unitw);
         a.ext_plane = B.ext_n;
-        SL_TRY(scratch((pf + ".ext").c_str(), static_cast<size_t>(B.ext_n) * planes + 1, &a.ext));
+        // A call that runs as ONE batch keeps plane 0 in the tile buffer of the pairwise kernel, whose records are dead by now
+        // (m2_prepare made sure it is large enough); with pipelined batches the next batch's alignments are writing there.
+        uint32_t* hi;
+        SL_TRY(scratch((pf + ".ext").c_str(), static_cast<size_t>(B.ext_n) * (planes - (B.alias_tiles ? 1 : 0)) + 1, &hi));
+        if (B.alias_tiles) {
+            const auto it = c.ws.find("msa.tb0");
+            if (it == c.ws.end() || it->second.cap < static_cast<size_t>(B.ext_n) * 4) return fail("sarlacc_amd: internal error: the tile buffer does not hold the extended library");
+            a.ext = static_cast<uint32_t*>(it->second.ptr);
+            a.ext_off1 = hi - a.ext;   // (both 4-byte aligned device addresses)
+        } else {
+            a.ext = hi;
+            a.ext_off1 = B.ext_n;
+        }
         hipLaunchKernelGGL(k_m2_first, dim3(static_cast<unsigned>(ng)), dim3(64), 0, s, a);
-        const unsigned gx = std::max(1u, std::min(8u, m2_blocks(B.max_len, 64 * M2_EXT_WAVES)));
-        const size_t lds = static_cast<size_t>(M2_EXT_WAVES) * std::max(B.max_n, 1) * 128;
-        if (unitw) hipLaunchKernelGGL((k_m2_extend<true>), dim3(gx, static_cast<unsigned>(nm)), dim3(64 * M2_EXT_WAVES), lds, s, a, d_mg, static_cast<int>(nm), B.max_n);
-        else hipLaunchKernelGGL((k_m2_extend<false>), dim3(gx, static_cast<unsigned>(nm)), dim3(64 * M2_EXT_WAVES), lds, s, a, d_mg, static_cast<int>(nm), B.max_n);
+        if (unitw && !option(OPT_MSA2_SIMPLE_EXTEND)) {
+            // (the LDS of a wavefront holds a window of 256 positions of every read of its group, 512 B each: one launch per size class,
+            // so that the few large groups do not set the occupancy of the many small ones -- the batch is ordered by decreasing size)
+            const unsigned gx = std::max(1u, std::min(8u, m2_blocks(B.max_len, 256)));
+            size_t q = 0;
+            for (const int cap : {M2_MAXN, 24, 12}) {
+                const int lower = cap == M2_MAXN ? 24 : (cap == 24 ? 12 : 0);   // this launch: groups of lower < n <= cap
+                size_t q1 = q;
+                while (q1 < ng && B.groups[q1].n > lower) ++q1;
+                if (q1 > q) {
+                    const int m0 = B.groups[q].first_member, m1 = B.groups[q1 - 1].first_member + B.groups[q1 - 1].n;
+                    // (msa2_wide_extend = largest group size that takes the four-positions kernel; default 12)
+                    const int wide_max = option(OPT_MSA2_WIDE_EXTEND) > 0 ? option(OPT_MSA2_WIDE_EXTEND) : 12;
+                    if (cap > wide_max) {
+                        // (256 positions of up to 64 reads are 32 KB of LDS per wavefront, five wavefronts per CU: the largest groups
+                        // go through the one-position-per-lane kernel, 8 KB per wavefront)
+                        const unsigned gx1 = std::max(1u, std::min(8u, m2_blocks(B.max_len, 64 * M2_EXT_WAVES)));
+                        hipLaunchKernelGGL((k_m2_extend<true>), dim3(gx1, static_cast<unsigned>(m1 - m0)), dim3(64 * M2_EXT_WAVES),
+                                           static_cast<size_t>(M2_EXT_WAVES) * std::max(B.max_n, 1) * 128, s, a, d_mg, m0, m1, B.max_n);
+                    } else
+                    hipLaunchKernelGGL(k_m2_extend_unit, dim3(gx, static_cast<unsigned>(m1 - m0)), dim3(64), static_cast<size_t>(std::min(cap, std::max(B.max_n, 1))) * 512, s, a, m0, m1);
+                }
+                q = q1;
+            }
+        } else {
+            const unsigned gx = std::max(1u, std::min(8u, m2_blocks(B.max_len, 64 * M2_EXT_WAVES)));
+            const size_t lds = static_cast<size_t>(M2_EXT_WAVES) * std::max(B.max_n, 1) * 128;
+            if (unitw) hipLaunchKernelGGL((k_m2_extend<true>), dim3(gx, static_cast<unsigned>(nm)), dim3(64 * M2_EXT_WAVES), lds, s, a, d_mg, 0, static_cast<int>(nm), B.max_n);
+            else hipLaunchKernelGGL((k_m2_extend<false>), dim3(gx, static_cast<unsigned>(nm)), dim3(64 * M2_EXT_WAVES), lds, s, a, d_mg, 0, static_cast<int>(nm), B.max_n);
+        }
         SL_HIP(hipGetLastError());
     }
     // ---- progressive merging: every join of every group in ONE round of launches ----
@@ -1587,7 +1819,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             return grp_off[ids[x] + 1] - grp_off[ids[x]] > grp_off[ids[y] + 1] - grp_off[ids[y]];
         });
         std::vector<size_t> again;
-        long long mem_all = 0, jobs_all = 0;
+        long long mem_all = 0, jobs_all = 0, ext_all = 0, cells_est = 0;
         std::vector<long long> cmem(todo.size() + 1, 0), cjobs(todo.size() + 1, 0);   // cumulative over the sorted list
         for (size_t x = 0; x < todo.size(); ++x) {
             const size_t q = todo[x];
@@ -1596,6 +1828,8 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             const long long sum = gsum[q], mx = gmx[q];
             const long long wc = exact_w ? sum : std::min(sum, m2_fast_width(n, mx));
             mem_all += 2 * (n - 1) * sum + 2 * n * wc + 2 * sum + n * (n - 1) / 2 * mx * 4 * m2_ext_planes(unitw_plan);
+            ext_all += n * (n - 1) / 2 * mx * 4 * m2_ext_planes(unitw_plan);
+            cells_est += n * std::min(sum, 2 * mx);   // (rows: about the longest read, some more for clusters of several molecules)
             mem_all += n * (n - 1) / 2 * ((2 * mx) / 16 + 2) * 4;   // the move strings of the bit-vector pairwise kernel (msa_pairwise.hip)
             jobs_all += n * (n - 1) / 2;
             cmem[x + 1] = mem_all; cjobs[x + 1] = jobs_all;
@@ -1613,8 +1847,21 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         c.counts["msa2_mem_all_gb"] = static_cast<double>(mem_all) / 1073741824.0;
         c.counts["msa2_mem_budget_gb"] = static_cast<double>(mem_budget) / 1073741824.0;
         long long nb = std::max<long long>(1, std::max((mem_all + mem_budget - 1) / mem_budget, (jobs_all + job_budget - 1) / job_budget));
+        // One batch whenever the device holds it: what the stage needs beside a batch's arrays is bounded -- the tile buffer of the
+        // alignments (48 GB at most, and it doubles as plane 0 of the extended library), the per-workgroup scratch of the merging
+        // (16 GB per class at most), the rows.  (Until the library was stored, a batch could have half of what was free and
+        // bench.py's pipeline workload fitted; with it the half-rule cut that call into 4 batches and the merging's launches, each
+        // as long as its longest group, into 4 rounds: 647 ms against 420.)
+        bool one_batch = false;
+        if (option(OPT_MSA2_BUDGET_GB) <= 0 && option(OPT_MSA2_BATCHES) <= 1 && jobs_all <= job_budget) {
+            const long long plane0 = ext_all / m2_ext_planes(unitw_plan);
+            const long long rows_est = 2 * cells_est;
+            const long long extra = std::max<long long>(48LL << 30, plane0) - plane0 + (48LL << 30) + rows_est + (8LL << 30);
+            one_batch = mem_all + extra <= static_cast<long long>(free_b) + reusable;
+            if (one_batch) nb = 1;
+        }
         const long long want = option(OPT_MSA2_BATCHES) > 0 ? option(OPT_MSA2_BATCHES) : 1;
-        if (std::max(nb, want) > 1) nb = std::max<long long>(want, std::max((2 * mem_all + mem_budget - 1) / mem_budget, (jobs_all + job_budget - 1) / job_budget));
+        if (!one_batch && std::max(nb, want) > 1) nb = std::max<long long>(want, std::max((2 * mem_all + mem_budget - 1) / mem_budget, (jobs_all + job_budget - 1) / job_budget));
         nb = std::min<long long>(nb, static_cast<long long>(todo.size()));
         std::vector<M2Batch> batches(static_cast<size_t>(nb));
         {
@@ -1648,6 +1895,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
             SL_TRY(m2_plan(B, grp_off, grp, rel.data(), gsum.data(), gmx.data(), exact_w, bandwidth));
             m2_host_time("plan", th);
             B.pair_done = MS.pair[k & 1];
+            B.alias_tiles = batches.size() == 1;
             SL_TRY(m2_prepare(B, pfs[k & 1], d_seq, match, mismatch, gap_extension, gap_opening, bandwidth, &cells, first, sp));
             pairs += static_cast<double>(B.njobs);
             if (first && overlap) SL_TRY((*overlap)());

@@ -9,6 +9,6 @@ mkdir -p gpurun_out
 for L in "$@"; do
     if [ "$L" = "-" ]; then unset SARLACC_LIB_PATH; else export SARLACC_LIB_PATH=$PWD/$L; fi
     echo "== $L" >> "$out"
-    timeout -k 10 200 python tools/perf_pipeline_resident.py 100000 2 2 pure 2>&1 | grep -A1 'rep 1' | cut -c1-900 >> "$out" || exit 1
-    timeout -k 10 200 python tools/perf_pipeline_resident.py 100000 2 2 2>&1 | grep -A3 '^rep 1' | grep -v 'stage s\|msa host' | cut -c1-1200 >> "$out" || exit 1
+    timeout -k 10 200 python tools/perf_pipeline_resident.py ${AB_MOLECULES:-100000} 2 2 pure 2>&1 | grep -A1 'rep 1' | cut -c1-900 >> "$out" || exit 1
+    timeout -k 10 200 python tools/perf_pipeline_resident.py ${AB_MOLECULES:-100000} 2 2 2>&1 | grep -A3 '^rep 1' | grep -v 'stage s\|msa host' | cut -c1-1200 >> "$out" || exit 1
 done
