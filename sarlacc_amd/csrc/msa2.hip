@@ -430,12 +430,14 @@ __global__ void __launch_bounds__(64 * M2_EXT_WAVES) k_m2_extend(M2Args A, const
                     if (__ballot(v && !m0)) {   // (same-molecule reads: nearly every triplet names the direct partner)
                         const bool m1 = v && q == q1, m2 = v && q == q2, m3 = v && q == q3;
                         w1 += m1 ? wt : 0u; w2 += m2 ? wt : 0u; w3 += m3 ? wt : 0u;
-                        const bool fresh = v && !m0 && !m1 && !m2 && !m3;   // a position not seen yet: the next free slot, if any
-                        const bool t1 = fresh && nalt == 0, t2 = fresh && nalt == 1, t3 = fresh && nalt == 2;
-                        q1 = t1 ? q : q1; w1 = t1 ? wt : w1;
-                        q2 = t2 ? q : q2; w2 = t2 ? wt : w2;
-                        q3 = t3 ? q : q3; w3 = t3 ? wt : w3;
-                        nalt += (t1 || t2 || t3) ? 1u : 0u;
+                        const bool fresh = v && !m0 && !m1 && !m2 && !m3 && nalt < 3u;   // a position not seen yet and a free slot for it
+                        if (__ballot(fresh)) {   // (among unrelated reads the three slots are taken after three candidates)
+                            const bool t1 = fresh && nalt == 0, t2 = fresh && nalt == 1, t3 = fresh && nalt == 2;
+                            q1 = t1 ? q : q1; w1 = t1 ? wt : w1;
+                            q2 = t2 ? q : q2; w2 = t2 ? wt : w2;
+                            q3 = t3 ? q : q3; w3 = t3 ? wt : w3;
+                            nalt += fresh ? 1u : 0u;
+                        }
                     }
                 }
             }
@@ -562,13 +564,16 @@ __global__ void __launch_bounds__(64) k_m2_extend_unit(M2Args A, int m0, int m1)
                         for (int k = 0; k < 4; ++k) {
                             const bool v = q[k] != M2_NONE && q[k] != q0[k];
                             const bool m1 = v && q[k] == q1[k], m2 = v && q[k] == q2[k], m3 = v && q[k] == q3[k];
-                            const bool fresh = v && !m1 && !m2 && !m3;   // a position not seen yet: the next free slot, if any
-                            const bool t1 = fresh && nalt[k] == 0, t2 = fresh && nalt[k] == 1, t3 = fresh && nalt[k] == 2;
-                            wp[k] += ((m1 || t1) ? 0x100u : 0u) + ((m2 || t2) ? 0x10000u : 0u) + ((m3 || t3) ? 0x1000000u : 0u);
-                            q1[k] = t1 ? q[k] : q1[k];
-                            q2[k] = t2 ? q[k] : q2[k];
-                            q3[k] = t3 ? q[k] : q3[k];
-                            nalt[k] += (t1 || t2 || t3) ? 1u : 0u;
+                            wp[k] += (m1 ? 0x100u : 0u) + (m2 ? 0x10000u : 0u) + (m3 ? 0x1000000u : 0u);
+                            const bool fresh = v && !m1 && !m2 && !m3 && nalt[k] < 3u;   // a position not seen yet and a free slot for it
+                            if (__ballot(fresh)) {
+                                const bool t1 = fresh && nalt[k] == 0, t2 = fresh && nalt[k] == 1, t3 = fresh && nalt[k] == 2;
+                                wp[k] += (t1 ? 0x100u : 0u) + (t2 ? 0x10000u : 0u) + (t3 ? 0x1000000u : 0u);
+                                q1[k] = t1 ? q[k] : q1[k];
+                                q2[k] = t2 ? q[k] : q2[k];
+                                q3[k] = t3 ? q[k] : q3[k];
+                                nalt[k] += fresh ? 1u : 0u;
+                            }
                         }
                     }
                 }
@@ -1581,8 +1586,9 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
                         // (256 positions of up to 64 reads are 32 KB of LDS per wavefront, five wavefronts per CU: the largest groups
                         // go through the one-position-per-lane kernel, 8 KB per wavefront)
                         const unsigned gx1 = std::max(1u, std::min(8u, m2_blocks(B.max_len, 64 * M2_EXT_WAVES)));
+                        const int cn = std::min(cap, std::max(B.max_n, 1));
                         hipLaunchKernelGGL((k_m2_extend<true>), dim3(gx1, static_cast<unsigned>(m1 - m0)), dim3(64 * M2_EXT_WAVES),
-                                           static_cast<size_t>(M2_EXT_WAVES) * std::max(B.max_n, 1) * 128, s, a, d_mg, m0, m1, B.max_n);
+                                           static_cast<size_t>(M2_EXT_WAVES) * cn * 128, s, a, d_mg, m0, m1, cn);
                     } else
                     hipLaunchKernelGGL(k_m2_extend_unit, dim3(gx, static_cast<unsigned>(m1 - m0)), dim3(64), static_cast<size_t>(std::min(cap, std::max(B.max_n, 1))) * 512, s, a, m0, m1);
                 }
