@@ -362,21 +362,37 @@ __global__ void __launch_bounds__(64) k_m2_first(M2Args A) {
 // One wavefront per 64 positions of member m (blockIdx.y = m; the block's 4 wavefronts take 4 consecutive windows, the grid's
 // x extent strides over the read).  gridDim.x = 8 puts the same windows of consecutive members -- the reads of one group, which
 // gather from the same maps -- on the same XCD, i.e. behind the same L2.
+// (What bounds this kernel is the SCALAR unit, one instruction per SIMD every four cycles: the first version took a candidate's
+// map base and length out of the lanes by v_readlane and did its 64-bit address arithmetic, the skip tests and two wave-wide
+// branches per candidate on it -- 31 scalar instructions per gather against 22 vector ones, 0.22 per cycle and SIMD
+// (rocprofv3 --pmc SQ_INSTS_SALU / SQ_INSTS_VALU / SQ_INSTS_VMEM).  Now the members' map addresses and lengths sit in an LDS
+// table read by broadcast, the lanes compute their own addresses, and a batch of eight candidates that all name the direct
+// partner -- the rule among same-molecule reads -- is recognised by ONE wave-wide test.)
+struct __attribute__((aligned(16))) M2XMember {   // LDS: what a lane needs to know about member c
+    const uint16_t* maps;   // its n - 1 position maps
+    const uint8_t* seq;     // its bases
+    int len, pad[3];
+};
 template <bool UNITW>
 __global__ void __launch_bounds__(64 * M2_EXT_WAVES) k_m2_extend(M2Args A, const int* member_group, int m0, int m1, int maxn) {   // members [m0, m1)
     extern __shared__ __align__(16) unsigned char m2_xs[];
     const int m = m0 + static_cast<int>(blockIdx.y);
     if (m >= m1) return;
     const m2_mask F = A.first[m];
-    if (!F) return;
-    const M2Group G = A.groups[member_group[m]];
-    const int n = G.n, fm = G.first_member, a = m - fm;
+    if (!F) return;   // (the whole workgroup: F belongs to the member)
+    const M2Member Ma = A.members[m];
+    const int n = Ma.n, fm = Ma.first_member, a = m - fm;
     const int lane = threadIdx.x & 63;
     const int wave = m2_rfl(static_cast<int>(threadIdx.x >> 6));
-    uint16_t* const s_r = reinterpret_cast<uint16_t*>(m2_xs) + static_cast<size_t>(wave) * maxn * 64 + lane;   // [c * 64]: this wavefront's, this lane's column
-    // the members' descriptors live in the lanes: lane c = member c
-    const M2Member Ml = A.members[fm + min(lane, n - 1)];
-    const M2Member Ma = A.members[m];
+    M2XMember* const s_mem = reinterpret_cast<M2XMember*>(m2_xs);
+    uint16_t* const s_r = reinterpret_cast<uint16_t*>(m2_xs + static_cast<size_t>(maxn) * sizeof(M2XMember)) + static_cast<size_t>(wave) * maxn * 64 + lane;   // [c * 64]: this wavefront's, this lane's column
+    if (threadIdx.x < static_cast<unsigned>(n)) {
+        const M2Member Mc = A.members[fm + threadIdx.x];
+        M2XMember X;
+        X.maps = A.map + Mc.map_base; X.seq = A.seq + Mc.seq_off; X.len = Mc.len; X.pad[0] = X.pad[1] = X.pad[2] = 0;
+        s_mem[threadIdx.x] = X;
+    }
+    __syncthreads();
     const int nwin = (Ma.len + 63) / 64;
     for (int w = blockIdx.x * M2_EXT_WAVES + wave; w < nwin; w += gridDim.x * M2_EXT_WAVES) {
         const int p = w * 64 + lane;
@@ -391,58 +407,66 @@ __global__ void __launch_bounds__(64 * M2_EXT_WAVES) k_m2_extend(M2Args A, const
         if (!UNITW) xa = dna5_code(A.seq[Ma.seq_off + pidx]);
         for (int b = 0; b < n; ++b) {
             if (!((F >> b) & 1ull)) continue;
-            const long long seqb = m2_readlane64(static_cast<m2_u64>(Ml.seq_off), b);
-            const unsigned q0 = s_r[b * 64];
+            const uint8_t* const seqb = s_mem[b].seq;
+            // Comparisons as integer arithmetic in vector registers (a difference is zero where two positions agree; boolean
+            // algebra on lane masks runs on the scalar unit): an invalid candidate is 0xFFFF, an empty slot 0x1FFFF, a missing
+            // direct partner 0x2FFFF -- no two of them equal, none equal to a position.
+            const unsigned q0r = s_r[b * 64];
+            const unsigned q0 = q0r != M2_NONE ? q0r : 0x2FFFFu;
             unsigned w0 = 0;
-            if (q0 != M2_NONE) w0 = UNITW ? 1u : static_cast<unsigned>(m2_w0(xa, dna5_code(A.seq[seqb + q0]), A.ma, A.mm));
-            unsigned q1 = M2_NONE, q2 = M2_NONE, q3 = M2_NONE, w1 = 0, w2 = 0, w3 = 0, nalt = 0;
+            if (q0r != M2_NONE) w0 = UNITW ? 1u : static_cast<unsigned>(m2_w0(xa, dna5_code(seqb[q0r]), A.ma, A.mm));
+            unsigned q1 = 0x1FFFFu, q2 = 0x1FFFFu, q3 = 0x1FFFFu, w1 = 0, w2 = 0, w3 = 0, nalt = 0;
             // the third reads eight at a time: their gathers are requested back to back, then the records updated in order of c
             for (int c0 = 0; c0 < n; c0 += 8) {
                 unsigned qq[8], ri[8];
-                bool hv[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int c = min(c0 + u, n - 1);
-                    const bool use = c0 + u < n && c != a && c != b;
-                    const int lenc = __builtin_amdgcn_readlane(Ml.len, c);
-                    const long long basec = static_cast<long long>(m2_readlane64(static_cast<m2_u64>(Ml.map_base), c)) +
-                                            static_cast<long long>(!use ? 0 : (b < c ? b : b - 1)) * lenc;
-                    const unsigned r = s_r[c * 64];
-                    hv[u] = use && r != M2_NONE;
-                    ri[u] = hv[u] ? r : 0u;
-                    qq[u] = A.map[basec + ri[u]];
+                    const bool use = c0 + u < n && c != a && c != b;   // (wave-uniform)
+                    const M2XMember X = s_mem[c];   // (one broadcast read)
+                    const unsigned r = use ? s_r[c * 64] : M2_NONE;
+                    ri[u] = r;
+                    const unsigned off = static_cast<unsigned>(c == b ? 0 : (b < c ? b : b - 1)) * static_cast<unsigned>(X.len) + min(r, static_cast<unsigned>(max(X.len - 1, 0)));
+                    const unsigned q = X.maps[off];   // (a gap reads the last entry of a valid map)
+                    qq[u] = r != M2_NONE ? q : M2_NONE;
+                }
+                unsigned other = 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) other |= (qq[u] ^ M2_NONE) ? (qq[u] ^ q0) : 0u;   // nonzero: a valid candidate that is not the direct partner
+                if (UNITW && !__ballot(other != 0u)) {   // every triplet of the batch names the direct partner (or nothing)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) w0 += qq[u] != M2_NONE ? 1u : 0u;
+                    continue;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const unsigned q = qq[u];
-                    const bool v = hv[u] && q != M2_NONE;
                     unsigned wt = 1;
                     if (!UNITW) {
+                        const bool v = q != M2_NONE;
                         const int c = min(c0 + u, n - 1);
-                        const long long seqc = m2_readlane64(static_cast<m2_u64>(Ml.seq_off), c);
-                        const int xc = dna5_code(A.seq[seqc + ri[u]]);
-                        const int xb = dna5_code(A.seq[seqb + (v ? q : 0u)]);
+                        const int xc = dna5_code(s_mem[c].seq[v ? ri[u] : 0u]);
+                        const int xb = dna5_code(seqb[v ? q : 0u]);
                         const int wac = m2_w0(xa, xc, A.ma, A.mm), wcb = m2_w0(xc, xb, A.ma, A.mm);
                         wt = static_cast<unsigned>(wac < wcb ? wac : wcb);
                     }
-                    const bool m0 = v && q == q0;
-                    w0 += m0 ? wt : 0u;
-                    if (__ballot(v && !m0)) {   // (same-molecule reads: nearly every triplet names the direct partner)
-                        const bool m1 = v && q == q1, m2 = v && q == q2, m3 = v && q == q3;
-                        w1 += m1 ? wt : 0u; w2 += m2 ? wt : 0u; w3 += m3 ? wt : 0u;
-                        const bool fresh = v && !m0 && !m1 && !m2 && !m3 && nalt < 3u;   // a position not seen yet and a free slot for it
-                        if (__ballot(fresh)) {   // (among unrelated reads the three slots are taken after three candidates)
-                            const bool t1 = fresh && nalt == 0, t2 = fresh && nalt == 1, t3 = fresh && nalt == 2;
-                            q1 = t1 ? q : q1; w1 = t1 ? wt : w1;
-                            q2 = t2 ? q : q2; w2 = t2 ? wt : w2;
-                            q3 = t3 ? q : q3; w3 = t3 ? wt : w3;
-                            nalt += fresh ? 1u : 0u;
-                        }
+                    const unsigned x0 = q ^ q0, x1 = q ^ q1, x2 = q ^ q2, x3 = q ^ q3;
+                    w0 += x0 == 0u ? wt : 0u; w1 += x1 == 0u ? wt : 0u; w2 += x2 == 0u ? wt : 0u; w3 += x3 == 0u ? wt : 0u;
+                    // nonzero: a position not seen yet (no slot agrees, the candidate is valid) and a free slot for it
+                    const unsigned fresh = min(min(min(x0, x1), min(x2, x3)), min(q ^ M2_NONE, 3u - nalt));
+                    if (__ballot(fresh != 0u)) {   // (among unrelated reads the three slots are taken after three candidates)
+                        const bool f = fresh != 0u;
+                        const bool t1 = f && nalt == 0, t2 = f && nalt == 1, t3 = f && nalt == 2;
+                        q1 = t1 ? q : q1; w1 = t1 ? wt : w1;
+                        q2 = t2 ? q : q2; w2 = t2 ? wt : w2;
+                        q3 = t3 ? q : q3; w3 = t3 ? wt : w3;
+                        nalt += f ? 1u : 0u;
                     }
                 }
             }
+            q1 &= 0xffffu; q2 &= 0xffffu; q3 &= 0xffffu;   // (an empty slot leaves as 0xFFFF)
             if (in) {
-                uint32_t* const E = A.ext + G.ext_base + m2_pair_index(a, b, n) * G.lmax + p;
+                uint32_t* const E = A.ext + Ma.ext_base + m2_pair_index(a, b, n) * Ma.lmax + p;
                 if (UNITW) {
                     E[0] = w0 | (nalt << 6) | (w1 << 8) | (q1 << 16);
                     if (nalt >= 2) E[A.ext_off1] = w2 | (q2 << 16);
@@ -1569,39 +1593,37 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
             a.ext_off1 = B.ext_n;
         }
         hipLaunchKernelGGL(k_m2_first, dim3(static_cast<unsigned>(ng)), dim3(64), 0, s, a);
-        if (unitw && !option(OPT_MSA2_SIMPLE_EXTEND)) {
-            // (the LDS of a wavefront holds a window of 256 positions of every read of its group, 512 B each: one launch per size class,
-            // so that the few large groups do not set the occupancy of the many small ones -- the batch is ordered by decreasing size)
-            const unsigned gx = std::max(1u, std::min(8u, m2_blocks(B.max_len, 256)));
-            size_t q = 0;
-            for (const int cap : {M2_MAXN, 24, 12}) {
-                const int lower = cap == M2_MAXN ? 24 : (cap == 24 ? 12 : 0);   // this launch: groups of lower < n <= cap
-                size_t q1 = q;
-                while (q1 < ng && B.groups[q1].n > lower) ++q1;
-                if (q1 > q) {
-                    const int m0 = B.groups[q].first_member, m1 = B.groups[q1 - 1].first_member + B.groups[q1 - 1].n;
-                    // (msa2_wide_extend = largest group size that takes the four-positions kernel; default 12)
-                    const int wide_max = option(OPT_MSA2_WIDE_EXTEND) > 0 ? option(OPT_MSA2_WIDE_EXTEND) : 12;
-                    if (cap > wide_max) {
-                        // (256 positions of up to 64 reads are 32 KB of LDS per wavefront, five wavefronts per CU: the largest groups
-                        // go through the one-position-per-lane kernel, 8 KB per wavefront)
-                        const unsigned gx1 = std::max(1u, std::min(8u, m2_blocks(B.max_len, 64 * M2_EXT_WAVES)));
-                        const int cn = std::min(cap, std::max(B.max_n, 1));
-                        hipLaunchKernelGGL((k_m2_extend<true>), dim3(gx1, static_cast<unsigned>(m1 - m0)), dim3(64 * M2_EXT_WAVES),
-                                           static_cast<size_t>(M2_EXT_WAVES) * cn * 128, s, a, d_mg, m0, m1, cn);
-                    } else
-                    hipLaunchKernelGGL(k_m2_extend_unit, dim3(gx, static_cast<unsigned>(m1 - m0)), dim3(64), static_cast<size_t>(std::min(cap, std::max(B.max_n, 1))) * 512, s, a, m0, m1);
-                }
-                q = q1;
-            }
-        } else {
-            const unsigned gx = std::max(1u, std::min(8u, m2_blocks(B.max_len, 64 * M2_EXT_WAVES)));
-            const size_t lds = static_cast<size_t>(M2_EXT_WAVES) * std::max(B.max_n, 1) * 128;
-            if (unitw) hipLaunchKernelGGL((k_m2_extend<true>), dim3(gx, static_cast<unsigned>(nm)), dim3(64 * M2_EXT_WAVES), lds, s, a, d_mg, 0, static_cast<int>(nm), B.max_n);
-            else hipLaunchKernelGGL((k_m2_extend<false>), dim3(gx, static_cast<unsigned>(nm)), dim3(64 * M2_EXT_WAVES), lds, s, a, d_mg, 0, static_cast<int>(nm), B.max_n);
-        }
         SL_HIP(hipGetLastError());
     }
+    // One launch of the extension per size class (the batch is ordered by decreasing size): groups of up to 12 reads through the
+    // four-positions kernel (unit weights; 6 KB of LDS per wavefront), larger ones through the one-position kernel (256 positions
+    // of 64 reads would be 32 KB per wavefront, five wavefronts per CU; msa2_wide_extend moves the limit, msa2_simple_extend sends
+    // everything through the one-position kernel).  The class of more than 24 reads goes first: its groups' merging -- the longest
+    // launches of the stage, a few workgroups waiting for memory -- then runs UNDER the extension of the other classes.
+    auto ext_class = [&](int cap) -> int {
+        if (B.ext_n <= 0) return 0;
+        const int lower = cap == M2_MAXN ? 24 : (cap == 24 ? 12 : 0);   // this launch: groups of lower < n <= cap
+        size_t q = 0, q1;
+        while (q < ng && B.groups[q].n > cap) ++q;
+        q1 = q;
+        while (q1 < ng && B.groups[q1].n > lower && B.groups[q1].n >= 2) ++q1;
+        if (q1 == q) return 0;
+        const int m0 = B.groups[q].first_member, m1 = B.groups[q1 - 1].first_member + B.groups[q1 - 1].n;
+        const int wide_max = !unitw || option(OPT_MSA2_SIMPLE_EXTEND) ? 0 : (option(OPT_MSA2_WIDE_EXTEND) > 0 ? option(OPT_MSA2_WIDE_EXTEND) : 12);
+        const int cn = std::min(cap, std::max(B.max_n, 1));
+        if (cap > wide_max) {
+            const unsigned gx1 = std::max(1u, std::min(8u, m2_blocks(B.max_len, 64 * M2_EXT_WAVES)));
+            const size_t lds = static_cast<size_t>(M2_EXT_WAVES) * cn * 128 + static_cast<size_t>(cn) * sizeof(M2XMember);
+            if (unitw) hipLaunchKernelGGL((k_m2_extend<true>), dim3(gx1, static_cast<unsigned>(m1 - m0)), dim3(64 * M2_EXT_WAVES), lds, s, a, d_mg, m0, m1, cn);
+            else hipLaunchKernelGGL((k_m2_extend<false>), dim3(gx1, static_cast<unsigned>(m1 - m0)), dim3(64 * M2_EXT_WAVES), lds, s, a, d_mg, m0, m1, cn);
+        } else {
+            const unsigned gx = std::max(1u, std::min(8u, m2_blocks(B.max_len, 256)));
+            hipLaunchKernelGGL(k_m2_extend_unit, dim3(gx, static_cast<unsigned>(m1 - m0)), dim3(64), static_cast<size_t>(cn) * 512, s, a, m0, m1);
+        }
+        SL_HIP(hipGetLastError());
+        return 0;
+    };
+    SL_TRY(ext_class(M2_MAXN));
     // ---- progressive merging: every join of every group in ONE round of launches ----
     // Groups are ordered by decreasing size.  A group is merged by one workgroup: one wavefront for the bulk (up to M2_NB reads),
     // 8 wavefronts up to 32 reads -- the cost of a group grows with the cube of its size, and the longest group sets the length of
@@ -1626,6 +1648,10 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
         struct Cls { size_t lo, hi; int nw; const char* tag; int stream; };   // stream: index into MS.st (2 is the alignments' own), -1 = s
         const Cls cls[3] = {{0, iD, M2_NWD, ".d", 3}, {iD, iC, 8, ".c", 0}, {iC, nmulti, 1, ".a", -1}};
         for (int k = 0; k < 3; ++k) {
+            if (k == 2) {   // (the side streams have their launches; the caller's stream goes on with the library of the smaller groups)
+                SL_TRY(ext_class(24));
+                SL_TRY(ext_class(12));
+            }
             if (cls[k].lo >= cls[k].hi) continue;
             // scratch of a resident workgroup: as wide as the widest profile capacity of the class
             int class_wcap = 1;
