@@ -723,27 +723,30 @@ def main():
                             "traffic": pm["traffic"], "traffic_source": pm["traffic_source"], "pmc": pm.get("derived"),
                             "algorithmic_bytes": msa_alg_bytes, "traffic_ratio": pm["traffic"] / msa_alg_bytes if pm["traffic"] else None}
             pc = pmc_record("k_consensus_code", ["consensus.hip", "msa_common.hpp"])
-            # k_m2_group, the merge stage of spec v2.  Algorithmic bytes: both position maps of every pair read
-            # once (2 B per base of either read), the columns of every base written once (4 B), the profiles' positions (2 B per cell
-            # of the final alignment) and the rows out as vote codes (2 B per cell).  What bounds it is the request rate of its small
-            # gathers, not the bytes: second entry, wave-wide gather instructions of the library walk against one per 16 cycles and CU
-            # (a wave64 dword gather occupies the address unit for 16 cycles).
+            # The merge stage of spec v2: k_m2_extend* (the extended library, once per group) + k_m2_group (the
+            # progressive merging).  Algorithmic bytes: both position maps of every pair read once (2 B per base of either read), plane 0
+            # of the library written once and read once (4 B per pair and base of its first-child read, twice; the further planes are
+            # touched only where a base has several partners), the columns of every base written once (4 B), the profiles' positions
+            # (2 B per cell of the final alignment) and the rows out as vote codes (2 B per cell).  The merging itself is bound by the
+            # round trips of its small gathers, not the bytes: second entry, wave-wide gather instructions of its rows phase against
+            # one per 16 cycles and CU (a wave64 dword gather occupies the address unit for 16 cycles).
             gsz = np.diff(last["goff"]).astype(np.float64)
             gbases = np.add.reduceat(np.diff(off_host)[last["gflat"].astype(np.int64) - 1], last["goff"][:-1]).astype(np.float64) if gsz.size else np.zeros(0)
-            m2_alg_bytes = float((2.0 * (gsz - 1.0) * gbases * 2.0).sum() + 4.0 * gbases.sum() + 4.0 * cnt["consensus_cells"])
+            m2_alg_bytes = float((2.0 * (gsz - 1.0) * gbases * 2.0).sum() + (0.5 * (gsz - 1.0) * gbases * 4.0 * 2.0).sum()
+                                 + 4.0 * gbases.sum() + 4.0 * cnt["consensus_cells"])
             pg = pmc_record("k_m2_group", ["msa2.hip", "msa_common.hpp"])
             mg_s = kms["msa_merge"] * 1e-3
             gather_peak = 256 * 2.4e9 / 16.0
             cyc = {k: cnt.get("msa2_cycles_" + k, 0.0) for k in ("rows", "chain", "walk", "renumber")}
             cyc_all = sum(cyc.values()) or 1.0
-            m2_roof = {"bound": "hbm", "kernel": "k_m2_group (1-, 4- and 8-wavefront instantiations side by side) + k_m2_tree / k_m2_tables / k_m2_init",
+            m2_roof = {"bound": "hbm", "kernel": "k_m2_first + k_m2_extend / k_m2_extend_unit (extended library) + k_m2_group (1-, 4- and 8-wavefront instantiations side by side) + k_m2_tree / k_m2_init",
                        "achieved": m2_alg_bytes / mg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": m2_alg_bytes / mg_s / 1e9 / HBM_PEAK_GBS,
                        "algorithmic_bytes": m2_alg_bytes, "traffic": pg["traffic"], "traffic_source": pg["traffic_source"], "pmc": pg.get("derived"),
                        "traffic_ratio": pg["traffic"] / m2_alg_bytes if pg["traffic"] else None,
                        "gather_issue": {"bound": "gather request rate", "achieved": cnt.get("msa2_gathers", 0.0) / mg_s, "peak": gather_peak,
                                         "unit": "wave-wide gathers/s", "frac": cnt.get("msa2_gathers", 0.0) / mg_s / gather_peak,
                                         "gathers": cnt.get("msa2_gathers", 0.0),
-                                        "note": "library walk only (rows phase); one wave64 gather per 16 cycles and CU x 256 CUs x 2.4 GHz"},
+                                        "note": "rows phase of k_m2_group only, a lower bound (records with several partners gather more); one wave64 gather per 16 cycles and CU x 256 CUs x 2.4 GHz"},
                        "phase_share_of_wavefront_cycles": {k: v / cyc_all for k, v in cyc.items()},
                        "groups_second_pass": cnt.get("msa2_groups_second_pass", 0.0), "batches": cnt.get("msa2_batches", 1.0)}
             if cnt.get("msa2_batches", 1.0) > 1.0:   # (pipelined batches: the alignments of batch k + 1 run under the merging of batch k)

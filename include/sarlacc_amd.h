@@ -309,7 +309,8 @@ int sarlacc_dev_umi_group_from_pairs(const char* umi, const int64_t* off, int64_
 
 /* Which written specification the MSA stage follows (the reference delegates to SeqAn's
  * T-Coffee, which cannot be run or pinned here): 2 (default) = consistency-based progressive alignment --
- * all-pairs banded alignments, primary library, triplet extension, neighbour-joining guide tree, progressive
+ * all-pairs banded alignments, primary library, triplet extension into a bounded library (the direct partner and three
+ * further positions per pair and base), neighbour-joining guide tree, progressive
  * heaviest-common-subsequence merging -- for groups of up to 64 reads, 1 = centre-star (also used by spec 2 for
  * larger groups, for reads beyond 65 471 bases and for alignments wider than 65 535 columns).  0 restores the default, spec 2 (SARLACC_MSA_SPEC only sets the
  * value the process starts with: the environment is read once). */
@@ -323,7 +324,10 @@ int sarlacc_set_msa_spec(int spec);
  *   "msa_int32", "msa_affine", "msa_bitvector" (-1 never, 2 one kernel for fill and walk), "msa_bitvector_core" (-1 whole
  *   records, 1 one word), "msa_bitvector_tile_gb" (GB), "umi_full_rounds", "umi_tile_search", "umi_split_min" (a set size),
  *   "umi_scan_single", "align_wide_barrier" (references beyond 1 024 columns: the kernel with a barrier per step everywhere),
- *   "align_wide_band" (rows either side of the main diagonal whose cells carry traceback codes in k_align_wide_q's first launch; -1: all).
+ *   "align_wide_band" (rows either side of the main diagonal whose cells carry traceback codes in k_align_wide_q's first launch; -1: all),
+ *   "msa2_budget_gb" (GB a batch of groups may take), "msa2_max_columns" (a lower ceiling of spec v2's profiles),
+ *   "msa2_simple_extend" (the extended library by the one-position-per-lane kernel everywhere), "msa2_wide_extend" (largest
+ *   group size of the four-positions-per-lane kernel).
  * The environment (SARLACC_<NAME>) is read once, when the first option is asked for; afterwards only this call changes a
  * value.  Nothing in the reference corresponds. */
 int sarlacc_set_option(const char* name, int value);

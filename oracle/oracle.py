@@ -346,7 +346,7 @@ def msa2_set_library(others=3):
 
 
 def msa2_stats(reset=True):
-    """Counters of spec v2's library walk since the last reset (names: MSA2_STAT_NAMES)."""
+    """Counters of spec v2's library and rows since the last reset (names: MSA2_STAT_NAMES)."""
     buf = np.zeros(len(MSA2_STAT_NAMES), np.int64)
     lib().orc_msa2_stats(_p(buf), C.c_int64(buf.size), int(bool(reset)))
     return dict(zip(MSA2_STAT_NAMES, buf.tolist()))

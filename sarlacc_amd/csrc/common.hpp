@@ -39,7 +39,7 @@ int fail(const char* fmt, ...);
 // through sarlacc_set_option -- no kernel launch path evaluates the environment.
 enum Opt {
     OPT_MSA_SPEC,             // 1: centre-star, 2: consistency-based progressive (0 = default = 2)
-    OPT_MSA2_GENERAL_ROWS,    // spec v2: the library walk by the any-weights code also for unit weights
+    OPT_MSA2_GENERAL_ROWS,    // spec v2: the any-weights records and row lists also for unit weights
     OPT_MSA2_CHAIN_HBM,       // spec v2: the chain's prefix maxima in HBM from the start (the fallback of the LDS ring)
     OPT_MSA2_WAVES_PER_CU,    // spec v2: resident wavefronts of the merge kernel per CU (perf sweeps)
     OPT_MSA2_SINGLE_WAVE,     // spec v2: one wavefront per group whatever its size (A/B of the 4- and 8-wavefront workgroups)
@@ -66,7 +66,7 @@ enum Opt {
     OPT_MSA2_MAX_COLUMNS,     // spec v2: alignments wider than this go to spec v1 (default and maximum 65535: 16-bit columns; tests lower it)
     OPT_ALIGN_WIDE_BAND,      // k_align_wide_q with traceback: rows either side of the main diagonal that carry codes in the first launch (default 96; -1: every cell)
     OPT_MSA2_SIMPLE_EXTEND,   // spec v2: the extended library by the one-position-per-lane kernel also for unit weights (A/B, tests)
-    OPT_MSA2_WIDE_EXTEND,     // spec v2: the four-positions-per-lane extension kernel also for groups of more than 24 reads (A/B)
+    OPT_MSA2_WIDE_EXTEND,     // spec v2: largest group size that takes the four-positions-per-lane extension kernel (default 12; A/B)
     OPT_N
 };
 int option(Opt o);

@@ -96,7 +96,7 @@ struct M2Group {
 
 // counters of one call (sarlacc_stage_count): how often spec v2's own rules act, and the chain's fallback
 enum { M2C_ROWS, M2C_ROWS_CAPPED, M2C_ENT_FILTERED, M2C_ROWS_FILTERED, M2C_ENT_KEPT, M2C_JOINS, M2C_JOINS_HBMQ,
-       M2C_GATHERS,   // wave-wide gather instructions of the library walk (positions, maps, columns): its request-rate roofline
+       M2C_GATHERS,   // wave-wide gather instructions of the rows phase (positions, map entries, records, columns): a lower bound
        // where the wavefronts' time goes (s_memtime cycles summed over the wavefronts) and when they leave (s_memrealtime, 100 MHz)
        M2C_CYC_ROWS, M2C_CYC_CHAIN, M2C_CYC_WALK, M2C_CYC_RENUMBER, M2C_T_START, M2C_T_FIRST_EXIT, M2C_T_LAST_EXIT,
        M2C_T_EXIT1, M2C_T_EXIT4, M2C_T_EXIT8,   // last exit of the instantiations: one wavefront per group / groups of 33 .. 64 reads / 8 wavefronts
@@ -1549,7 +1549,7 @@ static int m2_prepare(M2Batch& B, const std::string& pf, const uint8_t* d_seq, d
     return 0;
 }
 
-// Second half: guide trees, candidate tables, all the merging, widths back to the host -- on stream `s` (and the streams of
+// Second half: guide trees, the extended library, all the merging, widths back to the host -- on stream `s` (and the streams of
 // the side-by-side instantiations) once the batch's alignments are done.
 static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStream_t s) {
     Context& c = ctx();
@@ -1560,7 +1560,7 @@ static int m2_merge(M2Batch& B, const std::string& pf, double* counters, hipStre
     int32_t* const d_width = a.width;
     int* const d_ovf = a.ovf;
     SL_HIP(hipStreamWaitEvent(s, B.pair_done, 0));
-    // ---- guide trees, leaves, candidate tables ----
+    // ---- guide trees, leaves ----
     SL_TRY(c.stage_begin("msa_merge", s));
     hipLaunchKernelGGL(k_m2_tree, dim3(static_cast<unsigned>(ng)), dim3(64), 0, s, a);
     if (nm) hipLaunchKernelGGL(k_m2_init, dim3(std::min(2u, std::max(1u, m2_blocks(B.max_len, 256))), static_cast<unsigned>(nm)), dim3(256), 0, s, a, d_mg, static_cast<int>(nm));
@@ -1785,7 +1785,7 @@ static int msa2_core(const int64_t* grp_off, const int32_t* grp, const std::vect
         return 0;
     };
     // Batches.  What a batch holds per group is the library (both maps of every pair: 4 (n - 1) bytes per base), the positions /
-    // columns of its profiles and, with unit weights, its candidate tables -- about 60 GB for C4 (10^5 groups x 10 reads
+    // columns of its profiles and the extended library (12 or 16 bytes per pair and position) -- about 165 GB for C4 (10^5 groups x 10 reads
     // x 2 kb), sized for an HBM of 288 GB and bounded by a share of what is free now.  A large call is cut into a few
     // batches that are PIPELINED: the all-pairs alignments of batch k + 1 (vector-unit bound) run on a stream of their
     // own under the merging of batch k (memory-latency bound); two sets of workspaces alternate.

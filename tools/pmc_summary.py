@@ -143,7 +143,7 @@ def main():
             res["traffic_correction"] = "2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports half the bytes read), summed over the stage's launches"
     if kernel == "k_m2_group":
         # The merge stage of spec v2 is up to four instantiations of k_m2_group side by side (1, 4, 8 wavefronts per group) plus
-        # k_m2_tree / k_m2_init / k_m2_tables: its traffic is the sum over all of them, per stage (a stage starts with its k_m2_tree).
+        # k_m2_tree / k_m2_init / k_m2_first / k_m2_extend*: its traffic is the sum over all of them, per stage (a stage starts with its k_m2_tree).
         def stages(sub, counter):
             per = {}
             for r in counter_rows(os.path.join(out_dir, sub)):
@@ -165,7 +165,7 @@ def main():
             res["write_bytes_per_stage"] = sum(bw) / len(bw) * 1024.0
             res["traffic_bytes_per_launch"] = res["fetch_bytes_per_stage"] + res["write_bytes_per_stage"]
             res["traffic_bytes_per_stage_all"] = [(2.0 * a + b) * 1024.0 for a, b in zip(sf, sw)]
-            res["traffic_scope"] = ("one merge stage = k_m2_tree + k_m2_init + k_m2_tables + every instantiation of k_m2_group of one call; mean over "
+            res["traffic_scope"] = ("one merge stage = k_m2_tree + k_m2_init + k_m2_first + the launches of k_m2_extend / k_m2_extend_unit + every instantiation of k_m2_group of one call; mean over "
                                     "the %d stages on the pipeline's clusters (of %d: the pure groups of configs[3] are listed in traffic_bytes_per_stage_all)"
                                     % (len(bf), len(sf)))
             res["traffic_correction"] = "2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports half the bytes read), summed over the stage's launches"
