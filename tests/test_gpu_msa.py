@@ -374,8 +374,9 @@ def test_msa_spec2_many_groups_one_launch(oracle, ngroups):
 def test_msa_spec2_code_paths_agree(oracle):
     """Unit weights take the extension kernel with four positions per lane and packed row lists and keep the chain's prefix
     maxima in an LDS ring, in workgroups of 1, 4 or 8 wavefronts by group size; the options msa2_general_rows /
-    msa2_simple_extend / msa2_chain_hbm / msa2_single_wave send the same call through the any-weights records and lists,
-    through the one-position-per-lane extension kernel, through the chain's fallback (prefix maxima over all columns in HBM)
+    msa2_simple_extend / msa2_wide_extend = 64 / msa2_chain_hbm / msa2_single_wave send the same call through the any-weights
+    records and lists, through the one-position-per-lane extension kernel for every group, through the four-positions kernel for
+    every group (by default: up to 12 reads), through the chain's fallback (prefix maxima over all columns in HBM)
     and through one wavefront per group;
     msa2_batches = 3 cuts the call into three pipelined batches (alignments of batch k + 1 under the merging of batch k).  Rows must be identical, and those of the CPU
     statement, on ordinary clusters, on clusters of two and three molecules and on groups of very different sizes in one
@@ -397,7 +398,7 @@ def test_msa_spec2_code_paths_agree(oracle):
         for params in [(0, -1, -5, -1, 100), (1, -2, -2, -2, 20)]:
             new = calls.quick_msa(groups, reads, *params)
             assert new == oracle.quick_msa(groups, reads, *params, spec=2)
-            for opt, val in (("msa2_general_rows", 1), ("msa2_simple_extend", 1), ("msa2_chain_hbm", 1), ("msa2_single_wave", 1), ("msa2_batches", 3), ("msa_bitvector", -1)):
+            for opt, val in (("msa2_general_rows", 1), ("msa2_simple_extend", 1), ("msa2_wide_extend", 64), ("msa2_chain_hbm", 1), ("msa2_single_wave", 1), ("msa2_batches", 3), ("msa_bitvector", -1)):
                 calls.set_option(opt, val)
                 try:
                     other = calls.quick_msa(groups, reads, *params)

@@ -234,10 +234,10 @@ def case_msa(rng):
     params = [(0, -1, -5, -1), (0, -1, -1, -5), (1, -2, -2, -2), (2, -3, -1, -4), (0, -1, -1, -1)][int(rng.integers(0, 5))]
     bw = int(rng.choice([0, 3, 20, 100, 180, 600, 5000]))
     spec = int(rng.choice([1, 2, 2, 2]))
-    opts = [o for o in ("msa2_general_rows", "msa2_chain_hbm", "msa2_single_wave", "msa2_batches") if rng.random() < 0.15]   # the other code paths of spec v2
+    opts = [o for o in ("msa2_general_rows", "msa2_chain_hbm", "msa2_single_wave", "msa2_batches", "msa2_simple_extend", "msa2_wide_extend") if rng.random() < 0.15]   # the other code paths of spec v2
     calls.set_msa_spec(spec)
     for o_ in opts:
-        calls.set_option(o_, 3 if o_ == "msa2_batches" else 1)
+        calls.set_option(o_, 3 if o_ == "msa2_batches" else (64 if o_ == "msa2_wide_extend" else 1))   # (msa2_wide_extend = 64: the four-positions kernel for every group size)
     try:
         g, o, err = both(lambda: calls.quick_msa(groups, reads, *params, bw), lambda: O.quick_msa(groups, reads, *params, bw, spec=spec))
     finally:
