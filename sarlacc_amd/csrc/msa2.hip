@@ -766,9 +766,20 @@ __device__ __forceinline__ int m2_rows_ext(const M2Args& A, const M2Group& G, co
         int cnt = 0;
         bool capped = false;
         const bool row = i < nA;
-        for (int a = 0; a < n; ++a) {
-            if (!((J.maskA >> a) & 1)) continue;
-            const unsigned p = row ? A.pos[G.pos_base + static_cast<long long>(a) * G.wcap + i] : M2_NONE;
+        // the first child's members in ascending order; the positions of the NEXT member are requested before this one's pairs
+        MASK restA = J.maskA;
+        int a_next = m2_ctz(restA);
+        restA &= restA - 1;
+        unsigned p_next = row ? A.pos[G.pos_base + static_cast<long long>(a_next) * G.wcap + i] : M2_NONE;
+        for (bool more_a = true; more_a;) {
+            const int a = a_next;
+            const unsigned p = p_next;
+            more_a = restA != 0;
+            if (more_a) {
+                a_next = m2_ctz(restA);
+                restA &= restA - 1;
+                p_next = row ? A.pos[G.pos_base + static_cast<long long>(a_next) * G.wcap + i] : M2_NONE;
+            }
             const bool havep = p != M2_NONE;
             if (!__ballot(havep)) continue;
             const M2Member Ma = A.members[fm + a];
@@ -1031,18 +1042,26 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
     for (int j = tid; j < nB; j += NT) pb[j] = -1;
     __threadfence_block();
     __syncthreads();
-    for (int i = tid; i < nA; i += NT) {
-        const int pj = part[i];
-        if (pj >= 0) pb[pj] = i;
+    for (int i0 = tid; i0 < nA; i0 += 4 * NT) {   // (four loads in flight; see the scatter below)
+        int pj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pj[u] = i0 + u * NT < nA ? part[i0 + u * NT] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (pj[u] >= 0) pb[pj[u]] = i0 + u * NT;
     }
     __threadfence_block();
     __syncthreads();
     if (wave == 0) {
         // first child: column i -> i + (columns of the second child up to the previous matched partner) - matches before
+        // (in the three scans the NEXT block's entry is requested before this block's is used: the running values -- matches so
+        // far, last partner -- chain the blocks, the loads need not wait for them)
         int jprev = -1, t0 = 0;
+        int pj_next = lane < nA ? part[lane] : -1;
         for (int i0 = 0; i0 < nA; i0 += 64) {
             const int i = i0 + lane;
-            const int pj = i < nA ? part[i] : -1;
+            const int pj = pj_next;
+            pj_next = i + 64 < nA ? part[i + 64] : -1;
             const unsigned long long ball = __ballot(pj >= 0);
             const int before = __popcll(ball & ((1ull << lane) - 1ull));
             const int pm = max(m2_excl_max(pj, -1), jprev);
@@ -1054,9 +1073,12 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
         const int nm = t0;
         // second child: column j -> (row of the next matched pair, or nA) + j - matches before; descending for "next"
         int inext = nA;
-        for (int j0 = ((nB - 1) / 64) * 64; j0 >= 0 && nB > 0; j0 -= 64) {
+        const int jtop = ((nB - 1) / 64) * 64;
+        int pi_next = (nB > 0 && jtop + 63 - lane < nB) ? pb[jtop + 63 - lane] : -1;
+        for (int j0 = jtop; j0 >= 0 && nB > 0; j0 -= 64) {
             const int j = j0 + 63 - lane;     // (descending over the lanes: "at or after j" is a prefix)
-            const int pi = j < nB ? pb[j] : -1;
+            const int pi = pi_next;
+            pi_next = j0 >= 64 ? pb[j - 64] : -1;   // (a full block: every lane inside)
             const int sc = m2_scan_i32<2>(pi >= 0 ? pi : 0x7fffffff, 0x7fffffff);
             if (j < nB) ncb[j] = min(sc, inext);          // provisional: the row of the next matched pair at or after j
             inext = min(inext, __builtin_amdgcn_readlane(sc, 63));
@@ -1064,12 +1086,15 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
         __threadfence_block();
         __builtin_amdgcn_wave_barrier();
         int tb = 0;
+        int pi2_next = lane < nB ? pb[lane] : -1, nc_next = lane < nB ? ncb[lane] : 0;
         for (int j0 = 0; j0 < nB; j0 += 64) {
             const int j = j0 + lane;
-            const int pi = j < nB ? pb[j] : -1;
+            const int pi = pi2_next, ncj = nc_next;
+            pi2_next = j + 64 < nB ? pb[j + 64] : -1;
+            nc_next = j + 64 < nB ? ncb[j + 64] : 0;
             const unsigned long long ball = __ballot(pi >= 0);
             const int before = tb + __popcll(ball & ((1ull << lane) - 1ull));
-            if (j < nB) ncb[j] = ncb[j] + j - before;   // matched: next = its own row
+            if (j < nB) ncb[j] = ncj + j - before;   // matched: next = its own row
             tb += __popcll(ball);
         }
         if (lane == 0) *s_newW = nA + nB - nm;
@@ -1093,10 +1118,23 @@ __device__ __forceinline__ int m2_renumber(const M2Args& A, const M2Group& G, co
         const M2Member Me = A.members[fm + a];
         const int* nc = inA ? nca : ncb;
         uint16_t* row = A.pos + G.pos_base + static_cast<long long>(a) * G.wcap;
-        for (int p = tid; p < Me.len; p += NT) {
-            const int c = nc[A.col[Me.col_base + p]];
-            A.col[Me.col_base + p] = static_cast<uint16_t>(c);
-            row[c] = static_cast<uint16_t>(p);
+        // (four independent lookups in flight: col -> new number is a chain of two round trips, and one position per trip left the
+        // wavefront waiting through len / 64 of them per member)
+        for (int p0 = tid; p0 < Me.len; p0 += 4 * NT) {
+            unsigned oc[4];
+            int c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) oc[u] = A.col[Me.col_base + min(p0 + u * NT, Me.len - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = nc[oc[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + u * NT;
+                if (p < Me.len) {
+                    A.col[Me.col_base + p] = static_cast<uint16_t>(c[u]);
+                    row[c[u]] = static_cast<uint16_t>(p);
+                }
+            }
         }
     }
     __threadfence_block();
