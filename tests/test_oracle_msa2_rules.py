@@ -1,8 +1,8 @@
-"""The two own rules of MSA spec v2, step 5 -- the row cap of 16 partner columns and the noise
-filter -- bounded on the CPU statement of the spec (oracle/msa2.c carries switches for them and counters of how often
+"""The own rules of MSA spec v2, step 5 -- the bounded library (the direct partner and three further
+positions per pair and base), the row cap of 16 partner columns and the noise filter -- bounded on the CPU statement of the spec (oracle/msa2.c carries switches for them and counters of how often
 they act).  PARITY WITH THE REFERENCE IS UNPINNED for this stage (SeqAn is absent, the reference never tests quick_msa);
 what can be pinned is what our own departures from SeqAn's pipeline change.  tools/msa2_rules.py is the long version
-(C4-shaped clusters, five seeds; profiles/r03_msa2_rules_v1.txt)."""
+(C4-shaped clusters, five seeds; profiles/r05_msa2_rules_v2.txt)."""
 import numpy as np
 import pytest
 
@@ -75,3 +75,33 @@ def test_rules_on_clusters_of_two_molecules_and_on_hard_clusters(oracle, seed):
     assert st["rows_capped"] == 0
     free, _ = run(oracle, reads, groups, True, True)
     assert error(oracle, spec, truths) <= error(oracle, free, truths) + 5e-3
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_bounded_library_against_the_unbounded_one(oracle, seed):
+    """The library of round 5 keeps the direct partner and the first three other positions per (a, p, b); rounds 2-4 kept every
+    position (oracle.msa2_set_library(-1) restores their enumeration).  Same-molecule clusters: the bound ignores next to nothing
+    and the consensus is the same; clusters of two molecules: it ignores most of the noise the third reads of the other
+    molecule name, and the consensus against the majority molecule stays where the unbounded library put it."""
+    def with_library(others, reads, groups):
+        oracle.msa2_set_library(others)
+        oracle.msa2_stats()
+        try:
+            return oracle.quick_msa(groups, reads, *PARAMS), oracle.msa2_stats()
+        finally:
+            oracle.msa2_set_library(3)
+    reads, groups, truths = clusters("pure", 400 + seed, 6)
+    spec, st = with_library(3, reads, groups)
+    free, stf = with_library(-1, reads, groups)
+    assert st["library_positions_ignored"] < 0.001 * st["triples"] and stf["library_positions_ignored"] == 0
+    assert abs(error(oracle, spec, truths) - error(oracle, free, truths)) < 1e-3
+    wide, stw = with_library(63, reads, groups)
+    assert stw["library_positions_ignored"] == 0 and abs(error(oracle, wide, truths) - error(oracle, free, truths)) < 1e-3
+    reads, groups, truths = clusters("mixed", 500 + seed, 4)
+    spec, st = with_library(3, reads, groups)
+    free, _ = with_library(-1, reads, groups)
+    assert st["library_positions_ignored"] > 0
+    assert abs(error(oracle, spec, truths) - error(oracle, free, truths)) < 5e-3
+    for rows, g in zip(spec, groups):
+        assert len({len(r) for r in rows}) == 1 and [r.replace("-", "") for r in rows] == [reads[i - 1] for i in g]
+    assert oracle.quick_msa(groups, reads, *PARAMS) == spec   # (the default is back)
